@@ -1,0 +1,263 @@
+/*
+ * pfpp.h — C ABI of libpfpp_hip.so: the MI355X (gfx950) kernels behind the
+ * denoise-and-verify hot path of PuzzleFusion++.
+ *
+ * The reference has no native code on this path: every function below replaces
+ * a group of stock-PyTorch / third-party ops.  Each entry cites the reference
+ * lines it replaces (paths relative to the reference checkout).  The only
+ * native precedent in the reference tree is Jigsaw_matching/utils/chamfer/cuda/
+ * chamfer.cpp:8-23 (contiguity checks on the host side, raw pointers + sizes
+ * into the launcher); this header follows the same split: the Python wrappers
+ * validate dtype / contiguity / shapes, the C side takes plain pointers.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - all tensors are dense row-major; "ld*" = leading dimension in elements;
+ *   - fp32 everywhere (the reference runs precision 32,
+ *     config/denoiser/global_config.yaml:39); indices are int32 at this
+ *     boundary (the Python mirror widens to int64 where the reference API
+ *     returns int64);
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued,
+ *     never synchronised; nothing is allocated or freed by the library;
+ *   - return value: PFPP_OK (0) or a negative PFPP_E* code.  Nothing throws
+ *     across the ABI.  pfpp_last_error() returns a static string describing
+ *     the most recent failure on the calling thread.
+ */
+#ifndef PFPP_H_
+#define PFPP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFPP_OK 0
+#define PFPP_EINVAL (-1)     /* bad size / alignment / null pointer            */
+#define PFPP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define PFPP_EHIP (-3)       /* hipGetLastError() != hipSuccess after launch   */
+
+typedef void* pfpp_stream_t;
+
+/* ---- library ------------------------------------------------------------ */
+int pfpp_version(void);                 /* ABI version, currently 1          */
+const char* pfpp_last_error(void);
+/* number of compute units of the current device (for grid sizing in hosts) */
+int pfpp_device_cu_count(void);
+
+/* ---- a1: SE(3) rotate + valid-fragment gather ----------------------------
+ * Denoiser._apply_rots (puzzlefusion_plusplus/denoiser/model/denoiser.py:55-63,
+ * = auto_aggl.py:70-78) followed by the boolean gather denoiser.py:69.
+ *   q = pose[slot,3:7] / ||q||   (w,x,y,z);  out = (q * (0,p) * conj(q)).xyz
+ * evaluated in exactly pytorch3d's quaternion_raw_multiply operation order with
+ * no FMA contraction, so the rotated coordinates are bit-identical to the CPU
+ * path (FPS downstream is an argmax chain and must not fork).
+ *   part_pcs [n_slots, N, 3], pose [n_slots, 7], slot [F] (flattened b*P+p of
+ *   each valid fragment, ascending) -> out [F, N, 3]                          */
+int pfpp_se3_rotate_gather(const float* part_pcs, const float* pose,
+                           const int32_t* slot, float* out,
+                           int64_t F, int64_t N, pfpp_stream_t stream);
+
+/* ---- a19: pose apply  R(q^)p + t  ----------------------------------------
+ * utils/node_merge_utils.py:43-53 get_final_pose_pts (normalise=1) and the
+ * per-part body of get_final_pose_pts_dynamic :16-41 (normalise=0: pytorch3d
+ * quaternion_apply does not normalise).  pts [n, N, 3], pose [n,7]=(t, q).
+ * `scale` (may be NULL) multiplies the points first (auto_aggl.py:160-162). */
+int pfpp_pose_apply(const float* pts, const float* pose, const float* scale,
+                    float* out, int64_t n, int64_t N, int normalise,
+                    pfpp_stream_t stream);
+
+/* ---- a2: farthest point sampling -----------------------------------------
+ * torch_cluster.fps(random_start=False) as called at utils/pn2_utils.py:131-137
+ * + the centroid gather index_points :139.  Start index 0, d = (dx*dx + dy*dy)
+ * + dz*dz in fp32 without FMA, running min, next = first argmax.
+ *   xyz [F, N, 3] -> idx [F, S] (local indices), new_xyz [F, S, 3]
+ * Supported: 1 <= S <= N <= 4096.                                           */
+int pfpp_fps(const float* xyz, int32_t* idx, float* new_xyz,
+             int64_t F, int64_t N, int64_t S, pfpp_stream_t stream);
+
+/* ---- a3: ball query ---------------------------------------------------------
+ * square_distance + query_ball_point, utils/pn2_utils.py:21-42, 92-112.
+ * d = ((-2*dot) + |c|^2) + |p|^2 with dot = fma(c2,p2, fma(c1,p1, c0*p0))
+ * (what the CPU BLAS K=3 matmul evaluates) and squared norms (x*x+y*y)+z*z;
+ * a point is kept unless d > r2; the first `nsample` kept indices in index
+ * order are returned, padded with the first kept index.
+ *   xyz [F,N,3], new_xyz [F,S,3] -> idx [F,S,nsample]; nsample <= 64.       */
+int pfpp_ball_query(const float* xyz, const float* new_xyz, int32_t* idx,
+                    int64_t F, int64_t N, int64_t S, int64_t nsample,
+                    float r2, pfpp_stream_t stream);
+
+/* ---- a4: grouping --------------------------------------------------------
+ * index_points x3 + concat, utils/pn2_utils.py:139-146, written channels-last
+ * as the A operand of the first set-abstraction GEMM:
+ *   row (f,s,j) = [ feats[f, idx, 0:D] | xyz[f,idx]-new_xyz[f,s] | 0-pad ]
+ * (features first so the D-wide copy is 16-byte aligned; the packed conv
+ * weight has its input columns permuted the same way).
+ *   feats [F,N,D] or NULL (D=0), out [F*S*ns, ldo], ldo >= D+3, ldo % 4 == 0 */
+int pfpp_group_gather(const float* xyz, const float* new_xyz,
+                      const float* feats, const int32_t* idx, float* out,
+                      int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D,
+                      int64_t ldo, pfpp_stream_t stream);
+
+/* ---- GEMM: C = epilogue(A . op(W)) on fp32 MFMA ----------------------------
+ * The one contraction kernel behind a5 (1x1 conv + BN + ReLU + max over
+ * nsample, utils/pn2_utils.py:209-214), a6 (conv6, pn2.py:65), a9 (Linear
+ * 148->512 / 147->512, denoiser_transformer.py:131-134), a11 (AdaLN linear,
+ * attention.py:22), a12-a14 (to_q/k/v, QK^T, PV, to_out, GEGLU feed-forward,
+ * attention.py:77-90), a15 (output heads, denoiser_transformer.py:138-147)
+ * and a18 (verifier, verifier_transformer.py:42-66).
+ * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate.
+ *
+ *   A [M,K] row-major (lda);  W is [N,K] row-major (w_kmajor=0, the layout of
+ *   torch Linear / 1x1-conv weights) or [K,N] row-major (w_kmajor=1);
+ *   C [M,N] (ldc) — or [M/pool, N] when pool > 0.
+ *   lda, ldw multiples of 4, A/W 16-byte aligned.
+ * Batched: blockIdx.z = z; operand X is offset by (z / zdiv)*sX0 + (z % zdiv)*sX1.
+ * Epilogue order: v = acc; v = v*scale[n] + shift[n] (if scale) else v += bias[n]
+ * (if bias); activation; v += R[m,n] (if residual); store or max-pool.       */
+enum {
+  PFPP_ACT_NONE = 0,
+  PFPP_ACT_RELU = 1,
+  PFPP_ACT_SILU = 2,
+  PFPP_ACT_GELU = 3,  /* exact erf GELU */
+  PFPP_ACT_GEGLU = 4  /* C[m,j] = u * gelu(g): u,g = value/gate columns; W packed
+                         as 32-column value block followed by its 32-column gate
+                         block (see pfpp_hip.pack_geglu); C has N/2 columns   */
+};
+
+typedef struct pfpp_gemm_args {
+  const float* A; const float* W; float* C;
+  const float* bias;      /* [N] or NULL */
+  const float* scale;     /* [N] or NULL (then shift must be set) */
+  const float* shift;     /* [N] */
+  const float* residual;  /* [M, ldr] or NULL; batched with C's strides */
+  int64_t M, N, K;
+  int64_t lda, ldw, ldc, ldr;
+  int32_t w_kmajor;       /* 0: W[N,K]; 1: W[K,N] */
+  int32_t act;            /* PFPP_ACT_* */
+  int32_t pool;           /* 0, 32 or 64: max over groups of `pool` rows */
+  int32_t batch, zdiv;    /* batch >= 1; zdiv >= 1 */
+  int64_t sA0, sA1, sW0, sW1, sC0, sC1;
+  int64_t sV0, sV1;       /* batch strides of bias / scale / shift */
+  float alpha;            /* acc *= alpha before the epilogue (1.0 = off) */
+} pfpp_gemm_args;
+
+int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);
+
+/* ---- a7/a8: vector quantisation + scatter ----------------------------------
+ * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by
+ * VQVAE.encode (denoiser/model/modules/encoder.py:20-38): for every
+ * `dim`-wide sub-vector z: d_j = (|z|^2 + |e_j|^2) - 2*(z.e_j), first argmin,
+ * out = z + (e_j - z) (straight-through value, quantizer.py:63).  Results are
+ * scattered straight into the zero-initialised padded tensor at row
+ * slot[f] (denoiser.py:72-76): z_e [F, rows_per_frag, dim] ->
+ * z_q [n_slots, rows_per_frag, dim]; codes [F, rows_per_frag] (may be NULL).
+ * dim == 16, n_codes <= 1024.                                               */
+int pfpp_vq_encode(const float* z_e, const float* codebook, const int32_t* slot,
+                   float* z_q, int32_t* codes, int64_t F, int64_t rows_per_frag,
+                   int64_t dim, int64_t n_codes, pfpp_stream_t stream);
+
+/* scatter rows: out[slot[f], :] = in[f, :]  (xyz scatter, denoiser.py:76)   */
+int pfpp_scatter_rows(const float* in, const int32_t* slot, float* out,
+                      int64_t F, int64_t row_elems, pfpp_stream_t stream);
+
+/* ---- a9: token features ---------------------------------------------------
+ * DenoiserTransformer._gen_cond, denoiser_transformer.py:117-135 with
+ * EmbedderNerf.embed utils/model_utils.py:68-69 (include_input, 10 log-spaced
+ * frequencies 2^0..2^9, [sin, cos] per frequency):
+ *   shape_feat[(bp,l), :] = [latent(64) | PE(xyz)(63) | PE(scale)(21) | 0-pad]
+ *   pose_feat[bp, :]      = [PE(x)(147) | 0-pad]
+ *   latent [n, L, 64], xyz [n, L, 3], scale [n], x [n, 7];  ld = 148.       */
+int pfpp_token_features(const float* latent, const float* xyz, const float* scale,
+                        const float* x, float* shape_feat, float* pose_feat,
+                        int64_t n, int64_t L, pfpp_stream_t stream);
+
+/* token assembly, denoiser_transformer.py:150-156,173-185 + PositionalEncoding
+ * utils/model_utils.py:18-21:
+ *   tok[(b,p,l), :] = shape_emb[(b,p,l), :] + x_emb[(b,p), :]
+ *                     + ref_emb[ref[b,p] ? 1 : 0, :] + pe[p, :]              */
+int pfpp_token_combine(const float* shape_emb, const float* x_emb,
+                       const float* ref_emb, const uint8_t* ref_part,
+                       const float* pe, float* tok, int64_t B, int64_t P,
+                       int64_t L, int64_t C, pfpp_stream_t stream);
+
+/* ---- a11: AdaLN ---------------------------------------------------------------
+ * MyAdaLayerNorm, denoiser/model/modules/attention.py:21-25.
+ * pfpp_silu_embed: out[i, b, :] = silu(tables[i][t[b], :]) for the n_tab
+ * embedding tables (one per norm); tables [n_tab, n_emb, C] is a packed copy.
+ * pfpp_layernorm: y = LN(x) (eps, biased variance, no affine) then
+ *   mod != NULL : y*(1+mod[b, 0:C]) + mod[b, C:2C]   (b = row / rows_per_batch)
+ *   gamma != NULL : y*gamma + beta                   (norm3 / verifier norms)
+ * x may alias y.                                                              */
+int pfpp_silu_embed(const float* tables, const int64_t* t, float* out,
+                    int64_t n_tab, int64_t n_emb, int64_t B, int64_t C,
+                    pfpp_stream_t stream);
+int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
+                   const float* gamma, const float* beta, int64_t rows,
+                   int64_t C, int64_t rows_per_batch, float eps,
+                   pfpp_stream_t stream);
+
+/* ---- a10/a12: block-diagonal self-attention --------------------------------
+ * EncoderLayer self-attn (attention.py:77-80) with the block-diagonal mask of
+ * DenoiserTransformer._gen_mask (denoiser_transformer.py:158-162): every
+ * fragment's L tokens attend only to each other, so the [B,T,T] mask is never
+ * built.  qkv [n_frag*L, 3*H*dh] (q | k | v), out [n_frag*L, H*dh];
+ * softmax(q.k^T * scale).  L <= 32, dh == 64.                               */
+int pfpp_attn_blockdiag(const float* qkv, float* out, int64_t n_frag, int64_t L,
+                        int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+
+/* ---- a13/a18: masked row softmax for the dense attentions -------------------
+ * S [rows_total, ld] in place: p = softmax(S[r, 0:T] * scale) over the keys j
+ * with key_valid[batch(r), j] != 0 (batch(r) = r / rows_per_batch); masked
+ * keys and the pad columns [T, ld) get exactly 0.  key_valid [n_batch, T]
+ * (uint8): gen_mask of denoiser_transformer.py:163-164 / src_key_padding_mask
+ * of verifier_transformer.py:62.                                             */
+int pfpp_softmax_rows(float* S, const uint8_t* key_valid, int64_t rows_total,
+                      int64_t rows_per_batch, int64_t T, int64_t ld, float scale,
+                      pfpp_stream_t stream);
+
+/* ---- a15: mean pool over the L tokens of a fragment -----------------------
+ * denoiser_transformer.py:139-142.  x [n*L, C] -> out [n, C]                 */
+int pfpp_mean_pool(const float* x, float* out, int64_t n, int64_t L, int64_t C,
+                   pfpp_stream_t stream);
+
+/* ---- a16: DDPM ancestral step + reference-part re-pin ----------------------
+ * diffusers-0.21.4 DDPMScheduler.step as configured by PiecewiseScheduler
+ * (denoiser/model/modules/custom_diffusers.py:60-69) followed by
+ * `x[ref_part] = reference[ref_part]` (denoiser.py:184-185, auto_aggl.py:149-150)
+ *   x0 = (x - c_eps*eps)/c_div;  out = c_x0*x0 + c_x*x (+ c_noise*noise)
+ * coefficients are computed on the host in fp32 in the scheduler's op order;
+ * noise may be NULL (t == 0).  All tensors [n, 7]; ref_part [n] uint8 or NULL */
+int pfpp_ddpm_step(const float* x, const float* eps, const float* noise,
+                   const uint8_t* ref_part, const float* reference, float* out,
+                   int64_t n, float c_eps, float c_div, float c_x0, float c_x,
+                   float c_noise, pfpp_stream_t stream);
+
+/* add_noise (denoiser.py:92): out = sa[b]*x0 + sb[b]*noise, per-puzzle scalars */
+int pfpp_add_noise(const float* x0, const float* noise, const float* sqrt_ab,
+                   const float* sqrt_1mab, float* out, int64_t B,
+                   int64_t per_batch, pfpp_stream_t stream);
+
+/* ---- a18: verifier token embedding ------------------------------------------
+ * verifier_transformer.py:52-56: tok = feat_emb[(b,e), :] + [pe[i0] | pe[i1]]
+ * feat_emb [n, C] (output of the 7->C GEMM), edge_idx [n, 2] int64,
+ * pe [max_len, C/2].                                                         */
+int pfpp_verifier_embed(const float* feat_emb, const int64_t* edge_idx,
+                        const float* pe, float* tok, int64_t n, int64_t C,
+                        int64_t max_len, pfpp_stream_t stream);
+
+/* ---- a19: pose composition ---------------------------------------------------
+ * utils/node_merge_utils.py:275-306 get_param / :246-272
+ * extract_final_pred_trans_rots: M = [R(q[pivot[i]]) | t[pivot[i]]], optionally
+ * M <- M @ init_pose[i] (has_init[i] != 0), then (t, matrix_to_quaternion(R)).
+ * pose [P,7], pivot [n] int32, init_pose [n,16] row-major 4x4, out [n,7].
+ * quaternion_to_matrix / matrix_to_quaternion follow pytorch3d.  */
+int pfpp_pose_compose(const float* pose, const int32_t* pivot,
+                      const float* init_pose, const uint8_t* has_init,
+                      float* out, int64_t n, pfpp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFPP_H_ */

@@ -1,0 +1,548 @@
+"""TEST INFRASTRUCTURE — CPU restatement ("oracle") of the PuzzleFusion++ denoise-and-verify path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product (puzzlefusion-plusplus_amd/) never does.
+
+Every function restates one piece of the reference in plain torch-CPU fp32 (same operation
+order as the reference's Python) or, for the integer / argmax-chain pieces, calls the plain-C
+restatement in oracle/pfpp_oracle.c.  Citations are paths relative to the reference checkout.
+
+Pinning (tools/make_goldens.py, run in the build container where /root/reference exists):
+  * reference-owned code (utils/pn2_utils.py, vqvae/model/modules/{pn2,quantizer}.py,
+    denoiser/model/modules/{encoder,attention,denoiser_transformer,custom_diffusers}.py,
+    verifier/model/modules/verifier_transformer.py, utils/model_utils.py) is IMPORTED and run;
+    its outputs are committed as tests/golden/*.npz and this oracle must reproduce them.
+  * third-party code that is neither in the reference tree nor installed (torch_cluster.fps,
+    diffusers==0.21.4 Attention/FeedForward/DDPMScheduler, pytorch3d.transforms) is restated
+    from its documented semantics: PARITY UNPINNED for those pieces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = Path(__file__).resolve().parent
+_clib = None
+
+
+def clib() -> C.CDLL:
+    """the plain-C restatement (oracle/pfpp_oracle.c), built on demand with gcc"""
+    global _clib
+    if _clib is None:
+        from . import build as _b
+
+        lib = C.CDLL(str(_b.build()))
+        p, i64 = C.c_void_p, C.c_int64
+        lib.oracle_quat_apply.argtypes = [p, p, p, i64, C.c_int]
+        lib.oracle_fps.argtypes = [p, i64, i64, i64, p]
+        lib.oracle_ball_query.argtypes = [p, p, i64, i64, i64, i64, C.c_float, p]
+        lib.oracle_vq_argmin.argtypes = [p, p, i64, i64, i64, p]
+        for fn in (lib.oracle_quat_apply, lib.oracle_fps, lib.oracle_ball_query, lib.oracle_vq_argmin):
+            fn.restype = None
+        _clib = lib
+    return _clib
+
+
+def _np32(t) -> np.ndarray:
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# =============================================================================================
+# a1 / a19 — quaternion algebra (pytorch3d.transforms, real-first)
+# =============================================================================================
+def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    ow = aw * bw - ax * bx - ay * by - az * bz
+    ox = aw * bx + ax * bw + ay * bz - az * by
+    oy = aw * by - ax * bz + ay * bw + az * bx
+    oz = aw * bz + ax * by - ay * bx + az * bw
+    return torch.stack((ow, ox, oy, oz), -1)
+
+
+def quaternion_apply(q: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """(q * (0,p) * q^-1)[1:], no normalisation inside"""
+    pq = torch.cat((p.new_zeros(p.shape[:-1] + (1,)), p), -1)
+    q_inv = q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+    return quaternion_raw_multiply(quaternion_raw_multiply(q, pq), q_inv)[..., 1:]
+
+
+def apply_rots(part_pcs: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Denoiser._apply_rots, puzzlefusion_plusplus/denoiser/model/denoiser.py:55-63"""
+    q = x[..., 3:]
+    q = q / q.norm(dim=-1, keepdim=True)
+    return quaternion_apply(q.unsqueeze(2), part_pcs)
+
+
+def apply_rots_c(part_pcs: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """same through the plain-C restatement (must equal apply_rots bit for bit)"""
+    pcs = _np32(part_pcs)
+    pose = _np32(x)
+    lead = pcs.shape[:-2]
+    N = pcs.shape[-2]
+    pcs2 = pcs.reshape(-1, N, 3)
+    pose2 = pose.reshape(-1, 7)
+    out = np.empty_like(pcs2)
+    lib = clib()
+    for i in range(pcs2.shape[0]):
+        q = np.ascontiguousarray(pose2[i, 3:7])
+        lib.oracle_quat_apply(pcs2[i].ctypes.data, q.ctypes.data, out[i].ctypes.data, N, 1)
+    return torch.from_numpy(out.reshape(*lead, N, 3))
+
+
+def get_final_pose_pts(pts, trans, rots):
+    """utils/node_merge_utils.py:43-53"""
+    rots = rots / rots.norm(dim=-1, keepdim=True)
+    return quaternion_apply(rots.unsqueeze(2), pts) + trans.unsqueeze(2)
+
+
+def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack(
+        (
+            1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+            two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+            two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j),
+        ),
+        -1,
+    )
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def matrix_to_quaternion(m: torch.Tensor) -> torch.Tensor:
+    """pytorch3d git-HEAD semantics incl. standardisation to a non-negative real part"""
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m.reshape(m.shape[:-2] + (9,)), -1)
+    q_abs = torch.stack(
+        [1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], -1
+    )
+    q_abs = torch.where(q_abs > 0, torch.sqrt(torch.clamp(q_abs, min=0)), torch.zeros_like(q_abs))
+    cand = torch.stack(
+        [
+            torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+            torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+            torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+            torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1),
+        ],
+        -2,
+    )
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(-1)
+    out = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+    return torch.where(out[..., 0:1] < 0, -out, out)
+
+
+def pose_compose(pose: torch.Tensor, pivot, init_pose=None, has_init=None) -> torch.Tensor:
+    """get_param / extract_final_pred_trans_rots, utils/node_merge_utils.py:246-306"""
+    n = len(pivot)
+    out = torch.zeros(n, 7)
+    rm = quaternion_to_matrix(pose[:, 3:])
+    for i in range(n):
+        A = torch.eye(4)
+        A[:3, :3] = rm[pivot[i]]
+        A[:3, 3] = pose[pivot[i], :3]
+        if has_init is not None and has_init[i]:
+            A = A @ init_pose[i].reshape(4, 4)
+        out[i, :3] = A[:3, 3]
+        out[i, 3:] = matrix_to_quaternion(A[:3, :3])
+    return out
+
+
+# =============================================================================================
+# a2-a4 — PointNet++ sampling / grouping (utils/pn2_utils.py)
+# =============================================================================================
+def fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    """torch_cluster.fps(random_start=False) per fragment, local int64 indices [F,S]
+    (utils/pn2_utils.py:131-137)."""
+    a = _np32(xyz)
+    Fn, N, _ = a.shape
+    ratio = np.float64(npoint / N)
+    if int(math.ceil(ratio * N)) != npoint:
+        raise ValueError(f"ceil(ratio*N) != npoint for N={N}, npoint={npoint} (pn2_utils.py:132)")
+    idx = np.empty((Fn, npoint), dtype=np.int32)
+    clib().oracle_fps(a.ctypes.data, Fn, N, npoint, idx.ctypes.data)
+    return torch.from_numpy(idx.astype(np.int64))
+
+
+def r2_f32(radius: float) -> float:
+    """`sqrdists > radius ** 2` compares against the python double rounded to float32"""
+    return float(np.float32(radius ** 2))
+
+
+def query_ball_point(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    """utils/pn2_utils.py:92-112 (+ square_distance :21-42), int64 [F,S,nsample]"""
+    a, c = _np32(xyz), _np32(new_xyz)
+    Fn, N, _ = a.shape
+    S = c.shape[1]
+    idx = np.empty((Fn, S, nsample), dtype=np.int32)
+    clib().oracle_ball_query(a.ctypes.data, c.ctypes.data, Fn, N, S, nsample, C.c_float(r2_f32(radius)),
+                             idx.ctypes.data)
+    return torch.from_numpy(idx.astype(np.int64))
+
+
+def query_ball_point_torch(radius, nsample, xyz, new_xyz):
+    """the same algorithm through torch ops incl. the BLAS matmul (cross-check only)"""
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    d = -2 * torch.matmul(new_xyz, xyz.permute(0, 2, 1))
+    d += torch.sum(new_xyz ** 2, -1).view(B, S, 1)
+    d += torch.sum(xyz ** 2, -1).view(B, 1, N)
+    gi = torch.arange(N).view(1, 1, N).repeat(B, S, 1)
+    gi[d > radius ** 2] = N
+    gi = gi.sort(dim=-1)[0][:, :, :nsample]
+    first = gi[:, :, 0:1].expand(-1, -1, nsample)
+    return torch.where(gi == N, first, gi)
+
+
+def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """utils/pn2_utils.py:45-62"""
+    B = points.shape[0]
+    bi = torch.arange(B).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
+    return points[bi, idx, :]
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points):
+    """utils/pn2_utils.py:115-152 -> new_xyz [F,S,3], new_points [F,S,ns,3+D] (xyz first), fps idx, ball idx"""
+    fps_idx = fps(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = index_points(xyz, idx) - new_xyz.unsqueeze(2)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz, index_points(points, idx)], dim=-1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, fps_idx, idx
+
+
+# =============================================================================================
+# a5-a8 — set abstraction, PN2.encode, VQ
+# =============================================================================================
+SA_CFG = (  # vqvae/model/modules/pn2.py:16-18
+    ("sa1", 256, 0.2, 32),
+    ("sa2", 128, 0.4, 64),
+    ("sa3", None, 0.8, 64),  # npoint = cfg.ae.num_point (25)
+)
+
+
+def set_abstraction(sd: Dict[str, torch.Tensor], prefix: str, npoint, radius, nsample, xyz, points,
+                    capture: Optional[dict] = None):
+    """PointNetSetAbstraction.forward, utils/pn2_utils.py:190-216 (eval-mode BatchNorm).
+    xyz [F,N,3], points [F,N,D] channels-last -> new_xyz [F,S,3], new_points [F,S,C]"""
+    new_xyz, new_points, fps_idx, ball_idx = sample_and_group(npoint, radius, nsample, xyz, points)
+    h = new_points.permute(0, 3, 2, 1)  # [F, C+D, ns, S]
+    for i in range(3):
+        h = F.conv2d(h, sd[f"{prefix}.mlp_convs.{i}.weight"], sd[f"{prefix}.mlp_convs.{i}.bias"])
+        h = F.batch_norm(h, sd[f"{prefix}.mlp_bns.{i}.running_mean"], sd[f"{prefix}.mlp_bns.{i}.running_var"],
+                         sd[f"{prefix}.mlp_bns.{i}.weight"], sd[f"{prefix}.mlp_bns.{i}.bias"], False, 0.1, 1e-5)
+        h = F.relu(h)
+    h = torch.max(h, 2)[0]  # [F, C, S]
+    if capture is not None:
+        capture[f"{prefix}.fps_idx"] = fps_idx
+        capture[f"{prefix}.ball_idx"] = ball_idx
+        capture[f"{prefix}.new_xyz"] = new_xyz
+        capture[f"{prefix}.new_points"] = h.permute(0, 2, 1).contiguous()
+    return new_xyz, h.permute(0, 2, 1).contiguous()
+
+
+def pn2_encode(sd, part_pcs: torch.Tensor, num_point: int = 25, prefix: str = "pn2", capture=None):
+    """PN2.encode, vqvae/model/modules/pn2.py:57-68: part_pcs [F,N,3] -> z_e [F,L,64], xyz [F,L,3]"""
+    xyz, pts = part_pcs, None
+    for name, npoint, radius, nsample in SA_CFG:
+        xyz, pts = set_abstraction(sd, f"{prefix}.{name}", npoint or num_point, radius, nsample, xyz, pts, capture)
+    g = F.conv1d(pts.permute(0, 2, 1), sd[f"{prefix}.conv6.weight"], sd[f"{prefix}.conv6.bias"])
+    return g.permute(0, 2, 1).contiguous(), xyz
+
+
+def vector_quantize(codebook: torch.Tensor, z: torch.Tensor):
+    """VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 -> (z_q with the
+    straight-through value z + (e - z), code indices)"""
+    e_dim = codebook.shape[1]
+    zf = z.reshape(-1, e_dim)
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1) - 2 * torch.matmul(zf, codebook.t())
+    codes = torch.argmin(d, dim=1)
+    z_q = codebook[codes].view(z.shape)
+    return z + (z_q - z), codes
+
+
+def vector_quantize_c(codebook: torch.Tensor, z: torch.Tensor):
+    """argmin through the plain-C restatement (explicit rounding order)"""
+    cb = _np32(codebook)
+    zf = _np32(z).reshape(-1, cb.shape[1])
+    codes = np.empty(zf.shape[0], dtype=np.int32)
+    clib().oracle_vq_argmin(zf.ctypes.data, cb.ctypes.data, zf.shape[0], cb.shape[0], cb.shape[1], codes.ctypes.data)
+    codes_t = torch.from_numpy(codes.astype(np.int64))
+    z_q = codebook[codes_t].view(z.shape)
+    return z + (z_q - z), codes_t
+
+
+def vq_gap(codebook: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """distance gap between the best and the second-best code of every sub-vector (for the
+    near-tie accounting of the parity tests)"""
+    zf = z.reshape(-1, codebook.shape[1]).double()
+    cb = codebook.double()
+    d = (zf ** 2).sum(1, keepdim=True) + (cb ** 2).sum(1) - 2 * zf @ cb.t()
+    top2 = torch.topk(d, 2, dim=1, largest=False)[0]
+    return (top2[:, 1] - top2[:, 0]).float()
+
+
+def vqvae_encode(sd, part_pcs, num_point: int = 25, c_argmin: bool = True, capture=None):
+    """VQVAE.encode, denoiser/model/modules/encoder.py:20-38 (= vqvae/model/modules/vq_vae.py:52-68)"""
+    z_e, xyz = pn2_encode(sd, part_pcs, num_point, capture=capture)
+    Fn, L, Cc = z_e.shape
+    cb = sd["vector_quantization.embedding.weight"]
+    vq = vector_quantize_c if c_argmin else vector_quantize
+    z_q, codes = vq(cb, z_e.reshape(Fn, 4 * L, -1))
+    if capture is not None:
+        capture["z_e"] = z_e
+        capture["codes"] = codes.view(Fn, 4 * L)
+    return {"z_q": z_q.reshape(Fn, L, -1), "xyz": xyz}
+
+
+def extract_features(sd_enc, part_pcs, part_valids, x, num_point=25, num_dim=64):
+    """Denoiser._extract_features, denoiser.py:66-77"""
+    B, P = part_pcs.shape[:2]
+    rot = apply_rots(part_pcs, x)
+    valid = part_valids.bool()
+    enc = vqvae_encode(sd_enc, rot[valid], num_point)
+    latent = torch.zeros(B, P, num_point, num_dim)
+    xyz = torch.zeros(B, P, num_point, 3)
+    latent[valid] = enc["z_q"]
+    xyz[valid] = enc["xyz"]
+    return latent, xyz
+
+
+# =============================================================================================
+# a9-a15 — DenoiserTransformer
+# =============================================================================================
+def nerf_embed(x: torch.Tensor, multires: int = 10) -> torch.Tensor:
+    """EmbedderNerf.embed, utils/model_utils.py:39-69 (include_input, log-sampled 2^0..2^(m-1))"""
+    outs = [x]
+    for f in 2.0 ** torch.linspace(0.0, multires - 1, steps=multires):
+        outs.append(torch.sin(x * f))
+        outs.append(torch.cos(x * f))
+    return torch.cat(outs, -1)
+
+
+def positional_table(d_model: int, max_len: int = 20) -> torch.Tensor:
+    """PositionalEncoding.pe, utils/model_utils.py:5-16 -> [1, max_len, d_model]"""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0)
+
+
+def ada_layer_norm(sd, prefix, x, timestep):
+    """MyAdaLayerNorm.forward, denoiser/model/modules/attention.py:21-25"""
+    emb = F.linear(F.silu(sd[f"{prefix}.emb.weight"][timestep]), sd[f"{prefix}.linear.weight"], sd[f"{prefix}.linear.bias"])
+    scale, shift = emb.chunk(2, dim=1)
+    return F.layer_norm(x, (x.shape[-1],)) * (1 + scale[:, None]) + shift[:, None]
+
+
+def diffusers_attention(sd, prefix, x, mask, heads=8):
+    """diffusers 0.21.4 Attention with AttnProcessor2_0: no qkv bias, out bias,
+    bool mask True = may attend, [B,S,S] or [B,S] broadcast over heads."""
+    B, S, Cc = x.shape
+    q = F.linear(x, sd[f"{prefix}.to_q.weight"])
+    k = F.linear(x, sd[f"{prefix}.to_k.weight"])
+    v = F.linear(x, sd[f"{prefix}.to_v.weight"])
+    dh = Cc // heads
+    q, k, v = (t.view(B, S, heads, dh).transpose(1, 2) for t in (q, k, v))
+    m = mask.repeat_interleave(heads, dim=0).view(B, heads, -1, mask.shape[-1])
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(B, S, Cc)
+    return F.linear(o, sd[f"{prefix}.to_out.0.weight"], sd[f"{prefix}.to_out.0.bias"])
+
+
+def geglu_ff(sd, prefix, x):
+    """diffusers 0.21.4 FeedForward(activation_fn='geglu')"""
+    h, gate = F.linear(x, sd[f"{prefix}.net.0.proj.weight"], sd[f"{prefix}.net.0.proj.bias"]).chunk(2, dim=-1)
+    return F.linear(h * F.gelu(gate), sd[f"{prefix}.net.2.weight"], sd[f"{prefix}.net.2.bias"])
+
+
+def encoder_layer(sd, prefix, h, self_mask, gen_mask, timestep, heads=8):
+    """EncoderLayer.forward, denoiser/model/modules/attention.py:75-91"""
+    h = h + diffusers_attention(sd, f"{prefix}.self_attn", ada_layer_norm(sd, f"{prefix}.norm1", h, timestep), self_mask, heads)
+    h = h + diffusers_attention(sd, f"{prefix}.global_attn", ada_layer_norm(sd, f"{prefix}.norm2", h, timestep), gen_mask, heads)
+    n3 = F.layer_norm(h, (h.shape[-1],), sd[f"{prefix}.norm3.weight"], sd[f"{prefix}.norm3.bias"])
+    return geglu_ff(sd, f"{prefix}.ff", n3) + h
+
+
+def denoiser_tokens(sd, x, latent, xyz, scale, ref_part):
+    """_gen_cond + _add_ref_part_emb + token assembly + PositionalEncoding (eval: no dropout),
+    denoiser/model/modules/denoiser_transformer.py:117-135,150-156,173-185"""
+    B, P, L, _ = latent.shape
+    Cm = sd["param_fc.weight"].shape[0]
+    scale_emb = nerf_embed(scale.flatten(0, 1)).unsqueeze(1).repeat(1, L, 1)
+    feat = torch.cat((latent.flatten(0, 1), nerf_embed(xyz.flatten(0, 1)), scale_emb), dim=-1)
+    shape_emb = F.linear(feat, sd["shape_embedding.weight"], sd["shape_embedding.bias"])
+    x_emb = F.linear(nerf_embed(x.flatten(0, 1)), sd["param_fc.weight"], sd["param_fc.bias"])
+    x_emb = x_emb.reshape(B, -1, Cm)
+    ref = sd["ref_part_emb.weight"][0].repeat(B, P, 1)
+    ref[ref_part.to(torch.bool)] = sd["ref_part_emb.weight"][1]
+    x_emb = (x_emb + ref).reshape(B, P, 1, Cm).repeat(1, 1, L, 1)
+    tok = x_emb.reshape(B, P * L, Cm) + shape_emb.reshape(B, P * L, Cm)
+    tok = tok.reshape(B, P, L, Cm) + sd["pos_encoding.pe"].unsqueeze(2)
+    return tok.reshape(B, P * L, Cm)
+
+
+def denoiser_forward(sd, x, timesteps, latent, xyz, part_valids, scale, ref_part, heads=8, capture=None):
+    """DenoiserTransformer.forward, denoiser_transformer.py:169-203 (eval mode)"""
+    B, P, L, _ = latent.shape
+    h = denoiser_tokens(sd, x, latent, xyz, scale, ref_part)
+    if capture is not None:
+        capture["tokens"] = h
+    self_mask = torch.block_diag(*([torch.ones(L, L)] * P)).unsqueeze(0).repeat(B, 1, 1).to(torch.bool)
+    gen_mask = part_valids.unsqueeze(-1).repeat(1, 1, L).flatten(1, 2).to(torch.bool)
+    n_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("transformer_layers."))
+    for i in range(n_layers):
+        h = encoder_layer(sd, f"transformer_layers.{i}", h, self_mask, gen_mask, timesteps, heads)
+        if capture is not None:
+            capture[f"layer{i}"] = h
+    Cm = h.shape[-1]
+    pooled = h.reshape(B, P, L, Cm).mean(dim=2)
+
+    def head(name, v):
+        v = F.silu(F.linear(v, sd[f"{name}.0.weight"], sd[f"{name}.0.bias"]))
+        v = F.silu(F.linear(v, sd[f"{name}.2.weight"], sd[f"{name}.2.bias"]))
+        return F.linear(v, sd[f"{name}.4.weight"], sd[f"{name}.4.bias"])
+
+    return torch.cat([head("mlp_out_trans", pooled), head("mlp_out_rot", pooled)], dim=-1)
+
+
+# =============================================================================================
+# a16 — PiecewiseScheduler (custom_diffusers.py:5-69 + diffusers 0.21.4 DDPMScheduler)
+# =============================================================================================
+class PiecewiseSchedule:
+    def __init__(self, num_train_timesteps: int = 1000):
+        def alpha_bar(t):
+            t = t * 1000
+            if t <= 700:
+                return 1 - 0.1 * (t / 700) ** 2
+            return 0.9 * (1 - ((t - 700) / 300) ** 2)
+
+        betas = []
+        for i in range(num_train_timesteps):
+            t1, t2 = i / num_train_timesteps, (i + 1) / num_train_timesteps
+            betas.append(min(1 - alpha_bar(t2) / alpha_bar(t1), 0.999))
+        self.num_train_timesteps = num_train_timesteps
+        self.betas = torch.tensor(betas, dtype=torch.float32)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
+
+    def set_timesteps(self, n: int):
+        """timestep_spacing='leading', steps_offset=0"""
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts)
+
+    def add_noise(self, x0, noise, t):
+        ac = self.alphas_cumprod.to(dtype=x0.dtype)
+        sa = ac[t] ** 0.5
+        sb = (1 - ac[t]) ** 0.5
+        sa = sa.flatten()
+        sb = sb.flatten()
+        while sa.dim() < x0.dim():
+            sa = sa.unsqueeze(-1)
+            sb = sb.unsqueeze(-1)
+        return sa * x0 + sb * noise
+
+    def step_coefficients(self, t: int):
+        """the five scalars of DDPMScheduler.step (epsilon prediction, fixed_small variance,
+        no clipping) as 0-dim fp32 tensors, computed in the scheduler's own op order"""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t = 1 - a_t
+        b_prev = 1 - a_prev
+        cur_alpha = a_t / a_prev
+        cur_beta = 1 - cur_alpha
+        c_eps = b_t ** 0.5
+        c_div = a_t ** 0.5
+        c_x0 = (a_prev ** 0.5 * cur_beta) / b_t
+        c_x = cur_alpha ** 0.5 * b_prev / b_t
+        c_noise = torch.tensor(0.0)
+        if t > 0:
+            var = torch.clamp(b_prev / b_t * cur_beta, min=1e-20)
+            c_noise = var ** 0.5
+        return c_eps, c_div, c_x0, c_x, c_noise
+
+    def step(self, eps, t: int, x, noise=None):
+        c_eps, c_div, c_x0, c_x, c_noise = self.step_coefficients(int(t))
+        x0 = (x - c_eps * eps) / c_div
+        prev = c_x0 * x0 + c_x * x
+        if int(t) > 0:
+            prev = prev + c_noise * noise
+        return prev
+
+
+# =============================================================================================
+# a18 — VerifierTransformer (verifier/model/modules/verifier_transformer.py:42-66)
+# =============================================================================================
+def verifier_forward(sd, edge_features, edge_indices, mask, heads=8):
+    """explicit post-norm nn.TransformerEncoderLayer math, eval mode"""
+    B, E, _ = edge_indices.shape
+    Cm = sd["edge_feature_emb.weight"].shape[0]
+    h = F.linear(edge_features, sd["edge_feature_emb.weight"], sd["edge_feature_emb.bias"])
+    pe = sd["edge_indices_pe.pe"][0]
+    h = pe[edge_indices].reshape(B, E, -1) + h
+    key_pad = ~mask.to(torch.bool)
+    dh = Cm // heads
+    n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer_encoder.layers."))
+    for i in range(n_layers):
+        p = f"transformer_encoder.layers.{i}"
+        qkv = F.linear(h, sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"])
+        q, k, v = (t.view(B, E, heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+        am = torch.zeros(B, 1, 1, E).masked_fill(key_pad[:, None, None, :], float("-inf"))
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=am)
+        a = a.transpose(1, 2).reshape(B, E, Cm)
+        a = F.linear(a, sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
+        h = F.layer_norm(h + a, (Cm,), sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"])
+        f = F.linear(F.gelu(F.linear(h, sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"])),
+                     sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"])
+        h = F.layer_norm(h + f, (Cm,), sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"])
+    return F.linear(h, sd["mlp_out.weight"], sd["mlp_out.bias"])
+
+
+# =============================================================================================
+# sampler (Denoiser.validation_step, denoiser.py:153-185) — used for the CPU baseline
+# =============================================================================================
+def split_denoiser_ckpt(sd):
+    enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    den = {k[len("denoiser."):]: v for k, v in sd.items() if k.startswith("denoiser.")}
+    return enc, den
+
+
+def sample(sd_enc, sd_den, batch, x_init, noises, num_inference_steps=20, capture=None):
+    """20-step ancestral sampler with the encoder inside the loop; `noises[i]` is the injected
+    randn of step i (ignored when t == 0).  Returns the final [B,P,7] poses."""
+    sched = PiecewiseSchedule()
+    sched.set_timesteps(num_inference_steps)
+    ref = batch["ref_part"].bool()
+    gt = torch.cat([batch["part_trans"], batch["part_rots"]], dim=-1)
+    reference = torch.zeros_like(gt)
+    reference[ref] = gt[ref]
+    x = x_init.clone()
+    x[ref] = reference[ref]
+    B = x.shape[0]
+    for i, t in enumerate(sched.timesteps.tolist()):
+        ts = torch.full((B,), t, dtype=torch.int64)
+        latent, xyz = extract_features(sd_enc, batch["part_pcs"], batch["part_valids"], x)
+        eps = denoiser_forward(sd_den, x, ts, latent, xyz, batch["part_valids"], batch["part_scale"], ref)
+        x = sched.step(eps, t, x, noises[i])
+        x[ref] = reference[ref]
+        if capture is not None:
+            capture.append(x.clone())
+    return x

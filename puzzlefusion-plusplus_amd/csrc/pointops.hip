@@ -1,0 +1,492 @@
+// Point-cloud kernels of the fragment encoder and the SE(3) glue (gfx950).
+//
+// Everything here is index / byte work or an argmax chain whose results must be
+// BIT-IDENTICAL to the CPU path, so this file is
+// compiled with -ffp-contract=off and every place where the CPU evaluates a
+// fused multiply-add says so with an explicit __fmaf_rn.
+#include "pfpp_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// quaternion helpers — pytorch3d.transforms operation order
+// ---------------------------------------------------------------------------
+struct Quat { float w, x, y, z; };
+
+// quaternion_raw_multiply(a, b): left-to-right evaluation of each 4-term sum,
+// every product and every sum rounded to fp32 on its own (torch elementwise ops).
+__device__ __forceinline__ Quat quat_raw_mul(const Quat a, const Quat b) {
+  Quat o;
+  o.w = __fsub_rn(__fsub_rn(__fsub_rn(__fmul_rn(a.w, b.w), __fmul_rn(a.x, b.x)), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z));
+  o.x = __fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.w, b.x), __fmul_rn(a.x, b.w)), __fmul_rn(a.y, b.z)), __fmul_rn(a.z, b.y));
+  o.y = __fadd_rn(__fadd_rn(__fsub_rn(__fmul_rn(a.w, b.y), __fmul_rn(a.x, b.z)), __fmul_rn(a.y, b.w)), __fmul_rn(a.z, b.x));
+  o.z = __fadd_rn(__fsub_rn(__fadd_rn(__fmul_rn(a.w, b.z), __fmul_rn(a.x, b.y)), __fmul_rn(a.y, b.x)), __fmul_rn(a.z, b.w));
+  return o;
+}
+
+// q / ||q||, ||q|| = sqrt(((w*w + x*x) + y*y) + z*z)  (torch.norm over 4 values)
+__device__ __forceinline__ Quat quat_normalise(const Quat q) {
+  const float n2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(q.w, q.w), __fmul_rn(q.x, q.x)), __fmul_rn(q.y, q.y)), __fmul_rn(q.z, q.z));
+  const float n = __fsqrt_rn(n2);
+  Quat o;
+  o.w = __fdiv_rn(q.w, n);
+  o.x = __fdiv_rn(q.x, n);
+  o.y = __fdiv_rn(q.y, n);
+  o.z = __fdiv_rn(q.z, n);
+  return o;
+}
+
+// quaternion_apply(q, p) = (q * (0,p) * q^-1)[1:], q^-1 = q * (1,-1,-1,-1)
+__device__ __forceinline__ void quat_apply(const Quat q, float px, float py, float pz,
+                                           float& ox, float& oy, float& oz) {
+  Quat p;
+  p.w = 0.0f; p.x = px; p.y = py; p.z = pz;
+  const Quat t = quat_raw_mul(q, p);
+  Quat qi;
+  qi.w = q.w; qi.x = -q.x; qi.y = -q.y; qi.z = -q.z;
+  const Quat r = quat_raw_mul(t, qi);
+  ox = r.x; oy = r.y; oz = r.z;
+}
+
+// ---------------------------------------------------------------------------
+// a1: rotate + gather of the valid fragments
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se3_rotate_gather_kernel(
+    const float* __restrict__ part_pcs, const float* __restrict__ pose,
+    const int32_t* __restrict__ slot, float* __restrict__ out, int64_t F, int64_t N) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= F * N) return;
+  const int64_t f = gid / N;
+  const int64_t i = gid - f * N;
+  const int64_t s = slot[f];
+  const float* ps = pose + s * 7;
+  Quat q;
+  q.w = ps[3]; q.x = ps[4]; q.y = ps[5]; q.z = ps[6];
+  q = quat_normalise(q);
+  const float* p = part_pcs + (s * N + i) * 3;
+  float ox, oy, oz;
+  quat_apply(q, p[0], p[1], p[2], ox, oy, oz);
+  float* o = out + gid * 3;
+  o[0] = ox; o[1] = oy; o[2] = oz;
+}
+
+// a19: R(q)p + t with optional pre-scale and optional normalisation of q
+__global__ __launch_bounds__(256) void pose_apply_kernel(
+    const float* __restrict__ pts, const float* __restrict__ pose,
+    const float* __restrict__ scale, float* __restrict__ out, int64_t n, int64_t N,
+    int normalise) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * N) return;
+  const int64_t f = gid / N;
+  const float* ps = pose + f * 7;
+  Quat q;
+  q.w = ps[3]; q.x = ps[4]; q.y = ps[5]; q.z = ps[6];
+  if (normalise) q = quat_normalise(q);
+  const float* p = pts + gid * 3;
+  float x = p[0], y = p[1], z = p[2];
+  if (scale) {
+    const float sc = scale[f];
+    x = __fmul_rn(x, sc); y = __fmul_rn(y, sc); z = __fmul_rn(z, sc);
+  }
+  float ox, oy, oz;
+  quat_apply(q, x, y, z, ox, oy, oz);
+  float* o = out + gid * 3;
+  o[0] = __fadd_rn(ox, ps[0]);
+  o[1] = __fadd_rn(oy, ps[1]);
+  o[2] = __fadd_rn(oz, ps[2]);
+}
+
+// ---------------------------------------------------------------------------
+// wave-wide max of a float through DPP (no LDS traffic): quad swaps, half-row
+// mirror, row mirror, then the four row results through v_readlane.
+// ---------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int iv = __float_as_int(v);
+  const int o = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __int_as_float(o));
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max<0x141>(v);  // row_half_mirror
+  v = dpp_max<0x140>(v);  // row_mirror  -> every lane holds its row-of-16 max
+  const int iv = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// ---------------------------------------------------------------------------
+// a2: farthest point sampling.  One workgroup per fragment; the fragment's
+// points live in registers (PPT per thread, blocked ownership: thread t owns
+// indices [t*PPT, (t+1)*PPT) so "lowest lane with the maximum" == "lowest
+// index with the maximum" == torch.argmax's first-maximum rule) and in LDS
+// (for the broadcast fetch of the newly selected centroid).  One barrier per
+// selected point when NWAVES > 1, none when the fragment fits one wave.
+// ---------------------------------------------------------------------------
+template <int NWAVES, int PPT>
+__global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
+    const float* __restrict__ xyz, int32_t* __restrict__ idx_out,
+    float* __restrict__ new_xyz, int N, int S) {
+  extern __shared__ __align__(16) float fps_smem[];
+  constexpr int NT = NWAVES * 64;
+  float* s_pts = fps_smem;                                  // [3*N] (+pad)
+  float* s_slot_d = fps_smem + ((3 * N + 3) & ~3);          // [2][NWAVES]
+  int* s_slot_i = reinterpret_cast<int*>(s_slot_d + 2 * NWAVES);  // [2][NWAVES]
+
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const float* src = xyz + (size_t)f * N * 3;
+  for (int i = tid; i < 3 * N; i += NT) s_pts[i] = src[i];
+  __syncthreads();
+
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = tid * PPT + k;
+    const bool ok = i < N;
+    px[k] = ok ? s_pts[3 * i + 0] : 0.0f;
+    py[k] = ok ? s_pts[3 * i + 1] : 0.0f;
+    pz[k] = ok ? s_pts[3 * i + 2] : 0.0f;
+    dist[k] = ok ? __builtin_huge_valf() : -1.0f;   // pads can never win
+  }
+  float cx = s_pts[0], cy = s_pts[1], cz = s_pts[2];
+  int sel = 0;
+  int32_t* o_idx = idx_out + (size_t)f * S;
+  float* o_xyz = new_xyz + (size_t)f * S * 3;
+
+  for (int s = 0;;) {
+    if (tid == 0) {
+      o_idx[s] = sel;
+      o_xyz[3 * s + 0] = cx;
+      o_xyz[3 * s + 1] = cy;
+      o_xyz[3 * s + 2] = cz;
+    }
+    if (++s >= S) break;
+    float best = -2.0f;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = __fsub_rn(px[k], cx);
+      const float dy = __fsub_rn(py[k], cy);
+      const float dz = __fsub_rn(pz[k], cz);
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const float nd = fminf(dist[k], d);
+      dist[k] = nd;
+      if (nd > best) { best = nd; bi = tid * PPT + k; }
+    }
+    const float wmax = wave_max_f32(best);
+    const unsigned long long m = __ballot(best == wmax);
+    const int src_lane = __builtin_ctzll(m);
+    const int widx = __builtin_amdgcn_readlane(bi, src_lane);
+    if (NWAVES > 1) {
+      const int par = (s & 1) * NWAVES;
+      if (lane == 0) {
+        s_slot_d[par + wave] = wmax;
+        s_slot_i[par + wave] = widx;
+      }
+      __syncthreads();
+      float bm = s_slot_d[par];
+      int bidx = s_slot_i[par];
+#pragma unroll
+      for (int w = 1; w < NWAVES; ++w) {
+        const float d2 = s_slot_d[par + w];
+        const int i2 = s_slot_i[par + w];
+        if (d2 > bm) { bm = d2; bidx = i2; }
+      }
+      sel = bidx;
+    } else {
+      sel = widx;
+    }
+    cx = s_pts[3 * sel + 0];
+    cy = s_pts[3 * sel + 1];
+    cz = s_pts[3 * sel + 2];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a3: ball query.  One wave per centroid scans the fragment's points (SoA in
+// LDS, with |p|^2 precomputed) 64 at a time in index order; kept indices are
+// compacted in order with ballot + mbcnt; the scan stops at nsample hits.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    int32_t* __restrict__ idx, int N, int S, int ns, float r2, int cpb) {
+  extern __shared__ __align__(16) float bq_smem[];
+  float* xs = bq_smem;
+  float* ys = xs + N;
+  float* zs = ys + N;
+  float* pp = zs + N;
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const float* src = xyz + (size_t)f * N * 3;
+  for (int i = tid; i < N; i += 256) {
+    const float x = src[3 * i + 0], y = src[3 * i + 1], z = src[3 * i + 2];
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    pp[i] = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  }
+  __syncthreads();
+  const int c_begin = blockIdx.x * cpb;
+  const int c_end = min(c_begin + cpb, S);
+  for (int c = c_begin + wave; c < c_end; c += 4) {
+    const float* cp = new_xyz + ((size_t)f * S + c) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    const float nn = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
+    int32_t* out = idx + ((size_t)f * S + c) * ns;
+    int cnt = 0;
+    int first = N;  // reference value when nothing is in range (pn2_utils.py:106-111)
+    for (int base = 0; base < N && cnt < ns; base += 64) {
+      const int i = base + lane;
+      const bool ok = i < N;
+      const float x = ok ? xs[i] : 0.0f;
+      const float y = ok ? ys[i] : 0.0f;
+      const float z = ok ? zs[i] : 0.0f;
+      const float q = ok ? pp[i] : 0.0f;
+      // K=3 matmul on the CPU BLAS: fma chain over k = 0,1,2
+      const float dot = __fmaf_rn(cz, z, __fmaf_rn(cy, y, __fmul_rn(cx, x)));
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), nn), q);
+      const bool keep = ok && !(d > r2);
+      const unsigned long long m = __ballot(keep);
+      if (m != 0ull) {
+        if (cnt == 0) first = base + __builtin_ctzll(m);
+        const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        const int pos = cnt + prefix;
+        if (keep && pos < ns) out[pos] = i;
+        cnt += __builtin_popcountll(m);
+      }
+    }
+    const int total = cnt < ns ? cnt : ns;
+    if (lane >= total && lane < ns) out[lane] = first;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a4: grouping.  One thread per float4 of the output row
+//   [ feats[f, id, 0:D] | xyz[f,id] - new_xyz[f,s] | 0 ]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_gather_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    const float* __restrict__ feats, const int32_t* __restrict__ idx,
+    float* __restrict__ out, int64_t total4, int N, int S, int ns, int D, int ldo4) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total4) return;
+  const int64_t row = gid / ldo4;
+  const int c4 = (int)(gid - row * ldo4);
+  const int64_t fs = row / ns;      // f*S + s
+  const int64_t f = fs / S;
+  int id = idx[row];
+  id = id < N ? id : N - 1;          // memory safety only; see ball_query_kernel
+  float4 v;
+  const int col = c4 * 4;
+  if (col < D) {
+    v = *reinterpret_cast<const float4*>(feats + ((size_t)f * N + id) * D + col);
+  } else if (col == D) {
+    const float* p = xyz + ((size_t)f * N + id) * 3;
+    const float* c = new_xyz + fs * 3;
+    v.x = __fsub_rn(p[0], c[0]);
+    v.y = __fsub_rn(p[1], c[1]);
+    v.z = __fsub_rn(p[2], c[2]);
+    v.w = 0.0f;
+  } else {
+    v = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  *reinterpret_cast<float4*>(out + gid * 4) = v;
+}
+
+// ---------------------------------------------------------------------------
+// a19: pose composition (get_param / extract_final_pred_trans_rots)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_matrix(const float* q, float* m /*9*/) {
+  const float r = q[0], i = q[1], j = q[2], k = q[3];
+  const float two_s = 2.0f / (((r * r + i * i) + j * j) + k * k);
+  m[0] = 1.0f - two_s * (j * j + k * k);
+  m[1] = two_s * (i * j - k * r);
+  m[2] = two_s * (i * k + j * r);
+  m[3] = two_s * (i * j + k * r);
+  m[4] = 1.0f - two_s * (i * i + k * k);
+  m[5] = two_s * (j * k - i * r);
+  m[6] = two_s * (i * k - j * r);
+  m[7] = two_s * (j * k + i * r);
+  m[8] = 1.0f - two_s * (i * i + j * j);
+}
+
+__device__ __forceinline__ float sqrt_pos(float x) { return x > 0.0f ? sqrtf(x) : 0.0f; }
+
+__device__ __forceinline__ void matrix_to_quat(const float* m, float* q) {
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5],
+              m20 = m[6], m21 = m[7], m22 = m[8];
+  float qa[4];
+  qa[0] = sqrt_pos(1.0f + m00 + m11 + m22);
+  qa[1] = sqrt_pos(1.0f + m00 - m11 - m22);
+  qa[2] = sqrt_pos(1.0f - m00 + m11 - m22);
+  qa[3] = sqrt_pos(1.0f - m00 - m11 + m22);
+  float cand[4][4] = {
+      {qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01},
+      {m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20},
+      {m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21},
+      {m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]}};
+  int best = 0;
+#pragma unroll
+  for (int a = 1; a < 4; ++a)
+    if (qa[a] > qa[best]) best = a;   // first maximum, like argmax
+  float o[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (a == best) {
+      const float den = 2.0f * fmaxf(qa[a], 0.1f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = cand[a][c] / den;
+    }
+  }
+  // standardize_quaternion: non-negative real part
+  const float sgn = o[0] < 0.0f ? -1.0f : 1.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) q[c] = sgn < 0.0f ? -o[c] : o[c];
+}
+
+__global__ __launch_bounds__(64) void pose_compose_kernel(
+    const float* __restrict__ pose, const int32_t* __restrict__ pivot,
+    const float* __restrict__ init_pose, const uint8_t* __restrict__ has_init,
+    float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* ps = pose + (int64_t)pivot[i] * 7;
+  float R[9];
+  quat_to_matrix(ps + 3, R);
+  float t[3] = {ps[0], ps[1], ps[2]};
+  float Ro[9], to[3];
+  if (has_init && has_init[i]) {
+    const float* I = init_pose + i * 16;
+    // [R t; 0 1] @ I  (torch matmul of 4x4: k-ordered accumulation)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = R[r * 3 + 0] * I[0 * 4 + c];
+        acc = fmaf(R[r * 3 + 1], I[1 * 4 + c], acc);
+        acc = fmaf(R[r * 3 + 2], I[2 * 4 + c], acc);
+        acc = fmaf(t[r], I[3 * 4 + c], acc);
+        Ro[r * 3 + c] = acc;
+      }
+      float acc = R[r * 3 + 0] * I[0 * 4 + 3];
+      acc = fmaf(R[r * 3 + 1], I[1 * 4 + 3], acc);
+      acc = fmaf(R[r * 3 + 2], I[2 * 4 + 3], acc);
+      acc = fmaf(t[r], I[3 * 4 + 3], acc);
+      to[r] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ro[k] = R[k];
+    to[0] = t[0]; to[1] = t[1]; to[2] = t[2];
+  }
+  float q[4];
+  matrix_to_quat(Ro, q);
+  float* o = out + i * 7;
+  o[0] = to[0]; o[1] = to[1]; o[2] = to[2];
+  o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+}
+
+template <int NWAVES, int PPT>
+int launch_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int N, int S,
+               hipStream_t st) {
+  const size_t smem = (size_t)(((3 * N + 3) & ~3) + 4 * NWAVES) * sizeof(float);
+  hipLaunchKernelGGL((fps_kernel<NWAVES, PPT>), dim3((unsigned)F), dim3(NWAVES * 64), smem, st,
+                     xyz, idx, new_xyz, N, S);
+  return pfpp::check_launch("pfpp_fps");
+}
+
+}  // namespace
+
+extern "C" int pfpp_se3_rotate_gather(const float* part_pcs, const float* pose,
+                                      const int32_t* slot, float* out, int64_t F, int64_t N,
+                                      pfpp_stream_t stream) {
+  PFPP_REQUIRE(part_pcs && pose && slot && out, "null pointer");
+  PFPP_REQUIRE(F >= 0 && N > 0, "bad sizes");
+  if (F == 0) return PFPP_OK;
+  const int64_t total = F * N;
+  hipLaunchKernelGGL(se3_rotate_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), part_pcs, pose, slot, out, F, N);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_pose_apply(const float* pts, const float* pose, const float* scale,
+                               float* out, int64_t n, int64_t N, int normalise,
+                               pfpp_stream_t stream) {
+  PFPP_REQUIRE(pts && pose && out, "null pointer");
+  PFPP_REQUIRE(n >= 0 && N > 0, "bad sizes");
+  if (n == 0) return PFPP_OK;
+  const int64_t total = n * N;
+  hipLaunchKernelGGL(pose_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), pts, pose, scale, out, n, N, normalise);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N,
+                        int64_t S, pfpp_stream_t stream) {
+  PFPP_REQUIRE(xyz && idx && new_xyz, "null pointer");
+  PFPP_REQUIRE(F >= 0 && N >= 1 && S >= 1 && S <= N, "need 1 <= S <= N");
+  PFPP_SUPPORTED(N <= 4096, "N > 4096");
+  if (F == 0) return PFPP_OK;
+  hipStream_t st = pfpp::as_stream(stream);
+  const int n = (int)N, s = (int)S;
+  if (N <= 64) return launch_fps<1, 1>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 128) return launch_fps<1, 2>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 256) return launch_fps<1, 4>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 512) return launch_fps<2, 4>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 1024) return launch_fps<4, 4>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 2048) return launch_fps<4, 8>(xyz, idx, new_xyz, F, n, s, st);
+  return launch_fps<4, 16>(xyz, idx, new_xyz, F, n, s, st);
+}
+
+extern "C" int pfpp_ball_query(const float* xyz, const float* new_xyz, int32_t* idx, int64_t F,
+                               int64_t N, int64_t S, int64_t nsample, float r2,
+                               pfpp_stream_t stream) {
+  PFPP_REQUIRE(xyz && new_xyz && idx, "null pointer");
+  PFPP_REQUIRE(F >= 0 && N >= 1 && S >= 1 && nsample >= 1, "bad sizes");
+  PFPP_SUPPORTED(nsample <= 64, "nsample > 64");
+  PFPP_SUPPORTED(N <= 8192, "N > 8192");
+  PFPP_SUPPORTED(F <= 65535, "F > 65535 fragments per call");
+  if (F == 0) return PFPP_OK;
+  const int cpb = 16;  // centroids per workgroup (4 per wave)
+  const dim3 grid((unsigned)((S + cpb - 1) / cpb), (unsigned)F);
+  const size_t smem = (size_t)N * 4 * sizeof(float);
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), smem, pfpp::as_stream(stream), xyz,
+                     new_xyz, idx, (int)N, (int)S, (int)nsample, r2, cpb);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_group_gather(const float* xyz, const float* new_xyz, const float* feats,
+                                 const int32_t* idx, float* out, int64_t F, int64_t N, int64_t S,
+                                 int64_t ns, int64_t D, int64_t ldo, pfpp_stream_t stream) {
+  PFPP_REQUIRE(xyz && new_xyz && idx && out, "null pointer");
+  PFPP_REQUIRE(D == 0 || feats, "feats is NULL with D > 0");
+  PFPP_REQUIRE(D % 4 == 0 && ldo % 4 == 0 && ldo >= D + 4, "need D%4==0, ldo%4==0, ldo>=D+4");
+  PFPP_REQUIRE(pfpp::aligned16(out) && (D == 0 || pfpp::aligned16(feats)), "16-byte alignment");
+  const int64_t total4 = F * S * ns * (ldo / 4);
+  if (total4 == 0) return PFPP_OK;
+  hipLaunchKernelGGL(group_gather_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), xyz, new_xyz, feats, idx, out, total4, (int)N, (int)S,
+                     (int)ns, (int)D, (int)(ldo / 4));
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_pose_compose(const float* pose, const int32_t* pivot, const float* init_pose,
+                                 const uint8_t* has_init, float* out, int64_t n,
+                                 pfpp_stream_t stream) {
+  PFPP_REQUIRE(pose && pivot && out, "null pointer");
+  PFPP_REQUIRE(!has_init || init_pose, "has_init without init_pose");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(pose_compose_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                     pfpp::as_stream(stream), pose, pivot, init_pose, has_init, out, n);
+  return pfpp::check_launch(__func__);
+}

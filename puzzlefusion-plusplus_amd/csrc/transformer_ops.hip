@@ -1,0 +1,486 @@
+// Non-GEMM kernels of the Denoiser / Verifier transformers and the DDPM update
+// (gfx950).  All of them are HBM-bound streaming or tiny per-row work; the dense
+// contractions go through pfpp_gemm.
+#include "pfpp_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// a9: NeRF positional features (EmbedderNerf.embed, utils/model_utils.py:68-69):
+//   PE(v) = [v | sin(2^0 v) | cos(2^0 v) | ... | sin(2^9 v) | cos(2^9 v)],
+// each block as wide as v.  v*2^k is exact in fp32; sinf/cosf are the accurate
+// (range-reduced) device functions.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float nerf_pe(const float* v, int d, int c) {
+  // c in [0, 21*d): block = c / d, component = c % d
+  const int blk = c / d, comp = c - blk * d;
+  const float x = v[comp];
+  if (blk == 0) return x;
+  const int fi = (blk - 1) >> 1;
+  const float arg = x * (float)(1 << fi);
+  return ((blk - 1) & 1) ? cosf(arg) : sinf(arg);
+}
+
+constexpr int TOK_LD = 148;
+
+__global__ __launch_bounds__(256) void token_features_kernel(
+    const float* __restrict__ latent, const float* __restrict__ xyz,
+    const float* __restrict__ scale, const float* __restrict__ x,
+    float* __restrict__ shape_feat, float* __restrict__ pose_feat, int64_t n, int L) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_shape = n * L * TOK_LD;
+  if (gid < n_shape) {
+    const int64_t row = gid / TOK_LD;     // (bp, l)
+    const int c = (int)(gid - row * TOK_LD);
+    float v;
+    if (c < 64) {
+      v = latent[row * 64 + c];
+    } else if (c < 64 + 63) {
+      v = nerf_pe(xyz + row * 3, 3, c - 64);
+    } else if (c < 64 + 63 + 21) {
+      const float s = scale[row / L];
+      v = nerf_pe(&s, 1, c - 127);
+    } else {
+      v = 0.0f;
+    }
+    shape_feat[gid] = v;
+    return;
+  }
+  const int64_t g2 = gid - n_shape;
+  if (g2 < n * TOK_LD) {
+    const int64_t row = g2 / TOK_LD;
+    const int c = (int)(g2 - row * TOK_LD);
+    pose_feat[g2] = c < 147 ? nerf_pe(x + row * 7, 7, c) : 0.0f;
+  }
+}
+
+// tok = shape_emb + x_emb[bp] + ref_emb[ref] + pe[p]; evaluation order of the
+// reference: (x_emb + ref_emb) then + shape_emb then + pe
+// (denoiser_transformer.py:155,183-185)
+__global__ __launch_bounds__(256) void token_combine_kernel(
+    const float* __restrict__ shape_emb, const float* __restrict__ x_emb,
+    const float* __restrict__ ref_emb, const uint8_t* __restrict__ ref_part,
+    const float* __restrict__ pe, float* __restrict__ tok, int64_t total4, int P, int L, int C4) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total4) return;
+  const int64_t row = gid / C4;          // (b,p,l)
+  const int c4 = (int)(gid - row * C4);
+  const int64_t bp = row / L;
+  const int p = (int)(bp % P);
+  const float4 s = reinterpret_cast<const float4*>(shape_emb)[gid];
+  const float4 xe = reinterpret_cast<const float4*>(x_emb)[bp * C4 + c4];
+  const float4 re = reinterpret_cast<const float4*>(ref_emb)[(ref_part[bp] ? 1 : 0) * C4 + c4];
+  const float4 pp = reinterpret_cast<const float4*>(pe)[p * C4 + c4];
+  float4 o;
+  o.x = ((xe.x + re.x) + s.x) + pp.x;
+  o.y = ((xe.y + re.y) + s.y) + pp.y;
+  o.z = ((xe.z + re.z) + s.z) + pp.z;
+  o.w = ((xe.w + re.w) + s.w) + pp.w;
+  reinterpret_cast<float4*>(tok)[gid] = o;
+}
+
+// ---------------------------------------------------------------------------
+// a11: AdaLN
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_embed_kernel(const float* __restrict__ tables,
+                                                         const int64_t* __restrict__ t,
+                                                         float* __restrict__ out, int64_t total,
+                                                         int64_t n_emb, int B, int C) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  const int64_t ib = gid / C;
+  const int b = (int)(ib % B);
+  const int64_t i = ib / B;
+  const float v = tables[(i * n_emb + t[b]) * C + c];
+  out[gid] = v / (1.0f + expf(-v));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// one wave per row; VPL float4 per lane (C = 256*VPL)
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mod,
+    int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
+    int rows_per_batch, float eps) {
+  constexpr int C = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+  float4 v[VPL];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    v[k] = xr[lane + 64 * k];
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = wave_sum(q) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float4* yr = reinterpret_cast<float4*>(y + row * C);
+  const int64_t b = row / rows_per_batch;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    float4 o;
+    o.x = (v[k].x - mean) * rstd;
+    o.y = (v[k].y - mean) * rstd;
+    o.z = (v[k].z - mean) * rstd;
+    o.w = (v[k].w - mean) * rstd;
+    if (mod) {
+      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
+      const float4 sh = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+      o.x = o.x * (1.0f + sc.x) + sh.x;
+      o.y = o.y * (1.0f + sc.y) + sh.y;
+      o.z = o.z * (1.0f + sc.z) + sh.z;
+      o.w = o.w * (1.0f + sc.w) + sh.w;
+    } else if (gamma) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+      const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+      o.x = o.x * g.x + be.x;
+      o.y = o.y * g.y + be.y;
+      o.z = o.z * g.z + be.z;
+      o.w = o.w * g.w + be.w;
+    }
+    yr[c4] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a12: block-diagonal self-attention.  One wave per (fragment, head); lane =
+// query row (L <= 32 of the 64 lanes are busy), K and V of the fragment/head sit
+// in LDS and every lane reads the same key at the same time (LDS broadcast).
+// 80 kMAC per wave: negligible next to the projections, so plain VALU.
+// ---------------------------------------------------------------------------
+constexpr int AB_LMAX = 32;
+constexpr int AB_DH = 64;
+
+__global__ __launch_bounds__(256) void attn_blockdiag_kernel(const float* __restrict__ qkv,
+                                                             float* __restrict__ out,
+                                                             int64_t n_pairs, int L, int H,
+                                                             float scale) {
+  extern __shared__ __align__(16) float ab_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* sk = ab_smem + wave * (2 * AB_LMAX * AB_DH);
+  float* sv = sk + AB_LMAX * AB_DH;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;   // frag * H + h
+  if (pair >= n_pairs) return;                           // whole wave exits together
+  const int64_t frag = pair / H;
+  const int h = (int)(pair - frag * H);
+  const int64_t ld = 3ll * H * AB_DH;
+  const float* base = qkv + frag * L * ld + h * AB_DH;
+  // stage K and V: L rows x 16 float4
+  for (int i = lane; i < L * 16; i += 64) {
+    const int r = i >> 4, c4 = i & 15;
+    reinterpret_cast<float4*>(sk)[r * 16 + c4] =
+        *reinterpret_cast<const float4*>(base + r * ld + H * AB_DH + c4 * 4);
+    reinterpret_cast<float4*>(sv)[r * 16 + c4] =
+        *reinterpret_cast<const float4*>(base + r * ld + 2 * H * AB_DH + c4 * 4);
+  }
+  __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave visible to itself
+  __builtin_amdgcn_wave_barrier();
+  const bool active = lane < L;
+  const int qi = active ? lane : 0;
+  float q[AB_DH];
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const float4 v = *reinterpret_cast<const float4*>(base + qi * ld + c4 * 4);
+    q[4 * c4 + 0] = v.x; q[4 * c4 + 1] = v.y; q[4 * c4 + 2] = v.z; q[4 * c4 + 3] = v.w;
+  }
+  float s[AB_LMAX];
+  float m = -__builtin_huge_valf();
+#pragma unroll
+  for (int j = 0; j < AB_LMAX; ++j) {
+    s[j] = -__builtin_huge_valf();
+    if (j < L) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 k = reinterpret_cast<const float4*>(sk)[j * 16 + c4];
+        acc = fmaf(q[4 * c4 + 0], k.x, acc);
+        acc = fmaf(q[4 * c4 + 1], k.y, acc);
+        acc = fmaf(q[4 * c4 + 2], k.z, acc);
+        acc = fmaf(q[4 * c4 + 3], k.w, acc);
+      }
+      s[j] = acc * scale;
+      m = fmaxf(m, s[j]);
+    }
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < AB_LMAX; ++j) {
+    if (j < L) {
+      s[j] = expf(s[j] - m);
+      sum += s[j];
+    }
+  }
+  const float inv = 1.0f / sum;
+  float o[AB_DH];
+#pragma unroll
+  for (int d = 0; d < AB_DH; ++d) o[d] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < AB_LMAX; ++j) {
+    if (j < L) {
+      const float pj = s[j] * inv;
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 v = reinterpret_cast<const float4*>(sv)[j * 16 + c4];
+        o[4 * c4 + 0] = fmaf(pj, v.x, o[4 * c4 + 0]);
+        o[4 * c4 + 1] = fmaf(pj, v.y, o[4 * c4 + 1]);
+        o[4 * c4 + 2] = fmaf(pj, v.z, o[4 * c4 + 2]);
+        o[4 * c4 + 3] = fmaf(pj, v.w, o[4 * c4 + 3]);
+      }
+    }
+  }
+  if (active) {
+    float* op = out + (frag * L + lane) * (int64_t)(H * AB_DH) + h * AB_DH;
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4)
+      *reinterpret_cast<float4*>(op + c4 * 4) =
+          make_float4(o[4 * c4 + 0], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a13/a18: masked row softmax, one wave per row, three passes over a row that
+// stays in L1/L2 (T <= a few thousand)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S,
+                                                           const uint8_t* __restrict__ key_valid,
+                                                           int64_t rows_total, int rows_per_batch,
+                                                           int T, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows_total) return;
+  float* s = S + row * ld;
+  const uint8_t* kv = key_valid ? key_valid + (row / rows_per_batch) * T : nullptr;
+  float m = -__builtin_huge_valf();
+  for (int j = lane; j < T; j += 64)
+    if (!kv || kv[j]) m = fmaxf(m, s[j] * scale);
+  m = wave_max(m);
+  float sum = 0.0f;
+  for (int j = lane; j < T; j += 64) {
+    float e = 0.0f;
+    if (!kv || kv[j]) e = expf(s[j] * scale - m);
+    s[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+  for (int j = lane; j < ld; j += 64) s[j] = j < T ? s[j] * inv : 0.0f;
+}
+
+// a15: mean over the L tokens of a fragment (sum in l order, then / L)
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ out, int64_t total,
+                                                        int L, int C) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t n = gid / C;
+  const int c = (int)(gid - n * C);
+  const float* p = x + n * L * C + c;
+  float s = 0.0f;
+  for (int l = 0; l < L; ++l) s += p[(int64_t)l * C];
+  out[gid] = s / (float)L;
+}
+
+// ---------------------------------------------------------------------------
+// a16: scheduler
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddpm_step_kernel(
+    const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+    const uint8_t* __restrict__ ref_part, const float* __restrict__ reference,
+    float* __restrict__ out, int64_t total, float c_eps, float c_div, float c_x0, float c_x,
+    float c_noise) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t row = gid / 7;
+  float v;
+  if (ref_part && ref_part[row]) {
+    v = reference[gid];
+  } else {
+    const float xv = x[gid];
+    const float x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c_eps, eps[gid])), c_div);
+    v = __fadd_rn(__fmul_rn(c_x0, x0), __fmul_rn(c_x, xv));
+    if (noise) v = __fadd_rn(v, __fmul_rn(c_noise, noise[gid]));
+  }
+  out[gid] = v;
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x0,
+                                                        const float* __restrict__ noise,
+                                                        const float* __restrict__ sa,
+                                                        const float* __restrict__ sb,
+                                                        float* __restrict__ out, int64_t total,
+                                                        int per_batch) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t b = gid / per_batch;
+  out[gid] = __fadd_rn(__fmul_rn(sa[b], x0[gid]), __fmul_rn(sb[b], noise[gid]));
+}
+
+// a18: verifier token = feat_emb + [pe[i0] | pe[i1]]
+__global__ __launch_bounds__(256) void verifier_embed_kernel(const float* __restrict__ feat_emb,
+                                                             const int64_t* __restrict__ edge_idx,
+                                                             const float* __restrict__ pe,
+                                                             float* __restrict__ tok,
+                                                             int64_t total, int C, int max_len) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t row = gid / C;
+  const int c = (int)(gid - row * C);
+  const int half = C >> 1;
+  int64_t node = edge_idx[row * 2 + (c >= half ? 1 : 0)];
+  node = node < 0 ? 0 : (node >= max_len ? max_len - 1 : node);
+  tok[gid] = pe[node * half + (c >= half ? c - half : c)] + feat_emb[gid];
+}
+
+inline unsigned blocks_for(int64_t total, int per) { return (unsigned)((total + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int pfpp_token_features(const float* latent, const float* xyz, const float* scale,
+                                   const float* x, float* shape_feat, float* pose_feat, int64_t n,
+                                   int64_t L, pfpp_stream_t stream) {
+  PFPP_REQUIRE(latent && xyz && scale && x && shape_feat && pose_feat, "null pointer");
+  const int64_t total = n * L * TOK_LD + n * TOK_LD;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_features_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), latent, xyz, scale, x, shape_feat, pose_feat, n, (int)L);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_token_combine(const float* shape_emb, const float* x_emb, const float* ref_emb,
+                                  const uint8_t* ref_part, const float* pe, float* tok, int64_t B,
+                                  int64_t P, int64_t L, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(shape_emb && x_emb && ref_emb && ref_part && pe && tok, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0, "C % 4 != 0");
+  const int64_t total4 = B * P * L * (C / 4);
+  if (total4 == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, tok, total4,
+                     (int)P, (int)L, (int)(C / 4));
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_silu_embed(const float* tables, const int64_t* t, float* out, int64_t n_tab,
+                               int64_t n_emb, int64_t B, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(tables && t && out, "null pointer");
+  const int64_t total = n_tab * B * C;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(silu_embed_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), tables, t, out, total, n_emb, (int)B, (int)C);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
+                              const float* gamma, const float* beta, int64_t rows, int64_t C,
+                              int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && y, "null pointer");
+  PFPP_REQUIRE(!gamma || beta, "gamma without beta");
+  PFPP_REQUIRE(rows_per_batch >= 1, "rows_per_batch < 1");
+  PFPP_SUPPORTED(C == 256 || C == 512 || C == 1024, "C not in {256, 512, 1024}");
+  if (rows == 0) return PFPP_OK;
+  hipStream_t st = pfpp::as_stream(stream);
+  const dim3 grid(blocks_for(rows, 4));
+  if (C == 256)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
+  else if (C == 512)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_attn_blockdiag(const float* qkv, float* out, int64_t n_frag, int64_t L,
+                                   int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out, "null pointer");
+  PFPP_SUPPORTED(dh == AB_DH, "dim_head != 64");
+  PFPP_SUPPORTED(L >= 1 && L <= AB_LMAX, "L outside [1, 32]");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out), "16-byte alignment");
+  const int64_t pairs = n_frag * H;
+  if (pairs == 0) return PFPP_OK;
+  const size_t smem = 4 * 2 * AB_LMAX * AB_DH * sizeof(float);
+  hipLaunchKernelGGL(attn_blockdiag_kernel, dim3(blocks_for(pairs, 4)), dim3(256), smem,
+                     pfpp::as_stream(stream), qkv, out, pairs, (int)L, (int)H, scale);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_softmax_rows(float* S, const uint8_t* key_valid, int64_t rows_total,
+                                 int64_t rows_per_batch, int64_t T, int64_t ld, float scale,
+                                 pfpp_stream_t stream) {
+  PFPP_REQUIRE(S, "null pointer");
+  PFPP_REQUIRE(T >= 1 && ld >= T && rows_per_batch >= 1, "bad sizes");
+  if (rows_total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(blocks_for(rows_total, 4)), dim3(256), 0,
+                     pfpp::as_stream(stream), S, key_valid, rows_total, (int)rows_per_batch, (int)T,
+                     (int)ld, scale);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_mean_pool(const float* x, float* out, int64_t n, int64_t L, int64_t C,
+                              pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && out, "null pointer");
+  const int64_t total = n * C;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(mean_pool_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), x, out, total, (int)L, (int)C);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_ddpm_step(const float* x, const float* eps, const float* noise,
+                              const uint8_t* ref_part, const float* reference, float* out,
+                              int64_t n, float c_eps, float c_div, float c_x0, float c_x,
+                              float c_noise, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && eps && out, "null pointer");
+  PFPP_REQUIRE(!ref_part || reference, "ref_part without reference");
+  const int64_t total = n * 7;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), x, eps, noise, ref_part, reference, out, total, c_eps,
+                     c_div, c_x0, c_x, c_noise);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_add_noise(const float* x0, const float* noise, const float* sqrt_ab,
+                              const float* sqrt_1mab, float* out, int64_t B, int64_t per_batch,
+                              pfpp_stream_t stream) {
+  PFPP_REQUIRE(x0 && noise && sqrt_ab && sqrt_1mab && out, "null pointer");
+  const int64_t total = B * per_batch;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(add_noise_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), x0, noise, sqrt_ab, sqrt_1mab, out, total,
+                     (int)per_batch);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_verifier_embed(const float* feat_emb, const int64_t* edge_idx, const float* pe,
+                                   float* tok, int64_t n, int64_t C, int64_t max_len,
+                                   pfpp_stream_t stream) {
+  PFPP_REQUIRE(feat_emb && edge_idx && pe && tok, "null pointer");
+  PFPP_REQUIRE(C % 2 == 0, "C must be even");
+  const int64_t total = n * C;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(verifier_embed_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), feat_emb, edge_idx, pe, tok, total, (int)C,
+                     (int)max_len);
+  return pfpp::check_launch(__func__);
+}

@@ -1,0 +1,100 @@
+"""ctypes binding of libpfpp_hip.so (the C ABI declared in include/pfpp.h).
+
+There is no CPU fallback: if the shared object is missing the import of any
+kernel wrapper raises, and every wrapper refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libpfpp_hip.so"
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f32 = C.c_float
+
+
+class GemmArgs(C.Structure):
+    """mirror of struct pfpp_gemm_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("A", _p), ("W", _p), ("C", _p),
+        ("bias", _p), ("scale", _p), ("shift", _p), ("residual", _p),
+        ("M", _i64), ("N", _i64), ("K", _i64),
+        ("lda", _i64), ("ldw", _i64), ("ldc", _i64), ("ldr", _i64),
+        ("w_kmajor", _i32), ("act", _i32), ("pool", _i32),
+        ("batch", _i32), ("zdiv", _i32),
+        ("sA0", _i64), ("sA1", _i64), ("sW0", _i64), ("sW1", _i64), ("sC0", _i64), ("sC1", _i64),
+        ("sV0", _i64), ("sV1", _i64),
+        ("alpha", _f32),
+    ]
+
+
+# name -> argtypes (all return int); must list every symbol include/pfpp.h declares
+SIGNATURES = {
+    "pfpp_se3_rotate_gather": [_p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_pose_apply": [_p, _p, _p, _p, _i64, _i64, C.c_int, _p],
+    "pfpp_fps": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_ball_query": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_group_gather": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "pfpp_gemm": [C.POINTER(GemmArgs), _p],
+    "pfpp_vq_encode": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_scatter_rows": [_p, _p, _p, _i64, _i64, _p],
+    "pfpp_token_features": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_token_combine": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_silu_embed": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_layernorm": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_blockdiag": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_softmax_rows": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_mean_pool": [_p, _p, _i64, _i64, _i64, _p],
+    "pfpp_ddpm_step": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
+    "pfpp_add_noise": [_p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_verifier_embed": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
+}
+PLAIN = {
+    "pfpp_version": ([], C.c_int),
+    "pfpp_last_error": ([], C.c_char_p),
+    "pfpp_device_cu_count": ([], C.c_int),
+}
+
+ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}
+
+_lib = None
+
+
+class PfppError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libpfpp_hip.so and attach prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PfppError(
+            f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path. "
+            "Build them with `python __graft_entry__.py` (hipcc --offload-arch=gfx950)."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (argtypes, restype) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.pfpp_version() != 1:
+        raise PfppError(f"libpfpp_hip.so ABI version {lib.pfpp_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().pfpp_last_error()
+        raise PfppError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,131 @@
+"""DenoiserTransformer forward on the HIP kernels.
+
+Host orchestration only.  Per layer: AdaLN (LN kernel with the (scale, shift) of the batched
+AdaLN GEMM) -> packed QKV GEMM -> block-diagonal self-attention in one kernel (the [B,T,T]
+mask of the reference is never built) -> out-projection GEMM with bias+residual epilogue ->
+AdaLN -> QKV GEMM -> per-(puzzle, head) QK^T GEMM, key-masked softmax, P.V GEMM ->
+out-projection (+bias, +residual) -> LN -> GEGLU GEMM (gate fused in the epilogue) ->
+down-projection (+bias, +residual).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .packing import pack_geglu, pad_k, round_up
+
+
+def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, torch.Tensor]:
+    """sd: live tensors of a DenoiserTransformer keyed by state_dict names"""
+    pk: Dict[str, torch.Tensor] = {}
+    pk["shape.w"] = pad_k(sd["shape_embedding.weight"])
+    pk["shape.b"] = sd["shape_embedding.bias"].contiguous()
+    pk["param.w"] = pad_k(sd["param_fc.weight"])
+    pk["param.b"] = sd["param_fc.bias"].contiguous()
+    pk["ref_emb"] = sd["ref_part_emb.weight"].contiguous()
+    pk["pe"] = sd["pos_encoding.pe"][0].contiguous()
+    tabs, lw, lb = [], [], []
+    for i in range(num_layers):
+        p = f"transformer_layers.{i}"
+        for n in ("norm1", "norm2"):
+            tabs.append(sd[f"{p}.{n}.emb.weight"])
+            lw.append(sd[f"{p}.{n}.linear.weight"])
+            lb.append(sd[f"{p}.{n}.linear.bias"])
+        for a in ("self_attn", "global_attn"):
+            pk[f"{i}.{a}.wqkv"] = torch.cat(
+                [sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"], sd[f"{p}.{a}.to_v.weight"]], dim=0
+            ).contiguous()
+            pk[f"{i}.{a}.wo"] = sd[f"{p}.{a}.to_out.0.weight"].contiguous()
+            pk[f"{i}.{a}.bo"] = sd[f"{p}.{a}.to_out.0.bias"].contiguous()
+        pk[f"{i}.norm3.g"] = sd[f"{p}.norm3.weight"].contiguous()
+        pk[f"{i}.norm3.b"] = sd[f"{p}.norm3.bias"].contiguous()
+        pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"] = pack_geglu(sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"])
+        pk[f"{i}.ff.w2"] = sd[f"{p}.ff.net.2.weight"].contiguous()
+        pk[f"{i}.ff.b2"] = sd[f"{p}.ff.net.2.bias"].contiguous()
+    pk["ada.tables"] = torch.stack(tabs, 0).contiguous()   # [2*layers, n_emb, C]
+    pk["ada.w"] = torch.stack(lw, 0).contiguous()          # [2*layers, 2C, C]
+    pk["ada.b"] = torch.stack(lb, 0).contiguous()          # [2*layers, 2C]
+    for h in ("mlp_out_trans", "mlp_out_rot"):
+        for j in (0, 2, 4):
+            pk[f"{h}.{j}.w"] = sd[f"{h}.{j}.weight"].contiguous()
+            pk[f"{h}.{j}.b"] = sd[f"{h}.{j}.bias"].contiguous()
+    return pk
+
+
+def dense_attention(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, key_valid_u8: torch.Tensor,
+                    scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(Q K^T * scale + key mask) V per (batch, head) from a packed [B*T, 3*H*dh] projection.
+    Shared by the denoiser's global attention (a13) and the verifier (a18)."""
+    C = H * dh
+    ld = 3 * C
+    Tp = round_up(T, 4)
+    S = torch.empty((B * H, T, Tp), dtype=torch.float32, device=qkv.device)
+    # S[b,h] = Q_bh K_bh^T : A = Q rows (lda = 3C), W = K rows [T, dh] (ldw = 3C)
+    ops.gemm(qkv, qkv, M=T, N=T, K=dh, lda=ld, ldw=ld, out=S, ldc=Tp, batch=B * H, zdiv=H,
+             sA=(T * ld, dh), sW=(T * ld, dh), sC=(H * T * Tp, T * Tp), w_off=C)
+    ops.softmax_rows(S, key_valid_u8, H * T, T, scale)
+    if out is None:
+        out = torch.empty((B * T, C), dtype=torch.float32, device=qkv.device)
+    # O[b, :, h] = P_bh V_bh : W = V rows [T(k), dh(n)] k-major
+    ops.gemm(S, qkv, M=T, N=dh, K=T, lda=Tp, ldw=ld, out=out, ldc=C, w_kmajor=True, batch=B * H, zdiv=H,
+             sA=(H * T * Tp, T * Tp), sW=(T * ld, dh), sC=(T * C, dh), w_off=2 * C)
+    return out
+
+
+def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, num_layers: int,
+                     num_heads: int, capture: Optional[dict] = None) -> torch.Tensor:
+    """DenoiserTransformer.forward (denoiser_transformer.py:169-203), eval mode."""
+    B, P, L, _ = latent.shape
+    C = pk["shape.b"].numel()
+    n = B * P
+    T = P * L
+    M = B * T
+    dh = C // num_heads
+    if P > pk["pe"].shape[0]:
+        raise ValueError(f"P={P} fragments exceed PositionalEncoding max_len={pk['pe'].shape[0]}")
+    sf, pf = ops.token_features(latent.reshape(n, L, -1).contiguous(), xyz.reshape(n, L, 3).contiguous(),
+                                scale.reshape(n).contiguous(), x.reshape(n, 7).contiguous())
+    shape_emb = ops.linear(sf, pk["shape.w"], pk["shape.b"])
+    x_emb = ops.linear(pf, pk["param.w"], pk["param.b"])
+    ref_u8 = ref_part.reshape(n).to(torch.uint8).contiguous()
+    h = ops.token_combine(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], B, P, L)
+    if capture is not None:
+        capture["tokens"] = h.clone()
+    # all AdaLN (scale, shift) vectors of the step in one batched GEMM: [2*layers, B, 2C]
+    n_ada = 2 * num_layers
+    se = ops.silu_embed(pk["ada.tables"], timesteps.to(torch.int64).contiguous())
+    mods = torch.empty((n_ada, B, 2 * C), dtype=torch.float32, device=h.device)
+    ops.gemm(se, pk["ada.w"], M=B, N=2 * C, K=C, lda=C, ldw=C, out=mods, ldc=2 * C, bias=pk["ada.b"],
+             batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
+    key_valid = part_valids.reshape(B, P).to(torch.bool).repeat_interleave(L, dim=1).to(torch.uint8).contiguous()
+    att_scale = 1.0 / math.sqrt(dh)
+    norm = torch.empty_like(h)
+    att = torch.empty_like(h)
+    for i in range(num_layers):
+        ops.layernorm(h, mod=mods[2 * i], rows_per_batch=T, out=norm)
+        qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
+        att = ops.attn_blockdiag(qkv, n, L, num_heads, dh, att_scale)
+        ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C,
+                 bias=pk[f"{i}.self_attn.bo"], residual=h, ldr=C)
+        ops.layernorm(h, mod=mods[2 * i + 1], rows_per_batch=T, out=norm)
+        qkv = ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
+        dense_attention(qkv, B, T, num_heads, dh, key_valid, att_scale, out=att)
+        ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C,
+                 bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
+        ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
+        u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu")
+        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=u.shape[1], lda=u.shape[1], ldw=u.shape[1], out=h, ldc=C,
+                 bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
+        if capture is not None:
+            capture[f"layer{i}"] = h.clone()
+    pooled = ops.mean_pool(h, n, L)
+    out = torch.empty((n, 7), dtype=torch.float32, device=h.device)
+    for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
+        v = ops.linear(pooled, pk[f"{name}.0.w"], pk[f"{name}.0.b"], act="silu")
+        v = ops.linear(v, pk[f"{name}.2.w"], pk[f"{name}.2.b"], act="silu")
+        ops.gemm(v, pk[f"{name}.4.w"], M=n, N=width, K=v.shape[1], lda=v.shape[1], ldw=v.shape[1], out=out, ldc=7,
+                 bias=pk[f"{name}.4.b"], c_off=c0)
+    return out.view(B, P, 7)

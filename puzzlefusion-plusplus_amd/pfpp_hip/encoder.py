@@ -1,0 +1,111 @@
+"""Fragment encoder on the HIP kernels: rotate -> 3 x [FPS, ball query, group, SA-MLP, max]
+-> conv6 -> VQ -> scatter  (SURVEY.md §8a rows a1-a8).
+
+Host orchestration only; all arithmetic is in libpfpp_hip.so.  Activations are kept
+channels-last ([rows, C]) so every 1x1 convolution is one GEMM with the BatchNorm /
+ReLU / max-over-nsample epilogue fused in.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .packing import fold_conv_bn, pack_sa_first
+
+# (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
+SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
+
+
+def pack_encoder(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, torch.Tensor]:
+    """sd: live tensors of a VQVAE module keyed by state_dict names -> packed kernel weights"""
+    out: Dict[str, torch.Tensor] = {}
+    for name, _, _, _ in SA_LEVELS:
+        for i in range(3):
+            p = f"{prefix}pn2.{name}"
+            w, s, t = fold_conv_bn(
+                sd[f"{p}.mlp_convs.{i}.weight"], sd[f"{p}.mlp_convs.{i}.bias"],
+                sd[f"{p}.mlp_bns.{i}.weight"], sd[f"{p}.mlp_bns.{i}.bias"],
+                sd[f"{p}.mlp_bns.{i}.running_mean"], sd[f"{p}.mlp_bns.{i}.running_var"],
+            )
+            if i == 0:
+                w = pack_sa_first(w, w.shape[1] - 3)
+            out[f"{name}.w{i}"] = w.contiguous()
+            out[f"{name}.s{i}"] = s
+            out[f"{name}.t{i}"] = t
+    w6 = sd[f"{prefix}pn2.conv6.weight"]
+    out["conv6.w"] = w6.reshape(w6.shape[0], -1).contiguous()
+    out["conv6.b"] = sd[f"{prefix}pn2.conv6.bias"].contiguous()
+    out["codebook"] = sd[f"{prefix}vector_quantization.embedding.weight"].contiguous()
+    return out
+
+
+def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz: torch.Tensor,
+                    feats: Optional[torch.Tensor], capture: Optional[dict] = None):
+    """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3]"""
+    F = xyz.shape[0]
+    fps_idx, new_xyz = ops.fps(xyz, npoint)
+    ball = ops.ball_query(xyz, new_xyz, radius, nsample)
+    A = ops.group_gather(xyz, new_xyz, feats, ball)
+    h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+    del A
+    h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu")
+    h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
+    new_feats = h.view(F, npoint, -1)
+    if capture is not None:
+        capture[f"{name}.fps_idx"] = fps_idx
+        capture[f"{name}.ball_idx"] = ball
+        capture[f"{name}.new_xyz"] = new_xyz
+        capture[f"{name}.new_points"] = new_feats
+    return new_xyz, new_feats
+
+
+def pn2_encode(pk, pts: torch.Tensor, num_point: int = 25, capture: Optional[dict] = None):
+    """pts [F,N,3] (already rotated) -> z_e [F,L,64], xyz [F,L,3]   (pn2.py:57-68)"""
+    xyz, feats = pts, None
+    for name, npoint, radius, nsample in SA_LEVELS:
+        xyz, feats = set_abstraction(pk, name, npoint or num_point, radius, nsample, xyz, feats, capture)
+    F, L, C3 = feats.shape
+    z_e = ops.linear(feats.view(F * L, C3), pk["conv6.w"], pk["conv6.b"]).view(F, L, -1)
+    return z_e, xyz
+
+
+def encode_valid(pk, pts: torch.Tensor, num_point: int = 25, max_frag: int = 2048):
+    """VQVAE.encode on a dense list of fragments [F,N,3] -> {"z_q": [F,L,64], "xyz": [F,L,3]}"""
+    F = pts.shape[0]
+    slot = torch.arange(F, dtype=torch.int32, device=pts.device)
+    z_q = torch.empty((F, num_point, pk["conv6.w"].shape[0]), dtype=torch.float32, device=pts.device)
+    xyz_out = torch.empty((F, num_point, 3), dtype=torch.float32, device=pts.device)
+    for f0 in range(0, F, max_frag):
+        f1 = min(F, f0 + max_frag)
+        z_e, xyz = pn2_encode(pk, pts[f0:f1].contiguous(), num_point)
+        ops.vq_encode(z_e, pk["codebook"], slot[: f1 - f0].contiguous(), f1 - f0, z_q=z_q[f0:f1])
+        xyz_out[f0:f1] = xyz
+    return {"z_q": z_q, "xyz": xyz_out}
+
+
+def extract_features(pk, part_pcs: torch.Tensor, pose: torch.Tensor, slot: torch.Tensor,
+                     num_point: int = 25, max_frag: int = 2048, capture: Optional[dict] = None):
+    """Denoiser._extract_features (denoiser.py:66-77): part_pcs [B,P,N,3], pose [B,P,7],
+    slot = flattened indices of the valid fragments (int32, ascending)
+    -> latent [B,P,L,64], xyz [B,P,L,3] with zeros in the padded slots."""
+    B, P, N, _ = part_pcs.shape
+    n_slots = B * P
+    dev = part_pcs.device
+    latent = torch.zeros((n_slots, num_point, pk["conv6.w"].shape[0]), dtype=torch.float32, device=dev)
+    xyz_out = torch.zeros((n_slots, num_point, 3), dtype=torch.float32, device=dev)
+    pcs_flat = part_pcs.view(n_slots, N, 3)
+    pose_flat = pose.reshape(n_slots, 7).contiguous()
+    F = slot.numel()
+    for f0 in range(0, F, max_frag):
+        sl = slot[f0:f0 + max_frag].contiguous()
+        rot = ops.se3_rotate_gather(pcs_flat, pose_flat, sl)
+        if capture is not None:
+            capture["rotated"] = rot
+        z_e, xyz = pn2_encode(pk, rot, num_point, capture)
+        if capture is not None:
+            capture["z_e"] = z_e
+        ops.vq_encode(z_e, pk["codebook"], sl, n_slots, z_q=latent)
+        ops.scatter_rows(xyz, sl, n_slots, out=xyz_out)
+    return latent.view(B, P, num_point, -1), xyz_out.view(B, P, num_point, 3)

@@ -1,0 +1,350 @@
+"""Tensor-level wrappers over the C ABI (include/pfpp.h).
+
+Each wrapper validates device / dtype / contiguity / shape on the host (the C side
+only sees raw pointers), allocates the outputs with torch's caching allocator and
+enqueues the kernel on torch's current HIP stream.  Nothing here computes on the
+CPU: tensors that are not on a CUDA(HIP) device are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT, GemmArgs, check
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# --------------------------------------------------------------------------- SE(3)
+def se3_rotate_gather(part_pcs: torch.Tensor, pose: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
+    """part_pcs [n_slots,N,3], pose [n_slots,7], slot int32 [F] -> [F,N,3] (include/pfpp.h a1)"""
+    _chk(part_pcs, torch.float32, "part_pcs"); _chk(pose, torch.float32, "pose"); _chk(slot, torch.int32, "slot")
+    n_slots, N, three = part_pcs.shape
+    if three != 3 or pose.shape != (n_slots, 7):
+        raise ValueError("se3_rotate_gather: part_pcs [n,N,3] and pose [n,7] expected")
+    F = slot.numel()
+    out = torch.empty((F, N, 3), dtype=torch.float32, device=part_pcs.device)
+    check(_lib.load().pfpp_se3_rotate_gather(_ptr(part_pcs), _ptr(pose), _ptr(slot), _ptr(out), F, N, _stream()),
+          "pfpp_se3_rotate_gather")
+    return out
+
+
+def pose_apply(pts: torch.Tensor, pose: torch.Tensor, scale: Optional[torch.Tensor] = None,
+               normalise: bool = True) -> torch.Tensor:
+    """pts [n,N,3], pose [n,7] (t,q) -> R(q)(scale*p)+t  (include/pfpp.h a19)"""
+    _chk(pts, torch.float32, "pts"); _chk(pose, torch.float32, "pose")
+    n, N, _ = pts.shape
+    if pose.shape != (n, 7):
+        raise ValueError("pose_apply: pose must be [n,7]")
+    if scale is not None:
+        _chk(scale, torch.float32, "scale")
+        if scale.numel() != n:
+            raise ValueError("pose_apply: scale must have n elements")
+    out = torch.empty_like(pts)
+    check(_lib.load().pfpp_pose_apply(_ptr(pts), _ptr(pose), _ptr(scale), _ptr(out), n, N, int(normalise), _stream()),
+          "pfpp_pose_apply")
+    return out
+
+
+# --------------------------------------------------------------------------- PointNet++
+def fps(xyz: torch.Tensor, npoint: int):
+    """xyz [F,N,3] -> (idx int32 [F,S], new_xyz [F,S,3])  (include/pfpp.h a2)"""
+    _chk(xyz, torch.float32, "xyz")
+    F, N, three = xyz.shape
+    if three != 3:
+        raise ValueError("fps: xyz must be [F,N,3]")
+    if not (1 <= npoint <= N):
+        raise ValueError(f"fps: need 1 <= npoint <= N (npoint={npoint}, N={N})")
+    idx = torch.empty((F, npoint), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((F, npoint, 3), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().pfpp_fps(_ptr(xyz), _ptr(idx), _ptr(new_xyz), F, N, npoint, _stream()), "pfpp_fps")
+    return idx, new_xyz
+
+
+def ball_query(xyz: torch.Tensor, new_xyz: torch.Tensor, radius: float, nsample: int) -> torch.Tensor:
+    """-> idx int32 [F,S,nsample]  (include/pfpp.h a3).  r^2 is rounded to fp32 exactly as the
+    reference's `sqrdists > radius ** 2` comparison does (python double -> float32 scalar)."""
+    _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz")
+    F, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    if new_xyz.shape[0] != F:
+        raise ValueError("ball_query: batch mismatch")
+    r2 = torch.tensor(radius ** 2, dtype=torch.float64).to(torch.float32).item()
+    idx = torch.empty((F, S, nsample), dtype=torch.int32, device=xyz.device)
+    # grid.y carries the fragment index: chunk very large batches
+    step = 65535
+    lib = _lib.load()
+    for f0 in range(0, F, step):
+        f1 = min(F, f0 + step)
+        check(lib.pfpp_ball_query(_ptr(xyz[f0:f1]), _ptr(new_xyz[f0:f1]), _ptr(idx[f0:f1]), f1 - f0, N, S,
+                                  nsample, r2, _stream()), "pfpp_ball_query")
+    return idx
+
+
+def group_gather(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor],
+                 idx: torch.Tensor) -> torch.Tensor:
+    """-> A operand [F*S*ns, D+4] = [feats | rel_xyz | 0]  (include/pfpp.h a4)"""
+    _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    D = 0
+    if feats is not None:
+        _chk(feats, torch.float32, "feats")
+        if feats.shape[:2] != (F, N):
+            raise ValueError("group_gather: feats must be [F,N,D]")
+        D = feats.shape[2]
+    ldo = D + 4
+    out = torch.empty((F * S * ns, ldo), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().pfpp_group_gather(_ptr(xyz), _ptr(new_xyz), _ptr(feats), _ptr(idx), _ptr(out), F, N, S, ns, D,
+                                        ldo, _stream()), "pfpp_group_gather")
+    return out
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
+         out: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+         shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         ldr: int = 0, act: str = "none", pool: int = 0, w_kmajor: bool = False,
+         batch: int = 1, zdiv: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sV=(0, 0), alpha: float = 1.0,
+         a_off: int = 0, w_off: int = 0, c_off: int = 0) -> torch.Tensor:
+    """Raw pfpp_gemm call.  A/W/out are base tensors; *_off are element offsets into them
+    (used to address q/k/v slices of a packed projection without copies)."""
+    for t, nm in ((A, "A"), (W, "W")):
+        _chk(t, torch.float32, nm)
+    n_out_cols = N // 2 if act == "geglu" else N
+    if out is None:
+        rows = M // pool if pool else M
+        if ldc is None:
+            ldc = n_out_cols
+        out = torch.empty((batch, rows, ldc) if batch > 1 else (rows, ldc), dtype=torch.float32, device=A.device)
+        if batch > 1 and sC == (0, 0):
+            sC = (rows * ldc * zdiv, rows * ldc) if zdiv > 1 else (rows * ldc, 0)
+    else:
+        _chk(out, torch.float32, "out")
+        if ldc is None:
+            ldc = out.shape[-1]
+    for t, nm in ((bias, "bias"), (scale, "scale"), (shift, "shift"), (residual, "residual")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+    es = 4
+    args = GemmArgs()
+    args.A = A.data_ptr() + a_off * es
+    args.W = W.data_ptr() + w_off * es
+    args.C = out.data_ptr() + c_off * es
+    args.bias = 0 if bias is None else bias.data_ptr()
+    args.scale = 0 if scale is None else scale.data_ptr()
+    args.shift = 0 if shift is None else shift.data_ptr()
+    args.residual = 0 if residual is None else residual.data_ptr() + c_off * es
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldw, args.ldc, args.ldr = lda, ldw, ldc, ldr
+    args.w_kmajor = int(w_kmajor)
+    args.act = ACT[act]
+    args.pool = pool
+    args.batch, args.zdiv = batch, zdiv
+    args.sA0, args.sA1 = sA
+    args.sW0, args.sW1 = sW
+    args.sC0, args.sC1 = sC
+    args.sV0, args.sV1 = sV
+    args.alpha = alpha
+    check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: str = "none",
+           scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, pool: int = 0, K: Optional[int] = None) -> torch.Tensor:
+    """y = epilogue(x @ w^T): x [M, ldx] (first K columns used), w [N, ldw] packed with ldw % 4 == 0."""
+    M, ldx = x.shape
+    N, ldw = w.shape
+    if K is None:
+        K = min(ldx, ldw)
+    return gemm(x, w, M=M, N=N, K=K, lda=ldx, ldw=ldw, bias=bias, scale=scale, shift=shift,
+                residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool)
+
+
+# --------------------------------------------------------------------------- VQ
+def vq_encode(z_e: torch.Tensor, codebook: torch.Tensor, slot: torch.Tensor, n_slots: int,
+              z_q: Optional[torch.Tensor] = None, return_codes: bool = False):
+    """z_e [F, L, C] with C % 16 == 0 -> z_q scattered into zeros [n_slots, L, C]  (include/pfpp.h a7/a8)"""
+    _chk(z_e, torch.float32, "z_e"); _chk(codebook, torch.float32, "codebook"); _chk(slot, torch.int32, "slot")
+    F, L, Cc = z_e.shape
+    n_codes, dim = codebook.shape
+    if Cc % dim != 0:
+        raise ValueError("vq_encode: latent width must be a multiple of the code width")
+    sub = L * (Cc // dim)
+    if z_q is None:
+        z_q = torch.zeros((n_slots, L, Cc), dtype=torch.float32, device=z_e.device)
+    codes = torch.empty((F, sub), dtype=torch.int32, device=z_e.device) if return_codes else None
+    check(_lib.load().pfpp_vq_encode(_ptr(z_e), _ptr(codebook), _ptr(slot), _ptr(z_q), _ptr(codes), F, sub, dim,
+                                     n_codes, _stream()), "pfpp_vq_encode")
+    return (z_q, codes) if return_codes else z_q
+
+
+def scatter_rows(src: torch.Tensor, slot: torch.Tensor, n_slots: int,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[slot[f]] = src[f]; `out` defaults to zeros [n_slots, ...]  (denoiser.py:72-76)"""
+    _chk(src, torch.float32, "src"); _chk(slot, torch.int32, "slot")
+    F = src.shape[0]
+    row = src[0].numel() if F else 0
+    if out is None:
+        out = torch.zeros((n_slots, *src.shape[1:]), dtype=torch.float32, device=src.device)
+    else:
+        _chk(out, torch.float32, "out")
+    if F:
+        check(_lib.load().pfpp_scatter_rows(_ptr(src), _ptr(slot), _ptr(out), F, row, _stream()), "pfpp_scatter_rows")
+    return out
+
+
+# --------------------------------------------------------------------------- transformer pieces
+def token_features(latent, xyz, scale, x):
+    """latent [n,L,64], xyz [n,L,3], scale [n], x [n,7] -> shape_feat [n*L,148], pose_feat [n,148]"""
+    for t, nm in ((latent, "latent"), (xyz, "xyz"), (scale, "scale"), (x, "x")):
+        _chk(t, torch.float32, nm)
+    n, L, c = latent.shape
+    if c != 64 or xyz.shape != (n, L, 3) or scale.numel() != n or x.shape != (n, 7):
+        raise ValueError("token_features: shape mismatch")
+    sf = torch.empty((n * L, 148), dtype=torch.float32, device=latent.device)
+    pf = torch.empty((n, 148), dtype=torch.float32, device=latent.device)
+    check(_lib.load().pfpp_token_features(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(sf), _ptr(pf), n, L,
+                                          _stream()), "pfpp_token_features")
+    return sf, pf
+
+
+def token_combine(shape_emb, x_emb, ref_emb, ref_part_u8, pe, B, P, L):
+    for t, nm in ((shape_emb, "shape_emb"), (x_emb, "x_emb"), (ref_emb, "ref_emb"), (pe, "pe")):
+        _chk(t, torch.float32, nm)
+    _chk(ref_part_u8, torch.uint8, "ref_part")
+    Cc = shape_emb.shape[-1]
+    tok = torch.empty((B * P * L, Cc), dtype=torch.float32, device=shape_emb.device)
+    check(_lib.load().pfpp_token_combine(_ptr(shape_emb), _ptr(x_emb), _ptr(ref_emb), _ptr(ref_part_u8), _ptr(pe),
+                                         _ptr(tok), B, P, L, Cc, _stream()), "pfpp_token_combine")
+    return tok
+
+
+def silu_embed(tables: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """tables [n_tab, n_emb, C], t int64 [B] -> silu(tables[:, t]) [n_tab, B, C]"""
+    _chk(tables, torch.float32, "tables"); _chk(t, torch.int64, "t")
+    n_tab, n_emb, Cc = tables.shape
+    B = t.numel()
+    out = torch.empty((n_tab, B, Cc), dtype=torch.float32, device=tables.device)
+    check(_lib.load().pfpp_silu_embed(_ptr(tables), _ptr(t), _ptr(out), n_tab, n_emb, B, Cc, _stream()),
+          "pfpp_silu_embed")
+    return out
+
+
+def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+              beta: Optional[torch.Tensor] = None, rows_per_batch: int = 1, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [rows, C]; mod [B, 2C] (AdaLN scale|shift) or gamma/beta [C]"""
+    _chk(x, torch.float32, "x")
+    rows, Cc = x.shape
+    ld_mod = 0
+    if mod is not None:
+        _chk(mod, torch.float32, "mod")
+        ld_mod = mod.shape[-1]
+        if ld_mod != 2 * Cc:
+            raise ValueError("layernorm: mod must be [B, 2C]")
+    if gamma is not None:
+        _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().pfpp_layernorm(_ptr(x), _ptr(out), _ptr(mod), ld_mod, _ptr(gamma), _ptr(beta), rows, Cc,
+                                     rows_per_batch, eps, _stream()), "pfpp_layernorm")
+    return out
+
+
+def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float) -> torch.Tensor:
+    _chk(qkv, torch.float32, "qkv")
+    if qkv.shape != (n_frag * L, 3 * H * dh):
+        raise ValueError("attn_blockdiag: qkv must be [n_frag*L, 3*H*dh]")
+    out = torch.empty((n_frag * L, H * dh), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().pfpp_attn_blockdiag(_ptr(qkv), _ptr(out), n_frag, L, H, dh, scale, _stream()),
+          "pfpp_attn_blockdiag")
+    return out
+
+
+def softmax_rows(S: torch.Tensor, key_valid_u8: Optional[torch.Tensor], rows_per_batch: int, T: int,
+                 scale: float) -> torch.Tensor:
+    """in-place masked softmax over the first T columns of S [..., ld]"""
+    _chk(S, torch.float32, "S")
+    ld = S.shape[-1]
+    rows = S.numel() // ld
+    if key_valid_u8 is not None:
+        _chk(key_valid_u8, torch.uint8, "key_valid")
+    check(_lib.load().pfpp_softmax_rows(_ptr(S), _ptr(key_valid_u8), rows, rows_per_batch, T, ld, scale, _stream()),
+          "pfpp_softmax_rows")
+    return S
+
+
+def mean_pool(x: torch.Tensor, n: int, L: int) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    Cc = x.shape[-1]
+    out = torch.empty((n, Cc), dtype=torch.float32, device=x.device)
+    check(_lib.load().pfpp_mean_pool(_ptr(x), _ptr(out), n, L, Cc, _stream()), "pfpp_mean_pool")
+    return out
+
+
+def ddpm_step(x, eps, noise, ref_part_u8, reference, coef) -> torch.Tensor:
+    """coef = (c_eps, c_div, c_x0, c_x, c_noise) python floats (already fp32-rounded)"""
+    _chk(x, torch.float32, "x"); _chk(eps, torch.float32, "eps")
+    if noise is not None:
+        _chk(noise, torch.float32, "noise")
+    if ref_part_u8 is not None:
+        _chk(ref_part_u8, torch.uint8, "ref_part"); _chk(reference, torch.float32, "reference")
+    n = x.numel() // 7
+    out = torch.empty_like(x)
+    check(_lib.load().pfpp_ddpm_step(_ptr(x), _ptr(eps), _ptr(noise), _ptr(ref_part_u8), _ptr(reference), _ptr(out),
+                                     n, *[float(c) for c in coef], _stream()), "pfpp_ddpm_step")
+    return out
+
+
+def add_noise(x0, noise, sqrt_ab, sqrt_1mab) -> torch.Tensor:
+    for t, nm in ((x0, "x0"), (noise, "noise"), (sqrt_ab, "sqrt_ab"), (sqrt_1mab, "sqrt_1mab")):
+        _chk(t, torch.float32, nm)
+    B = x0.shape[0]
+    out = torch.empty_like(x0)
+    check(_lib.load().pfpp_add_noise(_ptr(x0), _ptr(noise), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(out), B,
+                                     x0.numel() // B, _stream()), "pfpp_add_noise")
+    return out
+
+
+def verifier_embed(feat_emb, edge_idx, pe) -> torch.Tensor:
+    _chk(feat_emb, torch.float32, "feat_emb"); _chk(edge_idx, torch.int64, "edge_indices"); _chk(pe, torch.float32, "pe")
+    n, Cc = feat_emb.shape
+    tok = torch.empty_like(feat_emb)
+    check(_lib.load().pfpp_verifier_embed(_ptr(feat_emb), _ptr(edge_idx), _ptr(pe), _ptr(tok), n, Cc, pe.shape[0],
+                                          _stream()), "pfpp_verifier_embed")
+    return tok
+
+
+def pose_compose(pose, pivot, init_pose=None, has_init=None) -> torch.Tensor:
+    _chk(pose, torch.float32, "pose"); _chk(pivot, torch.int32, "pivot")
+    n = pivot.numel()
+    if init_pose is not None:
+        _chk(init_pose, torch.float32, "init_pose"); _chk(has_init, torch.uint8, "has_init")
+    out = torch.empty((n, 7), dtype=torch.float32, device=pose.device)
+    check(_lib.load().pfpp_pose_compose(_ptr(pose), _ptr(pivot), _ptr(init_pose), _ptr(has_init), _ptr(out), n,
+                                        _stream()), "pfpp_pose_compose")
+    return out

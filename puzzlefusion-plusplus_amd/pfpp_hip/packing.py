@@ -1,0 +1,82 @@
+"""Host-side weight packing for the HIP kernels.
+
+The modules keep the reference's parameter names and shapes (so published state_dicts
+load unchanged); the kernels read re-laid-out copies built here.  Copies are cached by the
+owning module and rebuilt when a parameter changes (see PackCache).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pad_k(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    """[N,K] -> [N, round_up(K)] zero padded (16-byte aligned rows for the GEMM loader)"""
+    n, k = w.shape
+    kp = round_up(k, mult)
+    if kp == k:
+        return w.contiguous()
+    out = w.new_zeros((n, kp))
+    out[:, :k] = w
+    return out
+
+
+def fold_conv_bn(conv_w, conv_b, bn_w, bn_b, mean, var, eps: float = 1e-5):
+    """eval-mode BatchNorm folded into a per-channel scale/shift applied to the raw GEMM
+    accumulator:  bn(conv(x)) = acc*s + ((b - mean)*s + beta),  s = gamma / sqrt(var + eps)
+    (utils/pn2_utils.py:210-212)."""
+    w = conv_w.reshape(conv_w.shape[0], -1)
+    s = bn_w / torch.sqrt(var + eps)
+    t = (conv_b - mean) * s + bn_b
+    return w, s.contiguous(), t.contiguous()
+
+
+def pack_sa_first(w: torch.Tensor, d_feat: int) -> torch.Tensor:
+    """first conv of a set-abstraction level: input channels are [xyz(3) | feats(D)] in the
+    reference (utils/pn2_utils.py:146); the grouping kernel emits [feats(D) | xyz(3) | 0]."""
+    o, k = w.shape
+    assert k == d_feat + 3
+    out = w.new_zeros((o, d_feat + 4))
+    out[:, :d_feat] = w[:, 3:]
+    out[:, d_feat:d_feat + 3] = w[:, :3]
+    return out
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GEGLU projection [2I, C] (value rows then gate rows, diffusers `chunk(2)`) re-ordered in
+    blocks of 64 rows = 32 value rows followed by their 32 gate rows, so that one wave's two
+    MFMA column tiles hold a value and its gate in the same lane (csrc/gemm.hip)."""
+    two_i, c = w.shape
+    inner = two_i // 2
+    assert inner % 32 == 0
+    nb = inner // 32
+    wv = w[:inner].reshape(nb, 32, c)
+    wg = w[inner:].reshape(nb, 32, c)
+    wp = torch.stack((wv, wg), dim=1).reshape(two_i, c).contiguous()
+    bp = torch.stack((b[:inner].reshape(nb, 32), b[inner:].reshape(nb, 32)), dim=1).reshape(two_i).contiguous()
+    return wp, bp
+
+
+class PackCache:
+    """rebuilds packed weights when any source tensor was modified in place or replaced"""
+
+    def __init__(self):
+        self._key = None
+        self.packed: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def _fingerprint(tensors: Iterable[torch.Tensor]):
+        return tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+
+    def get(self, tensors, builder):
+        key = self._fingerprint(tensors)
+        if key != self._key:
+            with torch.no_grad():
+                self.packed = builder()
+            self._key = key
+        return self.packed

@@ -1,0 +1,62 @@
+"""VerifierTransformer forward on the HIP kernels.
+
+Post-norm nn.TransformerEncoderLayer math (verifier/model/modules/verifier_transformer.py:17-30):
+x = LN1(x + SA(x)); x = LN2(x + W2 gelu(W1 x)), key-padding mask on the attention keys.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as Fnn
+
+from . import ops
+from .denoiser import dense_attention
+from .packing import pad_k
+
+
+def pack_verifier(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, torch.Tensor]:
+    pk: Dict[str, torch.Tensor] = {}
+    pk["feat.w"] = pad_k(sd["edge_feature_emb.weight"])          # [C, 8]
+    pk["feat.b"] = sd["edge_feature_emb.bias"].contiguous()
+    pk["pe"] = sd["edge_indices_pe.pe"][0].contiguous()          # [max_len, C/2]
+    for i in range(num_layers):
+        p = f"transformer_encoder.layers.{i}"
+        for k_src, k_dst in (
+            ("self_attn.in_proj_weight", "wqkv"), ("self_attn.in_proj_bias", "bqkv"),
+            ("self_attn.out_proj.weight", "wo"), ("self_attn.out_proj.bias", "bo"),
+            ("linear1.weight", "w1"), ("linear1.bias", "b1"), ("linear2.weight", "w2"), ("linear2.bias", "b2"),
+            ("norm1.weight", "g1"), ("norm1.bias", "be1"), ("norm2.weight", "g2"), ("norm2.bias", "be2"),
+        ):
+            pk[f"{i}.{k_dst}"] = sd[f"{p}.{k_src}"].contiguous()
+    pk["out.w"] = sd["mlp_out.weight"].contiguous()
+    pk["out.b"] = sd["mlp_out.bias"].contiguous()
+    return pk
+
+
+def verifier_forward(pk, edge_features: torch.Tensor, edge_indices: torch.Tensor, mask: torch.Tensor, *,
+                     num_layers: int, num_heads: int) -> torch.Tensor:
+    """edge_features [B,E,7], edge_indices int64 [B,E,2], mask [B,E] -> logits [B,E,1]"""
+    B, E, nf = edge_features.shape
+    C = pk["feat.b"].numel()
+    dh = C // num_heads
+    M = B * E
+    kp = pk["feat.w"].shape[1]
+    feats = Fnn.pad(edge_features.reshape(M, nf).to(torch.float32), (0, kp - nf)).contiguous()  # 7 -> 8 columns
+    fe = ops.linear(feats, pk["feat.w"], pk["feat.b"])
+    h = ops.verifier_embed(fe, edge_indices.reshape(M, 2).to(torch.int64).contiguous(), pk["pe"])
+    key_valid = mask.reshape(B, E).to(torch.bool).to(torch.uint8).contiguous()
+    scale = 1.0 / math.sqrt(dh)
+    att = torch.empty_like(h)
+    for i in range(num_layers):
+        qkv = ops.linear(h, pk[f"{i}.wqkv"], pk[f"{i}.bqkv"])
+        dense_attention(qkv, B, E, num_heads, dh, key_valid, scale, out=att)
+        ops.gemm(att, pk[f"{i}.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C, bias=pk[f"{i}.bo"], residual=h, ldr=C)
+        ops.layernorm(h, gamma=pk[f"{i}.g1"], beta=pk[f"{i}.be1"], out=h)
+        f = ops.linear(h, pk[f"{i}.w1"], pk[f"{i}.b1"], act="gelu")
+        ops.gemm(f, pk[f"{i}.w2"], M=M, N=C, K=f.shape[1], lda=f.shape[1], ldw=f.shape[1], out=h, ldc=C,
+                 bias=pk[f"{i}.b2"], residual=h, ldr=C)
+        ops.layernorm(h, gamma=pk[f"{i}.g2"], beta=pk[f"{i}.be2"], out=h)
+    out = ops.linear(h, pk["out.w"], pk["out.b"])
+    return out.view(B, E, 1)
