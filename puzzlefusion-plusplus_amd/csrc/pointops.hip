@@ -16,23 +16,23 @@ struct Quat { float w, x, y, z; };
 // quaternion_raw_multiply(a, b): left-to-right evaluation of each 4-term sum,
 // every product and every sum rounded to fp32 on its own (torch elementwise ops).
 __device__ __forceinline__ Quat quat_raw_mul(const Quat a, const Quat b) {
-  Quat o;
-  o.w = __fsub_rn(__fsub_rn(__fsub_rn(__fmul_rn(a.w, b.w), __fmul_rn(a.x, b.x)), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z));
-  o.x = __fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.w, b.x), __fmul_rn(a.x, b.w)), __fmul_rn(a.y, b.z)), __fmul_rn(a.z, b.y));
-  o.y = __fadd_rn(__fadd_rn(__fsub_rn(__fmul_rn(a.w, b.y), __fmul_rn(a.x, b.z)), __fmul_rn(a.y, b.w)), __fmul_rn(a.z, b.x));
-  o.z = __fadd_rn(__fsub_rn(__fadd_rn(__fmul_rn(a.w, b.z), __fmul_rn(a.x, b.y)), __fmul_rn(a.y, b.x)), __fmul_rn(a.z, b.w));
+  Quat o;  // -ffp-contract=off: every product and sum below rounds on its own
+  o.w = ((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z;
+  o.x = ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y;
+  o.y = ((a.w * b.y - a.x * b.z) + a.y * b.w) + a.z * b.x;
+  o.z = ((a.w * b.z + a.x * b.y) - a.y * b.x) + a.z * b.w;
   return o;
 }
 
 // q / ||q||, ||q|| = sqrt(((w*w + x*x) + y*y) + z*z)  (torch.norm over 4 values)
 __device__ __forceinline__ Quat quat_normalise(const Quat q) {
-  const float n2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(q.w, q.w), __fmul_rn(q.x, q.x)), __fmul_rn(q.y, q.y)), __fmul_rn(q.z, q.z));
-  const float n = __fsqrt_rn(n2);
+  const float n2 = ((q.w * q.w + q.x * q.x) + q.y * q.y) + q.z * q.z;
+  const float n = sqrtf(n2);   // correctly rounded (no -ffast-math, default hipcc sqrt/div)
   Quat o;
-  o.w = __fdiv_rn(q.w, n);
-  o.x = __fdiv_rn(q.x, n);
-  o.y = __fdiv_rn(q.y, n);
-  o.z = __fdiv_rn(q.z, n);
+  o.w = q.w / n;
+  o.x = q.x / n;
+  o.y = q.y / n;
+  o.z = q.z / n;
   return o;
 }
 
@@ -86,14 +86,14 @@ __global__ __launch_bounds__(256) void pose_apply_kernel(
   float x = p[0], y = p[1], z = p[2];
   if (scale) {
     const float sc = scale[f];
-    x = __fmul_rn(x, sc); y = __fmul_rn(y, sc); z = __fmul_rn(z, sc);
+    x = x * sc; y = y * sc; z = z * sc;
   }
   float ox, oy, oz;
   quat_apply(q, x, y, z, ox, oy, oz);
   float* o = out + gid * 3;
-  o[0] = __fadd_rn(ox, ps[0]);
-  o[1] = __fadd_rn(oy, ps[1]);
-  o[2] = __fadd_rn(oz, ps[2]);
+  o[0] = ox + ps[0];
+  o[1] = oy + ps[1];
+  o[2] = oz + ps[2];
 }
 
 // ---------------------------------------------------------------------------

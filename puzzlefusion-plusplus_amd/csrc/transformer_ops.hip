@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(
     v = reference[gid];
   } else {
     const float xv = x[gid];
-    const float x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c_eps, eps[gid])), c_div);
+    const float x0 = (xv - c_eps * eps[gid]) / c_div;  // -ffp-contract=off; IEEE division
     v = __fadd_rn(__fmul_rn(c_x0, x0), __fmul_rn(c_x, xv));
     if (noise) v = __fadd_rn(v, __fmul_rn(c_noise, noise[gid]));
   }

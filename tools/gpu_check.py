@@ -95,6 +95,9 @@ def main():
     slot = torch.nonzero(valid.flatten()).flatten().to(torch.int32)
     rot_ref = O.apply_rots(batch["part_pcs"], x)[valid]
     rot = ops.se3_rotate_gather(batch["part_pcs"].view(B * P, N, 3).to(dev), x.view(B * P, 7).to(dev), slot.to(dev))
+    rot_ref_c = O.apply_rots_c(batch["part_pcs"], x)[valid]
+    print(f"      (oracle torch vs oracle C on this host: {(rot_ref != rot_ref_c).sum().item()} differing values)")
+    report("se3_rotate_gather bit-exact vs oracle C", torch.equal(rot.cpu(), rot_ref_c), f"maxdiff {maxdiff(rot, rot_ref_c):.2e}")
     report("se3_rotate_gather bit-exact", torch.equal(rot.cpu(), rot_ref), f"maxdiff {maxdiff(rot, rot_ref):.2e} F={slot.numel()}")
 
     for Npts, S in ((1000, 256), (1024, 256), (512, 256), (256, 128), (128, 25), (2048, 256), (300, 77)):
