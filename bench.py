@@ -1,0 +1,227 @@
+"""bench.py — denoiser DDPM-step throughput on synthetic Breaking-Bad-shaped puzzles.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one DDPM sampler step of the hot path over one batch resident in HBM:
+rotate every fragment by its current noisy pose -> PointNet++/VQ-VAE encode the valid fragments ->
+DenoiserTransformer -> ancestral scheduler step + reference re-pin
+(Denoiser.validation_step loop body, puzzlefusion_plusplus/denoiser/model/denoiser.py:172-185).
+Workload = BASELINE.json configs[1] shape on every GPU: 32 puzzles x 20 fragment slots x 1024 points,
+valid-fragment counts from SURVEY.md §8d's distribution.  N > 1: one process per GPU
+(torch.distributed / RCCL only for the barrier and the max-over-ranks clock): puzzles are
+independent, so ranks hold different puzzles and exchange nothing on the data path (weak scaling).
+
+Prints ONE JSON line (rank 0) with the extra objects:
+  roofline     — dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs of its launches / their
+                 HIP-event durations, against the 157.3 TFLOP/s dense fp32 matrix peak
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host on
+                 BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points), bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="puzzles per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--parts", type=int, default=None, help="fix the number of valid fragments per puzzle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class SamplerWorkload:
+    """device-resident state of the sampler loop for one batch of puzzles"""
+
+    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device):
+        from pfpp_hip import config, synthetic
+        from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+        torch.manual_seed(1234)
+        self.model = Denoiser(config.denoiser_config()).to(dev).eval()   # random-init weights of the reference architecture
+        with torch.no_grad():   # a codebook on the scale of the latents (a trained one is)
+            self.model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts)
+        self.data = {k: v.to(dev) for k, v in data.items()}
+        self.n_frag = int(self.data["part_valids"].sum().item())
+        gt = torch.cat([self.data["part_trans"], self.data["part_rots"]], dim=-1).float().contiguous()
+        self.ref = self.data["ref_part"]
+        self.reference = torch.zeros_like(gt)
+        self.reference[self.ref] = gt[self.ref]
+        g = torch.Generator(device=dev).manual_seed(99 + first_id)
+        self.x0 = torch.randn(gt.shape, device=dev, generator=g)
+        self.x0[self.ref] = self.reference[self.ref]
+        self.noise = [torch.randn(gt.shape, device=dev, generator=g) for _ in range(20)]
+        self.timesteps = self.model.noise_scheduler.timesteps.tolist()
+        self.ts_dev = {t: torch.full((batch,), t, dtype=torch.int64, device=dev) for t in self.timesteps}
+        self.x = self.x0.clone()
+        self.i = 0
+
+    @torch.no_grad()
+    def step(self):
+        m, d = self.model, self.data
+        k = self.i % len(self.timesteps)
+        if k == 0:
+            self.x = self.x0.clone()          # a new 20-step trajectory
+        t = self.timesteps[k]
+        latent, xyz = m._extract_features(d["part_pcs"], d["part_valids"], self.x)
+        eps = m.denoiser(self.x, self.ts_dev[t], latent, xyz, d["part_valids"], d["part_scale"], self.ref)
+        self.x = m.noise_scheduler.step(eps, t, self.x, variance_noise=self.noise[k], ref_part=self.ref,
+                                        reference=self.reference).prev_sample
+        self.i += 1
+
+
+def cpu_baseline(budget_s: float = 12.0, max_steps: int = 4):
+    """the CPU oracle on BASELINE.json configs[0]: 1 puzzle, 8 fragments x 512 points, sampler steps"""
+    from oracle import pfpp_oracle as O
+    from oracle import weights
+    from pfpp_hip import synthetic
+
+    enc_sd, den_sd = weights.vqvae_state_dict(), weights.denoiser_state_dict()
+    batch = synthetic.make_batch(0, 1, num_points=512, num_parts=8)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 20, 7, generator=g)
+    noises = [torch.randn(1, 20, 7, generator=g) for _ in range(20)]
+    sched = O.PiecewiseSchedule()
+    sched.set_timesteps(20)
+    ref = batch["ref_part"].bool()
+    ts_list = sched.timesteps.tolist()
+
+    def one(i, x):
+        t = ts_list[i % 20]
+        lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], x)
+        eps = O.denoiser_forward(den_sd, x, torch.full((1,), t, dtype=torch.int64), lat, xyz, batch["part_valids"],
+                                 batch["part_scale"], ref)
+        return sched.step(eps, t, x, noises[i % 20])
+
+    x = one(0, x)  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and (time.perf_counter() - t0) < budget_s:
+        x = one(n + 1, x)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": 8 * n / dt, "unit": "fragment*steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n} DDPM sampler steps of 1 puzzle, 8 fragments x 512 pts (BASELINE configs[0]), "
+                  f"{dt:.1f} s on {os.cpu_count()} logical CPUs, torch threads {torch.get_num_threads()}",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the only implementation of the path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from pfpp_hip import ops
+
+    wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev)
+    for _ in range(args.warmup):
+        wl.step()
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    frag_steps = float(wl.n_frag * args.steps)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+        ff = torch.tensor([frag_steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+        frag_steps = ff.item()
+
+    # ---- roofline of the dominant kernel: second, instrumented pass over the same steps ----------
+    roofline = None
+    if not args.no_roofline:
+        ops.GEMM_TRACE = []
+        for _ in range(args.steps):
+            wl.step()
+        torch.cuda.synchronize(dev)
+        trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        per = {}
+        for e0, e1, flops, name in trace:
+            ms = e0.elapsed_time(e1)
+            a = per.setdefault(name, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += ms; a[2] += 1
+        name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
+            "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
+            "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "denoiser DDPM-step throughput (fragment*steps/s)",
+            "value": round(frag_steps / elapsed, 2), "unit": "fragment*steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
+                            "scheduler step), BASELINE configs[1] shape, inference forward",
+                "puzzles_per_gpu": args.batch, "fragment_slots": 20, "points_per_fragment": args.points,
+                "valid_fragments_per_gpu": wl.n_frag, "puzzle_steps_per_s": round(args.batch * world * args.steps / elapsed, 2),
+                "weights": "random init, reference architecture (57.6M denoiser + 0.6M encoder params)",
+                "parallelism": f"independent puzzles x {world} GPU(s), no data-path collective",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,17 @@ def group_gather(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch
 
 
 # --------------------------------------------------------------------------- GEMM
+# When set to a list, every pfpp_gemm launch appends (start_event, end_event, flops, kernel_name):
+# bench.py uses it to time the dominant kernel with HIP events on the launch stream.
+GEMM_TRACE = None
+
+
+def gemm_kernel_name(N: int, act: str, w_kmajor: bool) -> str:
+    """which template instantiation csrc/gemm.hip dispatches to (mirror of pfpp_gemm's choice)"""
+    wide = N > 64 or act == "geglu"
+    return f"gemm_f32_mfma_kernel<2,{2 if wide else 1},{'true' if w_kmajor else 'false'}>"
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
          out: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
@@ -168,6 +179,13 @@ def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, 
     args.sC0, args.sC1 = sC
     args.sV0, args.sV1 = sV
     args.alpha = alpha
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
+        e1.record()
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, gemm_kernel_name(N, act, w_kmajor)))
+        return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
     return out
 

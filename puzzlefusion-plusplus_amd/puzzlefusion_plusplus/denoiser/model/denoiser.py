@@ -1,0 +1,104 @@
+"""Denoiser shell (drop-in for puzzlefusion_plusplus/denoiser/model/denoiser.py).
+
+Keeps the LightningModule surface of the reference (forward(data_dict) -> {pred_noise, gt_noise},
+_loss, training_step, validation_step, configure_optimizers; state_dict prefixes `denoiser.` and
+`encoder.`) and runs the hot path — rotate, encode, denoise, DDPM step — on the HIP kernels.
+Round-1 limits, raised loudly: no backward kernels yet (losses evaluate, gradients do not flow) and
+the encoder's BatchNorm runs in eval mode (the reference leaves it in train mode while "frozen",
+train_denoiser.py:33-35).  Evaluation metrics (evaluator.py) are a later row of the scope table.
+"""
+from __future__ import annotations
+
+import torch
+from torch.nn import functional as F
+
+from pfpp_hip.lightning_compat import LightningModule, instantiate
+from pfpp_hip.scheduler import PiecewiseScheduler
+from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+from puzzlefusion_plusplus.denoiser.model.modules.encoder import VQVAE
+
+
+class Denoiser(LightningModule):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.denoiser = DenoiserTransformer(cfg)
+        self.save_hyperparameters()
+        m = cfg.model
+        self.noise_scheduler = PiecewiseScheduler(
+            num_train_timesteps=m.DDPM_TRAIN_STEPS, beta_schedule=m.DDPM_BETA_SCHEDULE, prediction_type=m.PREDICT_TYPE,
+            beta_start=m.BETA_START, beta_end=m.BETA_END, clip_sample=False, timestep_spacing=m.timestep_spacing)
+        ae_name = getattr(cfg.ae, "ae_name", None)
+        self.encoder = instantiate(ae_name, cfg) if ae_name is not None else VQVAE(cfg)
+        self.num_points = m.num_point
+        self.num_channels = m.num_dim
+        self.noise_scheduler.set_timesteps(num_inference_steps=m.num_inference_steps)
+
+    # ------------------------------------------------------------------ hot path
+    def _extract_features(self, part_pcs, part_valids, noisy_trans_and_rots):
+        """rotate every fragment by its current noisy quaternion, encode the valid ones, scatter
+        into zero-padded [B,P,L,*] (denoiser.py:55-77) — one fused pipeline on the GPU"""
+        return self.encoder.extract_features(part_pcs, part_valids, noisy_trans_and_rots)
+
+    def forward(self, data_dict, noise=None, timesteps=None):
+        """training-style forward (denoiser.py:80-115); `noise` / `timesteps` may be injected"""
+        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
+        ref_part = data_dict["ref_part"]
+        B = gt.shape[0]
+        if noise is None:
+            noise = torch.randn(gt.shape, device=gt.device)
+        if timesteps is None:
+            timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (B,), device=gt.device).long()
+        noisy = self.noise_scheduler.add_noise(gt, noise, timesteps)
+        noisy[ref_part] = gt[ref_part]
+        latent, xyz = self._extract_features(data_dict["part_pcs"], data_dict["part_valids"], noisy)
+        pred = self.denoiser(noisy, timesteps, latent, xyz, data_dict["part_valids"], data_dict["part_scale"], ref_part)
+        return {"pred_noise": pred, "gt_noise": noise}
+
+    def _loss(self, data_dict, output_dict):
+        valids = data_dict["part_valids"].bool().clone()
+        valids[data_dict["ref_part"]] = False
+        return {"mse_loss": F.mse_loss(output_dict["pred_noise"][valids], output_dict["gt_noise"][valids])}
+
+    def training_step(self, data_dict, idx):
+        out = self(data_dict)
+        total = 0
+        for name, value in self._loss(data_dict, out).items():
+            total = total + value
+            self.log(f"train_loss/{name}", value, on_step=True, on_epoch=False)
+        self.log("train_loss/total_loss", total, on_step=True, on_epoch=False)
+        return total
+
+    @torch.no_grad()
+    def sample(self, data_dict, x_init=None, noises=None, record=None):
+        """the 20-step ancestral sampler of validation_step (denoiser.py:153-185); returns the final
+        [B,P,7] poses.  x_init / noises inject the random draws (parity tests)."""
+        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
+        ref_part = data_dict["ref_part"]
+        x = torch.randn(gt.shape, device=gt.device) if x_init is None else x_init.clone()
+        reference = torch.zeros_like(gt)
+        reference[ref_part] = gt[ref_part]
+        x[ref_part] = reference[ref_part]
+        B = x.shape[0]
+        for i, t in enumerate(self.noise_scheduler.timesteps.tolist()):
+            ts = torch.full((B,), t, dtype=torch.int64, device=x.device)
+            latent, xyz = self._extract_features(data_dict["part_pcs"], data_dict["part_valids"], x)
+            eps = self.denoiser(x, ts, latent, xyz, data_dict["part_valids"], data_dict["part_scale"], ref_part)
+            x = self.noise_scheduler.step(eps, t, x, variance_noise=None if noises is None else noises[i],
+                                          ref_part=ref_part, reference=reference).prev_sample
+            if record is not None:
+                record.append(x.clone())
+        return x
+
+    def validation_step(self, data_dict, idx):
+        out = self(data_dict)
+        for name, value in self._loss(data_dict, out).items():
+            self.log(f"val_loss/{name}", value, on_step=False, on_epoch=True)
+        return self.sample(data_dict)
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.AdamW(self.parameters(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08)
+        sched_cfg = getattr(self.cfg.model, "lr_scheduler", None)
+        if sched_cfg is None:
+            return optimizer
+        return {"optimizer": optimizer, "lr_scheduler": instantiate(sched_cfg, optimizer)}
