@@ -13,7 +13,12 @@ namespace pfpp {
 // thread-local "last error" text behind pfpp_last_error()
 void set_error(const char* fmt, ...);
 
-inline hipStream_t as_stream(pfpp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream right before launching: also drop any sticky error an
+// earlier, unrelated HIP call of the process left behind, so check_launch() reports only ours.
+inline hipStream_t as_stream(pfpp_stream_t s) {
+  (void)hipGetLastError();
+  return reinterpret_cast<hipStream_t>(s);
+}
 
 // after a launch: turn a launch failure into PFPP_EHIP
 int check_launch(const char* what);

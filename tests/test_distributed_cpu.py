@@ -1,0 +1,53 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of the benchmark = disjoint puzzle shards, no data-path
+collective, barrier + max-over-ranks clock + summed unit count."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank, world, port, out):
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip import synthetic
+    from pfpp_hip.parallel import max_over_ranks, shard_range, sum_over_ranks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard_range(6, rank, world)
+    data = synthetic.make_batch(a, b - a, num_points=64)          # each rank builds only its own puzzles
+    frags = float(data["part_valids"].sum())
+    dist.barrier()
+    clock = max_over_ranks(1.0 + rank)                            # slowest rank defines the time
+    total = sum_over_ranks(frags)
+    ids = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([a, b]))
+    if rank == 0:
+        out.put((clock, total, [t.tolist() for t in ids]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_clock():
+    from pfpp_hip import synthetic
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    clock, total, ids = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert clock == 2.0
+    assert ids == [[0, 3], [3, 6]]
+    ref = float(synthetic.make_batch(0, 6, num_points=64)["part_valids"].sum())
+    assert total == ref                                            # shards cover every puzzle exactly once

@@ -1,0 +1,330 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI wrappers, against the committed golden
+vectors (reference outputs), against the CPU oracle on seeded inputs, and — at BASELINE.json's full
+sizes — through size-independent properties.  Bars: bit-exact for indices (FPS, ball query, VQ
+codes, rotated coordinates); <= 1e-4 on predicted noise / logits / features (fp32 everywhere)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dsd(sd, dev):
+    return {k: v.to(dev) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------- a1 / a19
+def test_rotate_bit_exact_golden(golden, dev):
+    from pfpp_hip import ops
+
+    g = golden("rotate")
+    F = g["part_pcs"].shape[0]
+    slot = torch.arange(F, dtype=torch.int32, device=dev)
+    out = ops.se3_rotate_gather(T(g["part_pcs"]).to(dev), T(g["pose"]).to(dev), slot)
+    assert np.array_equal(out.cpu().numpy(), g["rotated"])
+    # gather semantics: arbitrary ascending subset of slots
+    sub = torch.tensor([F - 1, 0][::-1], dtype=torch.int32, device=dev)
+    out2 = ops.se3_rotate_gather(T(g["part_pcs"]).to(dev), T(g["pose"]).to(dev), sub)
+    assert np.array_equal(out2.cpu().numpy(), g["rotated"][[0, F - 1]])
+
+
+def test_pose_apply_and_compose_vs_oracle(dev, oracle_lib):
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(0)
+    P = 20
+    pose = torch.randn(P, 7, generator=g)
+    pts = torch.randn(P, 333, 3, generator=g)
+    sc = torch.rand(P, generator=g) + 0.1
+    want = O.get_final_pose_pts((pts * sc[:, None, None]).unsqueeze(0), pose[None, :, :3], pose[None, :, 3:])[0]
+    got = ops.pose_apply(pts.to(dev), pose.to(dev), sc.to(dev))
+    assert torch.equal(got.cpu(), want)
+    raw = O.quaternion_apply(pose[:, None, 3:], pts) + pose[:, None, :3]       # no normalisation (dynamic variant)
+    assert torch.equal(ops.pose_apply(pts.to(dev), pose.to(dev), normalise=False).cpu(), raw)
+    pivot = torch.randint(0, P, (P,), generator=g).to(torch.int32)
+    init = torch.eye(4).repeat(P, 1, 1)
+    init[:, :3, :3] = O.quaternion_to_matrix(torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=-1))
+    init[:, :3, 3] = torch.randn(P, 3, generator=g)
+    has = (torch.rand(P, generator=g) < 0.5).to(torch.uint8)
+    want = O.pose_compose(pose, pivot.tolist(), init.view(P, 16), has.tolist())
+    got = ops.pose_compose(pose.to(dev), pivot.to(dev), init.view(P, 16).contiguous().to(dev), has.to(dev))
+    assert (got.cpu() - want).abs().max() < 1e-5
+
+
+# ----------------------------------------------------------------------------- a2 / a3 / a4
+@pytest.mark.parametrize("N,S", [(1000, 256), (1024, 256), (512, 256), (256, 128), (128, 25), (2048, 256), (4096, 100),
+                                 (300, 77), (64, 64), (5, 3), (1, 1)])
+def test_fps_bit_exact_vs_oracle(dev, oracle_lib, N, S):
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(N * 7 + S)
+    pts = torch.rand(4, N, 3, generator=g) * 2 - 1
+    pts[1] = torch.round(pts[1] * 8) / 8            # a coarse grid: many exact distance ties -> lowest index must win
+    want = np.empty((4, S), np.int32)
+    O.clib().oracle_fps(O._np32(pts).ctypes.data, 4, N, S, want.ctypes.data)
+    idx, new_xyz = ops.fps(pts.to(dev), S)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert torch.equal(new_xyz.cpu(), O.index_points(pts, T(want.astype(np.int64))))
+
+
+@pytest.mark.parametrize("N,S,r,ns", [(1000, 256, 0.2, 32), (1024, 256, 0.2, 32), (256, 128, 0.4, 64), (128, 25, 0.8, 64),
+                                      (2048, 256, 0.2, 32), (70, 9, 0.3, 5), (40, 3, 0.2, 64)])
+def test_ball_query_bit_exact_vs_oracle(dev, oracle_lib, N, S, r, ns):
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(N + S)
+    pts = torch.rand(3, N, 3, generator=g) * 2 - 1
+    pts[2] = torch.round(pts[2] * 5) / 5            # points exactly ON the radius (d == r^2 is kept: `d > r2` drops)
+    c = pts[:, :S].contiguous()
+    want = O.query_ball_point(r, ns, pts, c)
+    got = ops.ball_query(pts.to(dev), c.to(dev), r, ns)
+    assert torch.equal(got.cpu().long(), want)
+
+
+def test_ball_query_empty_and_padding(dev):
+    from pfpp_hip import ops
+
+    p = torch.zeros(1, 10, 3); p[0, :, 0] = torch.arange(10).float()
+    got = ops.ball_query(p.to(dev), p[:, 5:6].contiguous().to(dev), 0.2, 4).cpu()
+    assert got[0, 0].tolist() == [5, 5, 5, 5]
+    far = torch.full((1, 1, 3), 100.0)
+    got = ops.ball_query(p.to(dev), far.to(dev), 0.2, 4).cpu()
+    assert got[0, 0].tolist() == [10, 10, 10, 10]   # nothing in range: the reference's sentinel N
+
+
+def test_encoder_stages_vs_golden(golden, weights_sd, dev):
+    """every stage of the fragment encoder against the reference's own outputs"""
+    from pfpp_hip import encoder as E
+
+    pk = E.pack_encoder(dsd(weights_sd("vqvae"), dev))
+    for tag in ("float", "grid"):
+        g = golden(f"encoder_{tag}")
+        cap = {}
+        z_e, xyz = E.pn2_encode(pk, T(g["pts"]).to(dev), 25, cap)
+        for lvl in ("sa1", "sa2", "sa3"):
+            assert np.array_equal(cap[f"{lvl}.fps_idx"].cpu().numpy(), g[f"{lvl}_fps_idx"].astype(np.int32)), (tag, lvl)
+            assert np.array_equal(cap[f"{lvl}.ball_idx"].cpu().numpy(), g[f"{lvl}_ball_idx"].astype(np.int32)), (tag, lvl)
+        assert np.abs(cap["sa1.new_points"][:, ::16].cpu().numpy() - g["sa1_feat_sub"]).max() < TOL
+        assert np.abs(cap["sa2.new_points"][:, ::8].cpu().numpy() - g["sa2_feat_sub"]).max() < TOL
+        assert np.abs(cap["sa3.new_points"].cpu().numpy() - g["sa3_feat"]).max() < TOL
+        assert np.abs(z_e.cpu().numpy() - g["z_e"]).max() < TOL
+        assert np.array_equal(xyz.cpu().numpy(), g["xyz"])
+        out = E.encode_valid(pk, T(g["pts"]).to(dev))
+        dq = np.abs(out["z_q"].cpu().numpy() - g["z_q"]).reshape(-1, 16).max(1)
+        # a code may only differ where the reference's own top-2 distance gap is at rounding level
+        assert (dq[g["vq_gap"] > 1e-4] < TOL).all() and (dq > TOL).sum() <= 2
+
+
+def test_vq_bit_exact_golden(golden, weights_sd, dev):
+    from pfpp_hip import ops
+
+    g = golden("vq")
+    cb = weights_sd("vqvae")["vector_quantization.embedding.weight"].to(dev)
+    z = T(g["z"]).reshape(6, 25, 64).to(dev)
+    zq, codes = ops.vq_encode(z, cb, torch.arange(6, dtype=torch.int32, device=dev), 6, return_codes=True)
+    assert np.array_equal(codes.cpu().numpy().reshape(-1), g["codes"].astype(np.int32))
+    assert np.array_equal(zq.cpu().numpy().reshape(6, 100, 16), g["z_q"])
+    # scatter: fragments land in their slots, other slots stay zero
+    slot = torch.tensor([7, 2, 3, 9, 0, 11], dtype=torch.int32, device=dev)
+    zq2 = ops.vq_encode(z, cb, slot, 12)
+    assert torch.equal(zq2[slot.long()], zq) and zq2[[1, 4, 5, 6, 8, 10]].abs().max() == 0
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,act,pool,bn", [
+    (1000, 192, 132, "relu", 0, True), (4096, 128, 64, "relu", 64, True), (2048, 64, 4, "relu", 32, True),
+    (777, 512, 148, "none", 0, False), (500, 1536, 512, "none", 0, False), (640, 3, 256, "none", 0, False),
+    (333, 256, 2048, "gelu", 0, False), (256, 512, 512, "silu", 0, False), (1, 64, 7, "none", 0, False),
+    (129, 65, 33, "relu", 0, True)])
+def test_gemm_vs_float64(dev, M, N, K, act, pool, bn):
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g); s = torch.rand(N, generator=g) + 0.5
+    Kp = (K + 3) // 4 * 4
+    Ap = torch.full((M, Kp), float("nan")); Ap[:, :K] = A          # padding must never be read as data
+    Wp = torch.full((N, Kp), float("nan")); Wp[:, :K] = W
+    ref = A.double() @ W.double().t()
+    ref = ref * s.double() + b.double() if bn else ref + b.double()
+    ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu, "none": lambda v: v}[act](ref)
+    if pool:
+        ref = ref.view(M // pool, pool, N).max(1)[0]
+    out = ops.linear(Ap.to(dev), Wp.to(dev), None if bn else b.to(dev), act=act, pool=pool, K=K,
+                     scale=s.to(dev) if bn else None, shift=b.to(dev) if bn else None)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_linearity_full_size(dev):
+    """BASELINE-size transformer GEMM (M = 32*500): f(a x + b y) == a f(x) + b f(y) to rounding"""
+    from pfpp_hip import ops
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    M, K, N = 16000, 512, 1536
+    x = torch.randn(M, K, device=dev, generator=g); y = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    lhs = ops.linear(2.0 * x + 0.5 * y, W)
+    rhs = 2.0 * ops.linear(x, W) + 0.5 * ops.linear(y, W)
+    assert (lhs - rhs).abs().max() < 1e-4
+    assert (lhs - (2.0 * x + 0.5 * y) @ W.t()).abs().max() < 2e-4       # vs rocBLAS (checker only)
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from pfpp_hip import ops
+    from pfpp_hip._lib import PfppError
+
+    A = torch.zeros(8, 6, device=dev); W = torch.zeros(8, 6, device=dev)
+    with pytest.raises(PfppError, match="multiples of 4"):
+        ops.gemm(A, W, M=8, N=8, K=6, lda=6, ldw=6)
+    with pytest.raises(PfppError, match="pool"):
+        ops.gemm(torch.zeros(8, 8, device=dev), torch.zeros(8, 8, device=dev), M=8, N=8, K=8, lda=8, ldw=8, pool=48)
+
+
+# ----------------------------------------------------------------------------- transformer / scheduler / verifier
+def test_denoiser_vs_golden(golden, weights_sd, dev):
+    from pfpp_hip import denoiser as D
+
+    g = golden("denoiser")
+    pk = D.pack_denoiser(dsd(weights_sd("denoiser"), dev), 6)
+    cap = {}
+    eps = D.denoiser_forward(pk, T(g["x"]).to(dev), T(g["timesteps"]).to(dev), T(g["latent"]).to(dev), T(g["xyz"]).to(dev),
+                             T(g["part_valids"]).to(dev), T(g["scale"]).to(dev), T(g["ref_part"]).to(dev),
+                             num_layers=6, num_heads=8, capture=cap)
+    assert np.abs(cap["tokens"].view(2, 500, 512)[:, ::25].cpu().numpy() - g["tokens_sub"]).max() < 1e-5
+    assert np.abs(eps.cpu().numpy() - g["pred_noise"]).max() < TOL
+
+
+def test_scheduler_vs_golden(golden, dev):
+    from pfpp_hip.scheduler import PiecewiseScheduler
+
+    g = golden("scheduler")
+    s = PiecewiseScheduler(); s.set_timesteps(20)
+    x, eps, noise = (T(g[k]).to(dev) for k in ("x", "eps", "noise"))
+    for i, t in enumerate(s.timesteps.tolist()):
+        out = s.step(eps, t, x, variance_noise=noise).prev_sample
+        assert np.abs(out.cpu().numpy() - g["step_out"][i]).max() <= 1e-6, t
+    an = s.add_noise(x, noise, T(g["add_noise_t"]).to(dev))
+    assert np.abs(an.cpu().numpy() - g["add_noise_out"]).max() <= 1e-6
+    # fused re-pin of the reference fragments
+    ref = torch.zeros(2, 20, dtype=torch.bool, device=dev); ref[0, 3] = True
+    pinned = s.step(eps, 950, x, variance_noise=noise, ref_part=ref, reference=torch.ones_like(x)).prev_sample
+    assert (pinned[0, 3] == 1).all() and torch.equal(pinned[1], s.step(eps, 950, x, variance_noise=noise).prev_sample[1])
+
+
+def test_verifier_vs_golden(golden, weights_sd, dev):
+    from pfpp_hip import verifier as V
+
+    g = golden("verifier")
+    pk = V.pack_verifier(dsd(weights_sd("verifier"), dev), 6)
+    lo = V.verifier_forward(pk, T(g["edge_features"]).to(dev), T(g["edge_indices"].astype(np.int64)).to(dev),
+                            T(g["edge_valids"]).to(dev), num_layers=6, num_heads=8)
+    m = g["edge_valids"].astype(bool)
+    assert np.abs(lo.cpu().numpy() - g["logits"])[m].max() < TOL
+
+
+# ----------------------------------------------------------------------------- end to end vs oracle
+def test_sampler_three_steps_vs_oracle(weights_sd, dev, oracle_lib):
+    """drop-in Denoiser module: three DDPM steps with injected noise == the CPU oracle's sampler"""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).eval()
+    batch = synthetic.make_batch(21, 2, num_points=512)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 20, 7, generator=g)
+    noises = [torch.randn(2, 20, 7, generator=g) for _ in range(20)]
+    rec_o = []
+    sched = O.PiecewiseSchedule(); sched.set_timesteps(20)
+    # oracle: first three steps of O.sample
+    ref = batch["ref_part"].bool(); gt = torch.cat([batch["part_trans"], batch["part_rots"]], -1)
+    reference = torch.zeros_like(gt); reference[ref] = gt[ref]
+    x = x0.clone(); x[ref] = reference[ref]
+    for i, t in enumerate(sched.timesteps.tolist()[:3]):
+        lat, xyz = O.extract_features(weights_sd("vqvae"), batch["part_pcs"], batch["part_valids"], x)
+        eps = O.denoiser_forward(weights_sd("denoiser"), x, torch.full((2,), t), lat, xyz, batch["part_valids"], batch["part_scale"], ref)
+        x = sched.step(eps, t, x, noises[i]); x[ref] = reference[ref]
+        rec_o.append(x.clone())
+    model.noise_scheduler.timesteps = model.noise_scheduler.timesteps[:3]
+    rec = []
+    model.sample({k: v.to(dev) for k, v in batch.items()}, x_init=x0.to(dev), noises=[n.to(dev) for n in noises], record=rec)
+    valid = batch["part_valids"].bool()
+    for a, b in zip(rec, rec_o):
+        assert (a.cpu() - b)[valid].abs().max() < TOL
+        assert (a.cpu() - b).abs().max() < 5 * TOL           # padded slots carry no information; still close
+
+
+def test_pn2_utils_dropin_api(weights_sd, dev, oracle_lib):
+    from oracle import pfpp_oracle as O
+    import utils.pn2_utils as pu
+
+    g = torch.Generator().manual_seed(2)
+    xyz = torch.rand(2, 512, 3, generator=g) * 2 - 1
+    feats = torch.randn(2, 512, 8, generator=g)
+    new_xyz, new_points = pu.sample_and_group(64, 0.3, 16, xyz.to(dev), feats.to(dev))
+    oxyz, opts, _, _ = O.sample_and_group(64, 0.3, 16, xyz, feats)
+    assert new_points.shape == (2, 64, 16, 11) and torch.equal(new_xyz.cpu(), oxyz) and torch.equal(new_points.cpu(), opts)
+    idx = pu.query_ball_point(0.3, 16, xyz.to(dev), new_xyz)
+    assert idx.dtype == torch.int64 and torch.equal(idx.cpu(), O.query_ball_point(0.3, 16, xyz, oxyz))
+    assert torch.equal(pu.farthest_point_sample(xyz.to(dev), 64).cpu(), O.fps(xyz, 64))
+    d = pu.square_distance(new_xyz, xyz.to(dev))
+    assert (d.cpu() - ((oxyz[:, :, None] - xyz[:, None]) ** 2).sum(-1)).abs().max() < 1e-5
+    assert torch.equal(pu.index_points(feats.to(dev), idx).cpu(), O.index_points(feats, idx.cpu()))
+
+
+# ----------------------------------------------------------------------------- full BASELINE size: properties
+def test_full_size_properties(dev):
+    """BASELINE configs[1] size (32 puzzles x 20 slots x 1024 points, random-init weights): properties that
+    do not need the oracle — FPS picks distinct points starting at 0, ball-query rows are ascending then padded
+    with the first hit and every hit lies within the radius, padded slots of the scattered latents stay zero,
+    the latent rows are codebook rows up to one rounding, the step is deterministic."""
+    from pfpp_hip import config, ops, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    model = Denoiser(config.denoiser_config()).to(dev).eval()
+    with torch.no_grad():
+        model.encoder.vector_quantization.embedding.weight.uniform_(-1, 1)
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(100, 32, num_points=1024).items()}
+    valid = data["part_valids"].bool()
+    slot = torch.nonzero(valid.flatten()).flatten().to(torch.int32)
+    x = torch.randn(32, 20, 7, device=dev)
+    rot = ops.se3_rotate_gather(data["part_pcs"].view(640, 1024, 3), x.view(640, 7), slot)
+    # rotation preserves norms
+    assert (rot.norm(dim=-1) - data["part_pcs"][valid].norm(dim=-1)).abs().max() < 1e-5
+    idx, new_xyz = ops.fps(rot, 256)
+    assert (idx[:, 0] == 0).all()
+    srt = idx.sort(dim=1)[0]
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+    ball = ops.ball_query(rot, new_xyz, 0.2, 32).long()
+    assert ball.min() >= 0 and ball.max() < 1024
+    inc = ball[:, :, 1:] > ball[:, :, :-1]
+    pad = ball[:, :, 1:] == ball[:, :, :1]
+    assert (inc | pad).all()
+    nb = torch.gather(rot, 1, ball.view(ball.shape[0], -1, 1).expand(-1, -1, 3)).view(*ball.shape, 3)
+    assert ((nb - new_xyz[:, :, None]).pow(2).sum(-1) <= 0.04 + 1e-5).all()
+    lat, xyz = model._extract_features(data["part_pcs"], data["part_valids"], x)
+    assert lat[~valid].abs().max() == 0 and xyz[~valid].abs().max() == 0
+    cb = model.encoder.vector_quantization.embedding.weight
+    sub = lat[valid].reshape(-1, 16)
+    assert torch.cdist(sub[:4096], cb).min(dim=1)[0].max() < 1e-5
+    ts = torch.full((32,), 500, dtype=torch.int64, device=dev)
+    e1 = model.denoiser(x, ts, lat, xyz, data["part_valids"], data["part_scale"], data["ref_part"])
+    e2 = model.denoiser(x, ts, lat, xyz, data["part_valids"], data["part_scale"], data["ref_part"])
+    assert torch.equal(e1, e2) and torch.isfinite(e1).all()
+    # puzzles are independent: evaluating half of the batch alone gives the same answer
+    e_half = model.denoiser(x[:16].contiguous(), ts[:16], lat[:16].contiguous(), xyz[:16].contiguous(),
+                            data["part_valids"][:16].contiguous(), data["part_scale"][:16].contiguous(),
+                            data["ref_part"][:16].contiguous())
+    assert (e_half - e1[:16]).abs().max() < 1e-5

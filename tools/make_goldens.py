@@ -1,0 +1,365 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE's own Python modules (build container only).
+
+    python tools/make_goldens.py            # needs /root/reference; writes tests/golden/
+
+What is imported verbatim from /root/reference (sys.dont_write_bytecode, nothing is copied):
+    utils/pn2_utils.py, utils/model_utils.py,
+    puzzlefusion_plusplus/vqvae/model/modules/{pn2,quantizer}.py,
+    puzzlefusion_plusplus/denoiser/model/modules/{encoder,attention,denoiser_transformer,custom_diffusers}.py,
+    puzzlefusion_plusplus/verifier/model/modules/verifier_transformer.py
+Third-party packages those files import but which are not installed (torch_cluster, chamferdist,
+diffusers==0.21.4) get minimal stand-ins below, restated from their documented semantics
+ — those pieces stay "parity unpinned"; everything the reference itself owns
+(grouping, ball query, SA-MLPs, VQ, AdaLN, masks, token assembly, heads, beta schedule, verifier) is
+pinned by the fixtures.  The script also checks the oracle (oracle/pfpp_oracle.py) against the
+reference outputs and refuses to write fixtures the oracle does not reproduce.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace as NS
+
+sys.dont_write_bytecode = True
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import pfpp_oracle as O
+from oracle import weights
+
+GOLD = ROOT / "tests" / "golden"
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-ins for absent third-party packages
+# ------------------------------------------------------------------------------------------------
+def install_standins():
+    tc = types.ModuleType("torch_cluster")
+
+    def fps(src, batch=None, ratio=None, random_start=True):
+        """torch_cluster.fps semantics: per batch element, m = ceil(ratio*n), start 0,
+        squared-L2 running min, first argmax; returns GLOBAL row indices."""
+        assert not random_start
+        counts = torch.bincount(batch)
+        out, off = [], 0
+        for n in counts.tolist():
+            m = int(torch.ceil(ratio * n).item())
+            idx = O.fps(src[off:off + n].unsqueeze(0), m)[0]
+            out.append(idx + off)
+            off += n
+        return torch.cat(out)
+
+    tc.fps = fps
+    sys.modules["torch_cluster"] = tc
+
+    cd = types.ModuleType("chamferdist")
+
+    class ChamferDistance(nn.Module):
+        def forward(self, *a, **k):
+            raise RuntimeError("chamferdist is not on the hot path")
+
+    cd.ChamferDistance = ChamferDistance
+    sys.modules["chamferdist"] = cd
+
+    # diffusers 0.21.4
+    class Attention(nn.Module):
+        def __init__(self, query_dim, heads=8, dim_head=64, dropout=0.0, bias=False):
+            super().__init__()
+            inner = heads * dim_head
+            self.heads = heads
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(query_dim, inner, bias=bias)
+            self.to_v = nn.Linear(query_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, attention_mask=None):
+            B, S, _ = hidden_states.shape
+            H = self.heads
+            q, k, v = self.to_q(hidden_states), self.to_k(hidden_states), self.to_v(hidden_states)
+            dh = q.shape[-1] // H
+            q, k, v = (t.view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+            m = attention_mask
+            if m.shape[0] < B * H:
+                m = m.repeat_interleave(H, dim=0)
+            m = m.view(B, H, -1, m.shape[-1])
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=m, dropout_p=0.0, is_causal=False)
+            o = o.transpose(1, 2).reshape(B, -1, H * dh)
+            return self.to_out[1](self.to_out[0](o))
+
+    class GEGLU(nn.Module):
+        def __init__(self, dim_in, dim_out):
+            super().__init__()
+            self.proj = nn.Linear(dim_in, dim_out * 2)
+
+        def forward(self, x):
+            h, gate = self.proj(x).chunk(2, dim=-1)
+            return h * F.gelu(gate)
+
+    class FeedForward(nn.Module):
+        def __init__(self, dim, dropout=0.0, activation_fn="geglu", final_dropout=False, mult=4):
+            super().__init__()
+            assert activation_fn == "geglu"
+            self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim)])
+
+        def forward(self, x):
+            for m in self.net:
+                x = m(x)
+            return x
+
+    class DDPMScheduler:
+        def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=2e-2, beta_schedule="linear",
+                     prediction_type="epsilon", clip_sample=True, timestep_spacing="leading", **kw):
+            self.config = NS(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type,
+                             clip_sample=clip_sample, timestep_spacing=timestep_spacing, steps_offset=0)
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+            self.alphas = 1.0 - self.betas
+            self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+            self.one = torch.tensor(1.0)
+            self.num_inference_steps = None
+            self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
+
+        def set_timesteps(self, num_inference_steps):
+            self.num_inference_steps = num_inference_steps
+            ratio = self.config.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            self.timesteps = torch.from_numpy(ts)
+
+        def previous_timestep(self, t):
+            return t - self.config.num_train_timesteps // self.num_inference_steps
+
+        def add_noise(self, x0, noise, timesteps):
+            ac = self.alphas_cumprod.to(dtype=x0.dtype)
+            sa = (ac[timesteps] ** 0.5).flatten()
+            sb = ((1 - ac[timesteps]) ** 0.5).flatten()
+            while sa.dim() < x0.dim():
+                sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+            return sa * x0 + sb * noise
+
+        def step(self, model_output, timestep, sample, variance_noise=None):
+            t = timestep
+            prev_t = self.previous_timestep(t)
+            a_t = self.alphas_cumprod[t]
+            a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+            b_t, b_prev = 1 - a_t, 1 - a_prev
+            cur_a = a_t / a_prev
+            cur_b = 1 - cur_a
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            c0 = (a_prev ** 0.5 * cur_b) / b_t
+            c1 = cur_a ** 0.5 * b_prev / b_t
+            prev = c0 * x0 + c1 * sample
+            if t > 0:
+                var = torch.clamp((1 - a_prev) / (1 - a_t) * cur_b, min=1e-20)
+                prev = prev + (var ** 0.5) * variance_noise
+            return NS(prev_sample=prev, pred_original_sample=x0)
+
+    dm = types.ModuleType("diffusers")
+    dm.DDPMScheduler = DDPMScheduler
+    dmm = types.ModuleType("diffusers.models")
+    dma = types.ModuleType("diffusers.models.attention")
+    dma.Attention, dma.FeedForward = Attention, FeedForward
+    dm.models = dmm
+    dmm.attention = dma
+    sys.modules.update({"diffusers": dm, "diffusers.models": dmm, "diffusers.models.attention": dma})
+
+
+def maxdiff(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def main():
+    assert REF.exists(), "run this in the build container (needs /root/reference)"
+    install_standins()
+    sys.path.insert(0, str(REF))
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k.startswith("puzzlefusion_plusplus")]:
+        del sys.modules[k]
+    import utils.pn2_utils as ref_pn2                       # noqa: E402  (the reference's)
+    from puzzlefusion_plusplus.denoiser.model.modules.custom_diffusers import PiecewiseScheduler, betas_for_alpha_bar
+    from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+    from puzzlefusion_plusplus.denoiser.model.modules.encoder import VQVAE
+    from puzzlefusion_plusplus.verifier.model.modules.verifier_transformer import VerifierTransformer
+    from utils.model_utils import EmbedderNerf, PositionalEncoding
+    assert ref_pn2.__file__.startswith(str(REF)), ref_pn2.__file__
+
+    # host-side synthetic data generator (numpy), loaded by path: the product's `utils` package must
+    # not shadow the reference's namespace package `utils` on sys.path
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pfpp_synthetic", ROOT / "puzzlefusion-plusplus_amd/pfpp_hip/synthetic.py")
+    synthetic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synthetic)
+
+    GOLD.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    cfg = NS(
+        ae=NS(n_embeddings=1024, embedding_dim=16, num_point=25, num_dim=64, local_decode_pts=40, beta=0.25),
+        model=NS(embed_dim=512, out_channels=7, num_layers=6, num_heads=8, num_dim=64, num_point=25),
+    )
+
+    # ============================ encoder =======================================================
+    data = synthetic.make_batch(7, 1, num_points=512, num_parts=3)
+    dataq = synthetic.make_batch(7, 1, num_points=512, num_parts=3, quantise_bits=9)
+    x = torch.randn(1, 20, 7)
+    enc_ref = VQVAE(cfg)
+    enc_sd = weights.vqvae_state_dict()
+    enc_ref.load_state_dict(enc_sd, strict=True)
+    enc_ref.eval()
+    for tag, d in (("float", data), ("grid", dataq)):
+        valid = d["part_valids"].bool()
+        pts = O.apply_rots(d["part_pcs"], x)[valid] if tag == "float" else d["part_pcs"][valid]
+        # stage-level reference outputs straight from the reference functions
+        cap = {}
+        xyz_l, feats_cf = pts, None
+        with torch.no_grad():
+            cur_xyz_cf = pts.permute(0, 2, 1)
+            for name, sa in (("sa1", enc_ref.pn2.sa1), ("sa2", enc_ref.pn2.sa2), ("sa3", enc_ref.pn2.sa3)):
+                xyz_cl = cur_xyz_cf.permute(0, 2, 1)
+                pts_cl = feats_cf.permute(0, 2, 1) if feats_cf is not None else None
+                new_xyz, new_points, grouped_xyz, fps_idx = ref_pn2.sample_and_group(
+                    sa.npoint, sa.radius, sa.nsample, xyz_cl, pts_cl, returnfps=True)
+                ball = ref_pn2.query_ball_point(sa.radius, sa.nsample, xyz_cl, new_xyz)
+                cap[f"{name}.fps_idx"] = fps_idx.reshape(pts.shape[0], -1)
+                cap[f"{name}.ball_idx"] = ball
+                cur_xyz_cf, feats_cf = sa(cur_xyz_cf, feats_cf)
+                cap[f"{name}.new_points"] = feats_cf.permute(0, 2, 1).contiguous()
+            out_ref = enc_ref.encode(pts)
+            z_e_ref, _ = enc_ref.pn2.encode(pts.permute(0, 2, 1))
+        ocap = {}
+        out_o = O.vqvae_encode(enc_sd, pts, capture=ocap)
+        for lvl in ("sa1", "sa2", "sa3"):
+            assert torch.equal(ocap[f"pn2.{lvl}.fps_idx"], cap[f"{lvl}.fps_idx"]), (tag, lvl, "fps")
+            nb = (ocap[f"pn2.{lvl}.ball_idx"] != cap[f"{lvl}.ball_idx"]).sum().item()
+            assert nb == 0, (tag, lvl, "ball query differs from the reference in", nb)
+            assert maxdiff(ocap[f"pn2.{lvl}.new_points"], cap[f"{lvl}.new_points"]) < 1e-6, (tag, lvl)
+        assert maxdiff(ocap["z_e"], z_e_ref) < 1e-6
+        assert torch.equal(out_o["xyz"], out_ref["xyz"])
+        nflip = ((out_o["z_q"] - out_ref["z_q"]).abs().reshape(-1, 16).amax(1) > 1e-6).sum().item()
+        gaps = O.vq_gap(enc_sd["vector_quantization.embedding.weight"], z_e_ref.reshape(-1, 16))
+        print(f"[encoder/{tag}] oracle == reference: fps/ball exact, feats<1e-6, VQ sub-vectors differing {nflip}, "
+              f"min top-2 gap {gaps.min():.2e}")
+        assert nflip == 0
+        np.savez_compressed(
+            GOLD / f"encoder_{tag}.npz",
+            pts=pts.numpy(),
+            **{f"{l}_fps_idx": cap[f"{l}.fps_idx"].numpy().astype(np.int16) for l in ("sa1", "sa2", "sa3")},
+            **{f"{l}_ball_idx": cap[f"{l}.ball_idx"].numpy().astype(np.int16) for l in ("sa1", "sa2", "sa3")},
+            sa1_feat_sub=cap["sa1.new_points"][:, ::16].numpy(), sa2_feat_sub=cap["sa2.new_points"][:, ::8].numpy(),
+            sa3_feat=cap["sa3.new_points"].numpy(), z_e=z_e_ref.numpy(), z_q=out_ref["z_q"].numpy(),
+            xyz=out_ref["xyz"].numpy(), vq_gap=gaps.numpy(),
+        )
+        if tag == "float":
+            np.savez_compressed(GOLD / "rotate.npz", part_pcs=d["part_pcs"][valid].numpy(), pose=x[valid].numpy(),
+                                rotated=pts.numpy())
+
+    # ball query on the reference's own code for all three level shapes (standalone)
+    g = torch.Generator().manual_seed(5)
+    for N, S, r, ns in ((1000, 256, 0.2, 32), (256, 128, 0.4, 64), (128, 25, 0.8, 64)):
+        p = torch.rand(2, N, 3, generator=g) * 2 - 1
+        c = p[:, :S].contiguous()
+        assert torch.equal(ref_pn2.query_ball_point(r, ns, p, c), O.query_ball_point(r, ns, p, c)), (N, S)
+        d_ref = ref_pn2.square_distance(c, p)
+    print("[ball query] oracle C == reference torch on random clouds for all three level shapes")
+
+    # ============================ VQ alone (spread latents) =====================================
+    from puzzlefusion_plusplus.vqvae.model.modules.quantizer import VectorQuantizer
+    vq = VectorQuantizer(1024, 16, 0.25)
+    vq.embedding.weight.data.copy_(enc_sd["vector_quantization.embedding.weight"])
+    z = torch.randn(6, 100, 16, generator=g)
+    with torch.no_grad():
+        _, zq_ref, _, _, codes_ref = vq(z)
+    zq_o, codes_o = O.vector_quantize_c(vq.embedding.weight.data, z)
+    assert torch.equal(codes_o, codes_ref.flatten()) and torch.equal(zq_o, zq_ref)
+    print("[vq] oracle C argmin == reference on 600 random sub-vectors")
+    np.savez_compressed(GOLD / "vq.npz", z=z.numpy(), z_q=zq_ref.numpy(), codes=codes_ref.flatten().numpy().astype(np.int16))
+
+    # ============================ model_utils ====================================================
+    pe_ref = PositionalEncoding(512).pe
+    assert torch.equal(pe_ref, O.positional_table(512, 20))
+    emb = EmbedderNerf(include_input=True, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
+                       periodic_fns=[torch.sin, torch.cos])
+    v = torch.randn(50, 3, generator=g)
+    assert torch.equal(emb.embed(v), O.nerf_embed(v)) and emb.out_dim == 63
+
+    # ============================ denoiser transformer ===========================================
+    den_ref = DenoiserTransformer(cfg)
+    den_sd = weights.denoiser_state_dict()
+    den_ref.load_state_dict(den_sd, strict=True)
+    den_ref.eval()
+    B, P, L = 2, 20, 25
+    valids = torch.zeros(B, P); valids[0, :8] = 1; valids[1, :20] = 1
+    latent = torch.randn(B, P, L, 64, generator=g) * valids[:, :, None, None]
+    xyz = (torch.rand(B, P, L, 3, generator=g) * 2 - 1) * valids[:, :, None, None]
+    scale = torch.rand(B, P, 1, generator=g) * 0.9 + 0.05
+    scale[valids == 0] = 1.0
+    xx = torch.randn(B, P, 7, generator=g)
+    ref_part = torch.zeros(B, P, dtype=torch.bool); ref_part[0, 2] = True; ref_part[1, 0] = True
+    ts = torch.tensor([950, 500])
+    with torch.no_grad():
+        eps_ref = den_ref(xx, ts, latent, xyz, valids, scale, ref_part)
+    ocap = {}
+    eps_o = O.denoiser_forward(den_sd, xx, ts, latent, xyz, valids, scale, ref_part, capture=ocap)
+    d = maxdiff(eps_o, eps_ref)
+    print(f"[denoiser] oracle vs reference pred_noise maxdiff {d:.2e}")
+    assert d < 1e-5
+    np.savez_compressed(GOLD / "denoiser.npz", x=xx.numpy(), timesteps=ts.numpy(), latent=latent.numpy(), xyz=xyz.numpy(),
+                        part_valids=valids.numpy(), scale=scale.numpy(), ref_part=ref_part.numpy(),
+                        pred_noise=eps_ref.numpy(), tokens_sub=ocap["tokens"][:, ::25].numpy(),
+                        layer_means=np.array([ocap[f"layer{i}"].double().abs().mean().item() for i in range(6)]))
+    for t_single in (0, 999):
+        with torch.no_grad():
+            e1 = den_ref(xx, torch.tensor([t_single, t_single]), latent, xyz, valids, scale, ref_part)
+        e2 = O.denoiser_forward(den_sd, xx, torch.tensor([t_single, t_single]), latent, xyz, valids, scale, ref_part)
+        assert maxdiff(e1, e2) < 1e-5
+
+    # ============================ scheduler =====================================================
+    sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
+                                 beta_start=1e-4, beta_end=2e-2, clip_sample=False, timestep_spacing="leading")
+    sch_ref.set_timesteps(20)
+    so = O.PiecewiseSchedule()
+    so.set_timesteps(20)
+    assert torch.equal(sch_ref.alphas_cumprod, so.alphas_cumprod) and torch.equal(sch_ref.timesteps, so.timesteps)
+    assert torch.equal(betas_for_alpha_bar(alpha_transform_type="piece_wise"), so.betas)
+    noise = torch.randn(B, P, 7, generator=g)
+    steps = []
+    for t in sch_ref.timesteps:
+        a = sch_ref.step(eps_ref, t, xx, variance_noise=noise).prev_sample
+        b = so.step(eps_ref, int(t), xx, noise)
+        assert torch.equal(a, b), int(t)
+        steps.append(a.numpy())
+    tt = torch.tensor([3, 700])
+    an = sch_ref.add_noise(xx, noise, tt)
+    assert torch.equal(an, so.add_noise(xx, noise, tt))
+    np.savez_compressed(GOLD / "scheduler.npz", alphas_cumprod=sch_ref.alphas_cumprod.numpy(),
+                        timesteps=sch_ref.timesteps.numpy(), x=xx.numpy(), eps=eps_ref.numpy(), noise=noise.numpy(),
+                        step_out=np.stack(steps), add_noise_t=tt.numpy(), add_noise_out=an.numpy())
+    print("[scheduler] oracle == reference PiecewiseScheduler (tables, 20 steps, add_noise) bit-exact; abar at the "
+          "20 timesteps:", [round(float(sch_ref.alphas_cumprod[t]), 6) for t in sch_ref.timesteps][:4], "...")
+
+    # ============================ verifier ======================================================
+    vcfg = NS(model=NS(embed_dim=256, num_layers=6, num_heads=8))
+    ver_ref = VerifierTransformer(vcfg)
+    ver_sd = weights.verifier_state_dict()
+    ver_ref.load_state_dict(ver_sd, strict=True)
+    ver_ref.eval()
+    ed = synthetic.make_edges(2, seed=3)
+    with torch.no_grad():
+        lo_ref = ver_ref(ed["edge_features"], ed["edge_indices"], ed["edge_valids"])
+    lo_o = O.verifier_forward(ver_sd, ed["edge_features"], ed["edge_indices"], ed["edge_valids"])
+    m = ed["edge_valids"].bool()
+    d = (lo_o - lo_ref).abs()[m].max().item()
+    print(f"[verifier] oracle vs reference logits (valid edges) maxdiff {d:.2e}")
+    assert d < 1e-5
+    np.savez_compressed(GOLD / "verifier.npz", edge_features=ed["edge_features"].numpy(),
+                        edge_indices=ed["edge_indices"].numpy().astype(np.int16), edge_valids=ed["edge_valids"].numpy(),
+                        logits=lo_ref.numpy())
+    total = sum(f.stat().st_size for f in GOLD.glob("*.npz"))
+    print(f"wrote {len(list(GOLD.glob('*.npz')))} fixtures, {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
