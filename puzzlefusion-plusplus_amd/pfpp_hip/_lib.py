@@ -69,6 +69,20 @@ class PfppError(RuntimeError):
     pass
 
 
+def _bind_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  The kernels must run on THAT runtime
+    (same device context, streams and allocations as the tensors they are handed), so it is
+    loaded with RTLD_GLOBAL before libpfpp_hip.so: the library's NEEDED libamdhip64 entry then
+    resolves to the already-loaded copy whatever the import order of the process was."""
+    import os
+
+    import torch
+
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """dlopen libpfpp_hip.so and attach prototypes; raises if it has not been built."""
     global _lib
@@ -79,6 +93,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path. "
             "Build them with `python __graft_entry__.py` (hipcc --offload-arch=gfx950)."
         )
+    _bind_torch_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -186,7 +186,7 @@ def test_gemm_rejects_bad_arguments(dev):
     with pytest.raises(PfppError, match="multiples of 4"):
         ops.gemm(A, W, M=8, N=8, K=6, lda=6, ldw=6)
     with pytest.raises(PfppError, match="pool"):
-        ops.gemm(torch.zeros(8, 8, device=dev), torch.zeros(8, 8, device=dev), M=8, N=8, K=8, lda=8, ldw=8, pool=48)
+        ops.gemm(torch.zeros(96, 8, device=dev), torch.zeros(8, 8, device=dev), M=96, N=8, K=8, lda=8, ldw=8, pool=48)
 
 
 # ----------------------------------------------------------------------------- transformer / scheduler / verifier
