@@ -33,7 +33,9 @@ for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
 
 import torch
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# /opt/skills/guides/MI355X_MICROARCH.md, dense peaks
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (exact fp32 path)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 (split-f16 path: 3 matrix instructions per fp32-grade product)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -182,15 +184,28 @@ def main():
         torch.cuda.synchronize(dev)
         trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
         per = {}
-        for e0, e1, flops, name in trace:
+        shapes = {}
+        for e0, e1, flops, name, shape in trace:
             ms = e0.elapsed_time(e1)
+            sa = shapes.setdefault((name,) + shape, [0.0, 0.0, 0])
+            sa[0] += flops; sa[1] += ms; sa[2] += 1
             a = per.setdefault(name, [0.0, 0.0, 0])
             a[0] += flops; a[1] += ms; a[2] += 1
+        if os.environ.get("BENCH_GEMM_SHAPES"):
+            for key, (fl, ms_, n_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {ms_ / args.steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // args.steps:3d}  {key}", file=sys.stderr)
         name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
-        achieved = flops / (ms * 1e-3) / 1e12
+        achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
+        split = "f16x3" in name
+        # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
+        # FLOPs is the f16 dense peak / 3
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
         roofline = {
-            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product"
+                          if split else "fp32 MFMA dense peak"),
+            "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
             "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
             "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
             "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
@@ -206,7 +221,7 @@ def main():
             "value": round(frag_steps / elapsed, 2), "unit": "fragment*steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (GEMMs: %s)" % ops.GEMM_MODE, "data": "synthetic",
             "config": {
                 "workload": "DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
                             "scheduler step), BASELINE configs[1] shape, inference forward",

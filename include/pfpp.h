@@ -126,8 +126,18 @@ enum {
                          block (see pfpp_hip.pack_geglu); C has N/2 columns   */
 };
 
+/* arithmetic of the contraction (see csrc/gemm.hip):
+ *   PFPP_GEMM_F32   v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s roofline)
+ *   PFPP_GEMM_F16X3 split-f16: x = hi + lo/2048 (hi, lo fp16), A.W = hi.hi + (hi.lo + lo.hi)/2048 on
+ *                   v_mfma_f32_32x32x16_f16 — fp32-grade error (dropped term 2^-22 relative) at up to
+ *                   16/3 of the fp32-MFMA rate; needs |x| < 65504; not available with w_kmajor.
+ *                   W may be handed over pre-split (w_hi/w_lo: fp16 [N, ldw] planes, ldw = K rounded
+ *                   up to 8 and zero padded, lo pre-scaled by 2048) or as fp32 (split on the fly). */
+enum { PFPP_GEMM_F32 = 0, PFPP_GEMM_F16X3 = 1 };
+
 typedef struct pfpp_gemm_args {
   const float* A; const float* W; float* C;
+  const void* w_hi; const void* w_lo;   /* pre-split fp16 planes of W, or NULL */
   const float* bias;      /* [N] or NULL */
   const float* scale;     /* [N] or NULL (then shift must be set) */
   const float* shift;     /* [N] */
@@ -138,6 +148,7 @@ typedef struct pfpp_gemm_args {
   int32_t act;            /* PFPP_ACT_* */
   int32_t pool;           /* 0, 32 or 64: max over groups of `pool` rows */
   int32_t batch, zdiv;    /* batch >= 1; zdiv >= 1 */
+  int32_t precision;      /* PFPP_GEMM_* */
   int64_t sA0, sA1, sW0, sW1, sC0, sC1;
   int64_t sV0, sV1;       /* batch strides of bias / scale / shift */
   float alpha;            /* acc *= alpha before the epilogue (1.0 = off) */

@@ -1,56 +1,43 @@
-// fp32 GEMM with fused epilogues on the CDNA4 matrix cores (gfx950).
+// GEMM with fused epilogues on the CDNA4 matrix cores (gfx950):  C = epilogue(A . op(W)).
 //
-//   C[M,N] = epilogue( A[M,K] . op(W) ),  op(W) = W^T for W[N,K] (torch Linear /
-//   1x1-conv weight layout) or W for W[K,N] (attention P.V).
+// Two arithmetic paths behind one interface (pfpp_gemm_args.precision):
 //
-// v_mfma_f32_32x32x2_f32 computes exact fp32 products with fp32 accumulation
-// (bitwise a k-ordered fmaf chain), which is what the 1e-4 parity bar on the
-// predicted noise needs; its rate (157 TFLOP/s dense) is the roofline of every
-// contraction on this path.
+//  PFPP_GEMM_F32 — v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (bitwise a
+//      k-ordered fmaf chain).  Roofline: 157.3 TFLOP/s.
 //
-// Structure: 256 threads = 4 waves as 2x2; each wave owns an (MT*32)x(NT*32)
-// sub-tile held in MT*NT accumulators of 16 VGPRs.  K advances in tiles of 32:
-// the next tile is fetched HBM->VGPR (16-byte loads, coalesced along K) while
-// the current one is multiplied out of LDS; one barrier per K-tile.  LDS rows are
-// padded to 36 floats so the 16-byte fragment reads (ds_read_b128, one row per
-// lane) are bank-conflict free.  Within an 8-wide K chunk lanes 0-31 feed
-// k = 0..3 and lanes 32-63 feed k = 4..7 to the four MFMAs, so one ds_read_b128
-// per operand serves four matrix instructions.
-// Workgroup ids are remapped so that consecutive tiles (which share the A
-// row-panel) run on the same XCD and hit its L2.
-#include "pfpp_common.h"
+//  PFPP_GEMM_F16X3 — "split-f16": every fp32 operand x is written as hi + lo/2048 with
+//      hi = f16(x), lo = f16((x - hi) * 2048) (x - hi is exact in fp32, so hi/lo carry 22 bits of
+//      x), and A.W is evaluated as  hi.hi + (hi.lo + lo.hi)/2048  with three
+//      v_mfma_f32_32x32x16_f16 per 16-deep step: f16 products are exact in the fp32 accumulator,
+//      the dropped lo.lo term is 2^-22 relative — fp32-grade results (measured against the 1e-4
+//      parity bar of the path) at 16/3 of the fp32-MFMA rate.  W's planes are pre-split once on
+//      the host (weights), A — and W when it is an activation, e.g. K in Q.K^T — is split while it
+//      is staged into LDS.  Requires |x| < 65504 (f16 range); the fp32 path has no such limit.
+//
+// Shared structure: 256 threads = 4 waves as 2x2, each wave owns (MT*32)x(NT*32) of a
+// (64*MT)x(64*NT) tile; K advances in tiles of 32 through a register-staged LDS double buffer with
+// one barrier per K-tile; the steady-state loop body (prefetch of the next full tile, fragment
+// reads, MFMAs, LDS writes) is one branch-free basic block so the compiler can interleave memory
+// and VALU work into the gaps between matrix instructions; rows outside M/N are clamped (their
+// results are discarded) instead of predicated.  LDS rows are padded (36 floats / 40 halfs) so
+// that the 16-byte fragment reads are bank-conflict free.  Tile ids are remapped XCD-aware.
+#include "gemm_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace pfpp_gemm_detail;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;  // 36 floats = 144 B: 16-byte aligned, conflict-free b128 reads
+constexpr int LDS_LD = BK + 4;   // fp32 path: 36 floats = 144 B rows
+constexpr int LDH = BK + 8;      // split path: 40 halfs = 80 B rows (5 x 16 B: conflict-free b128 reads)
 
-struct GemmP {
-  const float* A; const float* W; float* C;
-  const float* bias; const float* scale; const float* shift; const float* residual;
-  int M, N, K;
-  int64_t lda, ldw, ldc, ldr;
-  int act, pool, zdiv;
-  int64_t sA0, sA1, sW0, sW1, sC0, sC1, sV0, sV1;
-  float alpha;
-  int tiles_n;
-};
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-  switch (act) {
-    case PFPP_ACT_RELU: return v > 0.0f ? v : 0.0f;
-    case PFPP_ACT_SILU: return v / (1.0f + expf(-v));
-    case PFPP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    default: return v;
-  }
-}
-
-// 16-byte global load of A/W elements [k, k+4) of one row, zero beyond K
-__device__ __forceinline__ float4 load_k4(const float* row, int k, int K, bool row_ok) {
+// 16-byte global load of elements [k, k+4) of one row, zero beyond K
+__device__ __forceinline__ float4 load_k4(const float* row, int k, int K) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row_ok && k < K) {
+  if (k < K) {
     v = *reinterpret_cast<const float4*>(row + k);
     if (k + 4 > K) {  // ragged tail: the padding of the row may hold anything
       if (k + 1 >= K) v.y = 0.f;
@@ -61,6 +48,9 @@ __device__ __forceinline__ float4 load_k4(const float* row, int k, int K, bool r
   return v;
 }
 
+// =================================================================================================
+// fp32-MFMA path
+// =================================================================================================
 template <int MT, int NT, bool WK>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
   constexpr int BM = 64 * MT;
@@ -78,12 +68,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware bijective remap of the tile id (cdna guide T1)
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int tile = remap_tile(blockIdx.x, gridDim.x);
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -93,9 +78,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
   const float* W = p.W + z0 * p.sW0 + z1 * p.sW1;
   const int64_t c_off = z0 * p.sC0 + z1 * p.sC1;
   const int64_t v_off = z0 * p.sV0 + z1 * p.sV1;
-  const float* bias = p.bias ? p.bias + v_off : nullptr;
-  const float* scale = p.scale ? p.scale + v_off : nullptr;
-  const float* shift = p.shift ? p.shift + v_off : nullptr;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -105,45 +87,56 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // ---- global -> register staging ---------------------------------------
+  // ---- global -> register staging (rows clamped into range: no predication in the main loop) ----
   float4 ra[A_IT], rw[W_IT];
   const int a_row = tid >> 3, a_c4 = tid & 7;  // 8 lanes cover one 128-byte row slice
-  auto load_tiles = [&](int k0) {
+  const float* a_ptr[A_IT];
+  const float* w_ptr[W_IT];
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int row = a_row + 32 * it;
-      const int gm = m0 + row;
-      ra[it] = load_k4(A + (int64_t)gm * p.lda, k0 + a_c4 * 4, p.K, gm < p.M);
-    }
-    if (!WK) {
+  for (int it = 0; it < A_IT; ++it) {
+    const int gm = min(m0 + a_row + 32 * it, p.M - 1);
+    a_ptr[it] = A + (int64_t)gm * p.lda + a_c4 * 4;
+  }
 #pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        const int row = a_row + 32 * it;
-        const int gn = n0 + row;
-        rw[it] = load_k4(W + (int64_t)gn * p.ldw, k0 + a_c4 * 4, p.K, gn < p.N);
-      }
-    } else {
-      constexpr int C4 = BN / 4;             // float4 per k-row
-      constexpr int RPI = 256 / C4;          // k-rows per iteration
+  for (int it = 0; it < W_IT; ++it) {
+    const int gn = min(n0 + a_row + 32 * it, p.N - 1);
+    w_ptr[it] = WK ? W : W + (int64_t)gn * p.ldw + a_c4 * 4;
+  }
+  auto load_full = [&](int k0) {   // a K-tile that lies completely inside K ([N,K] layout only)
 #pragma unroll
-      for (int it = 0; it < W_IT; ++it) {
-        const int kr = tid / C4 + RPI * it;
-        const int c4 = tid % C4;
-        const int gk = k0 + kr;
-        const int gn = n0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gk < p.K && gn < p.N) {
-          const float* src = W + (int64_t)gk * p.ldw + gn;
-          if (gn + 4 <= p.N) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            v.x = src[0];
-            if (gn + 1 < p.N) v.y = src[1];
-            if (gn + 2 < p.N) v.z = src[2];
-          }
+    for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) rw[it] = *reinterpret_cast<const float4*>(w_ptr[it] + k0);
+  };
+  auto load_wk = [&](int k0) {     // W stored [K,N]: rows are k (predicated on K), 16-byte column groups
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = 256 / C4;
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int gk = k0 + tid / C4 + RPI * it;
+      const int gn = n0 + (tid % C4) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < p.K && gn < p.N) {
+        const float* src = W + (int64_t)gk * p.ldw + gn;
+        if (gn + 4 <= p.N) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (gn + 1 < p.N) v.y = src[1];
+          if (gn + 2 < p.N) v.z = src[2];
         }
-        rw[it] = v;
       }
+      rw[it] = v;
+    }
+  };
+  auto load_tail = [&](int k0) {   // a possibly ragged K-tile
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+    if (WK) {
+      load_wk(k0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it) rw[it] = load_k4(w_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -165,171 +158,313 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
     }
   };
 
+  const int l31 = lane & 31, lhi = lane >> 5;
+  auto chunk = [&](const float* as, const float* ws, int kc) {
+    float4 a[MT], b[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      a[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kc * 8);
+    if (!WK) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const float4*>(ws + (wn * 32 * NT + j * 32 + l31) * LDS_LD + lhi * 4 + kc * 8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float* bp = ws + (kc * 8 + lhi * 4) * WLD + wn * 32 * NT + j * 32 + l31;
+        b[j].x = bp[0];
+        b[j].y = bp[WLD];
+        b[j].z = bp[2 * WLD];
+        b[j].w = bp[3 * WLD];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+  auto frag_base_a = [&](int buf) { return As + buf * BM * LDS_LD + (wm * 32 * MT + l31) * LDS_LD + lhi * 4; };
+
+  const int nk_full = WK ? 0 : p.K / BK;               // the [K,N] layout always takes the predicated path
   const int nk = (p.K + BK - 1) / BK;
-  load_tiles(0);
+
+  if (nk_full > 0) load_full(0); else load_tail(0);
   store_tiles(0);
   __syncthreads();
 
-  const int l31 = lane & 31, lhi = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
+  int kt = 0;
+  // steady state: full tile kt in LDS, full tile kt+1 being fetched — one basic block
+  for (; kt + 1 < nk_full; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-    const float* as = As + buf * BM * LDS_LD + (wm * 32 * MT + l31) * LDS_LD + lhi * 4;
+    load_full((kt + 1) * BK);
+    const float* as = frag_base_a(buf);
+    const float* ws = Ws + buf * W_TILE;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) chunk(as, ws, kc);
+    store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+  // remaining tiles: the last full one (prefetching a ragged tail if there is one), then the tail
+  for (; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool has_next = kt + 1 < nk;
+    if (has_next) load_tail((kt + 1) * BK);
+    const float* as = frag_base_a(buf);
     const float* ws = Ws + buf * W_TILE;
     const int krem = p.K - kt * BK;
     const int nchunk = krem >= BK ? 4 : (krem + 7) >> 3;
-    for (int kc = 0; kc < nchunk; ++kc) {
-      float4 a[MT], b[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kc * 8);
-      if (!WK) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          b[j] = *reinterpret_cast<const float4*>(ws + (wn * 32 * NT + j * 32 + l31) * LDS_LD +
-                                                  lhi * 4 + kc * 8);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float* bp = ws + (kc * 8 + lhi * 4) * WLD + wn * 32 * NT + j * 32 + l31;
-          b[j].x = bp[0];
-          b[j].y = bp[WLD];
-          b[j].z = bp[2 * WLD];
-          b[j].w = bp[3 * WLD];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    for (int kc = 0; kc < nchunk; ++kc) chunk(as, ws, kc);
+    if (has_next) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue -------------------------------------------------------------
-  // accumulator element e of a 32x32 tile: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)
-  float* C = p.C + c_off;
-  const float* R = p.residual ? p.residual + c_off : nullptr;
-  const float alpha = p.alpha;
+  epilogue<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
+}
 
-  if (p.act == PFPP_ACT_GEGLU) {
-    if constexpr (NT == 2) {
-      // value columns in tile j=0, their gate columns in tile j=1 (host packing)
-      const int ncol = n0 + wn * 64 + l31;            // packed value column
-      const int ocol = (n0 >> 1) + wn * 32 + l31;     // output column
-      const bool col_ok = ncol + 32 < p.N;
-      const float bu = (bias && col_ok) ? bias[ncol] : 0.0f;
-      const float bg = (bias && col_ok) ? bias[ncol + 32] : 0.0f;
+// =================================================================================================
+// split-f16 x3 path
+// =================================================================================================
+__device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (row < p.M && col_ok) {
-            const float u = acc[i][0][e] * alpha + bu;
-            const float g = acc[i][1][e] * alpha + bg;
-            C[(int64_t)row * p.ldc + ocol] = u * act_apply(g, PFPP_ACT_GELU);
-          }
-        }
-    }
-    return;
-  }
-
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * 32 * NT + j * 32 + l31;
-    const bool col_ok = col < p.N;
-    float sc = 1.0f, sh = 0.0f;
-    if (col_ok) {
-      if (scale) { sc = scale[col]; sh = shift[col]; }
-      else if (bias) { sh = bias[col]; }
-    }
-    if (p.pool == 0) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm * 32 * MT + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (row < p.M && col_ok) {
-            float v = acc[i][j][e] * alpha;
-            v = scale ? v * sc + sh : v + sh;
-            v = act_apply(v, p.act);
-            if (R) v += R[(int64_t)row * p.ldr + col];
-            C[(int64_t)row * p.ldc + col] = v;
-          }
-        }
-    } else {
-      // max over groups of `pool` consecutive rows (pool = 32: one MFMA tile,
-      // pool = 64: both M-tiles of the wave); groups never straddle M
-      float mx[MT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        float m = -__builtin_huge_valf();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] * alpha;
-          v = scale ? v * sc + sh : v + sh;
-          v = act_apply(v, p.act);
-          m = fmaxf(m, v);
-        }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        mx[i] = m;
-      }
-      if (p.pool == 64) {
-        if constexpr (MT == 2) {
-          const int row0 = m0 + wm * 64;
-          if (lhi == 0 && col_ok && row0 < p.M)
-            C[(int64_t)(row0 >> 6) * p.ldc + col] = fmaxf(mx[0], mx[1]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row0 = m0 + wm * 32 * MT + i * 32;
-          if (lhi == 0 && col_ok && row0 < p.M) C[(int64_t)(row0 >> 5) * p.ldc + col] = mx[i];
-        }
-      }
-    }
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 h = (_Float16)x[e];
+    hi[e] = h;
+    lo[e] = (_Float16)((x[e] - (float)h) * 2048.0f);
   }
 }
 
+template <int MT, int NT, bool WPRE>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
+  constexpr int BM = 64 * MT;
+  constexpr int BN = 64 * NT;
+  constexpr int A_IT = BM / 32;            // float4 loads per thread (fp32 source, 8 lanes per row)
+  constexpr int WF_IT = BN / 32;           // same for an fp32 W
+  constexpr int WH_IT = BN / 64;           // 16-byte (8-half) loads per thread and plane for a pre-split W
+  constexpr int PLANE_A = BM * LDH;        // halfs per plane
+  constexpr int PLANE_W = BN * LDH;
+  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;
+  extern __shared__ __align__(16) _Float16 gemm_smem_h[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int tile = remap_tile(blockIdx.x, gridDim.x);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int z = blockIdx.z;
+  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
+  const float* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+  const int64_t w_off = z0 * p.sW0 + z1 * p.sW1;
+  const int64_t c_off = z0 * p.sC0 + z1 * p.sC1;
+  const int64_t v_off = z0 * p.sV0 + z1 * p.sV1;
+
+  f32x16 accM[MT][NT], accC[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
+
+  // ---- staging registers and (clamped) source rows ---------------------------------------------
+  constexpr int NWF = WPRE ? 1 : WF_IT;
+  constexpr int NWH = WPRE ? WH_IT : 1;
+  float4 ra[A_IT];
+  float4 rwf[NWF];
+  uint4 rwh[NWH], rwl[NWH];
+  const int a_row = tid >> 3, a_c4 = tid & 7;
+  const int h_row = tid >> 2, h_c8 = tid & 3;    // pre-split W: 4 lanes x 8 halfs cover a 32-half row slice
+  const float* a_ptr[A_IT];
+  const float* wf_ptr[NWF];
+  const _Float16* wh_ptr[NWH];
+  const _Float16* wl_ptr[NWH];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int gm = min(m0 + a_row + 32 * it, p.M - 1);
+    a_ptr[it] = A + (int64_t)gm * p.lda + a_c4 * 4;
+  }
+  if constexpr (WPRE) {
+#pragma unroll
+    for (int it = 0; it < WH_IT; ++it) {
+      const int gn = min(n0 + h_row + 64 * it, p.N - 1);
+      wh_ptr[it] = reinterpret_cast<const _Float16*>(p.Whi) + w_off + (int64_t)gn * p.ldw + h_c8 * 8;
+      wl_ptr[it] = reinterpret_cast<const _Float16*>(p.Wlo) + w_off + (int64_t)gn * p.ldw + h_c8 * 8;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < WF_IT; ++it) {
+      const int gn = min(n0 + a_row + 32 * it, p.N - 1);
+      wf_ptr[it] = p.W + w_off + (int64_t)gn * p.ldw + a_c4 * 4;
+    }
+  }
+  auto load_full = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
+    if constexpr (WPRE) {
+#pragma unroll
+      for (int it = 0; it < WH_IT; ++it) {
+        rwh[it] = *reinterpret_cast<const uint4*>(wh_ptr[it] + k0);
+        rwl[it] = *reinterpret_cast<const uint4*>(wl_ptr[it] + k0);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < WF_IT; ++it) rwf[it] = *reinterpret_cast<const float4*>(wf_ptr[it] + k0);
+    }
+  };
+  auto load_tail = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+    if constexpr (WPRE) {
+      // the planes are zero-padded to a multiple of 8 halfs per row (host packing): whole
+      // 16-byte groups are either inside the padded row or skipped
+      const bool ok = k0 + h_c8 * 8 < (int)p.ldw;
+#pragma unroll
+      for (int it = 0; it < WH_IT; ++it) {
+        rwh[it] = ok ? *reinterpret_cast<const uint4*>(wh_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
+        rwl[it] = ok ? *reinterpret_cast<const uint4*>(wl_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < WF_IT; ++it) rwf[it] = load_k4(wf_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    _Float16* st = gemm_smem_h + buf * STAGE;
+    _Float16* ahi = st, *alo = st + PLANE_A, *whi = st + 2 * PLANE_A, *wlo = st + 2 * PLANE_A + PLANE_W;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      half4 hi, lo;
+      split4(ra[it], hi, lo);
+      const int off = (a_row + 32 * it) * LDH + a_c4 * 4;
+      *reinterpret_cast<half4*>(ahi + off) = hi;
+      *reinterpret_cast<half4*>(alo + off) = lo;
+    }
+    if constexpr (WPRE) {
+#pragma unroll
+      for (int it = 0; it < WH_IT; ++it) {
+        const int off = (h_row + 64 * it) * LDH + h_c8 * 8;
+        *reinterpret_cast<uint4*>(whi + off) = rwh[it];
+        *reinterpret_cast<uint4*>(wlo + off) = rwl[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < WF_IT; ++it) {
+        half4 hi, lo;
+        split4(rwf[it], hi, lo);
+        const int off = (a_row + 32 * it) * LDH + a_c4 * 4;
+        *reinterpret_cast<half4*>(whi + off) = hi;
+        *reinterpret_cast<half4*>(wlo + off) = lo;
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const _Float16* st = gemm_smem_h + buf * STAGE;
+    const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
+    const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(a_base + i * 32 * LDH + ks * 16);
+        al[i] = *reinterpret_cast<const half8*>(a_base + PLANE_A + i * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(w_base + j * 32 * LDH + ks * 16);
+        bl[j] = *reinterpret_cast<const half8*>(w_base + PLANE_W + j * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk_full = p.K / BK;
+  const int nk = (p.K + BK - 1) / BK;
+  if (nk_full > 0) load_full(0); else load_tail(0);
+  store_tiles(0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk_full; ++kt) {        // steady state: one basic block
+    load_full((kt + 1) * BK);
+    compute(kt & 1);
+    store_tiles((kt & 1) ^ 1);
+    __syncthreads();
+  }
+  for (; kt < nk; ++kt) {
+    const bool has_next = kt + 1 < nk;
+    if (has_next) load_tail((kt + 1) * BK);
+    compute(kt & 1);                      // a ragged tile was zero-filled: the extra products are zeros
+    if (has_next) store_tiles((kt & 1) ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accM[i][j][e] += accC[i][j][e] * (1.0f / 2048.0f);
+  epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
+}
+
+// =================================================================================================
+template <typename K>
+int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set) {
+  if (!*attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    *attr_set = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  return pfpp::check_launch("pfpp_gemm");
+}
+
 template <int MT, int NT, bool WK>
-int launch_gemm(const GemmP& p, int batch, hipStream_t st) {
+int launch_f32(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr size_t smem = (size_t)(2 * BM * LDS_LD + 2 * (WK ? BK * BN : BN * LDS_LD)) * sizeof(float);
   static bool attr_set = false;
-  auto kern = gemm_f32_mfma_kernel<MT, NT, WK>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  GemmP q = p;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  q.tiles_n = (p.N + BN - 1) / BN;
-  const dim3 grid((unsigned)(tiles_m * q.tiles_n), 1, (unsigned)batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
-  return pfpp::check_launch("pfpp_gemm");
+  return launch(gemm_f32_mfma_kernel<MT, NT, WK>, smem, p, BM, BN, batch, st, &attr_set);
+}
+
+template <int MT, int NT, bool WPRE>
+int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
+  static bool attr_set = false;
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE>, smem, p, BM, BN, batch, st, &attr_set);
 }
 
 }  // namespace
 
 extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
-  PFPP_REQUIRE(a && a->A && a->W && a->C, "null pointer");
+  PFPP_REQUIRE(a && a->A && a->C, "null pointer");
+  PFPP_REQUIRE(a->W || (a->w_hi && a->w_lo), "W (or its pre-split planes) missing");
   PFPP_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "bad sizes");
   PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
-  PFPP_REQUIRE(a->lda % 4 == 0 && a->ldw % 4 == 0, "lda/ldw must be multiples of 4");
-  PFPP_REQUIRE(pfpp::aligned16(a->A) && pfpp::aligned16(a->W), "A/W must be 16-byte aligned");
+  PFPP_REQUIRE(a->lda % 4 == 0 && pfpp::aligned16(a->A), "lda must be a multiple of 4 and A 16-byte aligned");
   PFPP_REQUIRE(a->lda >= ((a->K + 3) & ~3ll), "lda smaller than K rounded up to 4");
-  PFPP_REQUIRE(a->w_kmajor ? a->ldw >= a->N : a->ldw >= ((a->K + 3) & ~3ll), "ldw too small");
   PFPP_REQUIRE(a->batch >= 1 && a->zdiv >= 1, "batch/zdiv must be >= 1");
-  PFPP_REQUIRE((a->sA0 % 4 == 0) && (a->sA1 % 4 == 0) && (a->sW0 % 4 == 0) && (a->sW1 % 4 == 0),
-               "batch strides of A/W must keep 16-byte alignment");
+  PFPP_REQUIRE((a->sA0 % 4 == 0) && (a->sA1 % 4 == 0), "batch strides of A must keep 16-byte alignment");
   PFPP_REQUIRE(!a->scale || a->shift, "scale without shift");
   PFPP_REQUIRE(!a->residual || a->ldr > 0, "residual without ldr");
   PFPP_REQUIRE(a->pool == 0 || a->pool == 32 || a->pool == 64, "pool must be 0, 32 or 64");
@@ -337,10 +472,22 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a->act >= PFPP_ACT_NONE && a->act <= PFPP_ACT_GEGLU, "unknown activation");
   PFPP_REQUIRE(a->act != PFPP_ACT_GEGLU || (a->N % 64 == 0 && a->pool == 0 && !a->scale && !a->residual),
                "GEGLU: N % 64 != 0 or unsupported epilogue combination");
+  PFPP_REQUIRE(a->precision == PFPP_GEMM_F32 || a->precision == PFPP_GEMM_F16X3, "unknown precision");
+  const bool pre = a->w_hi != nullptr;
+  if (pre) {
+    PFPP_REQUIRE(a->precision == PFPP_GEMM_F16X3 && a->w_lo && !a->w_kmajor, "pre-split W needs the f16x3 path, [N,K] layout");
+    PFPP_REQUIRE(a->ldw % 8 == 0 && a->ldw >= ((a->K + 7) & ~7ll), "pre-split W: ldw (halfs) must be K rounded up to 8");
+    PFPP_REQUIRE(pfpp::aligned16(a->w_hi) && pfpp::aligned16(a->w_lo) && a->sW0 % 8 == 0 && a->sW1 % 8 == 0,
+                 "pre-split W planes must be 16-byte aligned");
+  } else {
+    PFPP_REQUIRE(a->ldw % 4 == 0 && pfpp::aligned16(a->W), "ldw must be a multiple of 4 and W 16-byte aligned");
+    PFPP_REQUIRE(a->w_kmajor ? a->ldw >= a->N : a->ldw >= ((a->K + 3) & ~3ll), "ldw too small");
+    PFPP_REQUIRE((a->sW0 % 4 == 0) && (a->sW1 % 4 == 0), "batch strides of W must keep 16-byte alignment");
+  }
   if (a->M == 0) return PFPP_OK;
 
   GemmP p;
-  p.A = a->A; p.W = a->W; p.C = a->C;
+  p.A = a->A; p.W = a->W; p.C = a->C; p.Whi = a->w_hi; p.Wlo = a->w_lo;
   p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.residual = a->residual;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
@@ -351,10 +498,14 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.tiles_n = 0;
   hipStream_t st = pfpp::as_stream(stream);
 
-  // 128x128 tiles unless N is narrow (or GEGLU / pool=64 need the 2-tile wave shape)
+  // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)
   const bool wide = a->N > 64 || a->act == PFPP_ACT_GEGLU;
-  if (a->w_kmajor) {
-    return wide ? launch_gemm<2, 2, true>(p, a->batch, st) : launch_gemm<2, 1, true>(p, a->batch, st);
+  if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
+    if (pre) return wide ? launch_f16x3<2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
+    return wide ? launch_f16x3<2, 2, false>(p, a->batch, st) : launch_f16x3<2, 1, false>(p, a->batch, st);
   }
-  return wide ? launch_gemm<2, 2, false>(p, a->batch, st) : launch_gemm<2, 1, false>(p, a->batch, st);
+  if (a->w_kmajor) {
+    return wide ? launch_f32<2, 2, true>(p, a->batch, st) : launch_f32<2, 1, true>(p, a->batch, st);
+  }
+  return wide ? launch_f32<2, 2, false>(p, a->batch, st) : launch_f32<2, 1, false>(p, a->batch, st);
 }

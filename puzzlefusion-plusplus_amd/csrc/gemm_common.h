@@ -1,0 +1,132 @@
+// Shared pieces of the two GEMM kernels (fp32-MFMA exact path, split-f16 x3 path): launch
+// parameters, tile-id remap, and the fused epilogue (bias / BN scale+shift / activation / GEGLU gate /
+// residual / max over row groups).  Accumulator layout of a 32x32 MFMA tile (dtype independent on
+// gfx950): element e of lane l is C[row = (e&3) + 8*(e>>2) + 4*(l>>5)][col = l&31].
+#pragma once
+#include "pfpp_common.h"
+
+namespace pfpp_gemm_detail {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmP {
+  const float* A; const float* W; float* C;
+  const void* Whi; const void* Wlo;          // pre-split fp16 planes of W (split path) or null
+  const float* bias; const float* scale; const float* shift; const float* residual;
+  int M, N, K;
+  int64_t lda, ldw, ldc, ldr;
+  int act, pool, zdiv;
+  int64_t sA0, sA1, sW0, sW1, sC0, sC1, sV0, sV1;
+  float alpha;
+  int tiles_n;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case PFPP_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case PFPP_ACT_SILU: return v / (1.0f + expf(-v));
+    case PFPP_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+// XCD-aware bijective remap of the workgroup id: consecutive tiles (same A row panel) land on
+// the same XCD and share its L2 (cdna guide T1, bijective form)
+__device__ __forceinline__ int remap_tile(int bid, int nwg) {
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// acc[i][j]: MT x NT tiles of the wave whose top-left element is (row_w, col_w)
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int row_w, int col_w,
+                                         int n0, int wn, int lane, int64_t c_off, int64_t v_off) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* C = p.C + c_off;
+  const float* R = p.residual ? p.residual + c_off : nullptr;
+  const float* bias = p.bias ? p.bias + v_off : nullptr;
+  const float* scale = p.scale ? p.scale + v_off : nullptr;
+  const float* shift = p.shift ? p.shift + v_off : nullptr;
+  const float alpha = p.alpha;
+
+  if (p.act == PFPP_ACT_GEGLU) {
+    if constexpr (NT == 2) {
+      // value columns in tile j=0, their gate columns in tile j=1 (host packing)
+      const int ncol = col_w + l31;                   // packed value column
+      const int ocol = (n0 >> 1) + wn * 32 + l31;     // output column
+      const bool col_ok = ncol + 32 < p.N;
+      const float bu = (bias && col_ok) ? bias[ncol] : 0.0f;
+      const float bg = (bias && col_ok) ? bias[ncol + 32] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (row < p.M && col_ok) {
+            const float u = acc[i][0][e] * alpha + bu;
+            const float g = acc[i][1][e] * alpha + bg;
+            C[(int64_t)row * p.ldc + ocol] = u * act_apply(g, PFPP_ACT_GELU);
+          }
+        }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col_w + j * 32 + l31;
+    const bool col_ok = col < p.N;
+    float sc = 1.0f, sh = 0.0f;
+    if (col_ok) {
+      if (scale) { sc = scale[col]; sh = shift[col]; }
+      else if (bias) { sh = bias[col]; }
+    }
+    if (p.pool == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (row < p.M && col_ok) {
+            float v = acc[i][j][e] * alpha;
+            v = scale ? v * sc + sh : v + sh;
+            v = act_apply(v, p.act);
+            if (R) v += R[(int64_t)row * p.ldr + col];
+            C[(int64_t)row * p.ldc + col] = v;
+          }
+        }
+    } else {
+      // max over groups of `pool` consecutive rows (pool = 32: one MFMA tile, pool = 64: both
+      // M-tiles of the wave); groups never straddle M
+      float mx[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] * alpha;
+          v = scale ? v * sc + sh : v + sh;
+          v = act_apply(v, p.act);
+          m = fmaxf(m, v);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        mx[i] = m;
+      }
+      if (p.pool == 64) {
+        if constexpr (MT == 2) {
+          if (lhi == 0 && col_ok && row_w < p.M)
+            C[(int64_t)(row_w >> 6) * p.ldc + col] = fmaxf(mx[0], mx[1]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row0 = row_w + i * 32;
+          if (lhi == 0 && col_ok && row0 < p.M) C[(int64_t)(row0 >> 5) * p.ldc + col] = mx[i];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pfpp_gemm_detail

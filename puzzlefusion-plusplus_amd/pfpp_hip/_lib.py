@@ -21,11 +21,12 @@ class GemmArgs(C.Structure):
 
     _fields_ = [
         ("A", _p), ("W", _p), ("C", _p),
+        ("w_hi", _p), ("w_lo", _p),
         ("bias", _p), ("scale", _p), ("shift", _p), ("residual", _p),
         ("M", _i64), ("N", _i64), ("K", _i64),
         ("lda", _i64), ("ldw", _i64), ("ldc", _i64), ("ldr", _i64),
         ("w_kmajor", _i32), ("act", _i32), ("pool", _i32),
-        ("batch", _i32), ("zdiv", _i32),
+        ("batch", _i32), ("zdiv", _i32), ("precision", _i32),
         ("sA0", _i64), ("sA1", _i64), ("sW0", _i64), ("sW1", _i64), ("sC0", _i64), ("sC1", _i64),
         ("sV0", _i64), ("sV1", _i64),
         ("alpha", _f32),

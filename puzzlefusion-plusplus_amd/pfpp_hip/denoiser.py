@@ -15,15 +15,15 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .packing import pack_geglu, pad_k, round_up
+from .packing import PW, pack_geglu, round_up
 
 
 def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, torch.Tensor]:
     """sd: live tensors of a DenoiserTransformer keyed by state_dict names"""
     pk: Dict[str, torch.Tensor] = {}
-    pk["shape.w"] = pad_k(sd["shape_embedding.weight"])
+    pk["shape.w"] = PW(sd["shape_embedding.weight"])
     pk["shape.b"] = sd["shape_embedding.bias"].contiguous()
-    pk["param.w"] = pad_k(sd["param_fc.weight"])
+    pk["param.w"] = PW(sd["param_fc.weight"])
     pk["param.b"] = sd["param_fc.bias"].contiguous()
     pk["ref_emb"] = sd["ref_part_emb.weight"].contiguous()
     pk["pe"] = sd["pos_encoding.pe"][0].contiguous()
@@ -35,22 +35,23 @@ def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, tor
             lw.append(sd[f"{p}.{n}.linear.weight"])
             lb.append(sd[f"{p}.{n}.linear.bias"])
         for a in ("self_attn", "global_attn"):
-            pk[f"{i}.{a}.wqkv"] = torch.cat(
+            pk[f"{i}.{a}.wqkv"] = PW(torch.cat(
                 [sd[f"{p}.{a}.to_q.weight"], sd[f"{p}.{a}.to_k.weight"], sd[f"{p}.{a}.to_v.weight"]], dim=0
-            ).contiguous()
-            pk[f"{i}.{a}.wo"] = sd[f"{p}.{a}.to_out.0.weight"].contiguous()
+            ).contiguous())
+            pk[f"{i}.{a}.wo"] = PW(sd[f"{p}.{a}.to_out.0.weight"].contiguous())
             pk[f"{i}.{a}.bo"] = sd[f"{p}.{a}.to_out.0.bias"].contiguous()
         pk[f"{i}.norm3.g"] = sd[f"{p}.norm3.weight"].contiguous()
         pk[f"{i}.norm3.b"] = sd[f"{p}.norm3.bias"].contiguous()
-        pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"] = pack_geglu(sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"])
-        pk[f"{i}.ff.w2"] = sd[f"{p}.ff.net.2.weight"].contiguous()
+        w1, pk[f"{i}.ff.b1"] = pack_geglu(sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"])
+        pk[f"{i}.ff.w1"] = PW(w1)
+        pk[f"{i}.ff.w2"] = PW(sd[f"{p}.ff.net.2.weight"].contiguous())
         pk[f"{i}.ff.b2"] = sd[f"{p}.ff.net.2.bias"].contiguous()
     pk["ada.tables"] = torch.stack(tabs, 0).contiguous()   # [2*layers, n_emb, C]
-    pk["ada.w"] = torch.stack(lw, 0).contiguous()          # [2*layers, 2C, C]
+    pk["ada.w"] = PW(torch.stack(lw, 0).contiguous())      # [2*layers, 2C, C]
     pk["ada.b"] = torch.stack(lb, 0).contiguous()          # [2*layers, 2C]
     for h in ("mlp_out_trans", "mlp_out_rot"):
         for j in (0, 2, 4):
-            pk[f"{h}.{j}.w"] = sd[f"{h}.{j}.weight"].contiguous()
+            pk[f"{h}.{j}.w"] = PW(sd[f"{h}.{j}.weight"].contiguous())
             pk[f"{h}.{j}.b"] = sd[f"{h}.{j}.bias"].contiguous()
     return pk
 
@@ -98,7 +99,7 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
     n_ada = 2 * num_layers
     se = ops.silu_embed(pk["ada.tables"], timesteps.to(torch.int64).contiguous())
     mods = torch.empty((n_ada, B, 2 * C), dtype=torch.float32, device=h.device)
-    ops.gemm(se, pk["ada.w"], M=B, N=2 * C, K=C, lda=C, ldw=C, out=mods, ldc=2 * C, bias=pk["ada.b"],
+    ops.gemm(se, pk["ada.w"], M=B, N=2 * C, K=C, lda=C, out=mods, ldc=2 * C, bias=pk["ada.b"],
              batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
     key_valid = part_valids.reshape(B, P).to(torch.bool).repeat_interleave(L, dim=1).to(torch.uint8).contiguous()
     att_scale = 1.0 / math.sqrt(dh)
@@ -108,16 +109,16 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
         ops.layernorm(h, mod=mods[2 * i], rows_per_batch=T, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
         att = ops.attn_blockdiag(qkv, n, L, num_heads, dh, att_scale)
-        ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C,
+        ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
                  bias=pk[f"{i}.self_attn.bo"], residual=h, ldr=C)
         ops.layernorm(h, mod=mods[2 * i + 1], rows_per_batch=T, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
         dense_attention(qkv, B, T, num_heads, dh, key_valid, att_scale, out=att)
-        ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C,
+        ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
                  bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
         u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu")
-        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=u.shape[1], lda=u.shape[1], ldw=u.shape[1], out=h, ldc=C,
+        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=u.shape[1], lda=u.shape[1], out=h, ldc=C,
                  bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
         if capture is not None:
             capture[f"layer{i}"] = h.clone()
@@ -126,6 +127,6 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
     for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
         v = ops.linear(pooled, pk[f"{name}.0.w"], pk[f"{name}.0.b"], act="silu")
         v = ops.linear(v, pk[f"{name}.2.w"], pk[f"{name}.2.b"], act="silu")
-        ops.gemm(v, pk[f"{name}.4.w"], M=n, N=width, K=v.shape[1], lda=v.shape[1], ldw=v.shape[1], out=out, ldc=7,
+        ops.gemm(v, pk[f"{name}.4.w"], M=n, N=width, K=v.shape[1], lda=v.shape[1], out=out, ldc=7,
                  bias=pk[f"{name}.4.b"], c_off=c0)
     return out.view(B, P, 7)

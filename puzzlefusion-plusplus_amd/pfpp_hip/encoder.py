@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .packing import fold_conv_bn, pack_sa_first
+from .packing import PW, fold_conv_bn, pack_sa_first
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
@@ -31,11 +31,11 @@ def pack_encoder(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, tor
             )
             if i == 0:
                 w = pack_sa_first(w, w.shape[1] - 3)
-            out[f"{name}.w{i}"] = w.contiguous()
+            out[f"{name}.w{i}"] = PW(w.contiguous())
             out[f"{name}.s{i}"] = s
             out[f"{name}.t{i}"] = t
     w6 = sd[f"{prefix}pn2.conv6.weight"]
-    out["conv6.w"] = w6.reshape(w6.shape[0], -1).contiguous()
+    out["conv6.w"] = PW(w6.reshape(w6.shape[0], -1).contiguous())
     out["conv6.b"] = sd[f"{prefix}pn2.conv6.bias"].contiguous()
     out["codebook"] = sd[f"{prefix}vector_quantization.embedding.weight"].contiguous()
     return out
@@ -75,7 +75,7 @@ def encode_valid(pk, pts: torch.Tensor, num_point: int = 25, max_frag: int = 204
     """VQVAE.encode on a dense list of fragments [F,N,3] -> {"z_q": [F,L,64], "xyz": [F,L,3]}"""
     F = pts.shape[0]
     slot = torch.arange(F, dtype=torch.int32, device=pts.device)
-    z_q = torch.empty((F, num_point, pk["conv6.w"].shape[0]), dtype=torch.float32, device=pts.device)
+    z_q = torch.empty((F, num_point, pk["conv6.w"].N), dtype=torch.float32, device=pts.device)
     xyz_out = torch.empty((F, num_point, 3), dtype=torch.float32, device=pts.device)
     for f0 in range(0, F, max_frag):
         f1 = min(F, f0 + max_frag)
@@ -93,7 +93,7 @@ def extract_features(pk, part_pcs: torch.Tensor, pose: torch.Tensor, slot: torch
     B, P, N, _ = part_pcs.shape
     n_slots = B * P
     dev = part_pcs.device
-    latent = torch.zeros((n_slots, num_point, pk["conv6.w"].shape[0]), dtype=torch.float32, device=dev)
+    latent = torch.zeros((n_slots, num_point, pk["conv6.w"].N), dtype=torch.float32, device=dev)
     xyz_out = torch.zeros((n_slots, num_point, 3), dtype=torch.float32, device=dev)
     pcs_flat = part_pcs.view(n_slots, N, 3)
     pose_flat = pose.reshape(n_slots, 7).contiguous()

@@ -122,28 +122,55 @@ def group_gather(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch
 
 
 # --------------------------------------------------------------------------- GEMM
+# "f16x3": split-f16 contraction (3 x v_mfma_f32_32x32x16_f16, fp32-grade error, needs |x| < 65504);
+# "f32": exact fp32 MFMA.  PFPP_GEMM=f32 in the environment selects the exact path.
+import os as _os
+
+GEMM_MODE = _os.environ.get("PFPP_GEMM", "f16x3")
+PRECISION = {"f32": 0, "f16x3": 1}
+
 # When set to a list, every pfpp_gemm launch appends (start_event, end_event, flops, kernel_name):
 # bench.py uses it to time the dominant kernel with HIP events on the launch stream.
 GEMM_TRACE = None
 
 
-def gemm_kernel_name(N: int, act: str, w_kmajor: bool) -> str:
+def gemm_kernel_name(N: int, act: str, w_kmajor: bool, f16x3: bool = False, presplit: bool = False) -> str:
     """which template instantiation csrc/gemm.hip dispatches to (mirror of pfpp_gemm's choice)"""
     wide = N > 64 or act == "geglu"
+    if f16x3 and not w_kmajor:
+        return f"gemm_f16x3_kernel<2,{2 if wide else 1},{'true' if presplit else 'false'}>"
     return f"gemm_f32_mfma_kernel<2,{2 if wide else 1},{'true' if w_kmajor else 'false'}>"
 
 
-def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
+def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[int] = None,
          out: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
          shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          ldr: int = 0, act: str = "none", pool: int = 0, w_kmajor: bool = False,
          batch: int = 1, zdiv: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sV=(0, 0), alpha: float = 1.0,
-         a_off: int = 0, w_off: int = 0, c_off: int = 0) -> torch.Tensor:
+         a_off: int = 0, w_off: int = 0, c_off: int = 0, mode: Optional[str] = None) -> torch.Tensor:
     """Raw pfpp_gemm call.  A/W/out are base tensors; *_off are element offsets into them
-    (used to address q/k/v slices of a packed projection without copies)."""
-    for t, nm in ((A, "A"), (W, "W")):
-        _chk(t, torch.float32, nm)
+    (used to address q/k/v slices of a packed projection without copies).  W is an fp32 tensor or a
+    packing.PW (fp32 + pre-split fp16 planes); `mode` overrides ops.GEMM_MODE for this call."""
+    from .packing import PW
+
+    mode = mode or GEMM_MODE
+    f16x3 = mode == "f16x3" and not w_kmajor
+    planes = None
+    if isinstance(W, PW):
+        if f16x3:
+            planes = (W.hi, W.lo)
+            if ldw is None:
+                ldw = W.hi.shape[-1]
+            elif ldw != W.hi.shape[-1]:
+                raise ValueError("gemm: ldw does not match the pre-split planes")
+        else:
+            if ldw is None:
+                ldw = W.f32.shape[-1]
+        W = W.f32
+    if ldw is None:
+        ldw = W.shape[-1]
+    _chk(A, torch.float32, "A"); _chk(W, torch.float32, "W")
     n_out_cols = N // 2 if act == "geglu" else N
     if out is None:
         rows = M // pool if pool else M
@@ -163,6 +190,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, 
     args = GemmArgs()
     args.A = A.data_ptr() + a_off * es
     args.W = W.data_ptr() + w_off * es
+    args.w_hi = 0 if planes is None else planes[0].data_ptr() + w_off * 2
+    args.w_lo = 0 if planes is None else planes[1].data_ptr() + w_off * 2
+    args.precision = PRECISION["f16x3" if f16x3 else "f32"]
     args.C = out.data_ptr() + c_off * es
     args.bias = 0 if bias is None else bias.data_ptr()
     args.scale = 0 if scale is None else scale.data_ptr()
@@ -184,22 +214,33 @@ def gemm(A: torch.Tensor, W: torch.Tensor, *, M: int, N: int, K: int, lda: int, 
         e0.record()
         check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
         e1.record()
-        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, gemm_kernel_name(N, act, w_kmajor)))
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, gemm_kernel_name(N, act, w_kmajor, f16x3, planes is not None),
+                           (M, N, K, batch, act, pool)))
         return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
     return out
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: str = "none",
+def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str = "none",
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, pool: int = 0, K: Optional[int] = None) -> torch.Tensor:
-    """y = epilogue(x @ w^T): x [M, ldx] (first K columns used), w [N, ldw] packed with ldw % 4 == 0."""
+           residual: Optional[torch.Tensor] = None, pool: int = 0, K: Optional[int] = None,
+           mode: Optional[str] = None) -> torch.Tensor:
+    """y = epilogue(x @ w^T): x [M, ldx] (first K columns used); w = packing.PW or an fp32 tensor
+    [N, ldw] with ldw % 4 == 0."""
+    from .packing import PW
+
     M, ldx = x.shape
-    N, ldw = w.shape
-    if K is None:
-        K = min(ldx, ldw)
-    return gemm(x, w, M=M, N=N, K=K, lda=ldx, ldw=ldw, bias=bias, scale=scale, shift=shift,
-                residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool)
+    if isinstance(w, PW):
+        N = w.N
+        if K is None:
+            K = w.K
+    else:
+        N, ldw = w.shape
+        if K is None:
+            K = min(ldx, ldw)
+    return gemm(x, w, M=M, N=N, K=K, lda=ldx, bias=bias, scale=scale, shift=shift,
+                residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool,
+                mode=mode)
 
 
 # --------------------------------------------------------------------------- VQ

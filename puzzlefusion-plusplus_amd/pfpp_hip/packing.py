@@ -26,6 +26,38 @@ def pad_k(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
     return out
 
 
+def split_f16(w: torch.Tensor):
+    """fp32 [..., N, K] -> (hi, lo) fp16 planes [..., N, round_up(K, 8)] for the split-f16 GEMM:
+    hi = f16(w), lo = f16((w - hi) * 2048); zero padded (csrc/gemm.hip, PFPP_GEMM_F16X3)"""
+    k = w.shape[-1]
+    kp = round_up(k, 8)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    if kp != k:
+        pad = (0, kp - k)
+        hi = torch.nn.functional.pad(hi, pad)
+        lo = torch.nn.functional.pad(lo, pad)
+    return hi.contiguous(), lo.contiguous()
+
+
+class PW:
+    """a GEMM weight in kernel layout: fp32 [N, K4] (K padded to 4) for the exact path and the
+    pre-split fp16 planes [N, K8] for the split-f16 path; `K` is the true reduction length"""
+
+    __slots__ = ("f32", "hi", "lo", "N", "K")
+
+    def __init__(self, w: torch.Tensor, K: int = None):
+        w2 = w.reshape(-1, w.shape[-1])
+        self.K = int(K if K is not None else w.shape[-1])
+        self.N = int(w.shape[-2])
+        self.f32 = pad_k(w2).reshape(*w.shape[:-1], -1).contiguous()
+        self.hi, self.lo = split_f16(w[..., : self.K] if self.K != w.shape[-1] else w)
+
+    @property
+    def device(self):
+        return self.f32.device
+
+
 def fold_conv_bn(conv_w, conv_b, bn_w, bn_b, mean, var, eps: float = 1e-5):
     """eval-mode BatchNorm folded into a per-channel scale/shift applied to the raw GEMM
     accumulator:  bn(conv(x)) = acc*s + ((b - mean)*s + beta),  s = gamma / sqrt(var + eps)

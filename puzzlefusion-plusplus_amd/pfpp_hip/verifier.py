@@ -13,12 +13,12 @@ import torch.nn.functional as Fnn
 
 from . import ops
 from .denoiser import dense_attention
-from .packing import pad_k
+from .packing import PW, round_up
 
 
 def pack_verifier(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, torch.Tensor]:
     pk: Dict[str, torch.Tensor] = {}
-    pk["feat.w"] = pad_k(sd["edge_feature_emb.weight"])          # [C, 8]
+    pk["feat.w"] = PW(sd["edge_feature_emb.weight"])             # fp32 [C, 8], planes [C, 8]
     pk["feat.b"] = sd["edge_feature_emb.bias"].contiguous()
     pk["pe"] = sd["edge_indices_pe.pe"][0].contiguous()          # [max_len, C/2]
     for i in range(num_layers):
@@ -29,8 +29,9 @@ def pack_verifier(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, tor
             ("linear1.weight", "w1"), ("linear1.bias", "b1"), ("linear2.weight", "w2"), ("linear2.bias", "b2"),
             ("norm1.weight", "g1"), ("norm1.bias", "be1"), ("norm2.weight", "g2"), ("norm2.bias", "be2"),
         ):
-            pk[f"{i}.{k_dst}"] = sd[f"{p}.{k_src}"].contiguous()
-    pk["out.w"] = sd["mlp_out.weight"].contiguous()
+            t = sd[f"{p}.{k_src}"].contiguous()
+            pk[f"{i}.{k_dst}"] = PW(t) if k_dst in ("wqkv", "wo", "w1", "w2") else t
+    pk["out.w"] = PW(sd["mlp_out.weight"].contiguous())
     pk["out.b"] = sd["mlp_out.bias"].contiguous()
     return pk
 
@@ -42,7 +43,7 @@ def verifier_forward(pk, edge_features: torch.Tensor, edge_indices: torch.Tensor
     C = pk["feat.b"].numel()
     dh = C // num_heads
     M = B * E
-    kp = pk["feat.w"].shape[1]
+    kp = round_up(nf, 4)
     feats = Fnn.pad(edge_features.reshape(M, nf).to(torch.float32), (0, kp - nf)).contiguous()  # 7 -> 8 columns
     fe = ops.linear(feats, pk["feat.w"], pk["feat.b"])
     h = ops.verifier_embed(fe, edge_indices.reshape(M, 2).to(torch.int64).contiguous(), pk["pe"])
@@ -52,10 +53,10 @@ def verifier_forward(pk, edge_features: torch.Tensor, edge_indices: torch.Tensor
     for i in range(num_layers):
         qkv = ops.linear(h, pk[f"{i}.wqkv"], pk[f"{i}.bqkv"])
         dense_attention(qkv, B, E, num_heads, dh, key_valid, scale, out=att)
-        ops.gemm(att, pk[f"{i}.wo"], M=M, N=C, K=C, lda=C, ldw=C, out=h, ldc=C, bias=pk[f"{i}.bo"], residual=h, ldr=C)
+        ops.gemm(att, pk[f"{i}.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C, bias=pk[f"{i}.bo"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.g1"], beta=pk[f"{i}.be1"], out=h)
         f = ops.linear(h, pk[f"{i}.w1"], pk[f"{i}.b1"], act="gelu")
-        ops.gemm(f, pk[f"{i}.w2"], M=M, N=C, K=f.shape[1], lda=f.shape[1], ldw=f.shape[1], out=h, ldc=C,
+        ops.gemm(f, pk[f"{i}.w2"], M=M, N=C, K=f.shape[1], lda=f.shape[1], out=h, ldc=C,
                  bias=pk[f"{i}.b2"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.g2"], beta=pk[f"{i}.be2"], out=h)
     out = ops.linear(h, pk["out.w"], pk["out.b"])

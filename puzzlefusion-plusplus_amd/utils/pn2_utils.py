@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from pfpp_hip import ops
-from pfpp_hip.packing import PackCache, fold_conv_bn, pack_sa_first
+from pfpp_hip.packing import PW, PackCache, fold_conv_bn, pack_sa_first
 
 
 def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -102,7 +102,7 @@ class PointNetSetAbstraction(nn.Module):
                 w, s, t = fold_conv_bn(c.weight, c.bias, b.weight, b.bias, b.running_mean, b.running_var, b.eps)
                 if i == 0:
                     w = pack_sa_first(w, w.shape[1] - 3)
-                pk[f"w{i}"], pk[f"s{i}"], pk[f"t{i}"] = w.contiguous(), s, t
+                pk[f"w{i}"], pk[f"s{i}"], pk[f"t{i}"] = PW(w.contiguous()), s, t
             return pk
 
         return self._cache.get(srcs, build)

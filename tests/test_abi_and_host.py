@@ -44,7 +44,7 @@ def test_gemm_args_struct_matches_header():
         parts = decl.replace("*", " ").split()
         decl_names = " ".join(parts).split(" ", 2)
         # strip the type tokens: everything after the last type keyword, comma separated
-        m = re.match(r"(?:const\s+)?(?:float|int64_t|int32_t)\s*\*?\s*(.*)", decl)
+        m = re.match(r"(?:const\s+)?(?:float|void|int64_t|int32_t)\s*\*?\s*(.*)", decl)
         names += [n.strip(" *") for n in m.group(1).split(",")]
     assert names == [f[0] for f in GemmArgs._fields_]
 

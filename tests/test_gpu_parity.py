@@ -261,12 +261,20 @@ def test_sampler_steps_vs_oracle_teacher_forced(weights_sd, dev, oracle_lib):
         x_o = sched.step(eps_o, t, x, noises[i]); x_o[ref] = reference[ref]
         xd = x.to(dev)
         lat, xyz = model._extract_features(gb["part_pcs"], gb["part_valids"], xd)
-        eps = model.denoiser(xd, torch.full((2,), t, device=dev), lat, xyz, gb["part_valids"], gb["part_scale"], gb["ref_part"])
+        assert torch.equal(xyz.cpu(), xyz_o), f"step {i}: FPS/rotate diverged"
+        # a VQ code may only differ where the oracle's own top-2 distance gap is at rounding level
+        cap = {}
+        O.vqvae_encode(weights_sd("vqvae"), O.apply_rots(batch["part_pcs"], x)[valid], capture=cap)
+        gap = torch.full((2 * 20, 100), float("inf"))
+        gap[valid.flatten()] = O.vq_gap(weights_sd("vqvae")["vector_quantization.embedding.weight"],
+                                        cap["z_e"].reshape(-1, 16)).view(-1, 100)
+        differ = (lat.cpu() - lat_o).abs().reshape(40, 100, 16).amax(-1) > 1e-4
+        assert differ.sum() <= 3 and (gap[differ] < 1e-4).all(), f"step {i}: {int(differ.sum())} VQ flips, gaps {gap[differ]}"
+        # downstream of the (possibly flipped) codes: same latents into both transformers
+        lat_in = lat if not differ.any() else lat_o.to(dev)
+        eps = model.denoiser(xd, torch.full((2,), t, device=dev), lat_in, xyz, gb["part_valids"], gb["part_scale"], gb["ref_part"])
         x_g = model.noise_scheduler.step(eps, t, xd, variance_noise=noises[i].to(dev), ref_part=gb["ref_part"],
                                          reference=reference.to(dev)).prev_sample
-        assert torch.equal(xyz.cpu(), xyz_o), f"step {i}: FPS/rotate diverged"
-        flips = ((lat.cpu() - lat_o).abs().reshape(-1, 16).amax(1) > 1e-4).sum().item()
-        assert flips == 0, f"step {i}: {flips} VQ sub-vectors differ"
         assert (eps.cpu() - eps_o)[valid].abs().max() < TOL and (x_g.cpu() - x_o)[valid].abs().max() < TOL, i
         assert (x_g.cpu() - x_o).abs().max() < 5 * TOL          # padded slots carry no information; still close
         x = x_o
