@@ -21,7 +21,13 @@
 // and VALU work into the gaps between matrix instructions; rows outside M/N are clamped (their
 // results are discarded) instead of predicated.  LDS rows are padded (36 floats / 40 halfs) so
 // that the 16-byte fragment reads are bank-conflict free.  Tile ids are remapped XCD-aware.
+#include <stdlib.h>
+
 #include "gemm_common.h"
+
+namespace pfpp_gemm_detail {
+int launch_f16x3_ring(const GemmP& p, int batch, hipStream_t st, int group_m);   // gemm_ring.hip
+}
 
 namespace {
 
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   const int tile = remap_tile(blockIdx.x, gridDim.x);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  int tm, tn;
+  tile_coords(p, tile, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int z = blockIdx.z;
@@ -258,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int tile = remap_tile(blockIdx.x, gridDim.x);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  int tm, tn;
+  tile_coords(p, tile, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int z = blockIdx.z;
@@ -424,17 +432,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
   epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
 }
 
+int gemm_group_m() {
+  static const int v = getenv("PFPP_GEMM_GROUP_M") ? atoi(getenv("PFPP_GEMM_GROUP_M")) : 8;
+  return v;
+}
+
 // =================================================================================================
 template <typename K>
 int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set) {
   if (!*attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *attr_set = true;
   }
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int env_group = gemm_group_m();
+  static const int env_pad = getenv("PFPP_GEMM_LDS_PAD") ? atoi(getenv("PFPP_GEMM_LDS_PAD")) : 0;   // experiment knob
+  p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  p.group_m = p.tiles_n > 1 ? env_group : 0;
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem + env_pad, st, p);
   return pfpp::check_launch("pfpp_gemm");
 }
 
@@ -501,6 +517,10 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)
   const bool wide = a->N > 64 || a->act == PFPP_ACT_GEGLU;
   if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
+    // LDS-DMA ring variant (gemm_ring.hip): correct, but issue-bound by the per-wave A split (measured
+    // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
+    static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
+    if (pre && wide && use_ring && a->K % 32 == 0) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
     if (pre) return wide ? launch_f16x3<2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
     return wide ? launch_f16x3<2, 2, false>(p, a->batch, st) : launch_f16x3<2, 1, false>(p, a->batch, st);
   }

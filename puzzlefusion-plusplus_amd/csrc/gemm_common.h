@@ -18,7 +18,7 @@ struct GemmP {
   int act, pool, zdiv;
   int64_t sA0, sA1, sW0, sW1, sC0, sC1, sV0, sV1;
   float alpha;
-  int tiles_n;
+  int tiles_n, tiles_m, group_m;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -36,6 +36,24 @@ __device__ __forceinline__ int remap_tile(int bid, int nwg) {
   const int xcd = bid & 7, local = bid >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// tile id -> (tm, tn).  group_m > 0: ids walk group_m consecutive row panels column by column, so
+// the ~64 tiles an XCD runs at once span group_m panels of A and 64/group_m panels of W (L2 reuse of
+// both operands); group_m == 0: plain row-major order.
+__device__ __forceinline__ void tile_coords(const GemmP& p, int tile, int& tm, int& tn) {
+  if (p.group_m > 0) {
+    const int group = p.group_m * p.tiles_n;
+    const int g = tile / group;
+    const int first_m = g * p.group_m;
+    const int gsz = min(p.tiles_m - first_m, p.group_m);
+    const int r = tile - g * group;
+    tm = first_m + r % gsz;
+    tn = r / gsz;
+  } else {
+    tm = tile / p.tiles_n;
+    tn = tile - tm * p.tiles_n;
+  }
 }
 
 // acc[i][j]: MT x NT tiles of the wave whose top-left element is (row_w, col_w)

@@ -24,6 +24,7 @@ SOURCES = {
     "vq.hip": ["-ffp-contract=off"],
     "transformer_ops.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
+    "gemm_ring.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 
@@ -47,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
-    headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h"]
+    headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h", CSRC / "gemm_common.h"]
     objs = []
     for src, extra in SOURCES.items():
         s = CSRC / src

@@ -164,6 +164,34 @@ def test_gemm_vs_float64(dev, M, N, K, act, pool, bn):
     assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1000, 512, 512, "none"), (4096, 1536, 512, "none"), (300, 4096, 512, "geglu"),
+                                        (777, 512, 2048, "gelu"), (8192, 256, 128, "relu"), (130, 128, 32, "none"),
+                                        (500, 192, 132, "relu"), (64, 3, 256, "none")])
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_gemm_packed_weight_both_modes(dev, M, N, K, act, mode):
+    """packing.PW weights: split-f16 path (pre-split planes; LDS-DMA ring kernel where K % 32 == 0) and exact fp32 path"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, pack_geglu
+
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g) * 3.0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    if act == "geglu":
+        hh, gg = ref.chunk(2, -1)
+        ref = hh * torch.nn.functional.gelu(gg)
+        Wp, bp = pack_geglu(W, b)
+    else:
+        ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "none": lambda v: v}[act](ref)
+        Wp, bp = W, b
+    Kp = (K + 3) // 4 * 4
+    Ap = torch.zeros(M, Kp); Ap[:, :K] = A
+    out = ops.linear(Ap.to(dev), PW(Wp.to(dev)), bp.to(dev), act=act, mode=mode)
+    assert out.shape == ref.shape
+    assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_linearity_full_size(dev):
     """BASELINE-size transformer GEMM (M = 32*500): f(a x + b y) == a f(x) + b f(y) to rounding"""
     from pfpp_hip import ops
@@ -183,7 +211,7 @@ def test_gemm_rejects_bad_arguments(dev):
     from pfpp_hip._lib import PfppError
 
     A = torch.zeros(8, 6, device=dev); W = torch.zeros(8, 6, device=dev)
-    with pytest.raises(PfppError, match="multiples of 4"):
+    with pytest.raises(PfppError, match="multiple of 4"):
         ops.gemm(A, W, M=8, N=8, K=6, lda=6, ldw=6)
     with pytest.raises(PfppError, match="pool"):
         ops.gemm(torch.zeros(96, 8, device=dev), torch.zeros(8, 8, device=dev), M=96, N=8, K=8, lda=8, ldw=8, pool=48)
