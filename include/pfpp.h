@@ -228,6 +228,17 @@ int pfpp_softmax_rows(float* S, const uint8_t* key_valid, int64_t rows_total,
                       int64_t rows_per_batch, int64_t T, int64_t ld, float scale,
                       pfpp_stream_t stream);
 
+/* ---- a13/a18: fused dense masked attention ------------------------------------------------------
+ * softmax(Q K^T * scale + key mask) V per (sequence, head) straight from a packed projection
+ * qkv [rows, 3*H*dh] (q | k | v): EncoderLayer global attention (attention.py:82-85 with gen_mask of
+ * denoiser_transformer.py:163-164) and the verifier's self-attention (verifier_transformer.py:62,
+ * src_key_padding_mask).  Scores stay in registers (online softmax); exact fp32 MFMA products.
+ * Sequence s occupies rows [seq_off[s], seq_off[s] + seq_len[s]); key_valid (may be NULL) is
+ * [n_seq, kv_stride] uint8 with 0 = key masked out.  out [rows, H*dh].  dh in {32, 64}.         */
+int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,
+                    const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                    int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+
 /* ---- a15: mean pool over the L tokens of a fragment -----------------------
  * denoiser_transformer.py:139-142.  x [n*L, C] -> out [n, C]                 */
 int pfpp_mean_pool(const float* x, float* out, int64_t n, int64_t L, int64_t C,

@@ -1,0 +1,190 @@
+// a13 / a18: dense masked self-attention, fused (scores never leave the registers).
+//
+// Replaces  QK^T GEMM -> [B,H,T,T] scores in HBM -> softmax kernel -> P.V GEMM  of the global
+// attention of the denoiser (attention.py:82-85, key-padding mask of denoiser_transformer.py:163-164)
+// and of the verifier's encoder layers (verifier_transformer.py:62, src_key_padding_mask).
+//
+// One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries and walks
+// the keys in tiles of 32 with an online softmax.  fp32 MFMA (exact products) in the "swapped" form:
+//     S^T[key][query] = K_tile . Q^T          (A = K rows from LDS, B = Q held in registers)
+//     O^T[d][query]  += V_tile^T . P^T        (A = V from LDS,  B = P)
+// With v_mfma_f32_32x32x2_f32 and the lane-half k split used by the GEMM (lanes 0-31 feed k 0-3,
+// lanes 32-63 feed k 4-7 of each 8-chunk), accumulator element e = 4*kc + s of S^T is exactly the
+// B-operand element the PV product needs for key kc*8 + 4*(lane>>5) + s — so P is consumed in
+// place, no LDS round trip or cross-lane shuffle.  Each lane holds ONE query column: the row max /
+// sum are in-lane reductions plus one exchange with lane^32, and the online rescale of O is a
+// per-lane scalar multiply.  K/V tiles are shared by the 4 waves through a double-buffered LDS
+// stage (K rows padded to DH+4 floats: conflict-free 16-byte reads).
+// Sequences may have different lengths (seq_off / seq_len): padded fragments can be dropped.
+#include "pfpp_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dense_kernel(
+    const float* __restrict__ qkv, float* __restrict__ out, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
+    int H, float scale) {
+  constexpr int KT = 32;
+  constexpr int LDK = DH + 4;
+  constexpr int NCH = DH / 8;      // 8-wide k chunks of the head dimension
+  constexpr int NDT = DH / 32;     // 32-wide output column tiles
+  constexpr int F4 = KT * DH / 4 / 256;   // float4 per thread and tensor per key tile
+  __shared__ __align__(16) float Ks[2][KT * LDK];
+  __shared__ __align__(16) float Vs[2][KT * DH];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 128;
+  if (q_base >= T) return;                       // uniform for the workgroup, before any barrier
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+  const uint8_t* kv = key_valid ? key_valid + (int64_t)b * kv_stride : nullptr;
+
+  // Q fragments of this lane's query: d = kc*8 + lhi*4 + (0..3)
+  const int q_row = q_base + wave * 32 + l31;
+  const float* qp = base + (int64_t)min(q_row, T - 1) * ld + lhi * 4;
+  float4 qf[NCH];
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + kc * 8);
+
+  f32x16 o_acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  float4 rk[F4], rv[F4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      rk[it] = *reinterpret_cast<const float4*>(src);
+      rv[it] = *reinterpret_cast<const float4*>(src + C);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      *reinterpret_cast<float4*>(&Ks[buf][r * LDK + c4 * 4]) = rk[it];
+      *reinterpret_cast<float4*>(&Vs[buf][r * DH + c4 * 4]) = rv[it];
+    }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int k0 = t * KT;
+    if (t + 1 < nt) load_tile(k0 + KT);
+
+    // validity of the 32 keys of this tile as a bit mask (uniform)
+    const int kidx = k0 + l31;
+    const bool kval = kidx < T && (!kv || kv[kidx] != 0);
+    const unsigned kmask = (unsigned)(__ballot(kval) & 0xffffffffull);
+
+    // ---- S^T = K . Q^T ---------------------------------------------------------------------------
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+    const float* kp = &Ks[buf][l31 * LDK + lhi * 4];
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      const float4 a = *reinterpret_cast<const float4*>(kp + kc * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[kc].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[kc].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[kc].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[kc].w, s, 0, 0, 0);
+    }
+
+    // ---- online softmax over this lane's query column -------------------------------------------
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const float v = (kmask >> key) & 1u ? s[e] * scale : -__builtin_huge_valf();
+      s[e] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = expf(s[e] - m_new);       // exp(-inf) = 0 for masked keys
+      s[e] = pe;
+      psum += pe;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+
+    // ---- O^T += V^T . P^T  (P straight from the score registers) -------------------------------
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const float* vp = &Vs[buf][(lhi * 4) * DH + dt * 32 + l31];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(kc * 8 + 0) * DH], s[4 * kc + 0], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(kc * 8 + 1) * DH], s[4 * kc + 1], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(kc * 8 + 2) * DH], s[4 * kc + 2], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(kc * 8 + 3) * DH], s[4 * kc + 3], o_acc[dt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[query = l31][d = dt*32 + 8g + 4*lhi + (0..3)] ------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (q_row < T) {
+    float* op = out + (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(op + dt * 32 + 8 * g) =
+            make_float4(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv, o_acc[dt][4 * g + 2] * inv,
+                        o_acc[dt][4 * g + 3] * inv);
+  }
+}
+
+}  // namespace
+
+extern "C" int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,
+                               const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                               int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out && seq_off && seq_len, "null pointer");
+  PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1, "bad sizes");
+  PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
+  PFPP_SUPPORTED(n_seq <= 65535 && H <= 65535, "too many sequences / heads for one launch");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out), "16-byte alignment");
+  if (n_seq == 0) return PFPP_OK;
+  const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
+  hipStream_t st = pfpp::as_stream(stream);
+  if (dh == 64)
+    hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, seq_off, seq_len, key_valid, kv_stride,
+                       (int)H, scale);
+  else
+    hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, out, seq_off, seq_len, key_valid, kv_stride,
+                       (int)H, scale);
+  return pfpp::check_launch(__func__);
+}

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pfpp_silu_embed": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_layernorm": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_blockdiag": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_dense": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_softmax_rows": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_mean_pool": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_ddpm_step": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],

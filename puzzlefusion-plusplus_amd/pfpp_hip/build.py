@@ -23,6 +23,7 @@ SOURCES = {
     "pointops.hip": ["-ffp-contract=off"],
     "vq.hip": ["-ffp-contract=off"],
     "transformer_ops.hip": ["-ffp-contract=off"],
+    "attention.hip": [],
     "gemm.hip": [],
     "gemm_ring.hip": [],
 }

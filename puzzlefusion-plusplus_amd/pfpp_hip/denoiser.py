@@ -57,20 +57,39 @@ def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, tor
 
 
 def dense_attention(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, key_valid_u8: torch.Tensor,
-                    scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """softmax(Q K^T * scale + key mask) V per (batch, head) from a packed [B*T, 3*H*dh] projection.
-    Shared by the denoiser's global attention (a13) and the verifier (a18)."""
+                    scale: float, out: Optional[torch.Tensor] = None, seq=None) -> torch.Tensor:
+    """softmax(Q K^T * scale + key mask) V per (sequence, head) from a packed [rows, 3*H*dh] projection —
+    one fused kernel (pfpp_attn_dense).  Shared by the denoiser's global attention (a13) and the verifier
+    (a18).  `seq` = (seq_off, seq_len) int32 tensors; default: B sequences of T rows."""
+    if seq is None:
+        seq = uniform_sequences(B, T, qkv.device)
+    return ops.attn_dense(qkv, seq[0], seq[1], T, H, dh, scale, key_valid_u8, out=out)
+
+
+_SEQ_CACHE = {}
+
+
+def uniform_sequences(B: int, T: int, device):
+    key = (B, T, str(device))
+    if key not in _SEQ_CACHE:
+        off = (torch.arange(B, dtype=torch.int32) * T).to(device)
+        ln = torch.full((B,), T, dtype=torch.int32).to(device)
+        _SEQ_CACHE[key] = (off, ln)
+    return _SEQ_CACHE[key]
+
+
+def dense_attention_unfused(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, key_valid_u8: torch.Tensor,
+                            scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """the three-kernel form (QK^T GEMM -> masked softmax -> P.V GEMM), kept as a cross-check of the fused kernel"""
     C = H * dh
     ld = 3 * C
     Tp = round_up(T, 4)
     S = torch.empty((B * H, T, Tp), dtype=torch.float32, device=qkv.device)
-    # S[b,h] = Q_bh K_bh^T : A = Q rows (lda = 3C), W = K rows [T, dh] (ldw = 3C)
     ops.gemm(qkv, qkv, M=T, N=T, K=dh, lda=ld, ldw=ld, out=S, ldc=Tp, batch=B * H, zdiv=H,
              sA=(T * ld, dh), sW=(T * ld, dh), sC=(H * T * Tp, T * Tp), w_off=C)
     ops.softmax_rows(S, key_valid_u8, H * T, T, scale)
     if out is None:
         out = torch.empty((B * T, C), dtype=torch.float32, device=qkv.device)
-    # O[b, :, h] = P_bh V_bh : W = V rows [T(k), dh(n)] k-major
     ops.gemm(S, qkv, M=T, N=dh, K=T, lda=Tp, ldw=ld, out=out, ldc=C, w_kmajor=True, batch=B * H, zdiv=H,
              sA=(H * T * Tp, T * Tp), sW=(T * ld, dh), sC=(T * C, dh), w_off=2 * C)
     return out

@@ -344,6 +344,27 @@ def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scal
     return out
 
 
+def attn_dense(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, max_len: int, H: int, dh: int,
+               scale: float, key_valid_u8: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused softmax(QK^T*scale + key mask)V from a packed [rows, 3*H*dh] projection; sequences are row
+    ranges [seq_off[s], seq_off[s]+seq_len[s]) (int32); key_valid [n_seq, max_len] uint8 or None"""
+    _chk(qkv, torch.float32, "qkv"); _chk(seq_off, torch.int32, "seq_off"); _chk(seq_len, torch.int32, "seq_len")
+    rows, w = qkv.shape
+    if w != 3 * H * dh:
+        raise ValueError("attn_dense: qkv must be [rows, 3*H*dh]")
+    kv_stride = 0
+    if key_valid_u8 is not None:
+        _chk(key_valid_u8, torch.uint8, "key_valid")
+        kv_stride = key_valid_u8.shape[-1]
+    if out is None:
+        out = torch.empty((rows, H * dh), dtype=torch.float32, device=qkv.device)
+    else:
+        _chk(out, torch.float32, "out")
+    check(_lib.load().pfpp_attn_dense(_ptr(qkv), _ptr(out), _ptr(seq_off), _ptr(seq_len), _ptr(key_valid_u8), kv_stride,
+                                      seq_off.numel(), max_len, H, dh, scale, _stream()), "pfpp_attn_dense")
+    return out
+
+
 def softmax_rows(S: torch.Tensor, key_valid_u8: Optional[torch.Tensor], rows_per_batch: int, T: int,
                  scale: float) -> torch.Tensor:
     """in-place masked softmax over the first T columns of S [..., ld]"""

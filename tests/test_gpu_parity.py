@@ -217,6 +217,39 @@ def test_gemm_rejects_bad_arguments(dev):
         ops.gemm(torch.zeros(96, 8, device=dev), torch.zeros(8, 8, device=dev), M=96, N=8, K=8, lda=8, ldw=8, pool=48)
 
 
+@pytest.mark.parametrize("B,T,H,dh", [(3, 500, 8, 64), (2, 190, 8, 32), (1, 33, 2, 64), (2, 128, 1, 32)])
+def test_attn_dense_fused_vs_float64_and_unfused(dev, B, T, H, dh):
+    """fused attention kernel vs a float64 reference (key mask incl. a fully masked tile) and vs the 3-kernel form"""
+    from pfpp_hip import denoiser as D
+
+    g = torch.Generator().manual_seed(B * T + dh)
+    C = H * dh
+    qkv = torch.randn(B * T, 3 * C, generator=g)
+    valid = torch.rand(B, T, generator=g) < 0.6
+    valid[0, :40] = False                      # a whole 32-key tile masked at the start
+    valid[:, T - 1] = True
+    q, k, v = (t.view(B, T, H, dh).transpose(1, 2).double() for t in qkv.chunk(3, dim=-1))
+    sc = (q @ k.transpose(-1, -2)) / dh ** 0.5
+    sc = sc.masked_fill(~valid[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * T, C)
+    kvu8 = valid.to(torch.uint8).to(dev)
+    out = D.dense_attention(qkv.to(dev), B, T, H, dh, kvu8, 1.0 / dh ** 0.5)
+    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    out2 = D.dense_attention_unfused(qkv.to(dev), B, T, H, dh, kvu8, 1.0 / dh ** 0.5)
+    assert (out2.cpu().double() - ref).abs().max() < 2e-5
+    # ragged sequences: two sequences of different length packed back to back, no mask
+    if B >= 2:
+        lens = torch.tensor([T, T - 37], dtype=torch.int32)
+        offs = torch.tensor([0, T], dtype=torch.int32)
+        from pfpp_hip import ops
+        out3 = ops.attn_dense(qkv[: 2 * T].contiguous().to(dev), offs.to(dev), lens.to(dev), T, H, dh, 1.0 / dh ** 0.5)
+        for s_i in range(2):
+            L = int(lens[s_i]); o = int(offs[s_i])
+            qs, ks, vs = (t[o:o + L].view(L, H, dh).transpose(0, 1).double() for t in qkv[: 2 * T].chunk(3, dim=-1))
+            r = (torch.softmax(qs @ ks.transpose(-1, -2) / dh ** 0.5, -1) @ vs).transpose(0, 1).reshape(L, C)
+            assert (out3[o:o + L].cpu().double() - r).abs().max() < 2e-5
+
+
 # ----------------------------------------------------------------------------- transformer / scheduler / verifier
 def test_denoiser_vs_golden(golden, weights_sd, dev):
     from pfpp_hip import denoiser as D
