@@ -138,6 +138,9 @@ enum { PFPP_GEMM_F32 = 0, PFPP_GEMM_F16X3 = 1 };
 typedef struct pfpp_gemm_args {
   const float* A; const float* W; float* C;
   const void* w_hi; const void* w_lo;   /* pre-split fp16 planes of W, or NULL */
+  const void* a_hi; const void* a_lo;   /* pre-split fp16 planes of A [M, lda] (then A may be NULL; needs
+                                           w_hi/w_lo, K % 32 == 0, lda % 8 == 0), or NULL              */
+  void* c_hi; void* c_lo;               /* if set: write the result as split planes [.., ldc] instead of C */
   const float* bias;      /* [N] or NULL */
   const float* scale;     /* [N] or NULL (then shift must be set) */
   const float* shift;     /* [N] */
@@ -208,6 +211,11 @@ int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
                    const float* gamma, const float* beta, int64_t rows,
                    int64_t C, int64_t rows_per_batch, float eps,
                    pfpp_stream_t stream);
+/* same, but the result is written as split-f16 planes (hi, lo*2048) for the PFPP_GEMM_F16X3 path */
+int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
+                         const float* gamma, const float* beta, int64_t rows,
+                         int64_t C, int64_t rows_per_batch, float eps,
+                         pfpp_stream_t stream);
 
 /* ---- a10/a12: block-diagonal self-attention --------------------------------
  * EncoderLayer self-attn (attention.py:77-80) with the block-diagonal mask of
@@ -217,6 +225,9 @@ int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
  * softmax(q.k^T * scale).  L <= 32, dh == 64.                               */
 int pfpp_attn_blockdiag(const float* qkv, float* out, int64_t n_frag, int64_t L,
                         int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+/* out_hi/out_lo != NULL: additionally/instead write split-f16 planes (out may then be NULL) */
+int pfpp_attn_blockdiag_split(const float* qkv, void* out_hi, void* out_lo, int64_t n_frag, int64_t L,
+                              int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
 
 /* ---- a13/a18: masked row softmax for the dense attentions -------------------
  * S [rows_total, ld] in place: p = softmax(S[r, 0:T] * scale) over the keys j
@@ -238,6 +249,10 @@ int pfpp_softmax_rows(float* S, const uint8_t* key_valid, int64_t rows_total,
 int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,
                     const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
                     int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+int pfpp_attn_dense_split(const float* qkv, void* out_hi, void* out_lo, const int32_t* seq_off,
+                          const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride,
+                          int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                          pfpp_stream_t stream);
 
 /* ---- a15: mean pool over the L tokens of a fragment -----------------------
  * denoiser_transformer.py:139-142.  x [n*L, C] -> out [n, C]                 */

@@ -24,7 +24,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int DH>
 __global__ __launch_bounds__(256) void attn_dense_kernel(
-    const float* __restrict__ qkv, float* __restrict__ out, const int32_t* __restrict__ seq_off,
+    const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
+    _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
     int H, float scale) {
   constexpr int KT = 32;
@@ -156,35 +157,69 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   if (q_row < T) {
-    float* op = out + (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
+    const int64_t off = (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(op + dt * 32 + 8 * g) =
-            make_float4(o_acc[dt][4 * g + 0] * inv, o_acc[dt][4 * g + 1] * inv, o_acc[dt][4 * g + 2] * inv,
-                        o_acc[dt][4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = o_acc[dt][4 * g + 0] * inv, v1 = o_acc[dt][4 * g + 1] * inv;
+        const float v2 = o_acc[dt][4 * g + 2] * inv, v3 = o_acc[dt][4 * g + 3] * inv;
+        if (out_hi) {
+          typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+          half4 hi, lo;
+          PFPP_SPLIT_TO(v0, hi[0], lo[0]);
+          PFPP_SPLIT_TO(v1, hi[1], lo[1]);
+          PFPP_SPLIT_TO(v2, hi[2], lo[2]);
+          PFPP_SPLIT_TO(v3, hi[3], lo[3]);
+          *reinterpret_cast<half4*>(out_hi + off + dt * 32 + 8 * g) = hi;
+          *reinterpret_cast<half4*>(out_lo + off + dt * 32 + 8 * g) = lo;
+        } else {
+          *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
+        }
+      }
   }
 }
 
 }  // namespace
 
+static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
+                           const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq,
+                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+
 extern "C" int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,
                                const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
                                int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
-  PFPP_REQUIRE(qkv && out && seq_off && seq_len, "null pointer");
+  PFPP_REQUIRE(out, "null pointer");
+  return attn_dense_impl(qkv, out, nullptr, nullptr, seq_off, seq_len, key_valid, kv_stride, n_seq, max_len, H, dh,
+                         scale, stream);
+}
+
+extern "C" int pfpp_attn_dense_split(const float* qkv, void* out_hi, void* out_lo, const int32_t* seq_off,
+                                     const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride,
+                                     int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                                     pfpp_stream_t stream) {
+  PFPP_REQUIRE(out_hi && out_lo, "null pointer");
+  return attn_dense_impl(qkv, nullptr, (_Float16*)out_hi, (_Float16*)out_lo, seq_off, seq_len, key_valid, kv_stride,
+                         n_seq, max_len, H, dh, scale, stream);
+}
+
+static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
+                           const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq,
+                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && seq_off && seq_len, "null pointer");
   PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1, "bad sizes");
   PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
   PFPP_SUPPORTED(n_seq <= 65535 && H <= 65535, "too many sequences / heads for one launch");
-  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out), "16-byte alignment");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out) && pfpp::aligned16(out_hi) && pfpp::aligned16(out_lo),
+               "16-byte alignment");
   if (n_seq == 0) return PFPP_OK;
   const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
   hipStream_t st = pfpp::as_stream(stream);
   if (dh == 64)
-    hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, seq_off, seq_len, key_valid, kv_stride,
-                       (int)H, scale);
+    hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                       key_valid, kv_stride, (int)H, scale);
   else
-    hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, out, seq_off, seq_len, key_valid, kv_stride,
-                       (int)H, scale);
-  return pfpp::check_launch(__func__);
+    hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                       key_valid, kv_stride, (int)H, scale);
+  return pfpp::check_launch("pfpp_attn_dense");
 }

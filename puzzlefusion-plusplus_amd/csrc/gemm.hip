@@ -246,13 +246,14 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   }
 }
 
-template <int MT, int NT, bool WPRE>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
-  constexpr int BM = 64 * MT;
-  constexpr int BN = 64 * NT;
-  constexpr int A_IT = BM / 32;            // float4 loads per thread (fp32 source, 8 lanes per row)
-  constexpr int WF_IT = BN / 32;           // same for an fp32 W
-  constexpr int WH_IT = BN / 64;           // 16-byte (8-half) loads per thread and plane for a pre-split W
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void gemm_f16x3_kernel(const GemmP p) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int BM = 32 * MT * WM;
+  constexpr int BN = 32 * NT * WN;
+  constexpr int A_IT = BM / (NTHR / 8);    // float4 loads per thread (fp32 source, 8 lanes per row)
+  constexpr int WF_IT = BN / (NTHR / 8);   // same for an fp32 W
+  constexpr int WH_IT = BN / (NTHR / 4);   // 16-byte (8-half) loads per thread and plane for a pre-split W
   constexpr int PLANE_A = BM * LDH;        // halfs per plane
   constexpr int PLANE_W = BN * LDH;
   constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int tile = remap_tile(blockIdx.x, gridDim.x);
@@ -298,20 +299,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
   const _Float16* wl_ptr[NWH];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int gm = min(m0 + a_row + 32 * it, p.M - 1);
+    const int gm = min(m0 + a_row + (NTHR / 8) * it, p.M - 1);
     a_ptr[it] = A + (int64_t)gm * p.lda + a_c4 * 4;
   }
   if constexpr (WPRE) {
 #pragma unroll
     for (int it = 0; it < WH_IT; ++it) {
-      const int gn = min(n0 + h_row + 64 * it, p.N - 1);
+      const int gn = min(n0 + h_row + (NTHR / 4) * it, p.N - 1);
       wh_ptr[it] = reinterpret_cast<const _Float16*>(p.Whi) + w_off + (int64_t)gn * p.ldw + h_c8 * 8;
       wl_ptr[it] = reinterpret_cast<const _Float16*>(p.Wlo) + w_off + (int64_t)gn * p.ldw + h_c8 * 8;
     }
   } else {
 #pragma unroll
     for (int it = 0; it < WF_IT; ++it) {
-      const int gn = min(n0 + a_row + 32 * it, p.N - 1);
+      const int gn = min(n0 + a_row + (NTHR / 8) * it, p.N - 1);
       wf_ptr[it] = p.W + w_off + (int64_t)gn * p.ldw + a_c4 * 4;
     }
   }
@@ -353,14 +354,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
       split4(ra[it], hi, lo);
-      const int off = (a_row + 32 * it) * LDH + a_c4 * 4;
+      const int off = (a_row + (NTHR / 8) * it) * LDH + a_c4 * 4;
       *reinterpret_cast<half4*>(ahi + off) = hi;
       *reinterpret_cast<half4*>(alo + off) = lo;
     }
     if constexpr (WPRE) {
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
-        const int off = (h_row + 64 * it) * LDH + h_c8 * 8;
+        const int off = (h_row + (NTHR / 4) * it) * LDH + h_c8 * 8;
         *reinterpret_cast<uint4*>(whi + off) = rwh[it];
         *reinterpret_cast<uint4*>(wlo + off) = rwl[it];
       }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmP p) {
       for (int it = 0; it < WF_IT; ++it) {
         half4 hi, lo;
         split4(rwf[it], hi, lo);
-        const int off = (a_row + 32 * it) * LDH + a_c4 * 4;
+        const int off = (a_row + (NTHR / 8) * it) * LDH + a_c4 * 4;
         *reinterpret_cast<half4*>(whi + off) = hi;
         *reinterpret_cast<half4*>(wlo + off) = lo;
       }
@@ -439,7 +440,7 @@ int gemm_group_m() {
 
 // =================================================================================================
 template <typename K>
-int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set) {
+int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set, int nthr = 256) {
   if (!*attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *attr_set = true;
@@ -450,7 +451,7 @@ int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t 
   p.tiles_n = (p.N + BN - 1) / BN;
   p.group_m = p.tiles_n > 1 ? env_group : 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem + env_pad, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(nthr), smem + env_pad, st, p);
   return pfpp::check_launch("pfpp_gemm");
 }
 
@@ -462,23 +463,34 @@ int launch_f32(const GemmP& p, int batch, hipStream_t st) {
   return launch(gemm_f32_mfma_kernel<MT, NT, WK>, smem, p, BM, BN, batch, st, &attr_set);
 }
 
-template <int MT, int NT, bool WPRE>
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2>
 int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
-  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_kernel<MT, NT, WPRE>, smem, p, BM, BN, batch, st, &attr_set);
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN);
 }
 
 }  // namespace
 
 extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
-  PFPP_REQUIRE(a && a->A && a->C, "null pointer");
+  PFPP_REQUIRE(a && (a->A || (a->a_hi && a->a_lo)) && (a->C || (a->c_hi && a->c_lo)), "null pointer");
   PFPP_REQUIRE(a->W || (a->w_hi && a->w_lo), "W (or its pre-split planes) missing");
   PFPP_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "bad sizes");
   PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
-  PFPP_REQUIRE(a->lda % 4 == 0 && pfpp::aligned16(a->A), "lda must be a multiple of 4 and A 16-byte aligned");
-  PFPP_REQUIRE(a->lda >= ((a->K + 3) & ~3ll), "lda smaller than K rounded up to 4");
+  const bool apre = a->a_hi != nullptr;
+  if (apre) {
+    PFPP_REQUIRE(a->a_lo && a->w_hi && a->w_lo && a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor,
+                 "pre-split A needs the f16x3 path with a pre-split [N,K] W");
+    PFPP_REQUIRE(a->K % 32 == 0 && a->lda % 8 == 0 && a->lda >= a->K, "pre-split A: K % 32 == 0, lda % 8 == 0");
+    PFPP_REQUIRE(pfpp::aligned16(a->a_hi) && pfpp::aligned16(a->a_lo) && a->sA0 % 8 == 0 && a->sA1 % 8 == 0,
+                 "pre-split A planes must be 16-byte aligned");
+    PFPP_SUPPORTED(a->N > 64 || a->act == PFPP_ACT_GEGLU, "pre-split A with N <= 64");
+  } else {
+    PFPP_REQUIRE(a->lda % 4 == 0 && pfpp::aligned16(a->A), "lda must be a multiple of 4 and A 16-byte aligned");
+    PFPP_REQUIRE(a->lda >= ((a->K + 3) & ~3ll), "lda smaller than K rounded up to 4");
+  }
+  PFPP_REQUIRE(!a->c_hi || (a->c_lo && a->pool == 0), "split output: c_lo missing or combined with pooling");
   PFPP_REQUIRE(a->batch >= 1 && a->zdiv >= 1, "batch/zdiv must be >= 1");
   PFPP_REQUIRE((a->sA0 % 4 == 0) && (a->sA1 % 4 == 0), "batch strides of A must keep 16-byte alignment");
   PFPP_REQUIRE(!a->scale || a->shift, "scale without shift");
@@ -504,6 +516,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
 
   GemmP p;
   p.A = a->A; p.W = a->W; p.C = a->C; p.Whi = a->w_hi; p.Wlo = a->w_lo;
+  p.Ahi = a->a_hi; p.Alo = a->a_lo; p.Chi = a->c_hi; p.Clo = a->c_lo;
   p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.residual = a->residual;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
@@ -519,8 +532,13 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
     // LDS-DMA ring variant (gemm_ring.hip): correct, but issue-bound by the per-wave A split (measured
     // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
+    if (apre) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop, no conversions
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
     if (pre && wide && use_ring && a->K % 32 == 0) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
+    static const bool big_tile = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
+    // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
+    // row panels to fill the chip several times over
+    if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32) return launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
     if (pre) return wide ? launch_f16x3<2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
     return wide ? launch_f16x3<2, 2, false>(p, a->batch, st) : launch_f16x3<2, 1, false>(p, a->batch, st);
   }

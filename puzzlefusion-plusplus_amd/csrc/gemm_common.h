@@ -12,6 +12,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GemmP {
   const float* A; const float* W; float* C;
   const void* Whi; const void* Wlo;          // pre-split fp16 planes of W (split path) or null
+  const void* Ahi; const void* Alo;          // pre-split fp16 planes of A or null
+  void* Chi; void* Clo;                      // write the result as split planes instead of C
   const float* bias; const float* scale; const float* shift; const float* residual;
   int M, N, K;
   int64_t lda, ldw, ldc, ldr;
@@ -56,12 +58,22 @@ __device__ __forceinline__ void tile_coords(const GemmP& p, int tile, int& tm, i
   }
 }
 
+__device__ __forceinline__ void store_out(const GemmP& p, int64_t idx, float v) {
+  if (p.Chi) {
+    _Float16 hi, lo;
+    PFPP_SPLIT_TO(v, hi, lo);
+    reinterpret_cast<_Float16*>(p.Chi)[idx] = hi;
+    reinterpret_cast<_Float16*>(p.Clo)[idx] = lo;
+  } else {
+    p.C[idx] = v;
+  }
+}
+
 // acc[i][j]: MT x NT tiles of the wave whose top-left element is (row_w, col_w)
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int row_w, int col_w,
                                          int n0, int wn, int lane, int64_t c_off, int64_t v_off) {
   const int l31 = lane & 31, lhi = lane >> 5;
-  float* C = p.C + c_off;
   const float* R = p.residual ? p.residual + c_off : nullptr;
   const float* bias = p.bias ? p.bias + v_off : nullptr;
   const float* scale = p.scale ? p.scale + v_off : nullptr;
@@ -84,7 +96,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
           if (row < p.M && col_ok) {
             const float u = acc[i][0][e] * alpha + bu;
             const float g = acc[i][1][e] * alpha + bg;
-            C[(int64_t)row * p.ldc + ocol] = u * act_apply(g, PFPP_ACT_GELU);
+            store_out(p, c_off + (int64_t)row * p.ldc + ocol, u * act_apply(g, PFPP_ACT_GELU));
           }
         }
     }
@@ -111,7 +123,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
             v = scale ? v * sc + sh : v + sh;
             v = act_apply(v, p.act);
             if (R) v += R[(int64_t)row * p.ldr + col];
-            C[(int64_t)row * p.ldc + col] = v;
+            store_out(p, c_off + (int64_t)row * p.ldc + col, v);
           }
         }
     } else {
@@ -134,13 +146,13 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
       if (p.pool == 64) {
         if constexpr (MT == 2) {
           if (lhi == 0 && col_ok && row_w < p.M)
-            C[(int64_t)(row_w >> 6) * p.ldc + col] = fmaxf(mx[0], mx[1]);
+            store_out(p, c_off + (int64_t)(row_w >> 6) * p.ldc + col, fmaxf(mx[0], mx[1]));
         }
       } else {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int row0 = row_w + i * 32;
-          if (lhi == 0 && col_ok && row0 < p.M) C[(int64_t)(row0 >> 5) * p.ldc + col] = mx[i];
+          if (lhi == 0 && col_ok && row0 < p.M) store_out(p, c_off + (int64_t)(row0 >> 5) * p.ldc + col, mx[i]);
         }
       }
     }

@@ -27,6 +27,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace pfpp
 
+// x = hi + lo/2048 with hi = f16(x), lo = f16((x - hi) * 2048): x - hi is exact in fp32, so the pair
+// carries 22 bits of x (the operand format of the PFPP_GEMM_F16X3 path, csrc/gemm.hip)
+struct pfpp_hl { _Float16 hi, lo; };
+__device__ __forceinline__ pfpp_hl pfpp_split(float x) {
+  pfpp_hl r;
+  r.hi = (_Float16)x;
+  r.lo = (_Float16)((x - (float)r.hi) * 2048.0f);
+  return r;
+}
+// assigns into two targets (vector elements are not bindable to references)
+#define PFPP_SPLIT_TO(x, HI, LO) do { const pfpp_hl _s = pfpp_split(x); (HI) = _s.hi; (LO) = _s.lo; } while (0)
+
 #define PFPP_REQUIRE(cond, msg)                                   \
   do {                                                            \
     if (!(cond)) {                                                \

@@ -108,9 +108,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // one wave per row; VPL float4 per lane (C = 256*VPL)
-template <int VPL>
+template <int VPL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mod,
+    const float* __restrict__ x, float* __restrict__ y, _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
+    const float* __restrict__ mod,
     int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
     int rows_per_batch, float eps) {
   constexpr int C = 256 * VPL;
@@ -134,7 +135,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
   const float var = wave_sum(q) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
-  float4* yr = reinterpret_cast<float4*>(y + row * C);
   const int64_t b = row / rows_per_batch;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
@@ -159,7 +159,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
       o.z = o.z * g.z + be.z;
       o.w = o.w * g.w + be.w;
     }
-    yr[c4] = o;
+    if constexpr (SPLIT) {
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 hi, lo;
+      PFPP_SPLIT_TO(o.x, hi[0], lo[0]);
+      PFPP_SPLIT_TO(o.y, hi[1], lo[1]);
+      PFPP_SPLIT_TO(o.z, hi[2], lo[2]);
+      PFPP_SPLIT_TO(o.w, hi[3], lo[3]);
+      reinterpret_cast<half4*>(y_hi + row * C)[c4] = hi;
+      reinterpret_cast<half4*>(y_lo + row * C)[c4] = lo;
+    } else {
+      reinterpret_cast<float4*>(y + row * C)[c4] = o;
+    }
   }
 }
 
@@ -174,6 +185,8 @@ constexpr int AB_DH = 64;
 
 __global__ __launch_bounds__(256) void attn_blockdiag_kernel(const float* __restrict__ qkv,
                                                              float* __restrict__ out,
+                                                             _Float16* __restrict__ out_hi,
+                                                             _Float16* __restrict__ out_lo,
                                                              int64_t n_pairs, int L, int H,
                                                              float scale) {
   extern __shared__ __align__(16) float ab_smem[];
@@ -251,11 +264,24 @@ __global__ __launch_bounds__(256) void attn_blockdiag_kernel(const float* __rest
     }
   }
   if (active) {
-    float* op = out + (frag * L + lane) * (int64_t)(H * AB_DH) + h * AB_DH;
+    const int64_t off = (frag * L + lane) * (int64_t)(H * AB_DH) + h * AB_DH;
+    if (out_hi) {
+      typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4)
-      *reinterpret_cast<float4*>(op + c4 * 4) =
-          make_float4(o[4 * c4 + 0], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]);
+      for (int c8 = 0; c8 < 8; ++c8) {
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) PFPP_SPLIT_TO(o[8 * c8 + e], hi[e], lo[e]);
+        *reinterpret_cast<half8*>(out_hi + off + c8 * 8) = hi;
+        *reinterpret_cast<half8*>(out_lo + off + c8 * 8) = lo;
+      }
+    } else {
+      float* op = out + off;
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4)
+        *reinterpret_cast<float4*>(op + c4 * 4) =
+            make_float4(o[4 * c4 + 0], o[4 * c4 + 1], o[4 * c4 + 2], o[4 * c4 + 3]);
+    }
   }
 }
 
@@ -391,37 +417,76 @@ extern "C" int pfpp_silu_embed(const float* tables, const int64_t* t, float* out
   return pfpp::check_launch(__func__);
 }
 
+static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_lo, const float* mod,
+                          int64_t ld_mod, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                          int64_t rows_per_batch, float eps, pfpp_stream_t stream);
+
 extern "C" int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
                               const float* gamma, const float* beta, int64_t rows, int64_t C,
                               int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
   PFPP_REQUIRE(x && y, "null pointer");
+  return layernorm_impl(x, y, nullptr, nullptr, mod, ld_mod, gamma, beta, rows, C, rows_per_batch, eps, stream);
+}
+
+extern "C" int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
+                                    const float* gamma, const float* beta, int64_t rows, int64_t C,
+                                    int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && y_hi && y_lo, "null pointer");
+  return layernorm_impl(x, nullptr, (_Float16*)y_hi, (_Float16*)y_lo, mod, ld_mod, gamma, beta, rows, C,
+                        rows_per_batch, eps, stream);
+}
+
+static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_lo, const float* mod,
+                          int64_t ld_mod, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                          int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
+  const char* __func__name = "pfpp_layernorm";
+  (void)__func__name;
   PFPP_REQUIRE(!gamma || beta, "gamma without beta");
   PFPP_REQUIRE(rows_per_batch >= 1, "rows_per_batch < 1");
   PFPP_SUPPORTED(C == 256 || C == 512 || C == 1024, "C not in {256, 512, 1024}");
   if (rows == 0) return PFPP_OK;
   hipStream_t st = pfpp::as_stream(stream);
   const dim3 grid(blocks_for(rows, 4));
-  if (C == 256)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
-  else if (C == 512)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, x, y, mod, ld_mod, gamma, beta, rows, (int)rows_per_batch, eps);
-  return pfpp::check_launch(__func__);
+  const int rpb = (int)rows_per_batch;
+  if (y_hi) {
+    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+  } else {
+    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<4, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+  }
+  return pfpp::check_launch("pfpp_layernorm");
 }
+
+static int attn_blockdiag_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, int64_t n_frag,
+                               int64_t L, int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
 
 extern "C" int pfpp_attn_blockdiag(const float* qkv, float* out, int64_t n_frag, int64_t L,
                                    int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
   PFPP_REQUIRE(qkv && out, "null pointer");
+  return attn_blockdiag_impl(qkv, out, nullptr, nullptr, n_frag, L, H, dh, scale, stream);
+}
+
+extern "C" int pfpp_attn_blockdiag_split(const float* qkv, void* out_hi, void* out_lo, int64_t n_frag, int64_t L,
+                                         int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out_hi && out_lo, "null pointer");
+  return attn_blockdiag_impl(qkv, nullptr, (_Float16*)out_hi, (_Float16*)out_lo, n_frag, L, H, dh, scale, stream);
+}
+
+static int attn_blockdiag_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, int64_t n_frag,
+                               int64_t L, int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
   PFPP_SUPPORTED(dh == AB_DH, "dim_head != 64");
   PFPP_SUPPORTED(L >= 1 && L <= AB_LMAX, "L outside [1, 32]");
-  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out), "16-byte alignment");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out) && pfpp::aligned16(out_hi) && pfpp::aligned16(out_lo),
+               "16-byte alignment");
   const int64_t pairs = n_frag * H;
   if (pairs == 0) return PFPP_OK;
   const size_t smem = 4 * 2 * AB_LMAX * AB_DH * sizeof(float);
   hipLaunchKernelGGL(attn_blockdiag_kernel, dim3(blocks_for(pairs, 4)), dim3(256), smem,
-                     pfpp::as_stream(stream), qkv, out, pairs, (int)L, (int)H, scale);
-  return pfpp::check_launch(__func__);
+                     pfpp::as_stream(stream), qkv, out, out_hi, out_lo, pairs, (int)L, (int)H, scale);
+  return pfpp::check_launch("pfpp_attn_blockdiag");
 }
 
 extern "C" int pfpp_softmax_rows(float* S, const uint8_t* key_valid, int64_t rows_total,

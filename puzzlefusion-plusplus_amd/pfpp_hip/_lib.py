@@ -22,6 +22,7 @@ class GemmArgs(C.Structure):
     _fields_ = [
         ("A", _p), ("W", _p), ("C", _p),
         ("w_hi", _p), ("w_lo", _p),
+        ("a_hi", _p), ("a_lo", _p), ("c_hi", _p), ("c_lo", _p),
         ("bias", _p), ("scale", _p), ("shift", _p), ("residual", _p),
         ("M", _i64), ("N", _i64), ("K", _i64),
         ("lda", _i64), ("ldw", _i64), ("ldc", _i64), ("ldr", _i64),
@@ -47,8 +48,11 @@ SIGNATURES = {
     "pfpp_token_combine": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_silu_embed": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_layernorm": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_layernorm_split": [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_blockdiag": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_blockdiag_split": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_dense": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_dense_split": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_softmax_rows": [_p, _p, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_mean_pool": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_ddpm_step": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],

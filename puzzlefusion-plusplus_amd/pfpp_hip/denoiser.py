@@ -122,12 +122,19 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
              batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
     key_valid = part_valids.reshape(B, P).to(torch.bool).repeat_interleave(L, dim=1).to(torch.uint8).contiguous()
     att_scale = 1.0 / math.sqrt(dh)
-    norm = torch.empty_like(h)
-    att = torch.empty_like(h)
+    # In the split-f16 mode the GEMM inputs produced by our own kernels (normalised rows, attention
+    # outputs, GEGLU activations) travel as pre-split fp16 planes: the big GEMMs then do no conversions.
+    split = ops.split_mode()
+    inner = pk[f"0.ff.w2"].K
+    if split:
+        norm, att, u = (ops.SplitAct.empty(M, C, h.device), ops.SplitAct.empty(M, C, h.device),
+                        ops.SplitAct.empty(M, inner, h.device))
+    else:
+        norm, att, u = torch.empty_like(h), torch.empty_like(h), None
     for i in range(num_layers):
         ops.layernorm(h, mod=mods[2 * i], rows_per_batch=T, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
-        att = ops.attn_blockdiag(qkv, n, L, num_heads, dh, att_scale)
+        ops.attn_blockdiag(qkv, n, L, num_heads, dh, att_scale, out=att)
         ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
                  bias=pk[f"{i}.self_attn.bo"], residual=h, ldr=C)
         ops.layernorm(h, mod=mods[2 * i + 1], rows_per_batch=T, out=norm)
@@ -136,8 +143,8 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
         ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
                  bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
-        u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu")
-        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=u.shape[1], lda=u.shape[1], out=h, ldc=C,
+        u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu", out=u)
+        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=inner, lda=inner, out=h, ldc=C,
                  bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
         if capture is not None:
             capture[f"layer{i}"] = h.clone()

@@ -129,6 +129,36 @@ import os as _os
 GEMM_MODE = _os.environ.get("PFPP_GEMM", "f16x3")
 PRECISION = {"f32": 0, "f16x3": 1}
 
+class SplitAct:
+    """an activation travelling as split-f16 planes (hi, lo*2048), each fp16 [rows, C]: produced by the
+    LayerNorm / attention kernels and GEMM epilogues, consumed as the A operand of the split-f16 GEMM with
+    no conversion work (csrc/gemm_ring.hip)"""
+
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi: torch.Tensor, lo: torch.Tensor):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty(rows: int, cols: int, device) -> "SplitAct":
+        return SplitAct(torch.empty((rows, cols), dtype=torch.float16, device=device),
+                        torch.empty((rows, cols), dtype=torch.float16, device=device))
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def float(self) -> torch.Tensor:
+        return self.hi.float() + self.lo.float() / 2048.0
+
+
+def split_mode() -> bool:
+    """activations between kernels as pre-split fp16 planes (consumed by the LDS-DMA ring GEMM).  Correct and
+    tested, but measured slower than the register-staged kernels on MI355X (every wave pays ~100 cycles of
+    issue per LDS-DMA piece), so it is opt-in: PFPP_SPLIT_ACT=1."""
+    return GEMM_MODE == "f16x3" and _os.environ.get("PFPP_SPLIT_ACT", "0") == "1"
+
+
 # When set to a list, every pfpp_gemm launch appends (start_event, end_event, flops, kernel_name):
 # bench.py uses it to time the dominant kernel with HIP events on the launch stream.
 GEMM_TRACE = None
@@ -157,6 +187,17 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     mode = mode or GEMM_MODE
     f16x3 = mode == "f16x3" and not w_kmajor
     planes = None
+    a_planes = None
+    if isinstance(A, SplitAct):
+        if not (f16x3 and isinstance(W, PW)):
+            raise ValueError("gemm: a SplitAct operand needs the f16x3 mode and a packed (PW) weight")
+        a_planes = (A.hi, A.lo)
+        A = None
+    c_planes = None
+    if isinstance(out, SplitAct):
+        c_planes = (out.hi, out.lo)
+        if ldc is None:
+            ldc = out.hi.shape[-1]
     if isinstance(W, PW):
         if f16x3:
             planes = (W.hi, W.lo)
@@ -170,16 +211,21 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         W = W.f32
     if ldw is None:
         ldw = W.shape[-1]
-    _chk(A, torch.float32, "A"); _chk(W, torch.float32, "W")
+    if a_planes is None:
+        _chk(A, torch.float32, "A")
+    else:
+        _chk(a_planes[0], torch.float16, "A.hi"); _chk(a_planes[1], torch.float16, "A.lo")
+    _chk(W, torch.float32, "W")
+    dev_ = W.device
     n_out_cols = N // 2 if act == "geglu" else N
     if out is None:
         rows = M // pool if pool else M
         if ldc is None:
             ldc = n_out_cols
-        out = torch.empty((batch, rows, ldc) if batch > 1 else (rows, ldc), dtype=torch.float32, device=A.device)
+        out = torch.empty((batch, rows, ldc) if batch > 1 else (rows, ldc), dtype=torch.float32, device=dev_)
         if batch > 1 and sC == (0, 0):
             sC = (rows * ldc * zdiv, rows * ldc) if zdiv > 1 else (rows * ldc, 0)
-    else:
+    elif c_planes is None:
         _chk(out, torch.float32, "out")
         if ldc is None:
             ldc = out.shape[-1]
@@ -188,12 +234,16 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
             _chk(t, torch.float32, nm)
     es = 4
     args = GemmArgs()
-    args.A = A.data_ptr() + a_off * es
+    args.A = 0 if A is None else A.data_ptr() + a_off * es
+    args.a_hi = 0 if a_planes is None else a_planes[0].data_ptr() + a_off * 2
+    args.a_lo = 0 if a_planes is None else a_planes[1].data_ptr() + a_off * 2
     args.W = W.data_ptr() + w_off * es
     args.w_hi = 0 if planes is None else planes[0].data_ptr() + w_off * 2
     args.w_lo = 0 if planes is None else planes[1].data_ptr() + w_off * 2
     args.precision = PRECISION["f16x3" if f16x3 else "f32"]
-    args.C = out.data_ptr() + c_off * es
+    args.C = 0 if c_planes is not None else out.data_ptr() + c_off * es
+    args.c_hi = 0 if c_planes is None else c_planes[0].data_ptr() + c_off * 2
+    args.c_lo = 0 if c_planes is None else c_planes[1].data_ptr() + c_off * 2
     args.bias = 0 if bias is None else bias.data_ptr()
     args.scale = 0 if scale is None else scale.data_ptr()
     args.shift = 0 if shift is None else shift.data_ptr()
@@ -214,7 +264,9 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         e0.record()
         check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
         e1.record()
-        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, gemm_kernel_name(N, act, w_kmajor, f16x3, planes is not None),
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch,
+                           "gemm_f16x3_ring_kernel<4,true>" if a_planes is not None else
+                           gemm_kernel_name(N, act, w_kmajor, f16x3, planes is not None),
                            (M, N, K, batch, act, pool)))
         return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
@@ -224,12 +276,12 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str = "none",
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, pool: int = 0, K: Optional[int] = None,
-           mode: Optional[str] = None) -> torch.Tensor:
+           mode: Optional[str] = None, out=None):
     """y = epilogue(x @ w^T): x [M, ldx] (first K columns used); w = packing.PW or an fp32 tensor
     [N, ldw] with ldw % 4 == 0."""
     from .packing import PW
 
-    M, ldx = x.shape
+    M, ldx = x.shape          # works for torch.Tensor and SplitAct alike
     if isinstance(w, PW):
         N = w.N
         if K is None:
@@ -240,7 +292,7 @@ def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str 
             K = min(ldx, ldw)
     return gemm(x, w, M=M, N=N, K=K, lda=ldx, bias=bias, scale=scale, shift=shift,
                 residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool,
-                mode=mode)
+                mode=mode, out=out)
 
 
 # --------------------------------------------------------------------------- VQ
@@ -315,8 +367,9 @@ def silu_embed(tables: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 
 def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
               beta: Optional[torch.Tensor] = None, rows_per_batch: int = 1, eps: float = 1e-5,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [rows, C]; mod [B, 2C] (AdaLN scale|shift) or gamma/beta [C]"""
+              out=None):
+    """x [rows, C]; mod [B, 2C] (AdaLN scale|shift) or gamma/beta [C]; `out` may be a SplitAct (the
+    normalised rows are then written as split-f16 planes for the next GEMM)"""
     _chk(x, torch.float32, "x")
     rows, Cc = x.shape
     ld_mod = 0
@@ -327,6 +380,11 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
             raise ValueError("layernorm: mod must be [B, 2C]")
     if gamma is not None:
         _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    if isinstance(out, SplitAct):
+        check(_lib.load().pfpp_layernorm_split(_ptr(x), _ptr(out.hi), _ptr(out.lo), _ptr(mod), ld_mod, _ptr(gamma),
+                                               _ptr(beta), rows, Cc, rows_per_batch, eps, _stream()),
+              "pfpp_layernorm_split")
+        return out
     if out is None:
         out = torch.empty_like(x)
     check(_lib.load().pfpp_layernorm(_ptr(x), _ptr(out), _ptr(mod), ld_mod, _ptr(gamma), _ptr(beta), rows, Cc,
@@ -334,11 +392,16 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
     return out
 
 
-def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float) -> torch.Tensor:
+def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float, out=None):
     _chk(qkv, torch.float32, "qkv")
     if qkv.shape != (n_frag * L, 3 * H * dh):
         raise ValueError("attn_blockdiag: qkv must be [n_frag*L, 3*H*dh]")
-    out = torch.empty((n_frag * L, H * dh), dtype=torch.float32, device=qkv.device)
+    if isinstance(out, SplitAct):
+        check(_lib.load().pfpp_attn_blockdiag_split(_ptr(qkv), _ptr(out.hi), _ptr(out.lo), n_frag, L, H, dh, scale,
+                                                    _stream()), "pfpp_attn_blockdiag_split")
+        return out
+    if out is None:
+        out = torch.empty((n_frag * L, H * dh), dtype=torch.float32, device=qkv.device)
     check(_lib.load().pfpp_attn_blockdiag(_ptr(qkv), _ptr(out), n_frag, L, H, dh, scale, _stream()),
           "pfpp_attn_blockdiag")
     return out
@@ -356,6 +419,11 @@ def attn_dense(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, 
     if key_valid_u8 is not None:
         _chk(key_valid_u8, torch.uint8, "key_valid")
         kv_stride = key_valid_u8.shape[-1]
+    if isinstance(out, SplitAct):
+        check(_lib.load().pfpp_attn_dense_split(_ptr(qkv), _ptr(out.hi), _ptr(out.lo), _ptr(seq_off), _ptr(seq_len),
+                                                _ptr(key_valid_u8), kv_stride, seq_off.numel(), max_len, H, dh, scale,
+                                                _stream()), "pfpp_attn_dense_split")
+        return out
     if out is None:
         out = torch.empty((rows, H * dh), dtype=torch.float32, device=qkv.device)
     else:

@@ -192,6 +192,60 @@ def test_gemm_packed_weight_both_modes(dev, M, N, K, act, mode):
     assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1000, 512, 512, "none"), (4096, 1536, 512, "none"), (300, 4096, 512, "geglu"),
+                                        (777, 512, 2048, "none"), (130, 128, 32, "relu")])
+def test_gemm_split_activation_planes(dev, M, N, K, act):
+    """A handed over as pre-split fp16 planes (LDS-DMA ring kernel), result optionally written as planes again"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, pack_geglu, split_f16
+
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = torch.randn(M, K, generator=g) * 2.0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    if act == "geglu":
+        hh, gg = ref.chunk(2, -1)
+        ref = hh * torch.nn.functional.gelu(gg)
+        Wp, bp = pack_geglu(W, b)
+    else:
+        ref = torch.relu(ref) if act == "relu" else ref
+        Wp, bp = W, b
+    hi, lo = split_f16(A.to(dev))
+    a_split = ops.SplitAct(hi, lo)
+    assert (a_split.float().cpu() - A).abs().max() < 1e-6 * 8         # 22 bits of every element survive
+    out = ops.linear(a_split, PW(Wp.to(dev)), bp.to(dev), act=act, mode="f16x3")
+    assert (out.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    out_s = ops.linear(a_split, PW(Wp.to(dev)), bp.to(dev), act=act, mode="f16x3",
+                       out=ops.SplitAct.empty(M, ref.shape[1], dev))
+    assert (out_s.float().cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    if act == "none":
+        h = R.clone().to(dev)
+        ops.gemm(a_split, PW(Wp.to(dev)), M=M, N=N, K=K, lda=K, out=h, ldc=N, bias=bp.to(dev), residual=h, ldr=N, mode="f16x3")
+        assert (h.cpu().double() - (ref + R.double())).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_layernorm_and_attention_split_outputs(dev):
+    """LayerNorm / attention kernels writing split planes == their fp32 outputs re-split"""
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(777, 512, generator=g).to(dev)
+    mod = (torch.randn(3, 1024, generator=g) * 0.3).to(dev)
+    y = ops.layernorm(x, mod=mod, rows_per_batch=259)
+    ys = ops.layernorm(x, mod=mod, rows_per_batch=259, out=ops.SplitAct.empty(777, 512, dev))
+    assert (ys.float() - y).abs().max() < 4e-6
+    qkv = torch.randn(4 * 25, 3 * 512, generator=g).to(dev)
+    a = ops.attn_blockdiag(qkv, 4, 25, 8, 64, 0.125)
+    a_s = ops.attn_blockdiag(qkv, 4, 25, 8, 64, 0.125, out=ops.SplitAct.empty(100, 512, dev))
+    assert (a_s.float() - a).abs().max() < 4e-6
+    off = torch.tensor([0, 60], dtype=torch.int32, device=dev); ln = torch.tensor([60, 40], dtype=torch.int32, device=dev)
+    d = ops.attn_dense(qkv, off, ln, 60, 8, 64, 0.125)
+    d_s = ops.attn_dense(qkv, off, ln, 60, 8, 64, 0.125, out=ops.SplitAct.empty(100, 512, dev))
+    assert (d_s.float() - d).abs().max() < 4e-6
+
+
 def test_gemm_linearity_full_size(dev):
     """BASELINE-size transformer GEMM (M = 32*500): f(a x + b y) == a f(x) + b f(y) to rounding"""
     from pfpp_hip import ops
