@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="puzzles per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=None, help="fix the number of valid fragments per puzzle")
+    ap.add_argument("--compact", action="store_true",
+                    help="drop padded fragment slots in the transformer (valid-fragment outputs unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -55,12 +57,13 @@ def parse():
 class SamplerWorkload:
     """device-resident state of the sampler loop for one batch of puzzles"""
 
-    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device):
+    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, compact: bool = False):
         from pfpp_hip import config, synthetic
         from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
 
         torch.manual_seed(1234)
         self.model = Denoiser(config.denoiser_config()).to(dev).eval()   # random-init weights of the reference architecture
+        self.model.denoiser.compact_padded = compact
         with torch.no_grad():   # a codebook on the scale of the latents (a trained one is)
             self.model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
         data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts)
@@ -150,7 +153,7 @@ def main():
 
     from pfpp_hip import ops
 
-    wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev)
+    wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
     for _ in range(args.warmup):
         wl.step()
 
@@ -225,6 +228,7 @@ def main():
             "config": {
                 "workload": "DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
                             "scheduler step), BASELINE configs[1] shape, inference forward",
+                "padded_slots": "dropped (compact mode)" if args.compact else "evaluated like the reference",
                 "puzzles_per_gpu": args.batch, "fragment_slots": 20, "points_per_fragment": args.points,
                 "valid_fragments_per_gpu": wl.n_frag, "puzzle_steps_per_s": round(args.batch * world * args.steps / elapsed, 2),
                 "weights": "random init, reference architecture (57.6M denoiser + 0.6M encoder params)",

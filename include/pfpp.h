@@ -195,6 +195,11 @@ int pfpp_token_combine(const float* shape_emb, const float* x_emb,
                        const float* ref_emb, const uint8_t* ref_part,
                        const float* pe, float* tok, int64_t B, int64_t P,
                        int64_t L, int64_t C, pfpp_stream_t stream);
+/* same for a compacted fragment list (padded slots dropped): n fragments, frag_pos[f] = p (row of pe) */
+int pfpp_token_combine_list(const float* shape_emb, const float* x_emb,
+                            const float* ref_emb, const uint8_t* ref_part,
+                            const float* pe, const int32_t* frag_pos, float* tok,
+                            int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
 
 /* ---- a11: AdaLN ---------------------------------------------------------------
  * MyAdaLayerNorm, denoiser/model/modules/attention.py:21-25.
@@ -211,6 +216,11 @@ int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
                    const float* gamma, const float* beta, int64_t rows,
                    int64_t C, int64_t rows_per_batch, float eps,
                    pfpp_stream_t stream);
+/* batch of a row given by an explicit per-group map instead of row / rows_per_batch:
+ * b = group_batch[row / group_rows]  (compacted fragment lists: group = fragment, group_rows = L) */
+int pfpp_layernorm_grouped(const float* x, float* y, const float* mod, int64_t ld_mod,
+                           const int32_t* group_batch, int64_t group_rows, int64_t rows,
+                           int64_t C, float eps, pfpp_stream_t stream);
 /* same, but the result is written as split-f16 planes (hi, lo*2048) for the PFPP_GEMM_F16X3 path */
 int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
                          const float* gamma, const float* beta, int64_t rows,

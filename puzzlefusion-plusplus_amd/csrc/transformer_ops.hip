@@ -60,13 +60,14 @@ __global__ __launch_bounds__(256) void token_features_kernel(
 __global__ __launch_bounds__(256) void token_combine_kernel(
     const float* __restrict__ shape_emb, const float* __restrict__ x_emb,
     const float* __restrict__ ref_emb, const uint8_t* __restrict__ ref_part,
-    const float* __restrict__ pe, float* __restrict__ tok, int64_t total4, int P, int L, int C4) {
+    const float* __restrict__ pe, const int32_t* __restrict__ frag_pos, float* __restrict__ tok,
+    int64_t total4, int P, int L, int C4) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total4) return;
   const int64_t row = gid / C4;          // (b,p,l)
   const int c4 = (int)(gid - row * C4);
   const int64_t bp = row / L;
-  const int p = (int)(bp % P);
+  const int p = frag_pos ? frag_pos[bp] : (int)(bp % P);
   const float4 s = reinterpret_cast<const float4*>(shape_emb)[gid];
   const float4 xe = reinterpret_cast<const float4*>(x_emb)[bp * C4 + c4];
   const float4 re = reinterpret_cast<const float4*>(ref_emb)[(ref_part[bp] ? 1 : 0) * C4 + c4];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ x, float* __restrict__ y, _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
     const float* __restrict__ mod,
     int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
-    int rows_per_batch, float eps) {
+    int rows_per_batch, float eps, const int32_t* __restrict__ group_batch = nullptr, int group_rows = 1) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
   const float var = wave_sum(q) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
-  const int64_t b = row / rows_per_batch;
+  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int c4 = lane + 64 * k;
@@ -402,8 +403,21 @@ extern "C" int pfpp_token_combine(const float* shape_emb, const float* x_emb, co
   const int64_t total4 = B * P * L * (C / 4);
   if (total4 == 0) return PFPP_OK;
   hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
-                     pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, tok, total4,
+                     pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, nullptr, tok, total4,
                      (int)P, (int)L, (int)(C / 4));
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_token_combine_list(const float* shape_emb, const float* x_emb, const float* ref_emb,
+                                       const uint8_t* ref_part, const float* pe, const int32_t* frag_pos,
+                                       float* tok, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(shape_emb && x_emb && ref_emb && ref_part && pe && frag_pos && tok, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0, "C % 4 != 0");
+  const int64_t total4 = n * L * (C / 4);
+  if (total4 == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, frag_pos, tok, total4, 1,
+                     (int)L, (int)(C / 4));
   return pfpp::check_launch(__func__);
 }
 
@@ -419,7 +433,16 @@ extern "C" int pfpp_silu_embed(const float* tables, const int64_t* t, float* out
 
 static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_lo, const float* mod,
                           int64_t ld_mod, const float* gamma, const float* beta, int64_t rows, int64_t C,
-                          int64_t rows_per_batch, float eps, pfpp_stream_t stream);
+                          int64_t rows_per_batch, float eps, pfpp_stream_t stream,
+                          const int32_t* group_batch = nullptr, int64_t group_rows = 1);
+
+extern "C" int pfpp_layernorm_grouped(const float* x, float* y, const float* mod, int64_t ld_mod,
+                                      const int32_t* group_batch, int64_t group_rows, int64_t rows, int64_t C,
+                                      float eps, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && y && mod && group_batch && group_rows >= 1, "null pointer / bad group size");
+  return layernorm_impl(x, y, nullptr, nullptr, mod, ld_mod, nullptr, nullptr, rows, C, 1, eps, stream, group_batch,
+                        group_rows);
+}
 
 extern "C" int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
                               const float* gamma, const float* beta, int64_t rows, int64_t C,
@@ -438,7 +461,8 @@ extern "C" int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, cons
 
 static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_lo, const float* mod,
                           int64_t ld_mod, const float* gamma, const float* beta, int64_t rows, int64_t C,
-                          int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
+                          int64_t rows_per_batch, float eps, pfpp_stream_t stream, const int32_t* group_batch,
+                          int64_t group_rows) {
   const char* __func__name = "pfpp_layernorm";
   (void)__func__name;
   PFPP_REQUIRE(!gamma || beta, "gamma without beta");
@@ -449,13 +473,14 @@ static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_
   const dim3 grid(blocks_for(rows, 4));
   const int rpb = (int)rows_per_batch;
   if (y_hi) {
-    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
-    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
+    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
+    else hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
   } else {
-    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
-    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<4, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps);
+    const int gr = (int)group_rows;
+    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
+    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
+    else hipLaunchKernelGGL((layernorm_kernel<4, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
   }
   return pfpp::check_launch("pfpp_layernorm");
 }

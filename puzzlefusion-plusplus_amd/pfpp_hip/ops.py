@@ -354,6 +354,30 @@ def token_combine(shape_emb, x_emb, ref_emb, ref_part_u8, pe, B, P, L):
     return tok
 
 
+def token_combine_list(shape_emb, x_emb, ref_emb, ref_u8, pe, frag_pos, L):
+    """token assembly for a compacted fragment list: frag_pos[f] = index of the fragment inside its puzzle"""
+    for t, nm in ((shape_emb, "shape_emb"), (x_emb, "x_emb"), (ref_emb, "ref_emb"), (pe, "pe")):
+        _chk(t, torch.float32, nm)
+    _chk(ref_u8, torch.uint8, "ref_part"); _chk(frag_pos, torch.int32, "frag_pos")
+    n, Cc = x_emb.shape
+    tok = torch.empty((n * L, Cc), dtype=torch.float32, device=shape_emb.device)
+    check(_lib.load().pfpp_token_combine_list(_ptr(shape_emb), _ptr(x_emb), _ptr(ref_emb), _ptr(ref_u8), _ptr(pe),
+                                              _ptr(frag_pos), _ptr(tok), n, L, Cc, _stream()), "pfpp_token_combine_list")
+    return tok
+
+
+def layernorm_grouped(x: torch.Tensor, mod: torch.Tensor, group_batch: torch.Tensor, group_rows: int,
+                      eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """AdaLN over a compacted token list: the batch (row of `mod`) of token r is group_batch[r // group_rows]"""
+    _chk(x, torch.float32, "x"); _chk(mod, torch.float32, "mod"); _chk(group_batch, torch.int32, "group_batch")
+    rows, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().pfpp_layernorm_grouped(_ptr(x), _ptr(out), _ptr(mod), mod.shape[-1], _ptr(group_batch), group_rows,
+                                             rows, Cc, eps, _stream()), "pfpp_layernorm_grouped")
+    return out
+
+
 def silu_embed(tables: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     """tables [n_tab, n_emb, C], t int64 [B] -> silu(tables[:, t]) [n_tab, B, C]"""
     _chk(tables, torch.float32, "tables"); _chk(t, torch.int64, "t")

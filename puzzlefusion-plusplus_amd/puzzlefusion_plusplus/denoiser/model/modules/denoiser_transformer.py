@@ -42,6 +42,10 @@ class DenoiserTransformer(nn.Module):
         self.mlp_out_rot = nn.Sequential(nn.Linear(C, C), nn.SiLU(), nn.Linear(C, C // 2), nn.SiLU(),
                                          nn.Linear(C // 2, 4))
         self._cache = PackCache()
+        # False (default): every one of the P slots is evaluated, exactly like the reference.
+        # True: padded fragment slots are dropped (their don't-care outputs become 0; the outputs of
+        # valid fragments are unchanged) — see pfpp_hip.denoiser.denoiser_forward_compact.
+        self.compact_padded = False
 
     def packed(self):
         live = dict(self.named_parameters())
@@ -56,5 +60,6 @@ class DenoiserTransformer(nn.Module):
         if self.training:
             raise RuntimeError("DenoiserTransformer (HIP): inference forward only (dropout/backward are not "
                                "implemented yet); call .eval()")
-        return hip_denoiser.denoiser_forward(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale,
-                                             ref_part, num_layers=self.num_layers, num_heads=self.num_heads)
+        fwd = hip_denoiser.denoiser_forward_compact if self.compact_padded else hip_denoiser.denoiser_forward
+        return fwd(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale, ref_part,
+                   num_layers=self.num_layers, num_heads=self.num_heads)

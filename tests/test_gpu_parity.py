@@ -318,6 +318,21 @@ def test_denoiser_vs_golden(golden, weights_sd, dev):
     assert np.abs(eps.cpu().numpy() - g["pred_noise"]).max() < TOL
 
 
+def test_denoiser_compact_mode_equals_full_on_valid_fragments(golden, weights_sd, dev):
+    """dropping the padded slots: identical predictions for every valid fragment, zeros elsewhere"""
+    from pfpp_hip import denoiser as D
+
+    g = golden("denoiser")
+    pk = D.pack_denoiser(dsd(weights_sd("denoiser"), dev), 6)
+    args = [T(g[k]).to(dev) for k in ("x", "timesteps", "latent", "xyz", "part_valids", "scale", "ref_part")]
+    full = D.denoiser_forward(pk, *args, num_layers=6, num_heads=8)
+    comp = D.denoiser_forward_compact(pk, *args, num_layers=6, num_heads=8)
+    valid = T(g["part_valids"]).bool()
+    assert (comp.cpu() - full.cpu())[valid].abs().max() < 2e-5
+    assert np.abs(comp.cpu().numpy() - g["pred_noise"])[valid.numpy()].max() < TOL
+    assert comp.cpu()[~valid].abs().max() == 0
+
+
 def test_scheduler_vs_golden(golden, dev):
     from pfpp_hip.scheduler import PiecewiseScheduler
 
