@@ -304,6 +304,20 @@ int pfpp_pose_compose(const float* pose, const int32_t* pivot,
                       const float* init_pose, const uint8_t* has_init,
                       float* out, int64_t n, pfpp_stream_t stream);
 
+/* ---- 8f-1: verifier edge features -----------------------------------------------------------------
+ * pfpp_pose_apply_points: body of get_final_pose_pts_dynamic (utils/node_merge_utils.py:16-41): a flat
+ * list of points, point i is moved by pose[pose_idx[i]] = (t, q): quaternion_apply (normalise = 0 there)
+ * then + t.
+ * pfpp_edge_histogram: get_distance_for_matching_pts (:62-89) + _make_cd_to_bins (auto_aggl.py:385-389):
+ * edge e owns the matched pairs [edge_off[e], edge_off[e+1]) of (idx_a, idx_b) (indices into pts);
+ * d_i = min_j |a_i-b_j|^2 + min_j |b_i-a_j|^2 is counted into the 6 bins
+ * [0,1e-3) [1e-3,5e-3) [5e-3,1e-2) [1e-2,5e-2) [5e-2,1e-1) [1e-1,100) -> hist [n_edges, 6] int32.  */
+int pfpp_pose_apply_points(const float* pts, const int32_t* pose_idx, const float* pose, float* out,
+                           int64_t n, int normalise, pfpp_stream_t stream);
+int pfpp_edge_histogram(const float* pts, const int32_t* idx_a, const int32_t* idx_b,
+                        const int32_t* edge_off, int32_t* hist, int64_t n_edges, int64_t max_m,
+                        pfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

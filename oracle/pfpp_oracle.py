@@ -517,6 +517,41 @@ def verifier_forward(sd, edge_features, edge_indices, mask, heads=8):
 
 
 # =============================================================================================
+# 8f-1 — verifier edge features (auto_aggl.py:184-201, node_merge_utils.py:16-41,62-89); chamferdist
+# semantics per SURVEY.md A5 (squared L2, K=1, bidirectional element-wise sum) — parity unpinned
+# =============================================================================================
+def pose_apply_points(pts, pose_idx, pose):
+    """get_final_pose_pts_dynamic body: quaternion_apply (no normalisation) + translation, per point"""
+    q = pose[pose_idx.long(), 3:]
+    return quaternion_apply(q, pts) + pose[pose_idx.long(), :3]
+
+
+def edge_histogram(pts, idx_a, idx_b, edge_off):
+    bins = torch.tensor([0.0, 1e-3, 5e-3, 1e-2, 5e-2, 1e-1, 100])
+    out = torch.zeros(len(edge_off) - 1, 6, dtype=torch.int32)
+    for e in range(len(edge_off) - 1):
+        o, m = int(edge_off[e]), int(edge_off[e + 1] - edge_off[e])
+        if m == 0:
+            continue
+        a, b = pts[idx_a[o:o + m].long()], pts[idx_b[o:o + m].long()]
+        d = ((a[:, None] - b[None]) ** 2).sum(-1)
+        cd = d.min(1)[0] + d.min(0)[0]
+        bi = torch.bucketize(cd, bins, right=True)
+        out[e] = torch.bincount(bi, minlength=bins.numel())[1:7].to(torch.int32)
+    return out
+
+
+def edge_features_from_hist(hist_pp):
+    """auto_aggl.py:195-201: upper-triangular flatten, normalise by the count, append the count"""
+    B, P = hist_pp.shape[:2]
+    mask = torch.triu(torch.ones(P, P, dtype=torch.bool), diagonal=1)
+    ef = hist_pp[:, mask]
+    n = ef.sum(dim=-1, keepdim=True)
+    ef = ef / torch.where(n == 0, 1, n)
+    return torch.cat((ef, n), dim=-1), mask.nonzero(as_tuple=False).unsqueeze(0)
+
+
+# =============================================================================================
 # sampler (Denoiser.validation_step, denoiser.py:153-185) — used for the CPU baseline
 # =============================================================================================
 def split_denoiser_ckpt(sd):

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pfpp_add_noise": [_p, _p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_verifier_embed": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
+    "pfpp_pose_apply_points": [_p, _p, _p, _p, _i64, C.c_int, _p],
+    "pfpp_edge_histogram": [_p, _p, _p, _p, _p, _i64, _i64, _p],
 }
 PLAIN = {
     "pfpp_version": ([], C.c_int),

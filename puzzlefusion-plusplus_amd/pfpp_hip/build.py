@@ -24,6 +24,7 @@ SOURCES = {
     "vq.hip": ["-ffp-contract=off"],
     "transformer_ops.hip": ["-ffp-contract=off"],
     "attention.hip": [],
+    "edgefeat.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "gemm_ring.hip": [],
 }

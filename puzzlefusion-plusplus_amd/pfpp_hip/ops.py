@@ -520,3 +520,24 @@ def pose_compose(pose, pivot, init_pose=None, has_init=None) -> torch.Tensor:
     check(_lib.load().pfpp_pose_compose(_ptr(pose), _ptr(pivot), _ptr(init_pose), _ptr(has_init), _ptr(out), n,
                                         _stream()), "pfpp_pose_compose")
     return out
+
+
+def pose_apply_points(pts: torch.Tensor, pose_idx: torch.Tensor, pose: torch.Tensor, normalise: bool = False) -> torch.Tensor:
+    """pts [n,3], pose_idx int32 [n], pose [P,7] -> R(q[pose_idx]) p + t[pose_idx]  (node_merge_utils.py:16-41)"""
+    _chk(pts, torch.float32, "pts"); _chk(pose_idx, torch.int32, "pose_idx"); _chk(pose, torch.float32, "pose")
+    out = torch.empty_like(pts)
+    check(_lib.load().pfpp_pose_apply_points(_ptr(pts), _ptr(pose_idx), _ptr(pose), _ptr(out), pts.shape[0], int(normalise),
+                                             _stream()), "pfpp_pose_apply_points")
+    return out
+
+
+def edge_histogram(pts: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor, edge_off: torch.Tensor, max_m: int) -> torch.Tensor:
+    """per-edge 6-bin histogram of the bidirectional nearest-neighbour distances of the matched points"""
+    _chk(pts, torch.float32, "pts")
+    for t, nm in ((idx_a, "idx_a"), (idx_b, "idx_b"), (edge_off, "edge_off")):
+        _chk(t, torch.int32, nm)
+    n_edges = edge_off.numel() - 1
+    hist = torch.empty((n_edges, 6), dtype=torch.int32, device=pts.device)
+    check(_lib.load().pfpp_edge_histogram(_ptr(pts), _ptr(idx_a), _ptr(idx_b), _ptr(edge_off), _ptr(hist), n_edges, max_m,
+                                          _stream()), "pfpp_edge_histogram")
+    return hist

@@ -128,3 +128,47 @@ def make_edges(batch: int, num_edges: int = 190, num_nodes: int = 20, seed: int 
         "edge_indices": torch.from_numpy(idx).to(device),
         "edge_valids": torch.from_numpy(valid).to(device),
     }
+
+
+def make_matching(batch: Dict[str, torch.Tensor], seed: int = 0, total_points: int = 5000) -> Dict[str, object]:
+    """synthetic stand-in for the Jigsaw matching data of one puzzle (B = 1), in the on-disk layout the
+    reference reads (Jigsaw_matching/model/modules/matching_base_model.py:630-640): `edges [1,E,2]` =
+    (idx2, idx1) with idx1 < idx2, one `[M,2]` correspondence array per edge (indices into the critical
+    points of the two parts), `part_pcs_by_area [1,5000,3]` (points per part proportional to its size, in
+    the part's scaled local frame), `critical_pcs_idx [1,5000]`, `n_pcs [1,P]`, `n_critical_pcs [1,P]`."""
+    rng = np.random.default_rng(777 + seed)
+    pv = int(batch["num_parts"][0])
+    P = batch["part_valids"].shape[1]
+    scale = batch["part_scale"][0, :pv, 0].cpu().numpy().astype(np.float64)
+    n_pcs = np.maximum(50, np.floor(total_points * scale / scale.sum())).astype(np.int64)
+    n_pcs[0] += total_points - n_pcs.sum() if n_pcs.sum() <= total_points else 0
+    pts, crit, n_crit = [], [], []
+    N = batch["part_pcs"].shape[2]
+    for i in range(pv):
+        sel = rng.choice(N, size=int(n_pcs[i]), replace=int(n_pcs[i]) > N)
+        pts.append(batch["part_pcs"][0, i].cpu().numpy()[sel] * float(scale[i]))
+        nc = max(10, int(n_pcs[i]) // 4)
+        n_crit.append(nc)
+        c = np.zeros(int(n_pcs[i]), np.int64)
+        c[:nc] = rng.choice(int(n_pcs[i]), size=nc, replace=False)
+        crit.append(c)
+    tot = int(n_pcs.sum())
+    by_area = np.zeros((1, max(tot, total_points), 3), np.float32); by_area[0, :tot] = np.concatenate(pts)
+    crit_all = np.zeros((1, max(tot, total_points)), np.int64); crit_all[0, :tot] = np.concatenate(crit)
+    n_pcs_p = np.zeros((1, P), np.int64); n_pcs_p[0, :pv] = n_pcs
+    n_crit_p = np.zeros((1, P), np.int64); n_crit_p[0, :pv] = n_crit
+    edges, corr = [], []
+    for i in range(pv):
+        for j in range(i + 1, pv):
+            if rng.random() < min(1.0, 3.0 / pv):
+                m = int(rng.integers(30, 300))
+                edges.append((j, i))                     # (idx2, idx1)
+                corr.append(np.stack([rng.integers(0, n_crit[i], m), rng.integers(0, n_crit[j], m)], 1))
+    if not edges:
+        edges, corr = [(1, 0)], [np.stack([rng.integers(0, n_crit[0], 40), rng.integers(0, n_crit[1], 40)], 1)]
+    dev = batch["part_pcs"].device
+    return {
+        "edges": torch.tensor(edges, dtype=torch.int64)[None].to(dev), "correspondences": corr,
+        "part_pcs_by_area": torch.from_numpy(by_area).to(dev), "critical_pcs_idx": torch.from_numpy(crit_all).to(dev),
+        "n_pcs": torch.from_numpy(n_pcs_p).to(dev), "n_critical_pcs": torch.from_numpy(n_crit_p).to(dev),
+    }
