@@ -539,6 +539,12 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
     // row panels to fill the chip several times over
     if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32) return launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
+    // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
+    // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave
+    static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;
+    const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+    if (pre && wide && tiles128 < small_thresh && a->act != PFPP_ACT_GEGLU && a->pool == 0)
+      return launch_f16x3<2, 1, true>(p, a->batch, st);
     if (pre) return wide ? launch_f16x3<2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
     return wide ? launch_f16x3<2, 2, false>(p, a->batch, st) : launch_f16x3<2, 1, false>(p, a->batch, st);
   }

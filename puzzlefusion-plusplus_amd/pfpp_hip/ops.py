@@ -164,12 +164,21 @@ def split_mode() -> bool:
 GEMM_TRACE = None
 
 
-def gemm_kernel_name(N: int, act: str, w_kmajor: bool, f16x3: bool = False, presplit: bool = False) -> str:
-    """which template instantiation csrc/gemm.hip dispatches to (mirror of pfpp_gemm's choice)"""
+def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: bool, f16x3: bool = False,
+                     presplit: bool = False, a_presplit: bool = False) -> str:
+    """the template instantiation pfpp_gemm dispatches to (mirror of the choice in csrc/gemm.hip with the
+    default environment) — used to attribute HIP-event timings to the kernel names rocprofv3 reports"""
     wide = N > 64 or act == "geglu"
     if f16x3 and not w_kmajor:
-        return f"gemm_f16x3_kernel<2,{2 if wide else 1},{'true' if presplit else 'false'}>"
-    return f"gemm_f32_mfma_kernel<2,{2 if wide else 1},{'true' if w_kmajor else 'false'}>"
+        if a_presplit:
+            return "gemm_f16x3_ring_kernel<4, true>"
+        if presplit and wide and M >= 8192 and pool != 32:
+            return "gemm_f16x3_kernel<2, 2, true, 4, 2>"
+        tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        if presplit and wide and tiles128 < 1024 and act != "geglu" and pool == 0:
+            return "gemm_f16x3_kernel<2, 1, true, 2, 2>"
+        return f"gemm_f16x3_kernel<2, {2 if wide else 1}, {'true' if presplit else 'false'}, 2, 2>"
+    return f"gemm_f32_mfma_kernel<2, {2 if wide else 1}, {'true' if w_kmajor else 'false'}>"
 
 
 def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[int] = None,
@@ -265,8 +274,7 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
         e1.record()
         GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch,
-                           "gemm_f16x3_ring_kernel<4,true>" if a_planes is not None else
-                           gemm_kernel_name(N, act, w_kmajor, f16x3, planes is not None),
+                           gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, planes is not None, a_planes is not None),
                            (M, N, K, batch, act, pool)))
         return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
