@@ -128,11 +128,12 @@ enum {
 
 /* arithmetic of the contraction (see csrc/gemm.hip):
  *   PFPP_GEMM_F32   v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s roofline)
- *   PFPP_GEMM_F16X3 split-f16: x = hi + lo/2048 (hi, lo fp16), A.W = hi.hi + (hi.lo + lo.hi)/2048 on
- *                   v_mfma_f32_32x32x16_f16 — fp32-grade error (dropped term 2^-22 relative) at up to
- *                   16/3 of the fp32-MFMA rate; needs |x| < 65504; not available with w_kmajor.
+ *   PFPP_GEMM_F16X3 split-f16: x = hi + lo (hi = f16(x), lo = f16(x - hi)), A.W = hi.hi + hi.lo + lo.hi on
+ *                   v_mfma_f32_32x32x16_f16 — fp32-grade error (dropped term 2^-22 relative; elements
+ *                   below 2^-3 carry an absolute error <= 3e-8) at up to 16/3 of the fp32-MFMA rate;
+ *                   needs |x| < 65504; not available with w_kmajor.
  *                   W may be handed over pre-split (w_hi/w_lo: fp16 [N, ldw] planes, ldw = K rounded
- *                   up to 8 and zero padded, lo pre-scaled by 2048) or as fp32 (split on the fly). */
+ *                   up to 8 and zero padded) or as fp32 (split on the fly). */
 enum { PFPP_GEMM_F32 = 0, PFPP_GEMM_F16X3 = 1 };
 
 typedef struct pfpp_gemm_args {
@@ -221,7 +222,7 @@ int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
 int pfpp_layernorm_grouped(const float* x, float* y, const float* mod, int64_t ld_mod,
                            const int32_t* group_batch, int64_t group_rows, int64_t rows,
                            int64_t C, float eps, pfpp_stream_t stream);
-/* same, but the result is written as split-f16 planes (hi, lo*2048) for the PFPP_GEMM_F16X3 path */
+/* same, but the result is written as split-f16 planes (hi, lo) for the PFPP_GEMM_F16X3 path */
 int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
                          const float* gamma, const float* beta, int64_t rows,
                          int64_t C, int64_t rows_per_batch, float eps,

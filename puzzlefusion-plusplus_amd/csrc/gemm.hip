@@ -5,9 +5,10 @@
 //  PFPP_GEMM_F32 — v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (bitwise a
 //      k-ordered fmaf chain).  Roofline: 157.3 TFLOP/s.
 //
-//  PFPP_GEMM_F16X3 — "split-f16": every fp32 operand x is written as hi + lo/2048 with
-//      hi = f16(x), lo = f16((x - hi) * 2048) (x - hi is exact in fp32, so hi/lo carry 22 bits of
-//      x), and A.W is evaluated as  hi.hi + (hi.lo + lo.hi)/2048  with three
+//  PFPP_GEMM_F16X3 — "split-f16": every fp32 operand x is written as hi + lo with
+//      hi = f16(x), lo = f16(x - hi) (x - hi is exact in fp32, so hi/lo carry 22 bits of x; below
+//      |x| = 2^-3 lo becomes f16-subnormal: absolute error <= 3e-8), and A.W is evaluated as
+//      hi.hi + hi.lo + lo.hi  into ONE fp32 accumulator with three
 //      v_mfma_f32_32x32x16_f16 per 16-deep step: f16 products are exact in the fp32 accumulator,
 //      the dropped lo.lo term is 2^-22 relative — fp32-grade results (measured against the 1e-4
 //      parity bar of the path) at 16/3 of the fp32-MFMA rate.  W's planes are pre-split once on
@@ -27,6 +28,7 @@
 
 namespace pfpp_gemm_detail {
 int launch_f16x3_ring(const GemmP& p, int batch, hipStream_t st, int group_m);   // gemm_ring.hip
+int launch_f16x3_ws(const GemmP& p, int batch, hipStream_t st, int group_m);     // gemm_ws.hip
 }
 
 namespace {
@@ -242,12 +244,12 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   for (int e = 0; e < 4; ++e) {
     const _Float16 h = (_Float16)x[e];
     hi[e] = h;
-    lo[e] = (_Float16)((x[e] - (float)h) * 2048.0f);
+    lo[e] = (_Float16)(x[e] - (float)h);
   }
 }
 
 template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void gemm_f16x3_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_kernel(const GemmP p) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
@@ -277,13 +279,13 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void gemm_f16x3
   const int64_t c_off = z0 * p.sC0 + z1 * p.sC1;
   const int64_t v_off = z0 * p.sV0 + z1 * p.sV1;
 
-  f32x16 accM[MT][NT], accC[MT][NT];
+  f32x16 accM[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
+      for (int e = 0; e < 16; ++e) accM[i][j][e] = 0.0f;
 
   // ---- staging registers and (clamped) source rows ---------------------------------------------
   constexpr int NWF = WPRE ? 1 : WF_IT;
@@ -382,25 +384,31 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void gemm_f16x3
     const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        ah[i] = *reinterpret_cast<const half8*>(a_base + i * 32 * LDH + ks * 16);
-        al[i] = *reinterpret_cast<const half8*>(a_base + PLANE_A + i * 32 * LDH + ks * 16);
-      }
+      half8 bh[NT], bl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         bh[j] = *reinterpret_cast<const half8*>(w_base + j * 32 * LDH + ks * 16);
         bl[j] = *reinterpret_cast<const half8*>(w_base + PLANE_W + j * 32 * LDH + ks * 16);
       }
+      // A fragments two M-tiles at a time (keeps the 128x64 wave tile of the 256x256 variant in registers)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i0 = 0; i0 < MT; i0 += 2) {
+        half8 ah[2], al[2];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
-          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
-          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
+        for (int ii = 0; ii < 2; ++ii) {
+          ah[ii] = *reinterpret_cast<const half8*>(a_base + (i0 + ii) * 32 * LDH + ks * 16);
+          al[ii] = *reinterpret_cast<const half8*>(a_base + PLANE_A + (i0 + ii) * 32 * LDH + ks * 16);
         }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            // small terms first, then the leading one — all into the same accumulator
+            accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
+            accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bl[j], accM[i0 + ii][j], 0, 0, 0);
+            accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
+          }
+      }
     }
   };
 
@@ -424,12 +432,6 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void gemm_f16x3
     __syncthreads();
   }
 
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) accM[i][j][e] += accC[i][j][e] * (1.0f / 2048.0f);
   epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
 }
 
@@ -535,9 +537,17 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     if (apre) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop, no conversions
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
     if (pre && wide && use_ring && a->K % 32 == 0) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
+    static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;
+    if (pre && wide && use_ws) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
     static const bool big_tile = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
     // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
     // row panels to fill the chip several times over
+    // operand delivery from L2 is ~11 B/clk/CU whatever the load structure (profiles/README.md), so the
+    // matrix pipe's utilisation is set by bytes per MFMA ~ (BM+BN)/(BM*BN): 256x256 (8 waves of 128x64)
+    // where the grid still fills the chip, 256x128 for narrower N
+    static const bool big_waves4 = getenv("PFPP_GEMM_BIG4") && atoi(getenv("PFPP_GEMM_BIG4")) == 1;   // 4 waves of 128x128: slower (174 vs 245 TFLOP/s), experiment only
+    if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
+      return big_waves4 ? launch_f16x3<4, 4, true, 2, 2>(p, a->batch, st) : launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
     if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32) return launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
     // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
     // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave

@@ -69,42 +69,47 @@ __device__ __forceinline__ void store_out(const GemmP& p, int64_t idx, float v) 
   }
 }
 
+// activation over one accumulator tile: the switch sits outside the element loop, so the fully unrolled
+// epilogue touches each accumulator exactly once (a per-element switch, or one epilogue copy per
+// activation, keeps the 256-register accumulator array of the 4x4-tile waves in scratch)
+__device__ __forceinline__ f32x16 act_tile(f32x16 t, int act) {
+  switch (act) {
+    case PFPP_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = t[e] > 0.0f ? t[e] : 0.0f;
+      break;
+    case PFPP_ACT_SILU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = t[e] / (1.0f + expf(-t[e]));
+      break;
+    case PFPP_ACT_GELU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = 0.5f * t[e] * (1.0f + erff(t[e] * 0.70710678118654752440f));
+      break;
+    default: break;
+  }
+  return t;
+}
+
 // acc[i][j]: MT x NT tiles of the wave whose top-left element is (row_w, col_w)
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int row_w, int col_w,
                                          int n0, int wn, int lane, int64_t c_off, int64_t v_off) {
+  (void)n0; (void)wn;
   const int l31 = lane & 31, lhi = lane >> 5;
   const float* R = p.residual ? p.residual + c_off : nullptr;
   const float* bias = p.bias ? p.bias + v_off : nullptr;
   const float* scale = p.scale ? p.scale + v_off : nullptr;
   const float* shift = p.shift ? p.shift + v_off : nullptr;
   const float alpha = p.alpha;
-
-  if (p.act == PFPP_ACT_GEGLU) {
-    if constexpr (NT == 2) {
-      // value columns in tile j=0, their gate columns in tile j=1 (host packing)
-      const int ncol = col_w + l31;                   // packed value column
-      const int ocol = (n0 >> 1) + wn * 32 + l31;     // output column
-      const bool col_ok = ncol + 32 < p.N;
-      const float bu = (bias && col_ok) ? bias[ncol] : 0.0f;
-      const float bg = (bias && col_ok) ? bias[ncol + 32] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (row < p.M && col_ok) {
-            const float u = acc[i][0][e] * alpha + bu;
-            const float g = acc[i][1][e] * alpha + bg;
-            store_out(p, c_off + (int64_t)row * p.ldc + ocol, u * act_apply(g, PFPP_ACT_GELU));
-          }
-        }
-    }
-    return;
-  }
+  const bool geglu = p.act == PFPP_ACT_GEGLU;
+  const int pool = p.pool;
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
+    // GEGLU: value columns in the even tiles, their gate columns in the next odd tile (host packing:
+    // 32 value columns then their 32 gate columns per 64 packed columns); the odd tile's pass gates
+    // what the even tile's pass left in `held`
     const int col = col_w + j * 32 + l31;
     const bool col_ok = col < p.N;
     float sc = 1.0f, sh = 0.0f;
@@ -112,48 +117,56 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
       if (scale) { sc = scale[col]; sh = shift[col]; }
       else if (bias) { sh = bias[col]; }
     }
-    if (p.pool == 0) {
+    const int ocol = geglu ? ((col_w + (j & ~1) * 32) >> 1) + l31 : col;
+    float mx[MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+      f32x16 t = acc[i][j];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = t[e] * alpha;
+        t[e] = scale ? v * sc + sh : v + sh;
+      }
+      if (geglu) {
+        if constexpr (NT >= 2) {
+          if ((j & 1) == 0) { acc[i][j] = t; continue; }       // value tile: keep u for the gate pass
+          t = act_tile(t, PFPP_ACT_GELU);
+          const f32x16 u = acc[i][j - 1];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t[e] = u[e] * t[e];
+        }
+      } else {
+        t = act_tile(t, p.act);
+      }
+      if (pool == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
           if (row < p.M && col_ok) {
-            float v = acc[i][j][e] * alpha;
-            v = scale ? v * sc + sh : v + sh;
-            v = act_apply(v, p.act);
+            float v = t[e];
             if (R) v += R[(int64_t)row * p.ldr + col];
-            store_out(p, c_off + (int64_t)row * p.ldc + col, v);
+            store_out(p, c_off + (int64_t)row * p.ldc + ocol, v);
           }
         }
-    } else {
-      // max over groups of `pool` consecutive rows (pool = 32: one MFMA tile, pool = 64: both
-      // M-tiles of the wave); groups never straddle M
-      float mx[MT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      } else {
+        // max over groups of `pool` consecutive rows (pool = 32: one MFMA tile, pool = 64: both
+        // M-tiles of the wave); groups never straddle M
         float m = -__builtin_huge_valf();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] * alpha;
-          v = scale ? v * sc + sh : v + sh;
-          v = act_apply(v, p.act);
-          m = fmaxf(m, v);
-        }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        mx[i] = m;
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, t[e]);
+        mx[i] = fmaxf(m, __shfl_xor(m, 32));
       }
-      if (p.pool == 64) {
-        if constexpr (MT == 2) {
-          if (lhi == 0 && col_ok && row_w < p.M)
-            store_out(p, c_off + (int64_t)(row_w >> 6) * p.ldc + col, fmaxf(mx[0], mx[1]));
-        }
-      } else {
+    }
+    if (pool == 64) {
+      if constexpr (MT == 2) {
+        if (lhi == 0 && col_ok && row_w < p.M)
+          store_out(p, c_off + (int64_t)(row_w >> 6) * p.ldc + col, fmaxf(mx[0], mx[1]));
+      }
+    } else if (pool == 32) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row0 = row_w + i * 32;
-          if (lhi == 0 && col_ok && row0 < p.M) store_out(p, c_off + (int64_t)(row0 >> 5) * p.ldc + col, mx[i]);
-        }
+      for (int i = 0; i < MT; ++i) {
+        const int row0 = row_w + i * 32;
+        if (lhi == 0 && col_ok && row0 < p.M) store_out(p, c_off + (int64_t)(row0 >> 5) * p.ldc + col, mx[i]);
       }
     }
   }

@@ -59,7 +59,7 @@ __device__ __forceinline__ void split8(const v4f v0, const v4f v1, half8& hi, ha
   for (int e = 0; e < 8; ++e) {
     const _Float16 h = (_Float16)x[e];
     hi[e] = h;
-    lo[e] = (_Float16)((x[e] - (float)h) * 2048.0f);
+    lo[e] = (_Float16)(x[e] - (float)h);
   }
 }
 
@@ -138,13 +138,13 @@ __global__ __launch_bounds__(256) void gemm_f16x3_ring_kernel(const GemmP p) {
     }
   };
 
-  f32x16 accM[2][2], accC[2][2];
+  f32x16 accM[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
+      for (int e = 0; e < 16; ++e) accM[i][j][e] = 0.0f;
 
   // ---- fragment addressing ---------------------------------------------------------------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)ring_smem;
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void gemm_f16x3_ring_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], accM[i][j], 0, 0, 0);
-        accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accC[i][j], 0, 0, 0);
-        accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accC[i][j], 0, 0, 0);
+        accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], accM[i][j], 0, 0, 0);
+        accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], accM[i][j], 0, 0, 0);
       }
   };
 
@@ -233,12 +233,6 @@ __global__ __launch_bounds__(256) void gemm_f16x3_ring_kernel(const GemmP p) {
     mma(f1);
   }
 
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) accM[i][j][e] += accC[i][j][e] * (1.0f / 2048.0f);
   epilogue<2, 2>(p, accM, m0 + wm * 64, n0 + wn * 64, n0, wn, lane, c_off, v_off);
 }
 

@@ -27,13 +27,15 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace pfpp
 
-// x = hi + lo/2048 with hi = f16(x), lo = f16((x - hi) * 2048): x - hi is exact in fp32, so the pair
-// carries 22 bits of x (the operand format of the PFPP_GEMM_F16X3 path, csrc/gemm.hip)
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): x - hi is exact in fp32, so the pair carries 22 bits of
+// x for |x| >= 2^-3 and an absolute error <= 3e-8 below that (f16 subnormal spacing 6e-8) — the operand
+// format of the PFPP_GEMM_F16X3 path (csrc/gemm.hip).  lo is NOT pre-scaled, so hi.hi, hi.lo and lo.hi
+// accumulate into one fp32 accumulator.
 struct pfpp_hl { _Float16 hi, lo; };
 __device__ __forceinline__ pfpp_hl pfpp_split(float x) {
   pfpp_hl r;
   r.hi = (_Float16)x;
-  r.lo = (_Float16)((x - (float)r.hi) * 2048.0f);
+  r.lo = (_Float16)(x - (float)r.hi);
   return r;
 }
 // assigns into two targets (vector elements are not bindable to references)

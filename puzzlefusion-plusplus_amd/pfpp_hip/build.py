@@ -27,6 +27,7 @@ SOURCES = {
     "edgefeat.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "gemm_ring.hip": [],
+    "gemm_ws.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 

@@ -130,7 +130,7 @@ GEMM_MODE = _os.environ.get("PFPP_GEMM", "f16x3")
 PRECISION = {"f32": 0, "f16x3": 1}
 
 class SplitAct:
-    """an activation travelling as split-f16 planes (hi, lo*2048), each fp16 [rows, C]: produced by the
+    """an activation travelling as split-f16 planes (hi, lo = x - hi), each fp16 [rows, C]: produced by the
     LayerNorm / attention kernels and GEMM epilogues, consumed as the A operand of the split-f16 GEMM with
     no conversion work (csrc/gemm_ring.hip)"""
 
@@ -149,7 +149,7 @@ class SplitAct:
         return self.hi.shape
 
     def float(self) -> torch.Tensor:
-        return self.hi.float() + self.lo.float() / 2048.0
+        return self.hi.float() + self.lo.float()
 
 
 def split_mode() -> bool:
@@ -172,6 +172,8 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
     if f16x3 and not w_kmajor:
         if a_presplit:
             return "gemm_f16x3_ring_kernel<4, true>"
+        if presplit and wide and M >= 8192 and N >= 1024 and pool == 0:
+            return "gemm_f16x3_kernel<4, 2, true, 2, 4>"
         if presplit and wide and M >= 8192 and pool != 32:
             return "gemm_f16x3_kernel<2, 2, true, 4, 2>"
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch

@@ -28,11 +28,11 @@ def pad_k(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
 
 def split_f16(w: torch.Tensor):
     """fp32 [..., N, K] -> (hi, lo) fp16 planes [..., N, round_up(K, 8)] for the split-f16 GEMM:
-    hi = f16(w), lo = f16((w - hi) * 2048); zero padded (csrc/gemm.hip, PFPP_GEMM_F16X3)"""
+    hi = f16(w), lo = f16(w - hi) (unscaled); zero padded (csrc/gemm.hip, PFPP_GEMM_F16X3)"""
     k = w.shape[-1]
     kp = round_up(k, 8)
     hi = w.to(torch.float16)
-    lo = ((w - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
     if kp != k:
         pad = (0, kp - k)
         hi = torch.nn.functional.pad(hi, pad)
