@@ -319,6 +319,119 @@ int pfpp_edge_histogram(const float* pts, const int32_t* idx_a, const int32_t* i
                         const int32_t* edge_off, int32_t* hist, int64_t n_edges, int64_t max_m,
                         pfpp_stream_t stream);
 
+/* =====================================================================================================
+ * a17: training — backward of the DenoiserTransformer, loss and optimizer
+ * (Denoiser.forward/_loss/training_step/configure_optimizers, denoiser/model/denoiser.py:80-145,230-241).
+ * The encoder is frozen in the reference (train_denoiser.py:33-35): gradients stop at the tokens.
+ * ===================================================================================================== */
+
+/* ---- backward GEMMs (csrc/gemm_grad.hip) ----------------------------------------------------------
+ *   C[M,N] (+)= alpha * sum_k A(m,k) * W(n,k)
+ *   a_kmajor = 0: A(m,k) = A[m*lda + k]     a_kmajor = 1: A(m,k) = A[k*lda + m]
+ *   w_kmajor = 0: W(n,k) = W[n*ldw + k]     w_kmajor = 1: W(n,k) = W[k*ldw + n]
+ * dX = dY . W        : A = dY, W = the [out,in] weight with w_kmajor = 1
+ * dW = dY^T . X      : A = dY (a_kmajor = 1), W = X (w_kmajor = 1), K = rows
+ * split-f16 arithmetic (PFPP_GEMM_F16X3); a_scale / w_scale are powers of two applied before the
+ * f16 split (gradients are tiny) and divided out of the result.  split_k = 0 picks the number of K
+ * chunks; more than one chunk needs accumulate = 1 (fp32 atomics into a zero-initialised C).     */
+typedef struct pfpp_gemm_grad_args {
+  const float* A; const float* W; float* C;
+  int64_t M, N, K;
+  int64_t lda, ldw, ldc;
+  int32_t a_kmajor, w_kmajor;
+  int32_t accumulate;
+  int32_t split_k;
+  int32_t batch;
+  int64_t sA, sW, sC;
+  float a_scale, w_scale, alpha;
+} pfpp_gemm_grad_args;
+int pfpp_gemm_grad(const pfpp_gemm_grad_args* args, pfpp_stream_t stream);
+
+/* out[z, c] (+)= sum_r x[z, r, c]  (bias gradients).  x rows of stride ld, batches of stride sx / so */
+int pfpp_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld,
+                int64_t batch, int64_t sx, int64_t so, int accumulate, pfpp_stream_t stream);
+
+/* ---- counter-based dropout --------------------------------------------------------------------------
+ * keep(i) = rng(seed, site, i) >= p * 2^32 ; y = x * keep / (1 - p).  The same (seed, site) gives the
+ * same mask in forward and backward, so masks are never stored.  Sites of the denoiser: token dropout
+ * (PositionalEncoding, utils/model_utils.py:18-21, p = 0.1), the dropout after each attention
+ * out-projection and inside each FeedForward (diffusers Attention.to_out[1] / FeedForward.net[1],
+ * attention.py:46-72 with dropout_rate of config/denoiser/model.yaml).
+ * pfpp_dropout: out = (res ? res : 0) + x*keep/(1-p)   (x may alias out)
+ * pfpp_dropout_mask: the keep mask itself as uint8 (tests, oracle)                                  */
+int pfpp_dropout(const float* x, const float* res, float* out, int64_t n, float p,
+                 uint64_t seed, uint32_t site, pfpp_stream_t stream);
+int pfpp_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t site,
+                      pfpp_stream_t stream);
+
+/* ---- GEGLU (diffusers FeedForward "geglu", attention.py:67-72) with its dropout, training form ------
+ * z [rows, 2*inner] = proj output (value columns [0,inner), gate columns [inner, 2*inner))
+ * fwd: u[r,c] = drop(z[r,c] * gelu_erf(z[r,inner+c]))
+ * bwd: dz[r,c] = du' * gelu(g) ; dz[r,inner+c] = du' * v * gelu'(g) with du' = du*keep/(1-p)        */
+int pfpp_geglu(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed,
+               uint32_t site, pfpp_stream_t stream);
+int pfpp_geglu_bwd(const float* z, const float* du, float* dz, int64_t rows, int64_t inner, float p,
+                   uint64_t seed, uint32_t site, pfpp_stream_t stream);
+
+/* elementwise activation and its backward on a flat buffer (output heads: SiLU)                     */
+int pfpp_act(const float* pre, float* out, int64_t n, int act, pfpp_stream_t stream);
+int pfpp_act_bwd(const float* pre, const float* dy, float* dx, int64_t n, int act, pfpp_stream_t stream);
+
+/* ---- LayerNorm backward (MyAdaLayerNorm attention.py:21-25, norm3) ----------------------------------
+ * y = xhat * mult + add with  mult = 1 + mod[b, 0:C], add = mod[b, C:2C]  (mod != NULL, AdaLN)
+ *                       or    mult = gamma, add = beta                    (gamma != NULL)
+ *   dx[r, :]      += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * mult
+ *   dmult[b, c]   += sum_r dy * xhat       dadd[b, c] += sum_r dy      (b = 0 for the affine form)
+ * batch of a row: group_batch[row / group_rows] if group_batch else row / rows_per_batch; group_rows
+ * rows are handled per workgroup (rows_per_batch % group_rows == 0).  dmult/dadd rows have stride ld_d.
+ * C in {256, 512}.                                                                                   */
+int pfpp_layernorm_bwd(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                       const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                       int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                       int64_t rows, int64_t C, float eps, pfpp_stream_t stream);
+
+/* ---- attention backward ---------------------------------------------------------------------------
+ * dqkv [rows, 3*H*dh] receives (dq | dk | dv) of softmax(q.k^T * scale) v.
+ * pfpp_attn_dense_train: pfpp_attn_dense that also writes lse[row, h] = log sum_j exp(s_ij) (needed by
+ * the backward).  pfpp_attn_dense_bwd: two passes without atomics — dq per query block, dk/dv per key
+ * block, both recomputing the probabilities from q, k and lse.                                       */
+int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_frag,
+                            int64_t L, int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+int pfpp_attn_dense_train(const float* qkv, float* out, float* lse, const int32_t* seq_off,
+                          const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride,
+                          int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                          pfpp_stream_t stream);
+int pfpp_attn_dense_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                        float* dvec /* workspace [rows, H] */, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
+                        const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                        int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+
+/* ---- small backward pieces ----------------------------------------------------------------------------
+ * mean_pool_bwd:   dx[(f,l), :] = dpooled[f, :] / L                         (denoiser_transformer.py:139-142)
+ * token_combine_bwd: dx_emb[f, :] = sum_l dtok[(f,l), :]; dref_emb[ref[f], :] += dx_emb[f, :]
+ *                  (the shape-embedding gradient is dtok itself; pe is a buffer)
+ * silu_embed_bwd:  dtables[i][t[b], :] += dse[i, b, :] * silu'(tables[i][t[b], :])                     */
+int pfpp_mean_pool_bwd(const float* dpooled, float* dx, int64_t n, int64_t L, int64_t C,
+                       pfpp_stream_t stream);
+int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part, float* dx_emb, float* dref_emb,
+                           int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
+int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const float* dse, float* dtables,
+                        int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, pfpp_stream_t stream);
+
+/* ---- loss (Denoiser._loss, denoiser.py:118-126) ---------------------------------------------------------
+ * loss = mean over the selected rows (valid, non-reference fragments) x 7 of (pred - target)^2;
+ * dpred = grad_out * 2 (pred - target) / (7 * n_sel) on selected rows, 0 elsewhere.  loss [1].       */
+int pfpp_mse_loss(const float* pred, const float* target, const uint8_t* sel, float* loss,
+                  float* dpred, int64_t n, int64_t width, float grad_out, pfpp_stream_t stream);
+
+/* ---- AdamW (configure_optimizers, denoiser.py:230-241; torch.optim.AdamW semantics) ---------------------
+ * p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g^2;
+ * p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)      with bc1 = 1-b1^t, bc2 = 1-b2^t, g *= g_scale.
+ * hi/lo (may be NULL): refreshed split-f16 planes of p for the forward GEMMs.                        */
+int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo, int64_t n,
+               float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+               float bc2, float g_scale, pfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
     const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
     _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
-    int H, float scale) {
+    int H, float scale, float* __restrict__ lse) {
   constexpr int KT = 32;
   constexpr int LDK = DH + 4;
   constexpr int NCH = DH / 8;      // 8-wide k chunks of the head dimension
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
   // ---- normalise and store: lane holds O[query = l31][d = dt*32 + 8g + 4*lhi + (0..3)] ------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (lse && q_row < T && lhi == 0) lse[(row0 + q_row) * H + h] = m_run + logf(l_tot);   // training: saved for the backward
   if (q_row < T) {
     const int64_t off = (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
 #pragma unroll
@@ -184,7 +185,17 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
 
 static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
                            const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq,
-                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream,
+                           float* lse = nullptr);
+
+extern "C" int pfpp_attn_dense_train(const float* qkv, float* out, float* lse, const int32_t* seq_off,
+                                     const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride,
+                                     int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                                     pfpp_stream_t stream) {
+  PFPP_REQUIRE(out && lse, "null pointer");
+  return attn_dense_impl(qkv, out, nullptr, nullptr, seq_off, seq_len, key_valid, kv_stride, n_seq, max_len, H, dh,
+                         scale, stream, lse);
+}
 
 extern "C" int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,
                                const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
@@ -205,7 +216,7 @@ extern "C" int pfpp_attn_dense_split(const float* qkv, void* out_hi, void* out_l
 
 static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
                            const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq,
-                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+                           int64_t max_len, int64_t H, int64_t dh, float scale, pfpp_stream_t stream, float* lse) {
   PFPP_REQUIRE(qkv && seq_off && seq_len, "null pointer");
   PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1, "bad sizes");
   PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
@@ -217,9 +228,9 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   hipStream_t st = pfpp::as_stream(stream);
   if (dh == 64)
     hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
-                       key_valid, kv_stride, (int)H, scale);
+                       key_valid, kv_stride, (int)H, scale, lse);
   else
     hipLaunchKernelGGL(attn_dense_kernel<32>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
-                       key_valid, kv_stride, (int)H, scale);
+                       key_valid, kv_stride, (int)H, scale, lse);
   return pfpp::check_launch("pfpp_attn_dense");
 }

@@ -1,0 +1,426 @@
+// a17: backward of the two attentions of an EncoderLayer (attention.py:77-85).
+//
+// Dense (global) attention — two passes, no atomics, probabilities recomputed from q, k and the
+// log-sum-exp rows the training forward saved (pfpp_attn_dense_train):
+//   pass 1 (per 32-query block per wave, keys streamed through LDS like the forward):
+//       S^T = K.Q^T, P = exp(S*scale - lse), dP^T = V.dO^T, dS^T = P*(dP^T - D)*scale, dQ^T += K^T.dS^T
+//       with D[q] = dO[q].O[q]  (also written out for pass 2)
+//   pass 2 (per 32-key block per wave, queries streamed):
+//       S = Q.K^T, P, dP = dO.V^T, dS as above,  dV^T += dO^T.P,  dK^T += Q^T.dS
+// Both use the forward's register trick: with v_mfma_f32_32x32x2_f32 and the lane-half split of the
+// contraction index, the 16 accumulator values a lane holds of the first product are exactly the
+// B-operand values the second product needs, so P / dS never leave the registers.  Exact fp32
+// products (gradients need no operand scaling here).
+//
+// Block-diagonal self-attention (L <= 32 tokens per fragment): one wave per (fragment, head), all
+// five small products on the VALU out of LDS.
+#include "pfpp_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KT = 32;
+
+// ---------------------------------------------------------------------------------------------------
+// pass 1: dQ (and D)
+// ---------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dense_bwd_dq_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len,
+    const uint8_t* __restrict__ key_valid, int64_t kv_stride, int H, float scale) {
+  constexpr int LDK = DH + 4;
+  constexpr int NCH = DH / 8;
+  constexpr int NDT = DH / 32;
+  constexpr int F4 = KT * DH / 4 / 256;
+  __shared__ __align__(16) float Ks[2][KT * LDK];
+  __shared__ __align__(16) float Vs[2][KT * LDK];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 128;
+  if (q_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+  const uint8_t* kv = key_valid ? key_valid + (int64_t)b * kv_stride : nullptr;
+
+  const int q_row = q_base + wave * 32 + l31;
+  const int q_cl = min(q_row, T - 1);
+  const float* qp = base + (int64_t)q_cl * ld + lhi * 4;
+  const float* op = out + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+  const float* dop = dout + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+  float4 qf[NCH], dof[NCH];
+  float dpart = 0.0f;
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+    qf[kc] = *reinterpret_cast<const float4*>(qp + kc * 8);
+    dof[kc] = *reinterpret_cast<const float4*>(dop + kc * 8);
+    const float4 o = *reinterpret_cast<const float4*>(op + kc * 8);
+    dpart += (dof[kc].x * o.x + dof[kc].y * o.y) + (dof[kc].z * o.z + dof[kc].w * o.w);
+  }
+  const float Dq = dpart + __shfl_xor(dpart, 32);
+  const float lse_q = lse[(row0 + q_cl) * H + h];
+  if (q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
+
+  f32x16 dq_acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq_acc[dt][e] = 0.0f;
+
+  float4 rk[F4], rv[F4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      rk[it] = *reinterpret_cast<const float4*>(src);
+      rv[it] = *reinterpret_cast<const float4*>(src + C);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      *reinterpret_cast<float4*>(&Ks[buf][r * LDK + c4 * 4]) = rk[it];
+      *reinterpret_cast<float4*>(&Vs[buf][r * LDK + c4 * 4]) = rv[it];
+    }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int k0 = t * KT;
+    if (t + 1 < nt) load_tile(k0 + KT);
+    const int kidx = k0 + l31;
+    const bool kval = kidx < T && (!kv || kv[kidx] != 0);
+    const unsigned kmask = (unsigned)(__ballot(kval) & 0xffffffffull);
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.0f; dp[e] = 0.0f; }
+    const float* kp = &Ks[buf][l31 * LDK + lhi * 4];
+    const float* vp = &Vs[buf][l31 * LDK + lhi * 4];
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      const float4 a = *reinterpret_cast<const float4*>(kp + kc * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[kc].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[kc].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[kc].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[kc].w, s, 0, 0, 0);
+      const float4 c = *reinterpret_cast<const float4*>(vp + kc * 8);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, dof[kc].x, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, dof[kc].y, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, dof[kc].z, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, dof[kc].w, dp, 0, 0, 0);
+    }
+    // dS^T[key][query] in place of s
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const float p = (kmask >> key) & 1u ? expf(s[e] * scale - lse_q) : 0.0f;
+      s[e] = p * (dp[e] - Dq) * scale;
+    }
+    // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const float* kc_p = &Ks[buf][(lhi * 4) * LDK + dt * 32 + l31];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        dq_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc_p[(kc * 8 + 0) * LDK], s[4 * kc + 0], dq_acc[dt], 0, 0, 0);
+        dq_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc_p[(kc * 8 + 1) * LDK], s[4 * kc + 1], dq_acc[dt], 0, 0, 0);
+        dq_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc_p[(kc * 8 + 2) * LDK], s[4 * kc + 2], dq_acc[dt], 0, 0, 0);
+        dq_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc_p[(kc * 8 + 3) * LDK], s[4 * kc + 3], dq_acc[dt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    float* dst = dqkv + (row0 + q_row) * ld + h * DH + lhi * 4;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
+            make_float4(dq_acc[dt][4 * g + 0], dq_acc[dt][4 * g + 1], dq_acc[dt][4 * g + 2], dq_acc[dt][4 * g + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 2: dK, dV
+// ---------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dense_bwd_dkv_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride, int H,
+    float scale) {
+  constexpr int LDK = DH + 4;
+  constexpr int NCH = DH / 8;
+  constexpr int NDT = DH / 32;
+  constexpr int F4 = KT * DH / 4 / 256;
+  __shared__ __align__(16) float Qs[2][KT * LDK];
+  __shared__ __align__(16) float Gs[2][KT * LDK];     // dO tile
+  __shared__ float Ls[2][KT];                         // lse of the query tile
+  __shared__ float Ds[2][KT];                         // D of the query tile
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int k_base = blockIdx.x * 128;
+  if (k_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+  const uint8_t* kv = key_valid ? key_valid + (int64_t)b * kv_stride : nullptr;
+
+  const int k_row = k_base + wave * 32 + l31;
+  const bool key_ok = k_row < T && (!kv || kv[k_row] != 0);
+  const float* kp = base + (int64_t)min(k_row, T - 1) * ld + C + lhi * 4;
+  float4 kf[NCH], vf[NCH];
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+    kf[kc] = *reinterpret_cast<const float4*>(kp + kc * 8);
+    vf[kc] = *reinterpret_cast<const float4*>(kp + C + kc * 8);
+  }
+  f32x16 dk_acc[NDT], dv_acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk_acc[dt][e] = 0.0f; dv_acc[dt][e] = 0.0f; }
+
+  float4 rq[F4], rg[F4];
+  float rl = 0.0f, rd = 0.0f;
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const int64_t qr = min(q0 + r, T - 1);
+      rq[it] = *reinterpret_cast<const float4*>(base + qr * ld + c4 * 4);
+      rg[it] = *reinterpret_cast<const float4*>(dout + (row0 + qr) * (int64_t)C + h * DH + c4 * 4);
+    }
+    if (tid < KT) {
+      const int64_t qr = min(q0 + tid, T - 1);
+      rl = lse[(row0 + qr) * H + h];
+      rd = dvec[(row0 + qr) * H + h];
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      *reinterpret_cast<float4*>(&Qs[buf][r * LDK + c4 * 4]) = rq[it];
+      *reinterpret_cast<float4*>(&Gs[buf][r * LDK + c4 * 4]) = rg[it];
+    }
+    if (tid < KT) { Ls[buf][tid] = rl; Ds[buf][tid] = rd; }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int q0 = t * KT;
+    if (t + 1 < nt) load_tile(q0 + KT);
+
+    // S[q][key] = Q.K^T,  dP[q][key] = dO.V^T
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.0f; dp[e] = 0.0f; }
+    const float* qp = &Qs[buf][l31 * LDK + lhi * 4];
+    const float* gp = &Gs[buf][l31 * LDK + lhi * 4];
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + kc * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kf[kc].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kf[kc].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kf[kc].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kf[kc].w, s, 0, 0, 0);
+      const float4 c = *reinterpret_cast<const float4*>(gp + kc * 8);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, vf[kc].x, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, vf[kc].y, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, vf[kc].z, dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c.w, vf[kc].w, dp, 0, 0, 0);
+    }
+    // p in s, dS in dp
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const bool ok = key_ok && (q0 + qi) < T;
+      const float p = ok ? expf(s[e] * scale - Ls[buf][qi]) : 0.0f;
+      s[e] = p;
+      dp[e] = p * (dp[e] - Ds[buf][qi]) * scale;
+    }
+    // dV^T[d][key] += dO^T[d][q] . P[q][key];  dK^T[d][key] += Q^T[d][q] . dS[q][key]
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const float* gc = &Gs[buf][(lhi * 4) * LDK + dt * 32 + l31];
+      const float* qc = &Qs[buf][(lhi * 4) * LDK + dt * 32 + l31];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dv_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[(kc * 8 + j) * LDK], s[4 * kc + j], dv_acc[dt], 0, 0, 0);
+          dk_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[(kc * 8 + j) * LDK], dp[4 * kc + j], dk_acc[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (k_row < T) {
+    float* dst = dqkv + (row0 + k_row) * ld + C + h * DH + lhi * 4;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
+            make_float4(dk_acc[dt][4 * g + 0], dk_acc[dt][4 * g + 1], dk_acc[dt][4 * g + 2], dk_acc[dt][4 * g + 3]);
+        *reinterpret_cast<float4*>(dst + C + dt * 32 + 8 * g) =
+            make_float4(dv_acc[dt][4 * g + 0], dv_acc[dt][4 * g + 1], dv_acc[dt][4 * g + 2], dv_acc[dt][4 * g + 3]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// block-diagonal attention backward: one 64-thread workgroup per (fragment, head)
+// ---------------------------------------------------------------------------------------------------
+constexpr int BD_L = 32;
+constexpr int BD_DH = 64;
+constexpr int BD_LD = BD_DH + 4;    // 16-byte aligned rows, conflict-light
+constexpr int BD_LP = BD_L + 1;
+
+__global__ __launch_bounds__(64) void attn_blockdiag_bwd_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, int L, int H, float scale) {
+  __shared__ __align__(16) float sq[BD_L * BD_LD], sk[BD_L * BD_LD], sv[BD_L * BD_LD], sg[BD_L * BD_LD];
+  __shared__ float sp[BD_L * BD_LP], sd[BD_L * BD_LP];
+  const int tid = threadIdx.x;
+  const int64_t pair = blockIdx.x;
+  const int64_t frag = pair / H;
+  const int h = (int)(pair - frag * H);
+  const int C = H * BD_DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + frag * L * ld + h * BD_DH;
+  const float* gbase = dout + frag * L * (int64_t)C + h * BD_DH;
+  for (int i = tid; i < L * 16; i += 64) {
+    const int r = i >> 4, c4 = i & 15;
+    *reinterpret_cast<float4*>(&sq[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(base + r * ld + c4 * 4);
+    *reinterpret_cast<float4*>(&sk[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(base + r * ld + C + c4 * 4);
+    *reinterpret_cast<float4*>(&sv[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(base + r * ld + 2 * C + c4 * 4);
+    *reinterpret_cast<float4*>(&sg[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(gbase + r * (int64_t)C + c4 * 4);
+  }
+  __syncthreads();
+  // scores and dP
+  for (int idx = tid; idx < L * L; idx += 64) {
+    const int i = idx / L, j = idx - i * L;
+    float a = 0.0f, g = 0.0f;
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const float4 q = *reinterpret_cast<const float4*>(&sq[i * BD_LD + c4 * 4]);
+      const float4 k = *reinterpret_cast<const float4*>(&sk[j * BD_LD + c4 * 4]);
+      const float4 o = *reinterpret_cast<const float4*>(&sg[i * BD_LD + c4 * 4]);
+      const float4 v = *reinterpret_cast<const float4*>(&sv[j * BD_LD + c4 * 4]);
+      a = fmaf(q.x, k.x, a); a = fmaf(q.y, k.y, a); a = fmaf(q.z, k.z, a); a = fmaf(q.w, k.w, a);
+      g = fmaf(o.x, v.x, g); g = fmaf(o.y, v.y, g); g = fmaf(o.z, v.z, g); g = fmaf(o.w, v.w, g);
+    }
+    sp[i * BD_LP + j] = a * scale;
+    sd[i * BD_LP + j] = g;
+  }
+  __syncthreads();
+  // softmax rows, then dS = P*(dP - sum_j P*dP)*scale
+  if (tid < L) {
+    float m = -__builtin_huge_valf();
+    for (int j = 0; j < L; ++j) m = fmaxf(m, sp[tid * BD_LP + j]);
+    float sum = 0.0f;
+    for (int j = 0; j < L; ++j) {
+      const float e = expf(sp[tid * BD_LP + j] - m);
+      sp[tid * BD_LP + j] = e;
+      sum += e;
+    }
+    const float inv = 1.0f / sum;
+    float dsum = 0.0f;
+    for (int j = 0; j < L; ++j) {
+      const float p = sp[tid * BD_LP + j] * inv;
+      sp[tid * BD_LP + j] = p;
+      dsum += p * sd[tid * BD_LP + j];
+    }
+    for (int j = 0; j < L; ++j) sd[tid * BD_LP + j] = sp[tid * BD_LP + j] * (sd[tid * BD_LP + j] - dsum) * scale;
+  }
+  __syncthreads();
+  // thread = head-dim column d
+  const int d = tid;
+  float* obase = dqkv + frag * L * ld + h * BD_DH + d;
+  for (int i = 0; i < L; ++i) {
+    float dq = 0.0f, dk = 0.0f, dv = 0.0f;
+    for (int j = 0; j < L; ++j) {
+      dq = fmaf(sd[i * BD_LP + j], sk[j * BD_LD + d], dq);       // dQ[i] = sum_j dS[i][j] K[j]
+      dk = fmaf(sd[j * BD_LP + i], sq[j * BD_LD + d], dk);       // dK[i] = sum_j dS[j][i] Q[j]
+      dv = fmaf(sp[j * BD_LP + i], sg[j * BD_LD + d], dv);       // dV[i] = sum_j P[j][i] dO[j]
+    }
+    obase[i * ld] = dq;
+    obase[i * ld + C] = dk;
+    obase[i * ld + 2 * C] = dv;
+  }
+}
+
+}  // namespace
+
+extern "C" int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L,
+                                       int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && dout && dqkv, "null pointer");
+  PFPP_SUPPORTED(dh == BD_DH, "dim_head != 64");
+  PFPP_SUPPORTED(L >= 1 && L <= BD_L, "L outside [1, 32]");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(dout), "16-byte alignment");
+  const int64_t pairs = n_frag * H;
+  if (pairs == 0) return PFPP_OK;
+  hipLaunchKernelGGL(attn_blockdiag_bwd_kernel, dim3((unsigned)pairs), dim3(64), 0, pfpp::as_stream(stream), qkv, dout,
+                     dqkv, (int)L, (int)H, scale);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                                   float* dvec, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
+                                   const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                                   int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out && dout && lse && dvec && dqkv && seq_off && seq_len, "null pointer");
+  PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1, "bad sizes");
+  PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
+  PFPP_SUPPORTED(n_seq <= 65535 && H <= 65535, "too many sequences / heads for one launch");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out) && pfpp::aligned16(dout) && pfpp::aligned16(dqkv),
+               "16-byte alignment");
+  if (n_seq == 0) return PFPP_OK;
+  const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
+  hipStream_t st = pfpp::as_stream(stream);
+  if (dh == 64) {
+    hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<64>, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off,
+                       seq_len, key_valid, kv_stride, (int)H, scale);
+    hipLaunchKernelGGL(attn_dense_bwd_dkv_kernel<64>, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
+                       seq_len, key_valid, kv_stride, (int)H, scale);
+  } else {
+    hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<32>, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off,
+                       seq_len, key_valid, kv_stride, (int)H, scale);
+    hipLaunchKernelGGL(attn_dense_bwd_dkv_kernel<32>, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
+                       seq_len, key_valid, kv_stride, (int)H, scale);
+  }
+  return pfpp::check_launch(__func__);
+}

@@ -1,0 +1,317 @@
+// Training-side GEMMs (a17, backward of the linear layers of denoiser_transformer.py / attention.py):
+//
+//     dX[M,Kin]   = dY[M,Nout] . W[Nout,Kin]          "NN": A row-major, W k-major
+//     dW[Nout,Kin] = dY[M,Nout]^T . X[M,Kin]          "TN": both operands k-major (contraction over rows)
+//
+// Same split-f16 arithmetic, LDS layout and wave tiling as gemm.hip's forward kernel; what differs is
+// how a tile reaches LDS.  A k-major operand (element (r,k) at base[k*ld + r]) is read as 16-byte
+// loads along r for 4 consecutive k; the 4x4 block is transposed in registers (renaming only) and
+// written as four 8-byte k-runs, so the fragment reads and the MFMA loop are unchanged — no transposed
+// copy of dY, X or the weights ever exists in HBM.
+//
+// Gradient operands are small numbers (1e-3 .. 1e-7): `a_scale` / `w_scale` (powers of two, exact in
+// fp32) lift them into the normal f16 range before the hi/lo split and the epilogue divides back.
+//
+// Weight gradients have few output tiles and a long contraction (all tokens): the K range is cut into
+// `split_k` chunks over blockIdx.y which accumulate with hardware fp32 atomics (`accumulate`, also
+// what lets several micro-batches add into one .grad buffer).
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace {
+
+using namespace pfpp_gemm_detail;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDH = BK + 8;
+
+struct GradP {
+  const float* A; const float* W; float* C;
+  int M, N, K;
+  int64_t lda, ldw, ldc;
+  int64_t sA, sW, sC;
+  int k_chunk;              // K range per blockIdx.y (multiple of BK)
+  int accumulate;
+  float a_scale, w_scale, alpha;
+  int tiles_n, tiles_m, group_m;
+};
+
+__device__ __forceinline__ void split4s(const float4 v, float s, half4& hi, half4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 h = (_Float16)x[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(x[e] - (float)h);
+  }
+}
+
+// One operand tile: R rows (output rows or columns) x BK of the contraction -> hi/lo planes [R][LDH].
+template <int R, int NTHR, bool KM>
+struct OperandLoader {
+  // row-major: 8 lanes x float4 cover the 32 k of a row;  k-major: unit = (4 k) x (4 r)
+  static constexpr int UNITS = KM ? (R / 4) * 8 : R * 8;
+  static constexpr int IT = (UNITS + NTHR - 1) / NTHR;
+  float4 reg[IT][KM ? 4 : 1];
+
+  __device__ __forceinline__ void load(const float* base, int64_t ld, int r0, int rmax, int k0, int kend, int tid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int u = tid + it * NTHR;
+      if (UNITS % NTHR != 0 && u >= UNITS) break;
+      if constexpr (KM) {
+        const int kg = u & 7, c4 = u >> 3;
+        const int r = r0 + c4 * 4;
+        const bool r_ok = r < rmax;            // extents along r are multiples of 4 (checked on the host)
+        const float* src = base + (int64_t)(k0 + 4 * kg) * ld + (r_ok ? r : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = r_ok && (k0 + 4 * kg + j) < kend;
+          reg[it][j] = ok ? *reinterpret_cast<const float4*>(src + j * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        const int row = u >> 3, c4 = u & 7;
+        const float* src = base + (int64_t)min(r0 + row, rmax - 1) * ld;
+        const int k = k0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 4 <= kend) {
+          v = *reinterpret_cast<const float4*>(src + k);
+        } else if (k < kend) {
+          v = *reinterpret_cast<const float4*>(src + k);   // inside the (4-padded) row; mask the tail
+          if (k + 1 >= kend) v.y = 0.f;
+          if (k + 2 >= kend) v.z = 0.f;
+          v.w = 0.f;
+        }
+        reg[it][0] = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(_Float16* hi_plane, _Float16* lo_plane, float scale, int tid) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int u = tid + it * NTHR;
+      if (UNITS % NTHR != 0 && u >= UNITS) break;
+      if constexpr (KM) {
+        const int kg = u & 7, c4 = u >> 3;
+        const float4 a = reg[it][0], b = reg[it][1], c = reg[it][2], d = reg[it][3];
+        const float4 col[4] = {make_float4(a.x, b.x, c.x, d.x), make_float4(a.y, b.y, c.y, d.y),
+                               make_float4(a.z, b.z, c.z, d.z), make_float4(a.w, b.w, c.w, d.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          half4 hi, lo;
+          split4s(col[e], scale, hi, lo);
+          const int off = (c4 * 4 + e) * LDH + 4 * kg;
+          *reinterpret_cast<half4*>(hi_plane + off) = hi;
+          *reinterpret_cast<half4*>(lo_plane + off) = lo;
+        }
+      } else {
+        const int row = u >> 3, c4 = u & 7;
+        half4 hi, lo;
+        split4s(reg[it][0], scale, hi, lo);
+        const int off = row * LDH + c4 * 4;
+        *reinterpret_cast<half4*>(hi_plane + off) = hi;
+        *reinterpret_cast<half4*>(lo_plane + off) = lo;
+      }
+    }
+  }
+};
+
+template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP p) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int BM = 32 * MT * WM;
+  constexpr int BN = 32 * NT * WN;
+  constexpr int PLANE_A = BM * LDH;
+  constexpr int PLANE_W = BN * LDH;
+  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;
+  extern __shared__ __align__(16) _Float16 grad_smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int tile = remap_tile(blockIdx.x, gridDim.x);
+  int tm, tn;
+  {
+    GemmP g;
+    g.group_m = p.group_m; g.tiles_n = p.tiles_n; g.tiles_m = p.tiles_m;
+    tile_coords(g, tile, tm, tn);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const float* A = p.A + z * p.sA;
+  const float* W = p.W + z * p.sW;
+  float* C = p.C + z * p.sC;
+  const int kb = blockIdx.y * p.k_chunk;
+  const int ke = min(p.K, kb + p.k_chunk);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  OperandLoader<BM, NTHR, AKM> la;
+  OperandLoader<BN, NTHR, WKM> lw;
+
+  auto store_tiles = [&](int buf) {
+    _Float16* st = grad_smem + buf * STAGE;
+    la.store(st, st + PLANE_A, p.a_scale, tid);
+    lw.store(st + 2 * PLANE_A, st + 2 * PLANE_A + PLANE_W, p.w_scale, tid);
+  };
+  auto compute = [&](int buf) {
+    const _Float16* st = grad_smem + buf * STAGE;
+    const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
+    const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(a_base + i * 32 * LDH + ks * 16);
+        al[i] = *reinterpret_cast<const half8*>(a_base + PLANE_A + i * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(w_base + j * 32 * LDH + ks * 16);
+        bl[j] = *reinterpret_cast<const half8*>(w_base + PLANE_W + j * 32 * LDH + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = (ke - kb + BK - 1) / BK;
+  if (nk > 0) {
+    la.load(A, p.lda, m0, p.M, kb, ke, tid);
+    lw.load(W, p.ldw, n0, p.N, kb, ke, tid);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool has_next = kt + 1 < nk;
+    if (has_next) {
+      la.load(A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, tid);
+      lw.load(W, p.ldw, n0, p.N, kb + (kt + 1) * BK, ke, tid);
+    }
+    compute(kt & 1);
+    if (has_next) store_tiles((kt & 1) ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: plain store or atomic accumulate ------------------------------------------------
+  const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = col_w + j * 32 + l31;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        if (row < p.M) {
+          float* dst = C + (int64_t)row * p.ldc + col;
+          const float v = acc[i][j][e] * p.alpha;
+          if (p.accumulate) unsafeAtomicAdd(dst, v);
+          else *dst = v;
+        }
+      }
+  }
+}
+
+template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
+int launch_grad(GradP p, int batch, int splits, hipStream_t st) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
+  static bool attr_set = false;
+  auto kern = gemm_grad_kernel<MT, NT, WM, WN, AKM, WKM>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.group_m = p.tiles_n > 1 ? 8 : 0;
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, p);
+  return pfpp::check_launch("pfpp_gemm_grad");
+}
+
+template <bool AKM, bool WKM>
+int dispatch(GradP p, int batch, int split_k, hipStream_t st) {
+  // tile shape by how many workgroups the output gives: 256x128 when that still fills the chip
+  const auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
+  int bm = 128, bn = 64;
+  if (tiles(256, 128) >= 384) { bm = 256; bn = 128; }
+  else if (tiles(128, 128) >= 256 || p.N > 64) { bm = 128; bn = 128; }
+  if (bm == 128 && bn == 128 && tiles(128, 128) < 192 && split_k == 1 && p.N <= 2048) { bn = 64; }
+  int splits = split_k;
+  if (splits <= 0 && !p.accumulate) splits = 1;     // a plain store cannot be split
+  if (splits <= 0) {
+    // auto: enough workgroups for ~3 per CU, chunks of at least 256 deep
+    const int64_t t = tiles(bm, bn);
+    int64_t want = (768 + t - 1) / t;
+    const int64_t max_by_k = (p.K + 255) / 256;
+    if (want > max_by_k) want = max_by_k;
+    splits = (int)(want < 1 ? 1 : want);
+  }
+  int chunk = (p.K + splits - 1) / splits;
+  chunk = (chunk + BK - 1) / BK * BK;
+  splits = (p.K + chunk - 1) / chunk;
+  p.k_chunk = chunk;
+  if (splits > 1 && !p.accumulate) {
+    pfpp::set_error("pfpp_gemm_grad: split_k > 1 needs accumulate (zero-initialised output)");
+    return PFPP_EINVAL;
+  }
+  if (bm == 256) return launch_grad<2, 2, 4, 2, AKM, WKM>(p, batch, splits, st);
+  if (bn == 128) return launch_grad<2, 2, 2, 2, AKM, WKM>(p, batch, splits, st);
+  return launch_grad<2, 1, 2, 2, AKM, WKM>(p, batch, splits, st);
+}
+
+}  // namespace
+
+extern "C" int pfpp_gemm_grad(const pfpp_gemm_grad_args* a, pfpp_stream_t stream) {
+  PFPP_REQUIRE(a && a->A && a->W && a->C, "null pointer");
+  PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K >= 0, "bad sizes");
+  PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
+  PFPP_REQUIRE(a->lda % 4 == 0 && a->ldw % 4 == 0 && pfpp::aligned16(a->A) && pfpp::aligned16(a->W),
+               "lda/ldw must be multiples of 4 and A/W 16-byte aligned");
+  PFPP_REQUIRE(a->sA % 4 == 0 && a->sW % 4 == 0, "batch strides must keep 16-byte alignment");
+  if (a->a_kmajor) PFPP_REQUIRE(a->M % 4 == 0 && a->lda >= a->M, "k-major A: M % 4 != 0 or lda < M");
+  else PFPP_REQUIRE(a->lda >= ((a->K + 3) & ~3ll), "lda smaller than K rounded up to 4");
+  if (a->w_kmajor) PFPP_REQUIRE(a->N % 4 == 0 && a->ldw >= a->N, "k-major W: N % 4 != 0 or ldw < N");
+  else PFPP_REQUIRE(a->ldw >= ((a->K + 3) & ~3ll), "ldw smaller than K rounded up to 4");
+  PFPP_REQUIRE(a->ldc >= a->N && a->batch >= 1 && a->split_k >= 0, "bad ldc / batch / split_k");
+  PFPP_REQUIRE(a->a_scale > 0.0f && a->w_scale > 0.0f, "operand scales must be positive");
+  PFPP_SUPPORTED(a->a_kmajor == 0 || a->w_kmajor != 0, "k-major A with row-major W");
+
+  GradP p;
+  p.A = a->A; p.W = a->W; p.C = a->C;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.sA = a->sA; p.sW = a->sW; p.sC = a->sC;
+  p.accumulate = a->accumulate;
+  p.a_scale = a->a_scale; p.w_scale = a->w_scale;
+  p.alpha = a->alpha / (a->a_scale * a->w_scale);
+  p.k_chunk = 0;
+  hipStream_t st = pfpp::as_stream(stream);
+  if (a->a_kmajor) return dispatch<true, true>(p, a->batch, a->split_k, st);
+  if (a->w_kmajor) return dispatch<false, true>(p, a->batch, a->split_k, st);
+  return dispatch<false, false>(p, a->batch, a->split_k, st);
+}

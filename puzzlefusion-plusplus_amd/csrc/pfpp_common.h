@@ -41,6 +41,22 @@ __device__ __forceinline__ pfpp_hl pfpp_split(float x) {
 // assigns into two targets (vector elements are not bindable to references)
 #define PFPP_SPLIT_TO(x, HI, LO) do { const pfpp_hl _s = pfpp_split(x); (HI) = _s.hi; (LO) = _s.lo; } while (0)
 
+// counter-based generator behind the dropout sites (pfpp_dropout / pfpp_geglu): splitmix64 finaliser
+// of (seed, site, element index); forward and backward regenerate the same keep mask.
+__host__ __device__ __forceinline__ uint32_t pfpp_rng_u32(uint64_t seed, uint32_t site, uint64_t idx) {
+  uint64_t z = seed ^ ((uint64_t)site * 0xD6E8FEB86659FD93ull);
+  z += (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+// keep threshold for drop probability p: keep iff rng >= thresh
+inline uint32_t pfpp_drop_thresh(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+}
+
 #define PFPP_REQUIRE(cond, msg)                                   \
   do {                                                            \
     if (!(cond)) {                                                \

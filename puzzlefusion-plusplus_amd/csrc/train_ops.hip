@@ -1,0 +1,537 @@
+// a17: the memory-bound pieces of the training step — dropout, GEGLU forward/backward, LayerNorm
+// backward, bias gradients, pooling / token / embedding backward, the loss and AdamW.  Everything here
+// streams its operands once (float4 where the layout allows); column reductions finish with fp32
+// hardware atomics.  The contractions live in gemm_grad.hip, the attention backward in
+// attention_bwd.hip.
+#include "pfpp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float g) {
+  return 0.5f * (1.0f + erff(g * 0.70710678118654752440f)) + g * 0.39894228040143267794f * expf(-0.5f * g * g);
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_grad(float v) {
+  const float s = 1.0f / (1.0f + expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums
+// ---------------------------------------------------------------------------------------------------
+// block = 64 column lanes (float4 each) x 4 row phases; grid (col chunks of 256, row chunks, batch)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     int64_t rows, int cols, int64_t ld, int rows_per_block,
+                                                     int64_t sx, int64_t so) {
+  __shared__ float4 red[4][64];
+  const int cl = threadIdx.x & 63, rp = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cl) * 4;
+  const float* xb = x + blockIdx.z * sx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    for (int64_t r = r0 + rp; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + r * ld + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[rp][cl] = a;
+  __syncthreads();
+  if (rp == 0 && c < cols) {
+    const float4 b = red[1][cl], d = red[2][cl], e = red[3][cl];
+    float* o = out + blockIdx.z * so + c;
+    unsafeAtomicAdd(o + 0, (a.x + b.x) + (d.x + e.x));
+    unsafeAtomicAdd(o + 1, (a.y + b.y) + (d.y + e.y));
+    unsafeAtomicAdd(o + 2, (a.z + b.z) + (d.z + e.z));
+    unsafeAtomicAdd(o + 3, (a.w + b.w) + (d.w + e.w));
+  }
+}
+
+// unaligned / narrow fallback (output head: 3 and 4 columns inside a 7-wide buffer): one wave per column
+__global__ __launch_bounds__(64) void colsum_narrow_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           int64_t rows, int64_t ld, int64_t sx, int64_t so) {
+  const int c = blockIdx.x;
+  const float* xb = x + blockIdx.z * sx;
+  float a = 0.0f;
+  for (int64_t r = threadIdx.x; r < rows; r += 64) a += xb[r * ld + c];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out + blockIdx.z * so + c, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dropout
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                      float* __restrict__ out, int64_t n, uint32_t thresh,
+                                                      float inv_keep, uint64_t seed, uint32_t site) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 4 <= n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i4);
+    float4 r = res ? *reinterpret_cast<const float4*>(res + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.x += pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? v.x * inv_keep : 0.0f;
+    r.y += pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? v.y * inv_keep : 0.0f;
+    r.z += pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? v.z * inv_keep : 0.0f;
+    r.w += pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? v.w * inv_keep : 0.0f;
+    *reinterpret_cast<float4*>(out + i4) = r;
+  } else {
+    for (int64_t i = i4; i < n; ++i)
+      out[i] = (res ? res[i] : 0.0f) + (pfpp_rng_u32(seed, site, i) >= thresh ? x[i] * inv_keep : 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, int64_t n, uint32_t thresh,
+                                                           uint64_t seed, uint32_t site) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = pfpp_rng_u32(seed, site, i) >= thresh ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GEGLU
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ z, float* __restrict__ u, int64_t rows,
+                                                    int inner, uint32_t thresh, float inv_keep, uint64_t seed,
+                                                    uint32_t site) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // index into u [rows, inner]
+  if (i4 >= rows * inner) return;
+  const int64_t r = i4 / inner;
+  const int c = (int)(i4 - r * inner);
+  const float4 v = *reinterpret_cast<const float4*>(z + r * 2 * inner + c);
+  const float4 g = *reinterpret_cast<const float4*>(z + r * 2 * inner + inner + c);
+  float4 o;
+  o.x = v.x * gelu_f(g.x); o.y = v.y * gelu_f(g.y); o.z = v.z * gelu_f(g.z); o.w = v.w * gelu_f(g.w);
+  if (thresh) {
+    o.x = pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? o.x * inv_keep : 0.0f;
+    o.y = pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? o.y * inv_keep : 0.0f;
+    o.z = pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? o.z * inv_keep : 0.0f;
+    o.w = pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? o.w * inv_keep : 0.0f;
+  }
+  *reinterpret_cast<float4*>(u + i4) = o;
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ du,
+                                                        float* __restrict__ dz, int64_t rows, int inner,
+                                                        uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= rows * inner) return;
+  const int64_t r = i4 / inner;
+  const int c = (int)(i4 - r * inner);
+  const float4 v = *reinterpret_cast<const float4*>(z + r * 2 * inner + c);
+  const float4 g = *reinterpret_cast<const float4*>(z + r * 2 * inner + inner + c);
+  float4 d = *reinterpret_cast<const float4*>(du + i4);
+  if (thresh) {
+    d.x = pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? d.x * inv_keep : 0.0f;
+    d.y = pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? d.y * inv_keep : 0.0f;
+    d.z = pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? d.z * inv_keep : 0.0f;
+    d.w = pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? d.w * inv_keep : 0.0f;
+  }
+  float4 dv, dg;
+  dv.x = d.x * gelu_f(g.x); dv.y = d.y * gelu_f(g.y); dv.z = d.z * gelu_f(g.z); dv.w = d.w * gelu_f(g.w);
+  dg.x = d.x * v.x * gelu_grad(g.x); dg.y = d.y * v.y * gelu_grad(g.y);
+  dg.z = d.z * v.z * gelu_grad(g.z); dg.w = d.w * v.w * gelu_grad(g.w);
+  *reinterpret_cast<float4*>(dz + r * 2 * inner + c) = dv;
+  *reinterpret_cast<float4*>(dz + r * 2 * inner + inner + c) = dg;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ pre, const float* __restrict__ dy,
+                                                  float* __restrict__ out, int64_t n, int act) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = pre[i];
+  float r;
+  if (dy) {   // backward
+    const float d = dy[i];
+    switch (act) {
+      case PFPP_ACT_RELU: r = v > 0.0f ? d : 0.0f; break;
+      case PFPP_ACT_SILU: r = d * silu_grad(v); break;
+      case PFPP_ACT_GELU: r = d * gelu_grad(v); break;
+      default: r = d; break;
+    }
+  } else {
+    switch (act) {
+      case PFPP_ACT_RELU: r = v > 0.0f ? v : 0.0f; break;
+      case PFPP_ACT_SILU: r = silu_f(v); break;
+      case PFPP_ACT_GELU: r = gelu_f(v); break;
+      default: r = v; break;
+    }
+  }
+  out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward: one workgroup per group of rows that share (scale, shift); wave w takes rows
+// w, w+4, ...; a lane owns the same 4*VPL columns in every row, so the column sums of the group stay
+// in registers until the end (LDS across the 4 waves, then one atomic per column).
+// ---------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mod, int64_t ld_mod,
+    const float* __restrict__ gamma, const int32_t* __restrict__ group_batch, int group_rows, int rows_per_batch,
+    float* __restrict__ dx, float* __restrict__ dmult, float* __restrict__ dadd, int64_t ld_d, int64_t rows,
+    float eps) {
+  constexpr int C = 256 * VPL;
+  __shared__ float red[2][4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r_begin = (int64_t)blockIdx.x * group_rows;
+  const int64_t r_end = min(rows, r_begin + group_rows);
+  const int64_t b = group_batch ? (int64_t)group_batch[blockIdx.x] : (mod ? r_begin / rows_per_batch : 0);
+
+  float4 mult[VPL], accA[VPL], accB[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    if (mod) {
+      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
+      mult[k] = make_float4(1.0f + sc.x, 1.0f + sc.y, 1.0f + sc.z, 1.0f + sc.w);
+    } else if (gamma) {
+      mult[k] = reinterpret_cast<const float4*>(gamma)[c4];
+    } else {
+      mult[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    accA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accB[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+    float4 v[VPL], d[VPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      v[k] = xr[lane + 64 * k];
+      d[k] = dr[lane + 64 * k];
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+      q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.0f, s2 = 0.0f;
+    float4 g[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      v[k].x *= rstd; v[k].y *= rstd; v[k].z *= rstd; v[k].w *= rstd;          // xhat
+      g[k] = make_float4(d[k].x * mult[k].x, d[k].y * mult[k].y, d[k].z * mult[k].z, d[k].w * mult[k].w);
+      s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+      s2 += (g[k].x * v[k].x + g[k].y * v[k].y) + (g[k].z * v[k].z + g[k].w * v[k].w);
+      accA[k].x += d[k].x * v[k].x; accA[k].y += d[k].y * v[k].y;
+      accA[k].z += d[k].z * v[k].z; accA[k].w += d[k].w * v[k].w;
+      accB[k].x += d[k].x; accB[k].y += d[k].y; accB[k].z += d[k].z; accB[k].w += d[k].w;
+    }
+    const float c1 = wave_sum(s1) / (float)C;
+    const float c2 = wave_sum(s2) / (float)C;
+    float4* dxr = reinterpret_cast<float4*>(dx + row * C);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      float4 o = dxr[lane + 64 * k];
+      o.x += rstd * (g[k].x - c1 - v[k].x * c2);
+      o.y += rstd * (g[k].y - c1 - v[k].y * c2);
+      o.z += rstd * (g[k].z - c1 - v[k].z * c2);
+      o.w += rstd * (g[k].w - c1 - v[k].w * c2);
+      dxr[lane + 64 * k] = o;
+    }
+  }
+  if (!dmult) return;      // uniform
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    *reinterpret_cast<float4*>(&red[0][wave][c]) = accA[k];
+    *reinterpret_cast<float4*>(&red[1][wave][c]) = accB[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float a = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const float bb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    unsafeAtomicAdd(dmult + b * ld_d + c, a);
+    unsafeAtomicAdd(dadd + b * ld_d + c, bb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pooling / token / embedding backward
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restrict__ dp, float* __restrict__ dx,
+                                                            int64_t n, int L, int C) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;    // into dx [n*L, C]
+  if (i4 >= n * L * C) return;
+  const int64_t row = i4 / C;
+  const int c = (int)(i4 - row * C);
+  const int64_t f = row / L;
+  float4 v = *reinterpret_cast<const float4*>(dp + f * C + c);
+  const float inv = 1.0f / (float)L;
+  v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+  *reinterpret_cast<float4*>(dx + i4) = v;
+}
+
+// block per fragment: dx_emb[f, c] = sum_l dtok[(f,l), c]; dref[ref[f], c] += that
+__global__ __launch_bounds__(128) void token_combine_bwd_kernel(const float* __restrict__ dtok,
+                                                                const uint8_t* __restrict__ ref,
+                                                                float* __restrict__ dx_emb, float* __restrict__ dref,
+                                                                int L, int C) {
+  const int64_t f = blockIdx.x;
+  const int r = ref[f] ? 1 : 0;
+  for (int c = threadIdx.x * 4; c < C; c += 128 * 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; ++l) {
+      const float4 v = *reinterpret_cast<const float4*>(dtok + (f * L + l) * C + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dx_emb + f * C + c) = a;
+    float* d = dref + (int64_t)r * C + c;
+    unsafeAtomicAdd(d + 0, a.x); unsafeAtomicAdd(d + 1, a.y);
+    unsafeAtomicAdd(d + 2, a.z); unsafeAtomicAdd(d + 3, a.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_embed_bwd_kernel(const float* __restrict__ tables,
+                                                             const int64_t* __restrict__ t,
+                                                             const float* __restrict__ dse, float* __restrict__ dtables,
+                                                             int64_t n_emb, int64_t B, int C, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over [n_tab, B, C]
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t ib = i / C;
+  const int64_t b = ib % B, tab = ib / B;
+  const int64_t row = (tab * n_emb + t[b]) * C + c;
+  unsafeAtomicAdd(dtables + row, dse[i] * silu_grad(tables[row]));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loss
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const uint8_t* __restrict__ sel, float* __restrict__ loss,
+                                                        float* __restrict__ dpred, int64_t n, int width, float grad_out) {
+  __shared__ float s_sum[16];
+  __shared__ float s_cnt[16];
+  __shared__ float s_tot[2];
+  float sum = 0.0f, cnt = 0.0f;
+  for (int64_t r = threadIdx.x; r < n; r += 1024) {
+    if (sel[r]) {
+      cnt += 1.0f;
+      for (int c = 0; c < width; ++c) {
+        const float d = pred[r * width + c] - target[r * width + c];
+        sum += d * d;
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, b = 0.0f;
+    for (int w = 0; w < 16; ++w) { a += s_sum[w]; b += s_cnt[w]; }
+    s_tot[0] = a; s_tot[1] = b;
+    loss[0] = a / (b * (float)width);       // 0/0 = NaN like torch's mean over an empty selection
+  }
+  __syncthreads();
+  if (!dpred) return;
+  const float k = grad_out * 2.0f / (s_tot[1] * (float)width);
+  for (int64_t i = threadIdx.x; i < n * width; i += 1024) {
+    const int64_t r = i / width;
+    dpred[i] = sel[r] ? k * (pred[i] - target[i]) : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdamW
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n,
+                                                    float decay, float w1, float beta2, float w2, float eps,
+                                                    float step_size, float inv_sqrt_bc2, float g_scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gr = g[i] * g_scale;
+  float pp = p[i] * decay;
+  float mm = m[i];
+  mm = mm + w1 * (gr - mm);                         // exp_avg.lerp_(grad, 1 - beta1)
+  const float vv = v[i] * beta2 + w2 * (gr * gr);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+  pp = pp - step_size * (mm / denom);
+  p[i] = pp; m[i] = mm; v[i] = vv;
+  if (hi) {
+    const pfpp_hl s = pfpp_split(pp);
+    hi[i] = s.hi; lo[i] = s.lo;
+  }
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" int pfpp_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, int64_t batch,
+                           int64_t sx, int64_t so, int accumulate, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && out, "null pointer");
+  PFPP_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && batch >= 1, "bad sizes");
+  hipStream_t st = pfpp::as_stream(stream);
+  if (!accumulate) {
+    for (int64_t z = 0; z < batch; ++z)
+      if (hipMemsetAsync(out + z * so, 0, (size_t)cols * sizeof(float), st) != hipSuccess) return pfpp::check_launch(__func__);
+  }
+  if (rows == 0) return PFPP_OK;
+  const bool vec = cols % 4 == 0 && ld % 4 == 0 && sx % 4 == 0 && pfpp::aligned16(x);
+  if (vec) {
+    const int rpb = 256;
+    const dim3 grid(blocks_for(cols, 256), blocks_for(rows, rpb), (unsigned)batch);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, x, out, rows, (int)cols, ld, rpb, sx, so);
+  } else {
+    hipLaunchKernelGGL(colsum_narrow_kernel, dim3((unsigned)cols, 1, (unsigned)batch), dim3(64), 0, st, x, out, rows, ld, sx, so);
+  }
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_dropout(const float* x, const float* res, float* out, int64_t n, float p, uint64_t seed,
+                            uint32_t site, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && out, "null pointer");
+  PFPP_REQUIRE(p >= 0.0f && p < 1.0f, "p outside [0, 1)");
+  PFPP_REQUIRE(pfpp::aligned16(x) && pfpp::aligned16(out) && pfpp::aligned16(res), "16-byte alignment");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, pfpp::as_stream(stream), x, res, out, n,
+                     pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t seed, uint32_t site,
+                                 pfpp_stream_t stream) {
+  PFPP_REQUIRE(keep, "null pointer");
+  PFPP_REQUIRE(p >= 0.0f && p < 1.0f, "p outside [0, 1)");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), keep, n,
+                     pfpp_drop_thresh(p), seed, site);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_geglu(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed,
+                          uint32_t site, pfpp_stream_t stream) {
+  PFPP_REQUIRE(z && u, "null pointer");
+  PFPP_REQUIRE(inner > 0 && inner % 4 == 0 && p >= 0.0f && p < 1.0f, "inner % 4 != 0 or p outside [0, 1)");
+  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(u), "16-byte alignment");
+  if (rows == 0) return PFPP_OK;
+  hipLaunchKernelGGL(geglu_kernel, dim3(blocks_for(rows * inner, 1024)), dim3(256), 0, pfpp::as_stream(stream), z, u,
+                     rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_geglu_bwd(const float* z, const float* du, float* dz, int64_t rows, int64_t inner, float p,
+                              uint64_t seed, uint32_t site, pfpp_stream_t stream) {
+  PFPP_REQUIRE(z && du && dz, "null pointer");
+  PFPP_REQUIRE(inner > 0 && inner % 4 == 0 && p >= 0.0f && p < 1.0f, "inner % 4 != 0 or p outside [0, 1)");
+  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(du) && pfpp::aligned16(dz), "16-byte alignment");
+  if (rows == 0) return PFPP_OK;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(blocks_for(rows * inner, 1024)), dim3(256), 0, pfpp::as_stream(stream), z,
+                     du, dz, rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_act(const float* pre, float* out, int64_t n, int act, pfpp_stream_t stream) {
+  PFPP_REQUIRE(pre && out, "null pointer");
+  PFPP_REQUIRE(act >= PFPP_ACT_NONE && act <= PFPP_ACT_GELU, "unknown activation");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(act_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), pre,
+                     (const float*)nullptr, out, n, act);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_act_bwd(const float* pre, const float* dy, float* dx, int64_t n, int act, pfpp_stream_t stream) {
+  PFPP_REQUIRE(pre && dy && dx, "null pointer");
+  PFPP_REQUIRE(act >= PFPP_ACT_NONE && act <= PFPP_ACT_GELU, "unknown activation");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(act_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), pre, dy, dx, n, act);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_layernorm_bwd(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                                  const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                                  int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                                  int64_t rows, int64_t C, float eps, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && dy && dx, "null pointer");
+  PFPP_REQUIRE(!(mod && gamma), "mod and gamma are exclusive");
+  PFPP_REQUIRE(!dmult == !dadd, "dmult and dadd go together");
+  PFPP_SUPPORTED(C == 256 || C == 512, "C not in {256, 512}");
+  PFPP_REQUIRE(group_rows >= 1 && rows_per_batch >= 1, "bad group sizes");
+  PFPP_REQUIRE(group_batch || !mod || rows_per_batch % group_rows == 0, "rows_per_batch % group_rows != 0");
+  PFPP_REQUIRE(pfpp::aligned16(x) && pfpp::aligned16(dy) && pfpp::aligned16(dx) && pfpp::aligned16(mod) &&
+               pfpp::aligned16(gamma) && ld_mod % 4 == 0, "16-byte alignment");
+  if (rows == 0) return PFPP_OK;
+  const dim3 grid(blocks_for(rows, (int)group_rows));
+  hipStream_t st = pfpp::as_stream(stream);
+  if (C == 256)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
+                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
+                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_mean_pool_bwd(const float* dpooled, float* dx, int64_t n, int64_t L, int64_t C,
+                                  pfpp_stream_t stream) {
+  PFPP_REQUIRE(dpooled && dx, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0 && L >= 1 && pfpp::aligned16(dpooled) && pfpp::aligned16(dx), "C % 4 != 0 or alignment");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3(blocks_for(n * L * C, 1024)), dim3(256), 0, pfpp::as_stream(stream),
+                     dpooled, dx, n, (int)L, (int)C);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part, float* dx_emb, float* dref_emb,
+                                      int64_t n, int64_t L, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(dtok && ref_part && dx_emb && dref_emb, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0 && L >= 1 && pfpp::aligned16(dtok) && pfpp::aligned16(dx_emb), "C % 4 != 0 or alignment");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_combine_bwd_kernel, dim3((unsigned)n), dim3(128), 0, pfpp::as_stream(stream), dtok, ref_part,
+                     dx_emb, dref_emb, (int)L, (int)C);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const float* dse, float* dtables,
+                                   int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(tables && t && dse && dtables, "null pointer");
+  const int64_t total = n_tab * B * C;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(silu_embed_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, pfpp::as_stream(stream), tables,
+                     t, dse, dtables, n_emb, B, (int)C, total);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_mse_loss(const float* pred, const float* target, const uint8_t* sel, float* loss, float* dpred,
+                             int64_t n, int64_t width, float grad_out, pfpp_stream_t stream) {
+  PFPP_REQUIRE(pred && target && sel && loss, "null pointer");
+  PFPP_REQUIRE(n >= 0 && width >= 1, "bad sizes");
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, pfpp::as_stream(stream), pred, target, sel, loss, dpred, n,
+                     (int)width, grad_out);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                          float g_scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(p && g && m && v, "null pointer");
+  PFPP_REQUIRE(!hi == !lo, "hi and lo go together");
+  PFPP_REQUIRE(bc1 > 0.0f && bc2 > 0.0f, "bias corrections must be positive");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), p, g, m, v,
+                     (_Float16*)hi, (_Float16*)lo, n, 1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, eps,
+                     lr / bc1, 1.0f / sqrtf(bc2), g_scale);
+  return pfpp::check_launch(__func__);
+}

@@ -34,6 +34,22 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmGradArgs(C.Structure):
+    """mirror of struct pfpp_gemm_grad_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("A", _p), ("W", _p), ("C", _p),
+        ("M", _i64), ("N", _i64), ("K", _i64),
+        ("lda", _i64), ("ldw", _i64), ("ldc", _i64),
+        ("a_kmajor", _i32), ("w_kmajor", _i32), ("accumulate", _i32), ("split_k", _i32), ("batch", _i32),
+        ("sA", _i64), ("sW", _i64), ("sC", _i64),
+        ("a_scale", _f32), ("w_scale", _f32), ("alpha", _f32),
+    ]
+
+
+_u64 = C.c_uint64
+_u32 = C.c_uint32
+
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
     "pfpp_se3_rotate_gather": [_p, _p, _p, _p, _i64, _i64, _p],
@@ -63,6 +79,24 @@ SIGNATURES = {
     "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
     "pfpp_pose_apply_points": [_p, _p, _p, _p, _i64, C.c_int, _p],
     "pfpp_edge_histogram": [_p, _p, _p, _p, _p, _i64, _i64, _p],
+    # ---- training (a17)
+    "pfpp_gemm_grad": [C.POINTER(GemmGradArgs), _p],
+    "pfpp_colsum": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _p],
+    "pfpp_dropout": [_p, _p, _p, _i64, _f32, _u64, _u32, _p],
+    "pfpp_dropout_mask": [_p, _i64, _f32, _u64, _u32, _p],
+    "pfpp_geglu": [_p, _p, _i64, _i64, _f32, _u64, _u32, _p],
+    "pfpp_geglu_bwd": [_p, _p, _p, _i64, _i64, _f32, _u64, _u32, _p],
+    "pfpp_act": [_p, _p, _i64, C.c_int, _p],
+    "pfpp_act_bwd": [_p, _p, _p, _i64, C.c_int, _p],
+    "pfpp_layernorm_bwd": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_blockdiag_bwd": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_dense_train": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_dense_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_mean_pool_bwd": [_p, _p, _i64, _i64, _i64, _p],
+    "pfpp_token_combine_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_mse_loss": [_p, _p, _p, _p, _p, _i64, _i64, _f32, _p],
+    "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
 }
 PLAIN = {
     "pfpp_version": ([], C.c_int),

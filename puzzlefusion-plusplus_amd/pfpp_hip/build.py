@@ -28,6 +28,9 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_ring.hip": [],
     "gemm_ws.hip": [],
+    "gemm_grad.hip": ["-munsafe-fp-atomics"],
+    "train_ops.hip": ["-munsafe-fp-atomics"],
+    "attention_bwd.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 

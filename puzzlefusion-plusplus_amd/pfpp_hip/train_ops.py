@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the training entry points of the C ABI (include/pfpp.h, section a17).
+
+Same rules as ops.py: validation on the host, outputs from torch's allocator, kernels on the current HIP
+stream, no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT, GemmGradArgs, check
+from .ops import _chk, _ptr, _stream
+
+_f32 = torch.float32
+
+
+def gemm_grad(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
+              ldc: int, a_kmajor: bool = False, w_kmajor: bool = False, accumulate: bool = False,
+              split_k: int = 0, batch: int = 1, sA: int = 0, sW: int = 0, sC: int = 0, a_scale: float = 1.0,
+              w_scale: float = 1.0, alpha: float = 1.0, a_off: int = 0, w_off: int = 0, c_off: int = 0) -> torch.Tensor:
+    """raw pfpp_gemm_grad: out[M,N] (+)= alpha * sum_k A(m,k) W(n,k) with per-operand k-major layouts"""
+    _chk(A, _f32, "A"); _chk(W, _f32, "W"); _chk(out, _f32, "out")
+    a = GemmGradArgs()
+    a.A = A.data_ptr() + 4 * a_off
+    a.W = W.data_ptr() + 4 * w_off
+    a.C = out.data_ptr() + 4 * c_off
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldw, a.ldc = lda, ldw, ldc
+    a.a_kmajor, a.w_kmajor = int(a_kmajor), int(w_kmajor)
+    a.accumulate, a.split_k, a.batch = int(accumulate), split_k, batch
+    a.sA, a.sW, a.sC = sA, sW, sC
+    a.a_scale, a.w_scale, a.alpha = a_scale, w_scale, alpha
+    check(_lib.load().pfpp_gemm_grad(C.byref(a), _stream()), "pfpp_gemm_grad")
+    return out
+
+
+def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX [M, in] = dY [M, out] . W [out, in]   (W in torch Linear layout)"""
+    M, N_out = dY.shape
+    K_in = W.shape[1]
+    if W.shape[0] != N_out:
+        raise ValueError("grad_input: dY [M,out] and W [out,in] expected")
+    if out is None:
+        out = torch.empty((M, K_in), dtype=_f32, device=dY.device)
+    return gemm_grad(dY, W, out, M=M, N=K_in, K=N_out, lda=dY.stride(0), ldw=W.stride(0), ldc=out.stride(0),
+                     w_kmajor=True, a_scale=g_scale)
+
+
+def grad_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, g_scale: float = 1.0, k_cols: Optional[int] = None) -> torch.Tensor:
+    """dW [out, in] += dY [M, out]^T . X [M, in]   (accumulates with atomics; dW must be initialised)"""
+    M, N_out = dY.shape
+    K_in = X.shape[1] if k_cols is None else k_cols
+    if X.shape[0] != M or dW.shape[0] != N_out:
+        raise ValueError("grad_weight: shape mismatch")
+    return gemm_grad(dY, X, dW, M=N_out, N=K_in, K=M, lda=dY.stride(0), ldw=X.stride(0), ldc=dW.stride(0),
+                     a_kmajor=True, w_kmajor=True, accumulate=True, a_scale=g_scale)
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, *, rows: Optional[int] = None, cols: Optional[int] = None,
+           ld: Optional[int] = None, batch: int = 1, sx: int = 0, so: int = 0, accumulate: bool = True,
+           x_off: int = 0, o_off: int = 0) -> torch.Tensor:
+    """out[c] (+)= sum_r x[r, c]"""
+    _chk(x, _f32, "x"); _chk(out, _f32, "out")
+    if rows is None:
+        rows, cols = x.shape
+        ld = x.stride(0)
+    check(_lib.load().pfpp_colsum(C.c_void_p(x.data_ptr() + 4 * x_off), C.c_void_p(out.data_ptr() + 4 * o_off), rows, cols,
+                                  ld, batch, sx, so, int(accumulate), _stream()), "pfpp_colsum")
+    return out
+
+
+def dropout(x: torch.Tensor, p: float, seed: int, site: int, *, res: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = (res or 0) + x * keep / (1 - p) with the counter-based mask of (seed, site)"""
+    _chk(x, _f32, "x")
+    if res is not None:
+        _chk(res, _f32, "res")
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().pfpp_dropout(_ptr(x), _ptr(res), _ptr(out), x.numel(), p, seed, site, _stream()), "pfpp_dropout")
+    return out
+
+
+def dropout_mask(n: int, p: float, seed: int, site: int, device) -> torch.Tensor:
+    keep = torch.empty((n,), dtype=torch.uint8, device=device)
+    check(_lib.load().pfpp_dropout_mask(_ptr(keep), n, p, seed, site, _stream()), "pfpp_dropout_mask")
+    return keep
+
+
+def geglu(z: torch.Tensor, p: float = 0.0, seed: int = 0, site: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(z, _f32, "z")
+    rows, two_inner = z.shape
+    inner = two_inner // 2
+    if out is None:
+        out = torch.empty((rows, inner), dtype=_f32, device=z.device)
+    check(_lib.load().pfpp_geglu(_ptr(z), _ptr(out), rows, inner, p, seed, site, _stream()), "pfpp_geglu")
+    return out
+
+
+def geglu_bwd(z: torch.Tensor, du: torch.Tensor, p: float = 0.0, seed: int = 0, site: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(z, _f32, "z"); _chk(du, _f32, "du")
+    rows, two_inner = z.shape
+    if out is None:
+        out = torch.empty_like(z)
+    check(_lib.load().pfpp_geglu_bwd(_ptr(z), _ptr(du), _ptr(out), rows, two_inner // 2, p, seed, site, _stream()),
+          "pfpp_geglu_bwd")
+    return out
+
+
+def act(pre: torch.Tensor, kind: str) -> torch.Tensor:
+    _chk(pre, _f32, "pre")
+    out = torch.empty_like(pre)
+    check(_lib.load().pfpp_act(_ptr(pre), _ptr(out), pre.numel(), ACT[kind], _stream()), "pfpp_act")
+    return out
+
+
+def act_bwd(pre: torch.Tensor, dy: torch.Tensor, kind: str) -> torch.Tensor:
+    _chk(pre, _f32, "pre"); _chk(dy, _f32, "dy")
+    out = torch.empty_like(pre)
+    check(_lib.load().pfpp_act_bwd(_ptr(pre), _ptr(dy), _ptr(out), pre.numel(), ACT[kind], _stream()), "pfpp_act_bwd")
+    return out
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, *, mod: Optional[torch.Tensor] = None,
+                  gamma: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
+                  group_rows: int = 32, rows_per_batch: int = 1, dmult: Optional[torch.Tensor] = None,
+                  dadd: Optional[torch.Tensor] = None, ld_d: int = 0, eps: float = 1e-5) -> torch.Tensor:
+    """dx += LayerNorm backward; dmult/dadd (+)= the (scale, shift) / (gamma, beta) gradients (see pfpp.h)"""
+    _chk(x, _f32, "x"); _chk(dy, _f32, "dy"); _chk(dx, _f32, "dx")
+    rows, Cc = x.shape
+    ld_mod = 0
+    if mod is not None:
+        _chk(mod, _f32, "mod")
+        ld_mod = mod.stride(0)
+    if group_batch is not None:
+        _chk(group_batch, torch.int32, "group_batch")
+        if group_batch.numel() * group_rows < rows:
+            raise ValueError("layernorm_bwd: group_batch too short")
+    check(_lib.load().pfpp_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(mod), ld_mod, _ptr(gamma), _ptr(group_batch), group_rows,
+                                         rows_per_batch, _ptr(dx), _ptr(dmult), _ptr(dadd), ld_d, rows, Cc, eps, _stream()),
+          "pfpp_layernorm_bwd")
+    return dx
+
+
+def attn_blockdiag_bwd(qkv: torch.Tensor, dout: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(qkv, _f32, "qkv"); _chk(dout, _f32, "dout")
+    if out is None:
+        out = torch.empty_like(qkv)
+    check(_lib.load().pfpp_attn_blockdiag_bwd(_ptr(qkv), _ptr(dout), _ptr(out), n_frag, L, H, dh, scale, _stream()),
+          "pfpp_attn_blockdiag_bwd")
+    return out
+
+
+def attn_dense_train(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, max_len: int, H: int, dh: int,
+                     scale: float, key_valid: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pfpp_attn_dense that also returns lse [rows, H] for the backward"""
+    _chk(qkv, _f32, "qkv"); _chk(seq_off, torch.int32, "seq_off"); _chk(seq_len, torch.int32, "seq_len")
+    rows = qkv.shape[0]
+    if out is None:
+        out = torch.empty((rows, H * dh), dtype=_f32, device=qkv.device)
+    lse = torch.empty((rows, H), dtype=_f32, device=qkv.device)
+    kvs = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        kvs = key_valid.stride(0)
+    check(_lib.load().pfpp_attn_dense_train(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(seq_off), _ptr(seq_len), _ptr(key_valid),
+                                            kvs, seq_off.numel(), max_len, H, dh, scale, _stream()), "pfpp_attn_dense_train")
+    return out, lse
+
+
+def attn_dense_bwd(qkv: torch.Tensor, out_fwd: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, seq_off: torch.Tensor,
+                   seq_len: torch.Tensor, max_len: int, H: int, dh: int, scale: float,
+                   key_valid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(qkv, _f32, "qkv"); _chk(out_fwd, _f32, "out_fwd"); _chk(dout, _f32, "dout"); _chk(lse, _f32, "lse")
+    if out is None:
+        out = torch.empty_like(qkv)
+    dvec = torch.empty_like(lse)
+    kvs = 0
+    if key_valid is not None:
+        _chk(key_valid, torch.uint8, "key_valid")
+        kvs = key_valid.stride(0)
+    check(_lib.load().pfpp_attn_dense_bwd(_ptr(qkv), _ptr(out_fwd), _ptr(dout), _ptr(lse), _ptr(dvec), _ptr(out), _ptr(seq_off),
+                                          _ptr(seq_len), _ptr(key_valid), kvs, seq_off.numel(), max_len, H, dh, scale,
+                                          _stream()), "pfpp_attn_dense_bwd")
+    return out
+
+
+def mean_pool_bwd(dpooled: torch.Tensor, L: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(dpooled, _f32, "dpooled")
+    n, Cc = dpooled.shape
+    if out is None:
+        out = torch.empty((n * L, Cc), dtype=_f32, device=dpooled.device)
+    check(_lib.load().pfpp_mean_pool_bwd(_ptr(dpooled), _ptr(out), n, L, Cc, _stream()), "pfpp_mean_pool_bwd")
+    return out
+
+
+def token_combine_bwd(dtok: torch.Tensor, ref_u8: torch.Tensor, dref_emb: torch.Tensor, L: int) -> torch.Tensor:
+    """-> dx_emb [n, C]; dref_emb [2, C] accumulates"""
+    _chk(dtok, _f32, "dtok"); _chk(ref_u8, torch.uint8, "ref_part"); _chk(dref_emb, _f32, "dref_emb")
+    n = ref_u8.numel()
+    Cc = dtok.shape[1]
+    dx_emb = torch.empty((n, Cc), dtype=_f32, device=dtok.device)
+    check(_lib.load().pfpp_token_combine_bwd(_ptr(dtok), _ptr(ref_u8), _ptr(dx_emb), _ptr(dref_emb), n, L, Cc, _stream()),
+          "pfpp_token_combine_bwd")
+    return dx_emb
+
+
+def silu_embed_bwd(tables: torch.Tensor, t: torch.Tensor, dse: torch.Tensor, dtables: torch.Tensor) -> torch.Tensor:
+    _chk(tables, _f32, "tables"); _chk(t, torch.int64, "t"); _chk(dse, _f32, "dse"); _chk(dtables, _f32, "dtables")
+    n_tab, n_emb, Cc = tables.shape
+    check(_lib.load().pfpp_silu_embed_bwd(_ptr(tables), _ptr(t), _ptr(dse), _ptr(dtables), n_tab, n_emb, t.numel(), Cc,
+                                          _stream()), "pfpp_silu_embed_bwd")
+    return dtables
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor, sel_u8: torch.Tensor, grad_out: float = 1.0,
+             need_grad: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """-> (loss [1], dpred) over the rows with sel != 0 (Denoiser._loss)"""
+    _chk(pred, _f32, "pred"); _chk(target, _f32, "target"); _chk(sel_u8, torch.uint8, "sel")
+    n, width = pred.shape
+    loss = torch.empty((1,), dtype=_f32, device=pred.device)
+    dpred = torch.empty_like(pred) if need_grad else None
+    check(_lib.load().pfpp_mse_loss(_ptr(pred), _ptr(target), _ptr(sel_u8), _ptr(loss), _ptr(dpred), n, width, grad_out,
+                                    _stream()), "pfpp_mse_loss")
+    return loss, dpred
+
+
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, beta1: float, beta2: float,
+          eps: float, weight_decay: float, step: int, hi: Optional[torch.Tensor] = None,
+          lo: Optional[torch.Tensor] = None, g_scale: float = 1.0) -> None:
+    """one fused AdamW step over flat buffers (torch.optim.AdamW arithmetic); refreshes the split planes"""
+    for t_, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t_, _f32, nm)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.load().pfpp_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), p.numel(), lr, beta1, beta2, eps,
+                                 weight_decay, bc1, bc2, g_scale, _stream()), "pfpp_adamw")

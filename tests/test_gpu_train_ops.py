@@ -1,0 +1,311 @@
+"""GPU (-m gpu): the training kernels (include/pfpp.h section a17), each against torch autograd of the
+same operation evaluated in fp32 (fp64 where noted) on the CPU.  Tolerances are relative to the
+magnitude of the expected tensor: gradients are sums of thousands of fp32 products."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
+    return float((got.double().cpu() - want.double()).abs().max() / (want.double().abs().max() + 1e-30))
+
+
+# ----------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (3850, 2048, 512), (777 * 4, 512, 4096), (100, 148, 512), (640, 256, 512)])
+def test_grad_input_gemm(dev, M, N, K):
+    """dX = dY . W  (A row-major, W k-major), gradient-sized values with operand scaling"""
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, K, generator=g) * 1e-4          # K = out features (contraction)
+    W = torch.randn(K, N, generator=g) / math.sqrt(K)   # [out, in]
+    want = dY.double() @ W.double()
+    got = T.grad_input(dY.to(dev), W.to(dev), g_scale=2.0 ** 12)
+    assert rel_err(got, want) < 2e-6
+    # without scaling the f16 split of 1e-4-sized values loses bits: the scaled path must be no worse
+    got0 = T.grad_input(dY.to(dev), W.to(dev))
+    assert rel_err(got, want) <= rel_err(got0, want) * 1.5 + 1e-9
+
+
+@pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (16000, 1536, 512), (1234 * 4, 512, 2048), (640, 512, 148), (32, 1024, 512)])
+def test_grad_weight_gemm(dev, M, N, K):
+    """dW [N,K] = dY[M,N]^T . X[M,K]  (both operands k-major, split-K atomics)"""
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(M + K)
+    dY = torch.randn(M, N, generator=g) * 1e-4
+    X = torch.randn(M, K, generator=g)
+    want = dY.double().t() @ X.double()
+    dW = torch.zeros(N, K, device=dev)
+    T.grad_weight(dY.to(dev), X.to(dev), dW, g_scale=2.0 ** 12)
+    assert rel_err(dW, want) < 5e-6
+    T.grad_weight(dY.to(dev), X.to(dev), dW, g_scale=2.0 ** 12)      # accumulates
+    assert rel_err(dW, 2 * want) < 5e-6
+
+
+def test_gemm_grad_batched_and_bad_args(dev):
+    from pfpp_hip import _lib, train_ops as T
+
+    g = torch.Generator().manual_seed(3)
+    nb, B, C = 12, 32, 512
+    dmods = torch.randn(nb, B, 2 * C, generator=g) * 1e-3
+    se = torch.randn(nb, B, C, generator=g)
+    want = torch.einsum("zbn,zbk->znk", dmods.double(), se.double())
+    dW = torch.zeros(nb, 2 * C, C, device=dev)
+    T.gemm_grad(dmods.to(dev), se.to(dev), dW, M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                accumulate=True, batch=nb, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=1024.0)
+    assert rel_err(dW, want) < 5e-6
+    a = torch.randn(256, 64).to(dev)
+    o = torch.zeros(64, 64, device=dev)
+    with pytest.raises(_lib.PfppError, match="split_k"):
+        T.gemm_grad(a, a, o, M=64, N=64, K=256, lda=64, ldw=64, ldc=64, a_kmajor=True, w_kmajor=True, accumulate=False,
+                    split_k=2)
+    with pytest.raises(_lib.PfppError, match="k-major A"):
+        T.gemm_grad(dmods.to(dev), se.to(dev), dW, M=3, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                    accumulate=True)
+
+
+def test_colsum(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3851, 1536, generator=g)
+    out = torch.zeros(1536, device=dev)
+    T.colsum(x.to(dev), out)
+    assert rel_err(out, x.double().sum(0)) < 1e-6
+    # narrow, strided (output head: 3 of 7 columns)
+    y = torch.randn(154, 7, generator=g)
+    o3 = torch.zeros(3, device=dev)
+    T.colsum(y.to(dev), o3, rows=154, cols=3, ld=7, accumulate=False)
+    assert rel_err(o3, y[:, :3].double().sum(0)) < 1e-6
+    o4 = torch.zeros(4, device=dev)
+    T.colsum(y.to(dev), o4, rows=154, cols=4, ld=7, x_off=3)
+    assert rel_err(o4, y[:, 3:].double().sum(0)) < 1e-6
+
+
+# ----------------------------------------------------------------------------- dropout / GEGLU / activations
+def test_dropout_mask_statistics_and_consistency(dev):
+    from pfpp_hip import train_ops as T
+
+    n = 1 << 20
+    for p in (0.1, 0.2):
+        keep = T.dropout_mask(n, p, seed=1234, site=7, device=dev).cpu().float()
+        assert abs(float(keep.mean()) - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n)
+        # neighbouring elements / other sites are uncorrelated
+        k2 = T.dropout_mask(n, p, seed=1234, site=8, device=dev).cpu().float()
+        assert abs(float(((keep - keep.mean()) * (k2 - k2.mean())).mean())) < 5e-3 * p
+        assert abs(float(((keep[1:] - keep.mean()) * (keep[:-1] - keep.mean())).mean())) < 5e-3 * p
+    x = torch.randn(1000, 512)
+    res = torch.randn(1000, 512)
+    keep = T.dropout_mask(x.numel(), 0.2, 99, 3, dev).view(1000, 512).cpu().float()
+    got = T.dropout(x.to(dev), 0.2, 99, 3, res=res.to(dev))
+    assert torch.allclose(got.cpu(), res + x * keep / 0.8, rtol=1e-6, atol=1e-6)
+    assert torch.equal(T.dropout(x.to(dev), 0.0, 1, 1).cpu(), x)
+
+
+def test_geglu_fwd_bwd(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(5)
+    rows, inner = 777, 2048
+    z = torch.randn(rows, 2 * inner, generator=g, dtype=torch.float64, requires_grad=True)
+    du = torch.randn(rows, inner, generator=g, dtype=torch.float64)
+    p, seed, site = 0.1, 42, 11
+    keep = T.dropout_mask(rows * inner, p, seed, site, dev).view(rows, inner).cpu().double()
+    v, gate = z.chunk(2, dim=-1)
+    u = v * F.gelu(gate) * keep / (1 - p)
+    u.backward(du)
+    zf = z.detach().float().to(dev)
+    got_u = T.geglu(zf, p, seed, site)
+    assert rel_err(got_u, u.detach()) < 1e-6
+    got_dz = T.geglu_bwd(zf, du.float().to(dev), p, seed, site)
+    assert rel_err(got_dz, z.grad) < 1e-6
+
+
+def test_act_fwd_bwd(dev):
+    from pfpp_hip import train_ops as T
+
+    x = torch.randn(154, 512, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(154, 512, dtype=torch.float64)
+    y = F.silu(x)
+    y.backward(dy)
+    xf = x.detach().float().to(dev)
+    assert rel_err(T.act(xf, "silu"), y.detach()) < 1e-6
+    assert rel_err(T.act_bwd(xf, dy.float().to(dev), "silu"), x.grad) < 1e-6
+
+
+# ----------------------------------------------------------------------------- LayerNorm backward
+def test_layernorm_bwd_adaln_grouped(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(6)
+    B, L, C = 5, 25, 512
+    counts = [3, 1, 7, 2, 4]
+    frag_b = torch.tensor(sum(([b] * c for b, c in enumerate(counts)), []), dtype=torch.int32)
+    n = frag_b.numel()
+    x = torch.randn(n * L, C, generator=g, dtype=torch.float64, requires_grad=True)
+    mod = (torch.randn(B, 2 * C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    dy = torch.randn(n * L, C, generator=g, dtype=torch.float64) * 1e-3
+    rb = frag_b.long().repeat_interleave(L)
+    y = F.layer_norm(x, (C,)) * (1 + mod[rb, :C]) + mod[rb, C:]
+    y.backward(dy)
+    dx0 = torch.randn(n * L, C, generator=g) * 1e-3          # the running residual gradient the kernel adds to
+    dx = dx0.clone().to(dev)
+    dmod = torch.zeros(B, 2 * C, device=dev)
+    T.layernorm_bwd(x.detach().float().to(dev), dy.float().to(dev), dx, mod=mod.detach().float().to(dev),
+                    group_batch=frag_b.to(dev), group_rows=L, dmult=dmod, dadd=dmod[:, C:], ld_d=2 * C)
+    assert rel_err(dx.cpu() - dx0, x.grad) < 2e-5
+    assert rel_err(dmod, mod.grad) < 2e-5
+
+
+def test_layernorm_bwd_affine_and_uniform_batches(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(7)
+    rows, C = 1003, 512
+    x = torch.randn(rows, C, generator=g, dtype=torch.float64, requires_grad=True)
+    gamma = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    F.layer_norm(x, (C,), gamma, beta).backward(dy)
+    dx = torch.zeros(rows, C, device=dev)
+    dg = torch.zeros(2, C, device=dev)
+    T.layernorm_bwd(x.detach().float().to(dev), dy.float().to(dev), dx, gamma=gamma.detach().float().to(dev),
+                    group_rows=32, dmult=dg[0], dadd=dg[1], ld_d=0)
+    assert rel_err(dx, x.grad) < 2e-5
+    assert rel_err(dg[0], gamma.grad) < 2e-5 and rel_err(dg[1], beta.grad) < 2e-5
+    # AdaLN with uniform batches (padded layout): 2 puzzles x 100 rows, groups of 25 rows
+    x2 = torch.randn(200, 256, generator=g, dtype=torch.float64, requires_grad=True)
+    mod = torch.randn(2, 512, generator=g, dtype=torch.float64, requires_grad=True)
+    dy2 = torch.randn(200, 256, generator=g, dtype=torch.float64)
+    rb = torch.arange(200) // 100
+    (F.layer_norm(x2, (256,)) * (1 + mod[rb, :256]) + mod[rb, 256:]).backward(dy2)
+    dx2 = torch.zeros(200, 256, device=dev)
+    dm = torch.zeros(2, 512, device=dev)
+    T.layernorm_bwd(x2.detach().float().to(dev), dy2.float().to(dev), dx2, mod=mod.detach().float().to(dev), group_rows=25,
+                    rows_per_batch=100, dmult=dm, dadd=dm[:, 256:], ld_d=512)
+    assert rel_err(dx2, x2.grad) < 2e-5 and rel_err(dm, mod.grad) < 2e-5
+
+
+# ----------------------------------------------------------------------------- attention backward
+def _attn_ref(qkv, H, dh, scale, groups, key_valid=None):
+    """per-sequence softmax attention on a packed [rows, 3*H*dh] projection; groups = list of (start, len)"""
+    C = H * dh
+    outs = []
+    for gi, (s, n) in enumerate(groups):
+        q, k, v = (qkv[s:s + n, i * C:(i + 1) * C].view(n, H, dh).transpose(0, 1) for i in range(3))
+        sc = q @ k.transpose(1, 2) * scale
+        if key_valid is not None:
+            sc = sc.masked_fill(~key_valid[gi, :n].bool()[None, None, :], float("-inf"))
+        outs.append((sc.softmax(-1) @ v).transpose(0, 1).reshape(n, C))
+    return torch.cat(outs, 0)
+
+
+def test_attn_blockdiag_bwd(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(8)
+    n_frag, L, H, dh = 37, 25, 8, 64
+    qkv = torch.randn(n_frag * L, 3 * H * dh, generator=g, dtype=torch.float64, requires_grad=True)
+    dO = torch.randn(n_frag * L, H * dh, generator=g, dtype=torch.float64) * 1e-3
+    scale = 1 / math.sqrt(dh)
+    _attn_ref(qkv, H, dh, scale, [(f * L, L) for f in range(n_frag)]).backward(dO)
+    got = T.attn_blockdiag_bwd(qkv.detach().float().to(dev), dO.float().to(dev), n_frag, L, H, dh, scale)
+    assert rel_err(got, qkv.grad) < 2e-5
+
+
+@pytest.mark.parametrize("lens,dh,H,masked", [([50, 500, 125, 25], 64, 8, False), ([190, 190], 32, 8, True),
+                                              ([500, 500, 500], 64, 8, True)])
+def test_attn_dense_train_and_bwd(dev, lens, dh, H, masked):
+    from pfpp_hip import ops, train_ops as T
+
+    g = torch.Generator().manual_seed(sum(lens))
+    rows = sum(lens)
+    C = H * dh
+    qkv = torch.randn(rows, 3 * C, generator=g, dtype=torch.float64, requires_grad=True)
+    dO = torch.randn(rows, C, generator=g, dtype=torch.float64) * 1e-3
+    offs = [sum(lens[:i]) for i in range(len(lens))]
+    kvm = None
+    if masked:
+        kvm = (torch.rand(len(lens), max(lens), generator=g) < 0.6)
+        kvm[:, 0] = True
+    scale = 1 / math.sqrt(dh)
+    want = _attn_ref(qkv, H, dh, scale, list(zip(offs, lens)), kvm)
+    want.backward(dO)
+    so = torch.tensor(offs, dtype=torch.int32, device=dev)
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev)
+    kv8 = kvm.to(torch.uint8).contiguous().to(dev) if masked else None
+    qf = qkv.detach().float().to(dev)
+    out, lse = T.attn_dense_train(qf, so, sl, max(lens), H, dh, scale, key_valid=kv8)
+    assert rel_err(out, want.detach()) < 1e-5
+    assert torch.equal(out, ops.attn_dense(qf, so, sl, max(lens), H, dh, scale, kv8))
+    got = T.attn_dense_bwd(qf, out, dO.float().to(dev), lse, so, sl, max(lens), H, dh, scale, key_valid=kv8)
+    assert rel_err(got, qkv.grad) < 2e-5
+
+
+# ----------------------------------------------------------------------------- small pieces
+def test_pool_token_embed_backward(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(9)
+    n, L, C = 154, 25, 512
+    dp = torch.randn(n, C, generator=g)
+    got = T.mean_pool_bwd(dp.to(dev), L)
+    assert torch.allclose(got.cpu(), (dp / L).repeat_interleave(L, 0), rtol=1e-6, atol=1e-9)
+    dtok = torch.randn(n * L, C, generator=g)
+    ref = (torch.rand(n, generator=g) < 0.3).to(torch.uint8)
+    dref = torch.zeros(2, C, device=dev)
+    dx = T.token_combine_bwd(dtok.to(dev), ref.to(dev), dref, L)
+    want_dx = dtok.double().view(n, L, C).sum(1)
+    assert rel_err(dx, want_dx) < 1e-6
+    assert rel_err(dref[1], want_dx[ref.bool()].sum(0)) < 1e-5 and rel_err(dref[0], want_dx[~ref.bool()].sum(0)) < 1e-5
+    n_tab, n_emb, B = 12, 1000, 32
+    tables = torch.randn(n_tab, n_emb, C, generator=g, dtype=torch.float64, requires_grad=True)
+    t = torch.randint(0, n_emb, (B,), generator=g)
+    t[1] = t[0]                                                  # duplicate timestep: gradients add
+    dse = torch.randn(n_tab, B, C, generator=g, dtype=torch.float64)
+    F.silu(tables[:, t]).backward(dse)
+    dt = torch.zeros(n_tab, n_emb, C, device=dev)
+    T.silu_embed_bwd(tables.detach().float().to(dev), t.to(dev), dse.float().to(dev), dt)
+    assert rel_err(dt, tables.grad) < 1e-6
+
+
+def test_mse_loss(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(10)
+    n = 640
+    pred = torch.randn(n, 7, generator=g, dtype=torch.float64, requires_grad=True)
+    tgt = torch.randn(n, 7, generator=g, dtype=torch.float64)
+    sel = torch.rand(n, generator=g) < 0.2
+    loss = F.mse_loss(pred[sel], tgt[sel])
+    loss.backward()
+    got_l, got_d = T.mse_loss(pred.detach().float().to(dev), tgt.float().to(dev), sel.to(torch.uint8).to(dev))
+    assert abs(float(got_l) - float(loss)) < 1e-6 * float(loss)
+    assert rel_err(got_d, pred.grad) < 1e-6
+
+
+def test_adamw_matches_torch(dev):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(11)
+    n = 100003
+    p0 = torch.randn(n, generator=g) * 0.05
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    p = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    hi = torch.empty(n, dtype=torch.float16, device=dev)
+    lo = torch.empty(n, dtype=torch.float16, device=dev)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 1e-3
+        p_ref.grad = grad.clone()
+        opt.step()
+        T.adamw(p, grad.to(dev), m, v, lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=step, hi=hi, lo=lo)
+    assert (p.cpu() - p_ref.detach()).abs().max() < 2e-7
+    assert (hi.float() + lo.float() - p).abs().max() < 1e-7
