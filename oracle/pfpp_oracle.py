@@ -362,18 +362,25 @@ def diffusers_attention(sd, prefix, x, mask, heads=8):
     return F.linear(o, sd[f"{prefix}.to_out.0.weight"], sd[f"{prefix}.to_out.0.bias"])
 
 
-def geglu_ff(sd, prefix, x):
-    """diffusers 0.21.4 FeedForward(activation_fn='geglu')"""
+def geglu_ff(sd, prefix, x, drop=None, site=0):
+    """diffusers 0.21.4 FeedForward(activation_fn='geglu'): net = [GEGLU, Dropout, Linear]"""
     h, gate = F.linear(x, sd[f"{prefix}.net.0.proj.weight"], sd[f"{prefix}.net.0.proj.bias"]).chunk(2, dim=-1)
-    return F.linear(h * F.gelu(gate), sd[f"{prefix}.net.2.weight"], sd[f"{prefix}.net.2.bias"])
+    u = h * F.gelu(gate)
+    if drop is not None:
+        u = drop(site, u)
+    return F.linear(u, sd[f"{prefix}.net.2.weight"], sd[f"{prefix}.net.2.bias"])
 
 
-def encoder_layer(sd, prefix, h, self_mask, gen_mask, timestep, heads=8):
-    """EncoderLayer.forward, denoiser/model/modules/attention.py:75-91"""
-    h = h + diffusers_attention(sd, f"{prefix}.self_attn", ada_layer_norm(sd, f"{prefix}.norm1", h, timestep), self_mask, heads)
-    h = h + diffusers_attention(sd, f"{prefix}.global_attn", ada_layer_norm(sd, f"{prefix}.norm2", h, timestep), gen_mask, heads)
+def encoder_layer(sd, prefix, h, self_mask, gen_mask, timestep, heads=8, drop=None, layer=0):
+    """EncoderLayer.forward, denoiser/model/modules/attention.py:75-91.  `drop(site, tensor)` applies the
+    train-mode dropouts (Attention.to_out[1] after each out-projection, FeedForward.net[1]) with masks the
+    caller supplies; sites are numbered 1+3*layer, 2+3*layer, 3+3*layer (site 0 = token dropout)."""
+    a = diffusers_attention(sd, f"{prefix}.self_attn", ada_layer_norm(sd, f"{prefix}.norm1", h, timestep), self_mask, heads)
+    h = h + (drop(1 + 3 * layer, a) if drop is not None else a)
+    a = diffusers_attention(sd, f"{prefix}.global_attn", ada_layer_norm(sd, f"{prefix}.norm2", h, timestep), gen_mask, heads)
+    h = h + (drop(2 + 3 * layer, a) if drop is not None else a)
     n3 = F.layer_norm(h, (h.shape[-1],), sd[f"{prefix}.norm3.weight"], sd[f"{prefix}.norm3.bias"])
-    return geglu_ff(sd, f"{prefix}.ff", n3) + h
+    return geglu_ff(sd, f"{prefix}.ff", n3, drop, 3 + 3 * layer) + h
 
 
 def denoiser_tokens(sd, x, latent, xyz, scale, ref_part):
@@ -394,17 +401,22 @@ def denoiser_tokens(sd, x, latent, xyz, scale, ref_part):
     return tok.reshape(B, P * L, Cm)
 
 
-def denoiser_forward(sd, x, timesteps, latent, xyz, part_valids, scale, ref_part, heads=8, capture=None):
-    """DenoiserTransformer.forward, denoiser_transformer.py:169-203 (eval mode)"""
+def denoiser_forward(sd, x, timesteps, latent, xyz, part_valids, scale, ref_part, heads=8, capture=None, drop=None):
+    """DenoiserTransformer.forward, denoiser_transformer.py:169-203.  drop=None: eval mode; otherwise
+    drop(site, tensor) applies the train-mode dropout of that site (see encoder_layer; site 0 is the
+    PositionalEncoding dropout, utils/model_utils.py:18-21).  Differentiable: torch autograd through this
+    function is the oracle of the backward (a17)."""
     B, P, L, _ = latent.shape
     h = denoiser_tokens(sd, x, latent, xyz, scale, ref_part)
+    if drop is not None:
+        h = drop(0, h)
     if capture is not None:
         capture["tokens"] = h
     self_mask = torch.block_diag(*([torch.ones(L, L)] * P)).unsqueeze(0).repeat(B, 1, 1).to(torch.bool)
     gen_mask = part_valids.unsqueeze(-1).repeat(1, 1, L).flatten(1, 2).to(torch.bool)
     n_layers = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("transformer_layers."))
     for i in range(n_layers):
-        h = encoder_layer(sd, f"transformer_layers.{i}", h, self_mask, gen_mask, timesteps, heads)
+        h = encoder_layer(sd, f"transformer_layers.{i}", h, self_mask, gen_mask, timesteps, heads, drop, i)
         if capture is not None:
             capture[f"layer{i}"] = h
     Cm = h.shape[-1]
@@ -416,6 +428,26 @@ def denoiser_forward(sd, x, timesteps, latent, xyz, part_valids, scale, ref_part
         return F.linear(v, sd[f"{name}.4.weight"], sd[f"{name}.4.bias"])
 
     return torch.cat([head("mlp_out_trans", pooled), head("mlp_out_rot", pooled)], dim=-1)
+
+
+def denoiser_loss(pred_noise, gt_noise, part_valids, ref_part):
+    """Denoiser._loss, denoiser/model/denoiser.py:118-126: MSE over the valid, non-reference fragments"""
+    sel = part_valids.bool().clone()
+    sel[ref_part.bool()] = False
+    return F.mse_loss(pred_noise[sel], gt_noise[sel])
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6):
+    """torch.optim.AdamW (single-tensor form) as configured by Denoiser.configure_optimizers,
+    denoiser.py:230-237; in place on the lists of tensors"""
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        p.mul_(1 - lr * weight_decay)
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
 
 
 # =============================================================================================

@@ -1,0 +1,463 @@
+"""Training step of the DenoiserTransformer on the HIP kernels.
+
+Reference: Denoiser.forward / _loss / training_step / configure_optimizers (denoiser/model/denoiser.py:80-145,
+230-241) around DenoiserTransformer.forward (denoiser_transformer.py:169-203) in train mode, i.e. with the
+dropouts of PositionalEncoding (utils/model_utils.py:18-21) and of diffusers' Attention / FeedForward
+(attention.py:46-72) active.  The encoder is frozen (train_denoiser.py:33-35): gradients stop at the tokens.
+
+Design
+* Only valid fragments are evaluated ("compact" layout, see denoiser.denoiser_forward_compact).  For
+  training this is exact, not an approximation: the loss reads valid non-reference fragments only
+  (denoiser.py:118-126), no valid token depends on a padded one, so the padded rows of the reference
+  contribute exactly zero to every gradient.
+* Parameters live in ONE flat fp32 buffer (FlatParams) whose order makes the kernel-side packings free
+  views (q|k|v weights adjacent -> [3C, C]; the 12 AdaLN tables / linears adjacent -> batched GEMM operands);
+  gradients, Adam moments and the split-f16 planes of the forward GEMMs mirror that buffer, so the optimizer
+  is one fused launch and a data-parallel gradient exchange is a handful of large contiguous all-reduces.
+  The nn.Parameters of the module are re-pointed at views of the buffer: state_dict keys/shapes are unchanged.
+* Backward GEMMs read dY, X and W in place through the k-major loaders of csrc/gemm_grad.hip (no transposed
+  copies); gradient operands are lifted by a power-of-two `grad_scale` before the f16 split.
+* Dropout masks are regenerated from (seed, site) in the backward, never stored.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from . import train_ops as T
+from .packing import PW, round_up
+
+TOKEN_DROPOUT = 0.1          # PositionalEncoding(d_model, dropout=0.1), utils/model_utils.py:13-16
+
+
+def _param_order(num_layers: int) -> List[str]:
+    """flat layout: groups that the kernels read as one operand are adjacent"""
+    names: List[str] = []
+    lay = [f"transformer_layers.{i}" for i in range(num_layers)]
+    for p in lay:
+        names += [f"{p}.norm1.emb.weight", f"{p}.norm2.emb.weight"]
+    for p in lay:
+        names += [f"{p}.norm1.linear.weight", f"{p}.norm2.linear.weight"]
+    for p in lay:
+        names += [f"{p}.norm1.linear.bias", f"{p}.norm2.linear.bias"]
+    for p in lay:
+        for a in ("self_attn", "global_attn"):
+            names += [f"{p}.{a}.to_q.weight", f"{p}.{a}.to_k.weight", f"{p}.{a}.to_v.weight",
+                      f"{p}.{a}.to_out.0.weight", f"{p}.{a}.to_out.0.bias"]
+        names += [f"{p}.norm3.weight", f"{p}.norm3.bias", f"{p}.ff.net.0.proj.weight", f"{p}.ff.net.0.proj.bias",
+                  f"{p}.ff.net.2.weight", f"{p}.ff.net.2.bias"]
+    names += ["shape_embedding.weight", "shape_embedding.bias", "param_fc.weight", "param_fc.bias", "ref_part_emb.weight"]
+    for h in ("mlp_out_trans", "mlp_out_rot"):
+        for j in (0, 2, 4):
+            names += [f"{h}.{j}.weight", f"{h}.{j}.bias"]
+    return names
+
+
+def _pw_view(f32: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PW:
+    w = PW.__new__(PW)
+    w.f32, w.hi, w.lo = f32, hi, lo
+    w.N, w.K = int(f32.shape[-2]), int(f32.shape[-1])
+    return w
+
+
+class FlatParams:
+    """flat storage of a DenoiserTransformer's parameters, gradients, Adam moments and split-f16 planes"""
+
+    def __init__(self, module: torch.nn.Module):
+        named = dict(module.named_parameters())
+        self.module = module
+        self.num_layers = module.num_layers
+        self.order = _param_order(self.num_layers)
+        if set(self.order) != set(named):
+            raise ValueError(f"FlatParams: unexpected parameter set: {sorted(set(named) ^ set(self.order))}")
+        dev = next(module.parameters()).device
+        if dev.type != "cuda":
+            raise ValueError("FlatParams: the module must live on the GPU (there is no CPU training path)")
+        self.offset: Dict[str, int] = {}
+        total = 0
+        for n in self.order:
+            self.offset[n] = total
+            total += round_up(named[n].numel(), 8)          # 16-byte aligned fp16 planes
+        self.numel = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.hi = torch.zeros(total, dtype=torch.float16, device=dev)
+        self.lo = torch.zeros(total, dtype=torch.float16, device=dev)
+        self.named = named
+        with torch.no_grad():
+            for n in self.order:
+                p = named[n]
+                v = self.view(self.params, n, p.shape)
+                v.copy_(p.detach())
+                p.data = v
+        self.attach_grads()
+        self.refresh_planes()
+        self._views: Optional[Dict[str, object]] = None
+        # layer-wise slices (DDP buckets, in the order the backward completes them)
+        self.layer_ranges: List[Tuple[int, int]] = []
+        for i in range(self.num_layers):
+            a = self.offset[f"transformer_layers.{i}.self_attn.to_q.weight"]
+            last = f"transformer_layers.{i}.ff.net.2.bias"
+            b = self.offset[last] + round_up(named[last].numel(), 8)
+            self.layer_ranges.append((a, b))
+
+    # -- views -------------------------------------------------------------------------------------
+    def view(self, flat: torch.Tensor, name: str, shape=None) -> torch.Tensor:
+        shape = self.named[name].shape if shape is None else shape
+        n = int(math.prod(shape))
+        return flat[self.offset[name]: self.offset[name] + n].view(shape)
+
+    def span(self, flat: torch.Tensor, first: str, shape) -> torch.Tensor:
+        """a multi-parameter group starting at `first` read as one tensor of `shape`"""
+        n = int(math.prod(shape))
+        return flat[self.offset[first]: self.offset[first] + n].view(shape)
+
+    def attach_grads(self) -> None:
+        """(re-)point every .grad at its slice of the flat gradient buffer (zero_grad(set_to_none) detaches them)"""
+        for n in self.order:
+            p = self.named[n]
+            g = self.view(self.grads, n)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def refresh_planes(self) -> None:
+        """split-f16 planes of the whole buffer (the optimizer kernel keeps them current afterwards)"""
+        with torch.no_grad():
+            self.hi.copy_(self.params.to(torch.float16))
+            self.lo.copy_((self.params - self.hi.float()).to(torch.float16))
+        self._odd = None
+
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+
+    # -- kernel-side operands ------------------------------------------------------------------------
+    def operands(self) -> Dict[str, object]:
+        """weights as the kernels read them: views of the flat buffers (built once), plus the two
+        K-padded embeddings (148 / 147 input features) which are re-packed after every optimizer step"""
+        if self._views is None:
+            L = self.num_layers
+            C = self.named["shape_embedding.bias"].numel()
+            n_emb = self.named["transformer_layers.0.norm1.emb.weight"].shape[0]
+            v: Dict[str, object] = {}
+            t0 = "transformer_layers.0"
+            v["ada.tables"] = self.span(self.params, f"{t0}.norm1.emb.weight", (2 * L, n_emb, C))
+            v["ada.w"] = _pw_view(*(self.span(f, f"{t0}.norm1.linear.weight", (2 * L, 2 * C, C)) for f in (self.params, self.hi, self.lo)))
+            v["ada.b"] = self.span(self.params, f"{t0}.norm1.linear.bias", (2 * L, 2 * C))
+            g: Dict[str, torch.Tensor] = {}
+            g["ada.tables"] = self.span(self.grads, f"{t0}.norm1.emb.weight", (2 * L, n_emb, C))
+            g["ada.w"] = self.span(self.grads, f"{t0}.norm1.linear.weight", (2 * L, 2 * C, C))
+            g["ada.b"] = self.span(self.grads, f"{t0}.norm1.linear.bias", (2 * L, 2 * C))
+
+            def lin(key, wname, bname=None, shape=None):
+                v[key + ".w"] = _pw_view(*(self.span(f, wname, shape or self.named[wname].shape) for f in (self.params, self.hi, self.lo)))
+                g[key + ".w"] = self.span(self.grads, wname, shape or self.named[wname].shape)
+                if bname is not None:
+                    v[key + ".b"] = self.view(self.params, bname)
+                    g[key + ".b"] = self.view(self.grads, bname)
+
+            for i in range(L):
+                p = f"transformer_layers.{i}"
+                for a in ("self_attn", "global_attn"):
+                    lin(f"{i}.{a}.qkv", f"{p}.{a}.to_q.weight", None, (3 * C, C))
+                    lin(f"{i}.{a}.o", f"{p}.{a}.to_out.0.weight", f"{p}.{a}.to_out.0.bias")
+                v[f"{i}.norm3.g"] = self.view(self.params, f"{p}.norm3.weight")
+                v[f"{i}.norm3.b"] = self.view(self.params, f"{p}.norm3.bias")
+                g[f"{i}.norm3.g"] = self.view(self.grads, f"{p}.norm3.weight")
+                g[f"{i}.norm3.b"] = self.view(self.grads, f"{p}.norm3.bias")
+                lin(f"{i}.ff1", f"{p}.ff.net.0.proj.weight", f"{p}.ff.net.0.proj.bias")
+                lin(f"{i}.ff2", f"{p}.ff.net.2.weight", f"{p}.ff.net.2.bias")
+            for h in ("mlp_out_trans", "mlp_out_rot"):
+                for j in (0, 2, 4):
+                    lin(f"{h}.{j}", f"{h}.{j}.weight", f"{h}.{j}.bias")
+            for key, name in (("shape", "shape_embedding"), ("param", "param_fc")):
+                v[key + ".b"] = self.view(self.params, f"{name}.bias")
+                g[key + ".b"] = self.view(self.grads, f"{name}.bias")
+                g[key + ".w"] = self.view(self.grads, f"{name}.weight")
+            v["ref_emb"] = self.view(self.params, "ref_part_emb.weight")
+            g["ref_emb"] = self.view(self.grads, "ref_part_emb.weight")
+            v["pe"] = self.module.pos_encoding.pe[0].contiguous()
+            self._views = {"w": v, "g": g}
+        if self._odd is None:
+            with torch.no_grad():
+                self._odd = {"shape.w": PW(self.view(self.params, "shape_embedding.weight")),
+                             "param.w": PW(self.view(self.params, "param_fc.weight"))}
+        w = dict(self._views["w"])
+        w.update(self._odd)
+        return {"w": w, "g": self._views["g"]}
+
+    def after_optimizer_step(self) -> None:
+        self._odd = None
+
+
+class TrainContext:
+    """everything the backward needs from one forward"""
+
+    def __init__(self):
+        self.t: Dict[str, object] = {}
+
+
+class DenoiserTrainEngine:
+    """forward (train mode) / backward / optimizer step of a DenoiserTransformer on the HIP kernels"""
+
+    def __init__(self, module: torch.nn.Module, *, dropout: Optional[float] = None, token_dropout: float = TOKEN_DROPOUT,
+                 grad_scale: float = 4096.0):
+        self.flat = FlatParams(module)
+        self.module = module
+        self.num_layers = module.num_layers
+        self.num_heads = module.num_heads
+        self.p_layer = 0.2 if dropout is None else float(dropout)    # EncoderLayer(dropout=0.2), denoiser_transformer.py
+        self.p_token = float(token_dropout)
+        if math.log2(grad_scale) % 1 != 0:
+            raise ValueError("grad_scale must be a power of two (exact rescaling)")
+        self.grad_scale = float(grad_scale)
+        self.step_count = 0
+        self._handles: List[object] = []
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, seed: int = 0,
+                train: bool = True) -> Tuple[torch.Tensor, TrainContext]:
+        """-> (pred_noise [B,P,7] with zeros at padded slots, context).  `train=False` disables the dropouts
+        (the reference module in .eval())."""
+        ops_ = self.flat.operands()
+        w = ops_["w"]
+        B, P, L, _ = latent.shape
+        C = w["shape.b"].numel()
+        H = self.num_heads
+        dh = C // H
+        n_slots = B * P
+        dev = latent.device
+        p_tok = self.p_token if train else 0.0
+        p_lay = self.p_layer if train else 0.0
+        ctx = TrainContext()
+        s = ctx.t
+        valid = part_valids.reshape(n_slots).to(torch.bool)
+        slot = torch.nonzero(valid).flatten()
+        Fv = int(slot.numel())
+        if Fv == 0:
+            raise ValueError("training forward: the batch has no valid fragment")
+        frag_b = torch.div(slot, P, rounding_mode="floor").to(torch.int32).contiguous()
+        frag_p = (slot - frag_b.long() * P).to(torch.int32).contiguous()
+        counts = torch.bincount(frag_b.long(), minlength=B)
+        seq_len = (counts * L).to(torch.int32)
+        seq_off = (torch.cumsum(counts, 0) - counts).mul(L).to(torch.int32)
+        max_len = int(counts.max().item()) * L
+        M = Fv * L
+        sf, pf = ops.token_features(latent.reshape(n_slots, L, -1)[slot].contiguous(), xyz.reshape(n_slots, L, 3)[slot].contiguous(),
+                                    scale.reshape(n_slots)[slot].contiguous(), x.reshape(n_slots, 7)[slot].contiguous().float())
+        shape_emb = ops.linear(sf, w["shape.w"], w["shape.b"])
+        x_emb = ops.linear(pf, w["param.w"], w["param.b"])
+        ref_u8 = ref_part.reshape(n_slots)[slot].to(torch.uint8).contiguous()
+        h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L)
+        if p_tok > 0.0:
+            T.dropout(h, p_tok, seed, 0, out=h)
+        n_ada = 2 * self.num_layers
+        t64 = timesteps.to(torch.int64).contiguous()
+        se = ops.silu_embed(w["ada.tables"], t64)
+        mods = torch.empty((n_ada, B, 2 * C), dtype=torch.float32, device=dev)
+        ops.gemm(se, w["ada.w"], M=B, N=2 * C, K=C, lda=C, out=mods, ldc=2 * C, bias=w["ada.b"],
+                 batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
+        att_scale = 1.0 / math.sqrt(dh)
+        s.update(dict(B=B, P=P, L=L, C=C, Fv=Fv, M=M, slot=slot, frag_b=frag_b, seq_len=seq_len, seq_off=seq_off,
+                      max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
+                      p_lay=p_lay, att_scale=att_scale, n_slots=n_slots))
+        layers = []
+        for i in range(self.num_layers):
+            lay: Dict[str, torch.Tensor] = {"h0": h}
+            lay["n1"] = ops.layernorm_grouped(h, mods[2 * i], frag_b, L)
+            lay["qkv1"] = ops.linear(lay["n1"], w[f"{i}.self_attn.qkv.w"])
+            lay["att1"] = ops.attn_blockdiag(lay["qkv1"], Fv, L, H, dh, att_scale)
+            h = self._proj_residual(lay["att1"], w[f"{i}.self_attn.o.w"], w[f"{i}.self_attn.o.b"], h, p_lay, seed, 1 + 3 * i)
+            lay["h1"] = h
+            lay["n2"] = ops.layernorm_grouped(h, mods[2 * i + 1], frag_b, L)
+            lay["qkv2"] = ops.linear(lay["n2"], w[f"{i}.global_attn.qkv.w"])
+            lay["att2"], lay["lse"] = T.attn_dense_train(lay["qkv2"], seq_off, seq_len, max_len, H, dh, att_scale)
+            h = self._proj_residual(lay["att2"], w[f"{i}.global_attn.o.w"], w[f"{i}.global_attn.o.b"], h, p_lay, seed, 2 + 3 * i)
+            lay["h2"] = h
+            lay["n3"] = ops.layernorm(h, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
+            lay["z"] = ops.linear(lay["n3"], w[f"{i}.ff1.w"], w[f"{i}.ff1.b"])
+            lay["u"] = T.geglu(lay["z"], p_lay, seed, 3 + 3 * i)
+            inner = lay["u"].shape[1]
+            h = ops.gemm(lay["u"], w[f"{i}.ff2.w"], M=M, N=C, K=inner, lda=inner, ldc=C, bias=w[f"{i}.ff2.b"], residual=h, ldr=C)
+            layers.append(lay)
+        s["layers"] = layers
+        pooled = ops.mean_pool(h, Fv, L)
+        s["pooled"] = pooled
+        out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
+        heads = {}
+        for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
+            a0 = ops.linear(pooled, w[f"{name}.0.w"], w[f"{name}.0.b"])
+            v0 = T.act(a0, "silu")
+            a1 = ops.linear(v0, w[f"{name}.2.w"], w[f"{name}.2.b"])
+            v1 = T.act(a1, "silu")
+            ops.gemm(v1, w[f"{name}.4.w"], M=Fv, N=width, K=v1.shape[1], lda=v1.shape[1], out=out_c, ldc=7,
+                     bias=w[f"{name}.4.b"], c_off=c0)
+            heads[name] = (a0, v0, a1, v1)
+        s["heads"] = heads
+        out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
+        ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
+        return out.view(B, P, 7), ctx
+
+    @staticmethod
+    def _proj_residual(att, wo, bo, h, p, seed, site):
+        M, C = h.shape
+        if p > 0.0:
+            y = ops.gemm(att, wo, M=M, N=C, K=C, lda=C, ldc=C, bias=bo)
+            return T.dropout(y, p, seed, site, res=h, out=y)
+        return ops.gemm(att, wo, M=M, N=C, K=C, lda=C, ldc=C, bias=bo, residual=h, ldr=C)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, ctx: TrainContext, dpred: torch.Tensor) -> None:
+        """accumulate d(loss)/d(parameter) into the flat gradient buffer (= every parameter's .grad)"""
+        self.flat.attach_grads()
+        ops_ = self.flat.operands()
+        w, g = ops_["w"], ops_["g"]
+        s = ctx.t
+        G = self.grad_scale
+        B, L, C, Fv, M = s["B"], s["L"], s["C"], s["Fv"], s["M"]
+        H = self.num_heads
+        dh = C // H
+        dev = dpred.device
+        seed, p_lay, p_tok = s["seed"], s["p_lay"], s["p_tok"]
+        dout_c = dpred.reshape(s["n_slots"], 7)[s["slot"]].contiguous().float()         # [Fv, 7]
+
+        # ---- output heads (denoiser_transformer.py:138-147)
+        dpooled = torch.zeros((Fv, C), dtype=torch.float32, device=dev)
+        for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
+            a0, v0, a1, v1 = s["heads"][name]
+            dpad = torch.zeros((Fv, 4), dtype=torch.float32, device=dev)
+            dpad[:, :width] = dout_c[:, c0:c0 + width]
+            T.colsum(dout_c, g[f"{name}.4.b"], rows=Fv, cols=width, ld=7, x_off=c0)
+            dw4 = torch.zeros((4, v1.shape[1]), dtype=torch.float32, device=dev)
+            T.grad_weight(dpad, v1, dw4, g_scale=G)
+            g[f"{name}.4.w"].add_(dw4[:width])
+            dv1 = T.gemm_grad(dpad, w[f"{name}.4.w"].f32, torch.empty_like(v1), M=Fv, N=v1.shape[1], K=width, lda=4,
+                              ldw=v1.shape[1], ldc=v1.shape[1], w_kmajor=True, a_scale=G)
+            da1 = T.act_bwd(a1, dv1, "silu")
+            self._linear_bwd(da1, v0, w[f"{name}.2.w"], g[f"{name}.2.w"], g[f"{name}.2.b"])
+            dv0 = T.grad_input(da1, w[f"{name}.2.w"].f32, g_scale=G)
+            da0 = T.act_bwd(a0, dv0, "silu")
+            self._linear_bwd(da0, s["pooled"], w[f"{name}.0.w"], g[f"{name}.0.w"], g[f"{name}.0.b"])
+            T.gemm_grad(da0, w[f"{name}.0.w"].f32, dpooled, M=Fv, N=C, K=da0.shape[1], lda=da0.shape[1], ldw=C, ldc=C,
+                        w_kmajor=True, accumulate=True, split_k=1, a_scale=G)
+        dh_ = T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
+
+        dmods = torch.zeros_like(s["mods"])
+        for i in reversed(range(self.num_layers)):
+            lay = s["layers"][i]
+            # ---- feed-forward (attention.py:87-90)
+            self._linear_bwd(dh_, lay["u"], w[f"{i}.ff2.w"], g[f"{i}.ff2.w"], g[f"{i}.ff2.b"])
+            du = T.grad_input(dh_, w[f"{i}.ff2.w"].f32, g_scale=G)
+            dz = T.geglu_bwd(lay["z"], du, p_lay, seed, 3 + 3 * i)
+            del du
+            self._linear_bwd(dz, lay["n3"], w[f"{i}.ff1.w"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
+            dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G)
+            del dz
+            T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
+                            dadd=g[f"{i}.norm3.b"], ld_d=0)
+            # ---- global attention (attention.py:82-85)
+            dy = T.dropout(dh_, p_lay, seed, 2 + 3 * i) if p_lay > 0.0 else dh_
+            self._linear_bwd(dy, lay["att2"], w[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.b"])
+            datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
+            dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
+                                    s["att_scale"])
+            T.grad_weight(dqkv, lay["n2"], g[f"{i}.global_attn.qkv.w"], g_scale=G)
+            dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
+            T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
+                            dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C)
+            # ---- self attention (attention.py:77-80)
+            dy = T.dropout(dh_, p_lay, seed, 1 + 3 * i) if p_lay > 0.0 else dh_
+            self._linear_bwd(dy, lay["att1"], w[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"])
+            datt = T.grad_input(dy, w[f"{i}.self_attn.o.w"].f32, g_scale=G)
+            dqkv = T.attn_blockdiag_bwd(lay["qkv1"], datt, Fv, L, H, dh, s["att_scale"])
+            T.grad_weight(dqkv, lay["n1"], g[f"{i}.self_attn.qkv.w"], g_scale=G)
+            dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G)
+            T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
+                            dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C)
+            self._layer_done(i)
+
+        # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
+        dtok = T.dropout(dh_, p_tok, seed, 0) if p_tok > 0.0 else dh_
+        ld_sf = s["sf"].shape[1]
+        dws = torch.zeros((C, ld_sf), dtype=torch.float32, device=dev)
+        T.grad_weight(dtok, s["sf"], dws, g_scale=G)
+        g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
+        T.colsum(dtok, g["shape.b"])
+        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L)
+        ld_pf = s["pf"].shape[1]
+        dwp = torch.zeros((C, ld_pf), dtype=torch.float32, device=dev)
+        T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
+        g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
+        T.colsum(dx_emb, g["param.b"])
+
+        # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
+        n_ada = 2 * self.num_layers
+        se = s["se"]
+        T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
+        T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                    accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+        dse = torch.empty_like(se)
+        T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
+                    sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
+        T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
+        self._all_done()
+
+    def _linear_bwd(self, dy, x, wpw, gw, gb) -> None:
+        """dW += dy^T x, db += colsum(dy)"""
+        T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
+        if gb is not None:
+            T.colsum(dy, gb)
+
+    # ------------------------------------------------------------------------------------------ data parallel
+    def _layer_done(self, i: int) -> None:
+        """gradients of layer i are final: start their all-reduce while the earlier layers still compute"""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            a, b = self.flat.layer_ranges[i]
+            self._handles.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _all_done(self) -> None:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            a0 = self.flat.layer_ranges[0][0]
+            b1 = self.flat.layer_ranges[-1][1]
+            self._handles.append(dist.all_reduce(self.flat.grads[:a0], op=dist.ReduceOp.SUM, async_op=True))
+            self._handles.append(dist.all_reduce(self.flat.grads[b1:], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish_grad_exchange(self) -> float:
+        """wait for the gradient all-reduces; returns the factor that turns the summed gradients into the mean"""
+        import torch.distributed as dist
+
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if dist.is_available() and dist.is_initialized():
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:
+        """AdamW over the flat buffer (configure_optimizers, denoiser.py:230-237) — one launch"""
+        g_scale = self.finish_grad_exchange()
+        self.step_count += 1
+        f = self.flat
+        T.adamw(f.params, f.grads, f.exp_avg, f.exp_avg_sq, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
+                weight_decay=weight_decay, step=self.step_count, hi=f.hi, lo=f.lo, g_scale=g_scale)
+        f.after_optimizer_step()
+
+    # ------------------------------------------------------------------------------------------ whole step
+    def loss_and_grads(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, noise, *, seed: int = 0,
+                       train: bool = True) -> torch.Tensor:
+        """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1]"""
+        pred, ctx = self.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=train)
+        n = pred.shape[0] * pred.shape[1]
+        sel = (part_valids.reshape(n).to(torch.bool) & ~ref_part.reshape(n).to(torch.bool)).to(torch.uint8).contiguous()
+        loss, dpred = T.mse_loss(pred.reshape(n, 7), noise.reshape(n, 7).contiguous().float(), sel)
+        self.backward(ctx, dpred)
+        return loss

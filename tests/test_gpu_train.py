@@ -1,0 +1,147 @@
+"""GPU (-m gpu): the training step — DenoiserTrainEngine forward / loss / backward /
+AdamW against (1) the gradients of the REFERENCE module's autograd committed in tests/golden/train.npz and
+(2) torch autograd through the CPU oracle on the same inputs, including the train-mode dropouts (the masks
+are read back from the kernel's counter-based generator and handed to the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+class NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def make_module(weights_sd, dev):
+    from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+
+    cfg = NS(model=NS(embed_dim=512, out_channels=7, num_layers=6, num_heads=8, num_dim=64, num_point=25))
+    m = DenoiserTransformer(cfg)
+    m.load_state_dict(weights_sd("denoiser"), strict=True)
+    return m.to(dev)
+
+
+def golden_inputs(golden, dev=None):
+    g, t = golden("denoiser"), golden("train")
+    keys = ("x", "timesteps", "latent", "xyz", "part_valids", "scale", "ref_part")
+    inp = [T(g[k]) for k in keys]
+    noise = T(t["noise"])
+    if dev is not None:
+        inp = [v.to(dev) for v in inp]
+        noise = noise.to(dev)
+    return inp, noise, t
+
+
+def rel(got, want):
+    return float((got.double().cpu() - want.double()).abs().max() / (want.double().abs().max() + 1e-30))
+
+
+def test_loss_and_grads_vs_reference_golden(golden, weights_sd, dev):
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+    inp, noise, t = golden_inputs(golden, dev)
+    loss = eng.loss_and_grads(*inp, noise, train=False)
+    assert abs(float(loss) - float(t["loss"])) < 2e-5 * float(t["loss"])
+    named = dict(eng.module.named_parameters())
+    worst_norm, worst_sample = 0.0, 0.0
+    for i, name in enumerate(t["names"].tolist()):
+        gr = named[name].grad
+        assert gr is not None and gr.data_ptr() == eng.flat.view(eng.flat.grads, name).data_ptr()
+        n_ref = float(t["grad_norm"][i])
+        worst_norm = max(worst_norm, abs(float(gr.double().norm()) - n_ref) / (n_ref + 1e-30))
+        flat = gr.flatten()
+        smp = flat[:: max(1, flat.numel() // 16)][:16].cpu().numpy() if flat.numel() >= 16 else np.pad(flat.cpu().numpy(), (0, 16 - flat.numel()))
+        worst_sample = max(worst_sample, float(np.abs(smp - t["grad_sample"][i]).max()) / (float(t["grad_absmax"][i]) + 1e-30))
+    assert worst_norm < 1e-4, worst_norm
+    assert worst_sample < 1e-4, worst_sample
+
+
+def _oracle_grads(weights_sd, inp, noise, drop=None):
+    from oracle import pfpp_oracle as O
+
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoding.pe") for k, v in weights_sd("denoiser").items()}
+    pred = O.denoiser_forward(sd, *inp, drop=drop)
+    loss = O.denoiser_loss(pred, noise, inp[4], inp[6])
+    loss.backward()
+    return sd, pred.detach(), loss.detach()
+
+
+def test_train_mode_dropout_vs_oracle_autograd(golden, weights_sd, dev):
+    """full train-mode step: the oracle applies the very masks the kernels generate"""
+    from pfpp_hip import train_ops as TO
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+    inp_c, noise_c, _ = golden_inputs(golden)
+    inp = [v.to(dev) for v in inp_c]
+    seed = 20240917
+    B, P, L = 2, 20, 25
+    valid = inp_c[4].reshape(-1).bool()
+    slot = torch.nonzero(valid).flatten()
+    Fv = slot.numel()
+
+    def drop(site, tensor):
+        width = tensor.shape[-1]
+        p = eng.p_token if site == 0 else eng.p_layer
+        keep_c = TO.dropout_mask(Fv * L * width, p, seed, site, dev).view(Fv, L, width).cpu().to(tensor.dtype)
+        keep = torch.ones(B * P, L, width, dtype=tensor.dtype)
+        keep[slot] = keep_c                                   # compact row order = ascending valid slots
+        return tensor * keep.view(B, P * L, width) / (1 - p)
+
+    sd, pred_o, loss_o = _oracle_grads(weights_sd, inp_c, noise_c, drop)
+    pred, ctx = eng.forward(*inp, seed=seed, train=True)
+    sel = valid.view(B, P)
+    assert (pred.cpu() - pred_o)[sel].abs().max() < 1e-4
+    eng.flat.zero_grad()
+    loss = eng.loss_and_grads(*inp, noise_c.to(dev), seed=seed, train=True)
+    assert abs(float(loss) - float(loss_o)) < 2e-5 * float(loss_o)
+    named = dict(eng.module.named_parameters())
+    worst = max(rel(named[n].grad, sd[n].grad) for n in named)
+    assert worst < 2e-4, worst
+
+
+def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev):
+    """two AdamW steps (eval-mode dropout).  Adam's first updates are sign(g)*lr, so elements whose gradient is
+    within rounding of zero may legitimately move the other way: bounded count, bounded size."""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+    inp_c, noise_c, _ = golden_inputs(golden)
+    inp = [v.to(dev) for v in inp_c]
+    names = [n for n, _ in eng.module.named_parameters()]
+    sd = {k: v.clone() for k, v in weights_sd("denoiser").items()}
+    m = {n: torch.zeros_like(sd[n]) for n in names}
+    v = {n: torch.zeros_like(sd[n]) for n in names}
+    lr = 2e-4
+    for step in (1, 2):
+        req = {k: t.clone().requires_grad_(k in m) for k, t in sd.items()}
+        O.denoiser_loss(O.denoiser_forward(req, *inp_c), noise_c, inp_c[4], inp_c[6]).backward()
+        with torch.no_grad():
+            O.adamw_step([sd[n] for n in names], [req[n].grad for n in names], [m[n] for n in names], [v[n] for n in names], step)
+        eng.flat.zero_grad()
+        eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
+        eng.optimizer_step(lr=lr)
+    named = dict(eng.module.named_parameters())
+    total, off = 0, 0
+    for n in names:
+        d = (named[n].detach().cpu() - sd[n]).abs()
+        assert float(d.max()) <= 2 * 2 * lr * 1.01, n
+        total += d.numel()
+        off += int((d > 2e-6).sum())
+    assert off / total < 2e-3, off / total
+    # the refreshed split planes track the parameters
+    f = eng.flat
+    assert ((f.hi.float() + f.lo.float() - f.params).abs() <= 2.0 ** -21 * f.params.abs() + 1e-7).all()
+    # and the next forward uses them: eval prediction == oracle forward with the updated weights
+    pred, _ = eng.forward(*inp, train=False)
+    want = O.denoiser_forward(sd, *inp_c)
+    sel = inp_c[4].bool()
+    assert (pred.cpu() - want)[sel].abs().max() < 2e-3     # two sign-descent steps apart on ~1e-3 of the weights

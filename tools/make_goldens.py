@@ -316,6 +316,30 @@ def main():
         e2 = O.denoiser_forward(den_sd, xx, torch.tensor([t_single, t_single]), latent, xyz, valids, scale, ref_part)
         assert maxdiff(e1, e2) < 1e-5
 
+    # ============================ a17: loss and gradients (reference autograd, eval-mode dropout) ==========
+    noise_t = torch.randn(B, P, 7, generator=g)
+    den_ref.zero_grad()
+    pred_t = den_ref(xx, ts, latent, xyz, valids, scale, ref_part)
+    sel = valids.bool().clone()
+    sel[ref_part] = False
+    loss_ref = torch.nn.functional.mse_loss(pred_t[sel], noise_t[sel])       # Denoiser._loss, denoiser.py:118-126
+    loss_ref.backward()
+    sd_req = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "pos_encoding.pe") for k, v in den_sd.items()}
+    loss_o = O.denoiser_loss(O.denoiser_forward(sd_req, xx, ts, latent, xyz, valids, scale, ref_part), noise_t, valids, ref_part)
+    loss_o.backward()
+    names = [n for n, _ in den_ref.named_parameters()]
+    worst = 0.0
+    for n, p_ in den_ref.named_parameters():
+        worst = max(worst, maxdiff(p_.grad, sd_req[n].grad) / (p_.grad.abs().max().item() + 1e-30))
+    print(f"[train] loss ref {loss_ref.item():.6f} oracle {loss_o.item():.6f}; worst relative grad diff oracle vs reference {worst:.2e}")
+    assert abs(loss_ref.item() - loss_o.item()) < 1e-6 and worst < 1e-4
+    np.savez_compressed(
+        GOLD / "train.npz", noise=noise_t.numpy(), loss=np.float64(loss_ref.item()), names=np.array(names),
+        grad_norm=np.array([p_.grad.double().norm().item() for _, p_ in den_ref.named_parameters()]),
+        grad_absmax=np.array([p_.grad.abs().max().item() for _, p_ in den_ref.named_parameters()]),
+        grad_sample=np.stack([p_.grad.flatten()[:: max(1, p_.numel() // 16)][:16].numpy() if p_.numel() >= 16 else
+                              np.pad(p_.grad.flatten().numpy(), (0, 16 - p_.numel())) for _, p_ in den_ref.named_parameters()]))
+
     # ============================ scheduler =====================================================
     sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
                                  beta_start=1e-4, beta_end=2e-2, clip_sample=False, timestep_spacing="leading")
