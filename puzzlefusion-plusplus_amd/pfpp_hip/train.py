@@ -82,7 +82,7 @@ class FlatParams:
             self.offset[n] = total
             total += round_up(named[n].numel(), 8)          # 16-byte aligned fp16 planes
         self.numel = total
-        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev, requires_grad=False)
         self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -96,8 +96,8 @@ class FlatParams:
                 v.copy_(p.detach())
                 p.data = v
         self.attach_grads()
-        self.refresh_planes()
         self._views: Optional[Dict[str, object]] = None
+        self.refresh_planes()
         # layer-wise slices (DDP buckets, in the order the backward completes them)
         self.layer_ranges: List[Tuple[int, int]] = []
         for i in range(self.num_layers):
@@ -131,6 +131,11 @@ class FlatParams:
             self.hi.copy_(self.params.to(torch.float16))
             self.lo.copy_((self.params - self.hi.float()).to(torch.float16))
         self._odd = None
+        self._seen_version = self._versions()
+
+    def _versions(self):
+        """in-place edits of the parameters through torch (load_state_dict, another optimizer) bump these"""
+        return tuple(self.named[n]._version for n in self.order)
 
     def zero_grad(self) -> None:
         self.grads.zero_()
@@ -139,6 +144,12 @@ class FlatParams:
     def operands(self) -> Dict[str, object]:
         """weights as the kernels read them: views of the flat buffers (built once), plus the two
         K-padded embeddings (148 / 147 input features) which are re-packed after every optimizer step"""
+        first = self.named[self.order[0]]
+        if first.data_ptr() != self.params.data_ptr():
+            raise RuntimeError("FlatParams: the module's parameters were re-allocated (.to()/.cuda() after the training "
+                               "engine was created); build the engine after moving the module")
+        if self._versions() != self._seen_version:
+            self.refresh_planes()         # load_state_dict / in-place edits of the parameters through torch
         if self._views is None:
             L = self.num_layers
             C = self.named["shape_embedding.bias"].numel()
@@ -450,6 +461,9 @@ class DenoiserTrainEngine:
         T.adamw(f.params, f.grads, f.exp_avg, f.exp_avg_sq, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
                 weight_decay=weight_decay, step=self.step_count, hi=f.hi, lo=f.lo, g_scale=g_scale)
         f.after_optimizer_step()
+        cache = getattr(self.module, "_cache", None)
+        if cache is not None:
+            cache._key = None            # the eval-mode packing of the module is stale now
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, noise, *, seed: int = 0,

@@ -3,9 +3,9 @@
 Keeps the LightningModule surface of the reference (forward(data_dict) -> {pred_noise, gt_noise},
 _loss, training_step, validation_step, configure_optimizers; state_dict prefixes `denoiser.` and
 `encoder.`) and runs the hot path — rotate, encode, denoise, DDPM step — on the HIP kernels.
-Round-1 limits, raised loudly: no backward kernels yet (losses evaluate, gradients do not flow) and
-the encoder's BatchNorm runs in eval mode (the reference leaves it in train mode while "frozen",
-train_denoiser.py:33-35).  Evaluation metrics (evaluator.py) are a later row of the scope table.
+In train mode DenoiserTransformer.forward is one autograd node backed by pfpp_hip.train (dropouts, backward
+kernels, gradients accumulated into the parameters' .grad) and configure_optimizers returns the fused AdamW.
+Evaluation metrics (evaluator.py) are a later row of the scope table.
 """
 from __future__ import annotations
 
@@ -97,7 +97,11 @@ class Denoiser(LightningModule):
         return self.sample(data_dict)
 
     def configure_optimizers(self):
-        optimizer = torch.optim.AdamW(self.parameters(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08)
+        # same hyper-parameters as the reference (denoiser.py:230-237) on the fused kernel; the frozen encoder
+        # (train_denoiser.py:33-35) has no gradients and therefore no optimizer state in either implementation
+        from pfpp_hip.optim import FusedAdamW
+
+        optimizer = FusedAdamW(self.denoiser.train_engine(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08)
         sched_cfg = getattr(self.cfg.model, "lr_scheduler", None)
         if sched_cfg is None:
             return optimizer

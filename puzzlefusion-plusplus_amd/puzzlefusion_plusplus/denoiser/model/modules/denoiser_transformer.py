@@ -14,6 +14,24 @@ from puzzlefusion_plusplus.denoiser.model.modules.attention import EncoderLayer
 from utils.model_utils import EmbedderNerf, PositionalEncoding
 
 
+class _TrainFn(torch.autograd.Function):
+    """DenoiserTransformer.forward in train mode as one autograd node: backward() runs the HIP backward and
+    accumulates straight into the parameters' .grad (views of the engine's flat gradient buffer)"""
+
+    @staticmethod
+    def forward(ctx, eng, seed, x, timesteps, latent, xyz, part_valids, scale, ref_part, grad_anchor):
+        # grad_anchor: any parameter that requires grad, so that autograd records this node
+        pred, saved = eng.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=True)
+        ctx.eng, ctx.saved = eng, saved
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        ctx.eng.backward(ctx.saved, dpred.contiguous())
+        ctx.saved = None
+        return (None,) * 10
+
+
 class DenoiserTransformer(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -54,12 +72,27 @@ class DenoiserTransformer(nn.Module):
                                lambda: hip_denoiser.pack_denoiser({k: v.detach() for k, v in live.items()},
                                                                   self.num_layers))
 
+    def train_engine(self):
+        """the training engine (pfpp_hip.train.DenoiserTrainEngine); created on first use: from then on the
+        parameters are views of one flat buffer (same names, shapes and values)"""
+        if getattr(self, "_engine", None) is None:
+            from pfpp_hip.train import DenoiserTrainEngine
+
+            object.__setattr__(self, "_engine", DenoiserTrainEngine(self))
+        return self._engine
+
     def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part):
         """x [B,P,7], timesteps i64 [B], latent [B,P,L,64], xyz [B,P,L,3], part_valids [B,P],
         scale [B,P,1], ref_part bool [B,P] -> predicted noise [B,P,7] (trans 3 | rot 4)"""
+        if self.training and torch.is_grad_enabled():
+            # train mode (dropouts active) with gradients: the fused training engine behind autograd
+            eng = self.train_engine()
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # torch.manual_seed governs the dropout masks
+            return _TrainFn.apply(eng, seed, x, timesteps, latent, xyz, part_valids, scale, ref_part, self.ref_part_emb.weight)
         if self.training:
-            raise RuntimeError("DenoiserTransformer (HIP): inference forward only (dropout/backward are not "
-                               "implemented yet); call .eval()")
+            pred, _ = self.train_engine().forward(x, timesteps, latent, xyz, part_valids, scale, ref_part,
+                                                  seed=int(torch.randint(0, 2 ** 62, (1,)).item()), train=True)
+            return pred
         fwd = hip_denoiser.denoiser_forward_compact if self.compact_padded else hip_denoiser.denoiser_forward
         return fwd(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale, ref_part,
                    num_layers=self.num_layers, num_heads=self.num_heads)

@@ -145,3 +145,59 @@ def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev):
     want = O.denoiser_forward(sd, *inp_c)
     sel = inp_c[4].bool()
     assert (pred.cpu() - want)[sel].abs().max() < 2e-3     # two sign-descent steps apart on ~1e-3 of the weights
+
+
+def test_module_train_mode_autograd_and_optimizer(golden, weights_sd, dev):
+    """the drop-in surface: module.train(); loss.backward(); FusedAdamW.step() == the engine driven directly"""
+    import torch.nn.functional as F
+
+    from pfpp_hip.optim import FusedAdamW
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    inp, noise, _ = golden_inputs(golden, dev)
+    sel = inp[4].bool() & ~inp[6]
+    m = make_module(weights_sd, dev)
+    keys_before = list(m.state_dict().keys())
+    m.train()
+    opt = FusedAdamW(m.train_engine())
+    assert list(m.state_dict().keys()) == keys_before
+    torch.manual_seed(123)
+    pred = m(*inp)
+    assert pred.requires_grad
+    loss = F.mse_loss(pred[sel], noise[sel])
+    opt.zero_grad()
+    loss.backward()
+    g_mod = m.train_engine().flat.grads.clone()
+    # the same step through the engine API (same seed stream)
+    eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    loss2 = eng.loss_and_grads(*inp, noise, seed=seed, train=True)
+    assert abs(float(loss) - float(loss2)) < 1e-6 * float(loss2)
+    assert rel(g_mod, eng.flat.grads.cpu()) < 1e-5          # atomics: summation order differs between runs
+    opt.step()
+    eng.optimizer_step()
+    assert rel(m.train_engine().flat.params, eng.flat.params.cpu()) < 1e-5 or \
+        float((m.train_engine().flat.params - eng.flat.params).abs().gt(1e-6).float().mean()) < 1e-3
+    assert int(opt.state[m.ref_part_emb.weight]["step"]) == 1
+    # optimizer state_dict has torch.optim.AdamW's layout and round-trips
+    sd_opt = opt.state_dict()
+    assert set(sd_opt["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    opt2 = FusedAdamW(eng)
+    opt2.load_state_dict(sd_opt)
+    assert torch.equal(eng.flat.exp_avg, m.train_engine().flat.exp_avg) and eng.step_count == 1
+    # eval forward after the step uses the updated weights (pack cache invalidated); load_state_dict refreshes planes
+    m.eval()
+    with torch.no_grad():
+        e1 = m(*inp)
+    m.load_state_dict(weights_sd("denoiser"), strict=True)
+    m.train()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        t1 = m(*inp)
+    fresh = make_module(weights_sd, dev).train()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        t2 = fresh(*inp)
+    assert torch.equal(t1, t2)
+    assert (e1 - t1).abs().max() > 0
