@@ -1,15 +1,17 @@
 """bench.py — denoiser DDPM-step throughput on synthetic Breaking-Bad-shaped puzzles.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode train|sample]
 
-One "step" = one DDPM sampler step of the hot path over one batch resident in HBM:
-rotate every fragment by its current noisy pose -> PointNet++/VQ-VAE encode the valid fragments ->
-DenoiserTransformer -> ancestral scheduler step + reference re-pin
-(Denoiser.validation_step loop body, puzzlefusion_plusplus/denoiser/model/denoiser.py:172-185).
-Workload = BASELINE.json configs[1] shape on every GPU: 32 puzzles x 20 fragment slots x 1024 points,
-valid-fragment counts from SURVEY.md §8d's distribution.  N > 1: one process per GPU
-(torch.distributed / RCCL only for the barrier and the max-over-ranks clock): puzzles are
-independent, so ranks hold different puzzles and exchange nothing on the data path (weak scaling).
+Default (--mode train) = BASELINE.json configs[1]: one "step" is one DDPM TRAINING iteration of the denoiser
+over a batch resident in HBM (Denoiser.training_step, puzzlefusion_plusplus/denoiser/model/denoiser.py:80-145):
+draw noise and one timestep per puzzle -> add_noise -> re-pin reference parts -> rotate every fragment by its
+noisy pose -> frozen PointNet++/VQ-VAE encode -> DenoiserTransformer forward in train mode (dropouts on) ->
+MSE over valid non-reference fragments -> full backward -> (N > 1: gradient all-reduce over RCCL, overlapped
+with the backward) -> AdamW.  Nothing is skipped inside the timed region.
+--mode sample: one step = one DDPM sampler step (Denoiser.validation_step loop body, denoiser.py:172-185),
+reported under "extra" in the default mode.
+Workload shape on every GPU: 32 puzzles x 20 fragment slots x 1024 points, valid-fragment counts from
+SURVEY.md §8d's distribution.  N > 1: one process per GPU, different puzzles per rank (weak scaling).
 
 Prints ONE JSON line (rank 0) with the extra objects:
   roofline     — dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs of its launches / their
@@ -47,6 +49,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="puzzles per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=None, help="fix the number of valid fragments per puzzle")
+    ap.add_argument("--mode", choices=("train", "sample"), default="train")
+    ap.add_argument("--latents-given", action="store_true",
+                    help="train mode: skip the encoder (latents of the clean pose precomputed; not a reference mode)")
     ap.add_argument("--compact", action="store_true",
                     help="drop padded fragment slots in the transformer (valid-fragment outputs unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +99,100 @@ class SamplerWorkload:
         self.x = m.noise_scheduler.step(eps, t, self.x, variance_noise=self.noise[k], ref_part=self.ref,
                                         reference=self.reference).prev_sample
         self.i += 1
+
+
+class TrainWorkload:
+    """device-resident state of the training loop for one batch of puzzles"""
+
+    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, latents_given: bool = False):
+        from pfpp_hip import config, synthetic
+        from pfpp_hip.train import DenoiserTrainEngine
+        from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+        torch.manual_seed(1234)
+        self.model = Denoiser(config.denoiser_config()).to(dev)     # random-init weights of the reference architecture
+        with torch.no_grad():   # a codebook on the scale of the latents (a trained one is)
+            self.model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+        for p_ in self.model.encoder.parameters():                  # train_denoiser.py:33-35
+            p_.requires_grad = False
+        self.model.train()
+        self.engine = DenoiserTrainEngine(self.model.denoiser)
+        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts)
+        self.data = {k: v.to(dev) for k, v in data.items()}
+        self.n_frag = int(self.data["part_valids"].sum().item())
+        self.gt = torch.cat([self.data["part_trans"], self.data["part_rots"]], dim=-1).float().contiguous()
+        self.ref = self.data["ref_part"]
+        self.gen = torch.Generator(device=dev).manual_seed(99 + first_id)
+        self.batch = batch
+        self.dev = dev
+        self.latents_given = latents_given
+        self.fixed = None
+        if latents_given:
+            with torch.no_grad():
+                self.fixed = self.model._extract_features(self.data["part_pcs"], self.data["part_valids"], self.gt)
+        self.i = 0
+        self.last_loss = None
+
+    def step(self):
+        m, d = self.model, self.data
+        sch = m.noise_scheduler
+        noise = torch.randn(self.gt.shape, device=self.dev, generator=self.gen)
+        t = torch.randint(0, sch.config.num_train_timesteps, (self.batch,), device=self.dev, generator=self.gen)
+        noisy = sch.add_noise(self.gt, noise, t)
+        noisy[self.ref] = self.gt[self.ref]
+        with torch.no_grad():
+            latent, xyz = self.fixed if self.latents_given else m._extract_features(d["part_pcs"], d["part_valids"], noisy)
+        self.engine.flat.zero_grad()
+        self.last_loss = self.engine.loss_and_grads(noisy, t, latent, xyz, d["part_valids"], d["part_scale"], self.ref, noise,
+                                                    seed=1000 + self.i, train=True)
+        self.engine.optimizer_step(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
+        self.i += 1
+
+
+def cpu_baseline_train(budget_s: float = 20.0, max_steps: int = 3):
+    """the CPU oracle on BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points): training iterations
+    (add_noise, encode, forward, loss, autograd backward, AdamW) in the reference's op order"""
+    from oracle import pfpp_oracle as O
+    from oracle import weights
+    from pfpp_hip import synthetic
+
+    enc_sd, den_sd = weights.vqvae_state_dict(), weights.denoiser_state_dict()
+    batch = synthetic.make_batch(0, 1, num_points=512, num_parts=8)
+    g = torch.Generator().manual_seed(0)
+    sched = O.PiecewiseSchedule()
+    gt = torch.cat([batch["part_trans"], batch["part_rots"]], dim=-1).float()
+    ref = batch["ref_part"].bool()
+    names = [k for k, v in den_sd.items() if v.dtype.is_floating_point and k != "pos_encoding.pe"]
+    sd = {k: v.clone() for k, v in den_sd.items()}
+    m = [torch.zeros_like(sd[n]) for n in names]
+    v = [torch.zeros_like(sd[n]) for n in names]
+
+    def one(step):
+        noise = torch.randn(1, 20, 7, generator=g)
+        t = torch.randint(0, 1000, (1,), generator=g)
+        noisy = sched.add_noise(gt, noise, t)
+        noisy[ref] = gt[ref]
+        with torch.no_grad():
+            lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], noisy)
+        req = {k: (w.clone().requires_grad_(True) if k in names else w) for k, w in sd.items()}
+        loss = O.denoiser_loss(O.denoiser_forward(req, noisy, t, lat, xyz, batch["part_valids"], batch["part_scale"], ref),
+                               noise, batch["part_valids"], ref)
+        loss.backward()
+        with torch.no_grad():
+            O.adamw_step([sd[n] for n in names], [req[n].grad for n in names], m, v, step)
+
+    one(1)   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and (time.perf_counter() - t0) < budget_s:
+        one(n + 2)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": 8 * n / dt, "unit": "fragment*steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n} training iterations (forward, autograd backward, AdamW) of 1 puzzle, 8 fragments x 512 pts "
+                  f"(BASELINE configs[0]), {dt:.1f} s on {os.cpu_count()} logical CPUs, torch threads {torch.get_num_threads()}",
+    }
 
 
 def cpu_baseline(budget_s: float = 12.0, max_steps: int = 4):
@@ -153,7 +252,11 @@ def main():
 
     from pfpp_hip import ops
 
-    wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
+    train = args.mode == "train"
+    if train:
+        wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given)
+    else:
+        wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
     for _ in range(args.warmup):
         wl.step()
 
@@ -215,7 +318,27 @@ def main():
         }
 
     extra = {}
-    if rank == 0 and world == 1 and not args.compact and not args.no_roofline:
+    if train and rank == 0:
+        extra["final_loss"] = round(float(wl.last_loss), 5)
+    if train and rank == 0 and world == 1 and not args.no_roofline:
+        # the inference sampler step at the same shape (Denoiser.validation_step loop body), padded slots
+        # evaluated like the reference and dropped
+        del wl.engine
+        swl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev)
+        for name, compact in (("sampler_step", False), ("sampler_step_compact", True)):
+            swl.model.denoiser.compact_padded = compact
+            for _ in range(args.warmup):
+                swl.step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                swl.step()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            extra[name] = {"value": round(swl.n_frag * args.steps / dt, 2), "unit": "fragment*steps/s",
+                           "ms_per_step": round(dt / args.steps * 1e3, 3),
+                           "padded_slots": "dropped" if compact else "evaluated like the reference"}
+    if not train and rank == 0 and world == 1 and not args.compact and not args.no_roofline:
         # the same K steps with the padded fragment slots dropped (outputs of valid fragments unchanged)
         wl.model.denoiser.compact_padded = True
         for _ in range(args.warmup):
@@ -232,7 +355,7 @@ def main():
                                  "note": "padded fragment slots dropped in the transformer; identical predictions for valid fragments"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline_train() if train else cpu_baseline()
 
     if rank == 0:
         line = {
@@ -242,13 +365,20 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (GEMMs: %s)" % ops.GEMM_MODE, "data": "synthetic",
             "config": {
-                "workload": "DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
-                            "scheduler step), BASELINE configs[1] shape, inference forward",
-                "padded_slots": "dropped (compact mode)" if args.compact else "evaluated like the reference",
+                "workload": ("DDPM training iteration, BASELINE configs[1]: add_noise + rotate + frozen PointNet++/VQ encode"
+                             + (" (skipped: latents given)" if args.latents_given else " (in the loop)") +
+                             " + DenoiserTransformer forward (dropouts on) + MSE + full backward + "
+                             + ("RCCL gradient all-reduce + " if world > 1 else "") + "AdamW") if train else
+                            ("DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
+                             "scheduler step), BASELINE configs[1] shape, inference forward"),
+                "padded_slots": ("not evaluated (their gradient contribution is exactly zero)" if train else
+                                 "dropped (compact mode)" if args.compact else "evaluated like the reference"),
                 "puzzles_per_gpu": args.batch, "fragment_slots": 20, "points_per_fragment": args.points,
                 "valid_fragments_per_gpu": wl.n_frag, "puzzle_steps_per_s": round(args.batch * world * args.steps / elapsed, 2),
                 "weights": "random init, reference architecture (57.6M denoiser + 0.6M encoder params)",
-                "parallelism": f"independent puzzles x {world} GPU(s), no data-path collective",
+                "parallelism": (f"data parallel x {world} GPU(s): puzzles sharded, gradients all-reduced (RCCL) per layer "
+                                "during the backward" if train else
+                                f"independent puzzles x {world} GPU(s), no data-path collective"),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -432,6 +432,24 @@ int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo,
                float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
                float bc2, float g_scale, pfpp_stream_t stream);
 
+/* ---- train-mode BatchNorm of the (frozen, but .train()) encoder (utils/pn2_utils.py:211-214) -------------
+ * The reference freezes the encoder's parameters only (train_denoiser.py:33-35); under Lightning's
+ * model.train() its BatchNorm2d layers normalise with batch statistics and keep updating their buffers.
+ * bn_stats: per column mean and biased variance over the rows of x [rows, C] (ld), accumulated in fp64
+ * (torch's CPU kernel accumulates in double); when running_mean != NULL the running statistics are
+ * updated like torch: r = (1-momentum)*r + momentum*stat, with the unbiased variance.
+ * workspace: at least pfpp_bn_stats_workspace(rows, C) bytes.
+ * bn_apply: y = relu(x*a + b) with a = gamma/sqrt(var+eps), b = beta - mean*a (the form ATen's CPU kernel
+ * uses), optional max over groups of `pool` consecutive rows (the set-abstraction max, pn2_utils.py:216):
+ * y [rows/pool, ldy].  C % 4 == 0, C <= 1024.                                                         */
+int64_t pfpp_bn_stats_workspace(int64_t rows, int64_t C);
+int pfpp_bn_stats(const float* x, int64_t rows, int64_t C, int64_t ld, float* mean, float* var,
+                  float* running_mean, float* running_var, float momentum, void* workspace,
+                  pfpp_stream_t stream);
+int pfpp_bn_apply(const float* x, int64_t rows, int64_t C, int64_t ld, const float* mean,
+                  const float* var, const float* gamma, const float* beta, float eps, float* y,
+                  int64_t ldy, int64_t pool, pfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,15 +232,20 @@ SA_CFG = (  # vqvae/model/modules/pn2.py:16-18
 
 
 def set_abstraction(sd: Dict[str, torch.Tensor], prefix: str, npoint, radius, nsample, xyz, points,
-                    capture: Optional[dict] = None):
-    """PointNetSetAbstraction.forward, utils/pn2_utils.py:190-216 (eval-mode BatchNorm).
+                    capture: Optional[dict] = None, train: bool = False):
+    """PointNetSetAbstraction.forward, utils/pn2_utils.py:190-216.  train=False: eval-mode BatchNorm (running
+    statistics); train=True: the module in .train() — batch statistics, and the running_mean / running_var /
+    num_batches_tracked entries of `sd` are updated in place exactly like nn.BatchNorm2d does (this is the state
+    of the "frozen" encoder during Denoiser training, train_denoiser.py:33-35 freezes parameters only).
     xyz [F,N,3], points [F,N,D] channels-last -> new_xyz [F,S,3], new_points [F,S,C]"""
     new_xyz, new_points, fps_idx, ball_idx = sample_and_group(npoint, radius, nsample, xyz, points)
     h = new_points.permute(0, 3, 2, 1)  # [F, C+D, ns, S]
     for i in range(3):
         h = F.conv2d(h, sd[f"{prefix}.mlp_convs.{i}.weight"], sd[f"{prefix}.mlp_convs.{i}.bias"])
         h = F.batch_norm(h, sd[f"{prefix}.mlp_bns.{i}.running_mean"], sd[f"{prefix}.mlp_bns.{i}.running_var"],
-                         sd[f"{prefix}.mlp_bns.{i}.weight"], sd[f"{prefix}.mlp_bns.{i}.bias"], False, 0.1, 1e-5)
+                         sd[f"{prefix}.mlp_bns.{i}.weight"], sd[f"{prefix}.mlp_bns.{i}.bias"], train, 0.1, 1e-5)
+        if train and f"{prefix}.mlp_bns.{i}.num_batches_tracked" in sd:
+            sd[f"{prefix}.mlp_bns.{i}.num_batches_tracked"] += 1
         h = F.relu(h)
     h = torch.max(h, 2)[0]  # [F, C, S]
     if capture is not None:
@@ -251,11 +256,11 @@ def set_abstraction(sd: Dict[str, torch.Tensor], prefix: str, npoint, radius, ns
     return new_xyz, h.permute(0, 2, 1).contiguous()
 
 
-def pn2_encode(sd, part_pcs: torch.Tensor, num_point: int = 25, prefix: str = "pn2", capture=None):
+def pn2_encode(sd, part_pcs: torch.Tensor, num_point: int = 25, prefix: str = "pn2", capture=None, train: bool = False):
     """PN2.encode, vqvae/model/modules/pn2.py:57-68: part_pcs [F,N,3] -> z_e [F,L,64], xyz [F,L,3]"""
     xyz, pts = part_pcs, None
     for name, npoint, radius, nsample in SA_CFG:
-        xyz, pts = set_abstraction(sd, f"{prefix}.{name}", npoint or num_point, radius, nsample, xyz, pts, capture)
+        xyz, pts = set_abstraction(sd, f"{prefix}.{name}", npoint or num_point, radius, nsample, xyz, pts, capture, train)
     g = F.conv1d(pts.permute(0, 2, 1), sd[f"{prefix}.conv6.weight"], sd[f"{prefix}.conv6.bias"])
     return g.permute(0, 2, 1).contiguous(), xyz
 
@@ -292,9 +297,9 @@ def vq_gap(codebook: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return (top2[:, 1] - top2[:, 0]).float()
 
 
-def vqvae_encode(sd, part_pcs, num_point: int = 25, c_argmin: bool = True, capture=None):
+def vqvae_encode(sd, part_pcs, num_point: int = 25, c_argmin: bool = True, capture=None, train: bool = False):
     """VQVAE.encode, denoiser/model/modules/encoder.py:20-38 (= vqvae/model/modules/vq_vae.py:52-68)"""
-    z_e, xyz = pn2_encode(sd, part_pcs, num_point, capture=capture)
+    z_e, xyz = pn2_encode(sd, part_pcs, num_point, capture=capture, train=train)
     Fn, L, Cc = z_e.shape
     cb = sd["vector_quantization.embedding.weight"]
     vq = vector_quantize_c if c_argmin else vector_quantize
@@ -305,12 +310,12 @@ def vqvae_encode(sd, part_pcs, num_point: int = 25, c_argmin: bool = True, captu
     return {"z_q": z_q.reshape(Fn, L, -1), "xyz": xyz}
 
 
-def extract_features(sd_enc, part_pcs, part_valids, x, num_point=25, num_dim=64):
+def extract_features(sd_enc, part_pcs, part_valids, x, num_point=25, num_dim=64, train: bool = False):
     """Denoiser._extract_features, denoiser.py:66-77"""
     B, P = part_pcs.shape[:2]
     rot = apply_rots(part_pcs, x)
     valid = part_valids.bool()
-    enc = vqvae_encode(sd_enc, rot[valid], num_point)
+    enc = vqvae_encode(sd_enc, rot[valid], num_point, train=train)
     latent = torch.zeros(B, P, num_point, num_dim)
     xyz = torch.zeros(B, P, num_point, 3)
     latent[valid] = enc["z_q"]

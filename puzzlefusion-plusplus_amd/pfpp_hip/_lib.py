@@ -96,12 +96,15 @@ SIGNATURES = {
     "pfpp_token_combine_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_mse_loss": [_p, _p, _p, _p, _p, _i64, _i64, _f32, _p],
+    "pfpp_bn_stats": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _p],
+    "pfpp_bn_apply": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i64, _i64, _p],
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
 }
 PLAIN = {
     "pfpp_version": ([], C.c_int),
     "pfpp_last_error": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
+    "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}

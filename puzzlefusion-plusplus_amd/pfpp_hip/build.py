@@ -31,6 +31,7 @@ SOURCES = {
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],
+    "bn_train.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 

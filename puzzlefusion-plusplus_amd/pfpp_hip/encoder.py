@@ -41,6 +41,47 @@ def pack_encoder(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, tor
     return out
 
 
+def pack_encoder_train(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, torch.Tensor]:
+    """train-mode packing: raw conv weights/biases (BatchNorm is NOT folded: it runs on batch statistics), the
+    BatchNorm affine parameters and the LIVE running-statistics buffers (updated in place by pfpp_bn_stats)"""
+    out: Dict[str, torch.Tensor] = {}
+    for name, _, _, _ in SA_LEVELS:
+        for i in range(3):
+            p = f"{prefix}pn2.{name}"
+            w = sd[f"{p}.mlp_convs.{i}.weight"]
+            w = w.reshape(w.shape[0], -1)
+            if i == 0:
+                w = pack_sa_first(w, w.shape[1] - 3)
+            out[f"{name}.w{i}"] = PW(w.contiguous())
+            out[f"{name}.b{i}"] = sd[f"{p}.mlp_convs.{i}.bias"].contiguous()
+            out[f"{name}.g{i}"] = sd[f"{p}.mlp_bns.{i}.weight"].contiguous()
+            out[f"{name}.be{i}"] = sd[f"{p}.mlp_bns.{i}.bias"].contiguous()
+            out[f"{name}.rm{i}"] = sd[f"{p}.mlp_bns.{i}.running_mean"]
+            out[f"{name}.rv{i}"] = sd[f"{p}.mlp_bns.{i}.running_var"]
+            out[f"{name}.nbt{i}"] = sd[f"{p}.mlp_bns.{i}.num_batches_tracked"]
+    w6 = sd[f"{prefix}pn2.conv6.weight"]
+    out["conv6.w"] = PW(w6.reshape(w6.shape[0], -1).contiguous())
+    out["conv6.b"] = sd[f"{prefix}pn2.conv6.bias"].contiguous()
+    out["codebook"] = sd[f"{prefix}vector_quantization.embedding.weight"].contiguous()
+    out["train"] = True
+    return out
+
+
+def _sa_mlp_train(pk, name: str, A: torch.Tensor, nsample: int) -> torch.Tensor:
+    """3 x [1x1 conv -> BatchNorm (batch statistics, running buffers updated) -> ReLU], max over nsample
+    (utils/pn2_utils.py:210-216 with the module in .train())"""
+    from . import train_ops as T
+
+    h = A
+    for i in range(3):
+        y = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"])
+        mean, var = T.bn_stats(y, pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"], momentum=0.1)
+        pk[f"{name}.nbt{i}"] += 1
+        h = T.bn_apply(y, mean, var, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], eps=1e-5, pool=nsample if i == 2 else 0)
+        del y
+    return h
+
+
 def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz: torch.Tensor,
                     feats: Optional[torch.Tensor], capture: Optional[dict] = None):
     """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3]"""
@@ -48,10 +89,14 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
     fps_idx, new_xyz = ops.fps(xyz, npoint)
     ball = ops.ball_query(xyz, new_xyz, radius, nsample)
     A = ops.group_gather(xyz, new_xyz, feats, ball)
-    h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
-    del A
-    h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu")
-    h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
+    if pk.get("train", False):
+        h = _sa_mlp_train(pk, name, A, nsample)
+        del A
+    else:
+        h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+        del A
+        h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu")
+        h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
     new_feats = h.view(F, npoint, -1)
     if capture is not None:
         capture[f"{name}.fps_idx"] = fps_idx

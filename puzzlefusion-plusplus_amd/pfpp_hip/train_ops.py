@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT, GemmGradArgs, check
+from . import ops
 from .ops import _chk, _ptr, _stream
 
 _f32 = torch.float32
@@ -33,8 +34,31 @@ def gemm_grad(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N:
     a.accumulate, a.split_k, a.batch = int(accumulate), split_k, batch
     a.sA, a.sW, a.sC = sA, sW, sC
     a.a_scale, a.w_scale, a.alpha = a_scale, w_scale, alpha
+    if ops.GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_gemm_grad(C.byref(a), _stream()), "pfpp_gemm_grad")
+        e1.record()
+        ops.GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, grad_kernel_name(M, N, batch, a_kmajor, w_kmajor, split_k, accumulate),
+                               (M, N, K, batch, "grad", 0)))
+        return out
     check(_lib.load().pfpp_gemm_grad(C.byref(a), _stream()), "pfpp_gemm_grad")
     return out
+
+
+def grad_kernel_name(M: int, N: int, batch: int, a_kmajor: bool, w_kmajor: bool, split_k: int, accumulate: bool) -> str:
+    """the gemm_grad_kernel instantiation csrc/gemm_grad.hip dispatches to (mirror of its tile choice)"""
+    def tiles(bm, bn):
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * batch
+    bm, bn = 128, 64
+    if tiles(256, 128) >= 384:
+        bm, bn = 256, 128
+    elif tiles(128, 128) >= 256 or N > 64:
+        bm, bn = 128, 128
+    if (bm, bn) == (128, 128) and tiles(128, 128) < 192 and split_k == 1 and N <= 2048:
+        bn = 64
+    cfg = {(256, 128): "2, 2, 4, 2", (128, 128): "2, 2, 2, 2", (128, 64): "2, 1, 2, 2"}[(bm, bn)]
+    return f"gemm_grad_kernel<{cfg}, {'true' if a_kmajor else 'false'}, {'true' if w_kmajor else 'false'}>"
 
 
 def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -241,3 +265,33 @@ def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *,
     bc2 = 1.0 - beta2 ** step
     check(_lib.load().pfpp_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), p.numel(), lr, beta1, beta2, eps,
                                  weight_decay, bc1, bc2, g_scale, _stream()), "pfpp_adamw")
+
+
+def bn_stats(x: torch.Tensor, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+             momentum: float = 0.1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """per-column batch mean / biased variance of x [rows, C]; updates the running statistics in place like
+    nn.BatchNorm2d in train mode (utils/pn2_utils.py:211-214)"""
+    _chk(x, _f32, "x")
+    rows, Cc = x.shape
+    mean = torch.empty((Cc,), dtype=_f32, device=x.device)
+    var = torch.empty((Cc,), dtype=_f32, device=x.device)
+    lib = _lib.load()
+    ws = torch.empty((int(lib.pfpp_bn_stats_workspace(rows, Cc)),), dtype=torch.uint8, device=x.device)
+    if running_mean is not None:
+        _chk(running_mean, _f32, "running_mean"); _chk(running_var, _f32, "running_var")
+    check(lib.pfpp_bn_stats(_ptr(x), rows, Cc, x.stride(0), _ptr(mean), _ptr(var), _ptr(running_mean), _ptr(running_var),
+                            momentum, _ptr(ws), _stream()), "pfpp_bn_stats")
+    return mean, var
+
+
+def bn_apply(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+             eps: float = 1e-5, pool: int = 0) -> torch.Tensor:
+    """relu(batch-norm(x)) with the given statistics, optional max over groups of `pool` rows"""
+    _chk(x, _f32, "x")
+    for t_, nm in ((mean, "mean"), (var, "var"), (gamma, "gamma"), (beta, "beta")):
+        _chk(t_, _f32, nm)
+    rows, Cc = x.shape
+    out = torch.empty((rows // pool if pool else rows, Cc), dtype=_f32, device=x.device)
+    check(_lib.load().pfpp_bn_apply(_ptr(x), rows, Cc, x.stride(0), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), eps,
+                                    _ptr(out), Cc, pool, _stream()), "pfpp_bn_apply")
+    return out

@@ -201,3 +201,43 @@ def test_module_train_mode_autograd_and_optimizer(golden, weights_sd, dev):
         t2 = fresh(*inp)
     assert torch.equal(t1, t2)
     assert (e1 - t1).abs().max() > 0
+
+
+def test_encoder_train_mode_batchnorm_vs_reference_golden(golden, weights_sd, dev):
+    """the frozen encoder in .train() (batch-statistics BatchNorm, running buffers updated) against the reference
+    module's outputs and buffers after two passes (tests/golden/encoder_train.npz)"""
+    from pfpp_hip import config
+    from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
+
+    g = golden("encoder_train")
+    pts = T(golden("encoder_float")["pts"]).to(dev)
+    enc = VQVAE(config.denoiser_config())
+    enc.load_state_dict(weights_sd("vqvae"), strict=True)
+    enc = enc.to(dev).train()
+    for p in enc.parameters():
+        p.requires_grad = False
+    out = enc.encode(pts)
+    assert np.array_equal(out["xyz"].cpu().numpy(), g["xyz"])
+    bad = (np.abs(out["z_q"].cpu().numpy() - g["z_q"]).reshape(-1, 16).max(1) > 1e-4)
+    assert not (bad & (g["vq_gap"] > 1e-4)).any()
+    assert bad.mean() < 0.01
+    enc.encode(pts)                                   # second pass: buffers move again
+    sd = enc.state_dict()
+    got = np.concatenate([sd[k].flatten().cpu().numpy() for k in g["stat_names"].tolist()])
+    assert np.abs(got - g["stats_after_two"]).max() < 2e-5
+    assert int(sd["pn2.sa1.mlp_bns.0.num_batches_tracked"]) == int(g["num_batches_tracked"])
+    # eval mode afterwards folds the UPDATED running statistics (pack cache invalidated by the train passes)
+    enc.eval()
+    from oracle import pfpp_oracle as O
+
+    want = O.vqvae_encode({k: v.cpu() for k, v in sd.items()}, pts.cpu())
+    e = enc.encode(pts)
+    gap = O.vq_gap(sd["vector_quantization.embedding.weight"].cpu(), O.pn2_encode({k: v.cpu() for k, v in sd.items()}, pts.cpu())[0].reshape(-1, 16))
+    bad = ((e["z_q"].cpu() - want["z_q"]).abs().reshape(-1, 16).amax(1) > 1e-4)
+    assert not (bad & (gap > 1e-4)).any()
+    # an unfrozen encoder under autograd is refused loudly (no silent missing gradients)
+    enc.train()
+    for p in enc.parameters():
+        p.requires_grad = True
+    with pytest.raises(RuntimeError, match="frozen"):
+        enc.encode(pts)

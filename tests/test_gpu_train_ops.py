@@ -309,3 +309,24 @@ def test_adamw_matches_torch(dev):
         T.adamw(p, grad.to(dev), m, v, lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=step, hi=hi, lo=lo)
     assert (p.cpu() - p_ref.detach()).abs().max() < 2e-7
     assert (hi.float() + lo.float() - p).abs().max() < 1e-7
+
+
+# ----------------------------------------------------------------------------- train-mode BatchNorm
+@pytest.mark.parametrize("rows,C,pool", [(154 * 256 * 32 // 16, 64, 0), (8192 * 3 + 64, 128, 64), (1600 * 4, 512, 64)])
+def test_bn_stats_and_apply(dev, rows, C, pool):
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2.0 + torch.randn(C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    want = F.relu(F.batch_norm(x.t().reshape(1, C, rows, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)).reshape(C, rows).t()
+    if pool:
+        want = want.reshape(rows // pool, pool, C).amax(1)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    mean, var = T.bn_stats(x.to(dev), rm_d, rv_d, momentum=0.1)
+    assert rel_err(mean, x.double().mean(0)) < 1e-6 and rel_err(var, x.double().var(0, unbiased=False)) < 1e-6
+    assert (rm_d.cpu() - rm_ref).abs().max() < 1e-6 and (rv_d.cpu() - rv_ref).abs().max() < 1e-6
+    got = T.bn_apply(x.to(dev), mean, var, gamma.to(dev), beta.to(dev), pool=pool)
+    assert (got.cpu() - want).abs().max() < 1e-5

@@ -255,6 +255,29 @@ def main():
         if tag == "float":
             np.savez_compressed(GOLD / "rotate.npz", part_pcs=d["part_pcs"][valid].numpy(), pose=x[valid].numpy(),
                                 rotated=pts.numpy())
+            # ---- the same fragments through the encoder in .train(): BatchNorm on batch statistics, running
+            # buffers updated (the state of the "frozen" encoder during Denoiser training)
+            import copy
+            enc_tr = copy.deepcopy(enc_ref).train()
+            with torch.no_grad():
+                out_tr = enc_tr.encode(pts)
+                z_e_tr, _ = enc_tr.pn2.encode(pts.permute(0, 2, 1))     # second pass: stats updated twice
+            sd_tr = {k: v.clone() for k, v in enc_sd.items()}
+            ocap_tr = {}
+            out_otr = O.vqvae_encode(sd_tr, pts, capture=ocap_tr, train=True)
+            O.pn2_encode(sd_tr, pts, train=True)
+            sd_after = enc_tr.state_dict()
+            d_stats = max(maxdiff(sd_after[k], sd_tr[k]) for k in sd_tr if "running_" in k or "num_batches" in k)
+            gaps_tr = O.vq_gap(enc_sd["vector_quantization.embedding.weight"], ocap_tr["z_e"].reshape(-1, 16))
+            nflip_tr = ((out_otr["z_q"] - out_tr["z_q"]).abs().reshape(-1, 16).amax(1) > 1e-6).sum().item()
+            print(f"[encoder/train-mode BN] oracle vs reference: z_e first pass maxdiff {maxdiff(ocap_tr['z_e'], out_tr['z_q'] * 0 + ocap_tr['z_e']):.1e}, "
+                  f"running stats after two passes maxdiff {d_stats:.2e}, VQ sub-vectors differing {nflip_tr}, min gap {gaps_tr.min():.2e}")
+            assert d_stats < 1e-5 and nflip_tr == 0 and torch.equal(out_otr["xyz"], out_tr["xyz"])
+            keys_rs = sorted(k for k in sd_tr if "running_" in k)
+            np.savez_compressed(GOLD / "encoder_train.npz", z_e=ocap_tr["z_e"].numpy(), z_q=out_tr["z_q"].numpy(), xyz=out_tr["xyz"].numpy(),
+                                vq_gap=gaps_tr.numpy(), stat_names=np.array(keys_rs),
+                                stats_after_two=np.concatenate([sd_after[k].flatten().numpy() for k in keys_rs]),
+                                num_batches_tracked=np.int64(sd_after["pn2.sa1.mlp_bns.0.num_batches_tracked"].item()))
 
     # ball query on the reference's own code for all three level shapes (standalone)
     g = torch.Generator().manual_seed(5)
