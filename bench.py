@@ -302,7 +302,7 @@ def main():
                 print(f"  {ms_ / args.steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // args.steps:3d}  {key}", file=sys.stderr)
         name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
-        split = "f16x3" in name
+        split = "f16x3" in name or "gemm_grad" in name
         # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
         # FLOPs is the f16 dense peak / 3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS

@@ -40,17 +40,35 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int n_part, int64_t rows, int C,
-                                                          float* __restrict__ mean, float* __restrict__ var,
-                                                          float* __restrict__ rmean, float* __restrict__ rvar,
-                                                          float momentum) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// one workgroup per 16 columns: 16 column lanes x 64 partial phases, tree over the phases in LDS (fixed order:
+// deterministic), then the running-statistics update
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ part, int n_part, int64_t rows, int C,
+                                                           float* __restrict__ mean, float* __restrict__ var,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           float momentum) {
+  __shared__ double red[2][64][16];
+  const int cl = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0, q = 0.0;
-  for (int p = 0; p < n_part; ++p) {
-    s += part[(size_t)p * 2 * C + c];
-    q += part[(size_t)p * 2 * C + C + c];
+  if (c < C) {
+    for (int p = ph; p < n_part; p += 64) {
+      s += part[(size_t)p * 2 * C + c];
+      q += part[(size_t)p * 2 * C + C + c];
+    }
   }
+  red[0][ph][cl] = s;
+  red[1][ph][cl] = q;
+  __syncthreads();
+  for (int half = 32; half > 0; half >>= 1) {
+    if (ph < half) {
+      red[0][ph][cl] += red[0][ph + half][cl];
+      red[1][ph][cl] += red[1][ph + half][cl];
+    }
+    __syncthreads();
+  }
+  if (ph != 0 || c >= C) return;
+  s = red[0][0][cl];
+  q = red[1][0][cl];
   const double n = (double)rows;
   const double m = s / n;
   double v = q / n - m * m;
@@ -112,7 +130,7 @@ extern "C" int pfpp_bn_stats(const float* x, int64_t rows, int64_t C, int64_t ld
   const int RP = 256 / (int)(C / 4);
   const size_t smem = (size_t)RP * 2 * C * sizeof(double);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(n_part), dim3(256), smem, st, x, rows, (int)C, ld, (double*)workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, (const double*)workspace,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, st, (const double*)workspace,
                      n_part, rows, (int)C, mean, var, running_mean, running_var, momentum);
   return pfpp::check_launch(__func__);
 }

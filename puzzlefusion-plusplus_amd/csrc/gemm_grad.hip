@@ -264,10 +264,13 @@ int dispatch(GradP p, int batch, int split_k, hipStream_t st) {
   int splits = split_k;
   if (splits <= 0 && !p.accumulate) splits = 1;     // a plain store cannot be split
   if (splits <= 0) {
-    // auto: enough workgroups for ~3 per CU, chunks of at least 256 deep
+    // auto: ~1.5 workgroups per CU, chunks at least 512 deep (measured best on the [3850-token] training step:
+    // more, shallower chunks pay more in atomics than they gain in occupancy)
+    static const int target_wg = getenv("PFPP_GRAD_WG") ? atoi(getenv("PFPP_GRAD_WG")) : 384;
+    static const int min_k = getenv("PFPP_GRAD_MINK") ? atoi(getenv("PFPP_GRAD_MINK")) : 512;
     const int64_t t = tiles(bm, bn);
-    int64_t want = (768 + t - 1) / t;
-    const int64_t max_by_k = (p.K + 255) / 256;
+    int64_t want = (target_wg + t - 1) / t;
+    const int64_t max_by_k = (p.K + min_k - 1) / min_k;
     if (want > max_by_k) want = max_by_k;
     splits = (int)(want < 1 ? 1 : want);
   }

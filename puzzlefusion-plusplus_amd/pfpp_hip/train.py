@@ -228,6 +228,10 @@ class DenoiserTrainEngine:
         self.grad_scale = float(grad_scale)
         self.step_count = 0
         self._handles: List[object] = []
+        # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
+        # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
+        import os
+        self._side = torch.cuda.Stream(device=self.flat.params.device) if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, seed: int = 0,
@@ -376,7 +380,7 @@ class DenoiserTrainEngine:
             datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
                                     s["att_scale"])
-            T.grad_weight(dqkv, lay["n2"], g[f"{i}.global_attn.qkv.w"], g_scale=G)
+            self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
             T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
                             dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C)
@@ -385,7 +389,7 @@ class DenoiserTrainEngine:
             self._linear_bwd(dy, lay["att1"], w[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"])
             datt = T.grad_input(dy, w[f"{i}.self_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_blockdiag_bwd(lay["qkv1"], datt, Fv, L, H, dh, s["att_scale"])
-            T.grad_weight(dqkv, lay["n1"], g[f"{i}.self_attn.qkv.w"], g_scale=G)
+            self._linear_bwd(dqkv, lay["n1"], None, g[f"{i}.self_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G)
             T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
                             dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C)
@@ -418,10 +422,20 @@ class DenoiserTrainEngine:
         self._all_done()
 
     def _linear_bwd(self, dy, x, wpw, gw, gb) -> None:
-        """dW += dy^T x, db += colsum(dy)"""
-        T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
-        if gb is not None:
-            T.colsum(dy, gb)
+        """dW += dy^T x, db += colsum(dy) — on the side stream when there is one"""
+        if self._side is None:
+            T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
+            if gb is not None:
+                T.colsum(dy, gb)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)                 # dy (and x) are ready once everything queued so far has run
+        with torch.cuda.stream(self._side):
+            T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
+            if gb is not None:
+                T.colsum(dy, gb)
+        dy.record_stream(self._side)                 # the caching allocator must not recycle them under the side stream
+        x.record_stream(self._side)
 
     # ------------------------------------------------------------------------------------------ data parallel
     def _layer_done(self, i: int) -> None:
@@ -430,10 +444,15 @@ class DenoiserTrainEngine:
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             a, b = self.flat.layer_ranges[i]
-            self._handles.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            # issued from the stream that produced the layer's weight gradients: RCCL orders itself after it
+            with torch.cuda.stream(self._side if self._side is not None else torch.cuda.current_stream()):
+                self._handles.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def _all_done(self) -> None:
         import torch.distributed as dist
+
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             a0 = self.flat.layer_ranges[0][0]

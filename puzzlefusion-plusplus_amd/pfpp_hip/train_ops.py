@@ -16,6 +16,9 @@ from . import ops
 from .ops import _chk, _ptr, _stream
 
 _f32 = torch.float32
+import os as _os
+
+SPLIT_DX = _os.environ.get("PFPP_SPLIT_DX", "1") == "1"
 
 
 def gemm_grad(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
@@ -67,10 +70,13 @@ def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: 
     K_in = W.shape[1]
     if W.shape[0] != N_out:
         raise ValueError("grad_input: dY [M,out] and W [out,in] expected")
+    # few output tiles and a long contraction: cut K over several workgroups (atomics into a zeroed output)
+    tiles = ((M + 127) // 128) * ((K_in + 127) // 128)
+    split = out is None and SPLIT_DX and tiles < 256 and N_out >= 1024
     if out is None:
-        out = torch.empty((M, K_in), dtype=_f32, device=dY.device)
+        out = (torch.zeros if split else torch.empty)((M, K_in), dtype=_f32, device=dY.device)
     return gemm_grad(dY, W, out, M=M, N=K_in, K=N_out, lda=dY.stride(0), ldw=W.stride(0), ldc=out.stride(0),
-                     w_kmajor=True, a_scale=g_scale)
+                     w_kmajor=True, a_scale=g_scale, accumulate=split, split_k=0 if split else 1)
 
 
 def grad_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, g_scale: float = 1.0, k_cols: Optional[int] = None) -> torch.Tensor:
