@@ -156,6 +156,13 @@ typedef struct pfpp_gemm_args {
   int64_t sA0, sA1, sW0, sW1, sC0, sC1;
   int64_t sV0, sV1;       /* batch strides of bias / scale / shift */
   float alpha;            /* acc *= alpha before the epilogue (1.0 = off) */
+  /* train-mode BatchNorm fusion (set-abstraction MLPs with the encoder in .train(), see pfpp_bn_finalize):
+   * a_mul/a_add [K]: A is read as relu(A*a_mul[k] + a_add[k]);  stats: fp64 [stats_copies][2][N], receives
+   * (atomically) the column sums and sums of squares of the bias-added result;  c_min: with pool > 0 the
+   * per-group minimum [M/pool, ldc] next to the maximum in C.  All NULL/0 = off.                        */
+  const float* a_mul; const float* a_add;
+  double* stats; int32_t stats_copies;
+  float* c_min;
 } pfpp_gemm_args;
 
 int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);
@@ -442,6 +449,16 @@ int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo,
  * bn_apply: y = relu(x*a + b) with a = gamma/sqrt(var+eps), b = beta - mean*a (the form ATen's CPU kernel
  * uses), optional max over groups of `pool` consecutive rows (the set-abstraction max, pn2_utils.py:216):
  * y [rows/pool, ldy].  C % 4 == 0, C <= 1024.                                                         */
+/* fused form: the producing GEMM accumulates stats (see pfpp_gemm_args.stats); bn_finalize turns them into
+ * mean/var (optional outputs), updates the running buffers, writes the affine a = gamma/sqrt(var+eps),
+ * b = beta - mean*a for the consuming GEMM's a_mul/a_add, and clears stats for the next use.
+ * bn_minmax_apply: y = relu(a*(a >= 0 ? mx : mn) + b) == max over the pool group of relu(a*x + b).    */
+int pfpp_bn_finalize(double* stats, int64_t copies, int64_t rows, int64_t C, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* mean, float* var, float* a_mul, float* a_add,
+                     pfpp_stream_t stream);
+int pfpp_bn_minmax_apply(const float* mx, const float* mn, const float* a_mul, const float* a_add,
+                         float* y, int64_t rows, int64_t C, pfpp_stream_t stream);
 int64_t pfpp_bn_stats_workspace(int64_t rows, int64_t C);
 int pfpp_bn_stats(const float* x, int64_t rows, int64_t C, int64_t ld, float* mean, float* var,
                   float* running_mean, float* running_var, float momentum, void* workspace,

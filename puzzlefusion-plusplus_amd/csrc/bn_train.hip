@@ -111,7 +111,70 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   *reinterpret_cast<float4*>(y + orow * ldy + c) = o;
 }
 
+// fused path: stats [copies][2][C] from the GEMM epilogues -> affine for the consumer; clears stats
+__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(double* __restrict__ stats, int copies, int64_t rows, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, float momentum, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, float* __restrict__ mean,
+                                                                float* __restrict__ var, float* __restrict__ a_mul,
+                                                                float* __restrict__ a_add) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < copies; ++k) {
+    s += stats[(size_t)k * 2 * C + c];
+    q += stats[(size_t)k * 2 * C + C + c];
+    stats[(size_t)k * 2 * C + c] = 0.0;
+    stats[(size_t)k * 2 * C + C + c] = 0.0;
+  }
+  const double n = (double)rows;
+  const double m = s / n;
+  double v = q / n - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mf = (float)m, vf = (float)v;
+  if (mean) { mean[c] = mf; var[c] = vf; }
+  if (rmean) {
+    const double unbiased = rows > 1 ? v * n / (n - 1.0) : v;
+    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+  }
+  const float a = gamma[c] * (1.0f / sqrtf(vf + eps));
+  a_mul[c] = a;
+  a_add[c] = beta[c] - mf * a;
+}
+
+__global__ __launch_bounds__(256) void bn_minmax_apply_kernel(const float* __restrict__ mx, const float* __restrict__ mn,
+                                                              const float* __restrict__ a_mul, const float* __restrict__ a_add,
+                                                              float* __restrict__ y, int64_t total, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const float a = a_mul[c];
+  y[i] = fmaxf(a * (a >= 0.0f ? mx[i] : mn[i]) + a_add[c], 0.0f);
+}
+
 }  // namespace
+
+extern "C" int pfpp_bn_finalize(double* stats, int64_t copies, int64_t rows, int64_t C, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* mean, float* var, float* a_mul, float* a_add, pfpp_stream_t stream) {
+  PFPP_REQUIRE(stats && gamma && beta && a_mul && a_add, "null pointer");
+  PFPP_REQUIRE(copies >= 1 && rows >= 1 && C >= 1, "bad sizes");
+  PFPP_REQUIRE(!running_mean == !running_var && !mean == !var, "mean/var pointers go in pairs");
+  hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, pfpp::as_stream(stream), stats,
+                     (int)copies, rows, (int)C, gamma, beta, eps, momentum, running_mean, running_var, mean, var, a_mul, a_add);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_bn_minmax_apply(const float* mx, const float* mn, const float* a_mul, const float* a_add, float* y,
+                                    int64_t rows, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(mx && mn && a_mul && a_add && y, "null pointer");
+  const int64_t total = rows * C;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(bn_minmax_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, pfpp::as_stream(stream), mx,
+                     mn, a_mul, a_add, y, total, (int)C);
+  return pfpp::check_launch(__func__);
+}
 
 extern "C" int64_t pfpp_bn_stats_workspace(int64_t rows, int64_t C) {
   const int64_t n_part = (rows + SLAB - 1) / SLAB;

@@ -291,6 +291,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   constexpr int NWF = WPRE ? 1 : WF_IT;
   constexpr int NWH = WPRE ? WH_IT : 1;
   float4 ra[A_IT];
+  float4 r_mul = make_float4(1.f, 1.f, 1.f, 1.f), r_add = make_float4(0.f, 0.f, 0.f, 0.f);   // fused BN+ReLU on A
+  const bool a_aff = p.a_mul != nullptr;
   float4 rwf[NWF];
   uint4 rwh[NWH], rwl[NWH];
   const int a_row = tid >> 3, a_c4 = tid & 7;
@@ -321,6 +323,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   auto load_full = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
+    if (a_aff) {
+      r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
+      r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
+    }
     if constexpr (WPRE) {
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
@@ -355,7 +361,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
-      split4(ra[it], hi, lo);
+      float4 v = ra[it];
+      if (a_aff) {      // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
+        v.x = fmaxf(v.x * r_mul.x + r_add.x, 0.0f); v.y = fmaxf(v.y * r_mul.y + r_add.y, 0.0f);
+        v.z = fmaxf(v.z * r_mul.z + r_add.z, 0.0f); v.w = fmaxf(v.w * r_mul.w + r_add.w, 0.0f);
+      }
+      split4(v, hi, lo);
       const int off = (a_row + (NTHR / 8) * it) * LDH + a_c4 * 4;
       *reinterpret_cast<half4*>(ahi + off) = hi;
       *reinterpret_cast<half4*>(alo + off) = lo;
@@ -503,6 +514,16 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a->act != PFPP_ACT_GEGLU || (a->N % 64 == 0 && a->pool == 0 && !a->scale && !a->residual),
                "GEGLU: N % 64 != 0 or unsupported epilogue combination");
   PFPP_REQUIRE(a->precision == PFPP_GEMM_F32 || a->precision == PFPP_GEMM_F16X3, "unknown precision");
+  const bool fused_bn = a->a_mul || a->stats || a->c_min;
+  if (fused_bn) {
+    PFPP_REQUIRE(!a->a_mul == !a->a_add, "a_mul and a_add go together");
+    PFPP_REQUIRE(!a->stats || a->stats_copies >= 1, "stats without stats_copies");
+    PFPP_REQUIRE(!a->c_min || (a->pool != 0 && !a->c_hi), "c_min needs pooling and an fp32 output");
+    PFPP_SUPPORTED(a->precision == PFPP_GEMM_F16X3 && a->w_hi && !apre && a->batch == 1 && a->act == PFPP_ACT_NONE &&
+                   !a->scale && a->K % 32 == 0 || !a->a_mul,
+                   "fused BatchNorm input needs the f16x3 path with pre-split W, K % 32 == 0, no activation");
+    PFPP_SUPPORTED(a->precision == PFPP_GEMM_F16X3 && a->w_hi && !apre && a->batch == 1, "fused BatchNorm on this GEMM variant");
+  }
   const bool pre = a->w_hi != nullptr;
   if (pre) {
     PFPP_REQUIRE(a->precision == PFPP_GEMM_F16X3 && a->w_lo && !a->w_kmajor, "pre-split W needs the f16x3 path, [N,K] layout");
@@ -526,6 +547,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.sA0 = a->sA0; p.sA1 = a->sA1; p.sW0 = a->sW0; p.sW1 = a->sW1; p.sC0 = a->sC0; p.sC1 = a->sC1;
   p.sV0 = a->sV0; p.sV1 = a->sV1;
   p.alpha = a->alpha;
+  p.a_mul = a->a_mul; p.a_add = a->a_add; p.stats = a->stats; p.stats_copies = a->stats_copies; p.Cmin = a->c_min;
   p.tiles_n = 0;
   hipStream_t st = pfpp::as_stream(stream);
 
@@ -536,9 +558,9 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
     if (apre) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop, no conversions
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
-    if (pre && wide && use_ring && a->K % 32 == 0) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
+    if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
     static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;
-    if (pre && wide && use_ws) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
+    if (pre && wide && use_ws && !fused_bn) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
     static const bool big_tile = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
     // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
     // row panels to fill the chip several times over

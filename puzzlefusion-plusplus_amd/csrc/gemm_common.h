@@ -21,6 +21,12 @@ struct GemmP {
   int64_t sA0, sA1, sW0, sW1, sC0, sC1, sV0, sV1;
   float alpha;
   int tiles_n, tiles_m, group_m;
+  // train-mode BatchNorm fusion (bn_train.hip): A is read as relu(A*a_mul[k] + a_add[k]); per-column sum / sum of
+  // squares of the (bias-added) result go to stats[copy][0..1][N] (fp64 atomics, copy = workgroup % stats_copies);
+  // with pooling the per-group minimum goes to Cmin next to the maximum in C
+  const float* a_mul; const float* a_add;
+  double* stats; int stats_copies;
+  float* Cmin;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -118,7 +124,8 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
       else if (bias) { sh = bias[col]; }
     }
     const int ocol = geglu ? ((col_w + (j & ~1) * 32) >> 1) + l31 : col;
-    float mx[MT];
+    float mx[MT], mn[MT];
+    float st_s = 0.0f, st_q = 0.0f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x16 t = acc[i][j];
@@ -126,6 +133,15 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
       for (int e = 0; e < 16; ++e) {
         const float v = t[e] * alpha;
         t[e] = scale ? v * sc + sh : v + sh;
+      }
+      if (p.stats) {      // BatchNorm batch statistics of the pre-activation (act is NONE on this path)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          const float v = row < p.M ? t[e] : 0.0f;
+          st_s += v;
+          st_q += v * v;
+        }
       }
       if (geglu) {
         if constexpr (NT >= 2) {
@@ -151,22 +167,37 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
       } else {
         // max over groups of `pool` consecutive rows (pool = 32: one MFMA tile, pool = 64: both
         // M-tiles of the wave); groups never straddle M
-        float m = -__builtin_huge_valf();
+        float m = -__builtin_huge_valf(), n = __builtin_huge_valf();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m = fmaxf(m, t[e]);
+        for (int e = 0; e < 16; ++e) { m = fmaxf(m, t[e]); n = fminf(n, t[e]); }
         mx[i] = fmaxf(m, __shfl_xor(m, 32));
+        mn[i] = fminf(n, __shfl_xor(n, 32));
+      }
+    }
+    if (p.stats) {
+      st_s += __shfl_xor(st_s, 32);
+      st_q += __shfl_xor(st_q, 32);
+      if (lhi == 0 && col_ok) {
+        double* st = p.stats + (size_t)(blockIdx.x % p.stats_copies) * 2 * p.N;
+        unsafeAtomicAdd(st + col, (double)st_s);
+        unsafeAtomicAdd(st + p.N + col, (double)st_q);
       }
     }
     if (pool == 64) {
       if constexpr (MT == 2) {
-        if (lhi == 0 && col_ok && row_w < p.M)
+        if (lhi == 0 && col_ok && row_w < p.M) {
           store_out(p, c_off + (int64_t)(row_w >> 6) * p.ldc + col, fmaxf(mx[0], mx[1]));
+          if (p.Cmin) p.Cmin[c_off + (int64_t)(row_w >> 6) * p.ldc + col] = fminf(mn[0], mn[1]);
+        }
       }
     } else if (pool == 32) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row0 = row_w + i * 32;
-        if (lhi == 0 && col_ok && row0 < p.M) store_out(p, c_off + (int64_t)(row0 >> 5) * p.ldc + col, mx[i]);
+        if (lhi == 0 && col_ok && row0 < p.M) {
+          store_out(p, c_off + (int64_t)(row0 >> 5) * p.ldc + col, mx[i]);
+          if (p.Cmin) p.Cmin[c_off + (int64_t)(row0 >> 5) * p.ldc + col] = mn[i];
+        }
       }
     }
   }

@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("sA0", _i64), ("sA1", _i64), ("sW0", _i64), ("sW1", _i64), ("sC0", _i64), ("sC1", _i64),
         ("sV0", _i64), ("sV1", _i64),
         ("alpha", _f32),
+        ("a_mul", _p), ("a_add", _p), ("stats", _p), ("stats_copies", _i32), ("c_min", _p),
     ]
 
 
@@ -97,6 +98,8 @@ SIGNATURES = {
     "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_mse_loss": [_p, _p, _p, _p, _p, _i64, _i64, _f32, _p],
     "pfpp_bn_stats": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _p],
+    "pfpp_bn_finalize": [_p, _i64, _i64, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p],
+    "pfpp_bn_minmax_apply": [_p, _p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_bn_apply": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i64, _i64, _p],
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
 }

@@ -14,6 +14,10 @@ import torch
 from . import ops
 from .packing import PW, fold_conv_bn, pack_sa_first
 
+import os as _os
+
+BN_FUSED = _os.environ.get("PFPP_BN_FUSED", "1") == "1"
+
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
 
@@ -72,6 +76,24 @@ def _sa_mlp_train(pk, name: str, A: torch.Tensor, nsample: int) -> torch.Tensor:
     (utils/pn2_utils.py:210-216 with the module in .train())"""
     from . import train_ops as T
 
+    if ops.GEMM_MODE == "f16x3" and BN_FUSED:
+        # fused form: batch statistics come out of the producing GEMM's epilogue, normalise+ReLU is applied by the
+        # consuming GEMM while it stages its A tiles, and the last layer emits per-group max AND min instead of
+        # its [rows, C] activation (max_p relu(a*y_p + b) = relu(a*(a >= 0 ? max_p y_p : min_p y_p) + b))
+        rows = A.shape[0]
+        h, aff = A, None
+        for i in range(3):
+            Cout = pk[f"{name}.w{i}"].N
+            st = pk.setdefault(f"{name}.stats{i}", T.bn_stats_buffer(Cout, A.device))
+            if i < 2:
+                h = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"], a_affine=aff, stats=st)
+            else:
+                mn = torch.empty((rows // nsample, Cout), dtype=torch.float32, device=A.device)
+                mx = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"], a_affine=aff, stats=st, pool=nsample, c_min=mn)
+            aff = T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
+                                momentum=0.1, eps=1e-5)
+            pk[f"{name}.nbt{i}"] += 1
+        return T.bn_minmax_apply(mx, mn, aff[0], aff[1])
     h = A
     for i in range(3):
         y = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"])

@@ -189,7 +189,8 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
          shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          ldr: int = 0, act: str = "none", pool: int = 0, w_kmajor: bool = False,
          batch: int = 1, zdiv: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sV=(0, 0), alpha: float = 1.0,
-         a_off: int = 0, w_off: int = 0, c_off: int = 0, mode: Optional[str] = None) -> torch.Tensor:
+         a_off: int = 0, w_off: int = 0, c_off: int = 0, mode: Optional[str] = None,
+         a_affine=None, stats: Optional[torch.Tensor] = None, c_min: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw pfpp_gemm call.  A/W/out are base tensors; *_off are element offsets into them
     (used to address q/k/v slices of a packed projection without copies).  W is an fp32 tensor or a
     packing.PW (fp32 + pre-split fp16 planes); `mode` overrides ops.GEMM_MODE for this call."""
@@ -270,6 +271,19 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     args.sC0, args.sC1 = sC
     args.sV0, args.sV1 = sV
     args.alpha = alpha
+    if a_affine is not None:      # train-mode BatchNorm fusion (pfpp_gemm_args.a_mul / a_add / stats / c_min)
+        _chk(a_affine[0], torch.float32, "a_mul"); _chk(a_affine[1], torch.float32, "a_add")
+        if a_affine[0].numel() < K or a_affine[1].numel() < K:
+            raise ValueError("gemm: a_affine vectors shorter than K")
+        args.a_mul, args.a_add = a_affine[0].data_ptr(), a_affine[1].data_ptr()
+    if stats is not None:
+        _chk(stats, torch.float64, "stats")
+        if stats.dim() != 3 or stats.shape[1] != 2 or stats.shape[2] != N:
+            raise ValueError("gemm: stats must be float64 [copies, 2, N]")
+        args.stats, args.stats_copies = stats.data_ptr(), stats.shape[0]
+    if c_min is not None:
+        _chk(c_min, torch.float32, "c_min")
+        args.c_min = c_min.data_ptr()
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -286,7 +300,7 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str = "none",
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, pool: int = 0, K: Optional[int] = None,
-           mode: Optional[str] = None, out=None):
+           mode: Optional[str] = None, out=None, a_affine=None, stats=None, c_min=None):
     """y = epilogue(x @ w^T): x [M, ldx] (first K columns used); w = packing.PW or an fp32 tensor
     [N, ldw] with ldw % 4 == 0."""
     from .packing import PW
@@ -302,7 +316,7 @@ def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str 
             K = min(ldx, ldw)
     return gemm(x, w, M=M, N=N, K=K, lda=ldx, bias=bias, scale=scale, shift=shift,
                 residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool,
-                mode=mode, out=out)
+                mode=mode, out=out, a_affine=a_affine, stats=stats, c_min=c_min)
 
 
 # --------------------------------------------------------------------------- VQ

@@ -301,3 +301,37 @@ def bn_apply(x: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, gamma: torc
     check(_lib.load().pfpp_bn_apply(_ptr(x), rows, Cc, x.stride(0), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), eps,
                                     _ptr(out), Cc, pool, _stream()), "pfpp_bn_apply")
     return out
+
+
+BN_STAT_COPIES = 64      # the epilogues spread their fp64 atomics over this many accumulator copies
+
+
+def bn_stats_buffer(C: int, device) -> torch.Tensor:
+    return torch.zeros((BN_STAT_COPIES, 2, C), dtype=torch.float64, device=device)
+
+
+def bn_finalize(stats: torch.Tensor, rows: int, gamma: torch.Tensor, beta: torch.Tensor,
+                running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+                momentum: float = 0.1, eps: float = 1e-5, want_stats: bool = False):
+    """stats accumulated by a GEMM epilogue -> (a_mul, a_add) for the consumer [+ (mean, var)]; updates the running
+    buffers like nn.BatchNorm2d in train mode and clears `stats`"""
+    _chk(stats, torch.float64, "stats"); _chk(gamma, _f32, "gamma"); _chk(beta, _f32, "beta")
+    Cc = stats.shape[2]
+    a_mul = torch.empty((Cc,), dtype=_f32, device=stats.device)
+    a_add = torch.empty((Cc,), dtype=_f32, device=stats.device)
+    mean = torch.empty((Cc,), dtype=_f32, device=stats.device) if want_stats else None
+    var = torch.empty((Cc,), dtype=_f32, device=stats.device) if want_stats else None
+    check(_lib.load().pfpp_bn_finalize(_ptr(stats), stats.shape[0], rows, Cc, _ptr(gamma), _ptr(beta), eps, momentum,
+                                       _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(var), _ptr(a_mul), _ptr(a_add),
+                                       _stream()), "pfpp_bn_finalize")
+    return (a_mul, a_add, mean, var) if want_stats else (a_mul, a_add)
+
+
+def bn_minmax_apply(mx: torch.Tensor, mn: torch.Tensor, a_mul: torch.Tensor, a_add: torch.Tensor) -> torch.Tensor:
+    """max over a pool group of relu(a*x + b), from the group's max and min of x"""
+    _chk(mx, _f32, "mx"); _chk(mn, _f32, "mn"); _chk(a_mul, _f32, "a_mul"); _chk(a_add, _f32, "a_add")
+    rows, Cc = mx.shape
+    out = torch.empty_like(mx)
+    check(_lib.load().pfpp_bn_minmax_apply(_ptr(mx), _ptr(mn), _ptr(a_mul), _ptr(a_add), _ptr(out), rows, Cc, _stream()),
+          "pfpp_bn_minmax_apply")
+    return out
