@@ -391,7 +391,7 @@ extern "C" int pfpp_colsum(const float* x, float* out, int64_t rows, int64_t col
   if (rows == 0) return PFPP_OK;
   const bool vec = cols % 4 == 0 && ld % 4 == 0 && sx % 4 == 0 && pfpp::aligned16(x);
   if (vec) {
-    const int rpb = 256;
+    const int rpb = 64;      // row blocks of 64: enough workgroups for [3850 x 512] inputs; the tail is 4 atomics per column
     const dim3 grid(blocks_for(cols, 256), blocks_for(rows, rpb), (unsigned)batch);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, x, out, rows, (int)cols, ld, rpb, sx, so);
   } else {

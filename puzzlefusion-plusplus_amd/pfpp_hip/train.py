@@ -227,7 +227,9 @@ class DenoiserTrainEngine:
             raise ValueError("grad_scale must be a power of two (exact rescaling)")
         self.grad_scale = float(grad_scale)
         self.step_count = 0
-        self._handles: List[object] = []
+        from .parallel import GradExchange
+
+        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges)
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
         import os
@@ -439,37 +441,20 @@ class DenoiserTrainEngine:
 
     # ------------------------------------------------------------------------------------------ data parallel
     def _layer_done(self, i: int) -> None:
-        """gradients of layer i are final: start their all-reduce while the earlier layers still compute"""
-        import torch.distributed as dist
-
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            a, b = self.flat.layer_ranges[i]
-            # issued from the stream that produced the layer's weight gradients: RCCL orders itself after it
+        """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
+        from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
+        if self._exchange.active():
             with torch.cuda.stream(self._side if self._side is not None else torch.cuda.current_stream()):
-                self._handles.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                self._exchange.layer_done(i)
 
     def _all_done(self) -> None:
-        import torch.distributed as dist
-
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            a0 = self.flat.layer_ranges[0][0]
-            b1 = self.flat.layer_ranges[-1][1]
-            self._handles.append(dist.all_reduce(self.flat.grads[:a0], op=dist.ReduceOp.SUM, async_op=True))
-            self._handles.append(dist.all_reduce(self.flat.grads[b1:], op=dist.ReduceOp.SUM, async_op=True))
+        self._exchange.all_done()
 
     def finish_grad_exchange(self) -> float:
         """wait for the gradient all-reduces; returns the factor that turns the summed gradients into the mean"""
-        import torch.distributed as dist
-
-        for h in self._handles:
-            h.wait()
-        self._handles = []
-        if dist.is_available() and dist.is_initialized():
-            return 1.0 / dist.get_world_size()
-        return 1.0
+        return self._exchange.finish()
 
     # ------------------------------------------------------------------------------------------ optimizer
     def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:

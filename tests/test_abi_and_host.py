@@ -30,23 +30,25 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert _lib.load().pfpp_version() == 1
 
 
-def test_gemm_args_struct_matches_header():
-    from pfpp_hip._lib import GemmArgs
-
+def header_struct_fields(name: str):
     text = (ROOT / "include" / "pfpp.h").read_text()
-    body = text[text.index("typedef struct pfpp_gemm_args"):text.index("} pfpp_gemm_args;")]
+    body = text[text.index(f"typedef struct {name}"):text.index("} " + name + ";")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split("{", 1)[1].split(";"):
         decl = decl.strip()
         if not decl:
             continue
-        parts = decl.replace("*", " ").split()
-        decl_names = " ".join(parts).split(" ", 2)
-        # strip the type tokens: everything after the last type keyword, comma separated
-        m = re.match(r"(?:const\s+)?(?:float|void|int64_t|int32_t)\s*\*?\s*(.*)", decl)
+        m = re.match(r"(?:const\s+)?(?:float|double|void|int64_t|int32_t)\s*\*?\s*(.*)", decl)
         names += [n.strip(" *") for n in m.group(1).split(",")]
-    assert names == [f[0] for f in GemmArgs._fields_]
+    return names
+
+
+def test_gemm_args_struct_matches_header():
+    from pfpp_hip._lib import GemmArgs, GemmGradArgs
+
+    assert header_struct_fields("pfpp_gemm_args") == [f[0] for f in GemmArgs._fields_]
+    assert header_struct_fields("pfpp_gemm_grad_args") == [f[0] for f in GemmGradArgs._fields_]
 
 
 def test_wrappers_reject_cpu_tensors(hip_lib):
@@ -126,9 +128,9 @@ def test_state_dict_layout_matches_reference_keys(weights_sd):
     v = Verifier(config.verifier_config())
     assert set(v.state_dict().keys()) == {f"verifier.{k}" for k in weights_sd("verifier")}
     assert sum(p.numel() for p in v.verifier.parameters()) == 7_892_737
-    # the train-mode guards are loud
+    # an unfrozen encoder under autograd is refused loudly (gradients do not flow into it on this path)
     d.train()
-    with pytest.raises(RuntimeError, match="eval"):
+    with pytest.raises(RuntimeError, match="frozen"):
         d.encoder.encode(torch.zeros(1, 256, 3))
 
 

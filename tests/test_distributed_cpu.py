@@ -51,3 +51,50 @@ def test_two_rank_sharding_and_clock():
     assert ids == [[0, 3], [3, 6]]
     ref = float(synthetic.make_batch(0, 6, num_points=64)["part_valids"].sum())
     assert total == ref                                            # shards cover every puzzle exactly once
+
+
+def _grad_worker(rank, world, port, out):
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip.parallel import GradExchange
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    ranges = [(100, 400), (400, 700), (700, 900)]                  # three "layers"; [0,100) and [900,1000) = the rest
+    grads = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    ex = GradExchange(grads, ranges)
+    for i in reversed(range(len(ranges))):                          # the backward finishes layers last-to-first
+        ex.layer_done(i)
+    ex.all_done()
+    scale = ex.finish()
+    if rank == 0:
+        out.put((grads.clone(), scale))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange():
+    """the training exchange: every slice of the flat gradient buffer is summed exactly once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, scale = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert scale == 0.5
+    assert torch.equal(grads, torch.arange(1000, dtype=torch.float32) * 3)   # rank0 (x1) + rank1 (x2)
+
+
+def test_grad_exchange_is_a_no_op_without_a_process_group():
+    from pfpp_hip.parallel import GradExchange
+
+    g = torch.ones(10)
+    ex = GradExchange(g, [(2, 5)])
+    ex.layer_done(0); ex.all_done()
+    assert ex.finish() == 1.0 and torch.equal(g, torch.ones(10))
