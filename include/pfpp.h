@@ -326,6 +326,17 @@ int pfpp_edge_histogram(const float* pts, const int32_t* idx_a, const int32_t* i
                         const int32_t* edge_off, int32_t* hist, int64_t n_edges, int64_t max_m,
                         pfpp_stream_t stream);
 
+/* ---- 8f-3: evaluation metrics (denoiser/evaluation/evaluator.py, transform.py) ---------------------------
+ * pfpp_nn_dist: out[b, i] = min_j |src[b,i] - dst[b,j]|^2 — the KNN-1 term of chamferdist.ChamferDistance
+ * (squared L2, knn_points); calc_part_acc (evaluator.py:88-121) and calc_shape_cd (:124-153) call it in
+ * both directions.  src [batch, n, 3], dst [batch, m, 3], out [batch, n].
+ * pfpp_quat_to_euler_xyz: transform.quaternion_to_euler (transform.py:70-86) = pytorch3d
+ * quaternion_to_matrix + matrix_to_euler_angles("XYZ"); quat [n,4] (w first) -> euler [n,3].             */
+int pfpp_nn_dist(const float* src, const float* dst, float* out, int64_t batch, int64_t n, int64_t m,
+                 pfpp_stream_t stream);
+int pfpp_quat_to_euler_xyz(const float* quat, float* euler, int64_t n, int to_degree,
+                           pfpp_stream_t stream);
+
 /* =====================================================================================================
  * a17: training — backward of the DenoiserTransformer, loss and optimizer
  * (Denoiser.forward/_loss/training_step/configure_optimizers, denoiser/model/denoiser.py:80-145,230-241).

@@ -591,6 +591,89 @@ def edge_features_from_hist(hist_pp):
 # =============================================================================================
 # sampler (Denoiser.validation_step, denoiser.py:153-185) — used for the CPU baseline
 # =============================================================================================
+# =============================================================================================
+# 8f-3 — evaluation metrics (denoiser/evaluation/evaluator.py, transform.py; chamferdist / pytorch3d pieces
+# restated from their documented semantics, SURVEY.md appendix A — parity unpinned for those two)
+# =============================================================================================
+def nn_dist(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """knn_points(K=1) squared distances: [B,n,3], [B,m,3] -> [B,n]"""
+    out = []
+    for b in range(src.shape[0]):
+        d = (src[b][:, None, :] - dst[b][None, :, :])
+        out.append(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).min(dim=1)[0])
+    return torch.stack(out)
+
+
+def chamfer_distance(source, target, bidirectional=False, reverse=False, batch_reduction="mean", point_reduction="sum"):
+    """chamferdist.ChamferDistance.forward"""
+    def red(c):
+        if point_reduction == "sum":
+            c = c.sum(1)
+        elif point_reduction == "mean":
+            c = c.mean(1)
+        if batch_reduction == "sum":
+            c = c.sum()
+        elif batch_reduction == "mean":
+            c = c.mean()
+        return c
+    fwd = red(nn_dist(source, target)) if not reverse else None
+    bwd = red(nn_dist(target, source)) if (reverse or bidirectional) else None
+    if bidirectional:
+        return fwd + bwd
+    return bwd if reverse else fwd
+
+
+def transform_pc(trans, rot, pc):
+    """transform.py:26-57: quaternion_apply (no normalisation) then + t, one pose per cloud"""
+    return quaternion_apply(rot.unsqueeze(-2), pc) + trans.unsqueeze(-2)
+
+
+def quaternion_to_euler(quat, to_degree=True):
+    """transform.py:60-76: quaternion_to_matrix + matrix_to_euler_angles("XYZ")"""
+    m = quaternion_to_matrix(quat)
+    e = torch.stack((torch.atan2(-m[..., 1, 2], m[..., 2, 2]), torch.asin(m[..., 0, 2]), torch.atan2(-m[..., 0, 1], m[..., 0, 0])), -1)
+    return torch.rad2deg(e) if to_degree else e
+
+
+def valid_mean(loss_per_part, valids):
+    loss_per_part = torch.where(torch.isnan(loss_per_part), torch.zeros_like(loss_per_part), loss_per_part)
+    valids = valids.float()
+    return (loss_per_part * valids).sum(1) / valids.sum(1)
+
+
+def trans_metrics(t1, t2, valids, metric="rmse"):
+    d = (t1 - t2)
+    per = {"mse": d.pow(2).mean(-1), "rmse": d.pow(2).mean(-1) ** 0.5, "mae": d.abs().mean(-1)}[metric]
+    return valid_mean(per, valids)
+
+
+def rot_metrics(r1, r2, valids, metric="rmse"):
+    d1, d2 = quaternion_to_euler(r1), quaternion_to_euler(r2)
+    diff = torch.minimum((d1 - d2).abs(), 360.0 - (d1 - d2).abs())
+    per = {"mse": diff.pow(2).mean(-1), "rmse": diff.pow(2).mean(-1) ** 0.5, "mae": diff.abs().mean(-1)}[metric]
+    return valid_mean(per, valids)
+
+
+def calc_part_acc(pts, trans1, trans2, rot1, rot2, valids):
+    """evaluator.py:88-121"""
+    B, P = pts.shape[:2]
+    p1 = transform_pc(trans1, rot1, pts).flatten(0, 1)
+    p2 = transform_pc(trans2, rot2, pts).flatten(0, 1)
+    cd = chamfer_distance(p1, p2, bidirectional=True, point_reduction="mean", batch_reduction=None).view(B, P)
+    acc_pp = (cd < 0.01) & (valids == 1)
+    return acc_pp.sum(-1) / (valids == 1).sum(-1), acc_pp, cd
+
+
+def calc_shape_cd(pts, trans1, trans2, rot1, rot2, valids):
+    """evaluator.py:124-153"""
+    B, P, N, _ = pts.shape
+    pts = pts.clone().masked_fill(valids[..., None, None] == 0, 1e3)
+    s1 = transform_pc(trans1, rot1, pts).flatten(1, 2)
+    s2 = transform_pc(trans2, rot2, pts).flatten(1, 2)
+    cd = chamfer_distance(s1, s2, bidirectional=True, point_reduction=None, batch_reduction=None)
+    return valid_mean(cd.view(B, P, N).mean(-1), valids)
+
+
 def split_denoiser_ckpt(sd):
     enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
     den = {k[len("denoiser."):]: v for k, v in sd.items() if k.startswith("denoiser.")}

@@ -80,6 +80,8 @@ SIGNATURES = {
     "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
     "pfpp_pose_apply_points": [_p, _p, _p, _p, _i64, C.c_int, _p],
     "pfpp_edge_histogram": [_p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_nn_dist": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_quat_to_euler_xyz": [_p, _p, _i64, C.c_int, _p],
     # ---- training (a17)
     "pfpp_gemm_grad": [C.POINTER(GemmGradArgs), _p],
     "pfpp_colsum": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _p],

@@ -32,6 +32,7 @@ SOURCES = {
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],
     "bn_train.hip": [],
+    "metrics.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 

@@ -572,3 +572,30 @@ def edge_histogram(pts: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor, 
     check(_lib.load().pfpp_edge_histogram(_ptr(pts), _ptr(idx_a), _ptr(idx_b), _ptr(edge_off), _ptr(hist), n_edges, max_m,
                                           _stream()), "pfpp_edge_histogram")
     return hist
+
+
+# --------------------------------------------------------------------------- evaluation metrics (8f-3)
+def nn_dist(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """src [B,n,3], dst [B,m,3] -> [B,n] squared distance to the nearest neighbour (chamferdist's KNN-1 term)"""
+    _chk(src, torch.float32, "src"); _chk(dst, torch.float32, "dst")
+    if src.dim() != 3 or dst.dim() != 3 or src.shape[0] != dst.shape[0] or src.shape[2] != 3 or dst.shape[2] != 3:
+        raise ValueError("nn_dist: src [B,n,3] and dst [B,m,3] expected")
+    B, n, _ = src.shape
+    out = torch.empty((B, n), dtype=torch.float32, device=src.device)
+    lib = _lib.load()
+    for b0 in range(0, B, 65535):
+        b1 = min(B, b0 + 65535)
+        check(lib.pfpp_nn_dist(_ptr(src[b0:b1]), _ptr(dst[b0:b1]), _ptr(out[b0:b1]), b1 - b0, n, dst.shape[1], _stream()),
+              "pfpp_nn_dist")
+    return out
+
+
+def quat_to_euler_xyz(quat: torch.Tensor, to_degree: bool = True) -> torch.Tensor:
+    """[..., 4] (w first) -> [..., 3] Euler angles, convention XYZ (transform.quaternion_to_euler)"""
+    _chk(quat, torch.float32, "quat")
+    if quat.shape[-1] != 4:
+        raise ValueError("quat_to_euler_xyz: last dimension must be 4")
+    out = torch.empty(quat.shape[:-1] + (3,), dtype=torch.float32, device=quat.device)
+    check(_lib.load().pfpp_quat_to_euler_xyz(_ptr(quat), _ptr(out), quat.numel() // 4, int(to_degree), _stream()),
+          "pfpp_quat_to_euler_xyz")
+    return out

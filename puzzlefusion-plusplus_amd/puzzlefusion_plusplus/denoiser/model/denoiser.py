@@ -5,7 +5,7 @@ _loss, training_step, validation_step, configure_optimizers; state_dict prefixes
 `encoder.`) and runs the hot path — rotate, encode, denoise, DDPM step — on the HIP kernels.
 In train mode DenoiserTransformer.forward is one autograd node backed by pfpp_hip.train (dropouts, backward
 kernels, gradients accumulated into the parameters' .grad) and configure_optimizers returns the fused AdamW.
-Evaluation metrics (evaluator.py) are a later row of the scope table.
+validation_step computes the reference's four metrics with denoiser/evaluation/evaluator.py (HIP nearest-neighbour kernel).
 """
 from __future__ import annotations
 
@@ -33,6 +33,7 @@ class Denoiser(LightningModule):
         self.num_points = m.num_point
         self.num_channels = m.num_dim
         self.noise_scheduler.set_timesteps(num_inference_steps=m.num_inference_steps)
+        self.rmse_r_list, self.rmse_t_list, self.acc_list, self.cd_list = [], [], [], []
 
     # ------------------------------------------------------------------ hot path
     def _extract_features(self, part_pcs, part_valids, noisy_trans_and_rots):
@@ -91,10 +92,35 @@ class Denoiser(LightningModule):
         return x
 
     def validation_step(self, data_dict, idx):
-        out = self(data_dict)
-        for name, value in self._loss(data_dict, out).items():
-            self.log(f"val_loss/{name}", value, on_step=False, on_epoch=True)
-        return self.sample(data_dict)
+        """validation loss, the 20-step sampler and the four evaluation metrics (denoiser.py:147-208)"""
+        from puzzlefusion_plusplus.denoiser.evaluation.evaluator import (ChamferDistance, calc_part_acc, calc_shape_cd,
+                                                                        rot_metrics, trans_metrics)
+
+        with torch.no_grad():
+            out = self(data_dict)
+            for name, value in self._loss(data_dict, out).items():
+                self.log(f"val_loss/{name}", value, on_step=False, on_epoch=True)
+            x = self.sample(data_dict)
+        gt_trans, gt_rots = data_dict["part_trans"].float(), data_dict["part_rots"].float()
+        pred_trans, pred_rots = x[..., :3].contiguous(), x[..., 3:].contiguous()
+        pts = data_dict["part_pcs"] * data_dict["part_scale"].unsqueeze(-1)          # denoiser.py:189-190
+        metric = getattr(self, "metric", None) or ChamferDistance()
+        valids = data_dict["part_valids"]
+        acc, _, _ = calc_part_acc(pts, pred_trans, gt_trans, pred_rots, gt_rots, valids, metric)
+        shape_cd = calc_shape_cd(pts, pred_trans, gt_trans, pred_rots, gt_rots, valids, metric)
+        self.acc_list.append(acc)
+        self.rmse_r_list.append(rot_metrics(pred_rots, gt_rots, valids, "rmse"))
+        self.rmse_t_list.append(trans_metrics(pred_trans, gt_trans, valids, "rmse"))
+        self.cd_list.append(shape_cd)
+        return x
+
+    def on_validation_epoch_end(self):
+        """denoiser.py:211-227"""
+        total = [torch.mean(torch.cat(v)) for v in (self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list)]
+        for name, value in zip(("eval/part_acc", "eval/rmse_t", "eval/rmse_r", "eval/shape_cd"), total):
+            self.log(name, value, sync_dist=True)
+        self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list = [], [], [], []
+        return tuple(total)
 
     def configure_optimizers(self):
         # same hyper-parameters as the reference (denoiser.py:230-237) on the fused kernel; the frozen encoder

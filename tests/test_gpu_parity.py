@@ -538,3 +538,65 @@ def test_full_size_properties(dev):
                             data["part_valids"][:16].contiguous(), data["part_scale"][:16].contiguous(),
                             data["ref_part"][:16].contiguous())
     assert (e_half - e1[:16]).abs().max() < 1e-5
+
+
+# ----------------------------------------------------------------------------- 8f-3 evaluation metrics
+def test_evaluation_metrics_vs_reference_golden(golden, dev):
+    """denoiser/evaluation/evaluator.py drop-in against the reference evaluator's outputs (tests/golden/metrics.npz)"""
+    from puzzlefusion_plusplus.denoiser.evaluation import evaluator as E
+    from puzzlefusion_plusplus.denoiser.evaluation.transform import quaternion_to_euler, transform_pc
+
+    g = golden("metrics")
+    a = {k: T(g[k]).to(dev) for k in ("pts", "valids", "trans_gt", "rot_gt", "trans_pred", "rot_pred")}
+    acc, acc_pp, cd_pp = E.calc_part_acc(a["pts"], a["trans_pred"], a["trans_gt"], a["rot_pred"], a["rot_gt"], a["valids"], E.ChamferDistance())
+    assert np.array_equal(acc_pp.cpu().numpy(), g["acc_per_part"])
+    assert np.abs(cd_pp.cpu().numpy() - g["cd_per_part"]).max() < 1e-6 and np.array_equal(acc.cpu().numpy(), g["part_acc"])
+    scd = E.calc_shape_cd(a["pts"], a["trans_pred"], a["trans_gt"], a["rot_pred"], a["rot_gt"], a["valids"])
+    assert np.abs(scd.cpu().numpy() - g["shape_cd"]).max() < 1e-6
+    assert np.abs(E.rot_metrics(a["rot_pred"], a["rot_gt"], a["valids"], "rmse").cpu().numpy() - g["rmse_r"]).max() < 1e-3
+    assert np.abs(E.trans_metrics(a["trans_pred"], a["trans_gt"], a["valids"], "rmse").cpu().numpy() - g["rmse_t"]).max() < 1e-6
+    assert np.abs(quaternion_to_euler(a["rot_pred"]).cpu().numpy() - g["euler_pred"]).max() < 1e-3
+    for m in ("mse", "mae"):
+        assert torch.isfinite(E.rot_metrics(a["rot_pred"], a["rot_gt"], a["valids"], m)).all()
+    # transform_pc == the oracle's quaternion_apply + t, bit for bit (same kernel as the a19 pose helpers)
+    from oracle import pfpp_oracle as O
+
+    want = O.transform_pc(T(g["trans_pred"]), T(g["rot_pred"]), T(g["pts"]))
+    assert torch.equal(transform_pc(a["trans_pred"], a["rot_pred"], a["pts"]).cpu(), want)
+
+
+def test_nn_dist_sizes_and_chamfer_modes(dev):
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+    from puzzlefusion_plusplus.denoiser.evaluation.evaluator import ChamferDistance
+
+    g = torch.Generator().manual_seed(12)
+    for B, n, m in ((3, 1, 1), (2, 257, 1025), (1, 20000, 3000), (4, 1000, 1000)):
+        s, d = torch.randn(B, n, 3, generator=g), torch.randn(B, m, 3, generator=g)
+        got = ops.nn_dist(s.to(dev), d.to(dev)).cpu()
+        assert torch.equal(got, O.nn_dist(s, d)), (B, n, m)
+    cd = ChamferDistance()
+    s, d = torch.randn(2, 300, 3, generator=g), torch.randn(2, 400, 3, generator=g)
+    for kw in (dict(), dict(bidirectional=True), dict(reverse=True), dict(point_reduction="mean", batch_reduction=None),
+               dict(bidirectional=True, point_reduction="mean", batch_reduction="sum")):
+        assert torch.allclose(cd(s.to(dev), d.to(dev), **kw).cpu(), O.chamfer_distance(s, d, **kw), rtol=1e-5, atol=1e-6), kw
+    with pytest.raises(ValueError):
+        cd(s.to(dev), d.to(dev), bidirectional=True, reverse=True)
+
+
+def test_denoiser_validation_step_metrics(weights_sd, dev):
+    """the LightningModule surface: validation_step fills the four metric lists, on_validation_epoch_end reduces them"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    m = Denoiser(config.denoiser_config())
+    m.encoder.load_state_dict(weights_sd("vqvae"))
+    m.denoiser.load_state_dict(weights_sd("denoiser"))
+    m = m.to(dev).eval()
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(3, 2, num_points=1000, num_parts=4).items()}
+    x = m.validation_step(data, 0)
+    assert x.shape == (2, 20, 7) and len(m.acc_list) == 1
+    acc, rt, rr, cd = m.on_validation_epoch_end()
+    assert 0.0 <= float(acc) <= 1.0 and float(rt) >= 0 and 0 <= float(rr) <= 180.0 and float(cd) >= 0
+    assert m.acc_list == []

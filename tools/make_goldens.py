@@ -159,6 +159,40 @@ def install_standins():
                 prev = prev + (var ** 0.5) * variance_noise
             return NS(prev_sample=prev, pred_original_sample=x0)
 
+    # ---- pytorch3d.transforms (git HEAD semantics restated): only what the evaluation
+    # metrics import (denoiser/evaluation/transform.py:1-2)
+    p3d = types.ModuleType("pytorch3d")
+    p3t = types.ModuleType("pytorch3d.transforms")
+
+    def _angle_from_tan(axis, other_axis, data, horizontal, tait_bryan):
+        i1, i2 = {"X": (2, 1), "Y": (0, 2), "Z": (1, 0)}[axis]
+        if horizontal:
+            i2, i1 = i1, i2
+        even = (axis + other_axis) in ["XY", "YZ", "ZX"]
+        if horizontal == even:
+            return torch.atan2(data[..., i1], data[..., i2])
+        if tait_bryan:
+            return torch.atan2(-data[..., i2], data[..., i1])
+        return torch.atan2(data[..., i2], -data[..., i1])
+
+    def matrix_to_euler_angles(matrix, convention):
+        i0, i2 = "XYZ".index(convention[0]), "XYZ".index(convention[2])
+        tait_bryan = i0 != i2
+        if tait_bryan:
+            central = torch.asin(matrix[..., i0, i2] * (-1.0 if i0 - i2 in [-1, 2] else 1.0))
+        else:
+            central = torch.acos(matrix[..., i0, i0])
+        o = (_angle_from_tan(convention[0], convention[1], matrix[..., i2], False, tait_bryan), central,
+             _angle_from_tan(convention[2], convention[1], matrix[..., i0, :], True, tait_bryan))
+        return torch.stack(o, -1)
+
+    from oracle import pfpp_oracle as _O
+    p3t.quaternion_apply = _O.quaternion_apply
+    p3t.quaternion_to_matrix = _O.quaternion_to_matrix
+    p3t.matrix_to_euler_angles = matrix_to_euler_angles
+    p3d.transforms = p3t
+    sys.modules.update({"pytorch3d": p3d, "pytorch3d.transforms": p3t})
+
     dm = types.ModuleType("diffusers")
     dm.DDPMScheduler = DDPMScheduler
     dmm = types.ModuleType("diffusers.models")
@@ -362,6 +396,35 @@ def main():
         grad_absmax=np.array([p_.grad.abs().max().item() for _, p_ in den_ref.named_parameters()]),
         grad_sample=np.stack([p_.grad.flatten()[:: max(1, p_.numel() // 16)][:16].numpy() if p_.numel() >= 16 else
                               np.pad(p_.grad.flatten().numpy(), (0, 16 - p_.numel())) for _, p_ in den_ref.named_parameters()]))
+
+    # ============================ 8f-3: evaluation metrics (the reference's evaluator.py on the stand-ins) ======
+    from puzzlefusion_plusplus.denoiser.evaluation import evaluator as ref_eval
+
+    class _CD:                                   # chamferdist.ChamferDistance call signature
+        def __call__(self, a, b, **kw):
+            return O.chamfer_distance(a, b, **kw)
+
+    Bm, Pm, Nm = 2, 20, 200
+    vm = torch.zeros(Bm, Pm); vm[0, :5] = 1; vm[1, :20] = 1
+    pts_m = (torch.rand(Bm, Pm, Nm, 3, generator=g) - 0.5) * vm[:, :, None, None]
+    t_gt = torch.randn(Bm, Pm, 3, generator=g) * 0.3
+    q_gt = torch.nn.functional.normalize(torch.randn(Bm, Pm, 4, generator=g), dim=-1)
+    t_pr = t_gt + torch.randn(Bm, Pm, 3, generator=g) * 0.05 * (torch.rand(Bm, Pm, 1, generator=g) < 0.5)
+    q_pr = torch.nn.functional.normalize(q_gt + torch.randn(Bm, Pm, 4, generator=g) * 0.05 * (torch.rand(Bm, Pm, 1, generator=g) < 0.5), dim=-1)
+    acc_r, accpp_r, cdpp_r = ref_eval.calc_part_acc(pts_m, t_pr, t_gt, q_pr, q_gt, vm, _CD())
+    scd_r = ref_eval.calc_shape_cd(pts_m, t_pr, t_gt, q_pr, q_gt, vm, _CD())
+    rr_r = ref_eval.rot_metrics(q_pr, q_gt, vm, "rmse")
+    rt_r = ref_eval.trans_metrics(t_pr, t_gt, vm, "rmse")
+    acc_o, accpp_o, cdpp_o = O.calc_part_acc(pts_m, t_pr, t_gt, q_pr, q_gt, vm)
+    assert torch.equal(accpp_o, accpp_r) and maxdiff(cdpp_o, cdpp_r) < 1e-7 and maxdiff(acc_o, acc_r) == 0
+    assert maxdiff(O.calc_shape_cd(pts_m, t_pr, t_gt, q_pr, q_gt, vm), scd_r) < 1e-6
+    assert maxdiff(O.rot_metrics(q_pr, q_gt, vm), rr_r) < 1e-4 and maxdiff(O.trans_metrics(t_pr, t_gt, vm), rt_r) < 1e-7
+    print(f"[metrics] oracle == reference evaluator.py (on stand-in pytorch3d/chamferdist): part_acc {acc_r.tolist()}, "
+          f"shape_cd {scd_r.tolist()}, rmse_r {rr_r.tolist()}, rmse_t {rt_r.tolist()}")
+    np.savez_compressed(GOLD / "metrics.npz", pts=pts_m.numpy(), valids=vm.numpy(), trans_gt=t_gt.numpy(), rot_gt=q_gt.numpy(),
+                        trans_pred=t_pr.numpy(), rot_pred=q_pr.numpy(), part_acc=acc_r.numpy(), acc_per_part=accpp_r.numpy(),
+                        cd_per_part=cdpp_r.numpy(), shape_cd=scd_r.numpy(), rmse_r=rr_r.numpy(), rmse_t=rt_r.numpy(),
+                        euler_pred=ref_eval.quaternion_to_euler(q_pr).numpy())
 
     # ============================ scheduler =====================================================
     sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
