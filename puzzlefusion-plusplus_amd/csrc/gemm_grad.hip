@@ -160,14 +160,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  OperandLoader<BM, NTHR, AKM> la;
-  OperandLoader<BN, NTHR, WKM> lw;
+  // Two register sets = prefetch distance of two K-tiles.  These GEMMs run at one or two workgroups per CU
+  // (few output tiles, see dispatch()), so nothing but the prefetch depth hides the ~2 us a k-major tile takes
+  // to arrive: with one tile in flight the loop measured 2.4 us per K-tile against 0.32 us of matrix work.
+  OperandLoader<BM, NTHR, AKM> la0, la1;
+  OperandLoader<BN, NTHR, WKM> lw0, lw1;
 
-  auto store_tiles = [&](int buf) {
-    _Float16* st = grad_smem + buf * STAGE;
-    la.store(st, st + PLANE_A, p.a_scale, tid);
-    lw.store(st + 2 * PLANE_A, st + 2 * PLANE_A + PLANE_W, p.w_scale, tid);
-  };
   auto compute = [&](int buf) {
     const _Float16* st = grad_smem + buf * STAGE;
     const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
@@ -195,24 +193,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
         }
     }
   };
+#define GRAD_LOAD(SET, KT)                                              \
+  do {                                                                  \
+    la##SET.load(A, p.lda, m0, p.M, kb + (KT) * BK, ke, tid);           \
+    lw##SET.load(W, p.ldw, n0, p.N, kb + (KT) * BK, ke, tid);           \
+  } while (0)
+#define GRAD_STORE(SET, BUF)                                                                  \
+  do {                                                                                        \
+    _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
+    la##SET.store(st_, st_ + PLANE_A, p.a_scale, tid);                                        \
+    lw##SET.store(st_ + 2 * PLANE_A, st_ + 2 * PLANE_A + PLANE_W, p.w_scale, tid);            \
+  } while (0)
 
   const int nk = (ke - kb + BK - 1) / BK;
-  if (nk > 0) {
-    la.load(A, p.lda, m0, p.M, kb, ke, tid);
-    lw.load(W, p.ldw, n0, p.N, kb, ke, tid);
-    store_tiles(0);
-  }
+  if (nk > 0) GRAD_LOAD(0, 0);
+  if (nk > 1) GRAD_LOAD(1, 1);
+  if (nk > 0) GRAD_STORE(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool has_next = kt + 1 < nk;
-    if (has_next) {
-      la.load(A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, tid);
-      lw.load(W, p.ldw, n0, p.N, kb + (kt + 1) * BK, ke, tid);
-    }
-    compute(kt & 1);
-    if (has_next) store_tiles((kt & 1) ^ 1);
+  // invariant at the top of iteration kt: LDS stage kt&1 holds tile kt, register set (kt+1)&1 holds tile kt+1
+  // (in flight), register set kt&1 is free
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) GRAD_LOAD(0, kt + 2);
+    compute(0);
+    if (kt + 1 < nk) GRAD_STORE(1, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) GRAD_LOAD(1, kt + 3);
+    compute(1);
+    if (kt + 2 < nk) GRAD_STORE(0, 0);
     __syncthreads();
   }
+#undef GRAD_LOAD
+#undef GRAD_STORE
 
   // ---- epilogue: plain store or atomic accumulate ------------------------------------------------
   const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
@@ -258,7 +270,8 @@ int dispatch(GradP p, int batch, int split_k, hipStream_t st) {
   // tile shape by how many workgroups the output gives: 256x128 when that still fills the chip
   const auto tiles = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
   int bm = 128, bn = 64;
-  if (tiles(256, 128) >= 384) { bm = 256; bn = 128; }
+  static const bool big_split = getenv("PFPP_GRAD_BIG") && atoi(getenv("PFPP_GRAD_BIG")) == 1;   // experiment knob
+  if (tiles(256, 128) >= 384 || (big_split && p.accumulate && split_k != 1 && p.M >= 256 && p.N >= 128)) { bm = 256; bn = 128; }
   else if (tiles(128, 128) >= 256 || p.N > 64) { bm = 128; bn = 128; }
   if (bm == 128 && bn == 128 && tiles(128, 128) < 192 && split_k == 1 && p.N <= 2048) { bn = 64; }
   int splits = split_k;
