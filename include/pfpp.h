@@ -326,6 +326,21 @@ int pfpp_edge_histogram(const float* pts, const int32_t* idx_a, const int32_t* i
                         const int32_t* edge_off, int32_t* hist, int64_t n_edges, int64_t max_m,
                         pfpp_stream_t stream);
 
+/* ---- 8f-2: merge step of auto_aggl (utils/node_merge_utils.py:159-222) -------------------------------------
+ * pfpp_estimate_normals: pytorch3d.ops.estimate_pointcloud_normals(neighborhood_size=K) per part:
+ * pts [P, N, 3] -> normals [P, N, 3] (K nearest neighbours incl. the point, covariance about the
+ * neighbourhood mean, eigenvector of the smallest eigenvalue, majority-side sign).  K in {10, 20, 32}.
+ * pfpp_merge_keep_mask: keep[i,k] = 0 iff for some j != i  d[i,j,k] + d[j,i,k] < threshold and
+ * normals[i,k].normals[j,k] < 0;  d [P,P,N] = nearest-neighbour distances part i -> part j (pfpp_nn_dist).
+ * pfpp_fps_start: pfpp_fps with an explicit first index per fragment (torch_cluster.fps random_start,
+ * node_merge_utils.py:219); N up to 32768.                                                              */
+int pfpp_estimate_normals(const float* pts, float* normals, int64_t P, int64_t N, int64_t K,
+                          pfpp_stream_t stream);
+int pfpp_merge_keep_mask(const float* d, const float* normals, uint8_t* keep, int64_t P, int64_t N,
+                         float threshold, pfpp_stream_t stream);
+int pfpp_fps_start(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N, int64_t S,
+                   const int32_t* start, pfpp_stream_t stream);
+
 /* ---- 8f-3: evaluation metrics (denoiser/evaluation/evaluator.py, transform.py) ---------------------------
  * pfpp_nn_dist: out[b, i] = min_j |src[b,i] - dst[b,j]|^2 — the KNN-1 term of chamferdist.ChamferDistance
  * (squared L2, knn_points); calc_part_acc (evaluator.py:88-121) and calc_shape_cd (:124-153) call it in

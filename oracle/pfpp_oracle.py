@@ -674,6 +674,65 @@ def calc_shape_cd(pts, trans1, trans2, rot1, rot2, valids):
     return valid_mean(cd.view(B, P, N).mean(-1), valids)
 
 
+# =============================================================================================
+# 8f-2 — merge step (utils/node_merge_utils.py:125-222, auto_aggl.py:224-286)
+# =============================================================================================
+def fps_start(xyz: torch.Tensor, npoint: int, start: int = 0) -> torch.Tensor:
+    """torch_cluster.fps on ONE cloud [N,3] with a given first index (random_start draws it at random):
+    squared-L2 running min, first argmax; returns local indices [npoint]"""
+    N = xyz.shape[0]
+    dist = torch.full((N,), float("inf"))
+    idx = torch.empty(npoint, dtype=torch.int64)
+    cur = int(start)
+    for s in range(npoint):
+        idx[s] = cur
+        d = xyz - xyz[cur]
+        dist = torch.minimum(dist, (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        cur = int(torch.argmax(dist))
+    return idx
+
+
+def estimate_normals(pts: torch.Tensor, k: int = 20) -> torch.Tensor:
+    """pytorch3d.ops.estimate_pointcloud_normals(neighborhood_size=k) restated (parity
+    unpinned): pts [P,N,3] -> [P,N,3].  knn incl. the point itself, covariance about the neighbourhood mean,
+    eigenvector of the smallest eigenvalue (fp64), flipped when fewer than half of the neighbours project positively."""
+    out = []
+    for p in pts:
+        d = p[:, None, :] - p[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        idx = torch.topk(d2, k, dim=1, largest=False)[1]
+        nn = p[idx].double()                                              # [N,k,3]
+        c = nn - nn.mean(1, keepdim=True)
+        cov = (c.unsqueeze(3) * c.unsqueeze(2)).mean(1)
+        v = torch.linalg.eigh(cov)[1][:, :, 0]
+        proj = (v[:, None, :] * (nn - p.double()[:, None, :])).sum(2)
+        flip = (proj > 0).sum(1) < 0.5 * k
+        out.append(torch.where(flip[:, None], -v, v).float())
+    return torch.stack(out)
+
+
+def remove_intersect_points_and_fps_ds(merge_pcs: torch.Tensor, num_points: int = 1000, threshold: float = 1e-3,
+                                       start: int = 0, normals: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """node_merge_utils.py:159-222 with the random first FPS index passed in"""
+    parts = merge_pcs.reshape(-1, num_points, 3)
+    P = parts.shape[0]
+    nrm = estimate_normals(parts, 20) if normals is None else normals
+    kept = []
+    for i in range(P):
+        keep = torch.ones(num_points, dtype=torch.bool)
+        for j in range(P):
+            if i == j:
+                continue
+            cd = chamfer_distance(parts[i][None], parts[j][None], bidirectional=True, point_reduction=None, batch_reduction=None)[0]
+            within = cd < threshold
+            dot = (nrm[i][within] * nrm[j][within]).sum(1)
+            keep[torch.where(within)[0][dot < 0]] = False
+        kept.append(parts[i][keep])
+    final = torch.cat(kept, 0)
+    m = int(math.ceil((num_points / final.shape[0]) * final.shape[0]))
+    return final[fps_start(final, min(m, final.shape[0]), start)][:num_points]
+
+
 def split_denoiser_ckpt(sd):
     enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
     den = {k[len("denoiser."):]: v for k, v in sd.items() if k.startswith("denoiser.")}

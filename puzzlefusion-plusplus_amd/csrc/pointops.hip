@@ -129,23 +129,27 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // (for the broadcast fetch of the newly selected centroid).  One barrier per
 // selected point when NWAVES > 1, none when the fragment fits one wave.
 // ---------------------------------------------------------------------------
-template <int NWAVES, int PPT>
+// LDSPTS = false (clouds beyond the LDS budget, the merged clouds of auto_aggl): the selected centroid is
+// fetched from global memory instead.  `start` (may be NULL = 0) is the first selected index per fragment
+// (torch_cluster.fps random_start, utils/node_merge_utils.py:219).
+template <int NWAVES, int PPT, bool LDSPTS = true>
 __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
     const float* __restrict__ xyz, int32_t* __restrict__ idx_out,
-    float* __restrict__ new_xyz, int N, int S) {
+    float* __restrict__ new_xyz, int N, int S, const int32_t* __restrict__ start = nullptr) {
   extern __shared__ __align__(16) float fps_smem[];
   constexpr int NT = NWAVES * 64;
-  float* s_pts = fps_smem;                                  // [3*N] (+pad)
-  float* s_slot_d = fps_smem + ((3 * N + 3) & ~3);          // [2][NWAVES]
-  int* s_slot_i = reinterpret_cast<int*>(s_slot_d + 2 * NWAVES);  // [2][NWAVES]
-
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const float* src = xyz + (size_t)f * N * 3;
-  for (int i = tid; i < 3 * N; i += NT) s_pts[i] = src[i];
-  __syncthreads();
+  const float* s_pts = LDSPTS ? fps_smem : src;             // [3*N] (+pad)
+  float* s_slot_d = fps_smem + (LDSPTS ? ((3 * N + 3) & ~3) : 0);          // [2][NWAVES]
+  int* s_slot_i = reinterpret_cast<int*>(s_slot_d + 2 * NWAVES);  // [2][NWAVES]
+  if (LDSPTS) {
+    for (int i = tid; i < 3 * N; i += NT) fps_smem[i] = src[i];
+    __syncthreads();
+  }
 
   float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
     pz[k] = ok ? s_pts[3 * i + 2] : 0.0f;
     dist[k] = ok ? __builtin_huge_valf() : -1.0f;   // pads can never win
   }
-  float cx = s_pts[0], cy = s_pts[1], cz = s_pts[2];
-  int sel = 0;
+  int sel = start ? min(max(start[f], 0), N - 1) : 0;
+  float cx = s_pts[3 * sel + 0], cy = s_pts[3 * sel + 1], cz = s_pts[3 * sel + 2];
   int32_t* o_idx = idx_out + (size_t)f * S;
   float* o_xyz = new_xyz + (size_t)f * S * 3;
 
@@ -396,12 +400,12 @@ __global__ __launch_bounds__(64) void pose_compose_kernel(
   o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
 }
 
-template <int NWAVES, int PPT>
+template <int NWAVES, int PPT, bool LDSPTS = true>
 int launch_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int N, int S,
-               hipStream_t st) {
-  const size_t smem = (size_t)(((3 * N + 3) & ~3) + 4 * NWAVES) * sizeof(float);
-  hipLaunchKernelGGL((fps_kernel<NWAVES, PPT>), dim3((unsigned)F), dim3(NWAVES * 64), smem, st,
-                     xyz, idx, new_xyz, N, S);
+               hipStream_t st, const int32_t* start = nullptr) {
+  const size_t smem = (size_t)((LDSPTS ? ((3 * N + 3) & ~3) : 0) + 4 * NWAVES) * sizeof(float);
+  hipLaunchKernelGGL((fps_kernel<NWAVES, PPT, LDSPTS>), dim3((unsigned)F), dim3(NWAVES * 64), smem, st,
+                     xyz, idx, new_xyz, N, S, start);
   return pfpp::check_launch("pfpp_fps");
 }
 
@@ -431,21 +435,34 @@ extern "C" int pfpp_pose_apply(const float* pts, const float* pose, const float*
   return pfpp::check_launch(__func__);
 }
 
-extern "C" int pfpp_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N,
-                        int64_t S, pfpp_stream_t stream) {
+static int fps_impl(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N, int64_t S,
+                    const int32_t* start, pfpp_stream_t stream) {
   PFPP_REQUIRE(xyz && idx && new_xyz, "null pointer");
   PFPP_REQUIRE(F >= 0 && N >= 1 && S >= 1 && S <= N, "need 1 <= S <= N");
-  PFPP_SUPPORTED(N <= 4096, "N > 4096");
+  PFPP_SUPPORTED(N <= 32768, "N > 32768");
   if (F == 0) return PFPP_OK;
   hipStream_t st = pfpp::as_stream(stream);
   const int n = (int)N, s = (int)S;
-  if (N <= 64) return launch_fps<1, 1>(xyz, idx, new_xyz, F, n, s, st);
-  if (N <= 128) return launch_fps<1, 2>(xyz, idx, new_xyz, F, n, s, st);
-  if (N <= 256) return launch_fps<1, 4>(xyz, idx, new_xyz, F, n, s, st);
-  if (N <= 512) return launch_fps<2, 4>(xyz, idx, new_xyz, F, n, s, st);
-  if (N <= 1024) return launch_fps<4, 4>(xyz, idx, new_xyz, F, n, s, st);
-  if (N <= 2048) return launch_fps<4, 8>(xyz, idx, new_xyz, F, n, s, st);
-  return launch_fps<4, 16>(xyz, idx, new_xyz, F, n, s, st);
+  if (N <= 64) return launch_fps<1, 1>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 128) return launch_fps<1, 2>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 256) return launch_fps<1, 4>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 512) return launch_fps<2, 4>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 1024) return launch_fps<4, 4>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 2048) return launch_fps<4, 8>(xyz, idx, new_xyz, F, n, s, st, start);
+  if (N <= 4096) return launch_fps<4, 16>(xyz, idx, new_xyz, F, n, s, st, start);
+  // merged clouds (up to 20 parts x 1000 points, node_merge_utils.py:212-220): points in registers only
+  if (N <= 16384) return launch_fps<16, 16, false>(xyz, idx, new_xyz, F, n, s, st, start);
+  return launch_fps<16, 32, false>(xyz, idx, new_xyz, F, n, s, st, start);
+}
+
+extern "C" int pfpp_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N,
+                        int64_t S, pfpp_stream_t stream) {
+  return fps_impl(xyz, idx, new_xyz, F, N, S, nullptr, stream);
+}
+
+extern "C" int pfpp_fps_start(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N,
+                              int64_t S, const int32_t* start, pfpp_stream_t stream) {
+  return fps_impl(xyz, idx, new_xyz, F, N, S, start, stream);
 }
 
 extern "C" int pfpp_ball_query(const float* xyz, const float* new_xyz, int32_t* idx, int64_t F,

@@ -80,6 +80,9 @@ SIGNATURES = {
     "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
     "pfpp_pose_apply_points": [_p, _p, _p, _p, _i64, C.c_int, _p],
     "pfpp_edge_histogram": [_p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_estimate_normals": [_p, _p, _i64, _i64, _i64, _p],
+    "pfpp_merge_keep_mask": [_p, _p, _p, _i64, _i64, _f32, _p],
+    "pfpp_fps_start": [_p, _p, _p, _i64, _i64, _i64, _p, _p],
     "pfpp_nn_dist": [_p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_quat_to_euler_xyz": [_p, _p, _i64, C.c_int, _p],
     # ---- training (a17)

@@ -75,8 +75,9 @@ def pose_apply(pts: torch.Tensor, pose: torch.Tensor, scale: Optional[torch.Tens
 
 
 # --------------------------------------------------------------------------- PointNet++
-def fps(xyz: torch.Tensor, npoint: int):
-    """xyz [F,N,3] -> (idx int32 [F,S], new_xyz [F,S,3])  (include/pfpp.h a2)"""
+def fps(xyz: torch.Tensor, npoint: int, start: Optional[torch.Tensor] = None):
+    """xyz [F,N,3] -> (idx int32 [F,S], new_xyz [F,S,3])  (include/pfpp.h a2); start: int32 [F] first index
+    (torch_cluster's random_start), default 0"""
     _chk(xyz, torch.float32, "xyz")
     F, N, three = xyz.shape
     if three != 3:
@@ -85,6 +86,12 @@ def fps(xyz: torch.Tensor, npoint: int):
         raise ValueError(f"fps: need 1 <= npoint <= N (npoint={npoint}, N={N})")
     idx = torch.empty((F, npoint), dtype=torch.int32, device=xyz.device)
     new_xyz = torch.empty((F, npoint, 3), dtype=torch.float32, device=xyz.device)
+    if start is not None:
+        _chk(start, torch.int32, "start")
+        if start.numel() != F:
+            raise ValueError("fps: start must have one index per fragment")
+        check(_lib.load().pfpp_fps_start(_ptr(xyz), _ptr(idx), _ptr(new_xyz), F, N, npoint, _ptr(start), _stream()), "pfpp_fps_start")
+        return idx, new_xyz
     check(_lib.load().pfpp_fps(_ptr(xyz), _ptr(idx), _ptr(new_xyz), F, N, npoint, _stream()), "pfpp_fps")
     return idx, new_xyz
 
@@ -599,3 +606,26 @@ def quat_to_euler_xyz(quat: torch.Tensor, to_degree: bool = True) -> torch.Tenso
     check(_lib.load().pfpp_quat_to_euler_xyz(_ptr(quat), _ptr(out), quat.numel() // 4, int(to_degree), _stream()),
           "pfpp_quat_to_euler_xyz")
     return out
+
+
+# --------------------------------------------------------------------------- merge step (8f-2)
+def estimate_normals(pts: torch.Tensor, k: int = 20) -> torch.Tensor:
+    """pts [P,N,3] -> unit normals [P,N,3] (pytorch3d.ops.estimate_pointcloud_normals, neighborhood_size=k)"""
+    _chk(pts, torch.float32, "pts")
+    if pts.dim() != 3 or pts.shape[2] != 3:
+        raise ValueError("estimate_normals: pts must be [P,N,3]")
+    P, N, _ = pts.shape
+    out = torch.empty_like(pts)
+    check(_lib.load().pfpp_estimate_normals(_ptr(pts), _ptr(out), P, N, k, _stream()), "pfpp_estimate_normals")
+    return out
+
+
+def merge_keep_mask(d: torch.Tensor, normals: torch.Tensor, threshold: float = 1e-3) -> torch.Tensor:
+    """d [P,P,N] nearest-neighbour distances part i -> part j, normals [P,N,3] -> keep bool [P,N]
+    (node_merge_utils.py:176-205)"""
+    _chk(d, torch.float32, "d"); _chk(normals, torch.float32, "normals")
+    P, _, N = d.shape
+    keep = torch.empty((P, N), dtype=torch.uint8, device=d.device)
+    check(_lib.load().pfpp_merge_keep_mask(_ptr(d), _ptr(normals), _ptr(keep), P, N, threshold, _stream()),
+          "pfpp_merge_keep_mask")
+    return keep.bool()

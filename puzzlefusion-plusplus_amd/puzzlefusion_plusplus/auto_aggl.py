@@ -10,9 +10,10 @@ What runs where (reference line numbers refer to auto_aggl.py):
     per-edge bidirectional nearest-neighbour histogram (pfpp_edge_histogram), normalisation.
   * verifier + threshold, :203-205 — pfpp_hip.verifier.
   * reference-part promotion, :208-222 and the early-exit tests — host logic on a handful of booleans.
-  * node merging, :224-286 — NOT implemented in this round (normal estimation + intersect removal +
-    random-start FPS): `merge_fn` may be supplied by the caller; without it the
-    fragments stay separate (poses of promoted fragments are still frozen as in the reference).
+  * node merging, :224-286 — `_merge_components`: connected components of the accepted non-reference edges,
+    merged cloud = posed clouds of the component minus their centroid, intersect filter + FPS back to 1000 points
+    (utils/node_merge_utils.py on the HIP kernels), renormalisation, pivot / init-pose bookkeeping.  `merge_fn`
+    may replace it.  Statistical parity only: the reference's FPS starts at a random index.
 Batch size 1, as in the reference (docs/test.md:8).
 """
 from __future__ import annotations
@@ -108,7 +109,11 @@ class AutoAgglomerative(LightningModule):
         edge_indices = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1).nonzero(as_tuple=False)[None]
         edge_valids = self._edge_mask(num_parts, P)
         max_iters = self.cfg.verifier.max_iters
-        traj, step_no, verifier_calls = [], 0, 0
+        traj, step_no, verifier_calls, n_merges = [], 0, 0, 0
+        merged_edges: List = []
+        if have_matching:
+            data_dict = dict(data_dict)
+            data_dict["part_pcs_by_area"] = data_dict["part_pcs_by_area"].clone()      # mutated by the merges (:259-262)
         for it in range(max_iters):
             for t in self.noise_scheduler.timesteps.tolist():
                 ts = torch.full((B,), t, dtype=torch.int64, device=dev)
@@ -116,7 +121,7 @@ class AutoAgglomerative(LightningModule):
                 eps = self.denoiser(x, ts, latent, xyz, part_valids, part_scale, ref_part)
                 x = self.noise_scheduler.step(eps, t, x, variance_noise=None if noises is None else noises[step_no],
                                               ref_part=ref_part, reference=reference).prev_sample
-                traj.append(ops.pose_compose(x[0].contiguous(), pivot))      # get_param (:151), stays on the GPU
+                traj.append(self._compose(x, pivot, nodes))                  # get_param (:151), stays on the GPU
                 step_no += 1
             if it + 1 == max_iters or not have_matching:
                 break
@@ -149,20 +154,87 @@ class AutoAgglomerative(LightningModule):
             reference = x.clone()
             if bool((classified == larger).all()):
                 break
-            merges = [(a, b) for a, b in classified_edges
-                      if a not in ref_idx and b not in ref_idx and a not in new_ref and b not in new_ref]
-            if merges and self.merge_fn is not None:
-                self.merge_fn(self, merges, nodes, dict(x=x, part_pcs=part_pcs, part_scale=part_scale,
-                                                        part_valids=part_valids, classified=classified))
+            from utils.node_merge_utils import node_merge_valids_check
+
+            merges = [(a, b) for a, b in classified_edges if node_merge_valids_check((a, b), ref_part, nodes)]
+            if merges:
+                state = dict(x=x, part_pcs=part_pcs, part_scale=part_scale, part_valids=part_valids, classified=classified,
+                             pivot=pivot, pts_by_area=data_dict["part_pcs_by_area"], pts_by_area_t=pts_t, match=match,
+                             n_pcs=data_dict["n_pcs"], merged_edges=merged_edges)
+                if self.merge_fn is not None:
+                    self.merge_fn(self, merges, nodes, state)
+                else:
+                    self._merge_components(merges, nodes, state)
+                n_merges += 1
             if bool((classified == larger).all()):
                 break
-        final = ops.pose_compose(x[0].contiguous(), pivot)
+        final = self._compose(x, pivot, nodes)
         valid_nodes = data_dict["part_valids"][0, :n_nodes].bool()
         return {
             "pred_trans": final[:, :3], "pred_rots": final[:, 3:], "x": x,
             "trajectory": torch.stack(traj, 0)[:, valid_nodes],          # [T_total, Pv, 7] like predict_*.npy (:322-337)
-            "ref_part": ref_part, "verifier_calls": verifier_calls, "steps": step_no,
+            "ref_part": ref_part, "verifier_calls": verifier_calls, "steps": step_no, "merges": n_merges,
+            "part_valids": part_valids, "nodes": nodes,
         }
+
+    @staticmethod
+    def _compose(x, pivot, nodes):
+        """get_param / extract_final_pred_trans_rots (node_merge_utils.py:246-306): pose of every original part =
+        [R|t](pose of its pivot) @ its accumulated init_pose"""
+        if all(n["init_pose"] is None for n in nodes):
+            return ops.pose_compose(x[0].contiguous(), pivot)
+        dev = x.device
+        init = torch.stack([(n["init_pose"] if n["init_pose"] is not None else torch.eye(4, device=dev)).reshape(16) for n in nodes])
+        has = torch.tensor([n["init_pose"] is not None for n in nodes], dtype=torch.uint8, device=dev)
+        return ops.pose_compose(x[0].contiguous(), pivot, init.contiguous(), has)
+
+    def _merge_components(self, merges, nodes, st) -> None:
+        """auto_aggl.py:224-286: merge every connected component of the accepted non-reference edges"""
+        from utils.node_merge_utils import assign_init_pose, get_final_pose_pts, merge_node, remove_intersect_points_and_fps_ds
+
+        x, part_pcs, part_scale, part_valids = st["x"], st["part_pcs"], st["part_scale"], st["part_valids"]
+        st["merged_edges"].extend(merges)
+        n = len(nodes)
+        parent = list(range(n))                      # union-find over ALL edges merged so far (G keeps its edges)
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        for a, b in st["merged_edges"]:
+            parent[find(a)] = find(b)
+        comps = {}
+        for i in range(n):
+            comps.setdefault(find(i), []).append(i)
+        pred_trans, pred_rots = x[0, :, :3], x[0, :, 3:]
+        transformed = get_final_pose_pts(part_pcs * part_scale.unsqueeze(-1), x[..., :3], x[..., 3:])[0]     # [P,N,3]
+        scale_h = part_scale[0, :, 0].cpu()
+        n_pcs = st["n_pcs"]
+        start = torch.cumsum(n_pcs[0].long(), 0) - n_pcs[0].long()
+        for comp in comps.values():
+            if sum(1 for c in comp if nodes[c]["valids"]) <= 1:
+                continue
+            pivot_new = max(comp, key=lambda c: float(scale_h[c]))
+            merge_pcs = merge_node(comp, nodes, transformed)
+            centroid = merge_pcs.mean(dim=0)
+            merge_pcs = merge_pcs - centroid
+            assign_init_pose(nodes, pred_trans, pred_rots, centroid, comp)
+            for c in comp:                                    # the by-area points now live in the merged part's frame
+                a, b = int(start[c]), int(start[c] + n_pcs[0, c])
+                st["pts_by_area"][0, a:b] = st["pts_by_area_t"][a:b] - centroid
+                nodes[c]["pivot"] = pivot_new
+                st["pivot"][c] = pivot_new
+            ds = remove_intersect_points_and_fps_ds(merge_pcs)
+            m_scale = ds.abs().max()
+            part_scale[0, pivot_new] = m_scale
+            part_pcs[0, pivot_new] = ds / m_scale
+            part_valids[0, comp] = 0
+            part_valids[0, pivot_new] = 1
+            for c in comp:
+                nodes[c]["valids"] = c == pivot_new
+            st["classified"][0, comp] = True
 
     def save_inference_data(self, out, path: str):
         np.save(path, out["trajectory"].cpu().numpy())

@@ -600,3 +600,101 @@ def test_denoiser_validation_step_metrics(weights_sd, dev):
     acc, rt, rr, cd = m.on_validation_epoch_end()
     assert 0.0 <= float(acc) <= 1.0 and float(rt) >= 0 and 0 <= float(rr) <= 180.0 and float(cd) >= 0
     assert m.acc_list == []
+
+
+# ----------------------------------------------------------------------------- 8f-2 merge step
+def test_merge_kernels_vs_reference_golden(golden, dev):
+    """normal estimation, intersect filter and random-start FPS against the reference's
+    remove_intersect_points_and_fps_ds (run on stand-ins, tests/golden/merge.npz) and the oracle"""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+    from utils.node_merge_utils import remove_intersect_points_and_fps_ds
+
+    g = golden("merge")
+    parts = T(g["parts"])
+    P, N, _ = parts.shape
+    nrm = ops.estimate_normals(parts.to(dev), 20).cpu()
+    assert ((nrm.norm(dim=-1) - 1).abs() < 1e-5).all()
+    dots = (nrm * T(g["normals"])).sum(-1)
+    assert (dots.abs() > 0.999).float().mean() > 0.995          # same line (ill-conditioned patches excepted)
+    assert (dots > 0.999).float().mean() > 0.99                 # same side (majority-vote ties excepted)
+    # filter with the GOLDEN normals: must reproduce the oracle's keep decisions exactly
+    src = parts.unsqueeze(1).expand(P, P, N, 3).reshape(P * P, N, 3).contiguous().to(dev)
+    dst = parts.unsqueeze(0).expand(P, P, N, 3).reshape(P * P, N, 3).contiguous().to(dev)
+    d = ops.nn_dist(src, dst).view(P, P, N)
+    keep = ops.merge_keep_mask(d.contiguous(), T(g["normals"]).to(dev)).cpu()
+    want_keep = torch.ones(P, N, dtype=torch.bool)
+    for i in range(P):
+        for j in range(P):
+            if i != j:
+                cd = O.chamfer_distance(parts[i][None], parts[j][None], bidirectional=True, point_reduction=None, batch_reduction=None)[0]
+                w = cd < 1e-3
+                want_keep[i, torch.where(w)[0][(T(g["normals"])[i][w] * T(g["normals"])[j][w]).sum(1) < 0]] = False
+    assert torch.equal(keep, want_keep) and (~keep).sum() > 50     # the shared surface is really removed
+    # whole function, same first FPS index as the reference drew
+    got = remove_intersect_points_and_fps_ds(parts.reshape(-1, 3).to(dev), start=torch.tensor([int(g["start"])], device=dev)).cpu()
+    own_keep = ops.merge_keep_mask(d.contiguous(), nrm.to(dev)).cpu()
+    if torch.equal(own_keep, want_keep):
+        assert torch.equal(got, T(g["merged"]))                   # identical filter -> bit-identical sample
+    else:                                                         # a normal flipped at a tie: sets agree up to a few points
+        assert (own_keep != want_keep).float().mean() < 2e-3
+        cd = O.chamfer_distance(got[None], T(g["merged"])[None], bidirectional=True, point_reduction="mean", batch_reduction=None)
+        assert float(cd) < 5e-3
+    # FPS with a start index and a cloud beyond the LDS budget == sequential restatement
+    big = torch.randn(1, 9000, 3, generator=torch.Generator().manual_seed(2))
+    idx, _ = ops.fps(big.to(dev), 300, start=torch.tensor([4321], dtype=torch.int32, device=dev))
+    assert torch.equal(idx[0].cpu().long(), O.fps_start(big[0], 300, 4321))
+
+
+def test_auto_aggl_merge_step(weights_sd, dev):
+    """a verifier that accepts exactly two edges between non-reference parts: those components merge
+    (auto_aggl.py:224-286) and the bookkeeping (pivots, validity, init poses, renormalised cloud) is consistent"""
+    import itertools
+
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+
+    cfg = config.auto_aggl_config()
+    cfg.denoiser.model.num_inference_steps = 2
+    cfg.verifier.max_iters = 3
+    cfg.verifier.threshold = 0.5
+    model = AutoAgglomerative(cfg)
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).eval()
+    batch = {k: v.to(dev) for k, v in synthetic.make_batch(56, 1, num_points=1000, num_parts=6).items()}
+    batch.update(synthetic.make_matching(batch, seed=4))
+    ref = int(torch.where(batch["ref_part"])[1][0])
+    others = [i for i in range(6) if i != ref]
+    accept = {(min(others[0], others[1]), max(others[0], others[1])), (min(others[1], others[2]), max(others[1], others[2]))}
+    pairs = list(itertools.combinations(range(20), 2))
+
+    class FakeVerifier(torch.nn.Module):
+        def forward(self, ef, ei, ev):
+            lo = torch.full((1, len(pairs), 1), -10.0, device=dev)
+            for k, pr in enumerate(pairs):
+                if pr in accept:
+                    lo[0, k, 0] = 10.0
+            return lo
+
+    model.verifier = FakeVerifier()
+    calls = []
+
+    def spy(self_, merges, nodes, st):
+        calls.append(list(merges))
+        AutoAgglomerative._merge_components(self_, merges, nodes, st)
+
+    model.merge_fn = spy
+    torch.manual_seed(1)
+    out = model.test_step(batch)
+    assert calls and sorted(calls[0]) == sorted(accept)
+    assert torch.isfinite(out["trajectory"]).all() and (out["pred_rots"].norm(dim=-1) - 1).abs().max() < 1e-4
+    nodes = out["nodes"]
+    pv = out["part_valids"][0, :6].bool().cpu()
+    assert int(pv.sum()) == 4                     # three parts became one
+    comp = others[:3]
+    piv = nodes[comp[0]]["pivot"]
+    assert piv in comp and all(nodes[c]["pivot"] == piv for c in comp)
+    for i, nd in enumerate(nodes):
+        assert nd["valids"] == bool(pv[i])
+        assert (nd["init_pose"] is not None) == (i in comp)
+    assert out["merges"] >= 1 and out["steps"] >= 4

@@ -17,6 +17,7 @@ reference outputs and refuses to write fixtures the oracle does not reproduce.
 from __future__ import annotations
 
 import sys
+import math
 import types
 from pathlib import Path
 from types import SimpleNamespace as NS
@@ -46,6 +47,12 @@ def install_standins():
     def fps(src, batch=None, ratio=None, random_start=True):
         """torch_cluster.fps semantics: per batch element, m = ceil(ratio*n), start 0,
         squared-L2 running min, first argmax; returns GLOBAL row indices."""
+        if batch is None:                       # single cloud (utils/node_merge_utils.py:219): random first index
+            n = src.shape[0]
+            m = int(math.ceil(ratio * n))
+            start = int(torch.randint(0, n, (1,)).item()) if random_start else 0
+            fps.last_start = start
+            return O.fps_start(src, m, start)
         assert not random_start
         counts = torch.bincount(batch)
         out, off = [], 0
@@ -191,7 +198,10 @@ def install_standins():
     p3t.quaternion_to_matrix = _O.quaternion_to_matrix
     p3t.matrix_to_euler_angles = matrix_to_euler_angles
     p3d.transforms = p3t
-    sys.modules.update({"pytorch3d": p3d, "pytorch3d.transforms": p3t})
+    p3o = types.ModuleType("pytorch3d.ops")
+    p3o.estimate_pointcloud_normals = lambda pts, neighborhood_size=50, **kw: _O.estimate_normals(pts, neighborhood_size)
+    p3d.ops = p3o
+    sys.modules.update({"pytorch3d": p3d, "pytorch3d.transforms": p3t, "pytorch3d.ops": p3o})
 
     dm = types.ModuleType("diffusers")
     dm.DDPMScheduler = DDPMScheduler
@@ -425,6 +435,27 @@ def main():
                         trans_pred=t_pr.numpy(), rot_pred=q_pr.numpy(), part_acc=acc_r.numpy(), acc_per_part=accpp_r.numpy(),
                         cd_per_part=cdpp_r.numpy(), shape_cd=scd_r.numpy(), rmse_r=rr_r.numpy(), rmse_t=rt_r.numpy(),
                         euler_pred=ref_eval.quaternion_to_euler(q_pr).numpy())
+
+    # ============================ 8f-2: merge step (the reference's node_merge_utils.py on the stand-ins) ========
+    import utils.node_merge_utils as ref_merge
+
+    def surf(n, c, r, gen):                         # points on a sphere cap-ish blob: two overlapping shells
+        v = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        return v * r + c
+    mparts = torch.stack([surf(1000, torch.tensor([0.0, 0.0, 0.0]), 0.5, g), surf(1000, torch.tensor([0.3, 0.0, 0.0]), 0.5, g),
+                          surf(1000, torch.tensor([0.0, 0.9, 0.0]), 0.4, g)])
+    mparts[1, :300] = mparts[0, :300] + torch.randn(300, 3, generator=g) * 0.003        # a shared (fracture) surface
+    merge_pcs = mparts.reshape(-1, 3)
+    torch.manual_seed(77)
+    ds_ref = ref_merge.remove_intersect_points_and_fps_ds(merge_pcs.clone(), _CD())
+    start_used = sys.modules["torch_cluster"].fps.last_start
+    ds_o = O.remove_intersect_points_and_fps_ds(merge_pcs, start=start_used)
+    assert torch.equal(ds_o, ds_ref), "oracle merge != reference merge (on stand-ins)"
+    nrm_o = O.estimate_normals(mparts, 20)
+    print(f"[merge] oracle == reference remove_intersect_points_and_fps_ds on stand-ins; first FPS index {start_used}, "
+          f"{ds_ref.shape[0]} points")
+    np.savez_compressed(GOLD / "merge.npz", parts=mparts.numpy(), start=np.int64(start_used), merged=ds_ref.numpy(),
+                        normals=nrm_o.numpy())
 
     # ============================ scheduler =====================================================
     sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
