@@ -326,6 +326,19 @@ int pfpp_edge_histogram(const float* pts, const int32_t* idx_a, const int32_t* i
                         const int32_t* edge_off, int32_t* hist, int64_t n_edges, int64_t max_m,
                         pfpp_stream_t stream);
 
+/* ---- 8f-4: GPU-side augmentation of GeometryLatentDataset.__getitem__ (denoiser/dataset/dataset.py:165-215) ---
+ * For a batch of stored puzzles part_pcs_gt [B,P,N,3] (assembled frame, padded): rotate the whole assembly by
+ * R(q_global)^T, recentre on the reference part, then per part recentre + rotate by R(q_part)^T and divide by
+ * the max-abs coordinate.  q_global [B,4] / q_part [B,P,4] are the quaternions the dataset stores (pose_gt_r /
+ * part_rots, scalar first).  Outputs: part_pcs [B,P,N,3], part_trans [B,P,3], part_scale [B,P], init_pose_t [B,3];
+ * padded slots (p >= num_parts[b]) get zeros and scale 1.  float64 means/rotations like the numpy original.
+ * workspace: pfpp_fragment_prepare_workspace(B, P) bytes.  N <= 2048.                                       */
+int64_t pfpp_fragment_prepare_workspace(int64_t B, int64_t P);
+int pfpp_fragment_prepare(const float* part_pcs_gt, const int32_t* num_parts, const int32_t* ref_idx,
+                          const float* q_global, const float* q_part, float* part_pcs, float* part_trans,
+                          float* part_scale, float* init_pose_t, int64_t B, int64_t P, int64_t N,
+                          void* workspace, pfpp_stream_t stream);
+
 /* ---- 8f-2: merge step of auto_aggl (utils/node_merge_utils.py:159-222) -------------------------------------
  * pfpp_estimate_normals: pytorch3d.ops.estimate_pointcloud_normals(neighborhood_size=K) per part:
  * pts [P, N, 3] -> normals [P, N, 3] (K nearest neighbours incl. the point, covariance about the

@@ -733,6 +733,33 @@ def remove_intersect_points_and_fps_ds(merge_pcs: torch.Tensor, num_points: int 
     return final[fps_start(final, min(m, final.shape[0]), start)][:num_points]
 
 
+# =============================================================================================
+# 8f-4 — the augmentation of GeometryLatentDataset.__getitem__ (denoiser/dataset/dataset.py:165-215), float64 numpy,
+# with the random rotations passed in as the STORED quaternions (pose_gt_r / part_rots)
+# =============================================================================================
+def fragment_prepare(part_pcs_gt, num_parts, ref_idx, q_global, q_part):
+    gt = np.asarray(part_pcs_gt, dtype=np.float64)
+    B, P, N, _ = gt.shape
+    pcs = np.zeros((B, P, N, 3), np.float32); trans = np.zeros((B, P, 3), np.float32)
+    scale = np.ones((B, P, 1), np.float32); init_t = np.zeros((B, 3), np.float32)
+    for b in range(B):
+        Rg = quaternion_to_matrix(torch.as_tensor(np.asarray(q_global[b], dtype=np.float64))).numpy().T     # applied rotation
+        pts = (Rg @ gt[b].reshape(-1, 3).T).T.reshape(P, N, 3)
+        c_ref = pts[int(ref_idx[b])].mean(0)
+        pts = pts - c_ref
+        init_t[b] = c_ref
+        for p in range(int(num_parts[b])):
+            t = pts[p].mean(0)
+            Rp = quaternion_to_matrix(torch.as_tensor(np.asarray(q_part[b, p], dtype=np.float64))).numpy().T
+            z = ((Rp @ (pts[p] - t).T).T).astype(np.float32)
+            s = np.abs(z).max()
+            s = np.float32(1.0) if s == 0 else s
+            pcs[b, p] = z / s
+            trans[b, p] = t
+            scale[b, p, 0] = s
+    return pcs, trans, scale, init_t
+
+
 def split_denoiser_ckpt(sd):
     enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
     den = {k[len("denoiser."):]: v for k, v in sd.items() if k.startswith("denoiser.")}

@@ -80,6 +80,7 @@ SIGNATURES = {
     "pfpp_pose_compose": [_p, _p, _p, _p, _p, _i64, _p],
     "pfpp_pose_apply_points": [_p, _p, _p, _p, _i64, C.c_int, _p],
     "pfpp_edge_histogram": [_p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_fragment_prepare": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p],
     "pfpp_estimate_normals": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_merge_keep_mask": [_p, _p, _p, _i64, _i64, _f32, _p],
     "pfpp_fps_start": [_p, _p, _p, _i64, _i64, _i64, _p, _p],
@@ -113,6 +114,7 @@ PLAIN = {
     "pfpp_last_error": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
+    "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}

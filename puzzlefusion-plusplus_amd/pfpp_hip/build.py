@@ -34,6 +34,7 @@ SOURCES = {
     "bn_train.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
     "merge.hip": ["-ffp-contract=off"],
+    "augment.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 

@@ -170,9 +170,14 @@ class AutoAgglomerative(LightningModule):
                 break
         final = self._compose(x, pivot, nodes)
         valid_nodes = data_dict["part_valids"][0, :n_nodes].bool()
+        metrics = self._evaluate(data_dict, final, n_nodes)
+        traj_t = torch.stack(traj, 0)
+        if getattr(self.cfg, "experiment_output_path", None) is not None and "data_id" in data_dict:
+            self._save_inference_data(data_dict, traj_t, metrics["part_acc"])
         return {
+            "metrics": metrics,
             "pred_trans": final[:, :3], "pred_rots": final[:, 3:], "x": x,
-            "trajectory": torch.stack(traj, 0)[:, valid_nodes],          # [T_total, Pv, 7] like predict_*.npy (:322-337)
+            "trajectory": traj_t[:, valid_nodes],                        # [T_total, Pv, 7] like predict_*.npy (:322-337)
             "ref_part": ref_part, "verifier_calls": verifier_calls, "steps": step_no, "merges": n_merges,
             "part_valids": part_valids, "nodes": nodes,
         }
@@ -235,6 +240,57 @@ class AutoAgglomerative(LightningModule):
             for c in comp:
                 nodes[c]["valids"] = c == pivot_new
             st["classified"][0, comp] = True
+
+    def _evaluate(self, data_dict, final, n_nodes):
+        """the four metrics of test_step (auto_aggl.py:288-318) on the composed final poses"""
+        from puzzlefusion_plusplus.denoiser.evaluation.evaluator import (ChamferDistance, calc_part_acc, calc_shape_cd,
+                                                                        rot_metrics, trans_metrics)
+
+        P = data_dict["part_valids"].shape[1]
+        dev = final.device
+        pred = torch.zeros(1, P, 7, device=dev)
+        pred[0, :n_nodes] = final
+        pred[0, n_nodes:, 3] = 1.0
+        pts = (data_dict["part_pcs"] * data_dict["part_scale"].unsqueeze(-1)).float()
+        valids = data_dict["part_valids"]
+        gt_t, gt_r = data_dict["part_trans"].float(), data_dict["part_rots"].float()
+        gt_r = torch.where(gt_r.abs().sum(-1, keepdim=True) == 0, torch.tensor([1.0, 0, 0, 0], device=dev), gt_r)
+        cd = ChamferDistance()
+        pt, pr = pred[..., :3].contiguous(), pred[..., 3:].contiguous()
+        acc, _, _ = calc_part_acc(pts, pt, gt_t, pr, gt_r, valids, cd)
+        out = {"part_acc": acc, "shape_cd": calc_shape_cd(pts, pt, gt_t, pr, gt_r, valids, cd),
+               "rmse_r": rot_metrics(pr, gt_r, valids, "rmse"), "rmse_t": trans_metrics(pt, gt_t, valids, "rmse")}
+        for name, lst in (("part_acc", "acc_list"), ("rmse_r", "rmse_r_list"), ("rmse_t", "rmse_t_list"), ("shape_cd", "cd_list")):
+            if not hasattr(self, lst):
+                setattr(self, lst, [])
+            getattr(self, lst).append(out[name])
+        return out
+
+    def on_test_epoch_end(self):
+        """auto_aggl.py:360-375"""
+        total = [torch.mean(torch.cat(v)) for v in (self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list)]
+        for name, value in zip(("eval/part_acc", "eval/rmse_t", "eval/rmse_r", "eval/shape_cd"), total):
+            self.log(name, value, sync_dist=True)
+        self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list = [], [], [], []
+        return tuple(total)
+
+    def _save_inference_data(self, data_dict, trajectory, acc):
+        """predict_<acc>.npy / gt.npy / init_pose.npy / mesh_file_path.txt per puzzle (auto_aggl.py:322-357)"""
+        import os
+
+        from pfpp_hip import io as pfio
+
+        mask = (data_dict["part_valids"][0] == 1)
+        n_nodes = trajectory.shape[1]
+        did = data_dict["data_id"][0]
+        save_dir = os.path.join(self.cfg.experiment_output_path, "inference", str(getattr(self.cfg, "inference_dir", "results")),
+                                str(did.item() if hasattr(did, "item") else did))
+        gt = torch.cat([data_dict["part_trans"][0], data_dict["part_rots"][0]], dim=-1)[mask]
+        init = torch.cat([torch.as_tensor(data_dict["init_pose_t"][0]).float().cpu(), torch.as_tensor(data_dict["init_pose_r"][0]).float().cpu()], -1) \
+            if "init_pose_t" in data_dict else torch.zeros(7)
+        mesh = data_dict["mesh_file_path"][0] if "mesh_file_path" in data_dict else ""
+        return pfio.save_inference_data(save_dir, trajectory=trajectory[:, mask[:n_nodes]].cpu().numpy(), gt=gt.cpu().numpy(),
+                                        init_pose=init.numpy(), mesh_file_path=mesh, acc=float(acc[0]))
 
     def save_inference_data(self, out, path: str):
         np.save(path, out["trajectory"].cpu().numpy())

@@ -180,3 +180,59 @@ def test_shard_helpers():
     assert sorted(sum(groups, [])) == list(range(8))
     loads = [sum([20, 2, 3, 19, 5, 7, 2, 18][i] for i in g) for g in groups]
     assert abs(loads[0] - loads[1]) <= 2
+
+
+def test_on_disk_formats_round_trip(tmp_path):
+    """synthetic puzzles written in the reference's pc_data / matching_data / verifier_data
+    layouts are read back by the dataset drop-ins with the reference's keys, shapes and invariants"""
+    import subprocess
+    import sys
+    from types import SimpleNamespace as NS
+
+    subprocess.run([sys.executable, str(ROOT / "tools" / "make_synthetic_dataset.py"), str(tmp_path), "--n", "4", "--points", "200"],
+                   check=True)
+    from puzzlefusion_plusplus.denoiser.dataset.dataset import GeometryLatentDataset, build_test_dataloader
+    from puzzlefusion_plusplus.verifier.dataset.dataset import VerifierDataset
+
+    cfg = NS(data=NS(max_num_part=20, matching_data_path=str(tmp_path / "matching_data"), data_val_dir=str(tmp_path / "pc_data" / "train"),
+                     overfit=-1, val_batch_size=1, num_workers=0), model=NS(multiple_ref_parts=True))
+    ds = GeometryLatentDataset(cfg, str(tmp_path / "pc_data" / "train"), -1, "train")
+    assert len(ds) == 3
+    np.random.seed(0)
+    s = ds[0]
+    pv = s["num_parts"]
+    for key, shape in (("part_pcs", (20, 200, 3)), ("part_rots", (20, 4)), ("part_trans", (20, 3)), ("part_scale", (20, 1)),
+                       ("part_valids", (20,)), ("ref_part", (20,)), ("graph", (20, 20)), ("part_pcs_gt", (20, 200, 3))):
+        assert tuple(np.asarray(s[key]).shape) == shape, key
+    assert np.abs(s["part_pcs"][:pv]).max(axis=(1, 2)).round(5).tolist() == [1.0] * pv     # max-abs normalised
+    assert np.abs(s["part_pcs"][pv:]).max() == 0 and (s["part_scale"][pv:] == 1).all()
+    assert np.abs(s["part_pcs"][:pv].mean(1)).max() < 1e-5                                  # recentred
+    # the stored pose takes the normalised fragment back to the (rotated, recentred) assembly
+    from scipy.spatial.transform import Rotation as R
+
+    q = s["part_rots"][0][[1, 2, 3, 0]]
+    back = R.from_quat(q).apply(s["part_pcs"][0] * s["part_scale"][0]) + s["part_trans"][0]
+    glob = R.from_quat(s["init_pose_r"][[1, 2, 3, 0]]).inv().apply(ds.data_list[0]["part_pcs_gt"][0]) - s["init_pose_t"]
+    assert np.abs(back - glob).max() < 1e-4
+    # test mode: matching data attached, by-area points in each part's own frame
+    t = GeometryLatentDataset(cfg, str(tmp_path / "pc_data" / "train"), -1, "test")
+    st = t[1]
+    assert st["part_pcs_by_area"].shape == (5000, 3) and len(st["correspondences"]) == st["edges"].shape[0]
+    assert st["edges"].shape[1] == 2 and (st["edges"][:, 0] > st["edges"][:, 1]).all()       # (idx2, idx1)
+    batch = next(iter(build_test_dataloader(cfg)))
+    assert batch["part_pcs"].shape == (1, 20, 200, 3) and batch["part_pcs_by_area"].shape == (1, 5000, 3)
+    # device_augment: geometry only
+    raw = GeometryLatentDataset(cfg, str(tmp_path / "pc_data" / "train"), -1, "train", device_augment=True)[0]
+    assert "part_pcs" not in raw and raw["part_pcs_gt"].shape == (20, 200, 3)
+    v = VerifierDataset(str(tmp_path / "verifier_data"), -1, "all")
+    e = v[0]
+    assert e["edge_features"].shape == (190, 7) and e["edge_indices"].shape == (190, 2) and e["edge_valids"].sum() == e["num_edges"]
+    n = e["num_edges"]
+    assert np.allclose(e["edge_features"][:n, :6].sum(1)[e["edge_features"][:n, 6] > 0], 1.0, atol=1e-5)
+    # inference outputs in the renderer's layout
+    from pfpp_hip import io as pfio
+
+    files = pfio.save_inference_data(str(tmp_path / "inference" / "7"), trajectory=np.zeros((6, pv, 7), np.float32),
+                                     gt=np.zeros((pv, 7), np.float32), init_pose=np.zeros(7, np.float32), mesh_file_path="a/b", acc=0.5)
+    assert [Path(f).name for f in files] == ["predict_0.5.npy", "gt.npy", "init_pose.npy", "mesh_file_path.txt"]
+    assert np.load(files[0]).shape == (6, pv, 7)

@@ -491,6 +491,10 @@ def test_auto_aggl_loop_runs_and_pins_references(weights_sd, dev):
     r0 = batch["ref_part"]
     assert torch.equal(out["x"][r0], gt[r0])                          # the initial reference fragment never moves
     assert (out["pred_rots"].norm(dim=-1) - 1).abs().max() < 1e-5     # composed poses are unit quaternions
+    m = out["metrics"]                                                # auto_aggl.py:288-318
+    assert 0 <= float(m["part_acc"]) <= 1 and float(m["shape_cd"]) >= 0 and 0 <= float(m["rmse_r"]) <= 180 and float(m["rmse_t"]) >= 0
+    acc, rt, rr, cd = model.on_test_epoch_end()
+    assert float(acc) == float(m["part_acc"]) and model.acc_list == []
 
 
 # ----------------------------------------------------------------------------- full BASELINE size: properties
@@ -698,3 +702,47 @@ def test_auto_aggl_merge_step(weights_sd, dev):
         assert nd["valids"] == bool(pv[i])
         assert (nd["init_pose"] is not None) == (i in comp)
     assert out["merges"] >= 1 and out["steps"] >= 4
+
+
+# ----------------------------------------------------------------------------- 8f-4 GPU-side augmentation
+def test_fragment_prepare_vs_numpy_restatement(dev, tmp_path):
+    """the batch augmentation kernel against the float64 numpy arithmetic of GeometryLatentDataset.__getitem__, fed from
+    files in the reference's pc_data layout through the dataset drop-in (device_augment mode)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from types import SimpleNamespace as NS
+
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import augment
+    from puzzlefusion_plusplus.denoiser.dataset.dataset import GeometryLatentDataset
+
+    root = Path(__file__).resolve().parents[1]
+    subprocess.run([sys.executable, str(root / "tools" / "make_synthetic_dataset.py"), str(tmp_path), "--n", "4", "--points", "1000"], check=True)
+    cfg = NS(data=NS(max_num_part=20), model=NS(multiple_ref_parts=False))
+    ds = GeometryLatentDataset(cfg, str(tmp_path / "pc_data" / "train"), -1, "train", device_augment=True)
+    samples = [ds[i] for i in range(len(ds))]
+    batch = {k: torch.as_tensor(np.stack([np.asarray(s[k]) for s in samples])) for k in ("part_pcs_gt", "part_valids", "ref_part", "num_parts")}
+    g = torch.Generator(device=dev).manual_seed(5)
+    out = augment.augment_batch(batch, dev, g)
+    B = len(samples)
+    ref_idx = batch["ref_part"].float().argmax(1)
+    pcs, trans, scale, init_t = O.fragment_prepare(batch["part_pcs_gt"].numpy(), batch["num_parts"].numpy(), ref_idx.numpy(),
+                                                   out["init_pose_r"].cpu().numpy(), out["part_rots"].cpu().numpy() +
+                                                   (out["part_rots"].cpu().numpy().sum(-1, keepdims=True) == 0) * np.array([1, 0, 0, 0]))
+    assert np.abs(out["part_pcs"].cpu().numpy() - pcs).max() < 2e-6
+    assert np.abs(out["part_trans"].cpu().numpy() - trans).max() < 1e-6 and np.abs(out["part_scale"].cpu().numpy() - scale).max() < 1e-6
+    assert np.abs(out["init_pose_t"].cpu().numpy() - init_t).max() < 1e-6
+    for b in range(B):
+        pv = int(batch["num_parts"][b])
+        assert np.allclose(np.abs(out["part_pcs"][b, :pv].cpu().numpy()).max(axis=(1, 2)), 1.0, atol=1e-6)
+        assert float(out["part_pcs"][b, pv:].abs().max()) == 0 and (out["part_rots"][b, pv:] == 0).all()
+        r = int(ref_idx[b])
+        assert float(out["part_trans"][b, r].abs().max()) < 1e-6            # the reference part sits at the origin
+    # the augmented batch feeds the model: pose -> back to the (rotated, recentred) assembly
+    back = O.get_final_pose_pts((out["part_pcs"] * out["part_scale"].unsqueeze(-1)).cpu(), out["part_trans"].cpu(), out["part_rots"].cpu() +
+                                (out["part_rots"].cpu().sum(-1, keepdim=True) == 0) * torch.tensor([1.0, 0, 0, 0]))
+    Rg = O.quaternion_to_matrix(out["init_pose_r"].cpu().double()).transpose(1, 2)
+    want = torch.einsum("bij,bpnj->bpni", Rg, batch["part_pcs_gt"].double()) - out["init_pose_t"].cpu().double()[:, None, None]
+    pv0 = int(batch["num_parts"][0])
+    assert (back[0, :pv0].double() - want[0, :pv0]).abs().max() < 1e-5

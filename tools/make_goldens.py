@@ -457,6 +457,42 @@ def main():
     np.savez_compressed(GOLD / "merge.npz", parts=mparts.numpy(), start=np.int64(start_used), merged=ds_ref.numpy(),
                         normals=nrm_o.numpy())
 
+    # ============================ 8f-4: dataset classes on the reference's on-disk formats ======================
+    import subprocess, tempfile
+    from puzzlefusion_plusplus.denoiser.dataset.dataset import GeometryLatentDataset as RefDS
+    from puzzlefusion_plusplus.verifier.dataset.dataset import VerifierDataset as RefVDS
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([sys.executable, str(ROOT / "tools" / "make_synthetic_dataset.py"), td, "--n", "4", "--points", "300"], check=True)
+        dcfg = NS(data=NS(max_num_part=20, matching_data_path=td + "/matching_data"), model=NS(multiple_ref_parts=False))
+        ref_ds = RefDS(dcfg, td + "/pc_data/train", -1, "test")
+        spec2 = importlib.util.spec_from_file_location("pfpp_ds", ROOT / "puzzlefusion-plusplus_amd/puzzlefusion_plusplus/denoiser/dataset/dataset.py")
+        # the drop-in imports pfpp_hip.*: make the product package importable for this one module only
+        sys.path.append(str(ROOT / "puzzlefusion-plusplus_amd"))
+        mine_mod = importlib.util.module_from_spec(spec2); spec2.loader.exec_module(mine_mod)
+        sys.path.remove(str(ROOT / "puzzlefusion-plusplus_amd"))
+        my_ds = mine_mod.GeometryLatentDataset(dcfg, td + "/pc_data/train", -1, "test")
+        worst = 0.0
+        for i in range(len(ref_ds)):
+            np.random.seed(100 + i); a = ref_ds[i]
+            np.random.seed(100 + i); b = my_ds[i]
+            assert set(a.keys()) == set(b.keys()), set(a.keys()) ^ set(b.keys())
+            for k in a:
+                if isinstance(a[k], np.ndarray) and a[k].dtype != object:
+                    worst = max(worst, float(np.abs(a[k].astype(np.float64) - np.asarray(b[k]).astype(np.float64)).max()))
+                elif k == "correspondences":
+                    assert all(np.array_equal(x, y) for x, y in zip(a[k], b[k]))
+                else:
+                    assert a[k] == b[k], k
+        spec3 = importlib.util.spec_from_file_location("pfpp_vds", ROOT / "puzzlefusion-plusplus_amd/puzzlefusion_plusplus/verifier/dataset/dataset.py")
+        vmod = importlib.util.module_from_spec(spec3); spec3.loader.exec_module(vmod)
+        rv, mv = RefVDS(td + "/verifier_data", -1, "train"), vmod.VerifierDataset(td + "/verifier_data", -1, "train")
+        for i in range(len(rv)):
+            for k, val in rv[i].items():
+                assert np.array_equal(np.asarray(val), np.asarray(mv[i][k])), k
+        print(f"[datasets] drop-in GeometryLatentDataset / VerifierDataset == the reference's on the same files and numpy seed "
+              f"({len(ref_ds)} puzzles, test mode): max abs diff {worst:.2e}")
+        assert worst < 1e-5
+
     # ============================ scheduler =====================================================
     sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
                                  beta_start=1e-4, beta_end=2e-2, clip_sample=False, timestep_spacing="leading")
