@@ -149,6 +149,37 @@ class TrainWorkload:
         self.i += 1
 
 
+def aggl_puzzles_per_s(dev, n_puzzles: int = 3, points: int = 1000):
+    """BASELINE configs[2]-shaped: the full auto-agglomerative loop (denoise -> edge features -> verify -> promote/merge,
+    auto_aggl.py:86-318) on single puzzles (batch 1 like the reference's test.py), 20 DDPM steps per outer iteration,
+    up to cfg.verifier.max_iters = 6 iterations, synthetic matching data; random-init weights"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+
+    torch.manual_seed(4321)
+    model = AutoAgglomerative(config.auto_aggl_config()).to(dev).eval()
+    with torch.no_grad():
+        model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+    puzzles = []
+    for i in range(n_puzzles + 1):
+        b = {k: v.to(dev) for k, v in synthetic.make_batch(500 + i, 1, num_points=points).items()}
+        b.update(synthetic.make_matching(b, seed=i))
+        puzzles.append(b)
+    model.test_step(puzzles[0])                     # warm-up
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    steps = frags = 0
+    for b in puzzles[1:]:
+        out = model.test_step(b)
+        steps += out["steps"]
+        frags += int(b["num_parts"][0]) * out["steps"]
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_puzzles / dt, 3), "unit": "puzzles/s", "puzzles": n_puzzles, "ddpm_steps": steps,
+            "ms_per_ddpm_step": round(dt / steps * 1e3, 3), "fragment_steps_per_s": round(frags / dt, 1),
+            "note": "batch 1, full loop incl. verifier, promotion, merges and metrics; latency-bound (one puzzle in flight)"}
+
+
 def cpu_baseline_train(budget_s: float = 20.0, max_steps: int = 3):
     """the CPU oracle on BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points): training iterations
     (add_noise, encode, forward, loss, autograd backward, AdamW) in the reference's op order"""
@@ -338,6 +369,8 @@ def main():
             extra[name] = {"value": round(swl.n_frag * args.steps / dt, 2), "unit": "fragment*steps/s",
                            "ms_per_step": round(dt / args.steps * 1e3, 3),
                            "padded_slots": "dropped" if compact else "evaluated like the reference"}
+        del swl
+        extra["auto_aggl_full_loop"] = aggl_puzzles_per_s(dev)
     if not train and rank == 0 and world == 1 and not args.compact and not args.no_roofline:
         # the same K steps with the padded fragment slots dropped (outputs of valid fragments unchanged)
         wl.model.denoiser.compact_padded = True

@@ -95,8 +95,29 @@ def dense_attention_unfused(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, 
     return out
 
 
+class CompactLayout:
+    """which slots are valid fragments and how their tokens group into per-puzzle sequences — everything the compact
+    forward needs that depends on part_valids only.  Building it reads back from the GPU (nonzero / max), so callers
+    that keep part_valids fixed over many steps (the sampler loop, HIP-graph capture) build it once."""
+
+    __slots__ = ("slot", "slot32", "Fv", "frag_b", "frag_p", "seq_len", "seq_off", "max_len")
+
+    def __init__(self, part_valids: torch.Tensor, L: int):
+        B, P = part_valids.shape[:2]
+        valid = part_valids.reshape(B * P).to(torch.bool)
+        self.slot = torch.nonzero(valid).flatten()
+        self.slot32 = self.slot.to(torch.int32).contiguous()
+        self.Fv = int(self.slot.numel())
+        self.frag_b = torch.div(self.slot, P, rounding_mode="floor").to(torch.int32).contiguous()
+        self.frag_p = (self.slot - self.frag_b.long() * P).to(torch.int32).contiguous()
+        counts = torch.bincount(self.frag_b.long(), minlength=B)
+        self.seq_len = (counts * L).to(torch.int32)
+        self.seq_off = (torch.cumsum(counts, 0) - counts).mul(L).to(torch.int32)
+        self.max_len = (int(counts.max().item()) if self.Fv else 0) * L
+
+
 def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, num_layers: int,
-                             num_heads: int) -> torch.Tensor:
+                             num_heads: int, layout: Optional[CompactLayout] = None) -> torch.Tensor:
     """DenoiserTransformer.forward restricted to the VALID fragments.
 
     In the reference every one of the P = 20 slots is a query (denoiser_transformer.py:173-185) but keys are
@@ -110,25 +131,19 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     n_slots = B * P
     dh = C // num_heads
     dev = latent.device
-    valid = part_valids.reshape(n_slots).to(torch.bool)
-    slot = torch.nonzero(valid).flatten()                    # ascending flat slot ids of the valid fragments
-    Fv = int(slot.numel())
+    lay = layout if layout is not None else CompactLayout(part_valids, L)
+    slot, Fv, frag_b, frag_p = lay.slot, lay.Fv, lay.frag_b, lay.frag_p
+    seq_len, seq_off, max_len = lay.seq_len, lay.seq_off, lay.max_len
     out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
     if Fv == 0:
         return out.view(B, P, 7)
-    frag_b = torch.div(slot, P, rounding_mode="floor").to(torch.int32)
-    frag_p = (slot - frag_b.long() * P).to(torch.int32)
-    counts = torch.bincount(frag_b.long(), minlength=B)
-    seq_len = (counts * L).to(torch.int32)
-    seq_off = (torch.cumsum(counts, 0) - counts).mul(L).to(torch.int32)
-    max_len = int(counts.max().item()) * L
     M = Fv * L
     sf, pf = ops.token_features(latent.reshape(n_slots, L, -1)[slot].contiguous(), xyz.reshape(n_slots, L, 3)[slot].contiguous(),
                                 scale.reshape(n_slots)[slot].contiguous(), x.reshape(n_slots, 7)[slot].contiguous())
     shape_emb = ops.linear(sf, pk["shape.w"], pk["shape.b"])
     x_emb = ops.linear(pf, pk["param.w"], pk["param.b"])
     ref_u8 = ref_part.reshape(n_slots)[slot].to(torch.uint8).contiguous()
-    h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p.contiguous(), L)
+    h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p, L)
     n_ada = 2 * num_layers
     se = ops.silu_embed(pk["ada.tables"], timesteps.to(torch.int64).contiguous())
     mods = torch.empty((n_ada, B, 2 * C), dtype=torch.float32, device=dev)
@@ -138,7 +153,6 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     inner = pk["0.ff.w2"].K
     norm = torch.empty_like(h)
     att = torch.empty_like(h)
-    frag_b = frag_b.contiguous()
     for i in range(num_layers):
         ops.layernorm_grouped(h, mods[2 * i], frag_b, L, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
@@ -161,7 +175,7 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
         v = ops.linear(v, pk[f"{name}.2.w"], pk[f"{name}.2.b"], act="silu")
         ops.gemm(v, pk[f"{name}.4.w"], M=Fv, N=width, K=v.shape[1], lda=v.shape[1], out=out_c, ldc=7,
                  bias=pk[f"{name}.4.b"], c_off=c0)
-    ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
+    ops.scatter_rows(out_c, lay.slot32, n_slots, out=out)
     return out.view(B, P, 7)
 
 

@@ -33,7 +33,7 @@ from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
 
 
 class AutoAgglomerative(LightningModule):
-    def __init__(self, cfg, merge_fn: Optional[Callable] = None):
+    def __init__(self, cfg, merge_fn: Optional[Callable] = None, use_graphs: Optional[bool] = None):
         super().__init__()
         self.cfg = cfg
         self.denoiser = DenoiserTransformer(cfg.denoiser)
@@ -48,6 +48,11 @@ class AutoAgglomerative(LightningModule):
         self.num_channels = m.num_dim
         self.noise_scheduler.set_timesteps(num_inference_steps=m.num_inference_steps)
         self.merge_fn = merge_fn
+        # One puzzle per call means ~120 small launches per DDPM step: the step is launch-bound.  Within an outer
+        # iteration part_pcs / part_valids / part_scale / ref_part are fixed, so "rotate + encode + denoise" is captured
+        # once into a HIP graph (static x / timestep buffers) and replayed for the remaining timesteps.
+        import os
+        self.use_graphs = (os.environ.get("PFPP_AGGL_GRAPHS", "0") == "1") if use_graphs is None else use_graphs   # opt-in: the B = 1 step is GPU-latency bound (1.9 ms eager = 1.9 ms replayed), capture per outer iteration costs more than the 1.4 ms/step of host time it saves
 
     # ------------------------------------------------------------------ helpers
     def _extract_features(self, part_pcs, part_valids, x):
@@ -114,11 +119,14 @@ class AutoAgglomerative(LightningModule):
         if have_matching:
             data_dict = dict(data_dict)
             data_dict["part_pcs_by_area"] = data_dict["part_pcs_by_area"].clone()      # mutated by the merges (:259-262)
+        from pfpp_hip.denoiser import CompactLayout
+
         for it in range(max_iters):
+            # everything that depends on part_valids only, once per outer iteration (no device->host reads in the steps)
+            layout = CompactLayout(part_valids, self.num_points)
+            step_fn = self._make_step(part_pcs, part_valids, part_scale, ref_part, layout, x)
             for t in self.noise_scheduler.timesteps.tolist():
-                ts = torch.full((B,), t, dtype=torch.int64, device=dev)
-                latent, xyz = self._extract_features(part_pcs, part_valids, x)
-                eps = self.denoiser(x, ts, latent, xyz, part_valids, part_scale, ref_part)
+                eps = step_fn(x, t)
                 x = self.noise_scheduler.step(eps, t, x, variance_noise=None if noises is None else noises[step_no],
                                               ref_part=ref_part, reference=reference).prev_sample
                 traj.append(self._compose(x, pivot, nodes))                  # get_param (:151), stays on the GPU
@@ -181,6 +189,39 @@ class AutoAgglomerative(LightningModule):
             "ref_part": ref_part, "verifier_calls": verifier_calls, "steps": step_no, "merges": n_merges,
             "part_valids": part_valids, "nodes": nodes,
         }
+
+    def _make_step(self, part_pcs, part_valids, part_scale, ref_part, layout, x_like):
+        """-> f(x, t) = predicted noise.  Eager: rotate + encode + denoise with the precomputed layout.  Graphs: the same
+        sequence captured once (after an eager warm-up step that also fills the pack caches) over static buffers."""
+        dev = x_like.device
+        B = x_like.shape[0]
+
+        def eager(x, ts):
+            latent, xyz = self.encoder.extract_features(part_pcs, part_valids, x, slot=layout.slot32)
+            return self.denoiser(x, ts, latent, xyz, part_valids, part_scale, ref_part, layout=layout)
+
+        if not self.use_graphs:
+            return lambda x, t: eager(x, torch.full((B,), t, dtype=torch.int64, device=dev))
+        state = {"graph": None, "calls": 0}
+        x_buf = torch.empty_like(x_like)
+        ts_buf = torch.zeros((B,), dtype=torch.int64, device=dev)
+
+        def step(x, t):
+            state["calls"] += 1
+            if state["calls"] == 1:                      # warm-up: lazy initialisations must not happen under capture
+                return eager(x, torch.full((B,), t, dtype=torch.int64, device=dev))
+            x_buf.copy_(x)
+            ts_buf.fill_(t)
+            if state["graph"] is None:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize(dev)
+                with torch.cuda.graph(g):
+                    state["eps"] = eager(x_buf, ts_buf)
+                state["graph"] = g
+            state["graph"].replay()
+            return state["eps"].clone()
+
+        return step
 
     @staticmethod
     def _compose(x, pivot, nodes):

@@ -81,7 +81,7 @@ class DenoiserTransformer(nn.Module):
             object.__setattr__(self, "_engine", DenoiserTrainEngine(self))
         return self._engine
 
-    def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part):
+    def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, layout=None):
         """x [B,P,7], timesteps i64 [B], latent [B,P,L,64], xyz [B,P,L,3], part_valids [B,P],
         scale [B,P,1], ref_part bool [B,P] -> predicted noise [B,P,7] (trans 3 | rot 4)"""
         if self.training and torch.is_grad_enabled():
@@ -93,6 +93,11 @@ class DenoiserTransformer(nn.Module):
             pred, _ = self.train_engine().forward(x, timesteps, latent, xyz, part_valids, scale, ref_part,
                                                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()), train=True)
             return pred
-        fwd = hip_denoiser.denoiser_forward_compact if self.compact_padded else hip_denoiser.denoiser_forward
-        return fwd(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale, ref_part,
-                   num_layers=self.num_layers, num_heads=self.num_heads)
+        if self.compact_padded or layout is not None:
+            # `layout` (pfpp_hip.denoiser.CompactLayout, built once while part_valids is unchanged) makes the call
+            # free of device->host reads: required inside HIP-graph capture
+            return hip_denoiser.denoiser_forward_compact(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale,
+                                                         ref_part, num_layers=self.num_layers, num_heads=self.num_heads,
+                                                         layout=layout)
+        return hip_denoiser.denoiser_forward(self.packed(), x.float(), timesteps, latent, xyz, part_valids, scale, ref_part,
+                                             num_layers=self.num_layers, num_heads=self.num_heads)

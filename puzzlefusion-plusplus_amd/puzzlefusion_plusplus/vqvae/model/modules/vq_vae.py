@@ -52,10 +52,11 @@ class VQVAE(nn.Module):
             return hip_encoder.encode_valid(self.packed_train(), part_pcs.contiguous(), self.cfg.ae.num_point)
         return hip_encoder.encode_valid(self.packed(), part_pcs.contiguous(), self.cfg.ae.num_point)
 
-    def extract_features(self, part_pcs, part_valids, pose):
+    def extract_features(self, part_pcs, part_valids, pose, slot=None):
         """fused Denoiser._extract_features (denoiser.py:66-77): rotate by the current noisy
         quaternions, encode the valid fragments, scatter into zero-padded [B,P,L,*] tensors"""
-        slot = torch.nonzero(part_valids.reshape(-1).bool()).flatten().to(torch.int32)
+        if slot is None:       # callers that keep part_valids fixed pass the precomputed list (no device->host read)
+            slot = torch.nonzero(part_valids.reshape(-1).bool()).flatten().to(torch.int32)
         if self.training:
             self._encoder_grad_guard()
             if slot.numel() > 2048:

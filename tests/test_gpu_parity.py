@@ -746,3 +746,27 @@ def test_fragment_prepare_vs_numpy_restatement(dev, tmp_path):
     want = torch.einsum("bij,bpnj->bpni", Rg, batch["part_pcs_gt"].double()) - out["init_pose_t"].cpu().double()[:, None, None]
     pv0 = int(batch["num_parts"][0])
     assert (back[0, :pv0].double() - want[0, :pv0]).abs().max() < 1e-5
+
+
+def test_auto_aggl_graph_replay_matches_eager(weights_sd, dev):
+    """HIP-graph capture of the per-step work (rotate + encode + denoise) replays to the same trajectory as eager launches"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+
+    cfg = config.auto_aggl_config()
+    cfg.denoiser.model.num_inference_steps = 4
+    cfg.verifier.max_iters = 2
+    outs = []
+    for graphs in (False, True):
+        model = AutoAgglomerative(cfg, use_graphs=graphs)
+        model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+        model.verifier.load_state_dict(weights_sd("verifier"))
+        model = model.to(dev).eval()
+        batch = {k: v.to(dev) for k, v in synthetic.make_batch(57, 1, num_points=1000, num_parts=5).items()}
+        batch.update(synthetic.make_matching(batch, seed=6))
+        g = torch.Generator(device=dev).manual_seed(11)
+        x0 = torch.randn(1, 20, 7, device=dev, generator=g)
+        noises = [torch.randn(1, 20, 7, device=dev, generator=g) for _ in range(8)]
+        outs.append(model.test_step(batch, x_init=x0, noises=noises))
+    assert outs[0]["steps"] == outs[1]["steps"]
+    assert torch.equal(outs[0]["trajectory"], outs[1]["trajectory"])
