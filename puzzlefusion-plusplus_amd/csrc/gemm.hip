@@ -248,7 +248,7 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   }
 }
 
-template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2>
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_kernel(const GemmP p) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
@@ -290,11 +290,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   // ---- staging registers and (clamped) source rows ---------------------------------------------
   constexpr int NWF = WPRE ? 1 : WF_IT;
   constexpr int NWH = WPRE ? WH_IT : 1;
-  float4 ra[A_IT];
-  float4 r_mul = make_float4(1.f, 1.f, 1.f, 1.f), r_add = make_float4(0.f, 0.f, 0.f, 0.f);   // fused BN+ReLU on A
+  // one set of staging registers per K-tile in flight (PF2: two sets = prefetch distance 2, for grids of one or two
+  // workgroups per CU where nothing else hides the load latency)
+  struct Stage {
+    float4 ra[A_IT];
+    float4 rwf[NWF];
+    uint4 rwh[NWH], rwl[NWH];
+    float4 r_mul, r_add;      // fused BN+ReLU on A
+  };
+  Stage s0, s1;              // s1 is dead (and eliminated) unless PF2
+  s0.r_mul = make_float4(1.f, 1.f, 1.f, 1.f);
+  s0.r_add = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PF2) { s1.r_mul = s0.r_mul; s1.r_add = s0.r_add; }
   const bool a_aff = p.a_mul != nullptr;
-  float4 rwf[NWF];
-  uint4 rwh[NWH], rwl[NWH];
   const int a_row = tid >> 3, a_c4 = tid & 7;
   const int h_row = tid >> 2, h_c8 = tid & 3;    // pre-split W: 4 lanes x 8 halfs cover a 32-half row slice
   const float* a_ptr[A_IT];
@@ -320,51 +328,51 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
       wf_ptr[it] = p.W + w_off + (int64_t)gn * p.ldw + a_c4 * 4;
     }
   }
-  auto load_full = [&](int k0) {
+  auto load_full = [&](Stage& s, int k0) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
+    for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
     if (a_aff) {
-      r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
-      r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
+      s.r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
+      s.r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
     }
     if constexpr (WPRE) {
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
-        rwh[it] = *reinterpret_cast<const uint4*>(wh_ptr[it] + k0);
-        rwl[it] = *reinterpret_cast<const uint4*>(wl_ptr[it] + k0);
+        s.rwh[it] = *reinterpret_cast<const uint4*>(wh_ptr[it] + k0);
+        s.rwl[it] = *reinterpret_cast<const uint4*>(wl_ptr[it] + k0);
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < WF_IT; ++it) rwf[it] = *reinterpret_cast<const float4*>(wf_ptr[it] + k0);
+      for (int it = 0; it < WF_IT; ++it) s.rwf[it] = *reinterpret_cast<const float4*>(wf_ptr[it] + k0);
     }
   };
-  auto load_tail = [&](int k0) {
+  auto load_tail = [&](Stage& s, int k0) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+    for (int it = 0; it < A_IT; ++it) s.ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
     if constexpr (WPRE) {
       // the planes are zero-padded to a multiple of 8 halfs per row (host packing): whole
       // 16-byte groups are either inside the padded row or skipped
       const bool ok = k0 + h_c8 * 8 < (int)p.ldw;
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
-        rwh[it] = ok ? *reinterpret_cast<const uint4*>(wh_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
-        rwl[it] = ok ? *reinterpret_cast<const uint4*>(wl_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
+        s.rwh[it] = ok ? *reinterpret_cast<const uint4*>(wh_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
+        s.rwl[it] = ok ? *reinterpret_cast<const uint4*>(wl_ptr[it] + k0) : make_uint4(0, 0, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < WF_IT; ++it) rwf[it] = load_k4(wf_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+      for (int it = 0; it < WF_IT; ++it) s.rwf[it] = load_k4(wf_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const Stage& s, int buf) {
     _Float16* st = gemm_smem_h + buf * STAGE;
     _Float16* ahi = st, *alo = st + PLANE_A, *whi = st + 2 * PLANE_A, *wlo = st + 2 * PLANE_A + PLANE_W;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
-      float4 v = ra[it];
+      float4 v = s.ra[it];
       if (a_aff) {      // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
-        v.x = fmaxf(v.x * r_mul.x + r_add.x, 0.0f); v.y = fmaxf(v.y * r_mul.y + r_add.y, 0.0f);
-        v.z = fmaxf(v.z * r_mul.z + r_add.z, 0.0f); v.w = fmaxf(v.w * r_mul.w + r_add.w, 0.0f);
+        v.x = fmaxf(v.x * s.r_mul.x + s.r_add.x, 0.0f); v.y = fmaxf(v.y * s.r_mul.y + s.r_add.y, 0.0f);
+        v.z = fmaxf(v.z * s.r_mul.z + s.r_add.z, 0.0f); v.w = fmaxf(v.w * s.r_mul.w + s.r_add.w, 0.0f);
       }
       split4(v, hi, lo);
       const int off = (a_row + (NTHR / 8) * it) * LDH + a_c4 * 4;
@@ -375,14 +383,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
         const int off = (h_row + (NTHR / 4) * it) * LDH + h_c8 * 8;
-        *reinterpret_cast<uint4*>(whi + off) = rwh[it];
-        *reinterpret_cast<uint4*>(wlo + off) = rwl[it];
+        *reinterpret_cast<uint4*>(whi + off) = s.rwh[it];
+        *reinterpret_cast<uint4*>(wlo + off) = s.rwl[it];
       }
     } else {
 #pragma unroll
       for (int it = 0; it < WF_IT; ++it) {
         half4 hi, lo;
-        split4(rwf[it], hi, lo);
+        split4(s.rwf[it], hi, lo);
         const int off = (a_row + (NTHR / 8) * it) * LDH + a_c4 * 4;
         *reinterpret_cast<half4*>(whi + off) = hi;
         *reinterpret_cast<half4*>(wlo + off) = lo;
@@ -425,22 +433,44 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 
   const int nk_full = p.K / BK;
   const int nk = (p.K + BK - 1) / BK;
-  if (nk_full > 0) load_full(0); else load_tail(0);
-  store_tiles(0);
-  __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk_full; ++kt) {        // steady state: one basic block
-    load_full((kt + 1) * BK);
-    compute(kt & 1);
-    store_tiles((kt & 1) ^ 1);
+  if constexpr (!PF2) {
+    if (nk_full > 0) load_full(s0, 0); else load_tail(s0, 0);
+    store_tiles(s0, 0);
     __syncthreads();
-  }
-  for (; kt < nk; ++kt) {
-    const bool has_next = kt + 1 < nk;
-    if (has_next) load_tail((kt + 1) * BK);
-    compute(kt & 1);                      // a ragged tile was zero-filled: the extra products are zeros
-    if (has_next) store_tiles((kt & 1) ^ 1);
+    int kt = 0;
+    for (; kt + 1 < nk_full; ++kt) {        // steady state: one basic block
+      load_full(s0, (kt + 1) * BK);
+      compute(kt & 1);
+      store_tiles(s0, (kt & 1) ^ 1);
+      __syncthreads();
+    }
+    for (; kt < nk; ++kt) {
+      const bool has_next = kt + 1 < nk;
+      if (has_next) load_tail(s0, (kt + 1) * BK);
+      compute(kt & 1);                      // a ragged tile was zero-filled: the extra products are zeros
+      if (has_next) store_tiles(s0, (kt & 1) ^ 1);
+      __syncthreads();
+    }
+  } else {
+    auto load_any = [&](Stage& s, int kt_) {
+      if (kt_ < nk_full) load_full(s, kt_ * BK); else load_tail(s, kt_ * BK);
+    };
+    // invariant at the top of iteration kt: LDS stage kt&1 holds tile kt, set (kt+1)&1 holds tile kt+1 (in flight)
+    load_any(s0, 0);
+    if (nk > 1) load_any(s1, 1);
+    store_tiles(s0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) load_any(s0, kt + 2);
+      compute(0);
+      if (kt + 1 < nk) store_tiles(s1, 1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_any(s1, kt + 3);
+      compute(1);
+      if (kt + 2 < nk) store_tiles(s0, 0);
+      __syncthreads();
+    }
   }
 
   epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
@@ -476,12 +506,12 @@ int launch_f32(const GemmP& p, int batch, hipStream_t st) {
   return launch(gemm_f32_mfma_kernel<MT, NT, WK>, smem, p, BM, BN, batch, st, &attr_set);
 }
 
-template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2>
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false>
 int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN);
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN);
 }
 
 }  // namespace
@@ -567,16 +597,20 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // operand delivery from L2 is ~11 B/clk/CU whatever the load structure (profiles/README.md), so the
     // matrix pipe's utilisation is set by bytes per MFMA ~ (BM+BN)/(BM*BN): 256x256 (8 waves of 128x64)
     // where the grid still fills the chip, 256x128 for narrower N
-    static const bool big_waves4 = getenv("PFPP_GEMM_BIG4") && atoi(getenv("PFPP_GEMM_BIG4")) == 1;   // 4 waves of 128x128: slower (174 vs 245 TFLOP/s), experiment only
     if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
-      return big_waves4 ? launch_f16x3<4, 4, true, 2, 2>(p, a->batch, st) : launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
+      return launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
     if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32) return launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
     // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
     // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave
     static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+    // grids of at most ~two workgroups per CU: prefetch two K-tiles ahead (the load latency is all there is to hide)
+    static const bool pf2 = getenv("PFPP_GEMM_PF2") && atoi(getenv("PFPP_GEMM_PF2")) == 1;   // opt-in: measured slower (B = 1 step 2.23 vs 1.92 ms)
+    const bool deep = pf2 && tiles128 < 2 * small_thresh;
     if (pre && wide && tiles128 < small_thresh && a->act != PFPP_ACT_GEGLU && a->pool == 0)
-      return launch_f16x3<2, 1, true>(p, a->batch, st);
+      return deep ? launch_f16x3<2, 1, true, 2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
+    if (pre && deep)
+      return wide ? launch_f16x3<2, 2, true, 2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true, 2, 2, true>(p, a->batch, st);
     if (pre) return wide ? launch_f16x3<2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
     return wide ? launch_f16x3<2, 2, false>(p, a->batch, st) : launch_f16x3<2, 1, false>(p, a->batch, st);
   }
