@@ -187,13 +187,13 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
         if a_presplit:
             return "gemm_f16x3_ring_kernel<4, true>"
         if presplit and wide and M >= 8192 and N >= 1024 and pool == 0:
-            return "gemm_f16x3_kernel<4, 2, true, 2, 4>"
+            return "gemm_f16x3_kernel<4, 2, true, 2, 4, false>"
         if presplit and wide and M >= 8192 and pool != 32:
-            return "gemm_f16x3_kernel<2, 2, true, 4, 2>"
+            return "gemm_f16x3_kernel<2, 2, true, 4, 2, false>"
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
         if presplit and wide and tiles128 < 1024 and act != "geglu" and pool == 0:
-            return "gemm_f16x3_kernel<2, 1, true, 2, 2>"
-        return f"gemm_f16x3_kernel<2, {2 if wide else 1}, {'true' if presplit else 'false'}, 2, 2>"
+            return "gemm_f16x3_kernel<2, 1, true, 2, 2, false>"
+        return f"gemm_f16x3_kernel<2, {2 if wide else 1}, {'true' if presplit else 'false'}, 2, 2, false>"
     return f"gemm_f32_mfma_kernel<2, {2 if wide else 1}, {'true' if w_kmajor else 'false'}>"
 
 
