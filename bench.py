@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--mode", choices=("train", "sample"), default="train")
     ap.add_argument("--latents-given", action="store_true",
                     help="train mode: skip the encoder (latents of the clean pose precomputed; not a reference mode)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="train mode: run the frozen encoder of each iteration in line instead of one iteration ahead on its own stream")
     ap.add_argument("--compact", action="store_true",
                     help="drop padded fragment slots in the transformer (valid-fragment outputs unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,7 +106,8 @@ class SamplerWorkload:
 class TrainWorkload:
     """device-resident state of the training loop for one batch of puzzles"""
 
-    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, latents_given: bool = False):
+    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, latents_given: bool = False,
+                 pipeline: bool = True):
         from pfpp_hip import config, synthetic
         from pfpp_hip.train import DenoiserTrainEngine
         from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
@@ -132,16 +135,29 @@ class TrainWorkload:
                 self.fixed = self.model._extract_features(self.data["part_pcs"], self.data["part_valids"], self.gt)
         self.i = 0
         self.last_loss = None
+        from pfpp_hip.train import FeaturePipeline
+
+        self.pipeline = FeaturePipeline(self.model, dev) if (pipeline and not latents_given) else None
+
+    def _draw(self):
+        noise = torch.randn(self.gt.shape, device=self.dev, generator=self.gen)
+        t = torch.randint(0, self.model.noise_scheduler.config.num_train_timesteps, (self.batch,), device=self.dev, generator=self.gen)
+        return noise, t
 
     def step(self):
         m, d = self.model, self.data
         sch = m.noise_scheduler
-        noise = torch.randn(self.gt.shape, device=self.dev, generator=self.gen)
-        t = torch.randint(0, sch.config.num_train_timesteps, (self.batch,), device=self.dev, generator=self.gen)
-        noisy = sch.add_noise(self.gt, noise, t)
-        noisy[self.ref] = self.gt[self.ref]
-        with torch.no_grad():
-            latent, xyz = self.fixed if self.latents_given else m._extract_features(d["part_pcs"], d["part_valids"], noisy)
+        if self.pipeline is not None:
+            # the frozen encoder of the NEXT iteration's (noise, t) draw runs on its own stream under this iteration's
+            # transformer work; every iteration still does one full encoder pass + one full transformer step
+            f = self.pipeline.next(d, self.gt, self.ref, self._draw)
+            noisy, t, latent, xyz, noise = f["noisy"], f["t"], f["latent"], f["xyz"], f["noise"]
+        else:
+            noise, t = self._draw()
+            noisy = sch.add_noise(self.gt, noise, t)
+            noisy[self.ref] = self.gt[self.ref]
+            with torch.no_grad():
+                latent, xyz = self.fixed if self.latents_given else m._extract_features(d["part_pcs"], d["part_valids"], noisy)
         self.engine.flat.zero_grad()
         self.last_loss = self.engine.loss_and_grads(noisy, t, latent, xyz, d["part_valids"], d["part_scale"], self.ref, noise,
                                                     seed=1000 + self.i, train=True)
@@ -285,7 +301,8 @@ def main():
 
     train = args.mode == "train"
     if train:
-        wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given)
+        wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given,
+                           pipeline=not args.no_pipeline)
     else:
         wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
     for _ in range(args.warmup):
@@ -401,6 +418,7 @@ def main():
                 "workload": ("DDPM training iteration, BASELINE configs[1]: add_noise + rotate + frozen PointNet++/VQ encode"
                              + (" (skipped: latents given)" if args.latents_given else " (in the loop)") +
                              " + DenoiserTransformer forward (dropouts on) + MSE + full backward + "
+                             + ("" if args.no_pipeline or args.latents_given else "[encoder of iteration i+1 issued on its own stream during iteration i] ")
                              + ("RCCL gradient all-reduce + " if world > 1 else "") + "AdamW") if train else
                             ("DDPM sampler step, encoder in the loop (rotate+PointNet++/VQ encode+DenoiserTransformer+"
                              "scheduler step), BASELINE configs[1] shape, inference forward"),

@@ -479,3 +479,42 @@ class DenoiserTrainEngine:
         loss, dpred = T.mse_loss(pred.reshape(n, 7), noise.reshape(n, 7).contiguous().float(), sel)
         self.backward(ctx, dpred)
         return loss
+
+
+class FeaturePipeline:
+    """Runs the frozen encoder of the NEXT training batch on its own HIP stream while the transformer forward / backward
+    / optimizer of the current batch occupy the main stream.
+
+    The encoder does not depend on the weights being trained (train_denoiser.py:33-35 freezes it), only on the batch
+    and its freshly drawn (noise, timestep) — so step i+1's `add_noise -> rotate -> encode` can be issued before step i's
+    transformer work.  The token-sized transformer GEMMs leave most of the 256 CUs idle; the encoder's big GEMMs fill
+    them.  Order of the encoder's own state (BatchNorm running statistics) is preserved: all encoder work is on one stream.
+    """
+
+    def __init__(self, denoiser_module, device):
+        self.model = denoiser_module                  # puzzlefusion_plusplus...Denoiser (encoder + noise_scheduler)
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = None
+
+    def _issue(self, data, gt, ref, noise, t):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)                 # inputs were produced on the main stream
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            noisy = self.model.noise_scheduler.add_noise(gt, noise, t)
+            noisy[ref] = gt[ref]
+            latent, xyz = self.model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return dict(noisy=noisy, latent=latent, xyz=xyz, noise=noise, t=t, event=ev)
+
+    def next(self, data, gt, ref, draw):
+        """-> features of the batch issued on the previous call (or now, the first time), and issues the following one.
+        `draw()` returns (noise, timesteps) for a batch."""
+        if self.pending is None:
+            self.pending = self._issue(data, gt, ref, *draw())
+        cur, self.pending = self.pending, self._issue(data, gt, ref, *draw())
+        main = torch.cuda.current_stream()
+        main.wait_event(cur["event"])
+        for k in ("noisy", "latent", "xyz"):
+            cur[k].record_stream(main)                # allocated on the encoder stream, consumed on the main stream
+        return cur
