@@ -163,6 +163,12 @@ typedef struct pfpp_gemm_args {
   const float* a_mul; const float* a_add;
   double* stats; int32_t stats_copies;
   float* c_min;
+  /* optional split-K workspace (skinny GEMMs: few output tiles, long K — the B = 1 sampler step): when lent, the
+   * library may cut K over several workgroups per tile; partials are parked in split_ws (>= split_ws_bytes), the
+   * last workgroup of a tile (tickets in split_cnt, split_cnt_len ints, all zero between launches) adds them in chunk
+   * order and runs the epilogue — results are deterministic.  Must not be shared by launches that may overlap.  */
+  float* split_ws; int64_t split_ws_bytes;
+  int32_t* split_cnt; int64_t split_cnt_len;
 } pfpp_gemm_args;
 
 int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);

@@ -431,29 +431,33 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   };
 
-  const int nk_full = p.K / BK;
-  const int nk = (p.K + BK - 1) / BK;
+  // K range of this workgroup (the whole K unless split_k > 1; chunks are multiples of BK, so only the last chunk can
+  // have a ragged tile)
+  const int kb = p.split_k > 1 ? blockIdx.y * p.k_chunk : 0;
+  const int ke = p.split_k > 1 ? min(p.K, kb + p.k_chunk) : p.K;
+  const int nk_full = (ke - kb) / BK;
+  const int nk = (ke - kb + BK - 1) / BK;
   if constexpr (!PF2) {
-    if (nk_full > 0) load_full(s0, 0); else load_tail(s0, 0);
+    if (nk_full > 0) load_full(s0, kb); else load_tail(s0, kb);
     store_tiles(s0, 0);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk_full; ++kt) {        // steady state: one basic block
-      load_full(s0, (kt + 1) * BK);
+      load_full(s0, kb + (kt + 1) * BK);
       compute(kt & 1);
       store_tiles(s0, (kt & 1) ^ 1);
       __syncthreads();
     }
     for (; kt < nk; ++kt) {
       const bool has_next = kt + 1 < nk;
-      if (has_next) load_tail(s0, (kt + 1) * BK);
+      if (has_next) load_tail(s0, kb + (kt + 1) * BK);
       compute(kt & 1);                      // a ragged tile was zero-filled: the extra products are zeros
       if (has_next) store_tiles(s0, (kt & 1) ^ 1);
       __syncthreads();
     }
   } else {
     auto load_any = [&](Stage& s, int kt_) {
-      if (kt_ < nk_full) load_full(s, kt_ * BK); else load_tail(s, kt_ * BK);
+      if (kt_ < nk_full) load_full(s, kb + kt_ * BK); else load_tail(s, kb + kt_ * BK);
     };
     // invariant at the top of iteration kt: LDS stage kt&1 holds tile kt, set (kt+1)&1 holds tile kt+1 (in flight)
     load_any(s0, 0);
@@ -473,6 +477,43 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   }
 
+  if (p.split_k > 1) {
+    // park the partial tile (thread-contiguous layout: coalesced), take a ticket; the last arrival sums all chunks
+    constexpr int ELEMS = MT * NT * 16;
+    const int tile_lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const size_t n_tiles = (size_t)gridDim.x * gridDim.z;
+    float* mine = p.split_ws + ((size_t)blockIdx.y * n_tiles + tile_lin) * ELEMS * NTHR + tid;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[(size_t)((i * NT + j) * 16 + e) * NTHR] = accM[i][j][e];
+    __threadfence();
+    __syncthreads();
+    int* s_ticket = reinterpret_cast<int*>(gemm_smem_h);     // the tile buffers are free now (no static LDS: the 256x256
+                                                             // tile already uses all 160 KB)
+    if (tid == 0) *s_ticket = atomicAdd(p.split_cnt + tile_lin, 1);
+    __syncthreads();
+    if (*s_ticket != p.split_k - 1) return;
+    __threadfence();
+    if (tid == 0) p.split_cnt[tile_lin] = 0;          // ready for the next launch
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accM[i][j][e] = 0.0f;
+    for (int sidx = 0; sidx < p.split_k; ++sidx) {
+      const float* part = p.split_ws + ((size_t)sidx * n_tiles + tile_lin) * ELEMS * NTHR + tid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) accM[i][j][e] += part[(size_t)((i * NT + j) * 16 + e) * NTHR];
+    }
+  }
   epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
 }
 
@@ -482,8 +523,13 @@ int gemm_group_m() {
 }
 
 // =================================================================================================
+// capacity of the caller's split-K workspace for the launch being dispatched (set by pfpp_gemm)
+thread_local int64_t p_split_ws_bytes = 0;
+thread_local int64_t p_split_cnt_len = 0;
+
 template <typename K>
-int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set, int nthr = 256) {
+int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set, int nthr = 256,
+           bool can_split = false) {
   if (!*attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *attr_set = true;
@@ -493,7 +539,26 @@ int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t 
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.group_m = p.tiles_n > 1 ? env_group : 0;
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
+  // skinny launches (fewer tiles than CUs, K >= 1024): split K over blockIdx.y when the caller lent a workspace.  Measured on
+  // M = 125: 50.6 -> 25.4 us at K = 2048; at K = 512 the fix-up costs more than the four K-tiles it saves, hence the bound.
+  p.split_k = 1;
+  p.k_chunk = 0;
+  static const bool split_on = !(getenv("PFPP_GEMM_SPLITK") && atoi(getenv("PFPP_GEMM_SPLITK")) == 0);
+  const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
+  if (can_split && split_on && p.split_ws && p.split_cnt && tiles < 192 && p.K >= 1024 && p.pool == 0 && !p.stats) {
+    int want = (int)((384 + tiles - 1) / tiles);
+    const int max_by_k = p.K / 128;                          // at least 4 K-tiles per chunk
+    int splits = want < max_by_k ? want : max_by_k;
+    if (splits > 16) splits = 16;
+    const int64_t need = (int64_t)splits * tiles * BM * BN * (int64_t)sizeof(float);
+    if (splits > 1 && need <= p_split_ws_bytes && tiles <= p_split_cnt_len) {
+      int chunk = (p.K + splits - 1) / splits;
+      chunk = (chunk + 31) / 32 * 32;
+      p.split_k = (p.K + chunk - 1) / chunk;
+      p.k_chunk = chunk;
+    }
+  }
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.split_k, (unsigned)batch);
   hipLaunchKernelGGL(kern, grid, dim3(nthr), smem + env_pad, st, p);
   return pfpp::check_launch("pfpp_gemm");
 }
@@ -511,7 +576,7 @@ int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN);
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
 }
 
 }  // namespace
@@ -578,6 +643,9 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.sV0 = a->sV0; p.sV1 = a->sV1;
   p.alpha = a->alpha;
   p.a_mul = a->a_mul; p.a_add = a->a_add; p.stats = a->stats; p.stats_copies = a->stats_copies; p.Cmin = a->c_min;
+  p.split_ws = a->split_ws; p.split_cnt = a->split_cnt; p.split_k = 1; p.k_chunk = 0;
+  p_split_ws_bytes = a->split_ws ? a->split_ws_bytes : 0;
+  p_split_cnt_len = a->split_cnt ? a->split_cnt_len : 0;
   p.tiles_n = 0;
   hipStream_t st = pfpp::as_stream(stream);
 

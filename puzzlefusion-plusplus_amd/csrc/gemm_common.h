@@ -27,6 +27,10 @@ struct GemmP {
   const float* a_mul; const float* a_add;
   double* stats; int stats_copies;
   float* Cmin;
+  // split-K with a fix-up (skinny GEMMs: a handful of output tiles and a long K): blockIdx.y walks K chunks of
+  // k_chunk; every workgroup parks its accumulators in split_ws, the last one to arrive at a tile (ticket from
+  // split_cnt) adds the parked partials in chunk order (deterministic) and runs the normal epilogue
+  float* split_ws; int* split_cnt; int split_k; int k_chunk;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {

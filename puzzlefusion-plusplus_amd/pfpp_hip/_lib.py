@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("sV0", _i64), ("sV1", _i64),
         ("alpha", _f32),
         ("a_mul", _p), ("a_add", _p), ("stats", _p), ("stats_copies", _i32), ("c_min", _p),
+        ("split_ws", _p), ("split_ws_bytes", _i64), ("split_cnt", _p), ("split_cnt_len", _i64),
     ]
 
 

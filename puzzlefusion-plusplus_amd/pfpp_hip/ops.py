@@ -178,6 +178,21 @@ def split_mode() -> bool:
 GEMM_TRACE = None
 
 
+_SPLIT_WS = {}
+
+
+def _split_workspace(device):
+    """split-K workspace lent to pfpp_gemm: one (fp32 partials, int32 tickets) pair per (device, stream) — launches on one
+    stream are ordered, launches on different streams must not share it"""
+    key = (device.index, _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLIT_WS.get(key)
+    if ws is None:
+        ws = (torch.empty((16 * 1024 * 1024,), dtype=torch.float32, device=device),        # 64 MB
+              torch.zeros((1024,), dtype=torch.int32, device=device))
+        _SPLIT_WS[key] = ws
+    return ws
+
+
 def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: bool, f16x3: bool = False,
                      presplit: bool = False, a_presplit: bool = False) -> str:
     """the template instantiation pfpp_gemm dispatches to (mirror of the choice in csrc/gemm.hip with the
@@ -298,6 +313,10 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     if c_min is not None:
         _chk(c_min, torch.float32, "c_min")
         args.c_min = c_min.data_ptr()
+    ws = _split_workspace(dev_)
+    if ws is not None:
+        args.split_ws, args.split_ws_bytes = ws[0].data_ptr(), ws[0].numel() * 4
+        args.split_cnt, args.split_cnt_len = ws[1].data_ptr(), ws[1].numel()
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -770,3 +770,24 @@ def test_auto_aggl_graph_replay_matches_eager(weights_sd, dev):
         outs.append(model.test_step(batch, x_init=x0, noises=noises))
     assert outs[0]["steps"] == outs[1]["steps"]
     assert torch.equal(outs[0]["trajectory"], outs[1]["trajectory"])
+
+
+def test_gemm_split_k_fixup_is_deterministic_and_exact(dev):
+    """skinny GEMM (125 rows, K = 2048): the split-K path with the ticketed fix-up gives the single-pass result up to
+    the fp32 summation order, identical on every run, with bias + residual + activation applied exactly once"""
+    import os
+
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 125, 512, 2048
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    want = torch.nn.functional.silu(A.double() @ W.double().t() + b.double()) + R.double()
+    pw = PW(W.to(dev))
+    outs = [ops.linear(A.to(dev), pw, b.to(dev), act="silu", residual=R.to(dev)).cpu() for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert (outs[0].double() - want).abs().max() < 2e-5
