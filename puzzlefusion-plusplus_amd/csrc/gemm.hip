@@ -38,6 +38,13 @@ using namespace pfpp_gemm_detail;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (tools/diag/gemm_ablate.py): remove one ingredient of the K loop to see what bounds it.
+//   1 = no global loads after the first tile   2 = no MFMAs   3 = no fragment reads from LDS   4 = no LDS stores / splits
+//   5 = 1 + 4 (fragment reads + MFMAs + barrier only)   6 = 5 without the barrier
+#ifndef PFPP_ABLATE
+#define PFPP_ABLATE 0
+#endif
+
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // fp32 path: 36 floats = 144 B rows
 constexpr int LDH = BK + 8;      // split path: 40 halfs = 80 B rows (5 x 16 B: conflict-free b128 reads)
@@ -329,6 +336,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   }
   auto load_full = [&](Stage& s, int k0) {
+#if PFPP_ABLATE == 1 || PFPP_ABLATE == 5 || PFPP_ABLATE == 6
+    if (k0 != 0) return;
+#endif
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
     if (a_aff) {
@@ -364,6 +374,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   };
   auto store_tiles = [&](const Stage& s, int buf) {
+#if PFPP_ABLATE == 4 || PFPP_ABLATE == 5 || PFPP_ABLATE == 6
+    if (buf >= 0) return;
+#endif
     _Float16* st = gemm_smem_h + buf * STAGE;
     _Float16* ahi = st, *alo = st + PLANE_A, *whi = st + 2 * PLANE_A, *wlo = st + 2 * PLANE_A + PLANE_W;
 #pragma unroll
@@ -401,13 +414,54 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     const _Float16* st = gemm_smem_h + buf * STAGE;
     const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
     const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
+#ifndef PFPP_HOIST
+#define PFPP_HOIST 0     // experiment (tools/diag/gemm_ablate.py): isolated GEMMs +0..10 % at 3850 rows, -4 % at 16000x1536x512;
+                         // whole-step timings unchanged within noise, so the simpler loop stays
+#endif
+    if constexpr (PFPP_HOIST && MT == 2) {
+      // all fragment reads of the K-tile up front: the second 16-deep step's reads land behind the first step's MFMAs
+      half8 fa_h[2][MT], fa_l[2][MT], fb_h[2][NT], fb_l[2][NT];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          fa_h[ks][i] = *reinterpret_cast<const half8*>(a_base + i * 32 * LDH + ks * 16);
+          fa_l[ks][i] = *reinterpret_cast<const half8*>(a_base + PLANE_A + i * 32 * LDH + ks * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          fb_h[ks][j] = *reinterpret_cast<const half8*>(w_base + j * 32 * LDH + ks * 16);
+          fb_l[ks][j] = *reinterpret_cast<const half8*>(w_base + PLANE_W + j * 32 * LDH + ks * 16);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l[ks][i], fb_h[ks][j], accM[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[ks][i], fb_l[ks][j], accM[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[ks][i], fb_h[ks][j], accM[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       half8 bh[NT], bl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
+#if PFPP_ABLATE == 3
+        bh[j] = bl[j] = half8{(_Float16)(lane + j), 1, 2, 3, 4, 5, 6, 7};
+#else
         bh[j] = *reinterpret_cast<const half8*>(w_base + j * 32 * LDH + ks * 16);
         bl[j] = *reinterpret_cast<const half8*>(w_base + PLANE_W + j * 32 * LDH + ks * 16);
+#endif
       }
       // A fragments two M-tiles at a time (keeps the 128x64 wave tile of the 256x256 variant in registers)
 #pragma unroll
@@ -415,18 +469,38 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
         half8 ah[2], al[2];
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
+#if PFPP_ABLATE == 3
+          ah[ii] = al[ii] = half8{(_Float16)(lane + ii + ks), 1, 2, 3, 4, 5, 6, 7};
+#else
           ah[ii] = *reinterpret_cast<const half8*>(a_base + (i0 + ii) * 32 * LDH + ks * 16);
           al[ii] = *reinterpret_cast<const half8*>(a_base + PLANE_A + (i0 + ii) * 32 * LDH + ks * 16);
+#endif
         }
+        // term-major order: the three MFMAs that feed one accumulator are 2*NT instructions apart, never back to back
+        // (a dependent MFMA on the same accumulator waits for the previous one's passes; small terms first)
+#if PFPP_ABLATE == 2
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            // small terms first, then the leading one — all into the same accumulator
+          for (int j = 0; j < NT; ++j)
+            accM[i0 + ii][j][0] += (float)al[ii][0] * (float)bh[j][0] + (float)ah[ii][1] * (float)bl[j][1];
+#else
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bl[j], accM[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
-          }
+#endif
       }
     }
   };
@@ -446,7 +520,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
       load_full(s0, kb + (kt + 1) * BK);
       compute(kt & 1);
       store_tiles(s0, (kt & 1) ^ 1);
+#if PFPP_ABLATE != 6
       __syncthreads();
+#endif
     }
     for (; kt < nk; ++kt) {
       const bool has_next = kt + 1 < nk;
