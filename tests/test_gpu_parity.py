@@ -791,3 +791,37 @@ def test_gemm_split_k_fixup_is_deterministic_and_exact(dev):
     outs = [ops.linear(A.to(dev), pw, b.to(dev), act="silu", residual=R.to(dev)).cpu() for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert (outs[0].double() - want).abs().max() < 2e-5
+
+
+def test_stress_shapes_beyond_reference_limits(dev):
+    """BASELINE configs[4]-shaped sizes (100 fragments per puzzle, 2048 points, 4950 verifier edges): beyond what the
+    reference's max_len = 20 tables allow, so properties only — finite outputs, padded slots untouched, compact == padded"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+    from puzzlefusion_plusplus.verifier.model.modules.verifier_transformer import VerifierTransformer
+
+    torch.manual_seed(0)
+    cfg = config.denoiser_config(model=dict(max_len=100))
+    model = Denoiser(cfg).to(dev).eval()
+    with torch.no_grad():
+        model.encoder.vector_quantization.embedding.weight.uniform_(-1, 1)
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(900, 2, num_points=2048, max_parts=100, num_parts=60).items()}
+    x = torch.randn(2, 100, 7, device=dev)
+    ts = torch.tensor([950, 100], device=dev)
+    with torch.no_grad():
+        latent, xyz = model._extract_features(data["part_pcs"], data["part_valids"], x)
+        eps = model.denoiser(x, ts, latent, xyz, data["part_valids"], data["part_scale"], data["ref_part"])
+        model.denoiser.compact_padded = True
+        eps_c = model.denoiser(x, ts, latent, xyz, data["part_valids"], data["part_scale"], data["ref_part"])
+    v = data["part_valids"].bool()
+    assert eps.shape == (2, 100, 7) and torch.isfinite(eps).all()
+    assert float(latent[~v].abs().max()) == 0
+    assert (eps[v] - eps_c[v]).abs().max() < 1e-4 and float(eps_c[~v].abs().max()) == 0
+    ver = VerifierTransformer(config.verifier_config(model=dict(max_len=100))).to(dev).eval()
+    E = 100 * 99 // 2
+    iu = torch.triu(torch.ones(100, 100, dtype=torch.bool), diagonal=1).nonzero()[None].to(dev)
+    ef = torch.rand(1, E, 7, device=dev)
+    ev = ((iu[..., 0] < 60) & (iu[..., 1] < 60)).float()
+    with torch.no_grad():
+        lo = ver(ef, iu, ev)
+    assert lo.shape == (1, E, 1) and torch.isfinite(lo[ev.bool()]).all()
