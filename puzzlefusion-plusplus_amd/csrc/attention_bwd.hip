@@ -307,13 +307,21 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_kernel(
 constexpr int BD_L = 32;
 constexpr int BD_DH = 64;
 constexpr int BD_LD = BD_DH + 4;    // 16-byte aligned rows, conflict-light
-constexpr int BD_LP = BD_L + 1;
 
-__global__ __launch_bounds__(64) void attn_blockdiag_bwd_kernel(const float* __restrict__ qkv,
-                                                                const float* __restrict__ dout,
-                                                                float* __restrict__ dqkv, int L, int H, float scale) {
-  __shared__ __align__(16) float sq[BD_L * BD_LD], sk[BD_L * BD_LD], sv[BD_L * BD_LD], sg[BD_L * BD_LD];
-  __shared__ float sp[BD_L * BD_LP], sd[BD_L * BD_LP];
+// 256 threads per (fragment, head): the four waves split the score entries (phase 1) and the output rows (phase 3),
+// so a workgroup's ~30 k LDS reads are spread over four waves that hide each other's latency; LDS is sized for the
+// actual L (dynamic), which lets 4-5 workgroups share a CU instead of 3.
+__global__ __launch_bounds__(256) void attn_blockdiag_bwd_kernel(const float* __restrict__ qkv,
+                                                                 const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, int L, int H, float scale) {
+  extern __shared__ __align__(16) float bd_smem[];
+  const int LP = L + 1;
+  float* sq = bd_smem;                 // [L][BD_LD]
+  float* sk = sq + L * BD_LD;
+  float* sv = sk + L * BD_LD;
+  float* sg = sv + L * BD_LD;
+  float* sp = sg + L * BD_LD;          // [L][LP] probabilities
+  float* sd = sp + L * LP;             // [L][LP] dP then dS
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x;
   const int64_t frag = pair / H;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(64) void attn_blockdiag_bwd_kernel(const float* __r
   const int64_t ld = 3ll * C;
   const float* base = qkv + frag * L * ld + h * BD_DH;
   const float* gbase = dout + frag * L * (int64_t)C + h * BD_DH;
-  for (int i = tid; i < L * 16; i += 64) {
+  for (int i = tid; i < L * 16; i += 256) {
     const int r = i >> 4, c4 = i & 15;
     *reinterpret_cast<float4*>(&sq[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(base + r * ld + c4 * 4);
     *reinterpret_cast<float4*>(&sk[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(base + r * ld + C + c4 * 4);
@@ -330,8 +338,8 @@ __global__ __launch_bounds__(64) void attn_blockdiag_bwd_kernel(const float* __r
     *reinterpret_cast<float4*>(&sg[r * BD_LD + c4 * 4]) = *reinterpret_cast<const float4*>(gbase + r * (int64_t)C + c4 * 4);
   }
   __syncthreads();
-  // scores and dP
-  for (int idx = tid; idx < L * L; idx += 64) {
+  // phase 1: scores and dP, one (i, j) entry per thread and pass
+  for (int idx = tid; idx < L * L; idx += 256) {
     const int i = idx / L, j = idx - i * L;
     float a = 0.0f, g = 0.0f;
 #pragma unroll
@@ -343,39 +351,39 @@ __global__ __launch_bounds__(64) void attn_blockdiag_bwd_kernel(const float* __r
       a = fmaf(q.x, k.x, a); a = fmaf(q.y, k.y, a); a = fmaf(q.z, k.z, a); a = fmaf(q.w, k.w, a);
       g = fmaf(o.x, v.x, g); g = fmaf(o.y, v.y, g); g = fmaf(o.z, v.z, g); g = fmaf(o.w, v.w, g);
     }
-    sp[i * BD_LP + j] = a * scale;
-    sd[i * BD_LP + j] = g;
+    sp[i * LP + j] = a * scale;
+    sd[i * LP + j] = g;
   }
   __syncthreads();
-  // softmax rows, then dS = P*(dP - sum_j P*dP)*scale
+  // phase 2: softmax rows, then dS = P*(dP - sum_j P*dP)*scale (one thread per row: L <= 32)
   if (tid < L) {
     float m = -__builtin_huge_valf();
-    for (int j = 0; j < L; ++j) m = fmaxf(m, sp[tid * BD_LP + j]);
+    for (int j = 0; j < L; ++j) m = fmaxf(m, sp[tid * LP + j]);
     float sum = 0.0f;
     for (int j = 0; j < L; ++j) {
-      const float e = expf(sp[tid * BD_LP + j] - m);
-      sp[tid * BD_LP + j] = e;
+      const float e = expf(sp[tid * LP + j] - m);
+      sp[tid * LP + j] = e;
       sum += e;
     }
     const float inv = 1.0f / sum;
     float dsum = 0.0f;
     for (int j = 0; j < L; ++j) {
-      const float p = sp[tid * BD_LP + j] * inv;
-      sp[tid * BD_LP + j] = p;
-      dsum += p * sd[tid * BD_LP + j];
+      const float pj = sp[tid * LP + j] * inv;
+      sp[tid * LP + j] = pj;
+      dsum += pj * sd[tid * LP + j];
     }
-    for (int j = 0; j < L; ++j) sd[tid * BD_LP + j] = sp[tid * BD_LP + j] * (sd[tid * BD_LP + j] - dsum) * scale;
+    for (int j = 0; j < L; ++j) sd[tid * LP + j] = sp[tid * LP + j] * (sd[tid * LP + j] - dsum) * scale;
   }
   __syncthreads();
-  // thread = head-dim column d
-  const int d = tid;
+  // phase 3: wave w takes rows w, w+4, ...; lane = head-dim column
+  const int d = tid & 63;
   float* obase = dqkv + frag * L * ld + h * BD_DH + d;
-  for (int i = 0; i < L; ++i) {
+  for (int i = tid >> 6; i < L; i += 4) {
     float dq = 0.0f, dk = 0.0f, dv = 0.0f;
     for (int j = 0; j < L; ++j) {
-      dq = fmaf(sd[i * BD_LP + j], sk[j * BD_LD + d], dq);       // dQ[i] = sum_j dS[i][j] K[j]
-      dk = fmaf(sd[j * BD_LP + i], sq[j * BD_LD + d], dk);       // dK[i] = sum_j dS[j][i] Q[j]
-      dv = fmaf(sp[j * BD_LP + i], sg[j * BD_LD + d], dv);       // dV[i] = sum_j P[j][i] dO[j]
+      dq = fmaf(sd[i * LP + j], sk[j * BD_LD + d], dq);       // dQ[i] = sum_j dS[i][j] K[j]
+      dk = fmaf(sd[j * LP + i], sq[j * BD_LD + d], dk);       // dK[i] = sum_j dS[j][i] Q[j]
+      dv = fmaf(sp[j * LP + i], sg[j * BD_LD + d], dv);       // dV[i] = sum_j P[j][i] dO[j]
     }
     obase[i * ld] = dq;
     obase[i * ld + C] = dk;
@@ -393,7 +401,8 @@ extern "C" int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, floa
   PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(dout), "16-byte alignment");
   const int64_t pairs = n_frag * H;
   if (pairs == 0) return PFPP_OK;
-  hipLaunchKernelGGL(attn_blockdiag_bwd_kernel, dim3((unsigned)pairs), dim3(64), 0, pfpp::as_stream(stream), qkv, dout,
+  const size_t smem = (size_t)(4 * L * BD_LD + 2 * L * (L + 1)) * sizeof(float);
+  hipLaunchKernelGGL(attn_blockdiag_bwd_kernel, dim3((unsigned)pairs), dim3(256), smem, pfpp::as_stream(stream), qkv, dout,
                      dqkv, (int)L, (int)H, scale);
   return pfpp::check_launch(__func__);
 }

@@ -11,6 +11,15 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parents[1]
 
 
+
+def _free_port() -> int:
+    """an unused TCP port on 127.0.0.1 (rendezvous of the spawned ranks)"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _worker(rank, world, port, out):
     for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
         if p not in sys.path:
@@ -39,7 +48,7 @@ def test_two_rank_sharding_and_clock():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -79,7 +88,7 @@ def test_two_rank_gradient_exchange():
     """the training exchange: every slice of the flat gradient buffer is summed exactly once"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

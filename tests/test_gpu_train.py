@@ -9,6 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+
+def _free_port() -> int:
+    """an unused TCP port on 127.0.0.1 (rendezvous of the spawned ranks)"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -296,7 +305,7 @@ def test_two_rank_data_parallel_gradients(golden, weights_sd, dev):
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 32500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
