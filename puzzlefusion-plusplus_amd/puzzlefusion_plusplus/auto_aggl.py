@@ -87,108 +87,78 @@ class AutoAgglomerative(LightningModule):
             "point_part": point_part.to(torch.int32).to(device),
         }
 
-    # ------------------------------------------------------------------ test_step
+    # ------------------------------------------------------------------ test_step / test_batch
     @torch.no_grad()
     def test_step(self, data_dict, idx=0, x_init: Optional[torch.Tensor] = None, noises: Optional[List[torch.Tensor]] = None):
-        dev = data_dict["part_pcs"].device
-        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
-        B, P, N, _ = data_dict["part_pcs"].shape
-        if B != 1:
-            raise ValueError("AutoAgglomerative.test_step handles one puzzle per call (docs/test.md:8)")
-        x = torch.randn(gt.shape, device=dev) if x_init is None else x_init.clone()
-        ref_part = data_dict["ref_part"].clone()
-        reference = torch.zeros_like(gt)
-        reference[ref_part] = gt[ref_part]
-        x[ref_part] = reference[ref_part]
-        part_valids = data_dict["part_valids"].clone()
-        part_scale = data_dict["part_scale"].clone()
-        part_pcs = data_dict["part_pcs"].clone()
-        num_parts = data_dict["num_parts"].clone()
-        n_nodes = int(num_parts[0])
-        nodes = [{"pivot": i, "valids": True, "ref_part": False, "init_pose": None} for i in range(n_nodes)]
-        nodes[int(torch.where(ref_part)[1][0])]["ref_part"] = True
-        classified = torch.zeros_like(part_valids, dtype=torch.bool)
-        have_matching = "edges" in data_dict
-        match = self.prepare_matching(data_dict, dev) if have_matching else None
-        pivot = torch.arange(n_nodes, dtype=torch.int32, device=dev)
-        edge_indices = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1).nonzero(as_tuple=False)[None]
-        edge_valids = self._edge_mask(num_parts, P)
+        """one puzzle through the auto-agglomerative loop (auto_aggl.py:86-318), batch size 1 like the reference"""
+        if data_dict["part_pcs"].shape[0] != 1:
+            raise ValueError("AutoAgglomerative.test_step handles one puzzle per call (docs/test.md:8); use test_batch for several")
+        return self.test_batch([data_dict], None if x_init is None else [x_init], None if noises is None else [noises])[0]
+
+    @torch.no_grad()
+    def test_batch(self, data_dicts: List[dict], x_inits: Optional[List[torch.Tensor]] = None,
+                   noises: Optional[List[List[torch.Tensor]]] = None) -> List[dict]:
+        """Several independent puzzles through the loop at once (throughput mode).  The reference runs one puzzle per
+        call; puzzles never interact (attention is within a puzzle, batch statistics are not used in eval), so the
+        20 DDPM steps of an outer iteration run as ONE batched rotate + encode + denoise over all puzzles still
+        active, while the verifier / promotion / merge bookkeeping stays per puzzle.  Every puzzle sees exactly the
+        arithmetic of its own test_step up to the summation order inside the batched GEMMs."""
+        states = [_PuzzleState(self, d, None if x_inits is None else x_inits[i], None if noises is None else noises[i])
+                  for i, d in enumerate(data_dicts)]
         max_iters = self.cfg.verifier.max_iters
-        traj, step_no, verifier_calls, n_merges = [], 0, 0, 0
-        merged_edges: List = []
-        if have_matching:
-            data_dict = dict(data_dict)
-            data_dict["part_pcs_by_area"] = data_dict["part_pcs_by_area"].clone()      # mutated by the merges (:259-262)
         from pfpp_hip.denoiser import CompactLayout
 
         for it in range(max_iters):
+            active = [st for st in states if not st.done]
+            if not active:
+                break
+            cat = (lambda key: torch.cat([getattr(st, key) for st in active], 0)) if len(active) > 1 else (lambda key: getattr(active[0], key))
+            part_pcs, part_valids, part_scale, ref_part, reference = (cat(k) for k in ("part_pcs", "part_valids", "part_scale",
+                                                                                       "ref_part", "reference"))
+            x = cat("x")
             # everything that depends on part_valids only, once per outer iteration (no device->host reads in the steps)
             layout = CompactLayout(part_valids, self.num_points)
             step_fn = self._make_step(part_pcs, part_valids, part_scale, ref_part, layout, x)
+            compose = self._batched_compose(active)                                # pivots / init poses are fixed until the merges
+            composed = []
             for t in self.noise_scheduler.timesteps.tolist():
                 eps = step_fn(x, t)
-                x = self.noise_scheduler.step(eps, t, x, variance_noise=None if noises is None else noises[step_no],
-                                              ref_part=ref_part, reference=reference).prev_sample
-                traj.append(self._compose(x, pivot, nodes))                  # get_param (:151), stays on the GPU
-                step_no += 1
-            if it + 1 == max_iters or not have_matching:
-                break
-            # ---- edge features (:156-201) ---------------------------------------------------------
-            pts_t = ops.pose_apply_points(data_dict["part_pcs_by_area"][0].float().contiguous(),
-                                          pivot[match["point_part"].long()].contiguous(), x[0].contiguous(), normalise=False)
-            hist = ops.edge_histogram(pts_t, match["idx_a"], match["idx_b"], match["edge_off"], match["max_m"])
-            ef = torch.zeros(1, P, P, 6, dtype=torch.int32, device=dev)
-            if match["pairs"]:
-                i1 = torch.tensor([p[0] for p in match["pairs"]], device=dev)
-                i2 = torch.tensor([p[1] for p in match["pairs"]], device=dev)
-                ef[0, i1, i2] = hist
-            mat_mask = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1)
-            ef = ef[:, mat_mask]
-            cnt = ef.sum(dim=-1, keepdim=True)
-            ef = torch.cat((ef / torch.where(cnt == 0, 1, cnt), cnt), dim=-1).float()
-            # ---- verifier (:203-205) ----------------------------------------------------------------
-            logits = self.verifier(ef.contiguous(), edge_indices.contiguous(), edge_valids)
-            verifier_calls += 1
-            pred = (torch.sigmoid(logits) > self.cfg.verifier.threshold).squeeze(-1) & edge_valids
-            classified_edges = edge_indices[pred].cpu().tolist()
-            # ---- reference promotion (:208-222) -----------------------------------------------------
-            valid_b = part_valids.bool()
-            ref_idx = set(torch.where(ref_part)[1].cpu().tolist())
-            classified[0, list(ref_idx)] = True
-            larger = valid_b & (part_scale.squeeze(2) > 0.05)
-            new_ref = [a if a not in ref_idx else b for a, b in classified_edges if (a in ref_idx) != (b in ref_idx)]
-            for j in new_ref:
-                ref_part[0, j] = True
-            reference = x.clone()
-            if bool((classified == larger).all()):
-                break
-            from utils.node_merge_utils import node_merge_valids_check
+                vn = None
+                if noises is not None:
+                    vn = torch.cat([st.noises[st.step_no] for st in active], 0)
+                x = self.noise_scheduler.step(eps, t, x, variance_noise=vn, ref_part=ref_part, reference=reference).prev_sample
+                composed.append(compose(x))                                        # get_param (:151), one launch for all puzzles
+                for st in active:
+                    st.step_no += 1
+            composed = torch.stack(composed, 0)                                    # [steps, sum n_nodes, 7]
+            off = 0
+            for i, st in enumerate(active):
+                st.traj.append(composed[:, off:off + st.n_nodes])
+                off += st.n_nodes
+                st.x = x[i:i + 1].clone()
+            last = it + 1 == max_iters
+            # edge features per puzzle (ragged matching data), ONE verifier call for all of them, bookkeeping per puzzle
+            todo = [st for st in active if not st.finish_if_last(last)]
+            if todo:
+                efs = [st.edge_features() for st in todo]
+                logits = self.verifier(torch.cat(efs, 0).contiguous(), torch.cat([st.edge_indices for st in todo], 0).contiguous(),
+                                       torch.cat([st.edge_valids for st in todo], 0))
+                for i, st in enumerate(todo):
+                    st.after_verify(logits[i:i + 1])
+        return [st.result() for st in states]
 
-            merges = [(a, b) for a, b in classified_edges if node_merge_valids_check((a, b), ref_part, nodes)]
-            if merges:
-                state = dict(x=x, part_pcs=part_pcs, part_scale=part_scale, part_valids=part_valids, classified=classified,
-                             pivot=pivot, pts_by_area=data_dict["part_pcs_by_area"], pts_by_area_t=pts_t, match=match,
-                             n_pcs=data_dict["n_pcs"], merged_edges=merged_edges)
-                if self.merge_fn is not None:
-                    self.merge_fn(self, merges, nodes, state)
-                else:
-                    self._merge_components(merges, nodes, state)
-                n_merges += 1
-            if bool((classified == larger).all()):
-                break
-        final = self._compose(x, pivot, nodes)
-        valid_nodes = data_dict["part_valids"][0, :n_nodes].bool()
-        metrics = self._evaluate(data_dict, final, n_nodes)
-        traj_t = torch.stack(traj, 0)
-        if getattr(self.cfg, "experiment_output_path", None) is not None and "data_id" in data_dict:
-            self._save_inference_data(data_dict, traj_t, metrics["part_acc"])
-        return {
-            "metrics": metrics,
-            "pred_trans": final[:, :3], "pred_rots": final[:, 3:], "x": x,
-            "trajectory": traj_t[:, valid_nodes],                        # [T_total, Pv, 7] like predict_*.npy (:322-337)
-            "ref_part": ref_part, "verifier_calls": verifier_calls, "steps": step_no, "merges": n_merges,
-            "part_valids": part_valids, "nodes": nodes,
-        }
+    @staticmethod
+    def _batched_compose(active):
+        """-> f(x [n,P,7]) = composed poses of all original parts of all active puzzles, [sum n_nodes, 7] in one launch"""
+        dev = active[0].dev
+        P = active[0].P
+        pivot = torch.cat([st.pivot + i * P for i, st in enumerate(active)]).contiguous()
+        nodes = [n for st in active for n in st.nodes]
+        if all(n["init_pose"] is None for n in nodes):
+            return lambda x: ops.pose_compose(x.reshape(-1, 7).contiguous(), pivot)
+        init = torch.stack([(n["init_pose"] if n["init_pose"] is not None else torch.eye(4, device=dev)).reshape(16) for n in nodes]).contiguous()
+        has = torch.tensor([n["init_pose"] is not None for n in nodes], dtype=torch.uint8, device=dev)
+        return lambda x: ops.pose_compose(x.reshape(-1, 7).contiguous(), pivot, init, has)
 
     def _make_step(self, part_pcs, part_valids, part_scale, ref_part, layout, x_like):
         """-> f(x, t) = predicted noise.  Eager: rotate + encode + denoise with the precomputed layout.  Graphs: the same
@@ -335,3 +305,115 @@ class AutoAgglomerative(LightningModule):
 
     def save_inference_data(self, out, path: str):
         np.save(path, out["trajectory"].cpu().numpy())
+
+
+class _PuzzleState:
+    """everything the loop carries for ONE puzzle between outer iterations (the locals of the reference's test_step)"""
+
+    def __init__(self, model: "AutoAgglomerative", data_dict, x_init, noises):
+        self.m = model
+        dev = data_dict["part_pcs"].device
+        self.dev = dev
+        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
+        B, P, N, _ = data_dict["part_pcs"].shape
+        if B != 1:
+            raise ValueError("every puzzle is passed as its own batch-1 dict")
+        self.P = P
+        self.x = torch.randn(gt.shape, device=dev) if x_init is None else x_init.clone()
+        self.noises = noises
+        self.ref_part = data_dict["ref_part"].clone()
+        self.reference = torch.zeros_like(gt)
+        self.reference[self.ref_part] = gt[self.ref_part]
+        self.x[self.ref_part] = self.reference[self.ref_part]
+        self.part_valids = data_dict["part_valids"].clone()
+        self.part_scale = data_dict["part_scale"].clone()
+        self.part_pcs = data_dict["part_pcs"].clone()
+        self.num_parts = data_dict["num_parts"].clone()
+        self.n_nodes = int(self.num_parts[0])
+        self.nodes = [{"pivot": i, "valids": True, "ref_part": False, "init_pose": None} for i in range(self.n_nodes)]
+        self.nodes[int(torch.where(self.ref_part)[1][0])]["ref_part"] = True
+        self.classified = torch.zeros_like(self.part_valids, dtype=torch.bool)
+        self.have_matching = "edges" in data_dict
+        self.match = model.prepare_matching(data_dict, dev) if self.have_matching else None
+        self.pivot = torch.arange(self.n_nodes, dtype=torch.int32, device=dev)
+        self.edge_indices = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1).nonzero(as_tuple=False)[None]
+        self.edge_valids = model._edge_mask(self.num_parts, P)
+        self.traj, self.step_no, self.verifier_calls, self.n_merges = [], 0, 0, 0
+        self.merged_edges: List = []
+        self.data = dict(data_dict)
+        if self.have_matching:
+            self.data["part_pcs_by_area"] = data_dict["part_pcs_by_area"].clone()      # mutated by the merges (:259-262)
+        self.done = False
+
+    def finish_if_last(self, last: bool) -> bool:
+        if last or not self.have_matching:
+            self.done = True
+        return self.done
+
+    def edge_features(self) -> torch.Tensor:
+        """[1, 190, 7] verifier input of this puzzle from its current poses (auto_aggl.py:153-201)"""
+        m, dev, P = self.m, self.dev, self.P
+        x, match, pivot = self.x, self.match, self.pivot
+        # ---- edge features (:156-201) ---------------------------------------------------------
+        pts_t = ops.pose_apply_points(self.data["part_pcs_by_area"][0].float().contiguous(),
+                                      pivot[match["point_part"].long()].contiguous(), x[0].contiguous(), normalise=False)
+        hist = ops.edge_histogram(pts_t, match["idx_a"], match["idx_b"], match["edge_off"], match["max_m"])
+        ef = torch.zeros(1, P, P, 6, dtype=torch.int32, device=dev)
+        if match["pairs"]:
+            i1 = torch.tensor([p[0] for p in match["pairs"]], device=dev)
+            i2 = torch.tensor([p[1] for p in match["pairs"]], device=dev)
+            ef[0, i1, i2] = hist
+        mat_mask = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1)
+        ef = ef[:, mat_mask]
+        cnt = ef.sum(dim=-1, keepdim=True)
+        self._pts_t = pts_t
+        return torch.cat((ef / torch.where(cnt == 0, 1, cnt), cnt), dim=-1).float()
+
+    def after_verify(self, logits: torch.Tensor) -> None:
+        """threshold -> reference promotion -> merge for this puzzle (auto_aggl.py:203-286); sets `done`"""
+        m, x, match, pivot, pts_t = self.m, self.x, self.match, self.pivot, self._pts_t
+        self.verifier_calls += 1
+        pred = (torch.sigmoid(logits) > m.cfg.verifier.threshold).squeeze(-1) & self.edge_valids
+        classified_edges = self.edge_indices[pred].cpu().tolist()
+        # ---- reference promotion (:208-222) -----------------------------------------------------
+        valid_b = self.part_valids.bool()
+        ref_idx = set(torch.where(self.ref_part)[1].cpu().tolist())
+        self.classified[0, list(ref_idx)] = True
+        larger = valid_b & (self.part_scale.squeeze(2) > 0.05)
+        new_ref = [a if a not in ref_idx else b for a, b in classified_edges if (a in ref_idx) != (b in ref_idx)]
+        for j in new_ref:
+            self.ref_part[0, j] = True
+        self.reference = x.clone()
+        if bool((self.classified == larger).all()):
+            self.done = True
+            return
+        from utils.node_merge_utils import node_merge_valids_check
+
+        merges = [(a, b) for a, b in classified_edges if node_merge_valids_check((a, b), self.ref_part, self.nodes)]
+        if merges:
+            state = dict(x=x, part_pcs=self.part_pcs, part_scale=self.part_scale, part_valids=self.part_valids,
+                         classified=self.classified, pivot=pivot, pts_by_area=self.data["part_pcs_by_area"], pts_by_area_t=pts_t,
+                         match=match, n_pcs=self.data["n_pcs"], merged_edges=self.merged_edges)
+            if m.merge_fn is not None:
+                m.merge_fn(m, merges, self.nodes, state)
+            else:
+                m._merge_components(merges, self.nodes, state)
+            self.n_merges += 1
+        if bool((self.classified == larger).all()):
+            self.done = True
+
+    def result(self) -> dict:
+        m = self.m
+        final = m._compose(self.x, self.pivot, self.nodes)
+        valid_nodes = self.data["part_valids"][0, :self.n_nodes].bool()
+        metrics = m._evaluate(self.data, final, self.n_nodes)
+        traj_t = torch.cat(self.traj, 0)
+        if getattr(m.cfg, "experiment_output_path", None) is not None and "data_id" in self.data:
+            m._save_inference_data(self.data, traj_t, metrics["part_acc"])
+        return {
+            "metrics": metrics,
+            "pred_trans": final[:, :3], "pred_rots": final[:, 3:], "x": self.x,
+            "trajectory": traj_t[:, valid_nodes],                        # [T_total, Pv, 7] like predict_*.npy (:322-337)
+            "ref_part": self.ref_part, "verifier_calls": self.verifier_calls, "steps": self.step_no, "merges": self.n_merges,
+            "part_valids": self.part_valids, "nodes": self.nodes,
+        }

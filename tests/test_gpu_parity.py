@@ -825,3 +825,31 @@ def test_stress_shapes_beyond_reference_limits(dev):
     with torch.no_grad():
         lo = ver(ef, iu, ev)
     assert lo.shape == (1, E, 1) and torch.isfinite(lo[ev.bool()]).all()
+
+
+def test_auto_aggl_batched_equals_single(weights_sd, dev):
+    """throughput mode: several puzzles through the loop at once give each puzzle the result of its own test_step"""
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+
+    cfg = config.auto_aggl_config()
+    cfg.denoiser.model.num_inference_steps = 3
+    cfg.verifier.max_iters = 3
+    model = AutoAgglomerative(cfg)
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model.verifier.load_state_dict(weights_sd("verifier"))
+    model = model.to(dev).eval()
+    puzzles, x0s, nzs = [], [], []
+    g = torch.Generator(device=dev).manual_seed(8)
+    for i, parts in enumerate((4, 7, 2)):
+        b = {k: v.to(dev) for k, v in synthetic.make_batch(60 + i, 1, num_points=1000, num_parts=parts).items()}
+        b.update(synthetic.make_matching(b, seed=10 + i))
+        puzzles.append(b)
+        x0s.append(torch.randn(1, 20, 7, device=dev, generator=g))
+        nzs.append([torch.randn(1, 20, 7, device=dev, generator=g) for _ in range(9)])
+    single = [model.test_step(b, x_init=x0, noises=nz) for b, x0, nz in zip(puzzles, x0s, nzs)]
+    batched = model.test_batch(puzzles, x0s, nzs)
+    for s_, b_ in zip(single, batched):
+        assert s_["steps"] == b_["steps"] and s_["verifier_calls"] == b_["verifier_calls"] and s_["merges"] == b_["merges"]
+        assert torch.equal(s_["ref_part"], b_["ref_part"])
+        assert (s_["trajectory"] - b_["trajectory"]).abs().max() < 2e-4
