@@ -373,12 +373,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
       for (int it = 0; it < WF_IT; ++it) s.rwf[it] = load_k4(wf_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
     }
   };
-  auto store_tiles = [&](const Stage& s, int buf) {
+  auto store_tiles = [&](const Stage& s, int buf, int part = 2) {      // part 0: A planes, 1: W planes, 2: both
 #if PFPP_ABLATE == 4 || PFPP_ABLATE == 5 || PFPP_ABLATE == 6
     if (buf >= 0) return;
 #endif
     _Float16* st = gemm_smem_h + buf * STAGE;
     _Float16* ahi = st, *alo = st + PLANE_A, *whi = st + 2 * PLANE_A, *wlo = st + 2 * PLANE_A + PLANE_W;
+    if (part != 1)
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
       *reinterpret_cast<half4*>(ahi + off) = hi;
       *reinterpret_cast<half4*>(alo + off) = lo;
     }
+    if (part == 0) return;
     if constexpr (WPRE) {
 #pragma unroll
       for (int it = 0; it < WH_IT; ++it) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
       }
     }
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int ks_begin = 0, int ks_end = BK / 16) {
     const _Float16* st = gemm_smem_h + buf * STAGE;
     const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
     const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks < ks_begin || ks >= ks_end) continue;
       half8 bh[NT], bl[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -540,15 +543,21 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     if (nk > 1) load_any(s1, 1);
     store_tiles(s0, 0);
     __syncthreads();
+    // The tile for kt+1 already sits in registers (loaded one iteration ago), so its split + LDS stores do not wait
+    // on memory: they are placed BETWEEN the two 16-deep MFMA steps of tile kt to issue under the matrix pipe.
     for (int kt = 0; kt < nk; kt += 2) {
       if (kt + 2 < nk) load_any(s0, kt + 2);
-      compute(0);
-      if (kt + 1 < nk) store_tiles(s1, 1);
+      compute(0, 0, 1);
+      if (kt + 1 < nk) store_tiles(s1, 1, 0);
+      compute(0, 1, 2);
+      if (kt + 1 < nk) store_tiles(s1, 1, 1);
       __syncthreads();
       if (kt + 1 >= nk) break;
       if (kt + 3 < nk) load_any(s1, kt + 3);
-      compute(1);
-      if (kt + 2 < nk) store_tiles(s0, 0);
+      compute(1, 0, 1);
+      if (kt + 2 < nk) store_tiles(s0, 0, 0);
+      compute(1, 1, 2);
+      if (kt + 2 < nk) store_tiles(s0, 0, 1);
       __syncthreads();
     }
   }
@@ -743,7 +752,9 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // where the grid still fills the chip, 256x128 for narrower N
     if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
       return launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
-    if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32) return launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
+    static const bool pf2_big = getenv("PFPP_GEMM_PF2BIG") && atoi(getenv("PFPP_GEMM_PF2BIG")) == 1;
+    if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32)
+      return pf2_big ? launch_f16x3<2, 2, true, 4, 2, true>(p, a->batch, st) : launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
     // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
     // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave
     static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;

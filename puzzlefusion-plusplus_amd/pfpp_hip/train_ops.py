@@ -60,6 +60,8 @@ def grad_kernel_name(M: int, N: int, batch: int, a_kmajor: bool, w_kmajor: bool,
         bm, bn = 128, 128
     if (bm, bn) == (128, 128) and tiles(128, 128) < 192 and split_k == 1 and N <= 2048:
         bn = 64
+    if (bm, bn) == (128, 128) and accumulate and tiles(128, 128) < 40:
+        bn = 64
     cfg = {(256, 128): "2, 2, 4, 2", (128, 128): "2, 2, 2, 2", (128, 64): "2, 1, 2, 2"}[(bm, bn)]
     return f"gemm_grad_kernel<{cfg}, {'true' if a_kmajor else 'false'}, {'true' if w_kmajor else 'false'}>"
 
