@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--mode", choices=("train", "sample"), default="train")
     ap.add_argument("--latents-given", action="store_true",
                     help="train mode: skip the encoder (latents of the clean pose precomputed; not a reference mode)")
+    ap.add_argument("--serial", action="store_true",
+                    help="train mode: one stream only (no side stream for weight gradients, encoder in line) — the execution "
+                         "the roofline pass measures per-kernel durations in")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="train mode: run the frozen encoder of each iteration in line instead of one iteration ahead on its own stream")
     ap.add_argument("--compact", action="store_true",
@@ -311,7 +314,9 @@ def main():
     train = args.mode == "train"
     if train:
         wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given,
-                           pipeline=not args.no_pipeline)
+                           pipeline=not (args.no_pipeline or args.serial))
+        if args.serial:
+            wl.engine._side = None
     else:
         wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
     for _ in range(args.warmup):
@@ -341,6 +346,13 @@ def main():
     # ---- roofline of the dominant kernel: second, instrumented pass over the same steps ----------
     roofline = None
     if not args.no_roofline:
+        if train:
+            # per-kernel durations are taken with the streams serialised (no side stream, encoder in line): bracketing
+            # events on a stream that shares the chip with another stream measure the contention too, not the kernel
+            wl.engine._side = None
+            wl.pipeline = None
+            wl.step()
+            torch.cuda.synchronize(dev)
         ops.GEMM_TRACE = []
         for _ in range(args.steps):
             wl.step()
@@ -370,6 +382,7 @@ def main():
                           if split else "fp32 MFMA dense peak"),
             "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
             "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
+            "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if train else ""),
             "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
             "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
         }
