@@ -310,8 +310,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   s0.r_add = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (PF2) { s1.r_mul = s0.r_mul; s1.r_add = s0.r_add; }
   const bool a_aff = p.a_mul != nullptr;
-  const int a_row = tid >> 3, a_c4 = tid & 7;
-  const int h_row = tid >> 2, h_c8 = tid & 3;    // pre-split W: 4 lanes x 8 halfs cover a 32-half row slice
+  // staging rows: bits 0 and 2 of the row index are swapped, so the two rows a 16-lane (8-byte stores) or 8-lane
+  // (16-byte stores) LDS store group touches are 4 apart — with 80-byte rows their bank ranges are then disjoint
+  // (rows r, r+1 overlap in 4 of 32 banks: SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles)
+  auto swap02 = [](int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); };
+  const int a_row = swap02(tid >> 3), a_c4 = tid & 7;
+  const int h_row = swap02(tid >> 2), h_c8 = tid & 3;    // pre-split W: 4 lanes x 8 halfs cover a 32-half row slice
   const float* a_ptr[A_IT];
   const float* wf_ptr[NWF];
   const _Float16* wh_ptr[NWH];

@@ -50,6 +50,9 @@ __device__ __forceinline__ void split4s(const float4 v, float s, half4& hi, half
   }
 }
 
+// staging rows with bits 0 and 2 swapped: the two rows of an LDS store group are 4 apart (disjoint banks with 80-byte rows)
+__device__ __forceinline__ int swap02(int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); }
+
 // One operand tile: R rows (output rows or columns) x BK of the contraction -> hi/lo planes [R][LDH].
 template <int R, int NTHR, bool KM>
 struct OperandLoader {
@@ -74,7 +77,7 @@ struct OperandLoader {
           reg[it][j] = ok ? *reinterpret_cast<const float4*>(src + j * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       } else {
-        const int row = u >> 3, c4 = u & 7;
+        const int row = swap02(u >> 3), c4 = u & 7;
         const float* src = base + (int64_t)min(r0 + row, rmax - 1) * ld;
         const int k = k0 + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -110,7 +113,7 @@ struct OperandLoader {
           *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
       } else {
-        const int row = u >> 3, c4 = u & 7;
+        const int row = swap02(u >> 3), c4 = u & 7;
         half4 hi, lo;
         split4s(reg[it][0], scale, hi, lo);
         const int off = row * LDH + c4 * 4;
