@@ -444,7 +444,13 @@ class DenoiserTrainEngine:
         """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
         from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
         if self._exchange.active():
-            with torch.cuda.stream(self._side if self._side is not None else torch.cuda.current_stream()):
+            if self._side is None:
+                self._exchange.layer_done(i)
+                return
+            # the layer's slice holds gradients from BOTH streams (weights / biases: side stream; LayerNorm gamma / beta:
+            # main stream), so the collective is ordered after everything queued on either of them so far
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
                 self._exchange.layer_done(i)
 
     def _all_done(self) -> None:
