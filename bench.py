@@ -390,10 +390,28 @@ def main():
     extra = {}
     if train and rank == 0:
         extra["final_loss"] = round(float(wl.last_loss), 5)
+    if train and rank == 0 and world == 1 and not args.no_roofline and not args.latents_given:
+        # BASELINE configs[1] reads "VQ-VAE latents precomputed": the same iteration without the encoder (latents of the clean
+        # pose, computed once) — not a mode of the reference (its latents depend on the noisy rotation, denoiser.py:66-71)
+        del wl.engine
+        lwl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=True)
+        for _ in range(args.warmup):
+            lwl.step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lwl.step()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        extra["train_latents_given"] = {"value": round(lwl.n_frag * args.steps / dt, 2), "unit": "fragment*steps/s",
+                                        "ms_per_step": round(dt / args.steps * 1e3, 3),
+                                        "note": "transformer-only training iteration (forward, loss, backward, AdamW), encoder skipped"}
+        del lwl.engine, lwl
     if train and rank == 0 and world == 1 and not args.no_roofline:
         # the inference sampler step at the same shape (Denoiser.validation_step loop body), padded slots
         # evaluated like the reference and dropped
-        del wl.engine
+        if hasattr(wl, "engine"):
+            del wl.engine
         swl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev)
         for name, compact in (("sampler_step", False), ("sampler_step_compact", True)):
             swl.model.denoiser.compact_padded = compact
