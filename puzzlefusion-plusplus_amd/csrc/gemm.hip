@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #endif
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
-    if (a_aff) {
+    if (!PF2 && a_aff) {
       s.r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
       s.r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
     }
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
       float4 v = s.ra[it];
-      if (a_aff) {      // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
+      if (!PF2 && a_aff) {      // relu(batch-norm(y)) of the previous layer, applied while the tile is staged (the PF2
+                                // variants are never dispatched with it: no data-dependent branch in their K loop)
         v.x = fmaxf(v.x * s.r_mul.x + s.r_add.x, 0.0f); v.y = fmaxf(v.y * s.r_mul.y + s.r_add.y, 0.0f);
         v.z = fmaxf(v.z * s.r_mul.z + s.r_add.z, 0.0f); v.w = fmaxf(v.w * s.r_mul.w + s.r_add.w, 0.0f);
       }
@@ -549,7 +550,24 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     __syncthreads();
     // The tile for kt+1 already sits in registers (loaded one iteration ago), so its split + LDS stores do not wait
     // on memory: they are placed BETWEEN the two 16-deep MFMA steps of tile kt to issue under the matrix pipe.
-    for (int kt = 0; kt < nk; kt += 2) {
+    // Steady state is branch-free (two K-tiles per trip, everything unconditional) so that it is ONE scheduling
+    // region; the last tiles run through the guarded tail.
+    int kt = 0;
+    for (; kt + 3 < nk_full; kt += 2) {
+      load_full(s0, kb + (kt + 2) * BK);
+      compute(0, 0, 1);
+      store_tiles(s1, 1, 0);
+      compute(0, 1, 2);
+      store_tiles(s1, 1, 1);
+      __syncthreads();
+      load_full(s1, kb + (kt + 3) * BK);
+      compute(1, 0, 1);
+      store_tiles(s0, 0, 0);
+      compute(1, 1, 2);
+      store_tiles(s0, 0, 1);
+      __syncthreads();
+    }
+    for (; kt < nk; kt += 2) {
       if (kt + 2 < nk) load_any(s0, kt + 2);
       compute(0, 0, 1);
       if (kt + 1 < nk) store_tiles(s1, 1, 0);
@@ -756,16 +774,16 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // where the grid still fills the chip, 256x128 for narrower N
     if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
       return launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
-    static const bool pf2_big = getenv("PFPP_GEMM_PF2BIG") && atoi(getenv("PFPP_GEMM_PF2BIG")) == 1;
+    static const bool pf2_big = !(getenv("PFPP_GEMM_PF2BIG") && atoi(getenv("PFPP_GEMM_PF2BIG")) == 0);   // 16000x512x2048: 132 -> 111 us
     if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32)
-      return pf2_big ? launch_f16x3<2, 2, true, 4, 2, true>(p, a->batch, st) : launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
+      return (pf2_big && !fused_bn) ? launch_f16x3<2, 2, true, 4, 2, true>(p, a->batch, st) : launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
     // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
     // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave
     static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
     // grids of at most ~two workgroups per CU: prefetch two K-tiles ahead (the load latency is all there is to hide)
-    static const bool pf2 = getenv("PFPP_GEMM_PF2") && atoi(getenv("PFPP_GEMM_PF2")) == 1;   // opt-in: measured slower (B = 1 step 2.23 vs 1.92 ms)
-    const bool deep = pf2 && tiles128 < 2 * small_thresh;
+    static const bool pf2 = !(getenv("PFPP_GEMM_PF2") && atoi(getenv("PFPP_GEMM_PF2")) == 0);   // two-deep prefetch, branch-free steady state: +10..23 % at 3850 rows
+    const bool deep = pf2 && !fused_bn && tiles128 < 2 * small_thresh;
     if (pre && wide && tiles128 < small_thresh && a->act != PFPP_ACT_GEGLU && a->pool == 0)
       return deep ? launch_f16x3<2, 1, true, 2, 2, true>(p, a->batch, st) : launch_f16x3<2, 1, true>(p, a->batch, st);
     if (pre && deep)

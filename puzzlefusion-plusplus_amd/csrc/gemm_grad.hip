@@ -169,12 +169,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
   OperandLoader<BM, NTHR, AKM> la0, la1;
   OperandLoader<BN, NTHR, WKM> lw0, lw1;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int ks_begin = 0, int ks_end = BK / 16) {
     const _Float16* st = grad_smem + buf * STAGE;
     const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
     const _Float16* w_base = st + 2 * PLANE_A + (wn * 32 * NT + l31) * LDH + lhi * 8;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks < ks_begin || ks >= ks_end) continue;
       half8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -212,6 +213,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
     la##SET.store(st_, st_ + PLANE_A, p.a_scale, tid);                                        \
     lw##SET.store(st_ + 2 * PLANE_A, st_ + 2 * PLANE_A + PLANE_W, p.w_scale, tid);            \
   } while (0)
+#define GRAD_STORE_A(SET, BUF)                                                                \
+  do {                                                                                        \
+    _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
+    la##SET.store(st_, st_ + PLANE_A, p.a_scale, tid);                                        \
+  } while (0)
+#define GRAD_STORE_W(SET, BUF)                                                                \
+  do {                                                                                        \
+    _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
+    lw##SET.store(st_ + 2 * PLANE_A, st_ + 2 * PLANE_A + PLANE_W, p.w_scale, tid);            \
+  } while (0)
 
   const int nk = (ke - kb + BK - 1) / BK;
   if (nk > 0) GRAD_LOAD(0, 0);
@@ -219,8 +230,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
   if (nk > 0) GRAD_STORE(0, 0);
   __syncthreads();
   // invariant at the top of iteration kt: LDS stage kt&1 holds tile kt, register set (kt+1)&1 holds tile kt+1
-  // (in flight), register set kt&1 is free
-  for (int kt = 0; kt < nk; kt += 2) {
+  // (in flight), register set kt&1 is free.  Steady state: two K-tiles per trip, no branch inside (one scheduling
+  // region), the split + LDS stores of tile kt+1 placed between the two 16-deep MFMA steps of tile kt.
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {
+    GRAD_LOAD(0, kt + 2);
+    compute(0, 0, 1);
+    GRAD_STORE_A(1, 1);
+    compute(0, 1, 2);
+    GRAD_STORE_W(1, 1);
+    __syncthreads();
+    GRAD_LOAD(1, kt + 3);
+    compute(1, 0, 1);
+    GRAD_STORE_A(0, 0);
+    compute(1, 1, 2);
+    GRAD_STORE_W(0, 0);
+    __syncthreads();
+  }
+  for (; kt < nk; kt += 2) {
     if (kt + 2 < nk) GRAD_LOAD(0, kt + 2);
     compute(0);
     if (kt + 1 < nk) GRAD_STORE(1, 1);
@@ -233,6 +260,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
   }
 #undef GRAD_LOAD
 #undef GRAD_STORE
+#undef GRAD_STORE_A
+#undef GRAD_STORE_W
 
   // ---- epilogue: plain store or atomic accumulate ------------------------------------------------
   const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
