@@ -158,7 +158,7 @@ class TrainWorkload:
         else:
             noise, t = self._draw()
             noisy = sch.add_noise(self.gt, noise, t)
-            noisy[self.ref] = self.gt[self.ref]
+            noisy = torch.where(self.ref.unsqueeze(-1), self.gt, noisy)
             with torch.no_grad():
                 latent, xyz = self.fixed if self.latents_given else m._extract_features(d["part_pcs"], d["part_valids"], noisy)
         self.engine.flat.zero_grad()

@@ -97,23 +97,56 @@ def dense_attention_unfused(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, 
 
 class CompactLayout:
     """which slots are valid fragments and how their tokens group into per-puzzle sequences — everything the compact
-    forward needs that depends on part_valids only.  Building it reads back from the GPU (nonzero / max), so callers
-    that keep part_valids fixed over many steps (the sampler loop, HIP-graph capture) build it once."""
+    forward needs that depends on part_valids only.  Building it from a device tensor reads back from the GPU
+    (nonzero / max), which drains the stream the caller is on; callers that keep part_valids fixed over many steps
+    (the sampler loop, HIP-graph capture) build it once, `layout_of` below remembers it on the tensor, and a data
+    loader that still has the batch on the host builds it there (`from_host`) with no device read at all."""
 
-    __slots__ = ("slot", "slot32", "Fv", "frag_b", "frag_p", "seq_len", "seq_off", "max_len")
+    __slots__ = ("slot", "slot32", "Fv", "frag_b", "frag_p", "seq_len", "seq_off", "max_len", "counts")
 
     def __init__(self, part_valids: torch.Tensor, L: int):
         B, P = part_valids.shape[:2]
         valid = part_valids.reshape(B * P).to(torch.bool)
         self.slot = torch.nonzero(valid).flatten()
+        self._derive(B, P, L)
+
+    def _derive(self, B: int, P: int, L: int) -> None:
         self.slot32 = self.slot.to(torch.int32).contiguous()
         self.Fv = int(self.slot.numel())
         self.frag_b = torch.div(self.slot, P, rounding_mode="floor").to(torch.int32).contiguous()
         self.frag_p = (self.slot - self.frag_b.long() * P).to(torch.int32).contiguous()
         counts = torch.bincount(self.frag_b.long(), minlength=B)
+        self.counts = counts
         self.seq_len = (counts * L).to(torch.int32)
         self.seq_off = (torch.cumsum(counts, 0) - counts).mul(L).to(torch.int32)
         self.max_len = (int(counts.max().item()) if self.Fv else 0) * L
+
+    @classmethod
+    def from_host(cls, part_valids_host: torch.Tensor, L: int, device) -> "CompactLayout":
+        """the same layout from the batch as the data loader holds it (CPU): index arithmetic on the host, one small
+        async copy per index array, no device->host read"""
+        if part_valids_host.device.type != "cpu":
+            raise ValueError("CompactLayout.from_host: part_valids must be a host tensor")
+        lay = cls(part_valids_host, L)                       # CPU tensors: .item() is free
+        for name in ("slot", "slot32", "frag_b", "frag_p", "seq_len", "seq_off", "counts"):
+            setattr(lay, name, getattr(lay, name).to(device, non_blocking=True))
+        return lay
+
+
+def layout_of(part_valids: torch.Tensor, L: int) -> CompactLayout:
+    """the CompactLayout of this part_valids tensor, remembered ON the tensor object (it lives and dies with it; an
+    in-place write bumps `_version` and invalidates it).  A training / sampling loop that passes the same batch
+    tensor again — or a loader hook that attached a `from_host` layout with `attach_layout` — never reads back."""
+    tag = getattr(part_valids, "_pfpp_layout", None)
+    if tag is not None and tag[0] == part_valids._version and tag[1] == L:
+        return tag[2]
+    lay = CompactLayout(part_valids, L)
+    attach_layout(part_valids, L, lay)
+    return lay
+
+
+def attach_layout(part_valids: torch.Tensor, L: int, layout: CompactLayout) -> None:
+    part_valids._pfpp_layout = (part_valids._version, L, layout)
 
 
 def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, num_layers: int,
@@ -131,7 +164,7 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     n_slots = B * P
     dh = C // num_heads
     dev = latent.device
-    lay = layout if layout is not None else CompactLayout(part_valids, L)
+    lay = layout if layout is not None else layout_of(part_valids, L)
     slot, Fv, frag_b, frag_p = lay.slot, lay.Fv, lay.frag_b, lay.frag_p
     seq_len, seq_off, max_len = lay.seq_len, lay.seq_off, lay.max_len
     out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)

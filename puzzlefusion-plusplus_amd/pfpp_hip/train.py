@@ -252,17 +252,13 @@ class DenoiserTrainEngine:
         p_lay = self.p_layer if train else 0.0
         ctx = TrainContext()
         s = ctx.t
-        valid = part_valids.reshape(n_slots).to(torch.bool)
-        slot = torch.nonzero(valid).flatten()
-        Fv = int(slot.numel())
+        from .denoiser import layout_of
+
+        lay = layout_of(part_valids, L)                     # remembered on the tensor: no device read for a repeated batch
+        slot, Fv, frag_b, frag_p = lay.slot, lay.Fv, lay.frag_b, lay.frag_p
         if Fv == 0:
             raise ValueError("training forward: the batch has no valid fragment")
-        frag_b = torch.div(slot, P, rounding_mode="floor").to(torch.int32).contiguous()
-        frag_p = (slot - frag_b.long() * P).to(torch.int32).contiguous()
-        counts = torch.bincount(frag_b.long(), minlength=B)
-        seq_len = (counts * L).to(torch.int32)
-        seq_off = (torch.cumsum(counts, 0) - counts).mul(L).to(torch.int32)
-        max_len = int(counts.max().item()) * L
+        seq_len, seq_off, max_len = lay.seq_len, lay.seq_off, lay.max_len
         M = Fv * L
         sf, pf = ops.token_features(latent.reshape(n_slots, L, -1)[slot].contiguous(), xyz.reshape(n_slots, L, 3)[slot].contiguous(),
                                     scale.reshape(n_slots)[slot].contiguous(), x.reshape(n_slots, 7)[slot].contiguous().float())
@@ -367,32 +363,37 @@ class DenoiserTrainEngine:
         for i in reversed(range(self.num_layers)):
             lay = s["layers"][i]
             # ---- feed-forward (attention.py:87-90)
-            self._linear_bwd(dh_, lay["u"], w[f"{i}.ff2.w"], g[f"{i}.ff2.w"], g[f"{i}.ff2.b"])
+            self._linear_bwd(dh_, lay["u"], w[f"{i}.ff2.w"], g[f"{i}.ff2.w"], g[f"{i}.ff2.b"], guard=True)
             du = T.grad_input(dh_, w[f"{i}.ff2.w"].f32, g_scale=G)
             dz = T.geglu_bwd(lay["z"], du, p_lay, seed, 3 + 3 * i)
             del du
             self._linear_bwd(dz, lay["n3"], w[f"{i}.ff1.w"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
             dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G)
             del dz
+            self._before_inplace_update()
             T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
                             dadd=g[f"{i}.norm3.b"], ld_d=0)
             # ---- global attention (attention.py:82-85)
             dy = T.dropout(dh_, p_lay, seed, 2 + 3 * i) if p_lay > 0.0 else dh_
-            self._linear_bwd(dy, lay["att2"], w[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.b"])
+            self._linear_bwd(dy, lay["att2"], w[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.b"],
+                             guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
                                     s["att_scale"])
             self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
+            self._before_inplace_update()
             T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
                             dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C)
             # ---- self attention (attention.py:77-80)
             dy = T.dropout(dh_, p_lay, seed, 1 + 3 * i) if p_lay > 0.0 else dh_
-            self._linear_bwd(dy, lay["att1"], w[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"])
+            self._linear_bwd(dy, lay["att1"], w[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"],
+                             guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.self_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_blockdiag_bwd(lay["qkv1"], datt, Fv, L, H, dh, s["att_scale"])
             self._linear_bwd(dqkv, lay["n1"], None, g[f"{i}.self_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G)
+            self._before_inplace_update()
             T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
                             dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C)
             self._layer_done(i)
@@ -423,7 +424,7 @@ class DenoiserTrainEngine:
         T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
         self._all_done()
 
-    def _linear_bwd(self, dy, x, wpw, gw, gb) -> None:
+    def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:
         """dW += dy^T x, db += colsum(dy) — on the side stream when there is one"""
         if self._side is None:
             T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
@@ -438,6 +439,18 @@ class DenoiserTrainEngine:
                 T.colsum(dy, gb)
         dy.record_stream(self._side)                 # the caching allocator must not recycle them under the side stream
         x.record_stream(self._side)
+        if guard:                                    # the caller goes on to UPDATE dy in place on the main stream
+            self._dy_read = torch.cuda.Event()
+            self._dy_read.record(self._side)
+
+    def _before_inplace_update(self) -> None:
+        """the running residual-stream gradient is read by weight-gradient GEMMs on the side stream and then updated in
+        place (dx += LayerNorm backward) on the main stream: the update waits for those reads (write-after-read across
+        streams — record_stream only covers the allocator, not an explicit in-place write)"""
+        ev = getattr(self, "_dy_read", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._dy_read = None
 
     # ------------------------------------------------------------------------------------------ data parallel
     def _layer_done(self, i: int) -> None:
@@ -507,7 +520,7 @@ class FeaturePipeline:
         self.stream.wait_stream(main)                 # inputs were produced on the main stream
         with torch.cuda.stream(self.stream), torch.no_grad():
             noisy = self.model.noise_scheduler.add_noise(gt, noise, t)
-            noisy[ref] = gt[ref]
+            noisy = torch.where(ref.bool().unsqueeze(-1), gt, noisy)     # noisy[ref] = gt[ref] without the host sync of mask indexing
             latent, xyz = self.model._extract_features(data["part_pcs"], data["part_valids"], noisy)
             ev = torch.cuda.Event()
             ev.record(self.stream)

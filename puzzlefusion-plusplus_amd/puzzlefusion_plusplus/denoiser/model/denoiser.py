@@ -10,7 +10,6 @@ validation_step computes the reference's four metrics with denoiser/evaluation/e
 from __future__ import annotations
 
 import torch
-from torch.nn import functional as F
 
 from pfpp_hip.lightning_compat import LightningModule, instantiate
 from pfpp_hip.scheduler import PiecewiseScheduler
@@ -35,6 +34,24 @@ class Denoiser(LightningModule):
         self.noise_scheduler.set_timesteps(num_inference_steps=m.num_inference_steps)
         self.rmse_r_list, self.rmse_t_list, self.acc_list, self.cd_list = [], [], [], []
 
+    # ------------------------------------------------------------------ batch hooks (Lightning calls them around the H2D copy)
+    def on_before_batch_transfer(self, batch, dataloader_idx=0):
+        """while the collated batch is still on the host: derive the valid-fragment layout there, so the forward never
+        reads part_valids back from the GPU (a device->host read would drain the streams once per iteration)"""
+        pv = batch.get("part_valids") if isinstance(batch, dict) else None
+        if torch.is_tensor(pv) and pv.device.type == "cpu" and pv.dim() == 2:
+            batch["_pfpp_valids_host"] = pv.numpy().copy()        # numpy: the transfer leaves it on the host
+        return batch
+
+    def on_after_batch_transfer(self, batch, dataloader_idx=0):
+        host = batch.pop("_pfpp_valids_host", None) if isinstance(batch, dict) else None
+        if host is not None and batch["part_valids"].device.type == "cuda":
+            from pfpp_hip.denoiser import CompactLayout, attach_layout
+
+            attach_layout(batch["part_valids"], self.num_points,
+                          CompactLayout.from_host(torch.from_numpy(host), self.num_points, batch["part_valids"].device))
+        return batch
+
     # ------------------------------------------------------------------ hot path
     def _extract_features(self, part_pcs, part_valids, noisy_trans_and_rots):
         """rotate every fragment by its current noisy quaternion, encode the valid ones, scatter
@@ -51,15 +68,17 @@ class Denoiser(LightningModule):
         if timesteps is None:
             timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (B,), device=gt.device).long()
         noisy = self.noise_scheduler.add_noise(gt, noise, timesteps)
-        noisy[ref_part] = gt[ref_part]
+        noisy = torch.where(ref_part.bool().unsqueeze(-1), gt, noisy)    # == noisy[ref_part] = gt[ref_part] (denoiser.py:95), no host sync
         latent, xyz = self._extract_features(data_dict["part_pcs"], data_dict["part_valids"], noisy)
         pred = self.denoiser(noisy, timesteps, latent, xyz, data_dict["part_valids"], data_dict["part_scale"], ref_part)
         return {"pred_noise": pred, "gt_noise": noise}
 
     def _loss(self, data_dict, output_dict):
-        valids = data_dict["part_valids"].bool().clone()
-        valids[data_dict["ref_part"]] = False
-        return {"mse_loss": F.mse_loss(output_dict["pred_noise"][valids], output_dict["gt_noise"][valids])}
+        # F.mse_loss(pred[valids & ~ref], gt[valids & ~ref]) (denoiser.py:118-126) written as a masked mean: boolean-mask
+        # indexing reads the selection size back to the host, which would stall the enqueue of every iteration
+        sel = data_dict["part_valids"].bool() & ~data_dict["ref_part"].bool()
+        d = (output_dict["pred_noise"] - output_dict["gt_noise"]) * sel.unsqueeze(-1)
+        return {"mse_loss": (d * d).sum() / (sel.sum() * d.shape[-1])}
 
     def training_step(self, data_dict, idx):
         out = self(data_dict)
@@ -77,9 +96,9 @@ class Denoiser(LightningModule):
         gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
         ref_part = data_dict["ref_part"]
         x = torch.randn(gt.shape, device=gt.device) if x_init is None else x_init.clone()
-        reference = torch.zeros_like(gt)
-        reference[ref_part] = gt[ref_part]
-        x[ref_part] = reference[ref_part]
+        is_ref = ref_part.bool().unsqueeze(-1)
+        reference = torch.where(is_ref, gt, torch.zeros_like(gt))      # reference[ref] = gt[ref]; x[ref] = reference[ref]
+        x = torch.where(is_ref, reference, x)
         B = x.shape[0]
         for i, t in enumerate(self.noise_scheduler.timesteps.tolist()):
             ts = torch.full((B,), t, dtype=torch.int64, device=x.device)

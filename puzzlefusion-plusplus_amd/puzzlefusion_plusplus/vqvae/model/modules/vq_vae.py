@@ -56,7 +56,9 @@ class VQVAE(nn.Module):
         """fused Denoiser._extract_features (denoiser.py:66-77): rotate by the current noisy
         quaternions, encode the valid fragments, scatter into zero-padded [B,P,L,*] tensors"""
         if slot is None:       # callers that keep part_valids fixed pass the precomputed list (no device->host read)
-            slot = torch.nonzero(part_valids.reshape(-1).bool()).flatten().to(torch.int32)
+            from pfpp_hip.denoiser import layout_of
+
+            slot = layout_of(part_valids, self.cfg.ae.num_point).slot32
         if self.training:
             self._encoder_grad_guard()
             if slot.numel() > 2048:

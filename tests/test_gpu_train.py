@@ -369,3 +369,72 @@ def test_feature_pipeline_equals_inline_encoder(weights_sd, dev):
     # the pipelined run has issued one extra encoder pass (the prefetched 4th batch): compare after the same number of passes is
     # not possible from outside, so only require the buffers to have moved consistently (same direction, similar size)
     assert torch.isfinite(stats[1]).all() and (stats[0] - stats[1]).abs().max() < 0.5 * stats[0].abs().max()
+
+
+@pytest.mark.gpu
+def test_host_side_layout_and_no_device_read_in_the_step(weights_sd, dev):
+    """the valid-fragment layout built on the host by the batch-transfer hooks equals the one read back from the
+    device, a fresh part_valids tensor gets a fresh layout, and a training iteration on a batch whose layout is attached
+    performs no synchronising device->host read (the step can be enqueued ahead of the GPU)"""
+    import warnings
+
+    from pfpp_hip import config, synthetic
+    from pfpp_hip.denoiser import CompactLayout, layout_of
+    from pfpp_hip.train import DenoiserTrainEngine
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).train()
+    for p_ in model.encoder.parameters():
+        p_.requires_grad = False
+    host = synthetic.make_batch(71, 3, num_points=512)
+    batch = model.on_before_batch_transfer(dict(host))
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}      # what Lightning's transfer does
+    batch = model.on_after_batch_transfer(batch)
+    assert "_pfpp_valids_host" not in batch
+    lay = layout_of(batch["part_valids"], 25)
+    want = CompactLayout(batch["part_valids"].clone(), 25)
+    for name in ("slot", "slot32", "frag_b", "frag_p", "seq_len", "seq_off"):
+        assert torch.equal(getattr(lay, name), getattr(want, name)), name
+    assert (lay.Fv, lay.max_len) == (want.Fv, want.max_len)
+    # a different batch -> a different layout; an in-place write to the same tensor invalidates the remembered one
+    other = synthetic.make_batch(72, 3, num_points=512, num_parts=5)["part_valids"].to(dev)
+    assert layout_of(other, 25).Fv == 15
+    other[0, 4] = 0
+    assert layout_of(other, 25).Fv == 14
+
+    eng = DenoiserTrainEngine(model.denoiser)
+    gt = torch.cat([batch["part_trans"], batch["part_rots"]], -1).float().contiguous()
+    noise = torch.randn_like(gt)
+    t = torch.randint(0, 1000, (3,), device=dev)
+
+    def load(seed):
+        b_ = model.on_before_batch_transfer(dict(synthetic.make_batch(seed, 3, num_points=512)))
+        b_ = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b_.items()}
+        return model.on_after_batch_transfer(b_)
+
+    def iteration(b_, seed):
+        gt_ = torch.cat([b_["part_trans"], b_["part_rots"]], -1).float().contiguous()
+        noisy = torch.where(b_["ref_part"].unsqueeze(-1), gt_, model.noise_scheduler.add_noise(gt_, noise, t))
+        with torch.no_grad():
+            latent, xyz = model._extract_features(b_["part_pcs"], b_["part_valids"], noisy)
+        eng.flat.zero_grad()
+        loss_ = eng.loss_and_grads(noisy, t, latent, xyz, b_["part_valids"], b_["part_scale"], b_["ref_part"], noise, seed=seed)
+        eng.optimizer_step()
+        return loss_
+
+    iteration(batch, 0)                       # first call: packing, workspaces
+    fresh = load(73)                          # a NEW batch through the hooks (the H2D copies are outside the checked region)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            loss = iteration(fresh, 1)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    syncs = [f"{x.filename}:{x.lineno} {x.message}" for x in w if "synchroniz" in str(x.message)]
+    assert not syncs, syncs
+    assert torch.isfinite(loss).all()
