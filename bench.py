@@ -141,6 +141,10 @@ class TrainWorkload:
         from pfpp_hip.train import FeaturePipeline
 
         self.pipeline = FeaturePipeline(self.model, dev) if (pipeline and not latents_given) else None
+        # the transformer's dependency chain sets the length of the iteration; the encoder and the weight gradients fill
+        # the chip underneath it from their own streams — so the chain runs on a high-priority stream (10.05 -> 9.9 ms)
+        self._hi = (torch.cuda.Stream(device=dev, priority=-1)
+                    if (pipeline and os.environ.get("PFPP_MAIN_HIGH", "1") == "1") else None)
 
     def _draw(self):
         noise = torch.randn(self.gt.shape, device=self.dev, generator=self.gen)
@@ -148,6 +152,13 @@ class TrainWorkload:
         return noise, t
 
     def step(self):
+        if self._hi is not None:
+            with torch.cuda.stream(self._hi):
+                self._step()
+        else:
+            self._step()
+
+    def _step(self):
         m, d = self.model, self.data
         sch = m.noise_scheduler
         if self.pipeline is not None:
@@ -383,6 +394,9 @@ def main():
             "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
             "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
             "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if train else ""),
+            "variants": {k: {"launches_per_step": round(v[2] / args.steps, 1), "avg_launch_ms": round(v[1] / v[2], 4),
+                             "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
+                         for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
             "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
             "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
         }

@@ -398,6 +398,12 @@ typedef struct pfpp_gemm_grad_args {
   float a_scale, w_scale, alpha;
 } pfpp_gemm_grad_args;
 int pfpp_gemm_grad(const pfpp_gemm_grad_args* args, pfpp_stream_t stream);
+/* Up to 8 independent weight-gradient problems (both operands k-major, batch 1) in ONE launch: the six dW of a transformer
+ * layer (attention.py:60-90: to_q/k/v, to_out, ff.net.0.proj, ff.net.2 of the self- and global-attention blocks) each have
+ * few output tiles and a contraction over all tokens; launched together they fill the chip without cutting K into many
+ * atomically-accumulated chunks.  Replaces what autograd does one Linear at a time (torch.nn.Linear backward,
+ * denoiser_transformer.py:79-101 layers).  split_k of each problem: 0 = chosen for the group. */
+int pfpp_gemm_grad_group(const pfpp_gemm_grad_args* args, int count, pfpp_stream_t stream);
 
 /* out[z, c] (+)= sum_r x[z, r, c]  (bias gradients).  x rows of stride ld, batches of stride sx / so */
 int pfpp_colsum(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld,

@@ -255,7 +255,9 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
   }
 }
 
-template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false>
+// AFF (PF2 variants only): the A operand always carries the fused BatchNorm+ReLU affine — a compile-time property there,
+// because a data-dependent branch in the K loop splits the scheduling region the two-deep prefetch relies on
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false, bool AFF = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_kernel(const GemmP p) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #endif
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
-    if (!PF2 && a_aff) {
+    if (AFF || (!PF2 && a_aff)) {
       s.r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
       s.r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
     }
@@ -388,8 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
       float4 v = s.ra[it];
-      if (!PF2 && a_aff) {      // relu(batch-norm(y)) of the previous layer, applied while the tile is staged (the PF2
-                                // variants are never dispatched with it: no data-dependent branch in their K loop)
+      if (AFF || (!PF2 && a_aff)) {   // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
         v.x = fmaxf(v.x * s.r_mul.x + s.r_add.x, 0.0f); v.y = fmaxf(v.y * s.r_mul.y + s.r_add.y, 0.0f);
         v.z = fmaxf(v.z * s.r_mul.z + s.r_add.z, 0.0f); v.w = fmaxf(v.w * s.r_mul.w + s.r_add.w, 0.0f);
       }
@@ -678,12 +679,12 @@ int launch_f32(const GemmP& p, int batch, hipStream_t st) {
   return launch(gemm_f32_mfma_kernel<MT, NT, WK>, smem, p, BM, BN, batch, st, &attr_set);
 }
 
-template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false>
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false, bool AFF = false>
 int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2, AFF>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
 }
 
 }  // namespace
@@ -774,9 +775,21 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // where the grid still fills the chip, 256x128 for narrower N
     if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
       return launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
+    // train-mode encoder GEMMs (fused BatchNorm operands) run on their own stream UNDER the transformer's latency-bound
+    // kernels: a tile whose LDS footprint leaves room for a second workgroup lets those co-reside (160 KB per CU:
+    // 256x128 = 120 KB blocks a 61 KB transformer tile, 128x128 = 80 KB does not)
+    static const int bn_tile = getenv("PFPP_GEMM_BN_TILE") ? atoi(getenv("PFPP_GEMM_BN_TILE")) : 0;
+    if (pre && wide && fused_bn && bn_tile > 0 && a->M >= 8192) {
+      if (bn_tile == 3) return launch_f16x3<2, 2, true>(p, a->batch, st);     // one K-tile in flight, more workgroups per CU
+      if (bn_tile == 2 && a->pool == 0)
+        return a->a_mul ? launch_f16x3<2, 1, true, 2, 2, true, true>(p, a->batch, st) : launch_f16x3<2, 1, true, 2, 2, true>(p, a->batch, st);
+      return a->a_mul ? launch_f16x3<2, 2, true, 2, 2, true, true>(p, a->batch, st) : launch_f16x3<2, 2, true, 2, 2, true>(p, a->batch, st);
+    }
     static const bool pf2_big = !(getenv("PFPP_GEMM_PF2BIG") && atoi(getenv("PFPP_GEMM_PF2BIG")) == 0);   // 16000x512x2048: 132 -> 111 us
     if (pre && wide && big_tile && a->M >= 8192 && a->pool != 32)
-      return (pf2_big && !fused_bn) ? launch_f16x3<2, 2, true, 4, 2, true>(p, a->batch, st) : launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st);
+      return !pf2_big ? launch_f16x3<2, 2, true, 4, 2>(p, a->batch, st)
+             : a->a_mul ? launch_f16x3<2, 2, true, 4, 2, true, true>(p, a->batch, st)
+                        : launch_f16x3<2, 2, true, 4, 2, true>(p, a->batch, st);
     // small grids: a 128x128 tiling that cannot fill the 2 x 256 workgroup slots twice over runs as 128x64
     // tiles (twice the workgroups, same per-wave work shape) — GEGLU / pool=64 need the 2-tile-wide wave
     static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;

@@ -35,9 +35,11 @@ struct GradP {
   int64_t lda, ldw, ldc;
   int64_t sA, sW, sC;
   int k_chunk;              // K range per blockIdx.y (multiple of BK)
-  int accumulate;
+  int accumulate;           // C += result (else C = result)
+  int atomic;               // the += goes through hardware atomics (several workgroups add into one tile: split_k > 1)
   float a_scale, w_scale, alpha;
   int tiles_n, tiles_m, group_m;
+  int splits;               // grouped launch only: K chunks of this problem
 };
 
 __device__ __forceinline__ void split4s(const float4 v, float s, half4& hi, half4& lo) {
@@ -125,7 +127,7 @@ struct OperandLoader {
 };
 
 template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP p) {
+__device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const int ksplit, const int z) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
@@ -140,7 +142,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  const int tile = remap_tile(blockIdx.x, gridDim.x);
   int tm, tn;
   {
     GemmP g;
@@ -148,11 +149,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
     tile_coords(g, tile, tm, tn);
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z;
   const float* A = p.A + z * p.sA;
   const float* W = p.W + z * p.sW;
   float* C = p.C + z * p.sC;
-  const int kb = blockIdx.y * p.k_chunk;
+  const int kb = ksplit * p.k_chunk;
   const int ke = min(p.K, kb + p.k_chunk);
 
   f32x16 acc[MT][NT];
@@ -277,11 +277,43 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP 
         if (row < p.M) {
           float* dst = C + (int64_t)row * p.ldc + col;
           const float v = acc[i][j][e] * p.alpha;
-          if (p.accumulate) unsafeAtomicAdd(dst, v);
+          if (p.atomic) unsafeAtomicAdd(dst, v);
+          else if (p.accumulate) *dst += v;      // this workgroup is the only writer of the tile in this launch
           else *dst = v;
         }
       }
   }
+}
+
+template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_kernel(const GradP p) {
+  grad_tile<MT, NT, WM, WN, AKM, WKM>(p, remap_tile(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems in ONE launch (the weight gradients of a transformer layer: 6 small outputs, long
+// contractions).  Launched one by one each gives ~1 workgroup per CU unless its K range is split 4-15 ways (atomics, a
+// pipeline fill per chunk); together they fill the chip with long K loops.  The descriptors travel as kernel arguments.
+constexpr int MAX_GROUP = 8;
+struct GradGroup {
+  GradP p[MAX_GROUP];
+  int wg_start[MAX_GROUP + 1];      // first workgroup of problem i (multiples of 8: the XCD round-robin restarts per problem)
+  int count;
+};
+
+template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_grad_group_kernel(const GradGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.count && b >= g.wg_start[i + 1]) ++i;
+  const GradP p = g.p[i];
+  const int local = b - g.wg_start[i];
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int nwg = tiles * p.splits;
+  if (local >= nwg) return;           // padding up to the next multiple of 8
+  // split-major: the `tiles` workgroups of one K chunk are consecutive, remapped so neighbours share an XCD's L2
+  const int ksplit = local / tiles;
+  const int tile = remap_tile(local - ksplit * tiles, tiles);
+  grad_tile<MT, NT, WM, WN, AKM, WKM>(p, tile, ksplit, 0);
 }
 
 template <int MT, int NT, int WM, int WN, bool AKM, bool WKM>
@@ -362,6 +394,8 @@ extern "C" int pfpp_gemm_grad(const pfpp_gemm_grad_args* a, pfpp_stream_t stream
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
   p.sA = a->sA; p.sW = a->sW; p.sC = a->sC;
   p.accumulate = a->accumulate;
+  p.atomic = a->accumulate;     // several launches (micro-batches, streams) may add into one buffer
+  p.splits = 1;
   p.a_scale = a->a_scale; p.w_scale = a->w_scale;
   p.alpha = a->alpha / (a->a_scale * a->w_scale);
   p.k_chunk = 0;
@@ -369,4 +403,75 @@ extern "C" int pfpp_gemm_grad(const pfpp_gemm_grad_args* a, pfpp_stream_t stream
   if (a->a_kmajor) return dispatch<true, true>(p, a->batch, a->split_k, st);
   if (a->w_kmajor) return dispatch<false, true>(p, a->batch, a->split_k, st);
   return dispatch<false, false>(p, a->batch, a->split_k, st);
+}
+
+namespace {
+
+int fill_problem(const pfpp_gemm_grad_args* a, GradP& p) {
+  PFPP_REQUIRE(a->A && a->W && a->C, "null pointer");
+  PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "bad sizes");
+  PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
+  PFPP_REQUIRE(a->lda % 4 == 0 && a->ldw % 4 == 0 && pfpp::aligned16(a->A) && pfpp::aligned16(a->W),
+               "lda/ldw must be multiples of 4 and A/W 16-byte aligned");
+  PFPP_SUPPORTED(a->a_kmajor && a->w_kmajor && a->batch == 1, "grouped launch: weight-gradient form only (both operands k-major, batch 1)");
+  PFPP_REQUIRE(a->M % 4 == 0 && a->lda >= a->M && a->N % 4 == 0 && a->ldw >= a->N, "k-major operands: M, N % 4 != 0 or ld too small");
+  PFPP_REQUIRE(a->ldc >= a->N, "bad ldc");
+  PFPP_REQUIRE(a->a_scale > 0.0f && a->w_scale > 0.0f, "operand scales must be positive");
+  p.A = a->A; p.W = a->W; p.C = a->C;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.sA = p.sW = p.sC = 0;
+  p.accumulate = a->accumulate;
+  p.a_scale = a->a_scale; p.w_scale = a->w_scale;
+  p.alpha = a->alpha / (a->a_scale * a->w_scale);
+  return PFPP_OK;
+}
+
+}  // namespace
+
+extern "C" int pfpp_gemm_grad_group(const pfpp_gemm_grad_args* args, int count, pfpp_stream_t stream) {
+  PFPP_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per grouped launch");
+  constexpr int BM = 128, BN = 128;
+  GradGroup g;
+  int64_t tiles_total = 0;
+  for (int i = 0; i < count; ++i) {
+    const int rc = fill_problem(args + i, g.p[i]);
+    if (rc != PFPP_OK) return rc;
+    GradP& p = g.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.group_m = p.tiles_n > 1 ? 8 : 0;
+    tiles_total += (int64_t)p.tiles_m * p.tiles_n;
+  }
+  // one K split factor for the whole group: enough workgroups for ~2 per CU, chunks at least `min_k` deep
+  static const int target_wg = getenv("PFPP_GRAD_GROUP_WG") ? atoi(getenv("PFPP_GRAD_GROUP_WG")) : 1024;
+  static const int min_k = getenv("PFPP_GRAD_GROUP_MINK") ? atoi(getenv("PFPP_GRAD_GROUP_MINK")) : 640;
+  int start = 0;
+  for (int i = 0; i < count; ++i) {
+    GradP& p = g.p[i];
+    int64_t want = (target_wg + tiles_total / 2) / tiles_total;
+    const int64_t max_by_k = (p.K + min_k - 1) / min_k;
+    if (want > max_by_k) want = max_by_k;
+    if (want < 1 || !p.accumulate) want = 1;              // a plain store cannot be split
+    if (args[i].split_k > 0) want = args[i].split_k;
+    int chunk = (int)((p.K + want - 1) / want);
+    chunk = (chunk + BK - 1) / BK * BK;
+    p.splits = (p.K + chunk - 1) / chunk;
+    p.k_chunk = chunk;
+    PFPP_REQUIRE(p.splits == 1 || p.accumulate, "split_k > 1 needs accumulate (zero-initialised output)");
+    p.atomic = p.splits > 1;
+    g.wg_start[i] = start;
+    start += (p.tiles_m * p.tiles_n * p.splits + 7) & ~7;
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.wg_start[i] = start;
+  g.count = count;
+  constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
+  auto kern = gemm_grad_group_kernel<2, 2, 2, 2, true, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)start), dim3(256), smem, pfpp::as_stream(stream), g);
+  return pfpp::check_launch("pfpp_gemm_grad_group");
 }

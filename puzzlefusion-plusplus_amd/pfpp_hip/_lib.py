@@ -89,6 +89,7 @@ SIGNATURES = {
     "pfpp_quat_to_euler_xyz": [_p, _p, _i64, C.c_int, _p],
     # ---- training (a17)
     "pfpp_gemm_grad": [C.POINTER(GemmGradArgs), _p],
+    "pfpp_gemm_grad_group": [C.POINTER(GemmGradArgs), C.c_int, _p],
     "pfpp_colsum": [_p, _p, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _p],
     "pfpp_dropout": [_p, _p, _p, _i64, _f32, _u64, _u32, _p],
     "pfpp_dropout_mask": [_p, _i64, _f32, _u64, _u32, _p],

@@ -194,7 +194,7 @@ def _split_workspace(device):
 
 
 def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: bool, f16x3: bool = False,
-                     presplit: bool = False, a_presplit: bool = False, fused_bn: bool = False) -> str:
+                     presplit: bool = False, a_presplit: bool = False, fused_bn: bool = False, a_aff: bool = False) -> str:
     """the template instantiation pfpp_gemm dispatches to (mirror of the choice in csrc/gemm.hip with the
     default environment) — used to attribute HIP-event timings to the kernel names rocprofv3 reports"""
     wide = N > 64 or act == "geglu"
@@ -202,17 +202,16 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
         if a_presplit:
             return "gemm_f16x3_ring_kernel<4, true>"
         if presplit and wide and M >= 8192 and N >= 1024 and pool == 0:
-            return "gemm_f16x3_kernel<4, 2, true, 2, 4, false>"
-        pf = "false" if fused_bn else "true"      # two-deep prefetch variants (not with the fused-BatchNorm operands)
+            return "gemm_f16x3_kernel<4, 2, true, 2, 4, false, false>"
         if presplit and wide and M >= 8192 and pool != 32:
-            return f"gemm_f16x3_kernel<2, 2, true, 4, 2, {pf}>"
+            return f"gemm_f16x3_kernel<2, 2, true, 4, 2, true, {'true' if a_aff else 'false'}>"
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
         deep = not fused_bn and tiles128 < 2048
         if presplit and wide and tiles128 < 1024 and act != "geglu" and pool == 0:
-            return f"gemm_f16x3_kernel<2, 1, true, 2, 2, {'true' if deep else 'false'}>"
+            return f"gemm_f16x3_kernel<2, 1, true, 2, 2, {'true' if deep else 'false'}, false>"
         if presplit and deep:
-            return f"gemm_f16x3_kernel<2, {2 if wide else 1}, true, 2, 2, true>"
-        return f"gemm_f16x3_kernel<2, {2 if wide else 1}, {'true' if presplit else 'false'}, 2, 2, false>"
+            return f"gemm_f16x3_kernel<2, {2 if wide else 1}, true, 2, 2, true, false>"
+        return f"gemm_f16x3_kernel<2, {2 if wide else 1}, {'true' if presplit else 'false'}, 2, 2, false, false>"
     return f"gemm_f32_mfma_kernel<2, {2 if wide else 1}, {'true' if w_kmajor else 'false'}>"
 
 
@@ -328,7 +327,7 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         e1.record()
         GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch,
                            gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, planes is not None, a_planes is not None,
-                                            a_affine is not None or stats is not None or c_min is not None),
+                                            a_affine is not None or stats is not None or c_min is not None, a_affine is not None),
                            (M, N, K, batch, act, pool)))
         return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")

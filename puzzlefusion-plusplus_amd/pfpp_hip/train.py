@@ -22,6 +22,7 @@ Design
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -232,8 +233,11 @@ class DenoiserTrainEngine:
         self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges)
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
-        import os
-        self._side = torch.cuda.Stream(device=self.flat.params.device) if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None
+        self._side = (torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
+                      if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None)
+        self._group_dw = os.environ.get("PFPP_TRAIN_GROUP_DW", "0") == "1"
+        self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
+        self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, seed: int = 0,
@@ -358,6 +362,7 @@ class DenoiserTrainEngine:
             T.gemm_grad(da0, w[f"{name}.0.w"].f32, dpooled, M=Fv, N=C, K=da0.shape[1], lda=da0.shape[1], ldw=C, ldc=C,
                         w_kmajor=True, accumulate=True, split_k=1, a_scale=G)
         dh_ = T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
+        self._flush_dw()                                                                  # the heads' four small weight gradients
 
         dmods = torch.zeros_like(s["mods"])
         for i in reversed(range(self.num_layers)):
@@ -370,6 +375,8 @@ class DenoiserTrainEngine:
             self._linear_bwd(dz, lay["n3"], w[f"{i}.ff1.w"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
             dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G)
             del dz
+            if self._group_split:
+                self._flush_dw()                     # the two feed-forward weight gradients go now, the four attention ones at the layer's end
             self._before_inplace_update()
             T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
                             dadd=g[f"{i}.norm3.b"], ld_d=0)
@@ -425,7 +432,16 @@ class DenoiserTrainEngine:
         self._all_done()
 
     def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:
-        """dW += dy^T x, db += colsum(dy) — on the side stream when there is one"""
+        """dW += dy^T x, db += colsum(dy) — on the side stream when there is one.  `guard`: the caller goes on to update
+        dy in place on the main stream.  With PFPP_TRAIN_GROUP_DW=1 the request is only noted here and `_flush_dw` issues
+        all of a layer's weight gradients as one grouped launch (pfpp_gemm_grad_group): 6 % less GPU work per iteration
+        (12.7 -> 12.0 ms with everything on one stream), but the weight gradients then start later and the step, whose
+        length is set by the main stream's dependency chain when they overlap it, does not get shorter — off by default."""
+        if self._group_dw:
+            if guard:
+                dy = dy.clone()                      # the grouped launch runs after the in-place update: keep this version
+            self._pending.append((dy, x, gw, gb))
+            return
         if self._side is None:
             T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
             if gb is not None:
@@ -443,6 +459,29 @@ class DenoiserTrainEngine:
             self._dy_read = torch.cuda.Event()
             self._dy_read.record(self._side)
 
+    def _flush_dw(self) -> None:
+        """issue the noted weight / bias gradients: one grouped GEMM launch per (at most) 8 problems + the column sums"""
+        pend, self._pending = self._pending, []
+        if not pend:
+            return
+
+        def issue():
+            for k in range(0, len(pend), 8):
+                T.grad_weight_group([(dy, x, gw) for dy, x, gw, _ in pend[k:k + 8]], g_scale=self.grad_scale)
+            for dy, _, _, gb in pend:
+                if gb is not None:
+                    T.colsum(dy, gb)
+
+        if self._side is None:
+            issue()
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            issue()
+        for dy, x, _, _ in pend:
+            dy.record_stream(self._side)
+            x.record_stream(self._side)
+
     def _before_inplace_update(self) -> None:
         """the running residual-stream gradient is read by weight-gradient GEMMs on the side stream and then updated in
         place (dx += LayerNorm backward) on the main stream: the update waits for those reads (write-after-read across
@@ -456,6 +495,7 @@ class DenoiserTrainEngine:
     def _layer_done(self, i: int) -> None:
         """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
         from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
+        self._flush_dw()
         if self._exchange.active():
             if self._side is None:
                 self._exchange.layer_done(i)
@@ -467,6 +507,7 @@ class DenoiserTrainEngine:
                 self._exchange.layer_done(i)
 
     def _all_done(self) -> None:
+        self._flush_dw()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._exchange.all_done()
@@ -512,7 +553,7 @@ class FeaturePipeline:
 
     def __init__(self, denoiser_module, device):
         self.model = denoiser_module                  # puzzlefusion_plusplus...Denoiser (encoder + noise_scheduler)
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
         self.pending = None
 
     def _issue(self, data, gt, ref, noise, t):

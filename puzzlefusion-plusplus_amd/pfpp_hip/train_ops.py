@@ -91,6 +91,36 @@ def grad_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, g_scale:
                      a_kmajor=True, w_kmajor=True, accumulate=True, a_scale=g_scale)
 
 
+def grad_weight_group(problems, *, g_scale: float = 1.0) -> None:
+    """[(dY [M,out], X [M,in], dW [out,in]), ...] (at most 8): every dW += dY^T . X in ONE launch (pfpp_gemm_grad_group)"""
+    n = len(problems)
+    if not 1 <= n <= 8:
+        raise ValueError("grad_weight_group: 1..8 problems")
+    arr = (GemmGradArgs * n)()
+    flops = 0.0
+    for a, (dY, X, dW) in zip(arr, problems):
+        _chk(dY, _f32, "dY"); _chk(X, _f32, "X"); _chk(dW, _f32, "dW")
+        M, N_out = dY.shape
+        if X.shape[0] != M or dW.shape[0] != N_out or dW.shape[1] > X.shape[1]:
+            raise ValueError("grad_weight_group: shape mismatch")
+        a.A, a.W, a.C = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
+        a.M, a.N, a.K = N_out, dW.shape[1], M
+        a.lda, a.ldw, a.ldc = dY.stride(0), X.stride(0), dW.stride(0)
+        a.a_kmajor = a.w_kmajor = 1
+        a.accumulate, a.split_k, a.batch = 1, 0, 1
+        a.sA = a.sW = a.sC = 0
+        a.a_scale, a.w_scale, a.alpha = g_scale, 1.0, 1.0
+        flops += 2.0 * N_out * dW.shape[1] * M
+    if ops.GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_gemm_grad_group(arr, n, _stream()), "pfpp_gemm_grad_group")
+        e1.record()
+        ops.GEMM_TRACE.append((e0, e1, flops, "gemm_grad_group_kernel<2, 2, 2, 2, true, true>", (n, int(flops // 1e6), 0, 1, "grad_group", 0)))
+        return
+    check(_lib.load().pfpp_gemm_grad_group(arr, n, _stream()), "pfpp_gemm_grad_group")
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, *, rows: Optional[int] = None, cols: Optional[int] = None,
            ld: Optional[int] = None, batch: int = 1, sx: int = 0, so: int = 0, accumulate: bool = True,
            x_off: int = 0, o_off: int = 0) -> torch.Tensor:
