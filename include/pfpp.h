@@ -169,6 +169,13 @@ typedef struct pfpp_gemm_args {
    * order and runs the epilogue — results are deterministic.  Must not be shared by launches that may overlap.  */
   float* split_ws; int64_t split_ws_bytes;
   int32_t* split_cnt; int64_t split_cnt_len;
+  /* fused grouping (a4 + a5, utils/pn2_utils.py:127-151 followed by the first 1x1 convolution, :210-213): when
+   * gather_idx is set, row r = (f*S + s)*ns + j of the A operand is never materialised — it is read in place as
+   *   [ A[f*gather_N + gather_idx[r], 0:D] | gather_xyz[f, idx] - gather_ctr[f*S + s] | 0 ],  D = lda, K = D + 4
+   * i.e. exactly what pfpp_group_gather writes (A = the level's input features [F*N, D], unused when D = 0).
+   * Needs the f16x3 path with pre-split W, D % 32 == 0, batch 1, no a_mul.  NULL = off.                      */
+  const int32_t* gather_idx; const float* gather_xyz; const float* gather_ctr;
+  int32_t gather_N, gather_S, gather_ns;
 } pfpp_gemm_args;
 
 int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);

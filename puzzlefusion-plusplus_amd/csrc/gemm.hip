@@ -325,7 +325,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int gm = min(m0 + a_row + (NTHR / 8) * it, p.M - 1);
-    a_ptr[it] = A + (int64_t)gm * p.lda + a_c4 * 4;
+    if (p.g_idx) {     // fused grouping: the row lives in the level's feature table at its ball-query index
+      const int id = min(p.g_idx[gm], p.g_N - 1);
+      const int f = gm / (p.g_S * p.g_ns);
+      a_ptr[it] = A + ((int64_t)f * p.g_N + id) * p.lda + a_c4 * 4;
+    } else {
+      a_ptr[it] = A + (int64_t)gm * p.lda + a_c4 * 4;
+    }
   }
   if constexpr (WPRE) {
 #pragma unroll
@@ -363,8 +369,27 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   };
   auto load_tail = [&](Stage& s, int k0) {
+    if (p.g_idx) {
+      // fused grouping: the last 4 columns are the neighbour's offset from its centroid (+ a zero); recomputed from
+      // the row index here so that nothing extra stays live across the K loop
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) s.ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+      for (int it = 0; it < A_IT; ++it) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_c4 == 0) {
+          const int gm = min(m0 + a_row + (NTHR / 8) * it, p.M - 1);
+          const int id = min(p.g_idx[gm], p.g_N - 1);
+          const int fs = gm / p.g_ns;
+          const int f = fs / p.g_S;
+          const float* q = p.g_xyz + ((int64_t)f * p.g_N + id) * 3;
+          const float* c = p.g_ctr + (int64_t)fs * 3;
+          v.x = __fsub_rn(q[0], c[0]); v.y = __fsub_rn(q[1], c[1]); v.z = __fsub_rn(q[2], c[2]);
+        }
+        s.ra[it] = v;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) s.ra[it] = load_k4(a_ptr[it] - a_c4 * 4, k0 + a_c4 * 4, p.K);
+    }
     if constexpr (WPRE) {
       // the planes are zero-padded to a multiple of 8 halfs per row (host packing): whole
       // 16-byte groups are either inside the padded row or skipped
@@ -653,7 +678,7 @@ int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t 
   p.k_chunk = 0;
   static const bool split_on = !(getenv("PFPP_GEMM_SPLITK") && atoi(getenv("PFPP_GEMM_SPLITK")) == 0);
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
-  if (can_split && split_on && p.split_ws && p.split_cnt && tiles < 192 && p.K >= 1024 && p.pool == 0 && !p.stats) {
+  if (can_split && split_on && p.split_ws && p.split_cnt && tiles < 192 && p.K >= 1024 && p.pool == 0 && !p.stats && !p.g_idx) {
     int want = (int)((384 + tiles - 1) / tiles);
     const int max_by_k = p.K / 128;                          // at least 4 K-tiles per chunk
     int splits = want < max_by_k ? want : max_by_k;
@@ -690,7 +715,7 @@ int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
 }  // namespace
 
 extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
-  PFPP_REQUIRE(a && (a->A || (a->a_hi && a->a_lo)) && (a->C || (a->c_hi && a->c_lo)), "null pointer");
+  PFPP_REQUIRE(a && (a->A || (a->a_hi && a->a_lo) || (a->gather_idx && a->lda == 0)) && (a->C || (a->c_hi && a->c_lo)), "null pointer");
   PFPP_REQUIRE(a->W || (a->w_hi && a->w_lo), "W (or its pre-split planes) missing");
   PFPP_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "bad sizes");
   PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
@@ -702,6 +727,12 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     PFPP_REQUIRE(pfpp::aligned16(a->a_hi) && pfpp::aligned16(a->a_lo) && a->sA0 % 8 == 0 && a->sA1 % 8 == 0,
                  "pre-split A planes must be 16-byte aligned");
     PFPP_SUPPORTED(a->N > 64 || a->act == PFPP_ACT_GEGLU, "pre-split A with N <= 64");
+  } else if (a->gather_idx) {
+    PFPP_REQUIRE(a->gather_xyz && a->gather_ctr && a->gather_N > 0 && a->gather_S > 0 && a->gather_ns > 0, "fused grouping: missing tables");
+    PFPP_REQUIRE(a->lda % 32 == 0 && a->K == a->lda + 4 && (a->lda == 0 || pfpp::aligned16(a->A)), "fused grouping: K must be D + 4 with D = lda, D % 32 == 0");
+    PFPP_REQUIRE(a->M % ((int64_t)a->gather_S * a->gather_ns) == 0, "fused grouping: M must be F*S*ns");
+    PFPP_SUPPORTED(a->precision == PFPP_GEMM_F16X3 && a->w_hi && a->batch == 1 && !a->a_mul && !a->w_kmajor,
+                   "fused grouping needs the f16x3 path with pre-split W, batch 1, no fused BatchNorm input");
   } else {
     PFPP_REQUIRE(a->lda % 4 == 0 && pfpp::aligned16(a->A), "lda must be a multiple of 4 and A 16-byte aligned");
     PFPP_REQUIRE(a->lda >= ((a->K + 3) & ~3ll), "lda smaller than K rounded up to 4");
@@ -752,6 +783,8 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.alpha = a->alpha;
   p.a_mul = a->a_mul; p.a_add = a->a_add; p.stats = a->stats; p.stats_copies = a->stats_copies; p.Cmin = a->c_min;
   p.split_ws = a->split_ws; p.split_cnt = a->split_cnt; p.split_k = 1; p.k_chunk = 0;
+  p.g_idx = a->gather_idx; p.g_xyz = a->gather_xyz; p.g_ctr = a->gather_ctr;
+  p.g_N = a->gather_N; p.g_S = a->gather_S; p.g_ns = a->gather_ns;
   p_split_ws_bytes = a->split_ws ? a->split_ws_bytes : 0;
   p_split_cnt_len = a->split_cnt ? a->split_cnt_len : 0;
   p.tiles_n = 0;
@@ -764,9 +797,9 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
     if (apre) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop, no conversions
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
-    if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
+    if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn && !a->gather_idx) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
     static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;
-    if (pre && wide && use_ws && !fused_bn) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
+    if (pre && wide && use_ws && !fused_bn && !a->gather_idx) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
     static const bool big_tile = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
     // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
     // row panels to fill the chip several times over

@@ -31,6 +31,8 @@ struct GemmP {
   // k_chunk; every workgroup parks its accumulators in split_ws, the last one to arrive at a tile (ticket from
   // split_cnt) adds the parked partials in chunk order (deterministic) and runs the normal epilogue
   float* split_ws; int* split_cnt; int split_k; int k_chunk;
+  // fused grouping: row r of A is [A[f*g_N + g_idx[r]] (lda = D floats) | g_xyz[f, idx] - g_ctr[r / g_ns] | 0]
+  const int* g_idx; const float* g_xyz; const float* g_ctr; int g_N, g_S, g_ns;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {

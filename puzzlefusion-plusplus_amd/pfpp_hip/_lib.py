@@ -33,6 +33,8 @@ class GemmArgs(C.Structure):
         ("alpha", _f32),
         ("a_mul", _p), ("a_add", _p), ("stats", _p), ("stats_copies", _i32), ("c_min", _p),
         ("split_ws", _p), ("split_ws_bytes", _i64), ("split_cnt", _p), ("split_cnt_len", _i64),
+        ("gather_idx", _p), ("gather_xyz", _p), ("gather_ctr", _p),
+        ("gather_N", _i32), ("gather_S", _i32), ("gather_ns", _i32),
     ]
 
 

@@ -17,6 +17,9 @@ from .packing import PW, fold_conv_bn, pack_sa_first
 import os as _os
 
 BN_FUSED = _os.environ.get("PFPP_BN_FUSED", "1") == "1"
+# the grouped neighbourhoods [F*S*ns, D+4] are never written out: the first convolution's GEMM gathers its A rows from
+# the level's feature table (pfpp_gemm_args.gather_*); 0 = materialise them with pfpp_group_gather as before
+GATHER_FUSED = _os.environ.get("PFPP_GATHER_FUSED", "1") == "1"
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
@@ -71,7 +74,7 @@ def pack_encoder_train(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[st
     return out
 
 
-def _sa_mlp_train(pk, name: str, A: torch.Tensor, nsample: int) -> torch.Tensor:
+def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=None) -> torch.Tensor:
     """3 x [1x1 conv -> BatchNorm (batch statistics, running buffers updated) -> ReLU], max over nsample
     (utils/pn2_utils.py:210-216 with the module in .train())"""
     from . import train_ops as T
@@ -80,15 +83,18 @@ def _sa_mlp_train(pk, name: str, A: torch.Tensor, nsample: int) -> torch.Tensor:
         # fused form: batch statistics come out of the producing GEMM's epilogue, normalise+ReLU is applied by the
         # consuming GEMM while it stages its A tiles, and the last layer emits per-group max AND min instead of
         # its [rows, C] activation (max_p relu(a*y_p + b) = relu(a*(a >= 0 ? max_p y_p : min_p y_p) + b))
-        rows = A.shape[0]
+        dev = A.device if A is not None else grp[0].device
+        rows = A.shape[0] if A is not None else grp[3].numel()
         h, aff = A, None
         for i in range(3):
             Cout = pk[f"{name}.w{i}"].N
-            st = pk.setdefault(f"{name}.stats{i}", T.bn_stats_buffer(Cout, A.device))
-            if i < 2:
+            st = pk.setdefault(f"{name}.stats{i}", T.bn_stats_buffer(Cout, dev))
+            if i == 0 and A is None:
+                h = ops.grouped_linear(*grp, pk[f"{name}.w0"], pk[f"{name}.b0"], stats=st)
+            elif i < 2:
                 h = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"], a_affine=aff, stats=st)
             else:
-                mn = torch.empty((rows // nsample, Cout), dtype=torch.float32, device=A.device)
+                mn = torch.empty((rows // nsample, Cout), dtype=torch.float32, device=dev)
                 mx = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"], a_affine=aff, stats=st, pool=nsample, c_min=mn)
             aff = T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
                                 momentum=0.1, eps=1e-5)
@@ -110,12 +116,19 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
     F = xyz.shape[0]
     fps_idx, new_xyz = ops.fps(xyz, npoint)
     ball = ops.ball_query(xyz, new_xyz, radius, nsample)
-    A = ops.group_gather(xyz, new_xyz, feats, ball)
+    fused = GATHER_FUSED and ops.GEMM_MODE == "f16x3" and (feats is None or feats.shape[2] % 32 == 0)
+    A = None if fused else ops.group_gather(xyz, new_xyz, feats, ball)
+    grp = (xyz, new_xyz, None if feats is None else feats.contiguous(), ball)
     if pk.get("train", False):
-        h = _sa_mlp_train(pk, name, A, nsample)
+        if fused and not BN_FUSED:
+            A = ops.group_gather(xyz, new_xyz, feats, ball)
+        h = _sa_mlp_train(pk, name, A, nsample, grp)
         del A
     else:
-        h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+        if fused:
+            h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+        else:
+            h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
         del A
         h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu")
         h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)

@@ -222,7 +222,8 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
          ldr: int = 0, act: str = "none", pool: int = 0, w_kmajor: bool = False,
          batch: int = 1, zdiv: int = 1, sA=(0, 0), sW=(0, 0), sC=(0, 0), sV=(0, 0), alpha: float = 1.0,
          a_off: int = 0, w_off: int = 0, c_off: int = 0, mode: Optional[str] = None,
-         a_affine=None, stats: Optional[torch.Tensor] = None, c_min: Optional[torch.Tensor] = None) -> torch.Tensor:
+         a_affine=None, stats: Optional[torch.Tensor] = None, c_min: Optional[torch.Tensor] = None,
+         gather=None) -> torch.Tensor:
     """Raw pfpp_gemm call.  A/W/out are base tensors; *_off are element offsets into them
     (used to address q/k/v slices of a packed projection without copies).  W is an fp32 tensor or a
     packing.PW (fp32 + pre-split fp16 planes); `mode` overrides ops.GEMM_MODE for this call."""
@@ -255,7 +256,10 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         W = W.f32
     if ldw is None:
         ldw = W.shape[-1]
-    if a_planes is None:
+    if gather is not None:
+        if A is not None:
+            _chk(A, torch.float32, "A")
+    elif a_planes is None:
         _chk(A, torch.float32, "A")
     else:
         _chk(a_planes[0], torch.float16, "A.hi"); _chk(a_planes[1], torch.float16, "A.lo")
@@ -316,6 +320,14 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     if c_min is not None:
         _chk(c_min, torch.float32, "c_min")
         args.c_min = c_min.data_ptr()
+    if gather is not None:        # fused grouping: (ball indices [F,S,ns] int32, xyz [F,N,3], centroids [F,S,3])
+        g_idx, g_xyz, g_ctr = gather
+        _chk(g_idx, torch.int32, "gather idx"); _chk(g_xyz, torch.float32, "gather xyz"); _chk(g_ctr, torch.float32, "gather centroids")
+        Fg, Sg, nsg = g_idx.shape
+        if g_xyz.shape[0] != Fg or g_ctr.shape[:2] != (Fg, Sg) or M != Fg * Sg * nsg:
+            raise ValueError("gemm: gather tables do not match M = F*S*ns")
+        args.gather_idx, args.gather_xyz, args.gather_ctr = g_idx.data_ptr(), g_xyz.data_ptr(), g_ctr.data_ptr()
+        args.gather_N, args.gather_S, args.gather_ns = g_xyz.shape[1], Sg, nsg
     ws = _split_workspace(dev_)
     if ws is not None:
         args.split_ws, args.split_ws_bytes = ws[0].data_ptr(), ws[0].numel() * 4
@@ -354,6 +366,20 @@ def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str 
     return gemm(x, w, M=M, N=N, K=K, lda=ldx, bias=bias, scale=scale, shift=shift,
                 residual=residual, ldr=(residual.shape[-1] if residual is not None else 0), act=act, pool=pool,
                 mode=mode, out=out, a_affine=a_affine, stats=stats, c_min=c_min)
+
+
+def grouped_linear(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, w, bias=None, *,
+                   act: str = "none", scale=None, shift=None, pool: int = 0, stats=None) -> torch.Tensor:
+    """first 1x1 convolution of a set-abstraction level applied to the grouped neighbourhoods WITHOUT materialising them:
+    linear(group_gather(xyz, new_xyz, feats, idx), w, ...) with the gather done by the GEMM's A loader
+    (pfpp_gemm_args.gather_*; f16x3 mode, w = packing.PW)."""
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    D = 0 if feats is None else feats.shape[2]
+    if feats is not None and (feats.shape[:2] != (F, N) or not feats.is_contiguous()):
+        raise ValueError("grouped_linear: feats must be a contiguous [F,N,D]")
+    return gemm(None if feats is None else feats.view(F * N, D), w, M=F * S * ns, N=w.N, K=D + 4, lda=D, bias=bias, scale=scale,
+                shift=shift, act=act, pool=pool, stats=stats, gather=(idx, xyz, new_xyz), mode="f16x3")
 
 
 # --------------------------------------------------------------------------- VQ

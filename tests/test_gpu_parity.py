@@ -853,3 +853,36 @@ def test_auto_aggl_batched_equals_single(weights_sd, dev):
         assert s_["steps"] == b_["steps"] and s_["verifier_calls"] == b_["verifier_calls"] and s_["merges"] == b_["merges"]
         assert torch.equal(s_["ref_part"], b_["ref_part"])
         assert (s_["trajectory"] - b_["trajectory"]).abs().max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,S,ns,Nout,pool", [(0, 256, 32, 64, 0), (128, 128, 64, 128, 0), (256, 25, 64, 256, 64), (128, 7, 64, 128, 0)])
+def test_grouped_linear_equals_gather_then_linear(dev, D, S, ns, Nout, pool):
+    """the first set-abstraction convolution with the grouping fused into the GEMM's A loader (pfpp_gemm_args.gather_*)
+    is bit-identical to pfpp_group_gather followed by the same GEMM — eval epilogue (folded BN + ReLU, max-pool) and
+    train epilogue (bias + batch statistics) alike; ragged row count (F*S*ns not a multiple of the tile) included"""
+    from pfpp_hip import ops, train_ops as T
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(D + S)
+    F, N = 5, 300
+    xyz = torch.rand(F, N, 3, generator=g).to(dev)
+    new_xyz = xyz[:, :S].contiguous() if S <= N else None
+    feats = torch.randn(F, N, D, generator=g).to(dev) if D else None
+    idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32).to(dev)
+    idx[0, 0, :3] = N + 5                       # out-of-range ids are clamped (memory safety), same in both paths
+    w = PW((torch.randn(Nout, D + 4, generator=g) * 0.2).to(dev))
+    bias = torch.randn(Nout, generator=g).to(dev)
+    scale = (torch.rand(Nout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Nout, generator=g).to(dev)
+    A = ops.group_gather(xyz, new_xyz, feats, idx)
+    want = ops.linear(A, w, scale=scale, shift=shift, act="relu", pool=pool, mode="f16x3")
+    got = ops.grouped_linear(xyz, new_xyz, feats, idx, w, scale=scale, shift=shift, act="relu", pool=pool)
+    assert torch.equal(got, want)
+    if pool == 0:
+        st_a, st_b = T.bn_stats_buffer(Nout, dev), T.bn_stats_buffer(Nout, dev)
+        want = ops.linear(A, w, bias, stats=st_a, mode="f16x3")
+        got = ops.grouped_linear(xyz, new_xyz, feats, idx, w, bias, stats=st_b)
+        assert torch.equal(got, want)
+        # the statistics are fp64 atomics over 64 copies: same values up to the order of the additions
+        assert torch.allclose(st_a.sum(0), st_b.sum(0), rtol=1e-12, atol=0)
