@@ -180,6 +180,19 @@ typedef struct pfpp_gemm_args {
 
 int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);
 
+/* ---- a4 + a5 + a6 fused, for a set-abstraction level without input features ---------------------------
+ * PointNetSetAbstraction.forward with points = None (utils/pn2_utils.py:197-217; sa1 of PN2,
+ * vqvae/model/modules/pn2.py:16): sample_and_group's centred neighbourhoods (:127-151), three
+ * [1x1 conv -> BatchNorm2d (eval: folded into scale s_i / shift t_i, see pfpp_gemm) -> ReLU] and torch.max over
+ * nsample (:216), in one kernel: out [F*S, C3].  idx = the ball-query result [F,S,ns]; w*_hi / w*_lo = pre-split
+ * fp16 planes of the folded weights [C1, 8] (K = 3 + a zero, padded to 8), [C2, C1], [C3, C2].
+ * Same arithmetic as pfpp_group_gather + 3 x pfpp_gemm(PFPP_GEMM_F16X3).  ns == 32, (C1, C2, C3) == (64, 64, 128). */
+int pfpp_sa_mlp3_fused(const float* xyz, const float* new_xyz, const int32_t* idx,
+                       const void* w0_hi, const void* w0_lo, const void* w1_hi, const void* w1_lo,
+                       const void* w2_hi, const void* w2_lo, const float* s0, const float* t0, const float* s1,
+                       const float* t1, const float* s2, const float* t2, float* out, int64_t F, int64_t N,
+                       int64_t S, int64_t ns, int64_t C1, int64_t C2, int64_t C3, pfpp_stream_t stream);
+
 /* ---- a7/a8: vector quantisation + scatter ----------------------------------
  * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by
  * VQVAE.encode (denoiser/model/modules/encoder.py:20-38): for every

@@ -138,7 +138,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float v = t[e] * alpha;
-        t[e] = scale ? v * sc + sh : v + sh;
+        t[e] = scale ? __builtin_fmaf(v, sc, sh) : v + sh;      // explicit: sa_fused.hip reproduces this epilogue bit for bit
       }
       if (p.stats) {      // BatchNorm batch statistics of the pre-activation (act is NONE on this path)
 #pragma unroll

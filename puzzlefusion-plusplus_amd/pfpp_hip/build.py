@@ -28,6 +28,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_ring.hip": [],
     "gemm_ws.hip": [],
+    "sa_fused.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],

@@ -20,6 +20,8 @@ BN_FUSED = _os.environ.get("PFPP_BN_FUSED", "1") == "1"
 # the grouped neighbourhoods [F*S*ns, D+4] are never written out: the first convolution's GEMM gathers its A rows from
 # the level's feature table (pfpp_gemm_args.gather_*); 0 = materialise them with pfpp_group_gather as before
 GATHER_FUSED = _os.environ.get("PFPP_GATHER_FUSED", "1") == "1"
+# eval mode, first level (no input features): grouping + the three folded conv/BN/ReLU + the max in one kernel
+SA_FUSED = _os.environ.get("PFPP_SA_FUSED", "1") == "1"
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
@@ -124,6 +126,17 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             A = ops.group_gather(xyz, new_xyz, feats, ball)
         h = _sa_mlp_train(pk, name, A, nsample, grp)
         del A
+    elif (SA_FUSED and fused and feats is None and nsample == 32
+          and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (64, 64, 128)):
+        h = ops.sa_mlp3_fused(xyz, new_xyz, ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.w2"], pk[f"{name}.s0"], pk[f"{name}.t0"],
+                              pk[f"{name}.s1"], pk[f"{name}.t1"], pk[f"{name}.s2"], pk[f"{name}.t2"])
+        new_feats = h.view(F, npoint, -1)
+        if capture is not None:
+            capture[f"{name}.fps_idx"] = fps_idx
+            capture[f"{name}.ball_idx"] = ball
+            capture[f"{name}.new_xyz"] = new_xyz
+            capture[f"{name}.new_points"] = new_feats
+        return new_xyz, new_feats
     else:
         if fused:
             h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")

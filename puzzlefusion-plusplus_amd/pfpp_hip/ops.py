@@ -382,6 +382,23 @@ def grouped_linear(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[tor
                 shift=shift, act=act, pool=pool, stats=stats, gather=(idx, xyz, new_xyz), mode="f16x3")
 
 
+def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w0, w1, w2, s0, t0, s1, t1, s2, t2) -> torch.Tensor:
+    """grouping + three folded [conv, BN, ReLU] + max over nsample of a feature-less set-abstraction level in one kernel
+    (pfpp_sa_mlp3_fused); w* = packing.PW, s*/t* the folded BatchNorm scale / shift -> [F*S, C3]"""
+    _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    for t, nm in ((s0, "s0"), (t0, "t0"), (s1, "s1"), (t1, "t1"), (s2, "s2"), (t2, "t2")):
+        _chk(t, torch.float32, nm)
+    if w0.hi.shape != (w0.N, 8) or w1.hi.shape != (w1.N, w0.N) or w2.hi.shape != (w2.N, w1.N):
+        raise ValueError("sa_mlp3_fused: weight planes do not chain ([C1,8], [C2,C1], [C3,C2])")
+    out = torch.empty((F * S, w2.N), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().pfpp_sa_mlp3_fused(_ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi), _ptr(w1.lo),
+                                         _ptr(w2.hi), _ptr(w2.lo), _ptr(s0), _ptr(t0), _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
+                                         _ptr(out), F, N, S, ns, w0.N, w1.N, w2.N, _stream()), "pfpp_sa_mlp3_fused")
+    return out
+
+
 # --------------------------------------------------------------------------- VQ
 def vq_encode(z_e: torch.Tensor, codebook: torch.Tensor, slot: torch.Tensor, n_slots: int,
               z_q: Optional[torch.Tensor] = None, return_codes: bool = False):

@@ -886,3 +886,38 @@ def test_grouped_linear_equals_gather_then_linear(dev, D, S, ns, Nout, pool):
         assert torch.equal(got, want)
         # the statistics are fp64 atomics over 64 copies: same values up to the order of the additions
         assert torch.allclose(st_a.sum(0), st_b.sum(0), rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,N,S", [(3, 300, 256), (1, 64, 5), (7, 1024, 33)])
+def test_sa_mlp3_fused_equals_layerwise(dev, F, N, S):
+    """a4+a5+a6 of a feature-less set-abstraction level in one kernel (pfpp_sa_mlp3_fused) against the layer-by-layer
+    path (group_gather, three GEMMs with folded BatchNorm + ReLU, max-pool epilogue) and a float64 restatement"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(F * 1000 + S)
+    ns = 32
+    xyz = torch.rand(F, N, 3, generator=g)
+    new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
+    idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32)
+    w = [torch.randn(64, 4, generator=g) * 0.5, torch.randn(64, 64, generator=g) * 0.2, torch.randn(128, 64, generator=g) * 0.2]
+    w[0][:, 3] = 0.0
+    sc = [torch.rand(c, generator=g) + 0.5 for c in (64, 64, 128)]
+    sh = [torch.randn(c, generator=g) * 0.3 for c in (64, 64, 128)]
+    d = lambda t: t.to(dev)
+    pw = [PW(d(x)) for x in w]
+    A = ops.group_gather(d(xyz), d(new_xyz), None, d(idx))
+    h = ops.linear(A, pw[0], scale=d(sc[0]), shift=d(sh[0]), act="relu", mode="f16x3")
+    h = ops.linear(h, pw[1], scale=d(sc[1]), shift=d(sh[1]), act="relu", mode="f16x3")
+    want = ops.linear(h, pw[2], scale=d(sc[2]), shift=d(sh[2]), act="relu", pool=ns, mode="f16x3")
+    got = ops.sa_mlp3_fused(d(xyz), d(new_xyz), d(idx), *pw, d(sc[0]), d(sh[0]), d(sc[1]), d(sh[1]), d(sc[2]), d(sh[2]))
+    assert got.shape == want.shape == (F * S, 128)
+    assert torch.equal(got, want)             # same operand split, same products in the same order, same epilogue: bit-identical
+    # float64 restatement
+    grp = torch.gather(xyz.double().unsqueeze(1).expand(F, S, N, 3), 2, idx.long().unsqueeze(-1).expand(F, S, ns, 3)) - new_xyz.double().unsqueeze(2)
+    y = grp.reshape(-1, 3)
+    for i in range(3):
+        y = torch.relu(y @ w[i][:, : y.shape[1]].double().t() * sc[i].double() + sh[i].double())
+    ref = y.reshape(F * S, ns, 128).amax(1)
+    assert (got.double().cpu() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
