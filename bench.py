@@ -41,6 +41,30 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 (split-f16 path: 3 matr
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel: str, mode: str = "train"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/*_pmc_FETCH_SIZE.csv and
+    *_pmc_WRITE_SIZE.csv of the same bench mode, newest round first; separate --pmc runs of this bench, tools/diag/prof_pmc.sh).  The counters are in
+    KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section).  -> (bytes or None, description)"""
+    import csv
+    import glob
+
+    prof = os.path.join(ROOT, "profiles")
+    for fetch in sorted(glob.glob(os.path.join(prof, f"*_bench_{mode}_pmc_FETCH_SIZE.csv")), reverse=True):
+        write = fetch.replace("FETCH_SIZE", "WRITE_SIZE")
+        if not os.path.exists(write):
+            continue
+        vals = {}
+        for path, key in ((fetch, "fetch"), (write, "write")):
+            with open(path, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel in row["kernel"]:
+                        vals[key] = float(row["mean_value_per_dispatch"])
+        if len(vals) == 2:
+            return (int((2.0 * vals["fetch"] + vals["write"]) * 1024),
+                    f"{os.path.basename(fetch)} (x2, gfx950) + {os.path.basename(write)}, mean per dispatch")
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,9 +410,10 @@ def main():
         # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
         # FLOPs is the f16 dense peak / 3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = pmc_traffic(name, "train" if train else "sampler")
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product"
                           if split else "fp32 MFMA dense peak"),
             "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
