@@ -245,14 +245,22 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const GemmP p) {
 // =================================================================================================
 // split-f16 x3 path
 // =================================================================================================
+// hi = f16(x), lo = f16(x - hi), two elements at a time so that every step is one packed instruction
+// (v_cvt_pk_f16_f32, 2 x v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32: 2.5 VALU per element instead of 4.3 — the
+// element-wise form made the compiler convert every value twice)
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(const float2v x, half2v& hi, half2v& lo) {
+  hi = __builtin_convertvector(x, half2v);
+  const float2v back = __builtin_convertvector(hi, float2v);
+  lo = __builtin_convertvector(x - back, half2v);
+}
 __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 h = (_Float16)x[e];
-    hi[e] = h;
-    lo[e] = (_Float16)(x[e] - (float)h);
-  }
+  half2v h0, l0, h1, l1;
+  split2(float2v{v.x, v.y}, h0, l0);
+  split2(float2v{v.z, v.w}, h1, l1);
+  hi = half4{h0[0], h0[1], h1[0], h1[1]};
+  lo = half4{l0[0], l0[1], l1[0], l1[1]};
 }
 
 // AFF (PF2 variants only): the A operand always carries the fused BatchNorm+ReLU affine — a compile-time property there,

@@ -12,12 +12,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 CSRC = ROOT / "puzzlefusion-plusplus_amd" / "csrc"
 OUT = ROOT / "tools" / "diag" / "ablate_build"
-VARIANTS = {0: "baseline", 100: "hoisted fragment reads (-DPFPP_HOIST=1)"}
+VARIANTS = {0: "baseline", 1: "global loads of the first K-tile only", 4: "no split / LDS stores", 5: "no loads, no stores", 6: "no loads, no stores, no barrier"}
 
 
 def build():
     OUT.mkdir(parents=True, exist_ok=True)
-    objs = [str(CSRC / "build" / f"{n}.o") for n in ("lib", "pointops", "vq", "transformer_ops", "attention", "edgefeat", "gemm_ring", "gemm_ws",
+    objs = [str(CSRC / "build" / f"{n}.o") for n in ("lib", "pointops", "vq", "transformer_ops", "attention", "edgefeat", "gemm_ring", "gemm_ws", "sa_fused",
                                                        "gemm_grad", "train_ops", "attention_bwd", "bn_train", "metrics", "merge", "augment")]
     for v in VARIANTS:
         o = OUT / f"gemm_{v}.o"
@@ -39,7 +39,7 @@ import torch
 from pfpp_hip import ops
 from pfpp_hip.packing import PW
 dev = torch.device('cuda:0')
-for M, N, K in ((16000, 4096, 512), (16000, 512, 2048), (16000, 1536, 512), (3850, 1536, 512), (3850, 512, 2048), (1261568, 128, 128)):
+for M, N, K in ((3850, 512, 512), (3850, 1536, 512), (3850, 512, 2048), (3850, 4096, 512), (16000, 512, 2048)):
     A = torch.randn(M, K, device=dev); pw = PW(torch.randn(N, K, device=dev) * 0.05)
     for _ in range(3): ops.linear(A, pw)
     torch.cuda.synchronize()
