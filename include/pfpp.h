@@ -193,6 +193,17 @@ int pfpp_sa_mlp3_fused(const float* xyz, const float* new_xyz, const int32_t* id
                        const float* t1, const float* s2, const float* t2, float* out, int64_t F, int64_t N,
                        int64_t S, int64_t ns, int64_t C1, int64_t C2, int64_t C3, pfpp_stream_t stream);
 
+/* Same for a level WITH input features (sa2 of PN2, pn2.py:17): grouping (pn2_utils.py:127-151, rows
+ * [feats[f, idx] (D) | xyz[f, idx] - new_xyz (3)]) and the FIRST TWO [1x1 conv -> BatchNorm2d(eval, folded) -> ReLU]
+ * (:210-213) in one kernel: out [F*S*ns, C2] = the input of the level's third convolution (then pfpp_gemm with
+ * pool = ns).  w0 planes [C1, D + 8] in the column order of pfpp_group_gather (features first), w1 planes [C2, C1].
+ * ns == 64, D == C1 == C2 == 128. */
+int pfpp_sa_mlp2_fused(const float* feats, const float* xyz, const float* new_xyz, const int32_t* idx,
+                       const void* w0_hi, const void* w0_lo, const void* w1_hi, const void* w1_lo,
+                       const float* s0, const float* t0, const float* s1, const float* t1, float* out,
+                       int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
+                       pfpp_stream_t stream);
+
 /* ---- a7/a8: vector quantisation + scatter ----------------------------------
  * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by
  * VQVAE.encode (denoiser/model/modules/encoder.py:20-38): for every

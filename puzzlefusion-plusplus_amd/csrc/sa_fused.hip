@@ -233,6 +233,221 @@ __global__ __launch_bounds__(256, 1) void sa_mlp3_kernel(const SaP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Level with input features (sa2: 128 features + 3 coordinates -> 128 -> 128, nsample 64): grouping + the FIRST TWO folded
+// conv/BN/ReLU in one kernel; the third layer (its 256 x 128 weights no longer fit next to the others) stays a GEMM with the
+// max-pool epilogue.  Same scheme as above — a wave owns one neighbourhood (two 32-sample tiles), both layers transposed,
+// accumulator -> operand fragment through the lane exchange — but the weights (147 KB of fp16 planes) sit in LDS, shared by
+// the 4 waves of the one workgroup a CU holds, and the sample operand of layer 1 is read straight from the level's feature
+// table: every lane fetches the 32-byte runs of ITS neighbour's row (by ball-query index) into registers and splits them
+// there; the rows of the next neighbourhood are in flight while layer 2 of the current one computes.
+// Removes the 646 MB write + 646 MB read of the first layer's activations (and the gather pass before it).
+struct Sa2P {
+  const float* feats; const float* xyz; const float* ctr; const int32_t* idx;
+  const _Float16* w0h; const _Float16* w0l; const _Float16* w1h; const _Float16* w1l;
+  const float* s0; const float* t0; const float* s1; const float* t1;
+  float* out;        // [G*64, C2]
+  int N, S, G;
+};
+
+template <int D, int C1, int C2>
+__global__ __launch_bounds__(256, 1) void sa_mlp2_kernel(const Sa2P p) {
+  constexpr int KS0 = D / 16 + 1;                 // 16-deep steps of layer 1: the features, then [dx dy dz 0 ...]
+  constexpr int KP0 = D + 8;                      // row length of the layer-1 planes in memory (K = D + 3, padded to 8)
+  constexpr int LD0 = KS0 * 16 + 8, LD1 = C1 + 8; // LDS row strides in halfs (16-byte fragment reads conflict-free)
+  extern __shared__ __align__(16) unsigned char sa2_smem[];
+  _Float16* W0h = reinterpret_cast<_Float16*>(sa2_smem);
+  _Float16* W0l = W0h + C1 * LD0;
+  _Float16* W1h = W0l + C1 * LD0;
+  _Float16* W1l = W1h + C2 * LD1;
+  float* S0 = reinterpret_cast<float*>(W1l + C2 * LD1);
+  float* T0 = S0 + C1;
+  float* S1 = T0 + C1;
+  float* T1 = S1 + C2;
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C1 * (LD0 / 8); i += 256) {
+    const int r = i / (LD0 / 8), c8 = i - r * (LD0 / 8);
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+    if (c8 * 8 < KP0) {
+      vh = *reinterpret_cast<const uint4*>(p.w0h + (size_t)r * KP0 + c8 * 8);
+      vl = *reinterpret_cast<const uint4*>(p.w0l + (size_t)r * KP0 + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(W0h + r * LD0 + c8 * 8) = vh;
+    *reinterpret_cast<uint4*>(W0l + r * LD0 + c8 * 8) = vl;
+  }
+  for (int i = tid; i < C2 * (C1 / 8); i += 256) {
+    const int r = i / (C1 / 8), c8 = i - r * (C1 / 8);
+    *reinterpret_cast<uint4*>(W1h + r * LD1 + c8 * 8) = *reinterpret_cast<const uint4*>(p.w1h + (size_t)r * C1 + c8 * 8);
+    *reinterpret_cast<uint4*>(W1l + r * LD1 + c8 * 8) = *reinterpret_cast<const uint4*>(p.w1l + (size_t)r * C1 + c8 * 8);
+  }
+  for (int i = tid; i < C1; i += 256) { S0[i] = p.s0[i]; T0[i] = p.t0[i]; }
+  for (int i = tid; i < C2; i += 256) { S1[i] = p.s1[i]; T1[i] = p.t1[i]; }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  auto bn_relu_t = [&](f32x16 acc, const float* sc, const float* sh, int c0) {
+    f32x16 y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 s4 = *reinterpret_cast<const float4*>(sc + c0 + 8 * q + 4 * lhi);
+      const float4 t4 = *reinterpret_cast<const float4*>(sh + c0 + 8 * q + 4 * lhi);
+      const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = __builtin_fmaf(acc[4 * q + r], sv[r], tv[r]);
+        y[4 * q + r] = v > 0.0f ? v : 0.0f;
+      }
+    }
+    return y;
+  };
+  auto split8 = [&](const float4 a, const float4 b, half8& hi, half8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      _Float16 h, l;
+      split1(x[q], h, l);
+      hi[q] = h; lo[q] = l;
+    }
+  };
+
+  const int stride = gridDim.x * 4;
+  const int g0 = blockIdx.x * 4 + wave;
+  auto load_ids = [&](int g, int (&id)[2]) {
+    const int gc = g < p.G ? g : p.G - 1;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int v = p.idx[(int64_t)gc * 64 + st * 32 + l31];
+      id[st] = v < p.N ? v : p.N - 1;               // memory safety only, as in group_gather_kernel
+    }
+  };
+  // this lane's part of its two samples' feature rows: for every 16-deep step the 8 values at 8*lhi
+  auto load_rows = [&](int g, const int (&id)[2], float4 (&raw)[2][D / 16][2], float (&q)[2][3], float (&c)[3]) {
+    const int gc = g < p.G ? g : p.G - 1;
+    const int f = gc / p.S;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const float* row = p.feats + ((int64_t)f * p.N + id[st]) * D + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        raw[st][ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[st][ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+      const float* q3 = p.xyz + ((int64_t)f * p.N + id[st]) * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) q[st][d] = q3[d];
+    }
+    const float* c3 = p.ctr + (int64_t)gc * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = c3[d];
+  };
+
+  float4 raw[2][D / 16][2];
+  float qx[2][3], cx[3];
+  int id_nxt[2];
+  {
+    int id0[2];
+    load_ids(g0, id0);
+    load_rows(g0, id0, raw, qx, cx);
+    load_ids(g0 + stride, id_nxt);
+  }
+
+  for (int g = g0; g < p.G; g += stride) {
+    // the weight fragments are loop-invariant LDS reads: without this fence the compiler hoists all 544 registers' worth
+    // of them out of the loop and spills
+    asm volatile("" ::: "memory");
+    // ---- layer 1 (transposed): [C1 x (D+3)] . [(D+3) x 64 samples] ----
+    f32x16 acc[C1 / 32][2];
+#pragma unroll
+    for (int t = 0; t < C1 / 32; ++t)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][st][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS0; ++ks) {
+      half8 xh[2], xl[2];
+      if (ks < D / 16) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) split8(raw[st][ks < D / 16 ? ks : 0][0], raw[st][ks < D / 16 ? ks : 0][1], xh[st], xl[st]);
+      } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { xh[st][q] = (_Float16)0.0f; xl[st][q] = (_Float16)0.0f; }
+          if (lhi == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              _Float16 a, b;
+              split1(__fsub_rn(qx[st][d], cx[d]), a, b);
+              xh[st][d] = a; xl[st][d] = b;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < C1 / 32; ++t) {
+        const half8 wh = *reinterpret_cast<const half8*>(W0h + (t * 32 + l31) * LD0 + ks * 16 + lhi * 8);
+        const half8 wl = *reinterpret_cast<const half8*>(W0l + (t * 32 + l31) * LD0 + ks * 16 + lhi * 8);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[st], acc[t][st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[st], acc[t][st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[st], acc[t][st], 0, 0, 0);
+      }
+    }
+    // the feature rows are consumed: fetch the next neighbourhood's while layer 2 computes
+    {
+      int id_cur[2] = {id_nxt[0], id_nxt[1]};
+      load_rows(g + stride, id_cur, raw, qx, cx);
+      load_ids(g + 2 * stride, id_nxt);
+    }
+    half8 f1h[C1 / 16][2], f1l[C1 / 16][2];
+#pragma unroll
+    for (int t = 0; t < C1 / 32; ++t)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const f32x16 y = bn_relu_t(acc[t][st], S0, T0, t * 32);
+        half8 fh[2], fl[2];
+        tile_to_fragments(y, lhi, fh, fl);
+        f1h[2 * t][st] = fh[0]; f1h[2 * t + 1][st] = fh[1];
+        f1l[2 * t][st] = fl[0]; f1l[2 * t + 1][st] = fl[1];
+      }
+
+    // ---- layer 2 (transposed): [C2 x C1] . [C1 x 64 samples], written out as rows of [samples, C2] ----
+#pragma unroll
+    for (int t = 0; t < C2 / 32; ++t) {
+      f32x16 a2[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a2[st][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < C1 / 16; ++ks) {
+        const half8 wh = *reinterpret_cast<const half8*>(W1h + (t * 32 + l31) * LD1 + ks * 16 + lhi * 8);
+        const half8 wl = *reinterpret_cast<const half8*>(W1l + (t * 32 + l31) * LD1 + ks * 16 + lhi * 8);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f1l[ks][st], a2[st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, f1h[ks][st], a2[st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, f1h[ks][st], a2[st], 0, 0, 0);
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const f32x16 y = bn_relu_t(a2[st], S1, T1, t * 32);
+        float* orow = p.out + ((int64_t)g * 64 + st * 32 + l31) * C2 + t * 32 + 4 * lhi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(orow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pfpp_sa_mlp3_fused(const float* xyz, const float* new_xyz, const int32_t* idx,
@@ -259,3 +474,36 @@ extern "C" int pfpp_sa_mlp3_fused(const float* xyz, const float* new_xyz, const 
   hipLaunchKernelGGL((sa_mlp3_kernel<64, 64, 128>), dim3(grid), dim3(256), 0, pfpp::as_stream(stream), p);
   return pfpp::check_launch("pfpp_sa_mlp3_fused");
 }
+
+extern "C" int pfpp_sa_mlp2_fused(const float* feats, const float* xyz, const float* new_xyz, const int32_t* idx,
+                                  const void* w0_hi, const void* w0_lo, const void* w1_hi, const void* w1_lo,
+                                  const float* s0, const float* t0, const float* s1, const float* t1, float* out,
+                                  int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
+                                  pfpp_stream_t stream) {
+  PFPP_REQUIRE(feats && xyz && new_xyz && idx && w0_hi && w0_lo && w1_hi && w1_lo && s0 && t0 && s1 && t1 && out, "null pointer");
+  PFPP_REQUIRE(F >= 0 && N > 0 && S > 0, "bad sizes");
+  PFPP_SUPPORTED(ns == 64 && D == 128 && C1 == 128 && C2 == 128, "fused set-abstraction layers 1+2: nsample 64, 128 features, widths 128/128 only");
+  PFPP_REQUIRE(F * S < (1ll << 25), "too many neighbourhoods");
+  PFPP_REQUIRE(pfpp::aligned16(feats) && pfpp::aligned16(w0_hi) && pfpp::aligned16(w0_lo) && pfpp::aligned16(w1_hi) && pfpp::aligned16(w1_lo) &&
+               pfpp::aligned16(out), "16-byte alignment");
+  if (F == 0) return PFPP_OK;
+  Sa2P p;
+  p.feats = feats; p.xyz = xyz; p.ctr = new_xyz; p.idx = idx;
+  p.w0h = (const _Float16*)w0_hi; p.w0l = (const _Float16*)w0_lo; p.w1h = (const _Float16*)w1_hi; p.w1l = (const _Float16*)w1_lo;
+  p.s0 = s0; p.t0 = t0; p.s1 = s1; p.t1 = t1;
+  p.out = out;
+  p.N = (int)N; p.S = (int)S; p.G = (int)(F * S);
+  constexpr int d = 128, c1 = 128, c2 = 128;
+  constexpr size_t smem = (size_t)2 * (c1 * ((d / 16 + 1) * 16 + 8) + c2 * (c1 + 8)) * sizeof(_Float16) + (size_t)2 * (c1 + c2) * sizeof(float);
+  auto kern = sa_mlp2_kernel<d, c1, c2>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int64_t wgs_needed = (p.G + 3) / 4;
+  const unsigned grid = (unsigned)(wgs_needed < 256 ? wgs_needed : 256);      // persistent: one 4-wave workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, pfpp::as_stream(stream), p);
+  return pfpp::check_launch("pfpp_sa_mlp2_fused");
+}
+

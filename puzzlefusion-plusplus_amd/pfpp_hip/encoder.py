@@ -137,6 +137,19 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             capture[f"{name}.new_xyz"] = new_xyz
             capture[f"{name}.new_points"] = new_feats
         return new_xyz, new_feats
+    elif (SA_FUSED and fused and feats is not None and nsample == 64 and feats.shape[2] == 128
+          and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N) == (128, 128)):
+        # level 2: grouping + layers 1 and 2 in one kernel, layer 3 (+ max over nsample) as a GEMM
+        h = ops.sa_mlp2_fused(xyz, new_xyz, grp[2], ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.s0"], pk[f"{name}.t0"],
+                              pk[f"{name}.s1"], pk[f"{name}.t1"])
+        h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
+        new_feats = h.view(F, npoint, -1)
+        if capture is not None:
+            capture[f"{name}.fps_idx"] = fps_idx
+            capture[f"{name}.ball_idx"] = ball
+            capture[f"{name}.new_xyz"] = new_xyz
+            capture[f"{name}.new_points"] = new_feats
+        return new_xyz, new_feats
     else:
         if fused:
             h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")

@@ -399,6 +399,24 @@ def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w
     return out
 
 
+def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, w1, s0, t0, s1, t1) -> torch.Tensor:
+    """grouping + the first two folded [conv, BN, ReLU] of a set-abstraction level with input features in one kernel
+    (pfpp_sa_mlp2_fused) -> [F*S*ns, C2], the input of the level's third convolution"""
+    _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx"); _chk(feats, torch.float32, "feats")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    D = feats.shape[2]
+    for t, nm in ((s0, "s0"), (t0, "t0"), (s1, "s1"), (t1, "t1")):
+        _chk(t, torch.float32, nm)
+    if feats.shape[:2] != (F, N) or w0.hi.shape != (w0.N, D + 8) or w1.hi.shape != (w1.N, w0.N):
+        raise ValueError("sa_mlp2_fused: shapes do not chain (feats [F,N,D], w0 planes [C1,D+8], w1 planes [C2,C1])")
+    out = torch.empty((F * S * ns, w1.N), dtype=torch.float32, device=xyz.device)
+    check(_lib.load().pfpp_sa_mlp2_fused(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi), _ptr(w1.lo),
+                                         _ptr(s0), _ptr(t0), _ptr(s1), _ptr(t1), _ptr(out), F, N, S, ns, D, w0.N, w1.N, _stream()),
+          "pfpp_sa_mlp2_fused")
+    return out
+
+
 # --------------------------------------------------------------------------- VQ
 def vq_encode(z_e: torch.Tensor, codebook: torch.Tensor, slot: torch.Tensor, n_slots: int,
               z_q: Optional[torch.Tensor] = None, return_codes: bool = False):

@@ -921,3 +921,38 @@ def test_sa_mlp3_fused_equals_layerwise(dev, F, N, S):
         y = torch.relu(y @ w[i][:, : y.shape[1]].double().t() * sc[i].double() + sh[i].double())
     ref = y.reshape(F * S, ns, 128).amax(1)
     assert (got.double().cpu() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,N,S", [(3, 256, 128), (1, 64, 3), (5, 300, 37)])
+def test_sa_mlp2_fused_equals_layerwise(dev, F, N, S):
+    """grouping + the first two conv/BN/ReLU of a level with 128 input features in one kernel (pfpp_sa_mlp2_fused) against
+    group_gather + two GEMMs (bit-identical) and a float64 restatement"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, pack_sa_first
+
+    g = torch.Generator().manual_seed(F * 100 + S)
+    ns, D = 64, 128
+    xyz = torch.rand(F, N, 3, generator=g)
+    feats = torch.randn(F, N, D, generator=g)
+    new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
+    idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32)
+    w0_ref = torch.randn(128, D + 3, generator=g) * 0.1              # reference column order: [xyz | feats]
+    w1 = torch.randn(128, 128, generator=g) * 0.1
+    sc = [torch.rand(128, generator=g) + 0.5 for _ in range(2)]
+    sh = [torch.randn(128, generator=g) * 0.3 for _ in range(2)]
+    d = lambda t: t.to(dev)
+    pw0, pw1 = PW(d(pack_sa_first(w0_ref, D))), PW(d(w1))
+    A = ops.group_gather(d(xyz), d(new_xyz), d(feats), d(idx))
+    h = ops.linear(A, pw0, scale=d(sc[0]), shift=d(sh[0]), act="relu", mode="f16x3")
+    want = ops.linear(h, pw1, scale=d(sc[1]), shift=d(sh[1]), act="relu", mode="f16x3")
+    got = ops.sa_mlp2_fused(d(xyz), d(new_xyz), d(feats), d(idx), pw0, pw1, d(sc[0]), d(sh[0]), d(sc[1]), d(sh[1]))
+    assert got.shape == want.shape == (F * S * ns, 128)
+    assert torch.equal(got, want)
+    ii = idx.long()
+    gx = torch.gather(xyz.double().unsqueeze(1).expand(F, S, N, 3), 2, ii.unsqueeze(-1).expand(F, S, ns, 3)) - new_xyz.double().unsqueeze(2)
+    gf = torch.gather(feats.double().unsqueeze(1).expand(F, S, N, D), 2, ii.unsqueeze(-1).expand(F, S, ns, D))
+    y = torch.cat([gx, gf], -1).reshape(-1, D + 3)
+    y = torch.relu(y @ w0_ref.double().t() * sc[0].double() + sh[0].double())
+    y = torch.relu(y @ w1.double().t() * sc[1].double() + sh[1].double())
+    assert (got.double().cpu() - y).abs().max().item() < 2e-5 * y.abs().max().item()
