@@ -351,7 +351,7 @@ def main():
         wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given,
                            pipeline=not (args.no_pipeline or args.serial))
         if args.serial:
-            wl.engine._side = None
+            wl.engine.single_stream()
     else:
         wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
     for _ in range(args.warmup):
@@ -384,7 +384,7 @@ def main():
         if train:
             # per-kernel durations are taken with the streams serialised (no side stream, encoder in line): bracketing
             # events on a stream that shares the chip with another stream measure the contention too, not the kernel
-            wl.engine._side = None
+            wl.engine.single_stream()
             wl.pipeline = None
             wl.step()
             torch.cuda.synchronize(dev)

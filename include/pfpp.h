@@ -494,6 +494,12 @@ int pfpp_attn_dense_bwd(const float* qkv, const float* out, const float* dout, c
                         float* dvec /* workspace [rows, H] */, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
                         const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
                         int64_t H, int64_t dh, float scale, pfpp_stream_t stream);
+/* the same in separately launchable parts (bit 0: D = rowsum(dout . out) -> dvec, bit 1: dq, bit 2: dk/dv): once D is
+ * there dq and dk/dv are independent (disjoint columns of dqkv) and may be issued on two streams.               */
+int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, const float* dout, const float* lse,
+                              float* dvec, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
+                              const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                              int64_t H, int64_t dh, float scale, int parts, pfpp_stream_t stream);
 
 /* ---- small backward pieces ----------------------------------------------------------------------------
  * mean_pool_bwd:   dx[(f,l), :] = dpooled[f, :] / L                         (denoiser_transformer.py:139-142)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_kernel(
   }
   const float Dq = dpart + __shfl_xor(dpart, 32);
   const float lse_q = lse[(row0 + q_cl) * H + h];
-  if (q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
+  if (dvec && q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
 
   f32x16 dq_acc[NDT];
 #pragma unroll
@@ -157,6 +157,36 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_kernel(
         *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
             make_float4(dq_acc[dt][4 * g + 0], dq_acc[dt][4 * g + 1], dq_acc[dt][4 * g + 2], dq_acc[dt][4 * g + 3]);
   }
+}
+
+// D[row, h] = sum_d dO . O alone (same lane mapping and summation order as in pass 1, hence the same bits): with D
+// precomputed, pass 1 and pass 2 no longer depend on each other and can run on two streams
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dense_bwd_d_kernel(
+    const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dvec,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H) {
+  constexpr int NCH = DH / 8;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 128;
+  if (q_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int q_row = q_base + wave * 32 + l31;
+  const int q_cl = min(q_row, T - 1);
+  const float* op = out + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+  const float* dop = dout + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+  float dpart = 0.0f;
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+    const float4 d = *reinterpret_cast<const float4*>(dop + kc * 8);
+    const float4 o = *reinterpret_cast<const float4*>(op + kc * 8);
+    dpart += (d.x * o.x + d.y * o.y) + (d.z * o.z + d.w * o.w);
+  }
+  const float Dq = dpart + __shfl_xor(dpart, 32);
+  if (q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -433,3 +463,36 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
   }
   return pfpp::check_launch(__func__);
 }
+
+// The same backward in separately launchable parts (bit 0: D = rowsum(dO . O) -> dvec, bit 1: dq, bit 2: dk/dv), so that a
+// caller can put dq and dk/dv on two streams once D is there (they write disjoint columns of dqkv).
+extern "C" int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, const float* dout, const float* lse,
+                                         float* dvec, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
+                                         const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                                         int64_t H, int64_t dh, float scale, int parts, pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out && dout && lse && dvec && dqkv && seq_off && seq_len, "null pointer");
+  PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1 && parts >= 1 && parts <= 7, "bad sizes / parts");
+  PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
+  PFPP_SUPPORTED(n_seq <= 65535 && H <= 65535, "too many sequences / heads for one launch");
+  PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(out) && pfpp::aligned16(dout) && pfpp::aligned16(dqkv),
+               "16-byte alignment");
+  if (n_seq == 0) return PFPP_OK;
+  const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
+  hipStream_t st = pfpp::as_stream(stream);
+  const int Hi = (int)H;
+  if (dh == 64) {
+    if (parts & 1) hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
+    if (parts & 2) hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<64>, grid, dim3(256), 0, st, qkv, out, dout, lse, (float*)nullptr, dqkv,
+                                      seq_off, seq_len, key_valid, kv_stride, Hi, scale);
+    if (parts & 4) hipLaunchKernelGGL(attn_dense_bwd_dkv_kernel<64>, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
+                                      seq_len, key_valid, kv_stride, Hi, scale);
+  } else {
+    if (parts & 1) hipLaunchKernelGGL(attn_dense_bwd_d_kernel<32>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
+    if (parts & 2) hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<32>, grid, dim3(256), 0, st, qkv, out, dout, lse, (float*)nullptr, dqkv,
+                                      seq_off, seq_len, key_valid, kv_stride, Hi, scale);
+    if (parts & 4) hipLaunchKernelGGL(attn_dense_bwd_dkv_kernel<32>, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
+                                      seq_len, key_valid, kv_stride, Hi, scale);
+  }
+  return pfpp::check_launch(__func__);
+}
+

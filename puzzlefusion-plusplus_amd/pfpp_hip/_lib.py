@@ -105,6 +105,7 @@ SIGNATURES = {
     "pfpp_attn_blockdiag_bwd": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_dense_train": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_dense_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_attn_dense_bwd_parts": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, C.c_int, _p],
     "pfpp_mean_pool_bwd": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_token_combine_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],

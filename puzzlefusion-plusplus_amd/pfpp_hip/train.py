@@ -235,9 +235,19 @@ class DenoiserTrainEngine:
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
         self._side = (torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
                       if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None)
+        # the two passes of the dense attention backward (dq | dk, dv) are independent and can run on two streams
+        # (pfpp_attn_dense_bwd_parts) — measured: no gain (9.76 vs 9.75 ms; 8.36 vs 8.10 with the latents given: both are
+        # 1024-workgroup launches that already fill the chip, the extra D kernel and events cost more), so opt-in
+        self._aux = (torch.cuda.Stream(device=self.flat.params.device)
+                     if (self._side is not None and os.environ.get("PFPP_TRAIN_ATTN_SPLIT", "0") == "1") else None)
         self._group_dw = os.environ.get("PFPP_TRAIN_GROUP_DW", "0") == "1"
         self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
+
+    def single_stream(self) -> None:
+        """everything on the caller's stream from now on (profiling / per-kernel timing)"""
+        self._side = None
+        self._aux = None
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, seed: int = 0,
@@ -386,7 +396,7 @@ class DenoiserTrainEngine:
                              guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
-                                    s["att_scale"])
+                                    s["att_scale"], aux_stream=self._aux)
             self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
             self._before_inplace_update()

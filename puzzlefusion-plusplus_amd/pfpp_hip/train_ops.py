@@ -238,7 +238,10 @@ def attn_dense_train(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Te
 
 def attn_dense_bwd(qkv: torch.Tensor, out_fwd: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, seq_off: torch.Tensor,
                    seq_len: torch.Tensor, max_len: int, H: int, dh: int, scale: float,
-                   key_valid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   key_valid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                   aux_stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """dqkv of the dense (ragged, key-masked) attention.  With `aux_stream` the dk/dv pass runs there while dq runs on the
+    current stream (both after the small D = rowsum(dout . out) kernel); the current stream waits for both before returning."""
     _chk(qkv, _f32, "qkv"); _chk(out_fwd, _f32, "out_fwd"); _chk(dout, _f32, "dout"); _chk(lse, _f32, "lse")
     if out is None:
         out = torch.empty_like(qkv)
@@ -247,6 +250,21 @@ def attn_dense_bwd(qkv: torch.Tensor, out_fwd: torch.Tensor, dout: torch.Tensor,
     if key_valid is not None:
         _chk(key_valid, torch.uint8, "key_valid")
         kvs = key_valid.stride(0)
+    if aux_stream is not None:
+        def part(bits):
+            check(_lib.load().pfpp_attn_dense_bwd_parts(_ptr(qkv), _ptr(out_fwd), _ptr(dout), _ptr(lse), _ptr(dvec), _ptr(out),
+                                                        _ptr(seq_off), _ptr(seq_len), _ptr(key_valid), kvs, seq_off.numel(), max_len,
+                                                        H, dh, scale, bits, _stream()), "pfpp_attn_dense_bwd_parts")
+        main = torch.cuda.current_stream()
+        part(1)
+        aux_stream.wait_stream(main)
+        with torch.cuda.stream(aux_stream):
+            part(4)
+        part(2)
+        main.wait_stream(aux_stream)
+        for t in (qkv, dout, lse, dvec, out):
+            t.record_stream(aux_stream)
+        return out
     check(_lib.load().pfpp_attn_dense_bwd(_ptr(qkv), _ptr(out_fwd), _ptr(dout), _ptr(lse), _ptr(dvec), _ptr(out), _ptr(seq_off),
                                           _ptr(seq_len), _ptr(key_valid), kvs, seq_off.numel(), max_len, H, dh, scale,
                                           _stream()), "pfpp_attn_dense_bwd")

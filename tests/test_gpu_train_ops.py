@@ -274,6 +274,11 @@ def test_attn_dense_train_and_bwd(dev, lens, dh, H, masked):
     assert torch.equal(out, ops.attn_dense(qf, so, sl, max(lens), H, dh, scale, kv8))
     got = T.attn_dense_bwd(qf, out, dO.float().to(dev), lse, so, sl, max(lens), H, dh, scale, key_valid=kv8)
     assert rel_err(got, qkv.grad) < 2e-5
+    # the same in parts with dk/dv on a second stream (pfpp_attn_dense_bwd_parts): identical bits
+    aux = torch.cuda.Stream()
+    got2 = T.attn_dense_bwd(qf, out, dO.float().to(dev), lse, so, sl, max(lens), H, dh, scale, key_valid=kv8, aux_stream=aux)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, got)
 
 
 # ----------------------------------------------------------------------------- small pieces
