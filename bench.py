@@ -333,14 +333,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the only implementation of the path)")
-    dev = torch.device("cuda", local_rank)
+    # PFPP_BENCH_BACKEND=gloo: the N > 1 path with every rank on whatever GPUs exist (ranks may share one) — how the
+    # multi-rank logic is exercised on a single-GPU box; the measured configuration is always nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("PFPP_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -360,7 +366,7 @@ def main():
     def sync_all():
         torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
             torch.cuda.synchronize(dev)
 
     sync_all()

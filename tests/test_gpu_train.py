@@ -438,3 +438,27 @@ def test_host_side_layout_and_no_device_read_in_the_step(weights_sd, dev):
     syncs = [f"{x.filename}:{x.lineno} {x.message}" for x in w if "synchroniz" in str(x.message)]
     assert not syncs, syncs
     assert torch.isfinite(loss).all()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_with_gloo(dev):
+    """bench.py under torch.distributed.run with 2 ranks (both on this GPU, PFPP_BENCH_BACKEND=gloo): the N > 1 branch —
+    barriers, max-over-ranks clock, per-layer gradient exchange inside the timed step, one JSON line from rank 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PFPP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--points", "256", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["puzzles_per_gpu"] == 4
