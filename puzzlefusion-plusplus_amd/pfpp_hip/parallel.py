@@ -66,9 +66,12 @@ class GradExchange:
     the factor that turns the summed gradients into the mean (folded into the optimizer kernel, no extra pass).
     Works on any backend (tested with gloo on CPU tensors)."""
 
-    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]]):
+    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]], sparse_range: Tuple[int, int] = (0, 0)):
         self.grads = grads
         self.layer_ranges = list(layer_ranges)
+        # [a, b) of the head slice that is NOT all-reduced: the timestep-embedding tables (a third of all parameters) get
+        # gradients in only `batch` of their 3072 rows per step, so the ranks exchange those rows instead (gather_rows)
+        self.sparse_range = sparse_range
         self._handles: List[object] = []
 
     @staticmethod
@@ -89,8 +92,27 @@ class GradExchange:
 
     def all_done(self) -> None:
         if self.active():
-            self._reduce(0, self.layer_ranges[0][0])
+            a, b = self.sparse_range
+            first = self.layer_ranges[0][0]
+            if b > a:
+                self._reduce(0, a)
+                self._reduce(b, first)
+            else:
+                self._reduce(0, first)
             self._reduce(self.layer_ranges[-1][1], self.grads.numel())
+
+    def gather_rows(self, rows: torch.Tensor, index: torch.Tensor, dim: int = 1):
+        """every rank's (rows, index) concatenated along `dim` / 0 — the sparse form of an embedding-gradient exchange: the
+        caller scatter-adds ALL ranks' rows into its own table gradient, which then equals the all-reduced (summed) dense
+        gradient.  Needs the same `rows` / `index` shapes on every rank (equal per-rank batch size)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size()
+        rs = [torch.empty_like(rows) for _ in range(world)]
+        ix = [torch.empty_like(index) for _ in range(world)]
+        dist.all_gather(rs, rows.contiguous())
+        dist.all_gather(ix, index.contiguous())
+        return torch.cat(rs, dim).contiguous(), torch.cat(ix, 0).contiguous()
 
     def finish(self) -> float:
         import torch.distributed as dist

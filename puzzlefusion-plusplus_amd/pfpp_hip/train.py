@@ -230,7 +230,10 @@ class DenoiserTrainEngine:
         self.step_count = 0
         from .parallel import GradExchange
 
-        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges)
+        # the 12 AdaLN timestep tables open the flat buffer (see _param_order): exchanged as rows, not as 75 MB of zeros
+        self._sparse_tables = os.environ.get("PFPP_SPARSE_TABLE_GRADS", "1") == "1"
+        n_tab = self.flat.offset[f"transformer_layers.0.norm1.linear.weight"]       # the tables are the first group of the layout
+        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges, (0, n_tab) if self._sparse_tables else (0, 0))
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
         self._side = (torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
@@ -438,7 +441,11 @@ class DenoiserTrainEngine:
         dse = torch.empty_like(se)
         T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
                     sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
-        T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
+        if self._sparse_tables and self._exchange.active():
+            dse_all, t_all = self._exchange.gather_rows(dse, s["t64"], dim=1)       # [n_ada, world*B, C], [world*B]
+            T.silu_embed_bwd(w["ada.tables"], t_all, dse_all, g["ada.tables"])
+        else:
+            T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
         self._all_done()
 
     def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:

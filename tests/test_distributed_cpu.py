@@ -100,6 +100,54 @@ def test_two_rank_gradient_exchange():
     assert torch.equal(grads, torch.arange(1000, dtype=torch.float32) * 3)   # rank0 (x1) + rank1 (x2)
 
 
+def _sparse_worker(rank, world, port, out):
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip.parallel import GradExchange
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a 40-row x 4 "embedding table" gradient opens the buffer ([0,160)), then dense rest, one layer [200,300)
+    grads = torch.zeros(320)
+    grads[160:] = torch.arange(160, dtype=torch.float32) * (rank + 1)
+    ex = GradExchange(grads, [(200, 300)], sparse_range=(0, 160))
+    idx = torch.tensor([3, 7]) + 10 * rank                          # the rows this rank's batch touched
+    rows = torch.full((1, 2, 4), float(rank + 1))                   # [tables, batch, width]
+    ex.layer_done(0)
+    rows_all, idx_all = ex.gather_rows(rows, idx, dim=1)
+    table = grads[:160].view(40, 4)
+    table.index_add_(0, idx_all, rows_all[0])                       # every rank scatter-adds ALL ranks' rows
+    ex.all_done()
+    scale = ex.finish()
+    if rank == 0:
+        out.put((grads.clone(), idx_all.tolist(), scale))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sparse_row_exchange():
+    """embedding-table gradients travel as (rows, indices) instead of a dense all-reduce: the result equals the summed
+    dense gradient and the dense slices around the table are still reduced exactly once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, idx_all, scale = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert scale == 0.5 and idx_all == [3, 7, 13, 17]
+    want = torch.zeros(320)
+    want[160:] = torch.arange(160, dtype=torch.float32) * 3
+    t = want[:160].view(40, 4)
+    t[3] = t[7] = 1.0
+    t[13] = t[17] = 2.0
+    assert torch.equal(grads, want)
+
+
 def test_grad_exchange_is_a_no_op_without_a_process_group():
     from pfpp_hip.parallel import GradExchange
 
