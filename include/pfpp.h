@@ -271,6 +271,10 @@ int pfpp_layernorm_split(const float* x, void* y_hi, void* y_lo, const float* mo
                          const float* gamma, const float* beta, int64_t rows,
                          int64_t C, int64_t rows_per_batch, float eps,
                          pfpp_stream_t stream);
+/* pfpp_layernorm_grouped with the normalised rows written as split-f16 planes (input of the next GEMM) */
+int pfpp_layernorm_grouped_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
+                                 const int32_t* group_batch, int64_t group_rows, int64_t rows, int64_t C,
+                                 float eps, pfpp_stream_t stream);
 
 /* ---- a10/a12: block-diagonal self-attention --------------------------------
  * EncoderLayer self-attn (attention.py:77-80) with the block-diagonal mask of

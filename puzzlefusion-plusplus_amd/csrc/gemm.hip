@@ -265,8 +265,10 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 
 // AFF (PF2 variants only): the A operand always carries the fused BatchNorm+ReLU affine — a compile-time property there,
 // because a data-dependent branch in the K loop splits the scheduling region the two-deep prefetch relies on
-template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false, bool AFF = false>
-__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_kernel(const GemmP p) {
+// APRE: the A operand arrives as pre-split fp16 planes (p.Ahi / p.Alo, written by the producing kernel's epilogue): it is
+// staged exactly like a pre-split W — 16-byte loads, 16-byte LDS stores, no conversion instructions in the K loop
+template <int MT, int NT, bool WPRE, int WM, int WN, bool PF2, bool AFF, bool APRE>
+__device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
@@ -307,10 +309,14 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   // ---- staging registers and (clamped) source rows ---------------------------------------------
   constexpr int NWF = WPRE ? 1 : WF_IT;
   constexpr int NWH = WPRE ? WH_IT : 1;
+  constexpr int AH_IT = BM / (NTHR / 4);   // 16-byte (8-half) loads per thread and plane for a pre-split A
+  constexpr int NAF = APRE ? 1 : A_IT;
+  constexpr int NAH = APRE ? AH_IT : 1;
   // one set of staging registers per K-tile in flight (PF2: two sets = prefetch distance 2, for grids of one or two
   // workgroups per CU where nothing else hides the load latency)
   struct Stage {
-    float4 ra[A_IT];
+    float4 ra[NAF];
+    uint4 rah[NAH], ral[NAH];
     float4 rwf[NWF];
     uint4 rwh[NWH], rwl[NWH];
     float4 r_mul, r_add;      // fused BN+ReLU on A
@@ -326,10 +332,21 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   auto swap02 = [](int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); };
   const int a_row = swap02(tid >> 3), a_c4 = tid & 7;
   const int h_row = swap02(tid >> 2), h_c8 = tid & 3;    // pre-split W: 4 lanes x 8 halfs cover a 32-half row slice
-  const float* a_ptr[A_IT];
+  const float* a_ptr[NAF];
+  const _Float16* ah_ptr[NAH];
+  const _Float16* al_ptr[NAH];
   const float* wf_ptr[NWF];
   const _Float16* wh_ptr[NWH];
   const _Float16* wl_ptr[NWH];
+  if constexpr (APRE) {
+    const int64_t a_off = z0 * p.sA0 + z1 * p.sA1;
+#pragma unroll
+    for (int it = 0; it < AH_IT; ++it) {
+      const int gm = min(m0 + h_row + (NTHR / 4) * it, p.M - 1);
+      ah_ptr[it] = reinterpret_cast<const _Float16*>(p.Ahi) + a_off + (int64_t)gm * p.lda + h_c8 * 8;
+      al_ptr[it] = reinterpret_cast<const _Float16*>(p.Alo) + a_off + (int64_t)gm * p.lda + h_c8 * 8;
+    }
+  } else
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int gm = min(m0 + a_row + (NTHR / 8) * it, p.M - 1);
@@ -359,9 +376,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #if PFPP_ABLATE == 1 || PFPP_ABLATE == 5 || PFPP_ABLATE == 6
     if (k0 != 0) return;
 #endif
+    if constexpr (APRE) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
-    if (AFF || (!PF2 && a_aff)) {
+      for (int it = 0; it < AH_IT; ++it) {
+        s.rah[it] = *reinterpret_cast<const uint4*>(ah_ptr[it] + k0);
+        s.ral[it] = *reinterpret_cast<const uint4*>(al_ptr[it] + k0);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
+    }
+    if (!APRE && (AFF || (!PF2 && a_aff))) {
       s.r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
       s.r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
     }
@@ -377,7 +402,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
     }
   };
   auto load_tail = [&](Stage& s, int k0) {
-    if (p.g_idx) {
+    if constexpr (APRE) {        // pre-split A needs K % 32 == 0 (validated on the host): there is no ragged tile
+#pragma unroll
+      for (int it = 0; it < AH_IT; ++it) { s.rah[it] = make_uint4(0, 0, 0, 0); s.ral[it] = make_uint4(0, 0, 0, 0); }
+    } else if (p.g_idx) {
       // fused grouping: the last 4 columns are the neighbour's offset from its centroid (+ a zero); recomputed from
       // the row index here so that nothing extra stays live across the K loop
 #pragma unroll
@@ -418,7 +446,15 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
 #endif
     _Float16* st = gemm_smem_h + buf * STAGE;
     _Float16* ahi = st, *alo = st + PLANE_A, *whi = st + 2 * PLANE_A, *wlo = st + 2 * PLANE_A + PLANE_W;
-    if (part != 1)
+    if constexpr (APRE) {
+      if (part != 1)
+#pragma unroll
+        for (int it = 0; it < AH_IT; ++it) {
+          const int off = (h_row + (NTHR / 4) * it) * LDH + h_c8 * 8;
+          *reinterpret_cast<uint4*>(ahi + off) = s.rah[it];
+          *reinterpret_cast<uint4*>(alo + off) = s.ral[it];
+        }
+    } else if (part != 1)
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
@@ -658,6 +694,17 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   epilogue<MT, NT>(p, accM, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
 }
 
+template <int MT, int NT, bool WPRE, int WM = 2, int WN = 2, bool PF2 = false, bool AFF = false>
+__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_kernel(const GemmP p) {
+  gemm_f16x3_body<MT, NT, WPRE, WM, WN, PF2, AFF, false>(p);
+}
+
+// both operands pre-split (activations produced as fp16 planes by the previous kernel's epilogue, see ops.SplitAct)
+template <int MT, int NT, int WM, int WN, bool PF2>
+__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f16x3_apre_kernel(const GemmP p) {
+  gemm_f16x3_body<MT, NT, true, WM, WN, PF2, false, true>(p);
+}
+
 int gemm_group_m() {
   static const int v = getenv("PFPP_GEMM_GROUP_M") ? atoi(getenv("PFPP_GEMM_GROUP_M")) : 8;
   return v;
@@ -718,6 +765,14 @@ int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
   return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2, AFF>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
+}
+
+template <int MT, int NT, int WM, int WN, bool PF2>
+int launch_f16x3_apre(const GemmP& p, int batch, hipStream_t st) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
+  static bool attr_set = false;
+  return launch(gemm_f16x3_apre_kernel<MT, NT, WM, WN, PF2>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
 }
 
 }  // namespace
@@ -803,7 +858,17 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
     // LDS-DMA ring variant (gemm_ring.hip): correct, but issue-bound by the per-wave A split (measured
     // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
-    if (apre) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop, no conversions
+    static const bool apre_ring = getenv("PFPP_GEMM_APRE_RING") && atoi(getenv("PFPP_GEMM_APRE_RING")) == 1;
+    if (apre && apre_ring) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop (measured slower)
+    if (apre) {
+      // the register-staged kernels with A staged like W (no conversions in the loop); same tile choice as below
+      static const bool big = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
+      if (big && a->M >= 8192 && a->N >= 1024 && a->pool == 0) return launch_f16x3_apre<4, 2, 2, 4, false>(p, a->batch, st);
+      if (big && a->M >= 8192 && a->pool != 32) return launch_f16x3_apre<2, 2, 4, 2, true>(p, a->batch, st);
+      const int64_t t128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+      if (t128 < 1024 && a->act != PFPP_ACT_GEGLU && a->pool == 0) return launch_f16x3_apre<2, 1, 2, 2, true>(p, a->batch, st);
+      return launch_f16x3_apre<2, 2, 2, 2, true>(p, a->batch, st);
+    }
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
     if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn && !a->gather_idx) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
     static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;

@@ -444,6 +444,14 @@ extern "C" int pfpp_layernorm_grouped(const float* x, float* y, const float* mod
                         group_rows);
 }
 
+extern "C" int pfpp_layernorm_grouped_split(const float* x, void* y_hi, void* y_lo, const float* mod, int64_t ld_mod,
+                                            const int32_t* group_batch, int64_t group_rows, int64_t rows, int64_t C,
+                                            float eps, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && y_hi && y_lo && mod && group_batch && group_rows >= 1, "null pointer / bad group size");
+  return layernorm_impl(x, nullptr, (_Float16*)y_hi, (_Float16*)y_lo, mod, ld_mod, nullptr, nullptr, rows, C, 1, eps, stream,
+                        group_batch, group_rows);
+}
+
 extern "C" int pfpp_layernorm(const float* x, float* y, const float* mod, int64_t ld_mod,
                               const float* gamma, const float* beta, int64_t rows, int64_t C,
                               int64_t rows_per_batch, float eps, pfpp_stream_t stream) {
@@ -472,12 +480,12 @@ static int layernorm_impl(const float* x, float* y, _Float16* y_hi, _Float16* y_
   hipStream_t st = pfpp::as_stream(stream);
   const dim3 grid(blocks_for(rows, 4));
   const int rpb = (int)rows_per_batch;
+  const int gr = (int)group_rows;
   if (y_hi) {
-    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
-    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
-    else hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, nullptr, 1);
+    if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
+    else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
+    else hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
   } else {
-    const int gr = (int)group_rows;
     if (C == 256) hipLaunchKernelGGL((layernorm_kernel<1, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
     else if (C == 512) hipLaunchKernelGGL((layernorm_kernel<2, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);
     else hipLaunchKernelGGL((layernorm_kernel<4, false>), grid, dim3(256), 0, st, x, y, y_hi, y_lo, mod, ld_mod, gamma, beta, rows, rpb, eps, group_batch, gr);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "pfpp_token_combine": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_token_combine_list": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_layernorm_grouped": [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_layernorm_grouped_split": [_p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_silu_embed": [_p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_layernorm": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_layernorm_split": [_p, _p, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p],

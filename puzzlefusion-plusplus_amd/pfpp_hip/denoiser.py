@@ -184,8 +184,10 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
              batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
     att_scale = 1.0 / math.sqrt(dh)
     inner = pk["0.ff.w2"].K
-    norm = torch.empty_like(h)
-    att = torch.empty_like(h)
+    if ops.split_mode():      # GEMM inputs produced by our own kernels travel as pre-split fp16 planes (see ops.split_mode)
+        norm, att, u_buf = (ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, inner, dev))
+    else:
+        norm, att, u_buf = torch.empty_like(h), torch.empty_like(h), None
     for i in range(num_layers):
         ops.layernorm_grouped(h, mods[2 * i], frag_b, L, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
@@ -198,7 +200,7 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
         ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
                  bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
-        u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu")
+        u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu", out=u_buf)
         ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=inner, lda=inner, out=h, ldc=C,
                  bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
     pooled = ops.mean_pool(h, Fv, L)

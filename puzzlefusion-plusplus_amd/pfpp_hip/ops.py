@@ -167,9 +167,11 @@ class SplitAct:
 
 
 def split_mode() -> bool:
-    """activations between kernels as pre-split fp16 planes (consumed by the LDS-DMA ring GEMM).  Correct and
-    tested, but measured slower than the register-staged kernels on MI355X (every wave pays ~100 cycles of
-    issue per LDS-DMA piece), so it is opt-in: PFPP_SPLIT_ACT=1."""
+    """the activations our own kernels produce for the next GEMM (normalised rows, attention outputs, GEGLU products) as
+    pre-split fp16 planes — same bytes as fp32; the consuming GEMM stages them like a pre-split weight
+    (gemm_f16x3_apre_kernel: no conversion instructions in its K loop).  Bit-identical results, tested — and measured
+    no faster (compact sampler step 4.06 ms either way, all-slots 8.39 vs 8.28 ms): the conversions were not what the K
+    loop waits for.  Opt-in: PFPP_SPLIT_ACT=1."""
     return GEMM_MODE == "f16x3" and _os.environ.get("PFPP_SPLIT_ACT", "0") == "1"
 
 
@@ -200,7 +202,14 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
     wide = N > 64 or act == "geglu"
     if f16x3 and not w_kmajor:
         if a_presplit:
-            return "gemm_f16x3_ring_kernel<4, true>"
+            if M >= 8192 and N >= 1024 and pool == 0:
+                return "gemm_f16x3_apre_kernel<4, 2, 2, 4, false>"
+            if M >= 8192 and pool != 32:
+                return "gemm_f16x3_apre_kernel<2, 2, 4, 2, true>"
+            t128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
+            if t128 < 1024 and act != "geglu" and pool == 0:
+                return "gemm_f16x3_apre_kernel<2, 1, 2, 2, true>"
+            return "gemm_f16x3_apre_kernel<2, 2, 2, 2, true>"
         if presplit and wide and M >= 8192 and N >= 1024 and pool == 0:
             return "gemm_f16x3_kernel<4, 2, true, 2, 4, false, false>"
         if presplit and wide and M >= 8192 and pool != 32:
@@ -493,6 +502,10 @@ def layernorm_grouped(x: torch.Tensor, mod: torch.Tensor, group_batch: torch.Ten
     """AdaLN over a compacted token list: the batch (row of `mod`) of token r is group_batch[r // group_rows]"""
     _chk(x, torch.float32, "x"); _chk(mod, torch.float32, "mod"); _chk(group_batch, torch.int32, "group_batch")
     rows, Cc = x.shape
+    if isinstance(out, SplitAct):
+        check(_lib.load().pfpp_layernorm_grouped_split(_ptr(x), _ptr(out.hi), _ptr(out.lo), _ptr(mod), mod.shape[-1], _ptr(group_batch),
+                                                       group_rows, rows, Cc, eps, _stream()), "pfpp_layernorm_grouped_split")
+        return out
     if out is None:
         out = torch.empty_like(x)
     check(_lib.load().pfpp_layernorm_grouped(_ptr(x), _ptr(out), _ptr(mod), mod.shape[-1], _ptr(group_batch), group_rows,
