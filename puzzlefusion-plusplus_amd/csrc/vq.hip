@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int VQ_DIM = 16;
+constexpr int VQ_SPLIT = 4;      // lanes per sub-vector
 
 __global__ __launch_bounds__(256) void vq_encode_kernel(
     const float* __restrict__ z_e, const float* __restrict__ codebook,
@@ -33,10 +34,16 @@ __global__ __launch_bounds__(256) void vq_encode_kernel(
   }
   __syncthreads();
 
-  const int64_t gid = (int64_t)blockIdx.x * 256 + tid;
-  if (gid >= total) return;
+  // VQ_SPLIT adjacent lanes share one sub-vector, each scans a contiguous quarter of the codebook; the quarters are in
+  // index order and ties go to the lower index, so the merged result is torch.argmin's first minimum (4x the workgroups:
+  // at 15 400 sub-vectors one lane per sub-vector used 61 of the 256 CUs)
+  const int64_t tidg = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t gid = tidg / VQ_SPLIT;
+  const int part = (int)(tidg - gid * VQ_SPLIT);
+  const bool live = gid < total;
+  const int64_t gl = live ? gid : total - 1;
   float z[VQ_DIM];
-  const float4* zp = reinterpret_cast<const float4*>(z_e + gid * VQ_DIM);
+  const float4* zp = reinterpret_cast<const float4*>(z_e + gl * VQ_DIM);
 #pragma unroll
   for (int d4 = 0; d4 < VQ_DIM / 4; ++d4) {
     const float4 v = zp[d4];
@@ -47,8 +54,10 @@ __global__ __launch_bounds__(256) void vq_encode_kernel(
   for (int d = 0; d < VQ_DIM; ++d) zz = __fadd_rn(zz, __fmul_rn(z[d], z[d]));
 
   float best = __builtin_huge_valf();
-  int bj = 0;
-  for (int j = 0; j < n_codes; ++j) {
+  const int per = (n_codes + VQ_SPLIT - 1) / VQ_SPLIT;
+  const int j0 = part * per, j1 = min(n_codes, j0 + per);
+  int bj = j0 < n_codes ? j0 : 0;
+  for (int j = j0; j < j1; ++j) {
     const float4* e4 = reinterpret_cast<const float4*>(s_cb + j * VQ_DIM);
     // z @ E^T: k-ordered fma chain (what the fp32 matrix core and the CPU BLAS evaluate)
     float dot = 0.0f;
@@ -65,6 +74,13 @@ __global__ __launch_bounds__(256) void vq_encode_kernel(
     if (d < best) { best = d; bj = j; }   // first minimum, like torch.argmin
   }
 
+#pragma unroll
+  for (int m = 1; m < VQ_SPLIT; m <<= 1) {
+    const float ob = __shfl_xor(best, m);
+    const int oj = __shfl_xor(bj, m);
+    if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  if (!live || part != 0) return;
   // scatter: sub-vector gid belongs to fragment f, row r, part c of the latent
   const int sub_per_frag = rows_per_frag;   // rows are already the 16-wide sub-vectors
   const int64_t f = gid / sub_per_frag;
@@ -114,7 +130,7 @@ extern "C" int pfpp_vq_encode(const float* z_e, const float* codebook, const int
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (VQ_DIM + 1) * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL(vq_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), smem,
+  hipLaunchKernelGGL(vq_encode_kernel, dim3((unsigned)((total * VQ_SPLIT + 255) / 256)), dim3(256), smem,
                      pfpp::as_stream(stream), z_e, codebook, slot, z_q, codes, total,
                      (int)rows_per_frag, (int)n_codes);
   return pfpp::check_launch(__func__);
