@@ -58,9 +58,19 @@ class AutoAgglomerative(LightningModule):
     def _extract_features(self, part_pcs, part_valids, x):
         return self.encoder.extract_features(part_pcs, part_valids, x)
 
-    @staticmethod
-    def _edge_mask(num_parts: torch.Tensor, P: int) -> torch.Tensor:
-        e = torch.tensor(list(itertools.combinations(range(P), 2)), dtype=torch.int64, device=num_parts.device)
+    _PAIRS = {}
+
+    @classmethod
+    def _edge_pairs(cls, P: int, device) -> torch.Tensor:
+        """all (i, j), i < j, of P slots in the order of torch.triu(...).nonzero() = itertools.combinations — built once per (P, device)"""
+        key = (P, str(device))
+        if key not in cls._PAIRS:
+            cls._PAIRS[key] = torch.tensor(list(itertools.combinations(range(P), 2)), dtype=torch.int64, device=device)
+        return cls._PAIRS[key]
+
+    @classmethod
+    def _edge_mask(cls, num_parts: torch.Tensor, P: int) -> torch.Tensor:
+        e = cls._edge_pairs(P, num_parts.device)
         return (e[None, :, 0] < num_parts[:, None]) & (e[None, :, 1] < num_parts[:, None])
 
     @staticmethod
@@ -68,23 +78,36 @@ class AutoAgglomerative(LightningModule):
         """flatten the per-edge correspondence lists of the matching data into index arrays once:
         global index of a matched point = start(part) + critical_pcs_idx[start(part) + corr]
         (get_distance_for_matching_pts, node_merge_utils.py:62-89)"""
-        n_pcs = data_dict["n_pcs"][0].cpu().long()
-        crit = data_dict["critical_pcs_idx"][0].cpu().long()
-        edges = data_dict["edges"][0].cpu().long()
-        start = torch.cumsum(n_pcs, 0) - n_pcs
-        ia, ib, off, pairs = [], [], [0], []
-        for e in range(edges.shape[0]):
-            idx2, idx1 = int(edges[e, 0]), int(edges[e, 1])
-            corr = torch.as_tensor(data_dict["correspondences"][e]).reshape(-1, 2).long().cpu()
-            a = start[idx1] + crit[start[idx1] + corr[:, 0]]
-            b = start[idx2] + crit[start[idx2] + corr[:, 1]]
-            ia.append(a); ib.append(b); off.append(off[-1] + corr.shape[0]); pairs.append((idx1, idx2))
-        point_part = torch.repeat_interleave(torch.arange(n_pcs.numel()), n_pcs)
-        cat = lambda xs: (torch.cat(xs) if xs else torch.zeros(0, dtype=torch.long)).to(torch.int32).to(device)
+        n_pcs = data_dict["n_pcs"][0].cpu().numpy().astype(np.int64)
+        crit = data_dict["critical_pcs_idx"][0].cpu().numpy().astype(np.int64)
+        edges = data_dict["edges"][0].cpu().numpy().astype(np.int64)
+        start = np.cumsum(n_pcs) - n_pcs
+        as_np = lambda c: (c.detach().cpu().numpy() if torch.is_tensor(c) else np.asarray(c)).reshape(-1, 2).astype(np.int64)
+        corrs = [as_np(data_dict["correspondences"][e]) for e in range(edges.shape[0])]
+        counts = np.array([c.shape[0] for c in corrs], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        if corrs:
+            corr = np.concatenate(corrs, 0)
+            s1 = np.repeat(start[edges[:, 1]], counts)          # idx1 = edges[e, 1] owns column 0
+            s2 = np.repeat(start[edges[:, 0]], counts)          # idx2 = edges[e, 0] owns column 1
+            ia = s1 + crit[s1 + corr[:, 0]]
+            ib = s2 + crit[s2 + corr[:, 1]]
+        else:
+            ia = ib = np.zeros(0, np.int64)
+        pairs = [(int(e[1]), int(e[0])) for e in edges]
+        P = int(data_dict["n_pcs"].shape[1])                  # n_pcs is [1, P] (one entry per fragment slot)
+        i1, i2 = edges[:, 1], edges[:, 0]
+        # position of edge (i1 < i2) in the row-major upper triangle = the order of the verifier's 190 edge slots
+        pair_pos = i1 * P - i1 * (i1 + 1) // 2 + (i2 - i1 - 1)
+        if edges.size and ((i1 >= i2).any() or (i2 >= P).any()):
+            raise ValueError("prepare_matching: edges must be (idx2, idx1) with idx1 < idx2 < P")
+        point_part = np.repeat(np.arange(n_pcs.size), n_pcs)
+        dev_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32))).to(device)
         return {
-            "idx_a": cat(ia), "idx_b": cat(ib), "edge_off": torch.tensor(off, dtype=torch.int32, device=device),
-            "max_m": max([off[i + 1] - off[i] for i in range(len(off) - 1)], default=0), "pairs": pairs,
-            "point_part": point_part.to(torch.int32).to(device),
+            "idx_a": dev_i32(ia), "idx_b": dev_i32(ib), "edge_off": dev_i32(off),
+            "max_m": int(counts.max()) if counts.size else 0, "pairs": pairs,
+            "point_part": dev_i32(point_part),
+            "pair_pos": torch.from_numpy(np.ascontiguousarray(pair_pos)).to(device),
         }
 
     # ------------------------------------------------------------------ test_step / test_batch
@@ -145,7 +168,10 @@ class AutoAgglomerative(LightningModule):
                                        torch.cat([st.edge_valids for st in todo], 0))
                 for i, st in enumerate(todo):
                     st.after_verify(logits[i:i + 1])
-        return [st.result() for st in states]
+        # the four metrics for all puzzles in one batched evaluation (the evaluator's functions are batch functions)
+        finals = [self._compose(st.x, st.pivot, st.nodes) for st in states]
+        metrics = self._evaluate_many([st.data for st in states], finals, [st.n_nodes for st in states])
+        return [st.result(finals[i], {k: v[i:i + 1] for k, v in metrics.items()}) for i, st in enumerate(states)]
 
     @staticmethod
     def _batched_compose(active):
@@ -254,17 +280,24 @@ class AutoAgglomerative(LightningModule):
 
     def _evaluate(self, data_dict, final, n_nodes):
         """the four metrics of test_step (auto_aggl.py:288-318) on the composed final poses"""
+        return self._evaluate_many([data_dict], [final], [n_nodes])
+
+    def _evaluate_many(self, data_dicts, finals, n_nodes_list):
+        """_evaluate for several puzzles at once: every metric is a [n_puzzles] tensor (same functions, batched inputs)"""
         from puzzlefusion_plusplus.denoiser.evaluation.evaluator import (ChamferDistance, calc_part_acc, calc_shape_cd,
                                                                         rot_metrics, trans_metrics)
 
-        P = data_dict["part_valids"].shape[1]
-        dev = final.device
-        pred = torch.zeros(1, P, 7, device=dev)
-        pred[0, :n_nodes] = final
-        pred[0, n_nodes:, 3] = 1.0
-        pts = (data_dict["part_pcs"] * data_dict["part_scale"].unsqueeze(-1)).float()
-        valids = data_dict["part_valids"]
-        gt_t, gt_r = data_dict["part_trans"].float(), data_dict["part_rots"].float()
+        n = len(data_dicts)
+        P = data_dicts[0]["part_valids"].shape[1]
+        dev = finals[0].device
+        pred = torch.zeros(n, P, 7, device=dev)
+        pred[:, :, 3] = 1.0
+        for i, (final, n_nodes) in enumerate(zip(finals, n_nodes_list)):
+            pred[i, :n_nodes] = final
+        cat = (lambda key: torch.cat([d[key] for d in data_dicts], 0)) if n > 1 else (lambda key: data_dicts[0][key])
+        pts = (cat("part_pcs") * cat("part_scale").unsqueeze(-1)).float()
+        valids = cat("part_valids")
+        gt_t, gt_r = cat("part_trans").float(), cat("part_rots").float()
         gt_r = torch.where(gt_r.abs().sum(-1, keepdim=True) == 0, torch.tensor([1.0, 0, 0, 0], device=dev), gt_r)
         cd = ChamferDistance()
         pt, pr = pred[..., :3].contiguous(), pred[..., 3:].contiguous()
@@ -336,7 +369,7 @@ class _PuzzleState:
         self.have_matching = "edges" in data_dict
         self.match = model.prepare_matching(data_dict, dev) if self.have_matching else None
         self.pivot = torch.arange(self.n_nodes, dtype=torch.int32, device=dev)
-        self.edge_indices = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1).nonzero(as_tuple=False)[None]
+        self.edge_indices = model._edge_pairs(P, dev)[None]          # == triu(ones, 1).nonzero(): row-major upper triangle
         self.edge_valids = model._edge_mask(self.num_parts, P)
         self.traj, self.step_no, self.verifier_calls, self.n_merges = [], 0, 0, 0
         self.merged_edges: List = []
@@ -358,13 +391,11 @@ class _PuzzleState:
         pts_t = ops.pose_apply_points(self.data["part_pcs_by_area"][0].float().contiguous(),
                                       pivot[match["point_part"].long()].contiguous(), x[0].contiguous(), normalise=False)
         hist = ops.edge_histogram(pts_t, match["idx_a"], match["idx_b"], match["edge_off"], match["max_m"])
-        ef = torch.zeros(1, P, P, 6, dtype=torch.int32, device=dev)
+        # the reference scatters into a [P,P,6] matrix and reads its upper triangle (auto_aggl.py:193-197): same thing with the
+        # edges' triangle positions precomputed (no index tensors built from Python lists, no boolean-mask read-back per call)
+        ef = torch.zeros(1, P * (P - 1) // 2, 6, dtype=torch.int32, device=dev)
         if match["pairs"]:
-            i1 = torch.tensor([p[0] for p in match["pairs"]], device=dev)
-            i2 = torch.tensor([p[1] for p in match["pairs"]], device=dev)
-            ef[0, i1, i2] = hist
-        mat_mask = torch.triu(torch.ones(P, P, dtype=torch.bool, device=dev), diagonal=1)
-        ef = ef[:, mat_mask]
+            ef[0, match["pair_pos"]] = hist
         cnt = ef.sum(dim=-1, keepdim=True)
         self._pts_t = pts_t
         return torch.cat((ef / torch.where(cnt == 0, 1, cnt), cnt), dim=-1).float()
@@ -402,11 +433,13 @@ class _PuzzleState:
         if bool((self.classified == larger).all()):
             self.done = True
 
-    def result(self) -> dict:
+    def result(self, final=None, metrics=None) -> dict:
         m = self.m
-        final = m._compose(self.x, self.pivot, self.nodes)
+        if final is None:
+            final = m._compose(self.x, self.pivot, self.nodes)
         valid_nodes = self.data["part_valids"][0, :self.n_nodes].bool()
-        metrics = m._evaluate(self.data, final, self.n_nodes)
+        if metrics is None:
+            metrics = m._evaluate(self.data, final, self.n_nodes)
         traj_t = torch.cat(self.traj, 0)
         if getattr(m.cfg, "experiment_output_path", None) is not None and "data_id" in self.data:
             m._save_inference_data(self.data, traj_t, metrics["part_acc"])
