@@ -267,7 +267,9 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // because a data-dependent branch in the K loop splits the scheduling region the two-deep prefetch relies on
 // APRE: the A operand arrives as pre-split fp16 planes (p.Ahi / p.Alo, written by the producing kernel's epilogue): it is
 // staged exactly like a pre-split W — 16-byte loads, 16-byte LDS stores, no conversion instructions in the K loop
-template <int MT, int NT, bool WPRE, int WM, int WN, bool PF2, bool AFF, bool APRE>
+// PFD > 2: `PFD` K-tiles in flight in registers (latency-bound launches: a handful of workgroups, each walking its K range
+// alone — the sampler step of a single puzzle, 250 rows): generalisation of the two-deep loop, PFD tiles per branch-free trip
+template <int MT, int NT, bool WPRE, int WM, int WN, bool PF2, bool AFF, bool APRE, int PFD = 0>
 __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = 32 * MT * WM;
@@ -487,6 +489,7 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
       }
     }
   };
+  constexpr int IB = MT >= 2 ? 2 : 1;      // A fragments are read IB M-tiles at a time
   auto compute = [&](int buf, int ks_begin = 0, int ks_end = BK / 16) {
     const _Float16* st = gemm_smem_h + buf * STAGE;
     const _Float16* a_base = st + (wm * 32 * MT + l31) * LDH + lhi * 8;
@@ -543,10 +546,10 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
       }
       // A fragments two M-tiles at a time (keeps the 128x64 wave tile of the 256x256 variant in registers)
 #pragma unroll
-      for (int i0 = 0; i0 < MT; i0 += 2) {
-        half8 ah[2], al[2];
+      for (int i0 = 0; i0 < MT; i0 += IB) {
+        half8 ah[IB], al[IB];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < IB; ++ii) {
 #if PFPP_ABLATE == 3
           ah[ii] = al[ii] = half8{(_Float16)(lane + ii + ks), 1, 2, 3, 4, 5, 6, 7};
 #else
@@ -558,23 +561,23 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
         // (a dependent MFMA on the same accumulator waits for the previous one's passes; small terms first)
 #if PFPP_ABLATE == 2
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j][0] += (float)al[ii][0] * (float)bh[j][0] + (float)ah[ii][1] * (float)bl[j][1];
 #else
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bl[j], accM[i0 + ii][j], 0, 0, 0);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             accM[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ii], bh[j], accM[i0 + ii][j], 0, 0, 0);
@@ -589,7 +592,42 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
   const int ke = p.split_k > 1 ? min(p.K, kb + p.k_chunk) : p.K;
   const int nk_full = (ke - kb) / BK;
   const int nk = (ke - kb + BK - 1) / BK;
-  if constexpr (!PF2) {
+  if constexpr (PFD > 2) {
+    Stage sd[PFD];
+    auto load_any = [&](Stage& s, int kt_) {
+      if (kt_ < nk_full) load_full(s, kb + kt_ * BK); else load_tail(s, kb + kt_ * BK);
+    };
+    // invariant at the top of a trip (kt a multiple of PFD): register set d holds tile kt + d, LDS stage 0 holds tile kt
+#pragma unroll
+    for (int d = 0; d < PFD; ++d)
+      if (d < nk) load_any(sd[d], d);
+    store_tiles(sd[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 * PFD <= nk_full; kt += PFD) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j) {
+        load_full(sd[j], kb + (kt + j + PFD) * BK);           // set j is free: its tile sits in LDS stage j & 1
+        compute(j & 1, 0, 1);
+        store_tiles(sd[(j + 1) % PFD], (j + 1) & 1, 0);
+        compute(j & 1, 1, 2);
+        store_tiles(sd[(j + 1) % PFD], (j + 1) & 1, 1);
+        __syncthreads();
+      }
+    }
+    for (; kt < nk; kt += PFD) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j) {
+        if (kt + j >= nk) break;
+        if (kt + j + PFD < nk) load_any(sd[j], kt + j + PFD);
+        compute(j & 1, 0, 1);
+        if (kt + j + 1 < nk) store_tiles(sd[(j + 1) % PFD], (j + 1) & 1, 0);
+        compute(j & 1, 1, 2);
+        if (kt + j + 1 < nk) store_tiles(sd[(j + 1) % PFD], (j + 1) & 1, 1);
+        __syncthreads();
+      }
+    }
+  } else if constexpr (!PF2) {
     if (nk_full > 0) load_full(s0, kb); else load_tail(s0, kb);
     store_tiles(s0, 0);
     __syncthreads();
@@ -705,6 +743,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_f1
   gemm_f16x3_body<MT, NT, true, WM, WN, PF2, false, true>(p);
 }
 
+// latency-bound launches: PFD K-tiles in flight per workgroup (W pre-split, fp32 A, no fused-BatchNorm operands)
+template <int MT, int NT, int WM, int WN, int PFD>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f16x3_deep_kernel(const GemmP p) {
+  gemm_f16x3_body<MT, NT, true, WM, WN, true, false, false, PFD>(p);
+}
+
 int gemm_group_m() {
   static const int v = getenv("PFPP_GEMM_GROUP_M") ? atoi(getenv("PFPP_GEMM_GROUP_M")) : 8;
   return v;
@@ -765,6 +809,14 @@ int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
   return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2, AFF>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
+}
+
+template <int MT, int NT, int WM, int WN, int PFD>
+int launch_f16x3_deep(const GemmP& p, int batch, hipStream_t st) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
+  static bool attr_set = false;
+  return launch(gemm_f16x3_deep_kernel<MT, NT, WM, WN, PFD>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
 }
 
 template <int MT, int NT, int WM, int WN, bool PF2>
@@ -901,6 +953,20 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     static const int small_thresh = getenv("PFPP_GEMM_SMALL") ? atoi(getenv("PFPP_GEMM_SMALL")) : 1024;
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
     // grids of at most ~two workgroups per CU: prefetch two K-tiles ahead (the load latency is all there is to hide)
+    // latency-bound launches (see gemm_f16x3_deep_kernel).  PFPP_GEMM_DEEP: 0 off, 1 tiny grids only, 2 also the 3850-row grids
+    // Measured (M = 250: one puzzle's tokens): 512x512 15.9 -> 12.3 us, 1536x512 16.2 -> 12.5, GEGLU 4096x512 24.7 -> 17.8, the
+    // single-puzzle auto_aggl loop 4.39 -> 4.89 puzzles/s; no gain on the 3850-row grids (mode 2), and K >= 1024 stays with
+    // the split-K path of the 128-row tiles (40.5 vs 45.5 us).
+    static const int deep_mode = getenv("PFPP_GEMM_DEEP") ? atoi(getenv("PFPP_GEMM_DEEP")) : 1;
+    if (pre && deep_mode > 0 && !fused_bn && !a->gather_idx && a->pool == 0) {
+      const int64_t t64 = ((a->M + 63) / 64) * ((a->N + 63) / 64) * a->batch;
+      if (t64 <= 512 && a->K < 1024) {
+        if (a->act == PFPP_ACT_GEGLU) return launch_f16x3_deep<1, 2, 2, 2, 4>(p, a->batch, st);
+        return launch_f16x3_deep<1, 1, 2, 2, 8>(p, a->batch, st);
+      }
+      if (deep_mode > 1 && wide && tiles128 < small_thresh && a->act != PFPP_ACT_GEGLU)
+        return launch_f16x3_deep<2, 1, 2, 2, 4>(p, a->batch, st);
+    }
     static const bool pf2 = !(getenv("PFPP_GEMM_PF2") && atoi(getenv("PFPP_GEMM_PF2")) == 0);   // two-deep prefetch, branch-free steady state: +10..23 % at 3850 rows
     const bool deep = pf2 && !fused_bn && tiles128 < 2 * small_thresh;
     if (pre && wide && tiles128 < small_thresh && a->act != PFPP_ACT_GEGLU && a->pool == 0)

@@ -195,7 +195,7 @@ def _split_workspace(device):
     return ws
 
 
-def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: bool, f16x3: bool = False,
+def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: bool, f16x3: bool = False, K: int = 0,
                      presplit: bool = False, a_presplit: bool = False, fused_bn: bool = False, a_aff: bool = False) -> str:
     """the template instantiation pfpp_gemm dispatches to (mirror of the choice in csrc/gemm.hip with the
     default environment) — used to attribute HIP-event timings to the kernel names rocprofv3 reports"""
@@ -215,6 +215,8 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
         if presplit and wide and M >= 8192 and pool != 32:
             return f"gemm_f16x3_kernel<2, 2, true, 4, 2, true, {'true' if a_aff else 'false'}>"
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        if presplit and not fused_bn and pool == 0 and ((M + 63) // 64) * ((N + 63) // 64) * batch <= 512 and K < 1024:
+            return "gemm_f16x3_deep_kernel<1, 2, 2, 2, 4>" if act == "geglu" else "gemm_f16x3_deep_kernel<1, 1, 2, 2, 8>"
         deep = not fused_bn and tiles128 < 2048
         if presplit and wide and tiles128 < 1024 and act != "geglu" and pool == 0:
             return f"gemm_f16x3_kernel<2, 1, true, 2, 2, {'true' if deep else 'false'}, false>"
@@ -347,7 +349,7 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
         e1.record()
         GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch,
-                           gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, planes is not None, a_planes is not None,
+                           gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, K, planes is not None, a_planes is not None,
                                             a_affine is not None or stats is not None or c_min is not None, a_affine is not None),
                            (M, N, K, batch, act, pool)))
         return out
