@@ -761,7 +761,7 @@ thread_local int64_t p_split_cnt_len = 0;
 
 template <typename K>
 int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set, int nthr = 256,
-           bool can_split = false) {
+           bool can_split = false, int min_chunk = 128) {
   if (!*attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *attr_set = true;
@@ -779,7 +779,7 @@ int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t 
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
   if (can_split && split_on && p.split_ws && p.split_cnt && tiles < 192 && p.K >= 1024 && p.pool == 0 && !p.stats && !p.g_idx) {
     int want = (int)((384 + tiles - 1) / tiles);
-    const int max_by_k = p.K / 128;                          // at least 4 K-tiles per chunk
+    const int max_by_k = p.K / min_chunk;                    // at least min_chunk / 32 K-tiles per chunk (default 4)
     int splits = want < max_by_k ? want : max_by_k;
     if (splits > 16) splits = 16;
     const int64_t need = (int64_t)splits * tiles * BM * BN * (int64_t)sizeof(float);
@@ -816,7 +816,8 @@ int launch_f16x3_deep(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_deep_kernel<MT, NT, WM, WN, PFD>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
+  // split K only into chunks that still fill the prefetch pipeline twice over (the fix-up reads one partial per chunk)
+  return launch(gemm_f16x3_deep_kernel<MT, NT, WM, WN, PFD>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true, 512);
 }
 
 template <int MT, int NT, int WM, int WN, bool PF2>
@@ -954,13 +955,13 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
     // grids of at most ~two workgroups per CU: prefetch two K-tiles ahead (the load latency is all there is to hide)
     // latency-bound launches (see gemm_f16x3_deep_kernel).  PFPP_GEMM_DEEP: 0 off, 1 tiny grids only, 2 also the 3850-row grids
-    // Measured (M = 250: one puzzle's tokens): 512x512 15.9 -> 12.3 us, 1536x512 16.2 -> 12.5, GEGLU 4096x512 24.7 -> 17.8, the
-    // single-puzzle auto_aggl loop 4.39 -> 4.89 puzzles/s; no gain on the 3850-row grids (mode 2), and K >= 1024 stays with
-    // the split-K path of the 128-row tiles (40.5 vs 45.5 us).
+    // Measured (M = 250: one puzzle's tokens): 512x512 15.9 -> 12.3 us, 1536x512 16.2 -> 12.5, GEGLU 4096x512 24.7 -> 17.8,
+    // 512x2048 (K split into 512-deep chunks instead of 128-deep ones) 40.8 -> 29.7 us; the single-puzzle auto_aggl loop
+    // 4.39 -> 5.28 puzzles/s.  No gain on the wider 3850-row grids (PFPP_GEMM_DEEP=2 routes them here too).  0 = off.
     static const int deep_mode = getenv("PFPP_GEMM_DEEP") ? atoi(getenv("PFPP_GEMM_DEEP")) : 1;
     if (pre && deep_mode > 0 && !fused_bn && !a->gather_idx && a->pool == 0) {
       const int64_t t64 = ((a->M + 63) / 64) * ((a->N + 63) / 64) * a->batch;
-      if (t64 <= 512 && a->K < 1024) {
+      if (t64 <= 512) {
         if (a->act == PFPP_ACT_GEGLU) return launch_f16x3_deep<1, 2, 2, 2, 4>(p, a->batch, st);
         return launch_f16x3_deep<1, 1, 2, 2, 8>(p, a->batch, st);
       }
