@@ -215,7 +215,7 @@ def gemm_kernel_name(M: int, N: int, act: str, pool: int, batch: int, w_kmajor: 
         if presplit and wide and M >= 8192 and pool != 32:
             return f"gemm_f16x3_kernel<2, 2, true, 4, 2, true, {'true' if a_aff else 'false'}>"
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
-        if presplit and not fused_bn and pool == 0 and ((M + 63) // 64) * ((N + 63) // 64) * batch <= 512:
+        if presplit and not fused_bn and pool == 0 and ((M + 63) // 64) * ((N + 63) // 64) * batch <= 256:
             return "gemm_f16x3_deep_kernel<1, 2, 2, 2, 4>" if act == "geglu" else "gemm_f16x3_deep_kernel<1, 1, 2, 2, 8>"
         deep = not fused_bn and tiles128 < 2048
         if presplit and wide and tiles128 < 1024 and act != "geglu" and pool == 0:
