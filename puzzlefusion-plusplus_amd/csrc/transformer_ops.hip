@@ -286,6 +286,90 @@ __global__ __launch_bounds__(256) void attn_blockdiag_kernel(const float* __rest
   }
 }
 
+// The same on the matrix cores (exact fp32 products, v_mfma_f32_32x32x2_f32), no LDS: one wave per (fragment, head).
+//   S^T = K . Q^T   keys x queries: lane = query, 16 registers = the keys of this lane half; the softmax over a query's keys is
+//                   16 in-lane values + one exchange with lane ^ 32
+//   O^T = V^T . P^T the normalised accumulator IS the B operand (key slot t of lane half lhi = register t), V is read
+//                   straight from global memory, one coalesced row segment per key
+// 64 MFMAs per pair (4096 cycles) against ~4800 dependent FMAs per lane with 25 of 64 lanes working: 23 -> 8 us.
+typedef float abm_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void attn_blockdiag_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                                  int64_t n_pairs, int L, int H, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+  if (pair >= n_pairs) return;
+  const int64_t frag = pair / H;
+  const int h = (int)(pair - frag * H);
+  const int C = H * AB_DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + frag * L * ld + h * AB_DH;
+  const int row = l31 < L ? l31 : L - 1;
+  const float* qp = base + row * ld + lhi * 4;
+  const float* kp = qp + C;
+
+  abm_f32x16 s;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < AB_DH / 8; ++c) {
+    const float4 q4 = *reinterpret_cast<const float4*>(qp + c * 8);
+    const float4 k4 = *reinterpret_cast<const float4*>(kp + c * 8);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q4.x, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q4.y, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q4.z, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q4.w, s, 0, 0, 0);
+  }
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    s[e] = key < L ? s[e] * scale : -__builtin_huge_valf();
+    mx = fmaxf(mx, s[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    s[e] = key < L ? expf(s[e] - mx) : 0.0f;
+    sum += s[e];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] *= inv;
+
+  const float* vp = base + 2 * C + l31;
+  const int64_t orow = (frag * L + l31) * (int64_t)C + h * AB_DH;
+#pragma unroll
+  for (int tile = 0; tile < AB_DH / 32; ++tile) {
+    abm_f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int key = (t & 3) + 8 * (t >> 2) + 4 * lhi;
+      const float v = vp[(int64_t)(key < L ? key : L - 1) * ld + tile * 32];      // masked keys carry p = 0
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[t], o, 0, 0, 0);
+    }
+    if (l31 < L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t off = orow + tile * 32 + 8 * q + 4 * lhi;
+        if (out_hi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) PFPP_SPLIT_TO(o[4 * q + r], out_hi[off + r], out_lo[off + r]);
+        } else {
+          *reinterpret_cast<float4*>(out + off) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // a13/a18: masked row softmax, one wave per row, three passes over a row that
 // stays in L1/L2 (T <= a few thousand)
@@ -516,6 +600,12 @@ static int attn_blockdiag_impl(const float* qkv, float* out, _Float16* out_hi, _
                "16-byte alignment");
   const int64_t pairs = n_frag * H;
   if (pairs == 0) return PFPP_OK;
+  static const bool use_mfma = !(getenv("PFPP_ATTN_BD_MFMA") && atoi(getenv("PFPP_ATTN_BD_MFMA")) == 0);
+  if (use_mfma) {
+    hipLaunchKernelGGL(attn_blockdiag_mfma_kernel, dim3(blocks_for(pairs, 4)), dim3(256), 0, pfpp::as_stream(stream), qkv, out,
+                       out_hi, out_lo, pairs, (int)L, (int)H, scale);
+    return pfpp::check_launch("pfpp_attn_blockdiag");
+  }
   const size_t smem = 4 * 2 * AB_LMAX * AB_DH * sizeof(float);
   hipLaunchKernelGGL(attn_blockdiag_kernel, dim3(blocks_for(pairs, 4)), dim3(256), smem,
                      pfpp::as_stream(stream), qkv, out, out_hi, out_lo, pairs, (int)L, (int)H, scale);
