@@ -96,6 +96,26 @@ struct OperandLoader {
     }
   }
 
+  // interior K-tile: no bounds along the contraction, rows past the edge are read from row 0 instead (they only feed
+  // output rows / columns the epilogue never stores) — no conditional loads, so the steady-state loop stays one region
+  __device__ __forceinline__ void load_full(const float* base, int64_t ld, int r0, int rmax, int k0, int tid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int u = tid + it * NTHR;
+      if (UNITS % NTHR != 0 && u >= UNITS) break;
+      if constexpr (KM) {
+        const int kg = u & 7, c4 = u >> 3;
+        const int r = r0 + c4 * 4;
+        const float* src = base + (int64_t)(k0 + 4 * kg) * ld + (r < rmax ? r : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reg[it][j] = *reinterpret_cast<const float4*>(src + j * ld);
+      } else {
+        const int row = swap02(u >> 3), c4 = u & 7;
+        reg[it][0] = *reinterpret_cast<const float4*>(base + (int64_t)min(r0 + row, rmax - 1) * ld + k0 + c4 * 4);
+      }
+    }
+  }
+
   __device__ __forceinline__ void store(_Float16* hi_plane, _Float16* lo_plane, float scale, int tid) const {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -207,6 +227,11 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
     la##SET.load(A, p.lda, m0, p.M, kb + (KT) * BK, ke, tid);           \
     lw##SET.load(W, p.ldw, n0, p.N, kb + (KT) * BK, ke, tid);           \
   } while (0)
+#define GRAD_LOAD_FULL(SET, KT)                                         \
+  do {                                                                  \
+    la##SET.load_full(A, p.lda, m0, p.M, kb + (KT) * BK, tid);          \
+    lw##SET.load_full(W, p.ldw, n0, p.N, kb + (KT) * BK, tid);          \
+  } while (0)
 #define GRAD_STORE(SET, BUF)                                                                  \
   do {                                                                                        \
     _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
@@ -233,14 +258,15 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
   // (in flight), register set kt&1 is free.  Steady state: two K-tiles per trip, no branch inside (one scheduling
   // region), the split + LDS stores of tile kt+1 placed between the two 16-deep MFMA steps of tile kt.
   int kt = 0;
-  for (; kt + 3 < nk; kt += 2) {
-    GRAD_LOAD(0, kt + 2);
+  const int nk_full = (ke - kb) / BK;          // tiles that lie entirely inside [kb, ke)
+  for (; kt + 3 < nk_full; kt += 2) {
+    GRAD_LOAD_FULL(0, kt + 2);
     compute(0, 0, 1);
     GRAD_STORE_A(1, 1);
     compute(0, 1, 2);
     GRAD_STORE_W(1, 1);
     __syncthreads();
-    GRAD_LOAD(1, kt + 3);
+    GRAD_LOAD_FULL(1, kt + 3);
     compute(1, 0, 1);
     GRAD_STORE_A(0, 0);
     compute(1, 1, 2);
@@ -259,6 +285,7 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
     __syncthreads();
   }
 #undef GRAD_LOAD
+#undef GRAD_LOAD_FULL
 #undef GRAD_STORE
 #undef GRAD_STORE_A
 #undef GRAD_STORE_W
