@@ -327,7 +327,11 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
   s0.r_mul = make_float4(1.f, 1.f, 1.f, 1.f);
   s0.r_add = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (PF2) { s1.r_mul = s0.r_mul; s1.r_add = s0.r_add; }
-  const bool a_aff = p.a_mul != nullptr;
+  // the fused-BatchNorm operand is a run-time property only of the small one-deep tiles (set abstraction 1 in train mode);
+  // everywhere else it is a template parameter (AFF) or absent — a data-dependent branch in the K loop costs the whole
+  // loop its scheduling freedom (the 256x256 kernel's steady state had four of them)
+  constexpr bool RT_AFF = !PF2 && !APRE && PFD == 0 && (MT * NT <= 4);
+  const bool a_aff = RT_AFF && p.a_mul != nullptr;
   // staging rows: bits 0 and 2 of the row index are swapped, so the two rows a 16-lane (8-byte stores) or 8-lane
   // (16-byte stores) LDS store group touches are 4 apart — with 80-byte rows their bank ranges are then disjoint
   // (rows r, r+1 overlap in 4 of 32 banks: SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles)
@@ -388,7 +392,7 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) s.ra[it] = *reinterpret_cast<const float4*>(a_ptr[it] + k0);
     }
-    if (!APRE && (AFF || (!PF2 && a_aff))) {
+    if (!APRE && (AFF || (RT_AFF && a_aff))) {
       s.r_mul = *reinterpret_cast<const float4*>(p.a_mul + k0 + a_c4 * 4);
       s.r_add = *reinterpret_cast<const float4*>(p.a_add + k0 + a_c4 * 4);
     }
@@ -461,7 +465,7 @@ __device__ __forceinline__ void gemm_f16x3_body(const GemmP& p) {
     for (int it = 0; it < A_IT; ++it) {
       half4 hi, lo;
       float4 v = s.ra[it];
-      if (AFF || (!PF2 && a_aff)) {   // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
+      if (AFF || (RT_AFF && a_aff)) {   // relu(batch-norm(y)) of the previous layer, applied while the tile is staged
         v.x = fmaxf(v.x * s.r_mul.x + s.r_add.x, 0.0f); v.y = fmaxf(v.y * s.r_mul.y + s.r_add.y, 0.0f);
         v.z = fmaxf(v.z * s.r_mul.z + s.r_add.z, 0.0f); v.w = fmaxf(v.w * s.r_mul.w + s.r_add.w, 0.0f);
       }
@@ -932,7 +936,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // operand delivery from L2 is ~11 B/clk/CU whatever the load structure (profiles/README.md), so the
     // matrix pipe's utilisation is set by bytes per MFMA ~ (BM+BN)/(BM*BN): 256x256 (8 waves of 128x64)
     // where the grid still fills the chip, 256x128 for narrower N
-    if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0)
+    if (pre && wide && big_tile && a->M >= 8192 && a->N >= 1024 && a->pool == 0 && !a->a_mul)
       return launch_f16x3<4, 2, true, 2, 4>(p, a->batch, st);
     // train-mode encoder GEMMs (fused BatchNorm operands) run on their own stream UNDER the transformer's latency-bound
     // kernels: a tile whose LDS footprint leaves room for a second workgroup lets those co-reside (160 KB per CU:
