@@ -20,6 +20,33 @@ def _free_port() -> int:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
 
+def _run_two_ranks(worker, timeout=120):
+    """spawn two ranks of `worker(rank, world, port, queue)` and return what rank 0 put on the queue; one retry on a fresh
+    port if the rendezvous fails (another process can grab the port between _free_port() and the bind of the store)"""
+    last = None
+    for attempt in range(2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = q.get(timeout=timeout)
+            for p in procs:
+                p.join(timeout=60)
+            if all(p.exitcode == 0 for p in procs):
+                return out
+            last = RuntimeError(f"exit codes {[p.exitcode for p in procs]}")
+        except Exception as e:  # queue.Empty: a rank died before reporting
+            last = e
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    raise AssertionError(f"two-rank run failed twice: {last!r}")
+
+
 def _worker(rank, world, port, out):
     for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
         if p not in sys.path:
@@ -46,16 +73,7 @@ def _worker(rank, world, port, out):
 def test_two_rank_sharding_and_clock():
     from pfpp_hip import synthetic
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    clock, total, ids = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    clock, total, ids = _run_two_ranks(_worker)
     assert clock == 2.0
     assert ids == [[0, 3], [3, 6]]
     ref = float(synthetic.make_batch(0, 6, num_points=64)["part_valids"].sum())
@@ -86,16 +104,7 @@ def _grad_worker(rank, world, port, out):
 
 def test_two_rank_gradient_exchange():
     """the training exchange: every slice of the flat gradient buffer is summed exactly once"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    grads, scale = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    grads, scale = _run_two_ranks(_grad_worker)
     assert scale == 0.5
     assert torch.equal(grads, torch.arange(1000, dtype=torch.float32) * 3)   # rank0 (x1) + rank1 (x2)
 
@@ -129,16 +138,7 @@ def _sparse_worker(rank, world, port, out):
 def test_two_rank_sparse_row_exchange():
     """embedding-table gradients travel as (rows, indices) instead of a dense all-reduce: the result equals the summed
     dense gradient and the dense slices around the table are still reduced exactly once"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    grads, idx_all, scale = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    grads, idx_all, scale = _run_two_ranks(_sparse_worker)
     assert scale == 0.5 and idx_all == [3, 7, 13, 17]
     want = torch.zeros(320)
     want[160:] = torch.arange(160, dtype=torch.float32) * 3
