@@ -16,6 +16,8 @@
 // per-lane scalar multiply.  K/V tiles are shared by the 4 waves through a double-buffered LDS
 // stage (K rows padded to DH+4 floats: conflict-free 16-byte reads).
 // Sequences may have different lengths (seq_off / seq_len): padded fragments can be dropped.
+#include <stdlib.h>
+
 #include "pfpp_common.h"
 
 namespace {
@@ -181,6 +183,227 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// The same attention with the split-f16 contraction of the GEMMs (x = hi + lo, three v_mfma_f32_32x32x16_f16 per 16-deep
+// step, fp32 accumulation, lo.lo dropped: 2^-22 relative) instead of exact-fp32 MFMAs: 24 matrix instructions of 32 cycles
+// per 32-key tile instead of 64 of 64 cycles.  The kernel time of a step is set by the LONGEST sequence (a 20-fragment
+// puzzle walks 16 key tiles while a 4-fragment one walks 4), so the per-tile latency is what matters.
+//   S^T = K.Q^T   : K tile in LDS as fp16 planes [key][dim], Q fragments (8 consecutive dims per lane) split once
+//   O^T += V^T.P^T: V tile in LDS TRANSPOSED as planes [dim][key] (the A operand wants 8 consecutive keys per lane),
+//                   P^T from the score accumulator through the lane ^ 32 exchange (score_to_fragments)
+typedef _Float16 ad_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ad_half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ad_split(float x, _Float16& hi, _Float16& lo) {
+  const _Float16 h = (_Float16)x;
+  hi = h;
+  lo = (_Float16)(x - (float)h);
+}
+
+// accumulator tile (lane = query, register e = key (e&3) + 8*(e>>2) + 4*lhi) -> two 16-deep B fragments (lane = query,
+// 8 consecutive keys at 16*g + 8*lhi), hi and lo planes
+__device__ __forceinline__ void score_to_fragments(const f32x16 y, int lhi, ad_half8 (&fh)[2], ad_half8 (&fl)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    ad_half4 lo_h, lo_l, up_h, up_l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      _Float16 a, b;
+      ad_split(y[8 * g + q], a, b); lo_h[q] = a; lo_l[q] = b;
+      ad_split(y[8 * g + 4 + q], a, b); up_h[q] = a; up_l[q] = b;
+    }
+    const ad_half4 send_h = lhi ? lo_h : up_h, send_l = lhi ? lo_l : up_l;
+    union { ad_half4 h; int2 i; } sh, sl, rh, rl;
+    sh.h = send_h; sl.h = send_l;
+    rh.i.x = __shfl_xor(sh.i.x, 32); rh.i.y = __shfl_xor(sh.i.y, 32);
+    rl.i.x = __shfl_xor(sl.i.x, 32); rl.i.y = __shfl_xor(sl.i.y, 32);
+    const ad_half4 a_h = lhi ? rh.h : lo_h, b_h = lhi ? up_h : rh.h;
+    const ad_half4 a_l = lhi ? rl.h : lo_l, b_l = lhi ? up_l : rl.h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fh[g][q] = a_h[q]; fh[g][4 + q] = b_h[q];
+      fl[g][q] = a_l[q]; fl[g][4 + q] = b_l[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dense_f16_kernel(
+    const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
+    _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
+    int H, float scale, float* __restrict__ lse) {
+  constexpr int DH = 64, KT = 32;
+  constexpr int LDKH = DH + 8;          // halfs per K row  (16-byte fragment reads conflict-free)
+  constexpr int LDVH = KT + 8;          // halfs per V^T row
+  constexpr int F4 = KT * DH / 4 / 256;
+  __shared__ __align__(16) _Float16 Kh[2][KT * LDKH], Kl[2][KT * LDKH];
+  __shared__ __align__(16) _Float16 Vh[2][DH * LDVH], Vl[2][DH * LDVH];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 128;
+  if (q_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+  const uint8_t* kv = key_valid ? key_valid + (int64_t)b * kv_stride : nullptr;
+
+  // Q fragments of this lane's query: dims 16c + 8*lhi .. +7
+  const int q_row = q_base + wave * 32 + l31;
+  const float* qp = base + (int64_t)min(q_row, T - 1) * ld + lhi * 8;
+  ad_half8 qh[DH / 16], ql[DH / 16];
+#pragma unroll
+  for (int c = 0; c < DH / 16; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(qp + c * 16);
+    const float4 bq = *reinterpret_cast<const float4*>(qp + c * 16 + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 hh, ll;
+      ad_split(x[e], hh, ll);
+      qh[c][e] = hh; ql[c][e] = ll;
+    }
+  }
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  float4 rk[F4], rv[F4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      rk[it] = *reinterpret_cast<const float4*>(src);
+      rv[it] = *reinterpret_cast<const float4*>(src + C);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float kx[4] = {rk[it].x, rk[it].y, rk[it].z, rk[it].w};
+      const float vx[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+      ad_half4 kh4, kl4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 hh, ll;
+        ad_split(kx[j], hh, ll);
+        kh4[j] = hh; kl4[j] = ll;
+        ad_split(vx[j], hh, ll);
+        Vh[buf][(c4 * 4 + j) * LDVH + r] = hh;         // transposed: [dim][key]
+        Vl[buf][(c4 * 4 + j) * LDVH + r] = ll;
+      }
+      *reinterpret_cast<ad_half4*>(&Kh[buf][r * LDKH + c4 * 4]) = kh4;
+      *reinterpret_cast<ad_half4*>(&Kl[buf][r * LDKH + c4 * 4]) = kl4;
+    }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int k0 = t * KT;
+    if (t + 1 < nt) load_tile(k0 + KT);
+
+    const int kidx = k0 + l31;
+    const bool kval = kidx < T && (!kv || kv[kidx] != 0);
+    const unsigned kmask = (unsigned)(__ballot(kval) & 0xffffffffull);
+
+    // ---- S^T = K . Q^T ----
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DH / 16; ++c) {
+      const ad_half8 kh = *reinterpret_cast<const ad_half8*>(&Kh[buf][l31 * LDKH + c * 16 + lhi * 8]);
+      const ad_half8 kl = *reinterpret_cast<const ad_half8*>(&Kl[buf][l31 * LDKH + c * 16 + lhi * 8]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], s, 0, 0, 0);
+    }
+
+    // ---- online softmax over this lane's query column ----
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const float v = (kmask >> key) & 1u ? s[e] * scale : -__builtin_huge_valf();
+      s[e] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = expf(s[e] - m_new);
+      s[e] = pe;
+      psum += pe;
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+
+    // ---- O^T += V^T . P^T ----
+    ad_half8 ph[2], pl[2];
+    score_to_fragments(s, lhi, ph, pl);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[buf][(dt * 32 + l31) * LDVH + g * 16 + lhi * 8]);
+        const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[buf][(dt * 32 + l31) * LDVH + g * 16 + lhi * 8]);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], o_acc[dt], 0, 0, 0);
+      }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[query = l31][d = dt*32 + 8g + 4*lhi + (0..3)] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (lse && q_row < T && lhi == 0) lse[(row0 + q_row) * H + h] = m_run + logf(l_tot);
+  if (q_row < T) {
+    const int64_t off = (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = o_acc[dt][4 * g + 0] * inv, v1 = o_acc[dt][4 * g + 1] * inv;
+        const float v2 = o_acc[dt][4 * g + 2] * inv, v3 = o_acc[dt][4 * g + 3] * inv;
+        if (out_hi) {
+          ad_half4 hi, lo;
+          PFPP_SPLIT_TO(v0, hi[0], lo[0]);
+          PFPP_SPLIT_TO(v1, hi[1], lo[1]);
+          PFPP_SPLIT_TO(v2, hi[2], lo[2]);
+          PFPP_SPLIT_TO(v3, hi[3], lo[3]);
+          *reinterpret_cast<ad_half4*>(out_hi + off + dt * 32 + 8 * g) = hi;
+          *reinterpret_cast<ad_half4*>(out_lo + off + dt * 32 + 8 * g) = lo;
+        } else {
+          *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
+        }
+      }
+  }
+}
+
 }  // namespace
 
 static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
@@ -226,7 +449,16 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   if (n_seq == 0) return PFPP_OK;
   const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
   hipStream_t st = pfpp::as_stream(stream);
-  if (dh == 64)
+  // split-f16 kernel: 44.9 -> 28.3 us on the compacted (ragged, unmasked) token list, where the longest sequence's walk over
+  // its key tiles is the critical path; on the all-slots form (32 x 500 keys, masked: throughput-bound) its transposed
+  // 2-byte LDS stores of V conflict and it is 3x slower (661 vs 228 us) — so it takes the unmasked launches only.
+  // PFPP_ATTN_F16X3: 0 never, 1 unmasked launches (default), 2 always.
+  static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
+  const bool f16x3 = f16_mode == 2 || (f16_mode == 1 && key_valid == nullptr);
+  if (dh == 64 && f16x3)
+    hipLaunchKernelGGL(attn_dense_f16_kernel, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                       key_valid, kv_stride, (int)H, scale, lse);
+  else if (dh == 64)
     hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                        key_valid, kv_stride, (int)H, scale, lse);
   else
