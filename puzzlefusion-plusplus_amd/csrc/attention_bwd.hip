@@ -334,6 +334,335 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The two passes with the split-f16 contraction (three v_mfma_f32_32x32x16_f16 per 16-deep step, see attention.hip's
+// attn_dense_f16_kernel): 36 / 48 matrix instructions of 32 cycles per 32 x 32 tile pair instead of 96 / 128 of 64 cycles.
+// The step time of the backward is the walk of the LONGEST sequence over its tiles, so this is its critical path.
+// Gradient operands are lifted into the normal fp16 range by powers of two before the split (dO by 2^12, dS by 2^14)
+// and the accumulators are scaled back at the end.  Second-stage products read their A operand from TRANSPOSED tiles.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 ab_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ab_half4 __attribute__((ext_vector_type(4)));
+constexpr float AB_GS = 4096.0f;        // dO
+constexpr float AB_DS = 16384.0f;       // dS
+constexpr int AB_LDR = 64 + 8;          // halfs per row of a [row][dim] tile
+constexpr int AB_LDT = KT + 8;          // halfs per row of a transposed [dim][row] tile
+
+__device__ __forceinline__ void ab_split(float x, _Float16& hi, _Float16& lo) {
+  const _Float16 h = (_Float16)x;
+  hi = h;
+  lo = (_Float16)(x - (float)h);
+}
+
+// 8 consecutive floats (x scale) -> hi / lo operand fragment
+__device__ __forceinline__ void ab_frag8(const float* p, float sc, ab_half8& hi, ab_half8& lo) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 h, l;
+    ab_split(x[e] * sc, h, l);
+    hi[e] = h; lo[e] = l;
+  }
+}
+
+// accumulator tile (lane = column n, register e = row (e&3) + 8*(e>>2) + 4*lhi) -> two 16-deep B fragments
+// (lane = n, 8 consecutive rows at 16*g + 8*lhi); lanes l and l+32 exchange the quads the other one needs
+__device__ __forceinline__ void ab_acc_to_fragments(const f32x16 y, int lhi, ab_half8 (&fh)[2], ab_half8 (&fl)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    ab_half4 lo_h, lo_l, up_h, up_l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      _Float16 a, b;
+      ab_split(y[8 * g + q], a, b); lo_h[q] = a; lo_l[q] = b;
+      ab_split(y[8 * g + 4 + q], a, b); up_h[q] = a; up_l[q] = b;
+    }
+    const ab_half4 send_h = lhi ? lo_h : up_h, send_l = lhi ? lo_l : up_l;
+    union { ab_half4 h; int2 i; } sh, sl, rh, rl;
+    sh.h = send_h; sl.h = send_l;
+    rh.i.x = __shfl_xor(sh.i.x, 32); rh.i.y = __shfl_xor(sh.i.y, 32);
+    rl.i.x = __shfl_xor(sl.i.x, 32); rl.i.y = __shfl_xor(sl.i.y, 32);
+    const ab_half4 a_h = lhi ? rh.h : lo_h, b_h = lhi ? up_h : rh.h;
+    const ab_half4 a_l = lhi ? rl.h : lo_l, b_l = lhi ? up_l : rl.h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fh[g][q] = a_h[q]; fh[g][4 + q] = b_h[q];
+      fl[g][q] = a_l[q]; fl[g][4 + q] = b_l[q];
+    }
+  }
+}
+
+// acc += A(lo).B(hi) + A(hi).B(lo) + A(hi).B(hi) for the 16-deep fragments read at (row l31, offset) of the planes ah / al
+__device__ __forceinline__ f32x16 ab_mma3(const _Float16* ah, const _Float16* al, const ab_half8 bh, const ab_half8 bl, f32x16 acc) {
+  const ab_half8 xh = *reinterpret_cast<const ab_half8*>(ah);
+  const ab_half8 xl = *reinterpret_cast<const ab_half8*>(al);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, bh, acc, 0, 0, 0);
+  return acc;
+}
+
+// one float4 of a [row r][dims c4*4..] tile -> row planes (8-byte store) and, if tp, transposed planes (2-byte stores)
+__device__ __forceinline__ void ab_store4(const float4 v, float sc, int r, int c4, _Float16* rh, _Float16* rl, _Float16* th, _Float16* tl) {
+  const float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+  ab_half4 h4, l4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 h, l;
+    ab_split(x[j], h, l);
+    h4[j] = h; l4[j] = l;
+    if (th) {
+      th[(c4 * 4 + j) * AB_LDT + r] = h;
+      tl[(c4 * 4 + j) * AB_LDT + r] = l;
+    }
+  }
+  *reinterpret_cast<ab_half4*>(rh + r * AB_LDR + c4 * 4) = h4;
+  *reinterpret_cast<ab_half4*>(rl + r * AB_LDR + c4 * 4) = l4;
+}
+
+__global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+  constexpr int DH = 64;
+  constexpr int F4 = KT * DH / 4 / 256;
+  __shared__ __align__(16) _Float16 Kh[2][KT * AB_LDR], Kl[2][KT * AB_LDR], Vh[2][KT * AB_LDR], Vl[2][KT * AB_LDR];
+  __shared__ __align__(16) _Float16 Kth[2][DH * AB_LDT], Ktl[2][DH * AB_LDT];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 128;
+  if (q_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+
+  const int q_row = q_base + wave * 32 + l31;
+  const int q_cl = min(q_row, T - 1);
+  // D = rowsum(dO . O) in fp32, with the lane mapping of the exact kernels (same bits)
+  float Dq;
+  {
+    const float* op = out + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+    const float* dop = dout + (row0 + q_cl) * (int64_t)C + h * DH + lhi * 4;
+    float dpart = 0.0f;
+#pragma unroll
+    for (int kc = 0; kc < DH / 8; ++kc) {
+      const float4 d = *reinterpret_cast<const float4*>(dop + kc * 8);
+      const float4 o = *reinterpret_cast<const float4*>(op + kc * 8);
+      dpart += (d.x * o.x + d.y * o.y) + (d.z * o.z + d.w * o.w);
+    }
+    Dq = dpart + __shfl_xor(dpart, 32);
+    if (dvec && q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
+  }
+  const float lse_q = lse[(row0 + q_cl) * H + h];
+  ab_half8 qh[4], ql[4], gh[4], gl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ab_frag8(base + (int64_t)q_cl * ld + c * 16 + lhi * 8, 1.0f, qh[c], ql[c]);
+    ab_frag8(dout + (row0 + q_cl) * (int64_t)C + h * DH + c * 16 + lhi * 8, AB_GS, gh[c], gl[c]);
+  }
+  f32x16 dq_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq_acc[dt][e] = 0.0f;
+
+  float4 rk[F4], rv[F4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      rk[it] = *reinterpret_cast<const float4*>(src);
+      rv[it] = *reinterpret_cast<const float4*>(src + C);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      ab_store4(rk[it], 1.0f, r, c4, Kh[buf], Kl[buf], Kth[buf], Ktl[buf]);
+      ab_store4(rv[it], 1.0f, r, c4, Vh[buf], Vl[buf], nullptr, nullptr);
+    }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int k0 = t * KT;
+    if (t + 1 < nt) load_tile(k0 + KT);
+    const unsigned kmask = (unsigned)(__ballot(k0 + l31 < T) & 0xffffffffull);
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.0f; dp[e] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = l31 * AB_LDR + c * 16 + lhi * 8;
+      s = ab_mma3(&Kh[buf][off], &Kl[buf][off], qh[c], ql[c], s);        // S^T[key][query]
+      dp = ab_mma3(&Vh[buf][off], &Vl[buf][off], gh[c], gl[c], dp);      // dP^T * 2^12
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const float pv = (kmask >> key) & 1u ? expf(s[e] * scale - lse_q) : 0.0f;
+      s[e] = pv * (dp[e] * (1.0f / AB_GS) - Dq) * (scale * AB_DS);      // dS^T * 2^14
+    }
+    ab_half8 sh[2], sl[2];
+    ab_acc_to_fragments(s, lhi, sh, sl);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int off = (dt * 32 + l31) * AB_LDT + g * 16 + lhi * 8;
+        dq_acc[dt] = ab_mma3(&Kth[buf][off], &Ktl[buf][off], sh[g], sl[g], dq_acc[dt]);   // dQ^T[d][query] * 2^14
+      }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (q_row < T) {
+    float* dst = dqkv + (row0 + q_row) * ld + h * DH + lhi * 4;
+    constexpr float inv = 1.0f / AB_DS;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
+            make_float4(dq_acc[dt][4 * g + 0] * inv, dq_acc[dt][4 * g + 1] * inv, dq_acc[dt][4 * g + 2] * inv, dq_acc[dt][4 * g + 3] * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, int H, float scale) {
+  constexpr int DH = 64;
+  constexpr int F4 = KT * DH / 4 / 256;
+  __shared__ __align__(16) _Float16 Qh[2][KT * AB_LDR], Ql[2][KT * AB_LDR], Gh[2][KT * AB_LDR], Gl[2][KT * AB_LDR];
+  __shared__ __align__(16) _Float16 Qth[2][DH * AB_LDT], Qtl[2][DH * AB_LDT], Gth[2][DH * AB_LDT], Gtl[2][DH * AB_LDT];
+  __shared__ float Ls[2][KT], Ds[2][KT];
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int k_base = blockIdx.x * 128;
+  if (k_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+
+  const int k_row = k_base + wave * 32 + l31;
+  const bool key_ok = k_row < T;
+  const float* kp = base + (int64_t)min(k_row, T - 1) * ld + C + lhi * 8;
+  ab_half8 kh[4], kl[4], vh[4], vl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ab_frag8(kp + c * 16, 1.0f, kh[c], kl[c]);
+    ab_frag8(kp + C + c * 16, 1.0f, vh[c], vl[c]);
+  }
+  f32x16 dk_acc[2], dv_acc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk_acc[dt][e] = 0.0f; dv_acc[dt][e] = 0.0f; }
+
+  float4 rq[F4], rg[F4];
+  float rl = 0.0f, rd = 0.0f;
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const int64_t qr = min(q0 + r, T - 1);
+      rq[it] = *reinterpret_cast<const float4*>(base + qr * ld + c4 * 4);
+      rg[it] = *reinterpret_cast<const float4*>(dout + (row0 + qr) * (int64_t)C + h * DH + c4 * 4);
+    }
+    if (tid < KT) {
+      const int64_t qr = min(q0 + tid, T - 1);
+      rl = lse[(row0 + qr) * H + h];
+      rd = dvec[(row0 + qr) * H + h];
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      ab_store4(rq[it], 1.0f, r, c4, Qh[buf], Ql[buf], Qth[buf], Qtl[buf]);
+      ab_store4(rg[it], AB_GS, r, c4, Gh[buf], Gl[buf], Gth[buf], Gtl[buf]);
+    }
+    if (tid < KT) { Ls[buf][tid] = rl; Ds[buf][tid] = rd; }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int q0 = t * KT;
+    if (t + 1 < nt) load_tile(q0 + KT);
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.0f; dp[e] = 0.0f; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = l31 * AB_LDR + c * 16 + lhi * 8;
+      s = ab_mma3(&Qh[buf][off], &Ql[buf][off], kh[c], kl[c], s);        // S[query][key]
+      dp = ab_mma3(&Gh[buf][off], &Gl[buf][off], vh[c], vl[c], dp);      // dP * 2^12
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const bool ok = key_ok && (q0 + qi) < T;
+      const float pv = ok ? expf(s[e] * scale - Ls[buf][qi]) : 0.0f;
+      s[e] = pv;
+      dp[e] = pv * (dp[e] * (1.0f / AB_GS) - Ds[buf][qi]) * (scale * AB_DS);     // dS * 2^14
+    }
+    ab_half8 ph[2], pl[2], sh[2], sl[2];
+    ab_acc_to_fragments(s, lhi, ph, pl);
+    ab_acc_to_fragments(dp, lhi, sh, sl);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int off = (dt * 32 + l31) * AB_LDT + g * 16 + lhi * 8;
+        dv_acc[dt] = ab_mma3(&Gth[buf][off], &Gtl[buf][off], ph[g], pl[g], dv_acc[dt]);   // dV^T[d][key] * 2^12
+        dk_acc[dt] = ab_mma3(&Qth[buf][off], &Qtl[buf][off], sh[g], sl[g], dk_acc[dt]);   // dK^T[d][key] * 2^14
+      }
+    if (t + 1 < nt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (k_row < T) {
+    float* dst = dqkv + (row0 + k_row) * ld + C + h * DH + lhi * 4;
+    constexpr float ik = 1.0f / AB_DS, iv = 1.0f / AB_GS;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
+            make_float4(dk_acc[dt][4 * g + 0] * ik, dk_acc[dt][4 * g + 1] * ik, dk_acc[dt][4 * g + 2] * ik, dk_acc[dt][4 * g + 3] * ik);
+        *reinterpret_cast<float4*>(dst + C + dt * 32 + 8 * g) =
+            make_float4(dv_acc[dt][4 * g + 0] * iv, dv_acc[dt][4 * g + 1] * iv, dv_acc[dt][4 * g + 2] * iv, dv_acc[dt][4 * g + 3] * iv);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // block-diagonal attention backward: one 64-thread workgroup per (fragment, head)
 // ---------------------------------------------------------------------------------------------------
 constexpr int BD_L = 32;
@@ -573,6 +902,15 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
   if (n_seq == 0) return PFPP_OK;
   const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
   hipStream_t st = pfpp::as_stream(stream);
+  // split-f16 passes for the unmasked (ragged) launches, like pfpp_attn_dense (PFPP_ATTN_F16X3: 0 never, 1 unmasked, 2 -)
+  static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
+  if (dh == 64 && f16_mode >= 1 && key_valid == nullptr) {
+    hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
+                       (int)H, scale);
+    hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off, seq_len,
+                       (int)H, scale);
+    return pfpp::check_launch(__func__);
+  }
   if (dh == 64) {
     hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<64>, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off,
                        seq_len, key_valid, kv_stride, (int)H, scale);
@@ -603,6 +941,15 @@ extern "C" int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, con
   const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
   hipStream_t st = pfpp::as_stream(stream);
   const int Hi = (int)H;
+  static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
+  if (dh == 64 && f16_mode >= 1 && key_valid == nullptr) {      // same kernel choice as pfpp_attn_dense_bwd
+    if (parts & 1) hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
+    if (parts & 2) hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, (float*)nullptr, dqkv,
+                                      seq_off, seq_len, Hi, scale);
+    if (parts & 4) hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
+                                      seq_len, Hi, scale);
+    return pfpp::check_launch(__func__);
+  }
   if (dh == 64) {
     if (parts & 1) hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
     if (parts & 2) hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<64>, grid, dim3(256), 0, st, qkv, out, dout, lse, (float*)nullptr, dqkv,
