@@ -227,6 +227,10 @@ __device__ __forceinline__ void score_to_fragments(const f32x16 y, int lhi, ad_h
   }
 }
 
+// offset (halfs) of (dim, key) in the transposed V planes: keys in 16-byte chunks of 8, the chunk index XOR-swizzled by bits
+// 4-5 of the dim (the 16 lanes that write one key pair for dims 4*c4 + j then hit 16 different banks)
+__device__ __forceinline__ int ad_toff(int dim, int key) { return dim * (32 + 8) + ((((key >> 3) ^ (dim >> 4)) & 3) << 3) + (key & 7); }
+
 __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
     _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
@@ -293,18 +297,31 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
       const int r = idx / (DH / 4), c4 = idx % (DH / 4);
       const float kx[4] = {rk[it].x, rk[it].y, rk[it].z, rk[it].w};
       const float vx[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
-      ad_half4 kh4, kl4;
+      ad_half4 kh4, kl4, vh4, vl4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         _Float16 hh, ll;
         ad_split(kx[j], hh, ll);
         kh4[j] = hh; kl4[j] = ll;
         ad_split(vx[j], hh, ll);
-        Vh[buf][(c4 * 4 + j) * LDVH + r] = hh;         // transposed: [dim][key]
-        Vl[buf][(c4 * 4 + j) * LDVH + r] = ll;
+        vh4[j] = hh; vl4[j] = ll;
       }
       *reinterpret_cast<ad_half4*>(&Kh[buf][r * LDKH + c4 * 4]) = kh4;
       *reinterpret_cast<ad_half4*>(&Kl[buf][r * LDKH + c4 * 4]) = kl4;
+      // V transposed ([dim][key]): lanes r and r+1 (16 apart) swap halves, each then writes two keys of two dims as words
+      union { ad_half4 h; int2 i; } uh, ul;
+      uh.h = vh4; ul.h = vl4;
+      const bool odd = r & 1;
+      const int keep_h = odd ? uh.i.y : uh.i.x, send_h = odd ? uh.i.x : uh.i.y;
+      const int keep_l = odd ? ul.i.y : ul.i.x, send_l = odd ? ul.i.x : ul.i.y;
+      const int got_h = __shfl_xor(send_h, 16), got_l = __shfl_xor(send_l, 16);
+      const int a_h = odd ? got_h : keep_h, b_h = odd ? keep_h : got_h;
+      const int a_l = odd ? got_l : keep_l, b_l = odd ? keep_l : got_l;
+      const int d0 = c4 * 4 + (odd ? 2 : 0), r0 = r & ~1;
+      *reinterpret_cast<int*>(&Vh[buf][ad_toff(d0, r0)]) = (a_h & 0xffff) | (b_h << 16);
+      *reinterpret_cast<int*>(&Vh[buf][ad_toff(d0 + 1, r0)]) = ((unsigned)a_h >> 16) | (b_h & 0xffff0000);
+      *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0, r0)]) = (a_l & 0xffff) | (b_l << 16);
+      *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0 + 1, r0)]) = ((unsigned)a_l >> 16) | (b_l & 0xffff0000);
     }
   };
 
@@ -367,8 +384,8 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[buf][(dt * 32 + l31) * LDVH + g * 16 + lhi * 8]);
-        const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[buf][(dt * 32 + l31) * LDVH + g * 16 + lhi * 8]);
+        const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
+        const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o_acc[dt], 0, 0, 0);
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o_acc[dt], 0, 0, 0);
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], o_acc[dt], 0, 0, 0);
@@ -449,12 +466,12 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   if (n_seq == 0) return PFPP_OK;
   const dim3 grid((unsigned)((max_len + 127) / 128), (unsigned)H, (unsigned)n_seq);
   hipStream_t st = pfpp::as_stream(stream);
-  // split-f16 kernel: 44.9 -> 28.3 us on the compacted (ragged, unmasked) token list, where the longest sequence's walk over
-  // its key tiles is the critical path; on the all-slots form (32 x 500 keys, masked: throughput-bound) its transposed
-  // 2-byte LDS stores of V conflict and it is 3x slower (661 vs 228 us) — so it takes the unmasked launches only.
-  // PFPP_ATTN_F16X3: 0 never, 1 unmasked launches (default), 2 always.
+  // split-f16 kernel (default for dim_head 64): 44.6 -> 26.3 us on the compacted (ragged) token list, where the longest
+  // sequence's walk over its key tiles is the critical path, and 226 -> 127 us on the all-slots form (32 x 500 keys, masked).
+  // (Its first version stored V^T with 2-byte LDS writes: 661 us there; pairs of keys as swizzled 4-byte words fixed it.)
+  // PFPP_ATTN_F16X3=0: the exact-fp32 MFMA kernel.
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
-  const bool f16x3 = f16_mode == 2 || (f16_mode == 1 && key_valid == nullptr);
+  const bool f16x3 = f16_mode != 0;
   if (dh == 64 && f16x3)
     hipLaunchKernelGGL(attn_dense_f16_kernel, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                        key_valid, kv_stride, (int)H, scale, lse);

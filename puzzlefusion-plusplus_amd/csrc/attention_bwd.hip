@@ -403,7 +403,12 @@ __device__ __forceinline__ f32x16 ab_mma3(const _Float16* ah, const _Float16* al
   return acc;
 }
 
-// one float4 of a [row r][dims c4*4..] tile -> row planes (8-byte store) and, if tp, transposed planes (2-byte stores)
+// offset (halfs) of (dim, row) in a transposed plane: rows in 16-byte chunks of 8, the chunk index XOR-swizzled by bits 4-5
+// of the dim so that the 16 lanes that write the same row pair for dims 4*c4 + j land in 16 different banks
+__device__ __forceinline__ int ab_toff(int dim, int row) { return dim * AB_LDT + ((((row >> 3) ^ (dim >> 4)) & 3) << 3) + (row & 7); }
+
+// one float4 of a [row r][dims c4*4..] tile (thread idx = r*16 + c4) -> row planes (8-byte store) and, if th, transposed
+// planes: lanes r and r+1 (16 apart) swap halves first, so each writes TWO rows of two dims as 4-byte words
 __device__ __forceinline__ void ab_store4(const float4 v, float sc, int r, int c4, _Float16* rh, _Float16* rl, _Float16* th, _Float16* tl) {
   const float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
   ab_half4 h4, l4;
@@ -412,13 +417,29 @@ __device__ __forceinline__ void ab_store4(const float4 v, float sc, int r, int c
     _Float16 h, l;
     ab_split(x[j], h, l);
     h4[j] = h; l4[j] = l;
-    if (th) {
-      th[(c4 * 4 + j) * AB_LDT + r] = h;
-      tl[(c4 * 4 + j) * AB_LDT + r] = l;
-    }
   }
   *reinterpret_cast<ab_half4*>(rh + r * AB_LDR + c4 * 4) = h4;
   *reinterpret_cast<ab_half4*>(rl + r * AB_LDR + c4 * 4) = l4;
+  if (th) {
+    union { ab_half4 h; int2 i; } uh, ul;
+    uh.h = h4; ul.h = l4;
+    const bool odd = r & 1;
+    // even rows keep dims 0,1 (word .x) and send dims 2,3 (.y); odd rows keep dims 2,3 and send dims 0,1
+    const int keep_h = odd ? uh.i.y : uh.i.x, send_h = odd ? uh.i.x : uh.i.y;
+    const int keep_l = odd ? ul.i.y : ul.i.x, send_l = odd ? ul.i.x : ul.i.y;
+    const int got_h = __shfl_xor(send_h, 16), got_l = __shfl_xor(send_l, 16);
+    // (own row, partner row) in row order: even lane = (r, r+1), odd lane = (r-1, r)
+    const int a_h = odd ? got_h : keep_h, b_h = odd ? keep_h : got_h;
+    const int a_l = odd ? got_l : keep_l, b_l = odd ? keep_l : got_l;
+    const int d0 = c4 * 4 + (odd ? 2 : 0), r0 = r & ~1;
+    // word for dim d0: low half = row r0, high half = row r0+1 (low halves of a, b); dim d0+1: the high halves
+    const int w0_h = (a_h & 0xffff) | (b_h << 16), w1_h = ((unsigned)a_h >> 16) | (b_h & 0xffff0000);
+    const int w0_l = (a_l & 0xffff) | (b_l << 16), w1_l = ((unsigned)a_l >> 16) | (b_l & 0xffff0000);
+    *reinterpret_cast<int*>(th + ab_toff(d0, r0)) = w0_h;
+    *reinterpret_cast<int*>(th + ab_toff(d0 + 1, r0)) = w1_h;
+    *reinterpret_cast<int*>(tl + ab_toff(d0, r0)) = w0_l;
+    *reinterpret_cast<int*>(tl + ab_toff(d0 + 1, r0)) = w1_l;
+  }
 }
 
 __global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int off = (dt * 32 + l31) * AB_LDT + g * 16 + lhi * 8;
+        const int off = ab_toff(dt * 32 + l31, g * 16 + lhi * 8);
         dq_acc[dt] = ab_mma3(&Kth[buf][off], &Ktl[buf][off], sh[g], sl[g], dq_acc[dt]);   // dQ^T[d][query] * 2^14
       }
     if (t + 1 < nt) store_tile(buf ^ 1);
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int off = (dt * 32 + l31) * AB_LDT + g * 16 + lhi * 8;
+        const int off = ab_toff(dt * 32 + l31, g * 16 + lhi * 8);
         dv_acc[dt] = ab_mma3(&Gth[buf][off], &Gtl[buf][off], ph[g], pl[g], dv_acc[dt]);   // dV^T[d][key] * 2^12
         dk_acc[dt] = ab_mma3(&Qth[buf][off], &Qtl[buf][off], sh[g], sl[g], dk_acc[dt]);   // dK^T[d][key] * 2^14
       }
