@@ -362,11 +362,11 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __expf(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = expf(s[e] - m_new);
+      const float pe = __expf(s[e] - m_new);
       s[e] = pe;
       psum += pe;
     }

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      const float pv = (kmask >> key) & 1u ? expf(s[e] * scale - lse_q) : 0.0f;
+      const float pv = (kmask >> key) & 1u ? __expf(s[e] * scale - lse_q) : 0.0f;
       s[e] = pv * (dp[e] * (1.0f / AB_GS) - Dq) * (scale * AB_DS);      // dS^T * 2^14
     }
     ab_half8 sh[2], sl[2];
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
     for (int e = 0; e < 16; ++e) {
       const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
       const bool ok = key_ok && (q0 + qi) < T;
-      const float pv = ok ? expf(s[e] * scale - Ls[buf][qi]) : 0.0f;
+      const float pv = ok ? __expf(s[e] * scale - Ls[buf][qi]) : 0.0f;
       s[e] = pv;
       dp[e] = pv * (dp[e] * (1.0f / AB_GS) - Ds[buf][qi]) * (scale * AB_DS);     // dS * 2^14
     }
