@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-    st[e] = key < L ? expf(st[e] - mx) : 0.0f;
+    st[e] = key < L ? __expf(st[e] - mx) : 0.0f;
     sum += st[e];
   }
   sum += __shfl_xor(sum, 32);
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
   for (int e = 0; e < 16; ++e) {
     const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
     const float m_q = __shfl(mx, qi), i_q = __shfl(inv, qi), d_q = __shfl(dsum, qi);
-    const float pv = qi < L ? expf(sk[e] * scale - m_q) * i_q : 0.0f;          // queries >= L do not exist
+    const float pv = qi < L ? __expf(sk[e] * scale - m_q) * i_q : 0.0f;          // queries >= L do not exist
     pk[e] = pv;
     dp[e] = pv * (dp[e] - d_q) * scale;                                         // dS
   }

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_blockdiag_mfma_kernel(const float* _
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-    s[e] = key < L ? expf(s[e] - mx) : 0.0f;
+    s[e] = key < L ? __expf(s[e] - mx) : 0.0f;
     sum += s[e];
   }
   sum += __shfl_xor(sum, 32);
