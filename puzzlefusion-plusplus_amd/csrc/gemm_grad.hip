@@ -375,10 +375,11 @@ int dispatch(GradP p, int batch, int split_k, hipStream_t st) {
   int splits = split_k;
   if (splits <= 0 && !p.accumulate) splits = 1;     // a plain store cannot be split
   if (splits <= 0) {
-    // auto: ~1.5 workgroups per CU, chunks at least 512 deep (measured best on the [3850-token] training step:
-    // more, shallower chunks pay more in atomics than they gain in occupancy)
-    static const int target_wg = getenv("PFPP_GRAD_WG") ? atoi(getenv("PFPP_GRAD_WG")) : 384;
-    static const int min_k = getenv("PFPP_GRAD_MINK") ? atoi(getenv("PFPP_GRAD_MINK")) : 512;
+    // auto: ~1 workgroup per CU, chunks at least 1024 deep.  Measured on the [3850-token] training step after the K loop
+    // became one scheduling region (each workgroup is faster, so fewer, deeper chunks win — less atomic traffic):
+    // (384, 512) 8.66 ms, (256, 512) 8.48, (192, 512) 8.29, (256, 1024) 8.28, (320, 1024) 8.33, (256, 2048) 8.93 per iteration
+    static const int target_wg = getenv("PFPP_GRAD_WG") ? atoi(getenv("PFPP_GRAD_WG")) : 256;
+    static const int min_k = getenv("PFPP_GRAD_MINK") ? atoi(getenv("PFPP_GRAD_MINK")) : 1024;
     const int64_t t = tiles(bm, bn);
     int64_t want = (target_wg + t - 1) / t;
     const int64_t max_by_k = (p.K + min_k - 1) / min_k;
