@@ -483,6 +483,26 @@ int pfpp_layernorm_bwd(const float* x, const float* dy, const float* mod, int64_
                        int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
                        int64_t rows, int64_t C, float eps, pfpp_stream_t stream);
 
+/* The same with the dropout that follows each LayerNorm in the backward chain fused in (EncoderLayer's
+ * dropout after the attention out-projections attention.py:46-52, PositionalEncoding's token dropout
+ * model_utils.py:18-21): drop_out[r, c] = keep(seed, site, r*C + c) ? dx_new[r, c] / (1 - p) : 0 — the mask of
+ * pfpp_dropout over a [rows, C] tensor, so forward and backward sites regenerate each other's masks.      */
+int pfpp_layernorm_bwd_dropout(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                               const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                               int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                               int64_t rows, int64_t C, float eps, float* drop_out, float p, uint64_t seed,
+                               uint32_t site, pfpp_stream_t stream);
+
+/* Forward counterpart: h_out = (res or 0) + dropout(y; p, seed, site), n_out = LayerNorm(h_out) with the
+ * (mod | gamma, beta | none) forms and the row -> batch mapping of pfpp_layernorm / pfpp_layernorm_grouped
+ * (group_batch != NULL: batch = group_batch[row / group_rows], else row / rows_per_batch).  h_out may alias
+ * y or res.  h_out has the bits of pfpp_dropout, n_out those of pfpp_layernorm up to the contraction of the
+ * affine step (an ulp).  C in {256, 512}.                                                                 */
+int pfpp_dropout_layernorm(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                           int64_t ld_mod, const float* gamma, const float* beta, const int32_t* group_batch,
+                           int64_t group_rows, int64_t rows_per_batch, int64_t rows, int64_t C, float eps,
+                           float p, uint64_t seed, uint32_t site, pfpp_stream_t stream);
+
 /* ---- attention backward ---------------------------------------------------------------------------
  * dqkv [rows, 3*H*dh] receives (dq | dk | dv) of softmax(q.k^T * scale) v.
  * pfpp_attn_dense_train: pfpp_attn_dense that also writes lse[row, h] = log sum_j exp(s_ij) (needed by

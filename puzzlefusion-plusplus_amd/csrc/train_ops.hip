@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mod, int64_t ld_mod,
     const float* __restrict__ gamma, const int32_t* __restrict__ group_batch, int group_rows, int rows_per_batch,
     float* __restrict__ dx, float* __restrict__ dmult, float* __restrict__ dadd, int64_t ld_d, int64_t rows,
-    float eps) {
+    float eps, float* __restrict__ drop_out, uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
   constexpr int C = 256 * VPL;
   __shared__ float red[2][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -247,6 +247,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       o.z += rstd * (g[k].z - c1 - v[k].z * c2);
       o.w += rstd * (g[k].w - c1 - v[k].w * c2);
       dxr[lane + 64 * k] = o;
+      if (drop_out) {      // the dropout that follows in the backward chain (same mask as pfpp_dropout over [rows, C])
+        const uint64_t i4 = (uint64_t)row * C + (uint64_t)(lane + 64 * k) * 4;
+        float4 dd;
+        dd.x = pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? o.x * inv_keep : 0.0f;
+        dd.y = pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? o.y * inv_keep : 0.0f;
+        dd.z = pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? o.z * inv_keep : 0.0f;
+        dd.w = pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? o.w * inv_keep : 0.0f;
+        reinterpret_cast<float4*>(drop_out + row * C)[lane + 64 * k] = dd;
+      }
     }
   }
   if (!dmult) return;      // uniform
@@ -262,6 +271,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float bb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     unsafeAtomicAdd(dmult + b * ld_d + c, a);
     unsafeAtomicAdd(dadd + b * ld_d + c, bb);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// forward: h = (res or 0) + dropout(y), n = LayerNorm(h) in one pass (one wave per row, the arithmetic of
+// pfpp_dropout followed by pfpp_layernorm, one read of y/res instead of three passes)
+// ---------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void dropout_layernorm_kernel(
+    const float* __restrict__ y, const float* __restrict__ res, float* __restrict__ h_out, float* __restrict__ n_out,
+    const float* __restrict__ mod, int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int64_t rows, int rows_per_batch, float eps, const int32_t* __restrict__ group_batch, int group_rows,
+    uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
+  constexpr int C = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[VPL];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    const float4 a = reinterpret_cast<const float4*>(y + row * C)[c4];
+    float4 r = res ? reinterpret_cast<const float4*>(res + row * C)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint64_t i4 = (uint64_t)row * C + (uint64_t)c4 * 4;
+    r.x += pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? a.x * inv_keep : 0.0f;
+    r.y += pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? a.y * inv_keep : 0.0f;
+    r.z += pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? a.z * inv_keep : 0.0f;
+    r.w += pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? a.w * inv_keep : 0.0f;
+    reinterpret_cast<float4*>(h_out + row * C)[c4] = r;
+    v[k] = r;
+    s += (r.x + r.y) + (r.z + r.w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = wave_sum(q) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    float4 o;
+    o.x = (v[k].x - mean) * rstd;
+    o.y = (v[k].y - mean) * rstd;
+    o.z = (v[k].z - mean) * rstd;
+    o.w = (v[k].w - mean) * rstd;
+    if (mod) {
+      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
+      const float4 sh = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+      o.x = o.x * (1.0f + sc.x) + sh.x;
+      o.y = o.y * (1.0f + sc.y) + sh.y;
+      o.z = o.z * (1.0f + sc.z) + sh.z;
+      o.w = o.w * (1.0f + sc.w) + sh.w;
+    } else if (gamma) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+      const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+      o.x = o.x * g.x + be.x;
+      o.y = o.y * g.y + be.y;
+      o.z = o.z * g.z + be.z;
+      o.w = o.w * g.w + be.w;
+    }
+    reinterpret_cast<float4*>(n_out + row * C)[c4] = o;
   }
 }
 
@@ -460,10 +537,12 @@ extern "C" int pfpp_act_bwd(const float* pre, const float* dy, float* dx, int64_
   return pfpp::check_launch(__func__);
 }
 
-extern "C" int pfpp_layernorm_bwd(const float* x, const float* dy, const float* mod, int64_t ld_mod,
-                                  const float* gamma, const int32_t* group_batch, int64_t group_rows,
-                                  int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
-                                  int64_t rows, int64_t C, float eps, pfpp_stream_t stream) {
+namespace {
+int layernorm_bwd_impl(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                       const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                       int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                       int64_t rows, int64_t C, float eps, float* drop_out, float p, uint64_t seed, uint32_t site,
+                       pfpp_stream_t stream) {
   PFPP_REQUIRE(x && dy && dx, "null pointer");
   PFPP_REQUIRE(!(mod && gamma), "mod and gamma are exclusive");
   PFPP_REQUIRE(!dmult == !dadd, "dmult and dadd go together");
@@ -471,16 +550,66 @@ extern "C" int pfpp_layernorm_bwd(const float* x, const float* dy, const float* 
   PFPP_REQUIRE(group_rows >= 1 && rows_per_batch >= 1, "bad group sizes");
   PFPP_REQUIRE(group_batch || !mod || rows_per_batch % group_rows == 0, "rows_per_batch % group_rows != 0");
   PFPP_REQUIRE(pfpp::aligned16(x) && pfpp::aligned16(dy) && pfpp::aligned16(dx) && pfpp::aligned16(mod) &&
-               pfpp::aligned16(gamma) && ld_mod % 4 == 0, "16-byte alignment");
+               pfpp::aligned16(gamma) && pfpp::aligned16(drop_out) && ld_mod % 4 == 0, "16-byte alignment");
+  PFPP_REQUIRE(p >= 0.0f && p < 1.0f, "p outside [0, 1)");
   if (rows == 0) return PFPP_OK;
   const dim3 grid(blocks_for(rows, (int)group_rows));
   hipStream_t st = pfpp::as_stream(stream);
+  const uint32_t thresh = pfpp_drop_thresh(p);
+  const float inv_keep = 1.0f / (1.0f - p);
   if (C == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
-                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps);
+                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps, drop_out, thresh, inv_keep,
+                       seed, site);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
-                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps);
+                       (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps, drop_out, thresh, inv_keep,
+                       seed, site);
+  return pfpp::check_launch("pfpp_layernorm_bwd");
+}
+}  // namespace
+
+extern "C" int pfpp_layernorm_bwd(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                                  const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                                  int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                                  int64_t rows, int64_t C, float eps, pfpp_stream_t stream) {
+  return layernorm_bwd_impl(x, dy, mod, ld_mod, gamma, group_batch, group_rows, rows_per_batch, dx, dmult, dadd, ld_d, rows, C,
+                            eps, nullptr, 0.0f, 0, 0, stream);
+}
+
+extern "C" int pfpp_layernorm_bwd_dropout(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                                          const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                                          int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                                          int64_t rows, int64_t C, float eps, float* drop_out, float p, uint64_t seed,
+                                          uint32_t site, pfpp_stream_t stream) {
+  PFPP_REQUIRE(drop_out, "null pointer");
+  return layernorm_bwd_impl(x, dy, mod, ld_mod, gamma, group_batch, group_rows, rows_per_batch, dx, dmult, dadd, ld_d, rows, C,
+                            eps, drop_out, p, seed, site, stream);
+}
+
+extern "C" int pfpp_dropout_layernorm(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                                      int64_t ld_mod, const float* gamma, const float* beta,
+                                      const int32_t* group_batch, int64_t group_rows, int64_t rows_per_batch,
+                                      int64_t rows, int64_t C, float eps, float p, uint64_t seed, uint32_t site,
+                                      pfpp_stream_t stream) {
+  PFPP_REQUIRE(y && h_out && n_out, "null pointer");
+  PFPP_REQUIRE(!(mod && gamma) && (!gamma == !beta), "mod and gamma/beta are exclusive; gamma and beta go together");
+  PFPP_SUPPORTED(C == 256 || C == 512, "C not in {256, 512}");
+  PFPP_REQUIRE(group_rows >= 1 && rows_per_batch >= 1, "bad group sizes");
+  PFPP_REQUIRE(p >= 0.0f && p < 1.0f, "p outside [0, 1)");
+  PFPP_REQUIRE(pfpp::aligned16(y) && pfpp::aligned16(res) && pfpp::aligned16(h_out) && pfpp::aligned16(n_out) &&
+               pfpp::aligned16(mod) && pfpp::aligned16(gamma) && pfpp::aligned16(beta) && ld_mod % 4 == 0, "16-byte alignment");
+  if (rows == 0) return PFPP_OK;
+  const dim3 grid(blocks_for(rows, 4));
+  hipStream_t st = pfpp::as_stream(stream);
+  const uint32_t thresh = pfpp_drop_thresh(p);
+  const float inv_keep = 1.0f / (1.0f - p);
+  if (C == 256)
+    hipLaunchKernelGGL(dropout_layernorm_kernel<1>, grid, dim3(256), 0, st, y, res, h_out, n_out, mod, ld_mod, gamma, beta, rows,
+                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site);
+  else
+    hipLaunchKernelGGL(dropout_layernorm_kernel<2>, grid, dim3(256), 0, st, y, res, h_out, n_out, mod, ld_mod, gamma, beta, rows,
+                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site);
   return pfpp::check_launch(__func__);
 }
 

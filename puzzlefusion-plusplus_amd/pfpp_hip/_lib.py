@@ -103,6 +103,8 @@ SIGNATURES = {
     "pfpp_act": [_p, _p, _i64, C.c_int, _p],
     "pfpp_act_bwd": [_p, _p, _p, _i64, C.c_int, _p],
     "pfpp_layernorm_bwd": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_layernorm_bwd_dropout": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _f32, _u64, _u32, _p],
+    "pfpp_dropout_layernorm": [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _u32, _p],
     "pfpp_attn_blockdiag_bwd": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_dense_train": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_attn_dense_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p],

@@ -245,6 +245,8 @@ class DenoiserTrainEngine:
                      if (self._side is not None and os.environ.get("PFPP_TRAIN_ATTN_SPLIT", "0") == "1") else None)
         self._group_dw = os.environ.get("PFPP_TRAIN_GROUP_DW", "0") == "1"
         self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
+        # every dropout site is followed by a LayerNorm (forward) / follows a LayerNorm backward: one launch for both
+        self._fuse_drop = os.environ.get("PFPP_TRAIN_FUSE_DROP", "1") != "0"
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
 
     def single_stream(self) -> None:
@@ -283,7 +285,8 @@ class DenoiserTrainEngine:
         x_emb = ops.linear(pf, w["param.w"], w["param.b"])
         ref_u8 = ref_part.reshape(n_slots)[slot].to(torch.uint8).contiguous()
         h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L)
-        if p_tok > 0.0:
+        fuse = self._fuse_drop                        # dropout sites ride in the LayerNorm kernels that follow them
+        if p_tok > 0.0 and not fuse:
             T.dropout(h, p_tok, seed, 0, out=h)
         n_ada = 2 * self.num_layers
         t64 = timesteps.to(torch.int64).contiguous()
@@ -294,21 +297,33 @@ class DenoiserTrainEngine:
         att_scale = 1.0 / math.sqrt(dh)
         s.update(dict(B=B, P=P, L=L, C=C, Fv=Fv, M=M, slot=slot, frag_b=frag_b, seq_len=seq_len, seq_off=seq_off,
                       max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
-                      p_lay=p_lay, att_scale=att_scale, n_slots=n_slots))
+                      p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse))
         layers = []
         for i in range(self.num_layers):
-            lay: Dict[str, torch.Tensor] = {"h0": h}
-            lay["n1"] = ops.layernorm_grouped(h, mods[2 * i], frag_b, L)
+            lay: Dict[str, torch.Tensor] = {}
+            if i == 0 and fuse and p_tok > 0.0:
+                h, lay["n1"] = T.dropout_layernorm(h, None, p_tok, seed, 0, mod=mods[0], group_batch=frag_b, group_rows=L)
+            else:
+                lay["n1"] = ops.layernorm_grouped(h, mods[2 * i], frag_b, L)
+            lay["h0"] = h
             lay["qkv1"] = ops.linear(lay["n1"], w[f"{i}.self_attn.qkv.w"])
             lay["att1"] = ops.attn_blockdiag(lay["qkv1"], Fv, L, H, dh, att_scale)
-            h = self._proj_residual(lay["att1"], w[f"{i}.self_attn.o.w"], w[f"{i}.self_attn.o.b"], h, p_lay, seed, 1 + 3 * i)
+            if fuse and p_lay > 0.0:
+                y = ops.gemm(lay["att1"], w[f"{i}.self_attn.o.w"], M=M, N=C, K=C, lda=C, ldc=C, bias=w[f"{i}.self_attn.o.b"])
+                h, lay["n2"] = T.dropout_layernorm(y, h, p_lay, seed, 1 + 3 * i, mod=mods[2 * i + 1], group_batch=frag_b, group_rows=L)
+            else:
+                h = self._proj_residual(lay["att1"], w[f"{i}.self_attn.o.w"], w[f"{i}.self_attn.o.b"], h, p_lay, seed, 1 + 3 * i)
+                lay["n2"] = ops.layernorm_grouped(h, mods[2 * i + 1], frag_b, L)
             lay["h1"] = h
-            lay["n2"] = ops.layernorm_grouped(h, mods[2 * i + 1], frag_b, L)
             lay["qkv2"] = ops.linear(lay["n2"], w[f"{i}.global_attn.qkv.w"])
             lay["att2"], lay["lse"] = T.attn_dense_train(lay["qkv2"], seq_off, seq_len, max_len, H, dh, att_scale)
-            h = self._proj_residual(lay["att2"], w[f"{i}.global_attn.o.w"], w[f"{i}.global_attn.o.b"], h, p_lay, seed, 2 + 3 * i)
+            if fuse and p_lay > 0.0:
+                y = ops.gemm(lay["att2"], w[f"{i}.global_attn.o.w"], M=M, N=C, K=C, lda=C, ldc=C, bias=w[f"{i}.global_attn.o.b"])
+                h, lay["n3"] = T.dropout_layernorm(y, h, p_lay, seed, 2 + 3 * i, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
+            else:
+                h = self._proj_residual(lay["att2"], w[f"{i}.global_attn.o.w"], w[f"{i}.global_attn.o.b"], h, p_lay, seed, 2 + 3 * i)
+                lay["n3"] = ops.layernorm(h, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
             lay["h2"] = h
-            lay["n3"] = ops.layernorm(h, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
             lay["z"] = ops.linear(lay["n3"], w[f"{i}.ff1.w"], w[f"{i}.ff1.b"])
             lay["u"] = T.geglu(lay["z"], p_lay, seed, 3 + 3 * i)
             inner = lay["u"].shape[1]
@@ -352,7 +367,7 @@ class DenoiserTrainEngine:
         H = self.num_heads
         dh = C // H
         dev = dpred.device
-        seed, p_lay, p_tok = s["seed"], s["p_lay"], s["p_tok"]
+        seed, p_lay, p_tok, fuse = s["seed"], s["p_lay"], s["p_tok"], s["fuse"]
         dout_c = dpred.reshape(s["n_slots"], 7)[s["slot"]].contiguous().float()         # [Fv, 7]
 
         # ---- output heads (denoiser_transformer.py:138-147)
@@ -391,10 +406,11 @@ class DenoiserTrainEngine:
             if self._group_split:
                 self._flush_dw()                     # the two feed-forward weight gradients go now, the four attention ones at the layer's end
             self._before_inplace_update()
-            T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
-                            dadd=g[f"{i}.norm3.b"], ld_d=0)
+            dy = T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
+                                 dadd=g[f"{i}.norm3.b"], ld_d=0, drop=(p_lay, seed, 2 + 3 * i) if fuse and p_lay > 0.0 else None)
             # ---- global attention (attention.py:82-85)
-            dy = T.dropout(dh_, p_lay, seed, 2 + 3 * i) if p_lay > 0.0 else dh_
+            if p_lay > 0.0 and not fuse:
+                dy = T.dropout(dh_, p_lay, seed, 2 + 3 * i)
             self._linear_bwd(dy, lay["att2"], w[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.b"],
                              guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
@@ -403,10 +419,12 @@ class DenoiserTrainEngine:
             self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
             self._before_inplace_update()
-            T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
-                            dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C)
+            dy = T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
+                                 dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C,
+                                 drop=(p_lay, seed, 1 + 3 * i) if fuse and p_lay > 0.0 else None)
             # ---- self attention (attention.py:77-80)
-            dy = T.dropout(dh_, p_lay, seed, 1 + 3 * i) if p_lay > 0.0 else dh_
+            if p_lay > 0.0 and not fuse:
+                dy = T.dropout(dh_, p_lay, seed, 1 + 3 * i)
             self._linear_bwd(dy, lay["att1"], w[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"],
                              guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.self_attn.o.w"].f32, g_scale=G)
@@ -414,12 +432,14 @@ class DenoiserTrainEngine:
             self._linear_bwd(dqkv, lay["n1"], None, g[f"{i}.self_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G)
             self._before_inplace_update()
-            T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
-                            dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C)
+            dtok = T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
+                                   dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C,
+                                   drop=(p_tok, seed, 0) if i == 0 and fuse and p_tok > 0.0 else None)
             self._layer_done(i)
 
         # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
-        dtok = T.dropout(dh_, p_tok, seed, 0) if p_tok > 0.0 else dh_
+        if p_tok > 0.0 and not fuse:
+            dtok = T.dropout(dh_, p_tok, seed, 0)
         ld_sf = s["sf"].shape[1]
         dws = torch.zeros((C, ld_sf), dtype=torch.float32, device=dev)
         T.grad_weight(dtok, s["sf"], dws, g_scale=G)

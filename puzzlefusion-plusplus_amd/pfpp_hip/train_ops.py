@@ -190,8 +190,10 @@ def act_bwd(pre: torch.Tensor, dy: torch.Tensor, kind: str) -> torch.Tensor:
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, *, mod: Optional[torch.Tensor] = None,
                   gamma: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
                   group_rows: int = 32, rows_per_batch: int = 1, dmult: Optional[torch.Tensor] = None,
-                  dadd: Optional[torch.Tensor] = None, ld_d: int = 0, eps: float = 1e-5) -> torch.Tensor:
-    """dx += LayerNorm backward; dmult/dadd (+)= the (scale, shift) / (gamma, beta) gradients (see pfpp.h)"""
+                  dadd: Optional[torch.Tensor] = None, ld_d: int = 0, eps: float = 1e-5,
+                  drop: Optional[tuple] = None) -> torch.Tensor:
+    """dx += LayerNorm backward; dmult/dadd (+)= the (scale, shift) / (gamma, beta) gradients (see pfpp.h).
+    drop = (p, seed, site): also returns dropout(dx) of that site as a new tensor (pfpp_layernorm_bwd_dropout) instead of dx"""
     _chk(x, _f32, "x"); _chk(dy, _f32, "dy"); _chk(dx, _f32, "dx")
     rows, Cc = x.shape
     ld_mod = 0
@@ -202,10 +204,44 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, *, mod: O
         _chk(group_batch, torch.int32, "group_batch")
         if group_batch.numel() * group_rows < rows:
             raise ValueError("layernorm_bwd: group_batch too short")
+    if drop is not None:
+        p, seed, site = drop
+        out = torch.empty_like(dx)
+        check(_lib.load().pfpp_layernorm_bwd_dropout(_ptr(x), _ptr(dy), _ptr(mod), ld_mod, _ptr(gamma), _ptr(group_batch), group_rows,
+                                                     rows_per_batch, _ptr(dx), _ptr(dmult), _ptr(dadd), ld_d, rows, Cc, eps, _ptr(out),
+                                                     p, seed, site, _stream()), "pfpp_layernorm_bwd_dropout")
+        return out
     check(_lib.load().pfpp_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(mod), ld_mod, _ptr(gamma), _ptr(group_batch), group_rows,
                                          rows_per_batch, _ptr(dx), _ptr(dmult), _ptr(dadd), ld_d, rows, Cc, eps, _stream()),
           "pfpp_layernorm_bwd")
     return dx
+
+
+def dropout_layernorm(y: torch.Tensor, res: Optional[torch.Tensor], p: float, seed: int, site: int, *,
+                      mod: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                      beta: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None, group_rows: int = 1,
+                      rows_per_batch: int = 1, eps: float = 1e-5):
+    """-> (h, n): h = (res or 0) + dropout(y) written over y, n = LayerNorm(h) (AdaLN `mod` [B, 2C] or gamma/beta) — one launch
+    for pfpp_dropout + pfpp_layernorm (pfpp_dropout_layernorm)"""
+    _chk(y, _f32, "y")
+    rows, Cc = y.shape
+    ld_mod = 0
+    if res is not None:
+        _chk(res, _f32, "res")
+    if mod is not None:
+        _chk(mod, _f32, "mod")
+        ld_mod = mod.stride(0)
+        if mod.shape[-1] != 2 * Cc:
+            raise ValueError("dropout_layernorm: mod must be [B, 2C]")
+    if group_batch is not None:
+        _chk(group_batch, torch.int32, "group_batch")
+        if group_batch.numel() * group_rows < rows:
+            raise ValueError("dropout_layernorm: group_batch too short")
+    n = torch.empty_like(y)
+    check(_lib.load().pfpp_dropout_layernorm(_ptr(y), _ptr(res), _ptr(y), _ptr(n), _ptr(mod), ld_mod, _ptr(gamma), _ptr(beta),
+                                             _ptr(group_batch), group_rows, rows_per_batch, rows, Cc, eps, p, seed, site, _stream()),
+          "pfpp_dropout_layernorm")
+    return y, n
 
 
 def attn_blockdiag_bwd(qkv: torch.Tensor, dout: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float,

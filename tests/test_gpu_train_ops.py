@@ -220,6 +220,51 @@ def test_layernorm_bwd_affine_and_uniform_batches(dev):
     assert rel_err(dx2, x2.grad) < 2e-5 and rel_err(dm, mod.grad) < 2e-5
 
 
+def test_dropout_fused_into_layernorm_forward_and_backward(dev):
+    """pfpp_dropout_layernorm == pfpp_dropout then pfpp_layernorm, pfpp_layernorm_bwd_dropout == pfpp_layernorm_bwd then
+    pfpp_dropout: same masks, same values (the fused kernels repeat the arithmetic of the two they replace), all LayerNorm forms"""
+    from pfpp_hip import ops
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(16)
+    L, C = 25, 512
+    counts = [3, 1, 7, 2, 4]
+    frag_b = torch.tensor(sum(([b] * c for b, c in enumerate(counts)), []), dtype=torch.int32).to(dev)
+    rows = frag_b.numel() * L
+    y = torch.randn(rows, C, generator=g).to(dev)
+    res = torch.randn(rows, C, generator=g).to(dev)
+    mod = (torch.randn(len(counts), 2 * C, generator=g) * 0.3).to(dev)
+    gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    p, seed = 0.2, 77
+    # forward: AdaLN over the grouped token list with a residual, affine form with a residual, no residual (token dropout)
+    for site, r, kw, ln in ((4, res, dict(mod=mod, group_batch=frag_b, group_rows=L), lambda h: ops.layernorm_grouped(h, mod, frag_b, L)),
+                            (5, res, dict(gamma=gamma, beta=beta), lambda h: ops.layernorm(h, gamma=gamma, beta=beta)),
+                            (0, None, dict(mod=mod, group_batch=frag_b, group_rows=L), lambda h: ops.layernorm_grouped(h, mod, frag_b, L))):
+        h_ref = T.dropout(y, p, seed, site, res=r)
+        n_ref = ln(h_ref)
+        h, n = T.dropout_layernorm(y.clone(), r, p, seed, site, **kw)
+        assert torch.equal(h, h_ref) and rel_err(n, n_ref.cpu()) < 1e-6      # the affine step may contract differently: an ulp
+    kept = (T.dropout(torch.ones_like(y), p, seed, 4) != 0).float().mean().item()
+    assert abs(kept - 0.8) < 0.01
+    # backward
+    x = torch.randn(rows, C, generator=g).to(dev)
+    dy = (torch.randn(rows, C, generator=g) * 1e-3).to(dev)
+    dx0 = (torch.randn(rows, C, generator=g) * 1e-3).to(dev)
+    for kw in (dict(mod=mod, group_batch=frag_b, group_rows=L, ld_d=2 * C), dict(gamma=gamma, group_rows=32, ld_d=0)):
+        outs = []
+        for fused in (False, True):
+            dx = dx0.clone()
+            dm = torch.zeros(len(counts), 2 * C, device=dev)
+            d = T.layernorm_bwd(x, dy, dx, dmult=dm if "mod" in kw else dm[0, :C], dadd=dm[:, C:] if "mod" in kw else dm[0, C:],
+                                drop=(p, seed, 9) if fused else None, **kw)
+            if not fused:
+                assert d is dx
+                d = T.dropout(dx, p, seed, 9)
+            outs.append((dx, d, dm))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert rel_err(outs[1][2], outs[0][2].cpu()) < 1e-6          # atomics: order of the column sums differs between runs
+
+
 # ----------------------------------------------------------------------------- attention backward
 def _attn_ref(qkv, H, dh, scale, groups, key_valid=None):
     """per-sequence softmax attention on a packed [rows, 3*H*dh] projection; groups = list of (start, len)"""
