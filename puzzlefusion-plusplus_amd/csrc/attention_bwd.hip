@@ -442,18 +442,28 @@ __device__ __forceinline__ void ab_store4(const float4 v, float sc, int r, int c
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+// LDS of the two passes, carved from one buffer so that both can live in one launch (attn_dense_bwd_f16_kernel)
+typedef _Float16 AbRowTile[KT * AB_LDR];       // [row][dim] planes of a 32-row tile
+typedef _Float16 AbTrTile[64 * AB_LDT];        // [dim][row] planes
+constexpr int AB_DQ_SMEM = 8 * (int)sizeof(AbRowTile) + 4 * (int)sizeof(AbTrTile);
+constexpr int AB_DKV_SMEM = 8 * (int)sizeof(AbRowTile) + 8 * (int)sizeof(AbTrTile) + 4 * KT * (int)sizeof(float);
+
+__device__ __forceinline__ void ab_dq_f16_body(
+    char* smem, const int blk, const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
   constexpr int DH = 64;
   constexpr int F4 = KT * DH / 4 / 256;
-  __shared__ __align__(16) _Float16 Kh[2][KT * AB_LDR], Kl[2][KT * AB_LDR], Vh[2][KT * AB_LDR], Vl[2][KT * AB_LDR];
-  __shared__ __align__(16) _Float16 Kth[2][DH * AB_LDT], Ktl[2][DH * AB_LDT];
+  AbRowTile* Kh = reinterpret_cast<AbRowTile*>(smem);
+  AbRowTile* Kl = Kh + 2;
+  AbRowTile* Vh = Kl + 2;
+  AbRowTile* Vl = Vh + 2;
+  AbTrTile* Kth = reinterpret_cast<AbTrTile*>(Vl + 2);
+  AbTrTile* Ktl = Kth + 2;
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int T = seq_len[b];
-  const int q_base = blockIdx.x * 128;
+  const int q_base = blk * 128;
   if (q_base >= T) return;
   const int64_t row0 = seq_off[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -563,19 +573,35 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+__global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+  __shared__ __align__(16) char smem[AB_DQ_SMEM];
+  ab_dq_f16_body(smem, blockIdx.x, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
+}
+
+__device__ __forceinline__ void ab_dkv_f16_body(
+    char* smem, const int blk, const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, int H, float scale) {
   constexpr int DH = 64;
   constexpr int F4 = KT * DH / 4 / 256;
-  __shared__ __align__(16) _Float16 Qh[2][KT * AB_LDR], Ql[2][KT * AB_LDR], Gh[2][KT * AB_LDR], Gl[2][KT * AB_LDR];
-  __shared__ __align__(16) _Float16 Qth[2][DH * AB_LDT], Qtl[2][DH * AB_LDT], Gth[2][DH * AB_LDT], Gtl[2][DH * AB_LDT];
-  __shared__ float Ls[2][KT], Ds[2][KT];
+  AbRowTile* Qh = reinterpret_cast<AbRowTile*>(smem);
+  AbRowTile* Ql = Qh + 2;
+  AbRowTile* Gh = Ql + 2;
+  AbRowTile* Gl = Gh + 2;
+  AbTrTile* Qth = reinterpret_cast<AbTrTile*>(Gl + 2);
+  AbTrTile* Qtl = Qth + 2;
+  AbTrTile* Gth = Qtl + 2;
+  AbTrTile* Gtl = Gth + 2;
+  typedef float AbVec[KT];
+  AbVec* Ls = reinterpret_cast<AbVec*>(Gtl + 2);
+  AbVec* Ds = Ls + 2;
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int T = seq_len[b];
-  const int k_base = blockIdx.x * 128;
+  const int k_base = blk * 128;
   if (k_base >= T) return;
   const int64_t row0 = seq_off[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -681,6 +707,27 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
             make_float4(dv_acc[dt][4 * g + 0] * iv, dv_acc[dt][4 * g + 1] * iv, dv_acc[dt][4 * g + 2] * iv, dv_acc[dt][4 * g + 3] * iv);
       }
   }
+}
+
+__global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, int H, float scale) {
+  __shared__ __align__(16) char smem[AB_DKV_SMEM];
+  ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
+}
+
+// Both passes in ONE launch (D comes from attn_dense_bwd_d_kernel): workgroups [0, nblk) of a (sequence, head) take the key
+// blocks (dK, dV — the longer pass, dispatched first), [nblk, 2 nblk) the query blocks (dQ).  The two passes are independent
+// and each is as long as the longest sequence's tile walk: back to back they cost the sum, together the maximum.
+__global__ __launch_bounds__(256) void attn_dense_bwd_f16_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ dvec, float* __restrict__ dqkv,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+  __shared__ __align__(16) char smem[AB_DKV_SMEM > AB_DQ_SMEM ? AB_DKV_SMEM : AB_DQ_SMEM];
+  const int nblk = gridDim.x >> 1;
+  if ((int)blockIdx.x < nblk) ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
+  else ab_dq_f16_body(smem, blockIdx.x - nblk, qkv, out, dout, lse, nullptr, dqkv, seq_off, seq_len, H, scale);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -926,6 +973,17 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
   // split-f16 passes for the unmasked (ragged) launches, like pfpp_attn_dense (PFPP_ATTN_F16X3: 0 never, 1 unmasked, 2 -)
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
   if (dh == 64 && f16_mode >= 1 && key_valid == nullptr) {
+    // opt-in: measured slower (training iteration 8.43 -> 8.50 ms) — the longest sequence's workgroups of the two passes
+    // then share SIMDs and each walks its tiles more slowly than alone
+    static const bool merged = getenv("PFPP_ATTN_BWD_MERGED") && atoi(getenv("PFPP_ATTN_BWD_MERGED")) == 1;
+    if (merged) {
+      const int Hi = (int)H;
+      hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
+      const dim3 grid2(2 * grid.x, grid.y, grid.z);
+      hipLaunchKernelGGL(attn_dense_bwd_f16_kernel, grid2, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
+                         Hi, scale);
+      return pfpp::check_launch(__func__);
+    }
     hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
                        (int)H, scale);
     hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off, seq_len,
