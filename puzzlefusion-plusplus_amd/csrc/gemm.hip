@@ -765,7 +765,7 @@ thread_local int64_t p_split_cnt_len = 0;
 
 template <typename K>
 int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t st, bool* attr_set, int nthr = 256,
-           bool can_split = false, int min_chunk = 128) {
+           bool can_split = false, int min_chunk = 128, bool two_stage_layout = false) {
   if (!*attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *attr_set = true;
@@ -795,6 +795,10 @@ int launch(K kern, size_t smem, GemmP p, int BM, int BN, int batch, hipStream_t 
     }
   }
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.split_k, (unsigned)batch);
+  // a contraction of one K-tile never touches the second LDS stage: allocate one, more workgroups fit a CU (the
+  // [1.26 M x 4] first layer of the encoder: 128x64 tiles at 30 KB -> 3 per CU instead of 2, register-limited)
+  static const bool one_stage = !(getenv("PFPP_GEMM_1STAGE") && atoi(getenv("PFPP_GEMM_1STAGE")) == 0);
+  if (two_stage_layout && one_stage && p.K <= 32 && p.split_k == 1) smem /= 2;
   hipLaunchKernelGGL(kern, grid, dim3(nthr), smem + env_pad, st, p);
   return pfpp::check_launch("pfpp_gemm");
 }
@@ -812,7 +816,7 @@ int launch_f16x3(const GemmP& p, int batch, hipStream_t st) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t smem = (size_t)2 * (2 * BM * LDH + 2 * BN * LDH) * sizeof(_Float16);
   static bool attr_set = false;
-  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2, AFF>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true);
+  return launch(gemm_f16x3_kernel<MT, NT, WPRE, WM, WN, PF2, AFF>, smem, p, BM, BN, batch, st, &attr_set, 64 * WM * WN, true, 128, true);
 }
 
 template <int MT, int NT, int WM, int WN, int PFD>
