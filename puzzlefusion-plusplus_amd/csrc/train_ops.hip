@@ -185,9 +185,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   constexpr int C = 256 * VPL;
   __shared__ float red[2][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r_begin = (int64_t)blockIdx.x * group_rows;
-  const int64_t r_end = min(rows, r_begin + group_rows);
-  const int64_t b = group_batch ? (int64_t)group_batch[blockIdx.x] : (mod ? r_begin / rows_per_batch : 0);
+  // gridDim.y workgroups share a group: each takes a slice of its rows and adds its column sums with the same atomics
+  // (a group of 25 rows on one workgroup is 7 dependent row passes per wave and 154 workgroups on 256 CUs)
+  const int64_t g_begin = (int64_t)blockIdx.x * group_rows;
+  const int per = (group_rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int64_t r_begin = g_begin + (int64_t)blockIdx.y * per;
+  const int64_t r_end = min(min(rows, g_begin + group_rows), r_begin + per);
+  if (r_begin >= r_end) return;
+  const int64_t b = group_batch ? (int64_t)group_batch[blockIdx.x] : (mod ? g_begin / rows_per_batch : 0);
 
   float4 mult[VPL], accA[VPL], accB[VPL];
 #pragma unroll
@@ -553,7 +558,9 @@ int layernorm_bwd_impl(const float* x, const float* dy, const float* mod, int64_
                pfpp::aligned16(gamma) && pfpp::aligned16(drop_out) && ld_mod % 4 == 0, "16-byte alignment");
   PFPP_REQUIRE(p >= 0.0f && p < 1.0f, "p outside [0, 1)");
   if (rows == 0) return PFPP_OK;
-  const dim3 grid(blocks_for(rows, (int)group_rows));
+  static const int rows_per_wg = getenv("PFPP_LN_BWD_ROWS") ? atoi(getenv("PFPP_LN_BWD_ROWS")) : 8;
+  const int split = rows_per_wg > 0 ? (int)((group_rows + rows_per_wg - 1) / rows_per_wg) : 1;
+  const dim3 grid(blocks_for(rows, (int)group_rows), (unsigned)(split < 1 ? 1 : split));
   hipStream_t st = pfpp::as_stream(stream);
   const uint32_t thresh = pfpp_drop_thresh(p);
   const float inv_keep = 1.0f / (1.0f - p);
