@@ -330,6 +330,7 @@ class DenoiserTrainEngine:
             h = ops.gemm(lay["u"], w[f"{i}.ff2.w"], M=M, N=C, K=inner, lda=inner, ldc=C, bias=w[f"{i}.ff2.b"], residual=h, ldr=C)
             layers.append(lay)
         s["layers"] = layers
+        s["dx_pool"] = self._zeroed_dx_pool(M, C, w)
         pooled = ops.mean_pool(h, Fv, L)
         s["pooled"] = pooled
         out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
@@ -346,6 +347,32 @@ class DenoiserTrainEngine:
         out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
         ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
         return out.view(B, P, 7), ctx
+
+    def _zeroed_dx_pool(self, M, C, w):
+        """the split input-gradient GEMMs of the backward (3 per layer at token counts below ~8,000) add into zeroed outputs:
+        one fill for all of them, issued on the weight-gradient stream while it has nothing else to do (the forward), instead of
+        18 fills on the dependency chain of the backward -> (buffers [n, M, C], event) or None"""
+        inner2 = w["0.ff1.w"].f32.shape[0]
+        n = self.num_layers * ((2 if T.dx_splits(M, C, 3 * C) else 0) + (1 if T.dx_splits(M, C, inner2) else 0))
+        if n == 0 or self._side is None or os.environ.get("PFPP_TRAIN_DX_POOL", "1") == "0":
+            return None
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._side):
+            pool = torch.zeros((n, M, C), dtype=torch.float32, device=self.flat.params.device)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        pool.record_stream(main)
+        return [pool, ev, 0]
+
+    @staticmethod
+    def _take_zeroed(pool, M, K_in, N_out):
+        if pool is None or not T.dx_splits(M, K_in, N_out) or pool[2] >= pool[0].shape[0]:
+            return None
+        if pool[1] is not None:
+            torch.cuda.current_stream().wait_event(pool[1])
+            pool[1] = None
+        pool[2] += 1
+        return pool[0][pool[2] - 1]
 
     @staticmethod
     def _proj_residual(att, wo, bo, h, p, seed, site):
@@ -393,6 +420,7 @@ class DenoiserTrainEngine:
         self._flush_dw()                                                                  # the heads' four small weight gradients
 
         dmods = torch.zeros_like(s["mods"])
+        pool = s.get("dx_pool")
         for i in reversed(range(self.num_layers)):
             lay = s["layers"][i]
             # ---- feed-forward (attention.py:87-90)
@@ -401,7 +429,7 @@ class DenoiserTrainEngine:
             dz = T.geglu_bwd(lay["z"], du, p_lay, seed, 3 + 3 * i)
             del du
             self._linear_bwd(dz, lay["n3"], w[f"{i}.ff1.w"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
-            dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G)
+            dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G, zeroed=self._take_zeroed(pool, dz.shape[0], C, dz.shape[1]))
             del dz
             if self._group_split:
                 self._flush_dw()                     # the two feed-forward weight gradients go now, the four attention ones at the layer's end
@@ -417,7 +445,7 @@ class DenoiserTrainEngine:
             dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
                                     s["att_scale"], aux_stream=self._aux)
             self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
-            dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G)
+            dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G, zeroed=self._take_zeroed(pool, dqkv.shape[0], C, 3 * C))
             self._before_inplace_update()
             dy = T.layernorm_bwd(lay["h1"], dn, dh_, mod=s["mods"][2 * i + 1], group_batch=s["frag_b"], group_rows=L,
                                  dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C,
@@ -430,7 +458,7 @@ class DenoiserTrainEngine:
             datt = T.grad_input(dy, w[f"{i}.self_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_blockdiag_bwd(lay["qkv1"], datt, Fv, L, H, dh, s["att_scale"])
             self._linear_bwd(dqkv, lay["n1"], None, g[f"{i}.self_attn.qkv.w"], None)
-            dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G)
+            dn = T.grad_input(dqkv, w[f"{i}.self_attn.qkv.w"].f32, g_scale=G, zeroed=self._take_zeroed(pool, dqkv.shape[0], C, 3 * C))
             self._before_inplace_update()
             dtok = T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][2 * i], group_batch=s["frag_b"], group_rows=L,
                                    dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C,

@@ -66,17 +66,29 @@ def grad_kernel_name(M: int, N: int, batch: int, a_kmajor: bool, w_kmajor: bool,
     return f"gemm_grad_kernel<{cfg}, {'true' if a_kmajor else 'false'}, {'true' if w_kmajor else 'false'}>"
 
 
-def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dX [M, in] = dY [M, out] . W [out, in]   (W in torch Linear layout)"""
+def dx_splits(M: int, K_in: int, N_out: int) -> bool:
+    """does grad_input cut this contraction over several workgroups (atomics into a ZEROED output)?  Few output tiles and a
+    long contraction only."""
+    tiles = ((M + 127) // 128) * ((K_in + 127) // 128)
+    return SPLIT_DX and tiles < 256 and N_out >= 1024
+
+
+def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: Optional[torch.Tensor] = None,
+               zeroed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX [M, in] = dY [M, out] . W [out, in]   (W in torch Linear layout).  `zeroed`: a zero-filled [M, in] buffer the caller
+    prepared ahead (used instead of a fresh torch.zeros when the contraction is split, see dx_splits)"""
     M, N_out = dY.shape
     K_in = W.shape[1]
     if W.shape[0] != N_out:
         raise ValueError("grad_input: dY [M,out] and W [out,in] expected")
-    # few output tiles and a long contraction: cut K over several workgroups (atomics into a zeroed output)
-    tiles = ((M + 127) // 128) * ((K_in + 127) // 128)
-    split = out is None and SPLIT_DX and tiles < 256 and N_out >= 1024
+    split = out is None and dx_splits(M, K_in, N_out)
     if out is None:
-        out = (torch.zeros if split else torch.empty)((M, K_in), dtype=_f32, device=dY.device)
+        if split and zeroed is not None:
+            if zeroed.shape != (M, K_in):
+                raise ValueError("grad_input: zeroed buffer has the wrong shape")
+            out = zeroed
+        else:
+            out = (torch.zeros if split else torch.empty)((M, K_in), dtype=_f32, device=dY.device)
     return gemm_grad(dY, W, out, M=M, N=K_in, K=N_out, lda=dY.stride(0), ldw=W.stride(0), ldc=out.stride(0),
                      w_kmajor=True, a_scale=g_scale, accumulate=split, split_k=0 if split else 1)
 
