@@ -392,9 +392,11 @@ int dispatch(GradP p, int batch, int split_k, hipStream_t st) {
   if (splits <= 0) {
     // auto: ~1 workgroup per CU, chunks at least 1024 deep.  Measured on the [3850-token] training step after the K loop
     // became one scheduling region (each workgroup is faster, so fewer, deeper chunks win — less atomic traffic):
-    // (384, 512) 8.66 ms, (256, 512) 8.48, (192, 512) 8.29, (256, 1024) 8.28, (320, 1024) 8.33, (256, 2048) 8.93 per iteration
-    static const int target_wg = getenv("PFPP_GRAD_WG") ? atoi(getenv("PFPP_GRAD_WG")) : 256;
-    static const int min_k = getenv("PFPP_GRAD_MINK") ? atoi(getenv("PFPP_GRAD_MINK")) : 1024;
+    // (384, 512) 8.66 ms, (256, 512) 8.48, (192, 512) 8.29, (256, 1024) 8.28, (320, 1024) 8.33, (256, 2048) 8.93 per iteration;
+    // again with the chunk-major XCD assignment: (256, 1024) 8.27, (256, 768) 8.19, (224, 768) 8.28, (192, 896) 8.22,
+    // (192, 768) 8.16, (192, 640) 8.15, (160, 768) 8.20, (128, 1024) 8.83
+    static const int target_wg = getenv("PFPP_GRAD_WG") ? atoi(getenv("PFPP_GRAD_WG")) : 192;
+    static const int min_k = getenv("PFPP_GRAD_MINK") ? atoi(getenv("PFPP_GRAD_MINK")) : 768;
     const int64_t t = tiles(bm, bn);
     int64_t want = (target_wg + t - 1) / t;
     const int64_t max_by_k = (p.K + min_k - 1) / min_k;
