@@ -90,7 +90,9 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
         h, aff = A, None
         for i in range(3):
             Cout = pk[f"{name}.w{i}"].N
-            st = pk.setdefault(f"{name}.stats{i}", T.bn_stats_buffer(Cout, dev))
+            st = pk.get(f"{name}.stats{i}")
+            if st is None:                   # allocated (and zeroed) once: pfpp_bn_finalize clears the copies it has summed
+                st = pk[f"{name}.stats{i}"] = T.bn_stats_buffer(Cout, dev)
             if i == 0 and A is None:
                 h = ops.grouped_linear(*grp, pk[f"{name}.w0"], pk[f"{name}.b0"], stats=st)
             elif i < 2:
