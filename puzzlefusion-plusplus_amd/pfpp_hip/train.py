@@ -247,6 +247,8 @@ class DenoiserTrainEngine:
         self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
         # every dropout site is followed by a LayerNorm (forward) / follows a LayerNorm backward: one launch for both
         self._fuse_drop = os.environ.get("PFPP_TRAIN_FUSE_DROP", "1") != "0"
+        self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
+        self._early: List[int] = []                   # layers whose slice the armed backward has already updated
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
 
     def single_stream(self) -> None:
@@ -561,6 +563,14 @@ class DenoiserTrainEngine:
         """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
         from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
         self._flush_dw()
+        if self._armed is not None and self._side is not None and not self._exchange.active():
+            # optimizer in the backward (arm_optimizer): this layer's slice of the flat buffer is final once its weight
+            # gradients (side stream) and LayerNorm gradients (main stream, all queued by now) have run — update it on the side
+            # stream under the remaining backward instead of in the 0.3 ms AdamW launch that runs alone at the iteration's end
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, **self._armed)
+            self._early.append(i)
         if self._exchange.active():
             if self._side is None:
                 self._exchange.layer_done(i)
@@ -582,13 +592,39 @@ class DenoiserTrainEngine:
         return self._exchange.finish()
 
     # ------------------------------------------------------------------------------------------ optimizer
+    def arm_optimizer(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:
+        """optimizer-in-backward for the NEXT backward: every transformer layer's parameters take their AdamW update as soon as
+        the layer's gradients are final (on the weight-gradient stream, under the rest of the backward); optimizer_step() with
+        the same hyper-parameters then updates only what is left (embeddings, AdaLN tables and linears, output heads) and
+        closes the step.  Same arithmetic per element as one launch over the flat buffer.  One-shot; ignored (everything
+        happens in optimizer_step) without a second stream or when gradients are exchanged between ranks first."""
+        self._armed = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
+        self._early = []
+
+    def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay) -> None:
+        f = self.flat
+        T.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
+                weight_decay=weight_decay, step=step, hi=f.hi[a:b], lo=f.lo[a:b], g_scale=g_scale)
+
     def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:
-        """AdamW over the flat buffer (configure_optimizers, denoiser.py:230-237) — one launch"""
+        """AdamW over the flat buffer (configure_optimizers, denoiser.py:230-237) — one launch, or the ranges that an armed
+        backward (arm_optimizer) has not updated yet"""
         g_scale = self.finish_grad_exchange()
         self.step_count += 1
         f = self.flat
-        T.adamw(f.params, f.grads, f.exp_avg, f.exp_avg_sq, lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
-                weight_decay=weight_decay, step=self.step_count, hi=f.hi, lo=f.lo, g_scale=g_scale)
+        hp = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
+        early, self._early = self._early, []
+        armed, self._armed = self._armed, None
+        if early:
+            if armed != hp:
+                raise RuntimeError("optimizer_step: hyper-parameters differ from the ones the backward was armed with")
+            pos, total = 0, f.params.numel()
+            for a, b in sorted(f.layer_ranges[i] for i in early) + [(total, total)]:
+                if a > pos:
+                    self._adamw_range(pos, a, step=self.step_count, g_scale=g_scale, **hp)
+                pos = max(pos, b)
+        else:
+            self._adamw_range(0, f.params.numel(), step=self.step_count, g_scale=g_scale, **hp)
         f.after_optimizer_step()
         cache = getattr(self.module, "_cache", None)
         if cache is not None:

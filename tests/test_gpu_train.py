@@ -116,9 +116,12 @@ def test_train_mode_dropout_vs_oracle_autograd(golden, weights_sd, dev):
     assert worst < 2e-4, worst
 
 
-def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev):
+@pytest.mark.parametrize("armed", [False, True])
+def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev, armed):
     """two AdamW steps (eval-mode dropout).  Adam's first updates are sign(g)*lr, so elements whose gradient is
-    within rounding of zero may legitimately move the other way: bounded count, bounded size."""
+    within rounding of zero may legitimately move the other way: bounded count, bounded size.
+    armed: the optimizer-in-backward form (arm_optimizer: every layer's slice updated under the rest of the backward,
+    optimizer_step finishes the remaining ranges) must land on the same parameters."""
     from oracle import pfpp_oracle as O
     from pfpp_hip.train import DenoiserTrainEngine
 
@@ -136,8 +139,13 @@ def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev):
         with torch.no_grad():
             O.adamw_step([sd[n] for n in names], [req[n].grad for n in names], [m[n] for n in names], [v[n] for n in names], step)
         eng.flat.zero_grad()
+        if armed:
+            eng.arm_optimizer(lr=lr)
         eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
+        if armed:
+            assert sorted(eng._early) == list(range(eng.num_layers))       # every layer went early
         eng.optimizer_step(lr=lr)
+        assert eng._armed is None and eng._early == []
     named = dict(eng.module.named_parameters())
     total, off = 0, 0
     for n in names:
