@@ -431,6 +431,8 @@ typedef struct pfpp_gemm_grad_args {
   int32_t batch;
   int64_t sA, sW, sC;
   float a_scale, w_scale, alpha;
+  float* colsum;        /* NULL, or (weight-gradient form: a_kmajor = 1, batch = 1) colsum[m] += sum_k A[m, k] — the bias gradient of
+                           the same torch.nn.Linear (unscaled dY), accumulated with atomics from the A tiles as they are staged */
 } pfpp_gemm_grad_args;
 int pfpp_gemm_grad(const pfpp_gemm_grad_args* args, pfpp_stream_t stream);
 /* Up to 8 independent weight-gradient problems (both operands k-major, batch 1) in ONE launch: the six dW of a transformer

@@ -41,6 +41,7 @@ struct GradP {
   int tiles_n, tiles_m, group_m;
   int splits;               // grouped launch only: K chunks of this problem
   int kxcd;                 // split-K launch as a 1-D grid: an XCD walks ONE K chunk over many tiles (see gemm_grad_kernel)
+  float* colsum;            // weight-gradient form: colsum[m] += sum_k A[m, k] (the bias gradient), taken from the A tiles as they pass
 };
 
 __device__ __forceinline__ void split4s(const float4 v, float s, half4& hi, half4& lo) {
@@ -117,7 +118,10 @@ struct OperandLoader {
     }
   }
 
-  __device__ __forceinline__ void store(_Float16* hi_plane, _Float16* lo_plane, float scale, int tid) const {
+  // CS: also add the tile's 4 k-rows into `cs[it]` (per-thread partial sums over the contraction for its 4 output rows: the
+  // bias gradient rides along with the weight gradient, k-major operand only)
+  template <bool CS = false>
+  __device__ __forceinline__ void store(_Float16* hi_plane, _Float16* lo_plane, float scale, int tid, float4* cs = nullptr) const {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int u = tid + it * NTHR;
@@ -125,6 +129,12 @@ struct OperandLoader {
       if constexpr (KM) {
         const int kg = u & 7, c4 = u >> 3;
         const float4 a = reg[it][0], b = reg[it][1], c = reg[it][2], d = reg[it][3];
+        if constexpr (CS) {
+          cs[it].x += (a.x + b.x) + (c.x + d.x);
+          cs[it].y += (a.y + b.y) + (c.y + d.y);
+          cs[it].z += (a.z + b.z) + (c.z + d.z);
+          cs[it].w += (a.w + b.w) + (c.w + d.w);
+        }
         const float4 col[4] = {make_float4(a.x, b.x, c.x, d.x), make_float4(a.y, b.y, c.y, d.y),
                                make_float4(a.z, b.z, c.z, d.z), make_float4(a.w, b.w, c.w, d.w)};
 #pragma unroll
@@ -189,6 +199,10 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
   // to arrive: with one tile in flight the loop measured 2.4 us per K-tile against 0.32 us of matrix work.
   OperandLoader<BM, NTHR, AKM> la0, la1;
   OperandLoader<BN, NTHR, WKM> lw0, lw1;
+  constexpr int IT_A = OperandLoader<BM, NTHR, AKM>::IT;
+  float4 cs[IT_A];                 // bias-gradient partial sums (k-major A only; always accumulated: 16 adds per K-tile, no branch)
+#pragma unroll
+  for (int it = 0; it < IT_A; ++it) cs[it] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto compute = [&](int buf, int ks_begin = 0, int ks_end = BK / 16) {
     const _Float16* st = grad_smem + buf * STAGE;
@@ -236,13 +250,13 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
 #define GRAD_STORE(SET, BUF)                                                                  \
   do {                                                                                        \
     _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
-    la##SET.store(st_, st_ + PLANE_A, p.a_scale, tid);                                        \
+    la##SET.template store<AKM>(st_, st_ + PLANE_A, p.a_scale, tid, cs);                       \
     lw##SET.store(st_ + 2 * PLANE_A, st_ + 2 * PLANE_A + PLANE_W, p.w_scale, tid);            \
   } while (0)
 #define GRAD_STORE_A(SET, BUF)                                                                \
   do {                                                                                        \
     _Float16* st_ = grad_smem + (BUF) * STAGE;                                                \
-    la##SET.store(st_, st_ + PLANE_A, p.a_scale, tid);                                        \
+    la##SET.template store<AKM>(st_, st_ + PLANE_A, p.a_scale, tid, cs);                       \
   } while (0)
 #define GRAD_STORE_W(SET, BUF)                                                                \
   do {                                                                                        \
@@ -290,6 +304,28 @@ __device__ __forceinline__ void grad_tile(const GradP& p, const int tile, const 
 #undef GRAD_STORE
 #undef GRAD_STORE_A
 #undef GRAD_STORE_W
+
+  // ---- bias gradient: the tn == 0 tile of every (row panel, K chunk) adds its partial sums ------------
+  if constexpr (AKM) {
+    if (p.colsum != nullptr && tn == 0) {
+#pragma unroll
+      for (int it = 0; it < IT_A; ++it) {
+        float4 v = cs[it];
+#pragma unroll
+        for (int sh = 1; sh < 8; sh <<= 1) {          // the 8 k-groups of a row quad sit in 8 neighbouring lanes
+          v.x += __shfl_xor(v.x, sh); v.y += __shfl_xor(v.y, sh); v.z += __shfl_xor(v.z, sh); v.w += __shfl_xor(v.w, sh);
+        }
+        const int u = tid + it * NTHR;
+        const int r = m0 + (u >> 3) * 4;
+        if ((u & 7) == 0 && u < (BM / 4) * 8 && r < p.M) {      // M % 4 == 0 for k-major A (checked on the host)
+          unsafeAtomicAdd(p.colsum + r + 0, v.x);
+          unsafeAtomicAdd(p.colsum + r + 1, v.y);
+          unsafeAtomicAdd(p.colsum + r + 2, v.z);
+          unsafeAtomicAdd(p.colsum + r + 3, v.w);
+        }
+      }
+    }
+  }
 
   // ---- epilogue: plain store or atomic accumulate ------------------------------------------------
   const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
@@ -432,6 +468,7 @@ extern "C" int pfpp_gemm_grad(const pfpp_gemm_grad_args* a, pfpp_stream_t stream
   PFPP_REQUIRE(a->ldc >= a->N && a->batch >= 1 && a->split_k >= 0, "bad ldc / batch / split_k");
   PFPP_REQUIRE(a->a_scale > 0.0f && a->w_scale > 0.0f, "operand scales must be positive");
   PFPP_SUPPORTED(a->a_kmajor == 0 || a->w_kmajor != 0, "k-major A with row-major W");
+  PFPP_SUPPORTED(!a->colsum || (a->a_kmajor && a->batch == 1), "colsum: weight-gradient form (k-major A), batch 1 only");
 
   GradP p;
   p.A = a->A; p.W = a->W; p.C = a->C;
@@ -440,7 +477,7 @@ extern "C" int pfpp_gemm_grad(const pfpp_gemm_grad_args* a, pfpp_stream_t stream
   p.sA = a->sA; p.sW = a->sW; p.sC = a->sC;
   p.accumulate = a->accumulate;
   p.atomic = a->accumulate;     // several launches (micro-batches, streams) may add into one buffer
-  p.splits = 1; p.kxcd = 0;
+  p.splits = 1; p.kxcd = 0; p.colsum = a->colsum;
   p.a_scale = a->a_scale; p.w_scale = a->w_scale;
   p.alpha = a->alpha / (a->a_scale * a->w_scale);
   p.k_chunk = 0;
@@ -459,13 +496,14 @@ int fill_problem(const pfpp_gemm_grad_args* a, GradP& p) {
   PFPP_REQUIRE(a->lda % 4 == 0 && a->ldw % 4 == 0 && pfpp::aligned16(a->A) && pfpp::aligned16(a->W),
                "lda/ldw must be multiples of 4 and A/W 16-byte aligned");
   PFPP_SUPPORTED(a->a_kmajor && a->w_kmajor && a->batch == 1, "grouped launch: weight-gradient form only (both operands k-major, batch 1)");
+  PFPP_SUPPORTED(!a->colsum, "grouped launch: no fused column sums");
   PFPP_REQUIRE(a->M % 4 == 0 && a->lda >= a->M && a->N % 4 == 0 && a->ldw >= a->N, "k-major operands: M, N % 4 != 0 or ld too small");
   PFPP_REQUIRE(a->ldc >= a->N, "bad ldc");
   PFPP_REQUIRE(a->a_scale > 0.0f && a->w_scale > 0.0f, "operand scales must be positive");
   p.A = a->A; p.W = a->W; p.C = a->C;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
-  p.sA = p.sW = p.sC = 0; p.kxcd = 0;
+  p.sA = p.sW = p.sC = 0; p.kxcd = 0; p.colsum = nullptr;
   p.accumulate = a->accumulate;
   p.a_scale = a->a_scale; p.w_scale = a->w_scale;
   p.alpha = a->alpha / (a->a_scale * a->w_scale);

@@ -48,6 +48,7 @@ class GemmGradArgs(C.Structure):
         ("a_kmajor", _i32), ("w_kmajor", _i32), ("accumulate", _i32), ("split_k", _i32), ("batch", _i32),
         ("sA", _i64), ("sW", _i64), ("sC", _i64),
         ("a_scale", _f32), ("w_scale", _f32), ("alpha", _f32),
+        ("colsum", _p),
     ]
 
 

@@ -247,6 +247,7 @@ class DenoiserTrainEngine:
         self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
         # every dropout site is followed by a LayerNorm (forward) / follows a LayerNorm backward: one launch for both
         self._fuse_drop = os.environ.get("PFPP_TRAIN_FUSE_DROP", "1") != "0"
+        self._fuse_colsum = os.environ.get("PFPP_TRAIN_FUSE_COLSUM", "1") != "0"   # bias gradients from the weight-gradient GEMM's dY tiles
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
@@ -509,16 +510,17 @@ class DenoiserTrainEngine:
                 dy = dy.clone()                      # the grouped launch runs after the in-place update: keep this version
             self._pending.append((dy, x, gw, gb))
             return
+        fused_db = gb if (self._fuse_colsum and gb is not None and gb.is_contiguous()) else None    # bias sums ride in the dW GEMM
         if self._side is None:
-            T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
-            if gb is not None:
+            T.grad_weight(dy, x, gw, g_scale=self.grad_scale, db=fused_db)
+            if gb is not None and fused_db is None:
                 T.colsum(dy, gb)
             return
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)                 # dy (and x) are ready once everything queued so far has run
         with torch.cuda.stream(self._side):
-            T.grad_weight(dy, x, gw, g_scale=self.grad_scale)
-            if gb is not None:
+            T.grad_weight(dy, x, gw, g_scale=self.grad_scale, db=fused_db)
+            if gb is not None and fused_db is None:
                 T.colsum(dy, gb)
         dy.record_stream(self._side)                 # the caching allocator must not recycle them under the side stream
         x.record_stream(self._side)

@@ -24,10 +24,17 @@ SPLIT_DX = _os.environ.get("PFPP_SPLIT_DX", "1") == "1"
 def gemm_grad(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldw: int,
               ldc: int, a_kmajor: bool = False, w_kmajor: bool = False, accumulate: bool = False,
               split_k: int = 0, batch: int = 1, sA: int = 0, sW: int = 0, sC: int = 0, a_scale: float = 1.0,
-              w_scale: float = 1.0, alpha: float = 1.0, a_off: int = 0, w_off: int = 0, c_off: int = 0) -> torch.Tensor:
-    """raw pfpp_gemm_grad: out[M,N] (+)= alpha * sum_k A(m,k) W(n,k) with per-operand k-major layouts"""
+              w_scale: float = 1.0, alpha: float = 1.0, a_off: int = 0, w_off: int = 0, c_off: int = 0,
+              colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """raw pfpp_gemm_grad: out[M,N] (+)= alpha * sum_k A(m,k) W(n,k) with per-operand k-major layouts;
+    colsum [M] += sum_k A(m,k) (weight-gradient form only: the bias gradient from the same pass over dY)"""
     _chk(A, _f32, "A"); _chk(W, _f32, "W"); _chk(out, _f32, "out")
     a = GemmGradArgs()
+    if colsum is not None:
+        _chk(colsum, _f32, "colsum")
+        if colsum.numel() < M or not colsum.is_contiguous():
+            raise ValueError("gemm_grad: colsum must be a contiguous [M] tensor")
+        a.colsum = colsum.data_ptr()
     a.A = A.data_ptr() + 4 * a_off
     a.W = W.data_ptr() + 4 * w_off
     a.C = out.data_ptr() + 4 * c_off
@@ -93,14 +100,16 @@ def grad_input(dY: torch.Tensor, W: torch.Tensor, *, g_scale: float = 1.0, out: 
                      w_kmajor=True, a_scale=g_scale, accumulate=split, split_k=0 if split else 1)
 
 
-def grad_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, g_scale: float = 1.0, k_cols: Optional[int] = None) -> torch.Tensor:
-    """dW [out, in] += dY [M, out]^T . X [M, in]   (accumulates with atomics; dW must be initialised)"""
+def grad_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, g_scale: float = 1.0, k_cols: Optional[int] = None,
+                db: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [out, in] += dY [M, out]^T . X [M, in]   (accumulates with atomics; dW must be initialised);
+    db [out] += column sums of dY in the same launch (the bias gradient)"""
     M, N_out = dY.shape
     K_in = X.shape[1] if k_cols is None else k_cols
     if X.shape[0] != M or dW.shape[0] != N_out:
         raise ValueError("grad_weight: shape mismatch")
     return gemm_grad(dY, X, dW, M=N_out, N=K_in, K=M, lda=dY.stride(0), ldw=X.stride(0), ldc=dW.stride(0),
-                     a_kmajor=True, w_kmajor=True, accumulate=True, a_scale=g_scale)
+                     a_kmajor=True, w_kmajor=True, accumulate=True, a_scale=g_scale, colsum=db)
 
 
 def grad_weight_group(problems, *, g_scale: float = 1.0) -> None:

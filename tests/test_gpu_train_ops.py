@@ -45,6 +45,15 @@ def test_grad_weight_gemm(dev, M, N, K):
     assert rel_err(dW, want) < 5e-6
     T.grad_weight(dY.to(dev), X.to(dev), dW, g_scale=2.0 ** 12)      # accumulates
     assert rel_err(dW, 2 * want) < 5e-6
+    # the bias gradient from the same launch: db += column sums of the (unscaled) dY, taken from the staged dY tiles
+    dW2 = torch.zeros(N, K, device=dev)
+    db = torch.full((N,), 0.5, device=dev)
+    T.grad_weight(dY.to(dev), X.to(dev), dW2, g_scale=2.0 ** 12, db=db)
+    assert rel_err(dW2, want) < 5e-6
+    assert rel_err(db - 0.5, dY.double().sum(0)) < 2e-5
+    db2 = torch.zeros(N, device=dev)
+    T.colsum(dY.to(dev), db2)
+    assert rel_err(db - 0.5, db2.cpu()) < 2e-5
 
 
 def test_grad_weight_group(dev):
