@@ -29,6 +29,7 @@
 namespace pfpp_gemm_detail {
 int launch_f16x3_ring(const GemmP& p, int batch, hipStream_t st, int group_m);   // gemm_ring.hip
 int launch_f16x3_ws(const GemmP& p, int batch, hipStream_t st, int group_m);     // gemm_ws.hip
+int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant);   // gemm_pl.hip
 }
 
 namespace {
@@ -912,6 +913,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p_split_ws_bytes = a->split_ws ? a->split_ws_bytes : 0;
   p_split_cnt_len = a->split_cnt ? a->split_cnt_len : 0;
   p.tiles_n = 0;
+  p.dbg = 0;
   hipStream_t st = pfpp::as_stream(stream);
 
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)
@@ -921,6 +923,12 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
     static const bool apre_ring = getenv("PFPP_GEMM_APRE_RING") && atoi(getenv("PFPP_GEMM_APRE_RING")) == 1;
     if (apre && apre_ring) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop (measured slower)
+    // LDS-DMA staged, software-pipelined plane kernel (gemm_pl.hip).  PFPP_GEMM_PL: 0 = off, 1..3 = force a tile, unset / -1 = by shape
+    if (apre && !fused_bn && true) {
+      const char* e = getenv("PFPP_GEMM_PL");
+      const int v = e ? atoi(e) : -1;
+      if (v != 0) return launch_f16x3_planes(p, a->batch, st, gemm_group_m(), v < 0 ? 0 : v);
+    }
     if (apre) {
       // the register-staged kernels with A staged like W (no conversions in the loop); same tile choice as below
       static const bool big = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
