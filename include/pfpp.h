@@ -180,6 +180,82 @@ typedef struct pfpp_gemm_args {
 
 int pfpp_gemm(const pfpp_gemm_args* args, pfpp_stream_t stream);
 
+/* Optional split-f16 copy of a kernel's result, the operand format of pfpp_gemm_planes: hi = f16(scale * v),
+ * lo = f16(scale * v - hi), same indexing as the fp32 result.  scale is a power of two (gradients are lifted into the
+ * normal fp16 range; the consuming GEMM divides it out through alpha).  hi / lo: 8-byte aligned fp16 buffers.       */
+typedef struct pfpp_planes { void* hi; void* lo; float scale; } pfpp_planes;
+
+/* Plane-producing forms of the training kernels (a17): same arithmetic as the entry points they extend (cited
+ * there), with the result additionally — or, where the fp32 pointer may be NULL, only — written as pfpp_planes for the
+ * following pfpp_gemm_planes launches: no separate conversion pass over the activations / gradients.
+ *   pfpp_split_planes          planes of an fp32 tensor (n % 4 == 0)
+ *   pfpp_colsum_planes         out[c] += out_scale * sum_r (hi + lo)[r, c]   (bias gradients of dY given as planes)
+ *   pfpp_geglu_p / _bwd_p      pfpp_geglu / pfpp_geglu_bwd; u (dz) may be NULL
+ *   pfpp_dropout_layernorm_p   pfpp_dropout_layernorm; n_out may be NULL
+ *   pfpp_layernorm_bwd_p       pfpp_layernorm_bwd(_dropout): `dropout` selects the fused dropout of the backward chain
+ *                              (drop_out may then be NULL); ret_planes = planes of the value the chain continues with
+ *                              (dropped-out gradient, or the updated dx without dropout), dx_planes = planes of the updated dx
+ *   pfpp_attn_dense_train_p    pfpp_attn_dense_train; out may be NULL
+ *   pfpp_attn_dense_bwd_p, pfpp_attn_blockdiag_bwd_p    dqkv may be NULL (split-f16 / matrix-core kernels only)      */
+int pfpp_split_planes(const float* x, int64_t n, const pfpp_planes* planes, pfpp_stream_t stream);
+int pfpp_colsum_planes(const void* hi, const void* lo, float* out, int64_t rows, int64_t cols, int64_t ld,
+                       float out_scale, pfpp_stream_t stream);
+int pfpp_geglu_p(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed, uint32_t site,
+                 const pfpp_planes* u_planes, pfpp_stream_t stream);
+int pfpp_geglu_bwd_p(const float* z, const float* du, float* dz, int64_t rows, int64_t inner, float p, uint64_t seed,
+                     uint32_t site, const pfpp_planes* dz_planes, pfpp_stream_t stream);
+int pfpp_dropout_layernorm_p(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                             int64_t ld_mod, const float* gamma, const float* beta, const int32_t* group_batch,
+                             int64_t group_rows, int64_t rows_per_batch, int64_t rows, int64_t C, float eps, float p,
+                             uint64_t seed, uint32_t site, const pfpp_planes* n_planes, pfpp_stream_t stream);
+int pfpp_layernorm_bwd_p(const float* x, const float* dy, const float* mod, int64_t ld_mod, const float* gamma,
+                         const int32_t* group_batch, int64_t group_rows, int64_t rows_per_batch, float* dx,
+                         float* dmult, float* dadd, int64_t ld_d, int64_t rows, int64_t C, float eps, float* drop_out,
+                         float p, uint64_t seed, uint32_t site, int32_t dropout, const pfpp_planes* ret_planes,
+                         const pfpp_planes* dx_planes, pfpp_stream_t stream);
+int pfpp_attn_dense_train_p(const float* qkv, float* out, float* lse, const int32_t* seq_off, const int32_t* seq_len,
+                            const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len, int64_t H,
+                            int64_t dh, float scale, const pfpp_planes* out_planes, pfpp_stream_t stream);
+int pfpp_attn_dense_bwd_p(const float* qkv, const float* out, const float* dout, const float* lse, float* dvec,
+                          float* dqkv, const int32_t* seq_off, const int32_t* seq_len, const uint8_t* key_valid,
+                          int64_t kv_stride, int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                          const pfpp_planes* dqkv_planes, pfpp_stream_t stream);
+int pfpp_attn_blockdiag_bwd_p(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L, int64_t H,
+                              int64_t dh, float scale, const pfpp_planes* dqkv_planes, pfpp_stream_t stream);
+
+/* ---- GEMM on pre-split fp16 planes, all three products of a Linear layer ----------------------------------
+ * The PFPP_GEMM_F16X3 contraction (see pfpp_gemm) with BOTH operands given as hi/lo fp16 planes, staged by LDS-DMA:
+ *   forward   y  = x . W^T   (diffusers Attention to_q/to_k/to_v/to_out, FeedForward net.0.proj / net.2:
+ *                             denoiser/model/modules/attention.py:46-72; TransformerEncoderLayer linears,
+ *                             verifier_transformer.py:28-37):          A = x [M,K] row-major, W [N,K] row-major
+ *   dX = dY . W   (autograd of the same layers in Denoiser.training_step, denoiser.py:128-145):
+ *                             A = dY [M,K=out] row-major, W [K=out, N=in] k-major (w_kmajor = 1: the weight as stored)
+ *   dW = dY^T . X                                             A = dY [K=rows, M=out] k-major, W = X [K=rows, N=in] k-major
+ * k-major operands are read in place (no transposed copies); their contraction extent must be padded to a multiple of
+ * 32 rows of valid, zero-filled memory.  C [M, ldc] fp32 = act(alpha * A.W + bias) + residual, or with accumulate:
+ * C += alpha * A.W (+ bias + residual once).  A K split (splits > 1) goes through the workspace `ws` when one is lent
+ * (dense per-chunk slabs + a reduction launch, deterministic) and through fp32 atomics otherwise (accumulate only).
+ * splits = 0 / variant = 0: chosen by the library.  Results of the non-accumulating form are bit-identical to
+ * pfpp_gemm(PFPP_GEMM_F16X3) on the same planes.                                                               */
+typedef struct pfpp_gemm_planes_args {
+  const void* a_hi; const void* a_lo;   /* fp16 planes of A */
+  const void* w_hi; const void* w_lo;   /* fp16 planes of W */
+  float* C;
+  const float* bias;                    /* [N] or NULL */
+  const float* residual;                /* [M, ldr] or NULL */
+  int64_t M, N, K;                      /* output rows / columns, contraction length (K % 32 == 0) */
+  int64_t lda, ldw, ldc, ldr;           /* plane leading dimensions in halfs, C / residual in floats */
+  int32_t a_kmajor, w_kmajor;
+  int32_t act;                          /* PFPP_ACT_NONE / RELU / SILU / GELU */
+  int32_t accumulate;
+  int32_t splits, variant;
+  float alpha;
+  float* ws; int64_t ws_bytes;          /* optional K-split workspace (>= splits * M * N floats): chunks write dense slabs, a second
+                                           launch adds them in chunk order (deterministic); without it a K split uses atomics   */
+} pfpp_gemm_planes_args;
+
+int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);
+
 /* ---- a4 + a5 + a6 fused, for a set-abstraction level without input features ---------------------------
  * PointNetSetAbstraction.forward with points = None (utils/pn2_utils.py:197-217; sa1 of PN2,
  * vqvae/model/modules/pn2.py:16): sample_and_group's centred neighbourhoods (:127-151), three

@@ -176,9 +176,8 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
           PFPP_SPLIT_TO(v3, hi[3], lo[3]);
           *reinterpret_cast<half4*>(out_hi + off + dt * 32 + 8 * g) = hi;
           *reinterpret_cast<half4*>(out_lo + off + dt * 32 + 8 * g) = lo;
-        } else {
-          *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
         }
+        if (out) *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
       }
   }
 }
@@ -414,9 +413,8 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
           PFPP_SPLIT_TO(v3, hi[3], lo[3]);
           *reinterpret_cast<ad_half4*>(out_hi + off + dt * 32 + 8 * g) = hi;
           *reinterpret_cast<ad_half4*>(out_lo + off + dt * 32 + 8 * g) = lo;
-        } else {
-          *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
         }
+        if (out) *reinterpret_cast<float4*>(out + off + dt * 32 + 8 * g) = make_float4(v0, v1, v2, v3);
       }
   }
 }
@@ -435,6 +433,17 @@ extern "C" int pfpp_attn_dense_train(const float* qkv, float* out, float* lse, c
   PFPP_REQUIRE(out && lse, "null pointer");
   return attn_dense_impl(qkv, out, nullptr, nullptr, seq_off, seq_len, key_valid, kv_stride, n_seq, max_len, H, dh,
                          scale, stream, lse);
+}
+
+// training forward with the output additionally (or only) as split-f16 planes for the out-projection GEMM
+extern "C" int pfpp_attn_dense_train_p(const float* qkv, float* out, float* lse, const int32_t* seq_off,
+                                       const int32_t* seq_len, const uint8_t* key_valid, int64_t kv_stride,
+                                       int64_t n_seq, int64_t max_len, int64_t H, int64_t dh, float scale,
+                                       const pfpp_planes* out_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(lse && (out || out_planes) && pfpp_planes_ok(out_planes), "null pointer");
+  PFPP_REQUIRE(!out_planes || out_planes->scale == 1.0f, "forward planes are unscaled");
+  return attn_dense_impl(qkv, out, out_planes ? (_Float16*)out_planes->hi : nullptr, out_planes ? (_Float16*)out_planes->lo : nullptr,
+                         seq_off, seq_len, key_valid, kv_stride, n_seq, max_len, H, dh, scale, stream, lse);
 }
 
 extern "C" int pfpp_attn_dense(const float* qkv, float* out, const int32_t* seq_off, const int32_t* seq_len,

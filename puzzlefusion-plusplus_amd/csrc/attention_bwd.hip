@@ -451,7 +451,8 @@ constexpr int AB_DKV_SMEM = 8 * (int)sizeof(AbRowTile) + 8 * (int)sizeof(AbTrTil
 __device__ __forceinline__ void ab_dq_f16_body(
     char* smem, const int blk, const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
-    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale,
+    const pfpp_planes_out po = pfpp_planes_out{nullptr, nullptr, 1.0f}) {
   constexpr int DH = 64;
   constexpr int F4 = KT * DH / 4 / 256;
   AbRowTile* Kh = reinterpret_cast<AbRowTile*>(smem);
@@ -562,29 +563,32 @@ __device__ __forceinline__ void ab_dq_f16_body(
   }
 
   if (q_row < T) {
-    float* dst = dqkv + (row0 + q_row) * ld + h * DH + lhi * 4;
+    const int64_t d0 = (row0 + q_row) * ld + h * DH + lhi * 4;
     constexpr float inv = 1.0f / AB_DS;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
-            make_float4(dq_acc[dt][4 * g + 0] * inv, dq_acc[dt][4 * g + 1] * inv, dq_acc[dt][4 * g + 2] * inv, dq_acc[dt][4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = make_float4(dq_acc[dt][4 * g + 0] * inv, dq_acc[dt][4 * g + 1] * inv, dq_acc[dt][4 * g + 2] * inv, dq_acc[dt][4 * g + 3] * inv);
+        if (dqkv) *reinterpret_cast<float4*>(dqkv + d0 + dt * 32 + 8 * g) = v;
+        if (po.hi) pfpp_store4_planes(po, d0 + dt * 32 + 8 * g, v);
+      }
   }
 }
 
 __global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
-    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
   __shared__ __align__(16) char smem[AB_DQ_SMEM];
-  ab_dq_f16_body(smem, blockIdx.x, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
+  ab_dq_f16_body(smem, blockIdx.x, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
 }
 
 __device__ __forceinline__ void ab_dkv_f16_body(
     char* smem, const int blk, const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
-    const int32_t* __restrict__ seq_len, int H, float scale) {
+    const int32_t* __restrict__ seq_len, int H, float scale,
+    const pfpp_planes_out po = pfpp_planes_out{nullptr, nullptr, 1.0f}) {
   constexpr int DH = 64;
   constexpr int F4 = KT * DH / 4 / 256;
   AbRowTile* Qh = reinterpret_cast<AbRowTile*>(smem);
@@ -695,16 +699,22 @@ __device__ __forceinline__ void ab_dkv_f16_body(
   }
 
   if (k_row < T) {
-    float* dst = dqkv + (row0 + k_row) * ld + C + h * DH + lhi * 4;
+    const int64_t d0 = (row0 + k_row) * ld + C + h * DH + lhi * 4;
     constexpr float ik = 1.0f / AB_DS, iv = 1.0f / AB_GS;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<float4*>(dst + dt * 32 + 8 * g) =
-            make_float4(dk_acc[dt][4 * g + 0] * ik, dk_acc[dt][4 * g + 1] * ik, dk_acc[dt][4 * g + 2] * ik, dk_acc[dt][4 * g + 3] * ik);
-        *reinterpret_cast<float4*>(dst + C + dt * 32 + 8 * g) =
-            make_float4(dv_acc[dt][4 * g + 0] * iv, dv_acc[dt][4 * g + 1] * iv, dv_acc[dt][4 * g + 2] * iv, dv_acc[dt][4 * g + 3] * iv);
+        const float4 vk = make_float4(dk_acc[dt][4 * g + 0] * ik, dk_acc[dt][4 * g + 1] * ik, dk_acc[dt][4 * g + 2] * ik, dk_acc[dt][4 * g + 3] * ik);
+        const float4 vv = make_float4(dv_acc[dt][4 * g + 0] * iv, dv_acc[dt][4 * g + 1] * iv, dv_acc[dt][4 * g + 2] * iv, dv_acc[dt][4 * g + 3] * iv);
+        if (dqkv) {
+          *reinterpret_cast<float4*>(dqkv + d0 + dt * 32 + 8 * g) = vk;
+          *reinterpret_cast<float4*>(dqkv + d0 + C + dt * 32 + 8 * g) = vv;
+        }
+        if (po.hi) {
+          pfpp_store4_planes(po, d0 + dt * 32 + 8 * g, vk);
+          pfpp_store4_planes(po, d0 + C + dt * 32 + 8 * g, vv);
+        }
       }
   }
 }
@@ -712,9 +722,9 @@ __device__ __forceinline__ void ab_dkv_f16_body(
 __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
-    const int32_t* __restrict__ seq_len, int H, float scale) {
+    const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
   __shared__ __align__(16) char smem[AB_DKV_SMEM];
-  ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
+  ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
 }
 
 // Both passes in ONE launch (D comes from attn_dense_bwd_d_kernel): workgroups [0, nblk) of a (sequence, head) take the key
@@ -831,7 +841,7 @@ typedef float bdm_f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       float* __restrict__ dqkv, int64_t n_pairs, int L, int H,
-                                                                      float scale) {
+                                                                      float scale, pfpp_planes_out po) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
   const int64_t ld = 3ll * C;
   const float* base = qkv + frag * L * ld + h * BD_DH;                     // q of row 0; k at +C, v at +2C
   const float* dob = dout + frag * L * (int64_t)C + h * BD_DH;
-  float* gb = dqkv + frag * L * ld + h * BD_DH;
+  const int64_t gb = frag * L * ld + h * BD_DH;           // element offset of this pair's dq rows in dqkv (dk at +C, dv at +2C)
   const int row = l31 < L ? l31 : L - 1;
 
   // ---- this lane's row pieces (re-read for every product: they stay in L1/L2, and holding all four rows for the whole
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
     return acc;
   };
   // [64 dims] x [32 lanes] product with the accumulator `b` as the B operand: out^T[dim][lane] = sum_t src[idx(t)][dim] * b[t]
-  auto second = [&](const float* src, int64_t src_ld, const bdm_f32x16& b, float* dst) {
+  auto second = [&](const float* src, int64_t src_ld, const bdm_f32x16& b, int64_t dst) {
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
       bdm_f32x16 o;
@@ -881,9 +891,12 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
       }
       if (l31 < L) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(dst + l31 * ld + tile * 32 + 8 * q + 4 * lhi) =
-              make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+          const int64_t idx = dst + l31 * ld + tile * 32 + 8 * q + 4 * lhi;
+          if (dqkv) *reinterpret_cast<float4*>(dqkv + idx) = v;
+          if (po.hi) pfpp_store4_planes(po, idx, v);
+        }
       }
     }
   };
@@ -939,17 +952,24 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
 
 extern "C" int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L,
                                        int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
-  PFPP_REQUIRE(qkv && dout && dqkv, "null pointer");
+  PFPP_REQUIRE(dqkv, "null pointer");
+  return pfpp_attn_blockdiag_bwd_p(qkv, dout, dqkv, n_frag, L, H, dh, scale, nullptr, stream);
+}
+
+extern "C" int pfpp_attn_blockdiag_bwd_p(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L,
+                                         int64_t H, int64_t dh, float scale, const pfpp_planes* dqkv_planes,
+                                         pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && dout && (dqkv || dqkv_planes) && pfpp_planes_ok(dqkv_planes), "null pointer");
   PFPP_SUPPORTED(dh == BD_DH, "dim_head != 64");
   PFPP_SUPPORTED(L >= 1 && L <= BD_L, "L outside [1, 32]");
   PFPP_REQUIRE(pfpp::aligned16(qkv) && pfpp::aligned16(dout), "16-byte alignment");
   const int64_t pairs = n_frag * H;
   if (pairs == 0) return PFPP_OK;
   static const bool use_mfma = !(getenv("PFPP_ATTN_BD_MFMA") && atoi(getenv("PFPP_ATTN_BD_MFMA")) == 0);
-  if (use_mfma) {
+  if (use_mfma || dqkv_planes) {
     hipLaunchKernelGGL(attn_blockdiag_bwd_mfma_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, pfpp::as_stream(stream), qkv,
-                       dout, dqkv, pairs, (int)L, (int)H, scale);
-    return pfpp::check_launch(__func__);
+                       dout, dqkv, pairs, (int)L, (int)H, scale, pfpp_planes_arg(dqkv_planes));
+    return pfpp::check_launch("pfpp_attn_blockdiag_bwd");
   }
   const size_t smem = (size_t)(4 * L * BD_LD + 2 * L * (L + 1)) * sizeof(float);
   hipLaunchKernelGGL(attn_blockdiag_bwd_kernel, dim3((unsigned)pairs), dim3(256), smem, pfpp::as_stream(stream), qkv, dout,
@@ -961,7 +981,22 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
                                    float* dvec, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
                                    const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
                                    int64_t H, int64_t dh, float scale, pfpp_stream_t stream) {
-  PFPP_REQUIRE(qkv && out && dout && lse && dvec && dqkv && seq_off && seq_len, "null pointer");
+  PFPP_REQUIRE(dqkv, "null pointer");
+  return pfpp_attn_dense_bwd_p(qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len, key_valid, kv_stride, n_seq, max_len, H, dh,
+                               scale, nullptr, stream);
+}
+
+extern "C" int pfpp_attn_dense_bwd_p(const float* qkv, const float* out, const float* dout, const float* lse,
+                                     float* dvec, float* dqkv, const int32_t* seq_off, const int32_t* seq_len,
+                                     const uint8_t* key_valid, int64_t kv_stride, int64_t n_seq, int64_t max_len,
+                                     int64_t H, int64_t dh, float scale, const pfpp_planes* dqkv_planes,
+                                     pfpp_stream_t stream) {
+  PFPP_REQUIRE(qkv && out && dout && lse && dvec && (dqkv || dqkv_planes) && seq_off && seq_len && pfpp_planes_ok(dqkv_planes),
+               "null pointer");
+  static const int f16_mode_p = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
+  PFPP_SUPPORTED(!dqkv_planes || (dh == 64 && f16_mode_p >= 1 && key_valid == nullptr),
+                 "plane output of the attention backward needs the split-f16 passes (dim_head 64, no key mask)");
+  const pfpp_planes_out po = pfpp_planes_arg(dqkv_planes);
   PFPP_REQUIRE(n_seq >= 0 && max_len >= 1 && H >= 1, "bad sizes");
   PFPP_SUPPORTED(dh == 64 || dh == 32, "dim_head must be 32 or 64");
   PFPP_SUPPORTED(n_seq <= 65535 && H <= 65535, "too many sequences / heads for one launch");
@@ -976,7 +1011,7 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
     // opt-in: measured slower (training iteration 8.43 -> 8.50 ms) — the longest sequence's workgroups of the two passes
     // then share SIMDs and each walks its tiles more slowly than alone
     static const bool merged = getenv("PFPP_ATTN_BWD_MERGED") && atoi(getenv("PFPP_ATTN_BWD_MERGED")) == 1;
-    if (merged) {
+    if (merged && !dqkv_planes) {
       const int Hi = (int)H;
       hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
       const dim3 grid2(2 * grid.x, grid.y, grid.z);
@@ -985,10 +1020,10 @@ extern "C" int pfpp_attn_dense_bwd(const float* qkv, const float* out, const flo
       return pfpp::check_launch(__func__);
     }
     hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
-                       (int)H, scale);
+                       (int)H, scale, po);
     hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off, seq_len,
-                       (int)H, scale);
-    return pfpp::check_launch(__func__);
+                       (int)H, scale, po);
+    return pfpp::check_launch("pfpp_attn_dense_bwd");
   }
   if (dh == 64) {
     hipLaunchKernelGGL(attn_dense_bwd_dq_kernel<64>, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off,
@@ -1023,10 +1058,11 @@ extern "C" int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, con
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
   if (dh == 64 && f16_mode >= 1 && key_valid == nullptr) {      // same kernel choice as pfpp_attn_dense_bwd
     if (parts & 1) hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
+    const pfpp_planes_out none = pfpp_planes_arg(nullptr);
     if (parts & 2) hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, (float*)nullptr, dqkv,
-                                      seq_off, seq_len, Hi, scale);
+                                      seq_off, seq_len, Hi, scale, none);
     if (parts & 4) hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off,
-                                      seq_len, Hi, scale);
+                                      seq_len, Hi, scale, none);
     return pfpp::check_launch(__func__);
   }
   if (dh == 64) {

@@ -914,6 +914,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p_split_cnt_len = a->split_cnt ? a->split_cnt_len : 0;
   p.tiles_n = 0;
   p.dbg = 0;
+  p.accum = 0;
   hipStream_t st = pfpp::as_stream(stream);
 
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)

@@ -17,12 +17,23 @@
 //     keeps its fragments double-buffered in registers: the reads of half-step h+1 — across K-tile boundaries too —
 //     are issued before the MFMAs of half-step h, so the matrix instructions of a wave never wait for LDS;
 //   * two waves per SIMD (8-wave workgroups, or two 4-wave workgroups per CU) cover each other's barrier waits.
+// Operand layouts (template AK / WK).  Row-major: the operand's rows are output rows / columns and the contraction runs
+// along a row (forward GEMMs; 64-byte plane rows per K-tile, 16-byte chunks XOR-swizzled).  K-major: the operand is stored
+// [contraction][rows] — W in dX = dY . W, and both dY and X in dW = dY^T . X — and is NOT copied transposed: its K-tile is
+// staged as 32 contraction rows x BM (BN) columns, and fragments are fetched with ds_read_b64_tr_b16, which hands each lane
+// of a 16-lane group the 4 contraction-consecutive halfs of its own column out of a [4][16] block (lane -> element map
+// probed on gfx950: tools/gemm_lab/trprobe.hip).  Two such reads make one MFMA operand.  The 16-byte chunks of a
+// contraction row are rotated by 4 * (row & 3) (64-column tiles: 4 * ((row >> 1) & 1)) on the DMA source side so that the
+// four rows a 32-lane group touches fall into disjoint banks.
+// Split-K (grid.y > 1) and accumulate mode add alpha * acc into C with fp32 atomics (weight / input gradients).
 // Fragment reads are inline asm (hipcc drains vmcnt(0) in front of every ds_read it can see while an LDS-DMA is
 // in flight); the waits name every destination register, which is what orders the MFMAs behind them.
 // One __shared__ object only (a second one makes hipcc drain the DMA queue at every step, guide §5).
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "gemm_common.h"
 
@@ -35,6 +46,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 namespace pl {
 
 constexpr int BK = 32;
+thread_local int64_t p_ws_bytes = 0;     // capacity of the caller's K-split workspace for the launch being dispatched
 
 __device__ __forceinline__ void glds16(const char* gsrc, uint32_t ldst) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)ldst, 16, 0, 0);
@@ -65,6 +77,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // MT x NT 32x32 tiles per wave, WM x WN waves.  HS = row tiles per half-step (the fragment double buffer holds HS row tiles
 // and NT column tiles): HS == MT for one half-step per 16-deep step, MT / 2 for two.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+// transposing read: within a 16-lane group, lane j receives element j of each of the four 16-half rows the group's lanes
+// address (lanes 4r .. 4r+3 supply row r, 4 halfs each)
+template <int OFF>
+__device__ __forceinline__ half4 lds_rd_tr(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  half4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
 template <int MT, int NT, int WM, int WN, int NS>
 struct Cfg {
   static constexpr int HS = (MT == 4 && NT == 2) ? 2 : MT;
@@ -172,14 +195,15 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
 }
 
 // One workgroup = one output tile.  NS-stage DMA ring; see the header for the schedule.
-template <int MT, int NT, int WM, int WN, int NS, int DBG>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG>
 __device__ __forceinline__ void pl_body(const GemmP& p) {
   using C = Cfg<MT, NT, WM, WN, NS>;
   constexpr int BM = C::BM, BN = C::BN, NPW = C::NPW, STAGE = C::STAGE;
   constexpr int HS = C::HS;
   constexpr int NH = MT / HS;         // half-steps per 16-deep step
   constexpr int NMMA = 3 * HS * NT;   // MFMAs per half-step
-  constexpr int RA = 2 * HS, RB = 2 * NT;   // fragment reads of a half-step's A tiles / a step's W tiles
+  constexpr int RA = (AK ? 4 : 2) * HS, RB = (WK ? 4 : 2) * NT;   // fragment reads of a half-step's A tiles / a step's W tiles
+  constexpr int CPR_A = BM / 8, CPR_W = BN / 8;                  // 16-byte chunks per contraction row of a k-major tile
   extern __shared__ __align__(1024) char pl_smem[];
 
   const int tid = threadIdx.x;
@@ -188,10 +212,18 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  const int tile = remap_tile(blockIdx.x, gridDim.x);
+  // 1-D grid of (K chunk, tile) pairs, chunk-major after the XCD remap: an XCD walks one K range over many tiles
+  const int wg = remap_tile(blockIdx.x, gridDim.x);
+  const int n_tiles = p.tiles_m * p.tiles_n;
+  const int split = wg / n_tiles;
+  const int tile = wg - split * n_tiles;
   int tm, tn;
   tile_coords(p, tile, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+  const int nk_all = p.K / BK;
+  const int nk_base = nk_all / p.split_k, nk_rem = nk_all - nk_base * p.split_k;
+  const int kt0 = split * nk_base + min(split, nk_rem);      // first K-tile of this workgroup
+  const int nk = nk_base + (split < nk_rem ? 1 : 0);
   const int z = blockIdx.z;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
   const int64_t a_offz = z0 * p.sA0 + z1 * p.sA1;
@@ -201,31 +233,47 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)pl_smem;
 
-  // ---- DMA sources: piece q = wave + NW*j of a stage = LDS bytes [q KiB, (q+1) KiB) = 16 rows of one plane --------
-  // lane i of a piece lands at byte q*1024 + i*16: row (i >> 2) of the piece, physical chunk i & 3, which holds the
-  // row's logical 16-byte chunk (i & 3) ^ ((row >> 2) & 3)
+  // ---- DMA sources: piece q = wave + NW*j of a stage = LDS bytes [q KiB, (q+1) KiB) of one plane ----------------------------
+  // row-major operand: lane i of a piece lands at row (i >> 2) of the piece's 16 rows, physical chunk i & 3, which holds the
+  //   row's logical 16-byte chunk (i & 3) ^ ((row >> 2) & 3); the next K-tile is 64 bytes further along the row
+  // k-major operand: plane chunk ci = contraction row ci / CPR, slot ci % CPR, which holds column chunk
+  //   (slot - 4 * rot(row)) mod CPR of that row; the next K-tile is 32 rows further down
   const char* src[NPW];
   uint32_t dst[NPW];
+  const int64_t adv_a = AK ? (int64_t)32 * p.lda * 2 : 64, adv_w = WK ? (int64_t)32 * p.ldw * 2 : 64;
+  bool piece_a[NPW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int q = wave + C::NW * j;
     const int o = q * 1024;
     const bool is_a = o < 2 * C::PLANE_A;
+    piece_a[j] = is_a;
     const int o2 = is_a ? o : o - 2 * C::PLANE_A;
     const int psz = is_a ? C::PLANE_A : C::PLANE_W;
     const bool lo = o2 >= psz;
-    const int row = ((lo ? o2 - psz : o2) >> 6) + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int ci = ((lo ? o2 - psz : o2) >> 4) + lane;           // 16-byte chunk index within the plane
     const _Float16* base = reinterpret_cast<const _Float16*>(is_a ? (lo ? p.Alo : p.Ahi) : (lo ? p.Wlo : p.Whi));
-    const int64_t eoff = is_a ? a_offz + (int64_t)min(m0 + row, p.M - 1) * p.lda
-                              : w_offz + (int64_t)min(n0 + row, p.N - 1) * p.ldw;
-    src[j] = reinterpret_cast<const char*>(base + eoff + chunk * 8);
+    int64_t eoff;
+    auto kmajor_off = [&](int cpr, int g0, int lim, int64_t ld) {
+      const int krow = ci / cpr, slot = ci % cpr;
+      const int rot = cpr >= 16 ? (krow & 3) : ((krow >> 1) & 1);
+      const int nc = (slot - 4 * rot + cpr) % cpr;
+      const int col = min(g0 + 8 * nc, lim - 8);
+      return (int64_t)krow * ld + col;
+    };
+    auto rowmajor_off = [&](int g0, int lim, int64_t ld) {
+      const int row = ci >> 2;
+      const int chunk = (ci & 3) ^ ((row >> 2) & 3);
+      return (int64_t)min(g0 + row, lim - 1) * ld + chunk * 8;
+    };
+    if (is_a) eoff = a_offz + (AK ? kmajor_off(CPR_A, m0, p.M, p.lda) : rowmajor_off(m0, p.M, p.lda));
+    else eoff = w_offz + (WK ? kmajor_off(CPR_W, n0, p.N, p.ldw) : rowmajor_off(n0, p.N, p.ldw));
+    src[j] = reinterpret_cast<const char*>(base + eoff) + (int64_t)kt0 * (is_a ? adv_a : adv_w);
     dst[j] = lds0 + o;
   }
   auto issue = [&](int kt, uint32_t st_off) {
-    const int kb = kt * (BK * 2);
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) glds16(src[j] + kb, dst[j] + st_off);
+    for (int j = 0; j < NPW; ++j) glds16(src[j] + (int64_t)kt * (piece_a[j] ? adv_a : adv_w), dst[j] + st_off);
   };
 
   f32x16 acc[MT][NT];
@@ -236,42 +284,86 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // ---- fragment addressing: lane (l31, lhi) reads row l31 of a 32-row tile, logical chunk 2*s + lhi --------------------
+  // ---- fragment addressing -----------------------------------------------------------------------------------------------
+  // row-major: lane (l31, lhi) reads row l31 of a 32-row tile, logical chunk 2*s + lhi; one address per 16-deep step s
+  // k-major: lane (q = lane >> 4, j = lane & 15) reads 8 bytes at contraction row 16 s + 8 (q >> 1) + 4 t + (j >> 2), column
+  //   32 tile + 16 (q & 1) + 4 (j & 3); one address per tile of the wave, (s, t) go into the offset field
   const int sw = (l31 >> 2) & 3;
-  uint32_t a_ad[2], w_ad[2];
+  constexpr int NAD_A = AK ? MT : 2, NAD_W = WK ? NT : 2;
+  uint32_t a_ad[NAD_A], w_ad[NAD_W];
+  auto kmajor_ad = [&](int cpr, int it) {
+    const int q = lane >> 4, j = lane & 15;
+    const int krow = 8 * (q >> 1) + (j >> 2);
+    const int rot = cpr >= 16 ? ((j >> 2) & 3) : (((j >> 2) >> 1) & 1);
+    const int nc = 4 * it + 2 * (q & 1) + ((j & 3) >> 1);
+    return (uint32_t)((krow * cpr + ((nc + 4 * rot) % cpr)) * 16 + (j & 1) * 8);
+  };
+  if constexpr (AK) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    a_ad[s] = lds0 + (wm * 32 * MT + l31) * 64 + (((2 * s + lhi) ^ sw) << 4);
-    w_ad[s] = lds0 + 2 * C::PLANE_A + (wn * 32 * NT + l31) * 64 + (((2 * s + lhi) ^ sw) << 4);
+    for (int ii = 0; ii < MT; ++ii) a_ad[ii] = lds0 + kmajor_ad(CPR_A, wm * MT + ii);
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) a_ad[s2] = lds0 + (wm * 32 * MT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
   }
-  struct FA { half8 h[HS], l[HS]; };
-  struct FB { half8 h[NT], l[NT]; };
+  if constexpr (WK) {
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj) w_ad[jj] = lds0 + 2 * C::PLANE_A + kmajor_ad(CPR_W, wn * NT + jj);
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) w_ad[s2] = lds0 + 2 * C::PLANE_A + (wn * 32 * NT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
+  }
+  // a k-major fragment arrives as two 8-byte halves (contraction rows +0..3 and +4..7)
+  struct FA { half8 h[HS], l[HS]; half4 h2[AK ? HS : 1][2], l2[AK ? HS : 1][2]; };
+  struct FB { half8 h[NT], l[NT]; half4 h2[WK ? NT : 1][2], l2[WK ? NT : 1][2]; };
   FA fa[2];
   FB fb[2];
   // DBG (lab builds, -DPFPP_PL_LAB): 1 no epilogue, 2 no DMA after the prologue, 4 no barrier / DMA wait, 8 no fragment reads,
   // 16 no fragment waits
   constexpr bool dbg_noread = DBG & 8, dbg_nowait = DBG & 16;
-  // Fragment reads one at a time (q < HS: hi plane of row tile q, then the lo planes), each in its own gap between two MFMAs
+  // Fragment reads one at a time, each in its own gap between two MFMAs.  Row-major: q < HS: hi plane of row tile q, then
+  // the lo planes.  K-major: q = 4 * tile + 2 * plane + t.
   auto rd_a = [&](FA& f, uint32_t st, auto s_c, auto mh_c, auto q_c) {
     constexpr int s = decltype(s_c)::value, mh = decltype(mh_c)::value, q = decltype(q_c)::value;
     if constexpr (dbg_noread) return;
-    const uint32_t ad = a_ad[s] + st;
-    constexpr int t = q % HS;
-    if constexpr (q < HS) f.h[t] = lds_rd<(HS * mh + t) * 2048>(ad);
-    else f.l[t] = lds_rd<C::PLANE_A + (HS * mh + t) * 2048>(ad);
+    if constexpr (AK) {
+      constexpr int t = q / 4, pl_ = (q >> 1) & 1, hf = q & 1;
+      constexpr int off = pl_ * C::PLANE_A + (16 * s + 4 * hf) * CPR_A * 16;
+      const uint32_t ad = a_ad[HS * mh + t] + st;
+      if constexpr (pl_ == 0) f.h2[t][hf] = lds_rd_tr<off>(ad); else f.l2[t][hf] = lds_rd_tr<off>(ad);
+    } else {
+      const uint32_t ad = a_ad[s] + st;
+      constexpr int t = q % HS;
+      if constexpr (q < HS) f.h[t] = lds_rd<(HS * mh + t) * 2048>(ad);
+      else f.l[t] = lds_rd<C::PLANE_A + (HS * mh + t) * 2048>(ad);
+    }
   };
   auto rd_b = [&](FB& f, uint32_t st, auto s_c, auto q_c) {
     constexpr int s = decltype(s_c)::value, q = decltype(q_c)::value;
     if constexpr (dbg_noread) return;
-    const uint32_t ad = w_ad[s] + st;
-    constexpr int t = q % NT;
-    if constexpr (q < NT) f.h[t] = lds_rd<t * 2048>(ad);
-    else f.l[t] = lds_rd<C::PLANE_W + t * 2048>(ad);
+    if constexpr (WK) {
+      constexpr int t = q / 4, pl_ = (q >> 1) & 1, hf = q & 1;
+      constexpr int off = pl_ * C::PLANE_W + (16 * s + 4 * hf) * CPR_W * 16;
+      const uint32_t ad = w_ad[t] + st;
+      if constexpr (pl_ == 0) f.h2[t][hf] = lds_rd_tr<off>(ad); else f.l2[t][hf] = lds_rd_tr<off>(ad);
+    } else {
+      const uint32_t ad = w_ad[s] + st;
+      constexpr int t = q % NT;
+      if constexpr (q < NT) f.h[t] = lds_rd<t * 2048>(ad);
+      else f.l[t] = lds_rd<C::PLANE_W + t * 2048>(ad);
+    }
   };
-  // all outstanding LDS reads have landed; names the fragments the following MFMAs consume
+  // all outstanding LDS reads have landed; names the fragments the following MFMAs consume (k-major: and joins their halves)
+  auto join = [](const half4 x, const half4 y) { return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7); };
   auto wait_a = [&](FA& a) {
     if constexpr (dbg_nowait) return;
-    if constexpr (HS == 1)
+    if constexpr (AK) {
+      static_for<HS>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h2[t][0]), "+v"(a.h2[t][1]), "+v"(a.l2[t][0]), "+v"(a.l2[t][1]));
+        a.h[t] = join(a.h2[t][0], a.h2[t][1]);
+        a.l[t] = join(a.l2[t][0], a.l2[t][1]);
+      });
+    } else if constexpr (HS == 1)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]), "+v"(a.l[0]));
     else if constexpr (HS == 2)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]), "+v"(a.h[1]), "+v"(a.l[0]), "+v"(a.l[1]));
@@ -281,7 +373,14 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   };
   auto wait_b = [&](FB& b) {
     if constexpr (dbg_nowait) return;
-    if constexpr (NT == 1)
+    if constexpr (WK) {
+      static_for<NT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h2[t][0]), "+v"(b.h2[t][1]), "+v"(b.l2[t][0]), "+v"(b.l2[t][1]));
+        b.h[t] = join(b.h2[t][0], b.h2[t][1]);
+        b.l[t] = join(b.l2[t][0], b.l2[t][1]);
+      });
+    } else if constexpr (NT == 1)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h[0]), "+v"(b.l[0]));
     else if constexpr (NT == 2)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h[0]), "+v"(b.h[1]), "+v"(b.l[0]), "+v"(b.l[1]));
@@ -316,13 +415,12 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  const int nk = p.K / BK;
   constexpr int NP1 = NPW / 2;          // DMA pieces issued in the last half-step of a tile (right after the barrier) ...
   constexpr int NP2 = NPW - NP1;        // ... and in the first half-step of the next one
   constexpr int G0 = RA + RB;           // fillers of a half-step: its fragment reads first, DMA pieces behind them
   auto issue1 = [&](int kt, uint32_t st_off, auto j_c) {
     constexpr int j = decltype(j_c)::value;
-    glds16(src[j] + kt * (BK * 2), dst[j] + st_off);
+    glds16(src[j] + (int64_t)kt * (piece_a[j] ? adv_a : adv_w), dst[j] + st_off);
   };
 
   // ---- prologue: fill the ring, wait for tile 0, first fragments ---------------------------------------------------------
@@ -409,6 +507,44 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   tile_body(nk - 1, cur, 0u, prv, std::true_type{});
 
   if ((DBG & 1) && acc[0][0][0] != 12345.678f) return;
+  if (p.split_ws && p.split_k > 1) {
+    // K split with a workspace: this chunk's alpha * acc goes to its own dense [M, N] slab with 16-byte stores; pl_reduce_kernel
+    // adds the slabs in chunk order afterwards (deterministic; fp32 atomics on a shared C measured 1.2 TB/s: every chunk of a
+    // tile finishes at the same time and they all hit the same lines)
+    GemmP q = p;
+    q.C = p.split_ws + (size_t)split * p.M * p.N;
+    q.ldc = p.N;
+    q.bias = q.scale = q.shift = q.residual = nullptr;
+    q.act = PFPP_ACT_NONE;
+    q.Chi = q.Clo = nullptr;
+    __builtin_amdgcn_s_barrier();
+    epilogue_wide<MT, NT>(q, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, 0, 0, lds0 + wave * (32 * NT * 128));
+    return;
+  }
+  if (p.accum) {
+    // C += alpha * acc (+ bias / residual from the first K chunk): fp32 atomics; activation and pooling are excluded on the host
+    const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
+    const float* R = (p.residual && split == 0) ? p.residual + c_off : nullptr;
+    const float* bias = (p.bias && split == 0) ? p.bias + v_off : nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col_w + j * 32 + l31;
+      if (col >= p.N) continue;
+      const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (row < p.M) {
+            float v = acc[i][j][e] * p.alpha + b;
+            if (R) v += R[(int64_t)row * p.ldr + col];
+            unsafeAtomicAdd(p.C + c_off + (int64_t)row * p.ldc + col, v);
+          }
+        }
+    }
+    return;
+  }
   const bool wide_ok = p.pool == 0 && !p.stats && !(DBG & 128) && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
                        (!p.residual || (p.ldr & 3) == 0) && (p.act != PFPP_ACT_GEGLU || (p.N & 7) == 0);
   if (wide_ok) {
@@ -419,30 +555,55 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   }
 }
 
-template <int MT, int NT, int WM, int WN, int NS, int DBG>
-__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
-  pl_body<MT, NT, WM, WN, NS, DBG>(p);
+// second pass of a workspace K split: C = [C +] act(sum of the slabs + bias) + residual, four columns per thread
+__global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* C, const float* bias, const float* residual, int M,
+                                                        int N, int64_t ldc, int64_t ldr, int splits, int accumulate, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i >= (int64_t)M * n4) return;
+  const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
+  const size_t slab = (size_t)M * N;
+  const float* src = ws + (size_t)row * N + col;
+  float4 s = *reinterpret_cast<const float4*>(src);
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(src + k * slab);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+  s.x = act_apply(s.x, act); s.y = act_apply(s.y, act); s.z = act_apply(s.z, act); s.w = act_apply(s.w, act);
+  if (residual) {
+    const float4 r = *reinterpret_cast<const float4*>(residual + (int64_t)row * ldr + col);
+    s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+  }
+  float4* dstp = reinterpret_cast<float4*>(C + (int64_t)row * ldc + col);
+  if (accumulate) { const float4 c = *dstp; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+  *dstp = s;
 }
 
-template <int MT, int NT, int WM, int WN, int NS, int DBG = 0>
-int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m) {
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG>
+__global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
+  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG>(p);
+}
+
+template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0>
+int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits = 1) {
   using C = Cfg<MT, NT, WM, WN, NS>;
 #ifdef PFPP_PL_LAB
   if constexpr (DBG == 0) {
     const char* e = getenv("PFPP_GEMM_DBG");
     switch (e ? atoi(e) : 0) {
-      case 1: return launch_pl<MT, NT, WM, WN, NS, 1>(p0, batch, st, group_m);
-      case 3: return launch_pl<MT, NT, WM, WN, NS, 3>(p0, batch, st, group_m);
-      case 7: return launch_pl<MT, NT, WM, WN, NS, 7>(p0, batch, st, group_m);
-      case 15: return launch_pl<MT, NT, WM, WN, NS, 15>(p0, batch, st, group_m);
-      case 23: return launch_pl<MT, NT, WM, WN, NS, 23>(p0, batch, st, group_m);
-      case 128: return launch_pl<MT, NT, WM, WN, NS, 128>(p0, batch, st, group_m);
+      case 1: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 1>(p0, batch, st, group_m, splits);
+      case 3: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 3>(p0, batch, st, group_m, splits);
+      case 7: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 7>(p0, batch, st, group_m, splits);
+      case 15: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 15>(p0, batch, st, group_m, splits);
+      case 23: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 23>(p0, batch, st, group_m, splits);
+      case 128: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 128>(p0, batch, st, group_m, splits);
       default: break;
     }
   }
 #endif
   static bool attr_set = false;
-  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, DBG>;
+  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -451,35 +612,104 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m) {
   p.tiles_m = (p.M + C::BM - 1) / C::BM;
   p.tiles_n = (p.N + C::BN - 1) / C::BN;
   p.group_m = p.tiles_n > 1 ? group_m : 0;
-  p.split_k = 1;
+  const int nk_all = p.K / BK;
+  p.split_k = splits < 1 ? 1 : (splits > nk_all ? nk_all : splits);
+  const bool slabs = p.split_k > 1 && p.split_ws && batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
+                     (int64_t)p.split_k * p.M * p.N * (int64_t)sizeof(float) <= p_ws_bytes;
+  if (!slabs) p.split_ws = nullptr;
+  if (p.split_k > 1 && !slabs) {
+    if (p.act != PFPP_ACT_NONE || !p.accum) { p.split_k = 1; }     // atomics need an accumulating, activation-free epilogue
+  }
   p.k_chunk = 0;
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch);
+  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, p);
+  if (slabs) {
+    const int64_t n4 = (int64_t)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.split_ws, p.C, p.bias, p.residual, p.M,
+                       p.N, p.ldc, p.ldr, p.split_k, p.accum, p.act);
+  }
   return pfpp::check_launch("pfpp_gemm");
 }
 
 }  // namespace pl
 
 // variant: 0 = pick by shape, 1 = 256x256 (8 waves of 128x64, 2 stages), 2 = 256x128 (8 waves, 3 stages), 3 = 128x128 (4 waves,
-// 2 stages, two workgroups per CU), 4 / 6 = 128x64 (2 / 3 stages), 5 = 64x128: small tiles for narrow outputs
+// 2 stages, two workgroups per CU), 6 = 128x64 (3 stages): small tiles for narrow outputs
+template <bool AK, bool WK>
+static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m, int variant, int splits) {
+  switch (variant) {
+    case 1:
+      if constexpr (!AK && !WK) return pl::launch_pl<4, 2, 2, 4, 2, AK, WK>(p, batch, st, group_m, splits);
+      [[fallthrough]];
+    case 2: return pl::launch_pl<2, 2, 4, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    case 6: return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK>(p, batch, st, group_m, splits);
+  }
+}
+
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant) {
   if (variant == 0) {
     const int64_t t256 = ((int64_t)(p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
     const int64_t t21 = ((int64_t)(p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
-    variant = t256 >= 512 ? 1 : (t21 >= 224 ? 2 : 3);
+    const int64_t t11 = ((int64_t)(p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    variant = t256 >= 512 ? 1 : (t21 >= 160 ? 2 : (t11 >= 200 ? 3 : 6));
   }
-  switch (variant) {
-    case 1: return pl::launch_pl<4, 2, 2, 4, 2>(p, batch, st, group_m);
-    case 2: return pl::launch_pl<2, 2, 4, 2, 3>(p, batch, st, group_m);
-    case 4: return pl::launch_pl<2, 1, 2, 2, 2>(p, batch, st, group_m);      // 128x64, 4 waves of 64x32
-    case 5: return pl::launch_pl<1, 2, 2, 2, 2>(p, batch, st, group_m);      // 64x128, 4 waves of 32x64
-    case 6: return pl::launch_pl<2, 1, 2, 2, 3>(p, batch, st, group_m);      // 128x64, 3 stages
-    case 7: return pl::launch_pl<2, 1, 2, 2, 4>(p, batch, st, group_m);
-    case 8: return pl::launch_pl<2, 1, 2, 2, 6>(p, batch, st, group_m);
-    case 9: return pl::launch_pl<2, 2, 2, 2, 3>(p, batch, st, group_m);      // 128x128, 3 / 4 stages (one workgroup per CU)
-    case 10: return pl::launch_pl<2, 2, 2, 2, 4>(p, batch, st, group_m);
-    default: return pl::launch_pl<2, 2, 2, 2, 2>(p, batch, st, group_m);
-  }
+  // GEGLU gates pairs of column tiles (two per wave at least); the pool = 64 epilogue needs two row tiles per wave
+  if (variant == 6 && p.act == PFPP_ACT_GEGLU) variant = 3;
+  if (variant == 1 && p.pool == 64) variant = 2;
+  return launch_variant<false, false>(p, batch, st, group_m, variant, 1);
 }
 
 }  // namespace pfpp_gemm_detail
+
+using namespace pfpp_gemm_detail;
+
+extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t stream) {
+  PFPP_REQUIRE(a && a->a_hi && a->a_lo && a->w_hi && a->w_lo && a->C, "null pointer");
+  PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 32 == 0, "sizes: M, N > 0, K a positive multiple of 32");
+  PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
+  PFPP_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && pfpp::aligned16(a->a_hi) && pfpp::aligned16(a->a_lo) &&
+               pfpp::aligned16(a->w_hi) && pfpp::aligned16(a->w_lo), "planes: 16-byte aligned, leading dimensions % 8 == 0");
+  PFPP_REQUIRE(a->a_kmajor ? (a->M % 8 == 0 && a->lda >= a->M) : a->lda >= a->K, "A: lda too small (k-major: M % 8 == 0)");
+  PFPP_REQUIRE(a->w_kmajor ? (a->N % 8 == 0 && a->ldw >= a->N) : a->ldw >= a->K, "W: ldw too small (k-major: N % 8 == 0)");
+  PFPP_SUPPORTED(!(a->a_kmajor && !a->w_kmajor), "k-major A with a row-major W");
+  PFPP_REQUIRE(!a->residual || a->ldr > 0, "residual without ldr");
+  PFPP_REQUIRE(a->act >= PFPP_ACT_NONE && a->act <= PFPP_ACT_GELU, "activation");
+  PFPP_REQUIRE(a->splits >= 0 && (a->splits <= 1 || a->accumulate || a->ws), "split-K needs a workspace or accumulate");
+  PFPP_REQUIRE(!a->accumulate || a->act == PFPP_ACT_NONE, "accumulate excludes an activation");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.C = a->C; p.Ahi = a->a_hi; p.Alo = a->a_lo; p.Whi = a->w_hi; p.Wlo = a->w_lo;
+  p.bias = a->bias; p.residual = a->residual;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.act = a->act; p.zdiv = 1; p.alpha = a->alpha; p.accum = a->accumulate ? 1 : 0;
+  p.split_ws = a->ws;
+  pl::p_ws_bytes = a->ws ? a->ws_bytes : 0;
+  hipStream_t st = pfpp::as_stream(stream);
+  int variant = a->variant, splits = a->splits;
+  const int nk = p.K / 32;
+  if (variant == 0) {
+    // tile: the largest one that still yields about one workgroup per CU together with the K split
+    const int64_t t21 = ((int64_t)(p.M + 255) / 256) * ((p.N + 127) / 128);
+    const int64_t t11 = ((int64_t)(p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (a->accumulate || a->ws) variant = (t21 * (nk / 8 > 0 ? nk / 8 : 1) >= 128) ? 2 : (t11 >= 200 ? 3 : (t21 * (nk / 8 > 0 ? nk / 8 : 1) >= 64 ? 3 : 6));
+    else variant = t21 >= 160 ? 2 : (t11 >= 200 ? 3 : 6);
+  }
+  if (splits == 0) {
+    splits = 1;
+    if (a->accumulate || a->ws) {
+      const int bm = variant == 2 ? 256 : 128, bn = variant == 6 ? 64 : 128;
+      const int64_t tiles = ((int64_t)(p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+      const int64_t slots = variant == 2 ? 256 : 512;
+      splits = (int)((slots + tiles - 1) / tiles);
+      const int max_by_k = nk / 4 > 0 ? nk / 4 : 1;           // at least 4 K-tiles per chunk
+      if (splits > max_by_k) splits = max_by_k;
+      if (splits < 1) splits = 1;
+    }
+  }
+  const int gm = 8;
+  if (a->a_kmajor) return launch_variant<true, true>(p, 1, st, gm, variant, splits);
+  if (a->w_kmajor) return launch_variant<false, true>(p, 1, st, gm, variant, splits);
+  return launch_variant<false, false>(p, 1, st, gm, variant, splits);
+}

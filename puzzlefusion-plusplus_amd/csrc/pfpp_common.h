@@ -41,6 +41,30 @@ __device__ __forceinline__ pfpp_hl pfpp_split(float x) {
 // assigns into two targets (vector elements are not bindable to references)
 #define PFPP_SPLIT_TO(x, HI, LO) do { const pfpp_hl _s = pfpp_split(x); (HI) = _s.hi; (LO) = _s.lo; } while (0)
 
+// optional split-f16 copy of a kernel's result (operand of the plane GEMM, csrc/gemm_pl.hip): planes of scale * value.
+// Host side: pfpp_planes (include/pfpp.h) -> pfpp_planes_out by pfpp_planes_arg().
+struct pfpp_planes_out { _Float16* hi; _Float16* lo; float scale; };
+inline pfpp_planes_out pfpp_planes_arg(const pfpp_planes* p) {
+  pfpp_planes_out o;
+  o.hi = p ? reinterpret_cast<_Float16*>(p->hi) : nullptr;
+  o.lo = p ? reinterpret_cast<_Float16*>(p->lo) : nullptr;
+  o.scale = p ? p->scale : 1.0f;
+  return o;
+}
+inline bool pfpp_planes_ok(const pfpp_planes* p) {
+  return !p || (p->hi && p->lo && (reinterpret_cast<uintptr_t>(p->hi) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p->lo) & 7u) == 0);
+}
+__device__ __forceinline__ void pfpp_store4_planes(const pfpp_planes_out& po, int64_t idx, float4 v) {
+  typedef _Float16 h4_ __attribute__((ext_vector_type(4)));
+  h4_ hi, lo;
+  PFPP_SPLIT_TO(v.x * po.scale, hi[0], lo[0]);
+  PFPP_SPLIT_TO(v.y * po.scale, hi[1], lo[1]);
+  PFPP_SPLIT_TO(v.z * po.scale, hi[2], lo[2]);
+  PFPP_SPLIT_TO(v.w * po.scale, hi[3], lo[3]);
+  *reinterpret_cast<h4_*>(po.hi + idx) = hi;
+  *reinterpret_cast<h4_*>(po.lo + idx) = lo;
+}
+
 // counter-based generator behind the dropout sites (pfpp_dropout / pfpp_geglu): splitmix64 finaliser
 // of (seed, site, element index); forward and backward regenerate the same keep mask.
 __host__ __device__ __forceinline__ uint32_t pfpp_rng_u32(uint64_t seed, uint32_t site, uint64_t idx) {

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ z, float* __restrict__ u, int64_t rows,
                                                     int inner, uint32_t thresh, float inv_keep, uint64_t seed,
-                                                    uint32_t site) {
+                                                    uint32_t site, pfpp_planes_out po) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // index into u [rows, inner]
   if (i4 >= rows * inner) return;
   const int64_t r = i4 / inner;
@@ -116,12 +116,14 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ z,
     o.z = pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? o.z * inv_keep : 0.0f;
     o.w = pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? o.w * inv_keep : 0.0f;
   }
-  *reinterpret_cast<float4*>(u + i4) = o;
+  if (u) *reinterpret_cast<float4*>(u + i4) = o;
+  if (po.hi) pfpp_store4_planes(po, i4, o);
 }
 
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ du,
                                                         float* __restrict__ dz, int64_t rows, int inner,
-                                                        uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
+                                                        uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site,
+                                                        pfpp_planes_out po) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= rows * inner) return;
   const int64_t r = i4 / inner;
@@ -139,8 +141,54 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict_
   dv.x = d.x * gelu_f(g.x); dv.y = d.y * gelu_f(g.y); dv.z = d.z * gelu_f(g.z); dv.w = d.w * gelu_f(g.w);
   dg.x = d.x * v.x * gelu_grad(g.x); dg.y = d.y * v.y * gelu_grad(g.y);
   dg.z = d.z * v.z * gelu_grad(g.z); dg.w = d.w * v.w * gelu_grad(g.w);
-  *reinterpret_cast<float4*>(dz + r * 2 * inner + c) = dv;
-  *reinterpret_cast<float4*>(dz + r * 2 * inner + inner + c) = dg;
+  if (dz) {
+    *reinterpret_cast<float4*>(dz + r * 2 * inner + c) = dv;
+    *reinterpret_cast<float4*>(dz + r * 2 * inner + inner + c) = dg;
+  }
+  if (po.hi) {
+    pfpp_store4_planes(po, r * 2 * inner + c, dv);
+    pfpp_store4_planes(po, r * 2 * inner + inner + c, dg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// split-f16 planes of an fp32 tensor, and column sums of a tensor given as planes
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t n, pfpp_planes_out po) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  pfpp_store4_planes(po, i4, *reinterpret_cast<const float4*>(x + i4));
+}
+
+// block = 64 column lanes (4 columns each) x 4 row phases, like colsum_kernel; out[c] += out_scale * sum_r (hi + lo)[r, c]
+__global__ __launch_bounds__(256) void colsum_planes_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                            float* __restrict__ out, int64_t rows, int cols, int64_t ld,
+                                                            int rows_per_block, float out_scale) {
+  typedef _Float16 h4_ __attribute__((ext_vector_type(4)));
+  __shared__ float4 red[4][64];
+  const int cl = threadIdx.x & 63, rp = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cl) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    for (int64_t r = r0 + rp; r < r1; r += 4) {
+      const h4_ h = *reinterpret_cast<const h4_*>(hi + r * ld + c);
+      const h4_ l = *reinterpret_cast<const h4_*>(lo + r * ld + c);
+      a.x += (float)h[0] + (float)l[0]; a.y += (float)h[1] + (float)l[1];
+      a.z += (float)h[2] + (float)l[2]; a.w += (float)h[3] + (float)l[3];
+    }
+  }
+  red[rp][cl] = a;
+  __syncthreads();
+  if (rp == 0 && c < cols) {
+    const float4 b = red[1][cl], d = red[2][cl], e = red[3][cl];
+    float* o = out + c;
+    unsafeAtomicAdd(o + 0, ((a.x + b.x) + (d.x + e.x)) * out_scale);
+    unsafeAtomicAdd(o + 1, ((a.y + b.y) + (d.y + e.y)) * out_scale);
+    unsafeAtomicAdd(o + 2, ((a.z + b.z) + (d.z + e.z)) * out_scale);
+    unsafeAtomicAdd(o + 3, ((a.w + b.w) + (d.w + e.w)) * out_scale);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -181,7 +229,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mod, int64_t ld_mod,
     const float* __restrict__ gamma, const int32_t* __restrict__ group_batch, int group_rows, int rows_per_batch,
     float* __restrict__ dx, float* __restrict__ dmult, float* __restrict__ dadd, int64_t ld_d, int64_t rows,
-    float eps, float* __restrict__ drop_out, uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
+    float eps, float* __restrict__ drop_out, uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site,
+    int do_drop, pfpp_planes_out po_ret, pfpp_planes_out po_dx) {
+  // po_ret: planes of the value the backward chain continues with (the dropped-out gradient when do_drop, else the updated
+  // dx); po_dx: planes of the updated dx.  drop_out may be null when only the planes of the dropped-out gradient are wanted.
   constexpr int C = 256 * VPL;
   __shared__ float red[2][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,14 +303,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       o.z += rstd * (g[k].z - c1 - v[k].z * c2);
       o.w += rstd * (g[k].w - c1 - v[k].w * c2);
       dxr[lane + 64 * k] = o;
-      if (drop_out) {      // the dropout that follows in the backward chain (same mask as pfpp_dropout over [rows, C])
-        const uint64_t i4 = (uint64_t)row * C + (uint64_t)(lane + 64 * k) * 4;
+      const uint64_t i4 = (uint64_t)row * C + (uint64_t)(lane + 64 * k) * 4;
+      if (po_dx.hi) pfpp_store4_planes(po_dx, (int64_t)i4, o);
+      if (do_drop) {       // the dropout that follows in the backward chain (same mask as pfpp_dropout over [rows, C])
         float4 dd;
         dd.x = pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? o.x * inv_keep : 0.0f;
         dd.y = pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? o.y * inv_keep : 0.0f;
         dd.z = pfpp_rng_u32(seed, site, i4 + 2) >= thresh ? o.z * inv_keep : 0.0f;
         dd.w = pfpp_rng_u32(seed, site, i4 + 3) >= thresh ? o.w * inv_keep : 0.0f;
-        reinterpret_cast<float4*>(drop_out + row * C)[lane + 64 * k] = dd;
+        if (drop_out) reinterpret_cast<float4*>(drop_out + row * C)[lane + 64 * k] = dd;
+        if (po_ret.hi) pfpp_store4_planes(po_ret, (int64_t)i4, dd);
+      } else if (po_ret.hi) {
+        pfpp_store4_planes(po_ret, (int64_t)i4, o);
       }
     }
   }
@@ -289,7 +344,7 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
     const float* __restrict__ y, const float* __restrict__ res, float* __restrict__ h_out, float* __restrict__ n_out,
     const float* __restrict__ mod, int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta,
     int64_t rows, int rows_per_batch, float eps, const int32_t* __restrict__ group_batch, int group_rows,
-    uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site) {
+    uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site, pfpp_planes_out po) {
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -343,7 +398,8 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
       o.z = o.z * g.z + be.z;
       o.w = o.w * g.w + be.w;
     }
-    reinterpret_cast<float4*>(n_out + row * C)[c4] = o;
+    if (n_out) reinterpret_cast<float4*>(n_out + row * C)[c4] = o;
+    if (po.hi) pfpp_store4_planes(po, row * C + (int64_t)c4 * 4, o);
   }
 }
 
@@ -503,25 +559,58 @@ extern "C" int pfpp_dropout_mask(uint8_t* keep, int64_t n, float p, uint64_t see
   return pfpp::check_launch(__func__);
 }
 
-extern "C" int pfpp_geglu(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed,
-                          uint32_t site, pfpp_stream_t stream) {
-  PFPP_REQUIRE(z && u, "null pointer");
+extern "C" int pfpp_geglu_p(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed,
+                            uint32_t site, const pfpp_planes* u_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(z && (u || u_planes), "null pointer");
   PFPP_REQUIRE(inner > 0 && inner % 4 == 0 && p >= 0.0f && p < 1.0f, "inner % 4 != 0 or p outside [0, 1)");
-  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(u), "16-byte alignment");
+  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(u) && pfpp_planes_ok(u_planes), "alignment");
   if (rows == 0) return PFPP_OK;
   hipLaunchKernelGGL(geglu_kernel, dim3(blocks_for(rows * inner, 1024)), dim3(256), 0, pfpp::as_stream(stream), z, u,
-                     rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site);
+                     rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site, pfpp_planes_arg(u_planes));
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_geglu(const float* z, float* u, int64_t rows, int64_t inner, float p, uint64_t seed,
+                          uint32_t site, pfpp_stream_t stream) {
+  PFPP_REQUIRE(u, "null pointer");
+  return pfpp_geglu_p(z, u, rows, inner, p, seed, site, nullptr, stream);
+}
+
+extern "C" int pfpp_geglu_bwd_p(const float* z, const float* du, float* dz, int64_t rows, int64_t inner, float p,
+                                uint64_t seed, uint32_t site, const pfpp_planes* dz_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(z && du && (dz || dz_planes), "null pointer");
+  PFPP_REQUIRE(inner > 0 && inner % 4 == 0 && p >= 0.0f && p < 1.0f, "inner % 4 != 0 or p outside [0, 1)");
+  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(du) && pfpp::aligned16(dz) && pfpp_planes_ok(dz_planes), "alignment");
+  if (rows == 0) return PFPP_OK;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(blocks_for(rows * inner, 1024)), dim3(256), 0, pfpp::as_stream(stream), z,
+                     du, dz, rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site, pfpp_planes_arg(dz_planes));
   return pfpp::check_launch(__func__);
 }
 
 extern "C" int pfpp_geglu_bwd(const float* z, const float* du, float* dz, int64_t rows, int64_t inner, float p,
                               uint64_t seed, uint32_t site, pfpp_stream_t stream) {
-  PFPP_REQUIRE(z && du && dz, "null pointer");
-  PFPP_REQUIRE(inner > 0 && inner % 4 == 0 && p >= 0.0f && p < 1.0f, "inner % 4 != 0 or p outside [0, 1)");
-  PFPP_REQUIRE(pfpp::aligned16(z) && pfpp::aligned16(du) && pfpp::aligned16(dz), "16-byte alignment");
+  PFPP_REQUIRE(dz, "null pointer");
+  return pfpp_geglu_bwd_p(z, du, dz, rows, inner, p, seed, site, nullptr, stream);
+}
+
+extern "C" int pfpp_split_planes(const float* x, int64_t n, const pfpp_planes* planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(x && planes && pfpp_planes_ok(planes) && pfpp::aligned16(x), "null pointer / alignment");
+  PFPP_REQUIRE(n >= 0 && n % 4 == 0, "n % 4 != 0");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, pfpp::as_stream(stream), x, n,
+                     pfpp_planes_arg(planes));
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_colsum_planes(const void* hi, const void* lo, float* out, int64_t rows, int64_t cols, int64_t ld,
+                                  float out_scale, pfpp_stream_t stream) {
+  PFPP_REQUIRE(hi && lo && out, "null pointer");
+  PFPP_REQUIRE(cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols, "cols / ld must be multiples of 4");
   if (rows == 0) return PFPP_OK;
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(blocks_for(rows * inner, 1024)), dim3(256), 0, pfpp::as_stream(stream), z,
-                     du, dz, rows, (int)inner, pfpp_drop_thresh(p), 1.0f / (1.0f - p), seed, site);
+  const int rpb = 128;
+  const dim3 grid(blocks_for(cols, 256), blocks_for(rows, rpb));
+  hipLaunchKernelGGL(colsum_planes_kernel, grid, dim3(256), 0, pfpp::as_stream(stream), (const _Float16*)hi, (const _Float16*)lo,
+                     out, rows, (int)cols, ld, rpb, out_scale);
   return pfpp::check_launch(__func__);
 }
 
@@ -547,8 +636,12 @@ int layernorm_bwd_impl(const float* x, const float* dy, const float* mod, int64_
                        const float* gamma, const int32_t* group_batch, int64_t group_rows,
                        int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
                        int64_t rows, int64_t C, float eps, float* drop_out, float p, uint64_t seed, uint32_t site,
-                       pfpp_stream_t stream) {
+                       pfpp_stream_t stream, int do_drop = -1, const pfpp_planes* ret_planes = nullptr,
+                       const pfpp_planes* dx_planes = nullptr) {
   PFPP_REQUIRE(x && dy && dx, "null pointer");
+  PFPP_REQUIRE(pfpp_planes_ok(ret_planes) && pfpp_planes_ok(dx_planes), "planes: null / misaligned");
+  if (do_drop < 0) do_drop = drop_out != nullptr;
+  const pfpp_planes_out po_ret = pfpp_planes_arg(ret_planes), po_dx = pfpp_planes_arg(dx_planes);
   PFPP_REQUIRE(!(mod && gamma), "mod and gamma are exclusive");
   PFPP_REQUIRE(!dmult == !dadd, "dmult and dadd go together");
   PFPP_SUPPORTED(C == 256 || C == 512, "C not in {256, 512}");
@@ -567,11 +660,11 @@ int layernorm_bwd_impl(const float* x, const float* dy, const float* mod, int64_
   if (C == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
                        (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps, drop_out, thresh, inv_keep,
-                       seed, site);
+                       seed, site, do_drop, po_ret, po_dx);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, st, x, dy, mod, ld_mod, gamma, group_batch,
                        (int)group_rows, (int)rows_per_batch, dx, dmult, dadd, ld_d, rows, eps, drop_out, thresh, inv_keep,
-                       seed, site);
+                       seed, site, do_drop, po_ret, po_dx);
   return pfpp::check_launch("pfpp_layernorm_bwd");
 }
 }  // namespace
@@ -594,12 +687,48 @@ extern "C" int pfpp_layernorm_bwd_dropout(const float* x, const float* dy, const
                             eps, drop_out, p, seed, site, stream);
 }
 
+extern "C" int pfpp_layernorm_bwd_p(const float* x, const float* dy, const float* mod, int64_t ld_mod,
+                                    const float* gamma, const int32_t* group_batch, int64_t group_rows,
+                                    int64_t rows_per_batch, float* dx, float* dmult, float* dadd, int64_t ld_d,
+                                    int64_t rows, int64_t C, float eps, float* drop_out, float p, uint64_t seed,
+                                    uint32_t site, int32_t dropout, const pfpp_planes* ret_planes,
+                                    const pfpp_planes* dx_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(!dropout || drop_out || ret_planes, "dropout without an output for the dropped-out gradient");
+  return layernorm_bwd_impl(x, dy, mod, ld_mod, gamma, group_batch, group_rows, rows_per_batch, dx, dmult, dadd, ld_d, rows, C,
+                            eps, drop_out, dropout ? p : 0.0f, seed, site, stream, dropout ? 1 : 0, ret_planes, dx_planes);
+}
+
+static int dropout_layernorm_impl(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                                  int64_t ld_mod, const float* gamma, const float* beta, const int32_t* group_batch,
+                                  int64_t group_rows, int64_t rows_per_batch, int64_t rows, int64_t C, float eps, float p,
+                                  uint64_t seed, uint32_t site, const pfpp_planes* n_planes, pfpp_stream_t stream);
+
 extern "C" int pfpp_dropout_layernorm(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
                                       int64_t ld_mod, const float* gamma, const float* beta,
                                       const int32_t* group_batch, int64_t group_rows, int64_t rows_per_batch,
                                       int64_t rows, int64_t C, float eps, float p, uint64_t seed, uint32_t site,
                                       pfpp_stream_t stream) {
-  PFPP_REQUIRE(y && h_out && n_out, "null pointer");
+  PFPP_REQUIRE(n_out, "null pointer");
+  return dropout_layernorm_impl(y, res, h_out, n_out, mod, ld_mod, gamma, beta, group_batch, group_rows, rows_per_batch, rows, C,
+                                eps, p, seed, site, nullptr, stream);
+}
+
+extern "C" int pfpp_dropout_layernorm_p(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                                        int64_t ld_mod, const float* gamma, const float* beta,
+                                        const int32_t* group_batch, int64_t group_rows, int64_t rows_per_batch,
+                                        int64_t rows, int64_t C, float eps, float p, uint64_t seed, uint32_t site,
+                                        const pfpp_planes* n_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(n_out || n_planes, "null pointer");
+  return dropout_layernorm_impl(y, res, h_out, n_out, mod, ld_mod, gamma, beta, group_batch, group_rows, rows_per_batch, rows, C,
+                                eps, p, seed, site, n_planes, stream);
+}
+
+static int dropout_layernorm_impl(const float* y, const float* res, float* h_out, float* n_out, const float* mod,
+                                  int64_t ld_mod, const float* gamma, const float* beta, const int32_t* group_batch,
+                                  int64_t group_rows, int64_t rows_per_batch, int64_t rows, int64_t C, float eps, float p,
+                                  uint64_t seed, uint32_t site, const pfpp_planes* n_planes, pfpp_stream_t stream) {
+  PFPP_REQUIRE(y && h_out && pfpp_planes_ok(n_planes), "null pointer");
+  const pfpp_planes_out po = pfpp_planes_arg(n_planes);
   PFPP_REQUIRE(!(mod && gamma) && (!gamma == !beta), "mod and gamma/beta are exclusive; gamma and beta go together");
   PFPP_SUPPORTED(C == 256 || C == 512, "C not in {256, 512}");
   PFPP_REQUIRE(group_rows >= 1 && rows_per_batch >= 1, "bad group sizes");
@@ -613,11 +742,11 @@ extern "C" int pfpp_dropout_layernorm(const float* y, const float* res, float* h
   const float inv_keep = 1.0f / (1.0f - p);
   if (C == 256)
     hipLaunchKernelGGL(dropout_layernorm_kernel<1>, grid, dim3(256), 0, st, y, res, h_out, n_out, mod, ld_mod, gamma, beta, rows,
-                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site);
+                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site, po);
   else
     hipLaunchKernelGGL(dropout_layernorm_kernel<2>, grid, dim3(256), 0, st, y, res, h_out, n_out, mod, ld_mod, gamma, beta, rows,
-                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site);
-  return pfpp::check_launch(__func__);
+                       (int)rows_per_batch, eps, group_batch, (int)group_rows, thresh, inv_keep, seed, site, po);
+  return pfpp::check_launch("pfpp_dropout_layernorm");
 }
 
 extern "C" int pfpp_mean_pool_bwd(const float* dpooled, float* dx, int64_t n, int64_t L, int64_t C,

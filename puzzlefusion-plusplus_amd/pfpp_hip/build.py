@@ -28,7 +28,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_ring.hip": [],
     "gemm_ws.hip": [],
-    "gemm_pl.hip": (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
+    "gemm_pl.hip": ["-munsafe-fp-atomics"] + (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
     "sa_fused.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],

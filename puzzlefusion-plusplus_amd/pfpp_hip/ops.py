@@ -168,11 +168,10 @@ class SplitAct:
 
 def split_mode() -> bool:
     """the activations our own kernels produce for the next GEMM (normalised rows, attention outputs, GEGLU products) as
-    pre-split fp16 planes — same bytes as fp32; the consuming GEMM stages them like a pre-split weight
-    (gemm_f16x3_apre_kernel: no conversion instructions in its K loop).  Bit-identical results, tested — and measured
-    no faster (compact sampler step 4.06 ms either way, all-slots 8.39 vs 8.28 ms): the conversions were not what the K
-    loop waits for.  Opt-in: PFPP_SPLIT_ACT=1."""
-    return GEMM_MODE == "f16x3" and _os.environ.get("PFPP_SPLIT_ACT", "0") == "1"
+    pre-split fp16 planes — same bytes as fp32.  The consuming GEMM is then the LDS-DMA staged plane kernel
+    (csrc/gemm_pl.hip: no staging registers, no conversions, no ds_write in its K loop), bit-identical to the
+    register-staged kernel and 1.3-1.6x faster on the 3,850-row shapes.  PFPP_SPLIT_ACT=0 restores fp32 activations."""
+    return GEMM_MODE == "f16x3" and _os.environ.get("PFPP_SPLIT_ACT", "1") == "1"
 
 
 # When set to a list, every pfpp_gemm launch appends (start_event, end_event, flops, kernel_name):
