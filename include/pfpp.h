@@ -231,8 +231,8 @@ int pfpp_attn_blockdiag_bwd_p(const float* qkv, const float* dout, float* dqkv, 
  *   dX = dY . W   (autograd of the same layers in Denoiser.training_step, denoiser.py:128-145):
  *                             A = dY [M,K=out] row-major, W [K=out, N=in] k-major (w_kmajor = 1: the weight as stored)
  *   dW = dY^T . X                                             A = dY [K=rows, M=out] k-major, W = X [K=rows, N=in] k-major
- * k-major operands are read in place (no transposed copies); their contraction extent must be padded to a multiple of
- * 32 rows of valid, zero-filled memory.  C [M, ldc] fp32 = act(alpha * A.W + bias) + residual, or with accumulate:
+ * k-major operands are read in place (no transposed copies).  K % 32 == 0, except for dW (both operands k-major),
+ * where the contraction may have any length (rows beyond K are never read).  C [M, ldc] fp32 = act(alpha * A.W + bias) + residual, or with accumulate:
  * C += alpha * A.W (+ bias + residual once).  A K split (splits > 1) goes through the workspace `ws` when one is lent
  * (dense per-chunk slabs + a reduction launch, deterministic) and through fp32 atomics otherwise (accumulate only).
  * splits = 0 / variant = 0: chosen by the library.  Results of the non-accumulating form are bit-identical to
@@ -243,7 +243,7 @@ typedef struct pfpp_gemm_planes_args {
   float* C;
   const float* bias;                    /* [N] or NULL */
   const float* residual;                /* [M, ldr] or NULL */
-  int64_t M, N, K;                      /* output rows / columns, contraction length (K % 32 == 0) */
+  int64_t M, N, K;                      /* output rows / columns, contraction length */
   int64_t lda, ldw, ldc, ldr;           /* plane leading dimensions in halfs, C / residual in floats */
   int32_t a_kmajor, w_kmajor;
   int32_t act;                          /* PFPP_ACT_NONE / RELU / SILU / GELU */
@@ -255,6 +255,9 @@ typedef struct pfpp_gemm_planes_args {
 } pfpp_gemm_planes_args;
 
 int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);
+/* name of the kernel instantiation the calling thread's last pfpp_gemm / pfpp_gemm_planes call launched through the plane
+ * path ("" when that call took another kernel): lets a profiler-side tool attribute event timings to kernel names */
+const char* pfpp_last_gemm_kernel(void);
 
 /* ---- a4 + a5 + a6 fused, for a set-abstraction level without input features ---------------------------
  * PointNetSetAbstraction.forward with points = None (utils/pn2_utils.py:197-217; sa1 of PN2,

@@ -839,7 +839,10 @@ int launch_f16x3_apre(const GemmP& p, int batch, hipStream_t st) {
 
 }  // namespace
 
+namespace pfpp_gemm_detail { namespace pl { extern thread_local char last_kernel[96]; } }
+
 extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
+  pfpp_gemm_detail::pl::last_kernel[0] = 0;
   PFPP_REQUIRE(a && (a->A || (a->a_hi && a->a_lo) || (a->gather_idx && a->lda == 0)) && (a->C || (a->c_hi && a->c_lo)), "null pointer");
   PFPP_REQUIRE(a->W || (a->w_hi && a->w_lo), "W (or its pre-split planes) missing");
   PFPP_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "bad sizes");
@@ -915,6 +918,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.tiles_n = 0;
   p.dbg = 0;
   p.accum = 0;
+  p.k_valid = (int)a->K;
   hipStream_t st = pfpp::as_stream(stream);
 
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)

@@ -45,8 +45,13 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 namespace pl {
 
+// source of the DMA lanes whose contraction row lies beyond the operand's last valid row (k-major operands with a ragged
+// contraction length, e.g. 3,850 tokens): they read zeros from here instead of whatever follows the tensor
+__device__ __attribute__((aligned(64))) char pl_zero_row[64] = {0};
+
 constexpr int BK = 32;
 thread_local int64_t p_ws_bytes = 0;     // capacity of the caller's K-split workspace for the launch being dispatched
+thread_local char last_kernel[96] = "";  // template instantiation of the most recent plane-GEMM launch of this thread (pfpp_last_gemm_kernel)
 
 __device__ __forceinline__ void glds16(const char* gsrc, uint32_t ldst) {
   __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)(uintptr_t)ldst, 16, 0, 0);
@@ -242,6 +247,8 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   uint32_t dst[NPW];
   const int64_t adv_a = AK ? (int64_t)32 * p.lda * 2 : 64, adv_w = WK ? (int64_t)32 * p.ldw * 2 : 64;
   bool piece_a[NPW];
+  int piece_krow[NPW];                 // k-major pieces: this lane's contraction row within the K-tile
+  const int k_tail = p.k_valid - (nk_all - 1) * BK;      // valid rows of the last K-tile (BK when the contraction is not ragged)
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
     const int q = wave + C::NW * j;
@@ -254,8 +261,10 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     const int ci = ((lo ? o2 - psz : o2) >> 4) + lane;           // 16-byte chunk index within the plane
     const _Float16* base = reinterpret_cast<const _Float16*>(is_a ? (lo ? p.Alo : p.Ahi) : (lo ? p.Wlo : p.Whi));
     int64_t eoff;
+    piece_krow[j] = 0;
     auto kmajor_off = [&](int cpr, int g0, int lim, int64_t ld) {
       const int krow = ci / cpr, slot = ci % cpr;
+      piece_krow[j] = krow;
       const int rot = cpr >= 16 ? (krow & 3) : ((krow >> 1) & 1);
       const int nc = (slot - 4 * rot + cpr) % cpr;
       const int col = min(g0 + 8 * nc, lim - 8);
@@ -271,9 +280,16 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     src[j] = reinterpret_cast<const char*>(base + eoff) + (int64_t)kt0 * (is_a ? adv_a : adv_w);
     dst[j] = lds0 + o;
   }
+  auto piece_src = [&](int kt, int j) {
+    const char* s_ = src[j] + (int64_t)kt * (piece_a[j] ? adv_a : adv_w);
+    if constexpr (AK || WK) {
+      if (k_tail < BK && kt0 + kt == nk_all - 1 && (piece_a[j] ? AK : WK) && piece_krow[j] >= k_tail) s_ = pl_zero_row;
+    }
+    return s_;
+  };
   auto issue = [&](int kt, uint32_t st_off) {
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) glds16(src[j] + (int64_t)kt * (piece_a[j] ? adv_a : adv_w), dst[j] + st_off);
+    for (int j = 0; j < NPW; ++j) glds16(piece_src(kt, j), dst[j] + st_off);
   };
 
   f32x16 acc[MT][NT];
@@ -420,7 +436,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   constexpr int G0 = RA + RB;           // fillers of a half-step: its fragment reads first, DMA pieces behind them
   auto issue1 = [&](int kt, uint32_t st_off, auto j_c) {
     constexpr int j = decltype(j_c)::value;
-    glds16(src[j] + (int64_t)kt * (piece_a[j] ? adv_a : adv_w), dst[j] + st_off);
+    glds16(piece_src(kt, j), dst[j] + st_off);
   };
 
   // ---- prologue: fill the ring, wait for tile 0, first fragments ---------------------------------------------------------
@@ -622,6 +638,8 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
   p.k_chunk = 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
+           WK ? "true" : "false", DBG, slabs ? "+pl_reduce_kernel" : "");
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, p);
   if (slabs) {
     const int64_t n4 = (int64_t)p.M * (p.N >> 2);
@@ -664,9 +682,12 @@ int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, 
 
 using namespace pfpp_gemm_detail;
 
+extern "C" const char* pfpp_last_gemm_kernel(void) { return pl::last_kernel; }
+
 extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a && a->a_hi && a->a_lo && a->w_hi && a->w_lo && a->C, "null pointer");
-  PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 32 == 0, "sizes: M, N > 0, K a positive multiple of 32");
+  PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sizes must be positive");
+  PFPP_REQUIRE(a->K % 32 == 0 || (a->a_kmajor && a->w_kmajor), "K % 32 != 0 is only possible with both operands k-major");
   PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
   PFPP_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && pfpp::aligned16(a->a_hi) && pfpp::aligned16(a->a_lo) &&
                pfpp::aligned16(a->w_hi) && pfpp::aligned16(a->w_lo), "planes: 16-byte aligned, leading dimensions % 8 == 0");
@@ -681,7 +702,8 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   memset(&p, 0, sizeof(p));
   p.C = a->C; p.Ahi = a->a_hi; p.Alo = a->a_lo; p.Whi = a->w_hi; p.Wlo = a->w_lo;
   p.bias = a->bias; p.residual = a->residual;
-  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)((a->K + 31) / 32 * 32);
+  p.k_valid = (int)a->K;
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.act = a->act; p.zdiv = 1; p.alpha = a->alpha; p.accum = a->accumulate ? 1 : 0;
   p.split_ws = a->ws;
@@ -689,24 +711,42 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   hipStream_t st = pfpp::as_stream(stream);
   int variant = a->variant, splits = a->splits;
   const int nk = p.K / 32;
-  if (variant == 0) {
-    // tile: the largest one that still yields about one workgroup per CU together with the K split
-    const int64_t t21 = ((int64_t)(p.M + 255) / 256) * ((p.N + 127) / 128);
-    const int64_t t11 = ((int64_t)(p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (a->accumulate || a->ws) variant = (t21 * (nk / 8 > 0 ? nk / 8 : 1) >= 128) ? 2 : (t11 >= 200 ? 3 : (t21 * (nk / 8 > 0 ? nk / 8 : 1) >= 64 ? 3 : 6));
-    else variant = t21 >= 160 ? 2 : (t11 >= 200 ? 3 : 6);
-  }
-  if (splits == 0) {
-    splits = 1;
-    if (a->accumulate || a->ws) {
-      const int bm = variant == 2 ? 256 : 128, bn = variant == 6 ? 64 : 128;
-      const int64_t tiles = ((int64_t)(p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-      const int64_t slots = variant == 2 ? 256 : 512;
-      splits = (int)((slots + tiles - 1) / tiles);
-      const int max_by_k = nk / 4 > 0 ? nk / 4 : 1;           // at least 4 K-tiles per chunk
-      if (splits > max_by_k) splits = max_by_k;
-      if (splits < 1) splits = 1;
+  if (variant == 0 || splits == 0) {
+    // Tile and K split from a small cost model fitted to tools/gemm_lab measurements on 3,850-row shapes: a workgroup's main
+    // loop is bound by operand delivery (~45 GB/s of L2 -> LDS DMA per CU, shared by co-resident workgroups) or by its MFMAs
+    // (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
+    // slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.
+    const int cand_v[3] = {2, 3, 6};
+    const int cand_s[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+    double best = 1e30;
+    int best_v = 3, best_s = 1;
+    for (int vi = 0; vi < 3; ++vi) {
+      const int v = cand_v[vi];
+      if (a->variant != 0 && v != a->variant) continue;
+      const int bm = v == 2 ? 256 : 128, bn = v == 6 ? 64 : 128;
+      const double tiles = (double)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+      for (int si = 0; si < 9; ++si) {
+        const int sp = cand_s[si];
+        if (a->splits != 0 && sp != a->splits) continue;
+        if (sp > 1 && (sp > nk / 2 || !(a->ws || a->accumulate))) continue;
+        const bool slabs = sp > 1 && a->ws && (double)sp * p.M * p.N * 4.0 <= (double)a->ws_bytes;
+        if (sp > 1 && !slabs && !a->accumulate) continue;
+        const double wgs = tiles * sp;
+        const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;                  // co-resident workgroups share the CU's bandwidth
+        const double kc = (double)p.K / sp;
+        const double t_bw = rounds * kc * (bm + bn) * 4.0 / 45e9;
+        const double t_mma = rounds * (bm / 32.0) * (bn / 32.0) * (kc / 16.0) * 3.0 * 32.0 / 4.0 / 2.1e9 / 0.75;
+        const double cbytes = (double)p.M * p.N * 4.0;
+        double t_epi;
+        if (slabs) t_epi = (2.0 * sp * cbytes + (a->accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 2e-6;
+        else if (a->accumulate) t_epi = sp * cbytes / 1.2e12;
+        else t_epi = cbytes / 3.5e12;
+        const double t = (t_bw > t_mma ? t_bw : t_mma) + t_epi + 4e-6;
+        if (t < best) { best = t; best_v = v; best_s = sp; }
+      }
     }
+    if (variant == 0) variant = best_v;
+    if (splits == 0) splits = best_s;
   }
   const int gm = 8;
   if (a->a_kmajor) return launch_variant<true, true>(p, 1, st, gm, variant, splits);

@@ -55,6 +55,28 @@ class GemmGradArgs(C.Structure):
 _u64 = C.c_uint64
 _u32 = C.c_uint32
 
+
+class PlanesC(C.Structure):
+    """mirror of struct pfpp_planes (include/pfpp.h)"""
+
+    _fields_ = [("hi", _p), ("lo", _p), ("scale", _f32)]
+
+
+class GemmPlanesArgs(C.Structure):
+    """mirror of struct pfpp_gemm_planes_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("a_hi", _p), ("a_lo", _p), ("w_hi", _p), ("w_lo", _p), ("C", _p), ("bias", _p), ("residual", _p),
+        ("M", _i64), ("N", _i64), ("K", _i64),
+        ("lda", _i64), ("ldw", _i64), ("ldc", _i64), ("ldr", _i64),
+        ("a_kmajor", _i32), ("w_kmajor", _i32), ("act", _i32), ("accumulate", _i32), ("splits", _i32), ("variant", _i32),
+        ("alpha", _f32),
+        ("ws", _p), ("ws_bytes", _i64),
+    ]
+
+
+_pl = C.POINTER(PlanesC)
+
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
     "pfpp_se3_rotate_gather": [_p, _p, _p, _p, _i64, _i64, _p],
@@ -119,10 +141,23 @@ SIGNATURES = {
     "pfpp_bn_minmax_apply": [_p, _p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_bn_apply": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i64, _i64, _p],
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
+    # ---- plane GEMM and plane-producing forms of the training kernels
+    "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
+    "pfpp_split_planes": [_p, _i64, _pl, _p],
+    "pfpp_colsum_planes": [_p, _p, _p, _i64, _i64, _i64, _f32, _p],
+    "pfpp_geglu_p": [_p, _p, _i64, _i64, _f32, _u64, _u32, _pl, _p],
+    "pfpp_geglu_bwd_p": [_p, _p, _p, _i64, _i64, _f32, _u64, _u32, _pl, _p],
+    "pfpp_dropout_layernorm_p": [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _u32, _pl, _p],
+    "pfpp_layernorm_bwd_p": [_p, _p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _f32, _p, _f32, _u64, _u32, _i32,
+                             _pl, _pl, _p],
+    "pfpp_attn_dense_train_p": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _pl, _p],
+    "pfpp_attn_dense_bwd_p": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f32, _pl, _p],
+    "pfpp_attn_blockdiag_bwd_p": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _pl, _p],
 }
 PLAIN = {
     "pfpp_version": ([], C.c_int),
     "pfpp_last_error": ([], C.c_char_p),
+    "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),

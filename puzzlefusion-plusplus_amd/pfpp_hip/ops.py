@@ -347,9 +347,10 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
         e0.record()
         check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")
         e1.record()
+        pl_name = _lib.load().pfpp_last_gemm_kernel().decode()        # set when the call went to the plane kernel (gemm_pl.hip)
         GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch,
-                           gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, K, planes is not None, a_planes is not None,
-                                            a_affine is not None or stats is not None or c_min is not None, a_affine is not None),
+                           pl_name or gemm_kernel_name(M, N, act, pool, batch, w_kmajor, f16x3, K, planes is not None, a_planes is not None,
+                                                       a_affine is not None or stats is not None or c_min is not None, a_affine is not None),
                            (M, N, K, batch, act, pool)))
         return out
     check(_lib.load().pfpp_gemm(C.byref(args), _stream()), "pfpp_gemm")

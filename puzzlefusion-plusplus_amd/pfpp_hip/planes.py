@@ -1,0 +1,125 @@
+"""Split-f16 planes as first-class operands: the tensors the plane GEMM (csrc/gemm_pl.hip, pfpp_gemm_planes) consumes
+and the training kernels that produce them directly (include/pfpp.h, "plane-producing forms").
+
+A `Planes` is (hi, lo) fp16 tensors with hi + lo == scale * x to 22 bits; `scale` is a power of two (1 for forward
+activations and weights, the gradient scale for dY).  Same bytes as the fp32 tensor it stands for.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT, GemmPlanesArgs, PlanesC, check
+from .ops import _chk, _ptr, _stream
+
+_f32 = torch.float32
+_f16 = torch.float16
+
+
+class Planes:
+    __slots__ = ("hi", "lo", "scale")
+
+    def __init__(self, hi: torch.Tensor, lo: torch.Tensor, scale: float = 1.0):
+        if hi.dtype != _f16 or lo.dtype != _f16 or hi.shape != lo.shape or not (hi.is_contiguous() and lo.is_contiguous()):
+            raise ValueError("Planes: hi / lo must be contiguous fp16 tensors of one shape")
+        if hi.device.type != "cuda":
+            raise ValueError("Planes: tensors must live on the GPU (there is no CPU path)")
+        self.hi, self.lo, self.scale = hi, lo, float(scale)
+
+    @staticmethod
+    def empty(rows: int, cols: int, device, scale: float = 1.0) -> "Planes":
+        return Planes(torch.empty((rows, cols), dtype=_f16, device=device), torch.empty((rows, cols), dtype=_f16, device=device), scale)
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def float(self) -> torch.Tensor:
+        """the represented tensor (hi + lo) / scale"""
+        return (self.hi.float() + self.lo.float()) / self.scale
+
+    def record_stream(self, s) -> None:
+        self.hi.record_stream(s)
+        self.lo.record_stream(s)
+
+    def c(self) -> PlanesC:
+        return PlanesC(self.hi.data_ptr(), self.lo.data_ptr(), self.scale)
+
+
+def _pl(p: Optional[Planes]):
+    return None if p is None else C.byref(p.c())
+
+
+def split(x: torch.Tensor, scale: float = 1.0, out: Optional[Planes] = None) -> Planes:
+    """planes of scale * x (pfpp_split_planes)"""
+    _chk(x, _f32, "x")
+    if out is None:
+        out = Planes(torch.empty(x.shape, dtype=_f16, device=x.device), torch.empty(x.shape, dtype=_f16, device=x.device), scale)
+    out.scale = float(scale)
+    check(_lib.load().pfpp_split_planes(_ptr(x), x.numel(), _pl(out), _stream()), "pfpp_split_planes")
+    return out
+
+
+def colsum(p: Planes, out: torch.Tensor) -> torch.Tensor:
+    """out[c] += sum over rows of the tensor `p` stands for (bias gradient of a dY given as planes)"""
+    _chk(out, _f32, "out")
+    rows, cols = p.shape
+    check(_lib.load().pfpp_colsum_planes(_ptr(p.hi), _ptr(p.lo), _ptr(out), rows, cols, cols, 1.0 / p.scale, _stream()),
+          "pfpp_colsum_planes")
+    return out
+
+
+_WS = {}
+
+
+def _workspace(device):
+    """K-split workspace per (device, stream): launches on one stream are ordered, different streams must not share it"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty((24 * 1024 * 1024,), dtype=_f32, device=device)       # 96 MB
+        _WS[key] = ws
+    return ws
+
+
+def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_kmajor: bool = False, w_kmajor: bool = False,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
+         accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True) -> torch.Tensor:
+    """pfpp_gemm_planes: out [M, N] = act(alpha * A.W + bias) + residual, or += with accumulate.
+       forward  : A [M, K],              W [N, K]
+       dX       : A = dY [M, K],         W [K, N] (w_kmajor)
+       dW       : A = dY [K, M] (a_kmajor), W = X [K, N] (w_kmajor)
+    alpha defaults to 1 / (A.scale * W.scale)."""
+    _chk(out, _f32, "out")
+    a = GemmPlanesArgs()
+    a.a_hi, a.a_lo, a.w_hi, a.w_lo = A.hi.data_ptr(), A.lo.data_ptr(), W.hi.data_ptr(), W.lo.data_ptr()
+    a.C = out.data_ptr()
+    a.bias = 0 if bias is None else bias.data_ptr()
+    a.residual = 0 if residual is None else residual.data_ptr()
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldw = A.hi.shape[-1], W.hi.shape[-1]
+    a.ldc = out.shape[-1]
+    a.ldr = 0 if residual is None else residual.shape[-1]
+    a.a_kmajor, a.w_kmajor = int(a_kmajor), int(w_kmajor)
+    a.act = ACT[act]
+    a.accumulate = int(accumulate)
+    a.splits, a.variant = splits, variant
+    a.alpha = (1.0 / (A.scale * W.scale)) if alpha is None else alpha
+    if use_ws:
+        ws = _workspace(out.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    from . import ops
+
+    if ops.GEMM_TRACE is not None:        # bench.py: HIP events around the launch on its stream, attributed to the kernel name
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_gemm_planes(C.byref(a), _stream()), "pfpp_gemm_planes")
+        e1.record()
+        ops.GEMM_TRACE.append((e0, e1, 2.0 * M * N * K, _lib.load().pfpp_last_gemm_kernel().decode(),
+                               (M, N, K, 1, "tn" if a_kmajor else ("nn" if w_kmajor else "nt"), 0)))
+        return out
+    check(_lib.load().pfpp_gemm_planes(C.byref(a), _stream()), "pfpp_gemm_planes")
+    return out

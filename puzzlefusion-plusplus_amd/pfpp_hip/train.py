@@ -248,6 +248,10 @@ class DenoiserTrainEngine:
         # every dropout site is followed by a LayerNorm (forward) / follows a LayerNorm backward: one launch for both
         self._fuse_drop = os.environ.get("PFPP_TRAIN_FUSE_DROP", "1") != "0"
         self._fuse_colsum = os.environ.get("PFPP_TRAIN_FUSE_COLSUM", "1") != "0"   # bias gradients from the weight-gradient GEMM's dY tiles
+        # plane path (default): every transformer-block GEMM of the step — forward, dX = dY.W and dW = dY^T.X — runs on the
+        # LDS-DMA staged plane kernel (csrc/gemm_pl.hip); the LayerNorm / attention / GEGLU kernels hand their results over
+        # as split-f16 planes, gradients lifted by grad_scale.  PFPP_TRAIN_PLANES=0 restores the register-staged kernels.
+        self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
@@ -302,6 +306,32 @@ class DenoiserTrainEngine:
                       max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
                       p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse))
         layers = []
+        if self._planes:
+            h = self._forward_layers_planes(h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale)
+        else:
+            h = self._forward_layers(h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale, M, C)
+        s["layers"] = layers
+        s["dx_pool"] = None if self._planes else self._zeroed_dx_pool(M, C, w)
+        pooled = ops.mean_pool(h, Fv, L)
+        s["pooled"] = pooled
+        out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
+        heads = {}
+        for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
+            a0 = ops.linear(pooled, w[f"{name}.0.w"], w[f"{name}.0.b"])
+            v0 = T.act(a0, "silu")
+            a1 = ops.linear(v0, w[f"{name}.2.w"], w[f"{name}.2.b"])
+            v1 = T.act(a1, "silu")
+            ops.gemm(v1, w[f"{name}.4.w"], M=Fv, N=width, K=v1.shape[1], lda=v1.shape[1], out=out_c, ldc=7,
+                     bias=w[f"{name}.4.b"], c_off=c0)
+            heads[name] = (a0, v0, a1, v1)
+        s["heads"] = heads
+        out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
+        ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
+        return out.view(B, P, 7), ctx
+
+    def _forward_layers(self, h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale, M, C):
+        """transformer blocks on the register-staged GEMMs (fp32 activations between kernels)"""
+        frag_b, seq_off, seq_len, max_len = s["frag_b"], s["seq_off"], s["seq_len"], s["max_len"]
         for i in range(self.num_layers):
             lay: Dict[str, torch.Tensor] = {}
             if i == 0 and fuse and p_tok > 0.0:
@@ -332,24 +362,74 @@ class DenoiserTrainEngine:
             inner = lay["u"].shape[1]
             h = ops.gemm(lay["u"], w[f"{i}.ff2.w"], M=M, N=C, K=inner, lda=inner, ldc=C, bias=w[f"{i}.ff2.b"], residual=h, ldr=C)
             layers.append(lay)
-        s["layers"] = layers
-        s["dx_pool"] = self._zeroed_dx_pool(M, C, w)
-        pooled = ops.mean_pool(h, Fv, L)
-        s["pooled"] = pooled
-        out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
-        heads = {}
-        for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
-            a0 = ops.linear(pooled, w[f"{name}.0.w"], w[f"{name}.0.b"])
-            v0 = T.act(a0, "silu")
-            a1 = ops.linear(v0, w[f"{name}.2.w"], w[f"{name}.2.b"])
-            v1 = T.act(a1, "silu")
-            ops.gemm(v1, w[f"{name}.4.w"], M=Fv, N=width, K=v1.shape[1], lda=v1.shape[1], out=out_c, ldc=7,
-                     bias=w[f"{name}.4.b"], c_off=c0)
-            heads[name] = (a0, v0, a1, v1)
-        s["heads"] = heads
-        out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
-        ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
-        return out.view(B, P, 7), ctx
+        return h
+
+    def _forward_layers_planes(self, h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale):
+        """transformer blocks on the plane GEMM: every GEMM operand our own kernels produce (normalised rows, attention
+        outputs, GEGLU products) is written as split-f16 planes by its producer and kept for the backward's dW = dY^T.X"""
+        from . import planes as P
+
+        frag_b, seq_off, seq_len, max_len = s["frag_b"], s["seq_off"], s["seq_len"], s["max_len"]
+        M, C = h.shape
+        dev = h.device
+
+        def wp(key):
+            pw = w[key]
+            return P.Planes(pw.hi, pw.lo)
+
+        def lin(a, key, N, K, bias=None, residual=None):
+            out = torch.empty((M, N), dtype=torch.float32, device=dev)
+            return P.gemm(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual)
+
+        def ln_planes(x, i_mod=None, gamma=None, beta=None):
+            n = ops.SplitAct.empty(M, C, dev)
+            if i_mod is not None:
+                ops.layernorm_grouped(x, mods[i_mod], frag_b, L, out=n)
+            else:
+                ops.layernorm(x, gamma=gamma, beta=beta, out=n)
+            return P.Planes(n.hi, n.lo)
+
+        for i in range(self.num_layers):
+            lay: Dict[str, object] = {}
+            if i == 0 and fuse and p_tok > 0.0:
+                h, lay["n1"] = T.dropout_layernorm_planes(h, None, p_tok, seed, 0, mod=mods[0], group_batch=frag_b, group_rows=L)
+            else:
+                lay["n1"] = ln_planes(h, i_mod=2 * i)
+            lay["h0"] = h
+            lay["qkv1"] = lin(lay["n1"], f"{i}.self_attn.qkv.w", 3 * C, C)
+            a1 = ops.SplitAct.empty(M, C, dev)
+            ops.attn_blockdiag(lay["qkv1"], Fv, L, H, dh, att_scale, out=a1)
+            lay["att1"] = P.Planes(a1.hi, a1.lo)
+            if fuse and p_lay > 0.0:
+                y = lin(lay["att1"], f"{i}.self_attn.o.w", C, C, bias=w[f"{i}.self_attn.o.b"])
+                h, lay["n2"] = T.dropout_layernorm_planes(y, h, p_lay, seed, 1 + 3 * i, mod=mods[2 * i + 1], group_batch=frag_b, group_rows=L)
+            else:
+                if p_lay > 0.0:
+                    y = lin(lay["att1"], f"{i}.self_attn.o.w", C, C, bias=w[f"{i}.self_attn.o.b"])
+                    h = T.dropout(y, p_lay, seed, 1 + 3 * i, res=h, out=y)
+                else:
+                    h = lin(lay["att1"], f"{i}.self_attn.o.w", C, C, bias=w[f"{i}.self_attn.o.b"], residual=h)
+                lay["n2"] = ln_planes(h, i_mod=2 * i + 1)
+            lay["h1"] = h
+            lay["qkv2"] = lin(lay["n2"], f"{i}.global_attn.qkv.w", 3 * C, C)
+            lay["att2"], lay["att2p"], lay["lse"] = T.attn_dense_train_planes(lay["qkv2"], seq_off, seq_len, max_len, H, dh, att_scale)
+            if fuse and p_lay > 0.0:
+                y = lin(lay["att2p"], f"{i}.global_attn.o.w", C, C, bias=w[f"{i}.global_attn.o.b"])
+                h, lay["n3"] = T.dropout_layernorm_planes(y, h, p_lay, seed, 2 + 3 * i, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
+            else:
+                if p_lay > 0.0:
+                    y = lin(lay["att2p"], f"{i}.global_attn.o.w", C, C, bias=w[f"{i}.global_attn.o.b"])
+                    h = T.dropout(y, p_lay, seed, 2 + 3 * i, res=h, out=y)
+                else:
+                    h = lin(lay["att2p"], f"{i}.global_attn.o.w", C, C, bias=w[f"{i}.global_attn.o.b"], residual=h)
+                lay["n3"] = ln_planes(h, gamma=w[f"{i}.norm3.g"], beta=w[f"{i}.norm3.b"])
+            lay["h2"] = h
+            inner2 = w[f"{i}.ff1.w"].f32.shape[0]
+            lay["z"] = lin(lay["n3"], f"{i}.ff1.w", inner2, C, bias=w[f"{i}.ff1.b"])
+            lay["u"] = T.geglu_planes(lay["z"], p_lay, seed, 3 + 3 * i)
+            h = lin(lay["u"], f"{i}.ff2.w", C, inner2 // 2, bias=w[f"{i}.ff2.b"], residual=h)
+            layers.append(lay)
+        return h
 
     def _zeroed_dx_pool(self, M, C, w):
         """the split input-gradient GEMMs of the backward (3 per layer at token counts below ~8,000) add into zeroed outputs:
@@ -423,6 +503,49 @@ class DenoiserTrainEngine:
         self._flush_dw()                                                                  # the heads' four small weight gradients
 
         dmods = torch.zeros_like(s["mods"])
+        if self._planes:
+            dtok = self._backward_layers_planes(s, w, g, dh_, dmods)
+        else:
+            dtok = self._backward_layers(s, w, g, dh_, dmods)
+
+        # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
+        if p_tok > 0.0 and not fuse:
+            dtok = T.dropout(dh_, p_tok, seed, 0)
+        ld_sf = s["sf"].shape[1]
+        dws = torch.zeros((C, ld_sf), dtype=torch.float32, device=dev)
+        T.grad_weight(dtok, s["sf"], dws, g_scale=G)
+        g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
+        T.colsum(dtok, g["shape.b"])
+        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L)
+        ld_pf = s["pf"].shape[1]
+        dwp = torch.zeros((C, ld_pf), dtype=torch.float32, device=dev)
+        T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
+        g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
+        T.colsum(dx_emb, g["param.b"])
+
+        # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
+        n_ada = 2 * self.num_layers
+        se = s["se"]
+        T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
+        T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                    accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+        dse = torch.empty_like(se)
+        T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
+                    sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
+        if self._sparse_tables and self._exchange.active():
+            dse_all, t_all = self._exchange.gather_rows(dse, s["t64"], dim=1)       # [n_ada, world*B, C], [world*B]
+            T.silu_embed_bwd(w["ada.tables"], t_all, dse_all, g["ada.tables"])
+        else:
+            T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
+        self._all_done()
+
+    def _backward_layers(self, s, w, g, dh_, dmods):
+        """transformer blocks, register-staged backward GEMMs (csrc/gemm_grad.hip) -> d/d(tokens)"""
+        G = self.grad_scale
+        L, C, Fv = s["L"], s["C"], s["Fv"]
+        H = self.num_heads
+        dh = C // H
+        seed, p_lay, p_tok, fuse = s["seed"], s["p_lay"], s["p_tok"], s["fuse"]
         pool = s.get("dx_pool")
         for i in reversed(range(self.num_layers)):
             lay = s["layers"][i]
@@ -468,36 +591,93 @@ class DenoiserTrainEngine:
                                    drop=(p_tok, seed, 0) if i == 0 and fuse and p_tok > 0.0 else None)
             self._layer_done(i)
 
-        # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
-        if p_tok > 0.0 and not fuse:
-            dtok = T.dropout(dh_, p_tok, seed, 0)
-        ld_sf = s["sf"].shape[1]
-        dws = torch.zeros((C, ld_sf), dtype=torch.float32, device=dev)
-        T.grad_weight(dtok, s["sf"], dws, g_scale=G)
-        g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
-        T.colsum(dtok, g["shape.b"])
-        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L)
-        ld_pf = s["pf"].shape[1]
-        dwp = torch.zeros((C, ld_pf), dtype=torch.float32, device=dev)
-        T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
-        g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
-        T.colsum(dx_emb, g["param.b"])
+        return dtok
 
-        # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
-        n_ada = 2 * self.num_layers
-        se = s["se"]
-        T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
-        T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
-                    accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
-        dse = torch.empty_like(se)
-        T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
-                    sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
-        if self._sparse_tables and self._exchange.active():
-            dse_all, t_all = self._exchange.gather_rows(dse, s["t64"], dim=1)       # [n_ada, world*B, C], [world*B]
-            T.silu_embed_bwd(w["ada.tables"], t_all, dse_all, g["ada.tables"])
-        else:
-            T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
-        self._all_done()
+    def _dw_planes(self, dyp, xp, gw, gb) -> None:
+        """dW += dY^T . X (both operands read in place as k-major planes), db += colsum(dY) — on the side stream"""
+        from . import planes as P
+
+        def issue():
+            P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True)
+            if gb is not None:
+                P.colsum(dyp, gb)
+
+        if self._side is None:
+            issue()
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            issue()
+        dyp.record_stream(self._side)
+        xp.record_stream(self._side)
+
+    def _backward_layers_planes(self, s, w, g, dh_, dmods):
+        """transformer blocks on the plane GEMM: dX = dY . W reads the weight planes in place as the k-major operand, dW = dY^T . X
+        reads both dY and the saved activation planes in place; the kernels between them (GEGLU / LayerNorm / attention backward)
+        hand dY over as planes of grad_scale * dY -> d/d(tokens)"""
+        from . import planes as P
+
+        G = self.grad_scale
+        L, C, Fv, M = s["L"], s["C"], s["Fv"], s["M"]
+        H = self.num_heads
+        dh = C // H
+        dev = dh_.device
+        seed, p_lay, p_tok, fuse = s["seed"], s["p_lay"], s["p_tok"], s["fuse"]
+        frag_b = s["frag_b"]
+
+        def wp(key):
+            pw = w[key]
+            return P.Planes(pw.hi, pw.lo)
+
+        def dx(dyp, key, n_in):
+            out = torch.empty((M, n_in), dtype=torch.float32, device=dev)
+            return P.gemm(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], w_kmajor=True)
+
+        drop_lay = fuse and p_lay > 0.0
+        dhp = P.split(dh_, G)                         # d/dh of the last block's output: dY of its second feed-forward linear
+        dtok = None
+        for i in reversed(range(self.num_layers)):
+            lay = s["layers"][i]
+            inner = lay["u"].shape[1]
+            # ---- feed-forward (attention.py:87-90)
+            self._dw_planes(dhp, lay["u"], g[f"{i}.ff2.w"], g[f"{i}.ff2.b"])
+            du = dx(dhp, f"{i}.ff2.w", inner)
+            dzp = T.geglu_bwd_planes(lay["z"], du, p_lay, seed, 3 + 3 * i, G)
+            del du
+            self._dw_planes(dzp, lay["n3"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
+            dn = dx(dzp, f"{i}.ff1.w", C)
+            del dzp
+            dyp, _, _ = T.layernorm_bwd_planes(lay["h2"], dn, dh_, G, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
+                                               dadd=g[f"{i}.norm3.b"], ld_d=0, drop=(p_lay, seed, 2 + 3 * i) if drop_lay else None)
+            if p_lay > 0.0 and not fuse:
+                dyp = P.split(T.dropout(dh_, p_lay, seed, 2 + 3 * i), G)
+            # ---- global attention (attention.py:82-85)
+            self._dw_planes(dyp, lay["att2p"], g[f"{i}.global_attn.o.w"], g[f"{i}.global_attn.o.b"])
+            datt = dx(dyp, f"{i}.global_attn.o.w", C)
+            dqkvp = T.attn_dense_bwd_planes(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
+                                            s["att_scale"], G)
+            self._dw_planes(dqkvp, lay["n2"], g[f"{i}.global_attn.qkv.w"], None)
+            dn = dx(dqkvp, f"{i}.global_attn.qkv.w", C)
+            dyp, _, _ = T.layernorm_bwd_planes(lay["h1"], dn, dh_, G, mod=s["mods"][2 * i + 1], group_batch=frag_b, group_rows=L,
+                                               dmult=dmods[2 * i + 1], dadd=dmods[2 * i + 1][:, C:], ld_d=2 * C,
+                                               drop=(p_lay, seed, 1 + 3 * i) if drop_lay else None)
+            if p_lay > 0.0 and not fuse:
+                dyp = P.split(T.dropout(dh_, p_lay, seed, 1 + 3 * i), G)
+            # ---- self attention (attention.py:77-80)
+            self._dw_planes(dyp, lay["att1"], g[f"{i}.self_attn.o.w"], g[f"{i}.self_attn.o.b"])
+            datt = dx(dyp, f"{i}.self_attn.o.w", C)
+            dqkvp = T.attn_blockdiag_bwd_planes(lay["qkv1"], datt, Fv, L, H, dh, s["att_scale"], G)
+            self._dw_planes(dqkvp, lay["n1"], g[f"{i}.self_attn.qkv.w"], None)
+            dn = dx(dqkvp, f"{i}.self_attn.qkv.w", C)
+            if i > 0:
+                # the updated running gradient is the dY of block i-1's second feed-forward linear
+                _, dhp, _ = T.layernorm_bwd_planes(lay["h0"], dn, dh_, G, mod=s["mods"][2 * i], group_batch=frag_b, group_rows=L,
+                                                   dmult=dmods[2 * i], dadd=dmods[2 * i][:, C:], ld_d=2 * C, want_ret=False, want_dx=True)
+            else:
+                dtok = T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][0], group_batch=frag_b, group_rows=L, dmult=dmods[0],
+                                       dadd=dmods[0][:, C:], ld_d=2 * C, drop=(p_tok, seed, 0) if fuse and p_tok > 0.0 else None)
+            self._layer_done(i)
+        return dtok
 
     def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:
         """dW += dy^T x, db += colsum(dy) — on the side stream when there is one.  `guard`: the caller goes on to update

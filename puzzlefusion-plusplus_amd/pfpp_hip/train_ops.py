@@ -442,3 +442,126 @@ def bn_minmax_apply(mx: torch.Tensor, mn: torch.Tensor, a_mul: torch.Tensor, a_a
     check(_lib.load().pfpp_bn_minmax_apply(_ptr(mx), _ptr(mn), _ptr(a_mul), _ptr(a_add), _ptr(out), rows, Cc, _stream()),
           "pfpp_bn_minmax_apply")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plane-producing forms (include/pfpp.h): the result goes out as split-f16 planes for the plane GEMM (pfpp_hip.planes)
+# ------------------------------------------------------------------------------------------------------------------
+def geglu_planes(z: torch.Tensor, p: float, seed: int, site: int):
+    """-> Planes of u = value * gelu(gate) (+ dropout) [rows, inner]; no fp32 copy"""
+    from .planes import Planes, _pl
+
+    _chk(z, _f32, "z")
+    rows, two_inner = z.shape
+    out = Planes.empty(rows, two_inner // 2, z.device)
+    check(_lib.load().pfpp_geglu_p(_ptr(z), None, rows, two_inner // 2, p, seed, site, _pl(out), _stream()), "pfpp_geglu_p")
+    return out
+
+
+def geglu_bwd_planes(z: torch.Tensor, du: torch.Tensor, p: float, seed: int, site: int, scale: float):
+    """-> Planes of scale * dz [rows, 2 inner]; no fp32 copy"""
+    from .planes import Planes, _pl
+
+    _chk(z, _f32, "z"); _chk(du, _f32, "du")
+    rows, two_inner = z.shape
+    out = Planes.empty(rows, two_inner, z.device, scale)
+    check(_lib.load().pfpp_geglu_bwd_p(_ptr(z), _ptr(du), None, rows, two_inner // 2, p, seed, site, _pl(out), _stream()),
+          "pfpp_geglu_bwd_p")
+    return out
+
+
+def dropout_layernorm_planes(y: torch.Tensor, res: Optional[torch.Tensor], p: float, seed: int, site: int, *,
+                             mod: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                             beta: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None, group_rows: int = 1,
+                             rows_per_batch: int = 1, eps: float = 1e-5):
+    """dropout_layernorm with the normalised rows as Planes: -> (h written over y, Planes n)"""
+    from .planes import Planes, _pl
+
+    _chk(y, _f32, "y")
+    rows, Cc = y.shape
+    ld_mod = 0
+    if res is not None:
+        _chk(res, _f32, "res")
+    if mod is not None:
+        _chk(mod, _f32, "mod")
+        ld_mod = mod.stride(0)
+        if mod.shape[-1] != 2 * Cc:
+            raise ValueError("dropout_layernorm: mod must be [B, 2C]")
+    if group_batch is not None:
+        _chk(group_batch, torch.int32, "group_batch")
+        if group_batch.numel() * group_rows < rows:
+            raise ValueError("dropout_layernorm: group_batch too short")
+    n = Planes.empty(rows, Cc, y.device)
+    check(_lib.load().pfpp_dropout_layernorm_p(_ptr(y), _ptr(res), _ptr(y), None, _ptr(mod), ld_mod, _ptr(gamma), _ptr(beta),
+                                               _ptr(group_batch), group_rows, rows_per_batch, rows, Cc, eps, p, seed, site,
+                                               _pl(n), _stream()), "pfpp_dropout_layernorm_p")
+    return y, n
+
+
+def layernorm_bwd_planes(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, scale: float, *, mod: Optional[torch.Tensor] = None,
+                         gamma: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
+                         group_rows: int = 32, rows_per_batch: int = 1, dmult: Optional[torch.Tensor] = None,
+                         dadd: Optional[torch.Tensor] = None, ld_d: int = 0, eps: float = 1e-5,
+                         drop: Optional[tuple] = None, want_ret: bool = True, want_dx: bool = False,
+                         ret_fp32: bool = False):
+    """layernorm_bwd (dx += ..., in place) that also emits Planes (scale * value) of what the backward chain continues with
+    (`ret`: dropout(dx) for drop = (p, seed, site), else dx) and / or of the updated dx.  -> (ret_planes, dx_planes, ret_fp32_tensor)"""
+    from .planes import Planes, _pl
+
+    _chk(x, _f32, "x"); _chk(dy, _f32, "dy"); _chk(dx, _f32, "dx")
+    rows, Cc = x.shape
+    ld_mod = 0
+    if mod is not None:
+        _chk(mod, _f32, "mod")
+        ld_mod = mod.stride(0)
+    if group_batch is not None:
+        _chk(group_batch, torch.int32, "group_batch")
+        if group_batch.numel() * group_rows < rows:
+            raise ValueError("layernorm_bwd: group_batch too short")
+    p, seed, site = drop if drop is not None else (0.0, 0, 0)
+    ret = Planes.empty(rows, Cc, x.device, scale) if want_ret else None
+    dxp = Planes.empty(rows, Cc, x.device, scale) if want_dx else None
+    out32 = torch.empty_like(dx) if (ret_fp32 and drop is not None) else None
+    check(_lib.load().pfpp_layernorm_bwd_p(_ptr(x), _ptr(dy), _ptr(mod), ld_mod, _ptr(gamma), _ptr(group_batch), group_rows,
+                                           rows_per_batch, _ptr(dx), _ptr(dmult), _ptr(dadd), ld_d, rows, Cc, eps, _ptr(out32),
+                                           p, seed, site, int(drop is not None), _pl(ret), _pl(dxp), _stream()),
+          "pfpp_layernorm_bwd_p")
+    return ret, dxp, (out32 if drop is not None else dx) if ret_fp32 else None
+
+
+def attn_dense_train_planes(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, max_len: int, H: int, dh: int,
+                            scale: float):
+    """attn_dense_train with the output both as fp32 (the backward's D = rowsum(dO . O)) and as Planes -> (out, Planes, lse)"""
+    from .planes import Planes, _pl
+
+    _chk(qkv, _f32, "qkv"); _chk(seq_off, torch.int32, "seq_off"); _chk(seq_len, torch.int32, "seq_len")
+    rows = qkv.shape[0]
+    out = torch.empty((rows, H * dh), dtype=_f32, device=qkv.device)
+    outp = Planes.empty(rows, H * dh, qkv.device)
+    lse = torch.empty((rows, H), dtype=_f32, device=qkv.device)
+    check(_lib.load().pfpp_attn_dense_train_p(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(seq_off), _ptr(seq_len), None, 0,
+                                              seq_off.numel(), max_len, H, dh, scale, _pl(outp), _stream()), "pfpp_attn_dense_train_p")
+    return out, outp, lse
+
+
+def attn_dense_bwd_planes(qkv, out_fwd, dout, lse, seq_off, seq_len, max_len: int, H: int, dh: int, scale: float, g_scale: float):
+    """-> Planes of g_scale * dqkv (no fp32 copy)"""
+    from .planes import Planes, _pl
+
+    _chk(qkv, _f32, "qkv"); _chk(out_fwd, _f32, "out_fwd"); _chk(dout, _f32, "dout"); _chk(lse, _f32, "lse")
+    dq = Planes.empty(qkv.shape[0], qkv.shape[1], qkv.device, g_scale)
+    dvec = torch.empty_like(lse)
+    check(_lib.load().pfpp_attn_dense_bwd_p(_ptr(qkv), _ptr(out_fwd), _ptr(dout), _ptr(lse), _ptr(dvec), None, _ptr(seq_off),
+                                            _ptr(seq_len), None, 0, seq_off.numel(), max_len, H, dh, scale, _pl(dq), _stream()),
+          "pfpp_attn_dense_bwd_p")
+    return dq
+
+
+def attn_blockdiag_bwd_planes(qkv, dout, n_frag: int, L: int, H: int, dh: int, scale: float, g_scale: float):
+    from .planes import Planes, _pl
+
+    _chk(qkv, _f32, "qkv"); _chk(dout, _f32, "dout")
+    dq = Planes.empty(qkv.shape[0], qkv.shape[1], qkv.device, g_scale)
+    check(_lib.load().pfpp_attn_blockdiag_bwd_p(_ptr(qkv), _ptr(dout), None, n_frag, L, H, dh, scale, _pl(dq), _stream()),
+          "pfpp_attn_blockdiag_bwd_p")
+    return dq

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     if (n < 4) { printf("bad spec %s\n", argv[ai]); return 1; }
     const bool ak = !strcmp(mode, "tn"), wk = ak || !strcmp(mode, "nn");
     const bool accum = ak || (splits >= 0 && splits != 1);
-    if (splits < 0) splits = accum ? 0 : 1;
+    if (splits < 0) splits = 0;
     const int64_t lda = ak ? M : K, ldw = wk ? N : K;
     const size_t na = (size_t)(ak ? K : M) * lda, nw = (size_t)(wk ? K : N) * ldw;
     std::vector<float> hA(na), hW(nw), hb(N);
