@@ -30,6 +30,7 @@ namespace pfpp_gemm_detail {
 int launch_f16x3_ring(const GemmP& p, int batch, hipStream_t st, int group_m);   // gemm_ring.hip
 int launch_f16x3_ws(const GemmP& p, int batch, hipStream_t st, int group_m);     // gemm_ws.hip
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant);   // gemm_pl.hip
+int launch_f16x3_planes_af32(const GemmP& p, int batch, hipStream_t st, int group_m);
 }
 
 namespace {
@@ -943,6 +944,12 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
       if (t128 < 1024 && a->act != PFPP_ACT_GEGLU && a->pool == 0) return launch_f16x3_apre<2, 1, 2, 2, true>(p, a->batch, st);
       return launch_f16x3_apre<2, 2, 2, 2, true>(p, a->batch, st);
     }
+    // big-M GEMMs with a short contraction (the train-mode set-abstraction MLPs: 1.26 M rows, K = 64..256, fused BatchNorm
+    // operand / statistics / pooling): LDS-DMA staged plane kernel with the fp32 A operand converted at fragment-read time
+    static const bool af32 = !(getenv("PFPP_GEMM_AF32") && atoi(getenv("PFPP_GEMM_AF32")) == 0);
+    if (af32 && pre && !apre && !a->gather_idx && a->batch == 1 && a->M >= 65536 && a->K % 32 == 0 && a->K <= 256 && a->lda % 4 == 0 &&
+        a->act != PFPP_ACT_GEGLU && !a->c_hi && (a->pool == 0 || a->pool == 32 || a->N > 64))
+      return launch_f16x3_planes_af32(p, a->batch, st, gemm_group_m());
     static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
     if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn && !a->gather_idx) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
     static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;

@@ -83,6 +83,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // MT x NT 32x32 tiles per wave, WM x WN waves.  HS = row tiles per half-step (the fragment double buffer holds HS row tiles
 // and NT column tiles): HS == MT for one half-step per 16-deep step, MT / 2 for two.
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_rd_f4(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 // transposing read: within a 16-lane group, lane j receives element j of each of the four 16-half rows the group's lanes
 // address (lanes 4r .. 4r+3 supply row r, 4 halfs each)
 template <int OFF>
@@ -127,11 +135,11 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
   const float alpha = p.alpha;
   const bool geglu = p.act == PFPP_ACT_GEGLU;
   constexpr int ROWB = NT * 128;                 // bytes per patch row: NT x 32 floats
-  float sc[NT], sh[NT];
+  float sc[NT], sh[NT], st_s[NT], st_q[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = col_w + j * 32 + l31;
-    sc[j] = 1.0f; sh[j] = 0.0f;
+    sc[j] = 1.0f; sh[j] = 0.0f; st_s[j] = 0.0f; st_q[j] = 0.0f;
     if (col < p.N) {
       if (scale) { sc[j] = scale[col]; sh[j] = shift[col]; }
       else if (bias) sh[j] = bias[col];
@@ -153,6 +161,15 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
       for (int e = 0; e < 16; ++e) {
         const float v = t[e] * alpha;
         t[e] = scale ? __builtin_fmaf(v, sc[j], sh[j]) : v + sh[j];
+      }
+      if (p.stats) {      // BatchNorm batch statistics of the pre-activation (same sums as the generic epilogue)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          const float v = row < p.M ? t[e] : 0.0f;
+          st_s[j] += v;
+          st_q[j] += v * v;
+        }
       }
       int pc = j * 32 + l31;                     // patch column
       if (NT >= 2 && geglu) {
@@ -197,11 +214,24 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
       }
     }
   }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col_w + j * 32 + l31;
+      const float a = st_s[j] + __shfl_xor(st_s[j], 32), b = st_q[j] + __shfl_xor(st_q[j], 32);
+      if (lhi == 0 && col < p.N) {
+        double* st = p.stats + (size_t)(blockIdx.x % p.stats_copies) * 2 * p.N;
+        unsafeAtomicAdd(st + col, (double)a);
+        unsafeAtomicAdd(st + p.N + col, (double)b);
+      }
+    }
+  }
 }
 
 // One workgroup = one output tile.  NS-stage DMA ring; see the header for the schedule.
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false>
 __device__ __forceinline__ void pl_body(const GemmP& p) {
+  static_assert(!(AF && AK), "an fp32 A operand is row-major");
   using C = Cfg<MT, NT, WM, WN, NS>;
   constexpr int BM = C::BM, BN = C::BN, NPW = C::NPW, STAGE = C::STAGE;
   constexpr int HS = C::HS;
@@ -245,7 +275,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   //   (slot - 4 * rot(row)) mod CPR of that row; the next K-tile is 32 rows further down
   const char* src[NPW];
   uint32_t dst[NPW];
-  const int64_t adv_a = AK ? (int64_t)32 * p.lda * 2 : 64, adv_w = WK ? (int64_t)32 * p.ldw * 2 : 64;
+  const int64_t adv_a = AK ? (int64_t)32 * p.lda * 2 : (AF ? 128 : 64), adv_w = WK ? (int64_t)32 * p.ldw * 2 : 64;
   bool piece_a[NPW];
   int piece_krow[NPW];                 // k-major pieces: this lane's contraction row within the K-tile
   const int k_tail = p.k_valid - (nk_all - 1) * BK;      // valid rows of the last K-tile (BK when the contraction is not ragged)
@@ -275,6 +305,15 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       const int chunk = (ci & 3) ^ ((row >> 2) & 3);
       return (int64_t)min(g0 + row, lim - 1) * ld + chunk * 8;
     };
+    if (AF && is_a) {
+      // fp32 rows of 128 bytes (32 k): plane-region chunk index cf = row * 8 + physical chunk, logical = physical ^ ((row >> 1) & 7)
+      const int cf = (o >> 4) + lane;
+      const int row = cf >> 3;
+      const int chunk = (cf & 7) ^ ((row >> 1) & 7);
+      src[j] = reinterpret_cast<const char*>(p.A + a_offz + (int64_t)min(m0 + row, p.M - 1) * p.lda + chunk * 4) + (int64_t)kt0 * adv_a;
+      dst[j] = lds0 + o;
+      continue;
+    }
     if (is_a) eoff = a_offz + (AK ? kmajor_off(CPR_A, m0, p.M, p.lda) : rowmajor_off(m0, p.M, p.lda));
     else eoff = w_offz + (WK ? kmajor_off(CPR_W, n0, p.N, p.ldw) : rowmajor_off(n0, p.N, p.ldw));
     src[j] = reinterpret_cast<const char*>(base + eoff) + (int64_t)kt0 * (is_a ? adv_a : adv_w);
@@ -305,7 +344,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   // k-major: lane (q = lane >> 4, j = lane & 15) reads 8 bytes at contraction row 16 s + 8 (q >> 1) + 4 t + (j >> 2), column
   //   32 tile + 16 (q & 1) + 4 (j & 3); one address per tile of the wave, (s, t) go into the offset field
   const int sw = (l31 >> 2) & 3;
-  constexpr int NAD_A = AK ? MT : 2, NAD_W = WK ? NT : 2;
+  constexpr int NAD_A = AK ? MT : (AF ? 4 : 2), NAD_W = WK ? NT : 2;
   uint32_t a_ad[NAD_A], w_ad[NAD_W];
   auto kmajor_ad = [&](int cpr, int it) {
     const int q = lane >> 4, j = lane & 15;
@@ -317,9 +356,27 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   if constexpr (AK) {
 #pragma unroll
     for (int ii = 0; ii < MT; ++ii) a_ad[ii] = lds0 + kmajor_ad(CPR_A, wm * MT + ii);
+  } else if constexpr (AF) {
+    // fp32 tile: row l31, 16-byte chunks 4 s + 2 lhi and + 1 (8 k-values), physical = logical ^ ((row >> 1) & 7)
+    const int swf = (l31 >> 1) & 7;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      a_ad[2 * s2] = lds0 + (wm * 32 * MT + l31) * 128 + (((4 * s2 + 2 * lhi) ^ swf) << 4);
+      a_ad[2 * s2 + 1] = lds0 + (wm * 32 * MT + l31) * 128 + (((4 * s2 + 2 * lhi + 1) ^ swf) << 4);
+    }
   } else {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) a_ad[s2] = lds0 + (wm * 32 * MT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
+  }
+  // fp32 A with the train-mode BatchNorm + ReLU of the previous layer fused in: (a_mul, a_add) [K] staged in LDS behind the ring
+  const uint32_t aff0 = lds0 + NS * STAGE;
+  if constexpr (AF) {
+    float* affp = reinterpret_cast<float*>(pl_smem + NS * STAGE);
+    for (int k = tid; k < 256; k += C::NTHR) {
+      affp[k] = (p.a_mul && k < p.K) ? p.a_mul[k] : 1.0f;
+      affp[256 + k] = (p.a_add && k < p.K) ? p.a_add[k] : 0.0f;
+    }
+    __syncthreads();       // before any LDS-DMA is in flight: a plain barrier is enough here
   }
   if constexpr (WK) {
 #pragma unroll
@@ -329,7 +386,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     for (int s2 = 0; s2 < 2; ++s2) w_ad[s2] = lds0 + 2 * C::PLANE_A + (wn * 32 * NT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
   }
   // a k-major fragment arrives as two 8-byte halves (contraction rows +0..3 and +4..7)
-  struct FA { half8 h[HS], l[HS]; half4 h2[AK ? HS : 1][2], l2[AK ? HS : 1][2]; };
+  struct FA { half8 h[HS], l[HS]; half4 h2[AK ? HS : 1][2], l2[AK ? HS : 1][2]; f32x4 r[AF ? HS : 1][2]; f32x4 am[2], aa[2]; };
   struct FB { half8 h[NT], l[NT]; half4 h2[WK ? NT : 1][2], l2[WK ? NT : 1][2]; };
   FA fa[2];
   FB fb[2];
@@ -338,6 +395,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   constexpr bool dbg_noread = DBG & 8, dbg_nowait = DBG & 16;
   // Fragment reads one at a time, each in its own gap between two MFMAs.  Row-major: q < HS: hi plane of row tile q, then
   // the lo planes.  K-major: q = 4 * tile + 2 * plane + t.
+  int kt_aff = 0;          // AF: K-tile the next fragment reads belong to (selects the slice of the affine table)
   auto rd_a = [&](FA& f, uint32_t st, auto s_c, auto mh_c, auto q_c) {
     constexpr int s = decltype(s_c)::value, mh = decltype(mh_c)::value, q = decltype(q_c)::value;
     if constexpr (dbg_noread) return;
@@ -346,6 +404,15 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       constexpr int off = pl_ * C::PLANE_A + (16 * s + 4 * hf) * CPR_A * 16;
       const uint32_t ad = a_ad[HS * mh + t] + st;
       if constexpr (pl_ == 0) f.h2[t][hf] = lds_rd_tr<off>(ad); else f.l2[t][hf] = lds_rd_tr<off>(ad);
+    } else if constexpr (AF) {
+      // q < HS: first 16 bytes of row tile q's 8 k-values, then the second 16 bytes; the affine pair of this 16-deep step
+      // rides with the first two reads
+      constexpr int t = q % HS, hf = q / HS;
+      f.r[t][hf] = lds_rd_f4<(HS * mh + t) * 4096>(a_ad[2 * s + hf] + st);
+      if constexpr (t == 0) {
+        f.am[hf] = lds_rd_f4<0>(aff0 + kt_aff * 128 + (16 * s + 8 * lhi + 4 * hf) * 4);
+        f.aa[hf] = lds_rd_f4<1024>(aff0 + kt_aff * 128 + (16 * s + 8 * lhi + 4 * hf) * 4);
+      }
     } else {
       const uint32_t ad = a_ad[s] + st;
       constexpr int t = q % HS;
@@ -378,6 +445,20 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h2[t][0]), "+v"(a.h2[t][1]), "+v"(a.l2[t][0]), "+v"(a.l2[t][1]));
         a.h[t] = join(a.h2[t][0], a.h2[t][1]);
         a.l[t] = join(a.l2[t][0], a.l2[t][1]);
+      });
+    } else if constexpr (AF) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.am[0]), "+v"(a.am[1]), "+v"(a.aa[0]), "+v"(a.aa[1]));
+      static_for<HS>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.r[t][0]), "+v"(a.r[t][1]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = a.r[t][e >> 2][e & 3];
+          if (p.a_mul) x = fmaxf(x * a.am[e >> 2][e & 3] + a.aa[e >> 2][e & 3], 0.0f);      // relu(batch-norm(y)), as gemm_f16x3_kernel
+          const _Float16 hh = (_Float16)x;
+          a.h[t][e] = hh;
+          a.l[t][e] = (_Float16)(x - (float)hh);
+        }
       });
     } else if constexpr (HS == 1)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]), "+v"(a.l[0]));
@@ -455,6 +536,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   // right behind the barrier that frees its stage.  The prologue issued tiles 0 .. NS-1 completely.
   auto tile_body = [&](int kt, uint32_t cur, uint32_t nxt, uint32_t prv, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
+    kt_aff = kt;
     const bool dma2 = !(DBG & 2) && kt >= 1 && kt + NS - 1 < nk;     // second half of tile kt + NS - 1 -> stage of tile kt - 1
     const bool dma1 = !(DBG & 2) && !LAST && kt + NS < nk;           // first half of tile kt + NS -> this tile's stage
     auto fill_dma2 = [&](auto m_c) {
@@ -497,6 +579,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       // every read of this tile has landed: its stage is free; the next tile must be in LDS before it is read
       wait_ab(fa[1], fb[1]);
       if constexpr (!LAST) sync_next();
+      kt_aff = kt + 1;
       half_step(fa[1], fb[1], I1{}, std::integral_constant<int, G0 + NP1>{}, fill_next);
     } else {
       // h0 = s0, h1 = s1 (all row tiles of the wave)
@@ -509,6 +592,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       });
       wait_ab(fa[1], fb[1]);
       if constexpr (!LAST) sync_next();
+      kt_aff = kt + 1;
       half_step(fa[1], fb[1], I0{}, std::integral_constant<int, G0 + NP1>{}, fill_next);
     }
   };
@@ -561,7 +645,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     }
     return;
   }
-  const bool wide_ok = p.pool == 0 && !p.stats && !(DBG & 128) && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+  const bool wide_ok = p.pool == 0 && !(DBG & 128) && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
                        (!p.residual || (p.ldr & 3) == 0) && (p.act != PFPP_ACT_GEGLU || (p.N & 7) == 0);
   if (wide_ok) {
     __builtin_amdgcn_s_barrier();      // every wave is done with the DMA ring: its first bytes become the transposition patches
@@ -596,12 +680,12 @@ __global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* 
   *dstp = s;
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
-  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG>(p);
+  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF>(p);
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0>
+template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false>
 int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits = 1) {
   using C = Cfg<MT, NT, WM, WN, NS>;
 #ifdef PFPP_PL_LAB
@@ -619,7 +703,7 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
 #endif
   static bool attr_set = false;
-  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG>;
+  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG, AF>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -638,9 +722,9 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
   p.k_chunk = 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
-  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
-           WK ? "true" : "false", DBG, slabs ? "+pl_reduce_kernel" : "");
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, p);
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
+           WK ? "true" : "false", DBG, AF ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM + (AF ? 2048 : 0), st, p);
   if (slabs) {
     const int64_t n4 = (int64_t)p.M * (p.N >> 2);
     hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.split_ws, p.C, p.bias, p.residual, p.M,
@@ -663,6 +747,22 @@ static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m
     case 6: return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
     default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK>(p, batch, st, group_m, splits);
   }
+}
+
+// fp32 A read in place (LDS-DMA of fp32 rows, converted when a wave fetches its fragments) with the train-mode BatchNorm + ReLU of
+// the previous set-abstraction layer fused in: the [1.26 M x 64..256] encoder GEMMs, bound by HBM, not by the conversions
+int launch_f16x3_planes_af32(const GemmP& p0, int batch, hipStream_t st, int group_m) {
+  GemmP p = p0;
+  if (getenv("PFPP_DIAG_NO_STATS")) p.stats = nullptr;       // diagnostic only: what do the statistics atomics cost?
+  if (getenv("PFPP_DIAG_NO_POOL")) { p.pool = 0; p.Cmin = nullptr; }
+  // measured on the train-mode set-abstraction shapes (tools/diag/gemm_calls.py): every tile / stage choice lands within 10 % — these
+  // launches are bound by the per-workgroup fixed costs of a 2..8 K-tile contraction (cold-HBM prologue, epilogue) and by HBM
+  // itself (3.6 TB/s on the layers that write their activation), not by the K loop.  Two or three co-resident workgroups per CU
+  // hide a little more of the prologue than one large one.
+  static const int afv = getenv("PFPP_GEMM_AF32_VARIANT") ? atoi(getenv("PFPP_GEMM_AF32_VARIANT")) : 0;
+  if (afv == 4) return pl::launch_pl<2, 2, 4, 2, 3, false, false, 0, true>(p, batch, st, group_m, 1);       // 256 x 128, one per CU
+  if (p.N <= 64) return pl::launch_pl<2, 1, 2, 2, 2, false, false, 0, true>(p, batch, st, group_m, 1);      // 128 x 64, three per CU
+  return pl::launch_pl<2, 2, 2, 2, 2, false, false, 0, true>(p, batch, st, group_m, 1);                      // 128 x 128, two per CU
 }
 
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant) {
