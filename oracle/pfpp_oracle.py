@@ -139,6 +139,18 @@ def matrix_to_quaternion(m: torch.Tensor) -> torch.Tensor:
     return torch.where(out[..., 0:1] < 0, -out, out)
 
 
+def assign_init_pose(nodes, trans: torch.Tensor, rots: torch.Tensor, centroid: torch.Tensor, component) -> None:
+    """utils/node_merge_utils.py:225-244: node.init_pose <- [R(q_pivot) | t_pivot - centroid] @ node.init_pose for every node
+    of the merged component (`nodes`: mapping index -> dict with "pivot" and "init_pose")"""
+    for idx in component:
+        node = nodes[idx]
+        piv = node["pivot"]
+        a = torch.eye(4)
+        a[:3, :3] = quaternion_to_matrix(rots[piv])
+        a[:3, 3] = trans[piv] - centroid
+        node["init_pose"] = a if node["init_pose"] is None else a @ node["init_pose"]
+
+
 def pose_compose(pose: torch.Tensor, pivot, init_pose=None, has_init=None) -> torch.Tensor:
     """get_param / extract_final_pred_trans_rots, utils/node_merge_utils.py:246-306"""
     n = len(pivot)

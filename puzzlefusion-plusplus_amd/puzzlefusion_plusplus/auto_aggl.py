@@ -32,6 +32,21 @@ from puzzlefusion_plusplus.verifier.model.modules.verifier_transformer import Ve
 from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
 
 
+def normalise_edge_hist(ef: torch.Tensor) -> torch.Tensor:
+    """[.., E, 6] histogram counts -> [.., E, 7]: the six bins divided by the edge's number of matched points (1 where there are
+    none) and that number as the seventh feature (auto_aggl.py:198-201)"""
+    cnt = ef.sum(dim=-1, keepdim=True)
+    return torch.cat((ef / torch.where(cnt == 0, 1, cnt), cnt), dim=-1).float()
+
+
+def edge_features_from_hist(hist_pp: torch.Tensor):
+    """[B, P, P, 6] per-pair histograms (row = idx1 < column = idx2) -> (edge features [B, P(P-1)/2, 7], edge indices
+    [1, P(P-1)/2, 2]) in the upper-triangle order of torch.triu(...).nonzero() (auto_aggl.py:195-201)"""
+    B, P = hist_pp.shape[:2]
+    pairs = AutoAgglomerative._edge_pairs(P, hist_pp.device)
+    return normalise_edge_hist(hist_pp[:, pairs[:, 0], pairs[:, 1]]), pairs.unsqueeze(0)
+
+
 class AutoAgglomerative(LightningModule):
     def __init__(self, cfg, merge_fn: Optional[Callable] = None, use_graphs: Optional[bool] = None):
         super().__init__()
@@ -396,9 +411,8 @@ class _PuzzleState:
         ef = torch.zeros(1, P * (P - 1) // 2, 6, dtype=torch.int32, device=dev)
         if match["pairs"]:
             ef[0, match["pair_pos"]] = hist
-        cnt = ef.sum(dim=-1, keepdim=True)
         self._pts_t = pts_t
-        return torch.cat((ef / torch.where(cnt == 0, 1, cnt), cnt), dim=-1).float()
+        return normalise_edge_hist(ef)
 
     def after_verify(self, logits: torch.Tensor) -> None:
         """threshold -> reference promotion -> merge for this puzzle (auto_aggl.py:203-286); sets `done`"""

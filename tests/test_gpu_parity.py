@@ -106,7 +106,7 @@ def test_encoder_stages_vs_golden(golden, weights_sd, dev):
     from pfpp_hip import encoder as E
 
     pk = E.pack_encoder(dsd(weights_sd("vqvae"), dev))
-    for tag in ("float", "grid"):
+    for tag in ("float", "grid", "ref"):      # "ref": the reference shape, F = 4 fragments x N = 1000 points
         g = golden(f"encoder_{tag}")
         cap = {}
         z_e, xyz = E.pn2_encode(pk, T(g["pts"]).to(dev), 25, cap)
@@ -315,6 +315,11 @@ def test_denoiser_vs_golden(golden, weights_sd, dev):
                              T(g["part_valids"]).to(dev), T(g["scale"]).to(dev), T(g["ref_part"]).to(dev),
                              num_layers=6, num_heads=8, capture=cap)
     assert np.abs(cap["tokens"].view(2, 500, 512)[:, ::25].cpu().numpy() - g["tokens_sub"]).max() < 1e-5
+    # the hidden state after every encoder layer (mean |h|, as stored with the fixture): a per-layer check next to the
+    # end-to-end one — a compensating pair of errors in two layers would show up here
+    for i in range(6):
+        got = cap[f"layer{i}"].double().abs().mean().item()
+        assert abs(got - float(g["layer_means"][i])) < 1e-5 * max(1.0, float(g["layer_means"][i])), (i, got, g["layer_means"][i])
     assert np.abs(eps.cpu().numpy() - g["pred_noise"]).max() < TOL
 
 
@@ -410,6 +415,65 @@ def test_sampler_steps_vs_oracle_teacher_forced(weights_sd, dev, oracle_lib):
         x = x_o
 
 
+def test_sampler_50_steps_configs2(weights_sd, dev, oracle_lib):
+    """BASELINE configs[2]'s step count: set_timesteps(50) (step ratio 20, t = 980 .. 0; the reference has no DDIM — DDPM `step`,
+    SURVEY.md §8d) free-running on the GPU with injected noise, checked against the CPU oracle teacher-forced from the GPU's
+    own trajectory at the first, a middle and the last step (t = 0: no noise term), and the auto-agglomerative loop at 50 steps
+    per outer iteration"""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).eval()
+    batch = synthetic.make_batch(33, 1, num_points=512, num_parts=8)           # configs[0]'s puzzle: 8 fragments x 512 points
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(1, 20, 7, generator=g)
+    noises = [torch.randn(1, 20, 7, generator=g) for _ in range(50)]
+    model.noise_scheduler.set_timesteps(50)
+    assert model.noise_scheduler.timesteps.tolist() == list(range(980, -1, -20))
+    rec = []
+    out = model.sample(gb, x_init=x0.to(dev), noises=[n.to(dev) for n in noises], record=rec)
+    assert len(rec) == 50 and torch.isfinite(out).all()
+    ref = batch["ref_part"].bool(); gt = torch.cat([batch["part_trans"], batch["part_rots"]], -1)
+    assert torch.equal(out.cpu()[ref], gt[ref])
+    sched = O.PiecewiseSchedule(); sched.set_timesteps(50)
+    assert sched.timesteps.tolist() == model.noise_scheduler.timesteps.tolist()
+    valid = batch["part_valids"].bool()
+    reference = torch.zeros_like(gt); reference[ref] = gt[ref]
+    x_start = x0.clone(); x_start[ref] = reference[ref]
+    for i in (0, 24, 49):
+        t = sched.timesteps.tolist()[i]
+        x_in = x_start if i == 0 else rec[i - 1].cpu()
+        lat_o, xyz_o = O.extract_features(weights_sd("vqvae"), batch["part_pcs"], batch["part_valids"], x_in)
+        lat, xyz = model._extract_features(gb["part_pcs"], gb["part_valids"], x_in.to(dev))
+        assert torch.equal(xyz.cpu(), xyz_o), f"step {i}: FPS / rotate diverged"
+        differ = (lat.cpu() - lat_o).abs().reshape(20, 100, 16).amax(-1) > 1e-4
+        assert differ.sum() <= 3, f"step {i}: {int(differ.sum())} VQ codes differ"
+        # the oracle continues from the GPU's latents where a near-tie flipped a code (the flip itself is bounded above)
+        eps_o = O.denoiser_forward(weights_sd("denoiser"), x_in, torch.full((1,), t), lat.cpu() if differ.any() else lat_o, xyz_o,
+                                   batch["part_valids"], batch["part_scale"], ref)
+        x_o = sched.step(eps_o, t, x_in, noises[i]); x_o[ref] = reference[ref]
+        assert (rec[i].cpu() - x_o)[valid].abs().max() < TOL, (i, t)
+    # auto-agglomerative loop at 50 sampler steps per outer iteration
+    cfg = config.auto_aggl_config()
+    cfg.denoiser.model.num_inference_steps = 50
+    cfg.verifier.max_iters = 2
+    aggl = AutoAgglomerative(cfg)
+    aggl.encoder.load_state_dict(weights_sd("vqvae")); aggl.denoiser.load_state_dict(weights_sd("denoiser"))
+    aggl.verifier.load_state_dict(weights_sd("verifier"))
+    aggl = aggl.to(dev).eval()
+    ab = {k: v.to(dev) for k, v in synthetic.make_batch(56, 1, num_points=512, num_parts=6).items()}
+    ab.update(synthetic.make_matching(ab, seed=3))
+    res = aggl.test_step(ab)
+    assert res["steps"] in (50, 100) and res["trajectory"].shape == (res["steps"], 6, 7) and torch.isfinite(res["trajectory"]).all()
+    agt = torch.cat([ab["part_trans"], ab["part_rots"]], -1)
+    assert torch.equal(res["x"][ab["ref_part"]], agt[ab["ref_part"]])
+
+
 def test_sampler_api_runs(weights_sd, dev):
     """Denoiser.sample / forward / _loss surface (shapes, re-pinned reference fragments, finite loss)"""
     from pfpp_hip import config, synthetic
@@ -445,6 +509,44 @@ def test_pn2_utils_dropin_api(weights_sd, dev, oracle_lib):
     d = pu.square_distance(new_xyz, xyz.to(dev))
     assert (d.cpu() - ((oxyz[:, :, None] - xyz[:, None]) ** 2).sum(-1)).abs().max() < 1e-5
     assert torch.equal(pu.index_points(feats.to(dev), idx).cpu(), O.index_points(feats, idx.cpu()))
+
+
+def test_aggl_glue_vs_reference_golden(golden, dev):
+    """the pose / matching / bookkeeping helpers of the auto-agglomerative loop against outputs of the reference's OWN functions
+    (tests/golden/aggl_glue.npz: utils/node_merge_utils.py:16-53,62-89,225-306 and auto_aggl.py:195-201,385-389 run by
+    tools/make_goldens.py) — SURVEY.md rows a19 and 8f-1"""
+    import utils.node_merge_utils as NM
+    from pfpp_hip import ops
+
+    g = golden("aggl_glue")
+    # get_final_pose_pts (normalises the quaternion)
+    out = NM.get_final_pose_pts(T(g["pts"]).to(dev), T(g["trans"]).to(dev), T(g["rots"]).to(dev))
+    assert np.array_equal(out.cpu().numpy(), g["final_pts"])
+    # get_final_pose_pts_dynamic: quaternion_apply WITHOUT normalisation, pose of the node's pivot
+    pose = torch.cat([T(g["dyn_trans"]), T(g["dyn_rots"])], -1).to(dev)
+    dyn = ops.pose_apply_points(T(g["area"]).to(dev), T(g["pose_idx"]).to(dev), pose)
+    assert np.array_equal(dyn.cpu().numpy(), g["dyn_pts"])
+    # get_distance_for_matching_pts + _make_cd_to_bins per candidate edge
+    off = g["edge_off"]
+    hist = ops.edge_histogram(dyn, T(g["idx_a"]).to(dev), T(g["idx_b"]).to(dev), T(off).to(dev), int((off[1:] - off[:-1]).max()))
+    assert np.array_equal(hist.cpu().numpy(), g["bins"])
+    # flatten / normalise / count column (auto_aggl.py:195-201) as the drop-in's loop computes it
+    from puzzlefusion_plusplus.auto_aggl import edge_features_from_hist
+
+    ef, eidx = edge_features_from_hist(T(g["hist_pp"]).to(dev))
+    assert np.array_equal(ef.cpu().numpy(), g["edge_features"]) and np.array_equal(eidx.cpu().numpy(), g["edge_indices"])
+    # three merges (assign_init_pose), then get_param / extract_final_pred_trans_rots through pfpp_pose_compose
+    P = g["pivots"].shape[0]
+    nodes = {i: dict(pivot=int(g["pivots"][i]), init_pose=None) for i in range(P)}
+    for comp, cen, tr, ro in zip(g["merge_components"], g["merge_centroids"], g["merge_trans"], g["merge_rots"]):
+        NM.assign_init_pose(nodes, T(tr).to(dev), T(ro).to(dev), T(cen).to(dev), [int(c) for c in comp if c >= 0])
+    init = torch.stack([nodes[i]["init_pose"] if nodes[i]["init_pose"] is not None else torch.zeros(4, 4, device=dev) for i in range(P)])
+    assert np.abs(init.cpu().numpy() - g["init_pose"]).max() < 1e-6
+    has = torch.tensor([nodes[i]["init_pose"] is not None for i in range(P)], dtype=torch.uint8, device=dev)
+    assert np.array_equal(has.cpu().numpy().astype(bool), g["has_init"])
+    comp = ops.pose_compose(T(g["param"]).to(dev), T(g["pivots"]).to(dev), init.reshape(P, 16).contiguous(), has)
+    assert np.abs(comp.cpu().numpy() - g["composed"]).max() < 2e-6
+    assert np.abs(comp.cpu().numpy() - np.concatenate([g["final_trans"], g["final_rots"]], -1)).max() < 2e-6
 
 
 def test_edge_features_vs_oracle(dev):

@@ -331,6 +331,70 @@ def test_two_rank_data_parallel_gradients(golden, weights_sd, dev):
     assert rel(got, want / 2) < 1e-5
 
 
+def test_full_size_training_iteration_properties(weights_sd, dev):
+    """BASELINE configs[1] size (32 puzzles x 20 slots x 1024 points, 154 valid fragments = 3,850 tokens, the size bench.py
+    times): the gradient of the batch loss equals the selected-fragment-weighted sum of the two half-batch gradients (the
+    weight-gradient contraction runs over a ragged 3,850 vs 1,900 / 1,950 tokens, different tiles and K splits), is finite,
+    and repeats to rounding with the dropouts on"""
+    from pfpp_hip import config, synthetic
+    from pfpp_hip import train_ops as T
+    from pfpp_hip.train import DenoiserTrainEngine
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev)
+    model.encoder.eval()
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(1234, 32, num_points=1024).items()}
+    gt = torch.cat([data["part_trans"], data["part_rots"]], -1).float().contiguous()
+    ref = data["ref_part"]
+    gen = torch.Generator(device=dev).manual_seed(11)
+    noise = torch.randn(gt.shape, device=dev, generator=gen)
+    t = torch.randint(0, 1000, (32,), device=dev, generator=gen)
+    noisy = model.noise_scheduler.add_noise(gt, noise, t)
+    noisy = torch.where(ref.bool().unsqueeze(-1), gt, noisy)
+    with torch.no_grad():
+        latent, xyz = model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+    eng = DenoiserTrainEngine(model.denoiser)
+
+    def grads_of(sl, weight):
+        pv = data["part_valids"][sl].contiguous()
+        pred, ctx = eng.forward(noisy[sl].contiguous(), t[sl].contiguous(), latent[sl].contiguous(), xyz[sl].contiguous(), pv,
+                                data["part_scale"][sl].contiguous(), ref[sl].contiguous(), seed=0, train=False)
+        n = pred.shape[0] * pred.shape[1]
+        sel = (pv.reshape(n).bool() & ~ref[sl].reshape(n).bool()).to(torch.uint8).contiguous()
+        loss, dpred = T.mse_loss(pred.reshape(n, 7), noise[sl].reshape(n, 7).contiguous().float(), sel)
+        eng.backward(ctx, dpred * weight)
+        return float(loss), int(sel.sum())
+
+    eng.flat.zero_grad()
+    loss_full, n_full = grads_of(slice(0, 32), 1.0)
+    torch.cuda.synchronize()
+    g_full = eng.flat.grads.clone()
+    assert torch.isfinite(g_full).all() and g_full.abs().max() > 0
+    eng.flat.zero_grad()
+    n_a = int((data["part_valids"][:16].bool() & ~ref[:16].bool()).sum())
+    n_b = n_full - n_a
+    loss_a, _ = grads_of(slice(0, 16), n_a / n_full)
+    loss_b, _ = grads_of(slice(16, 32), n_b / n_full)
+    torch.cuda.synchronize()
+    g_split = eng.flat.grads.clone()
+    assert abs((n_a * loss_a + n_b * loss_b) / n_full - loss_full) < 1e-5 * loss_full
+    for name in eng.flat.order:
+        a, b = eng.flat.view(g_full, name), eng.flat.view(g_split, name)
+        assert (a - b).abs().max() <= 2e-4 * max(a.abs().max().item(), 1e-6), name
+    # dropouts on: the same seed repeats the iteration to rounding (counter-based masks; only atomic summation order may differ)
+    outs = []
+    for _ in range(2):
+        eng.flat.zero_grad()
+        outs.append(float(eng.loss_and_grads(noisy, t, latent, xyz, data["part_valids"], data["part_scale"], ref, noise, seed=5)))
+        torch.cuda.synchronize()
+        outs.append(eng.flat.grads.clone())
+    assert outs[0] == pytest.approx(outs[2], rel=1e-6)
+    assert (outs[1] - outs[3]).abs().max() <= 1e-5 * outs[1].abs().max()
+
+
 def test_feature_pipeline_equals_inline_encoder(weights_sd, dev):
     """the encoder of iteration i+1 issued on its own stream during iteration i yields the same features, losses and
     encoder buffers as running it in line (same (noise, t) draws)"""

@@ -20,7 +20,7 @@ def test_rotate_matches_golden_and_c(golden, oracle_lib):
 
 def test_encoder_stages_match_golden(golden, weights_sd, oracle_lib):
     sd = weights_sd("vqvae")
-    for tag in ("float", "grid"):
+    for tag in ("float", "grid", "ref"):      # "ref": the reference shape, F = 4 fragments x N = 1000 points
         g = golden(f"encoder_{tag}")
         cap = {}
         out = O.vqvae_encode(sd, T(g["pts"]), capture=cap)
@@ -118,3 +118,28 @@ def test_quaternion_roundtrip():
     assert torch.allclose(O.matrix_to_quaternion(m), q, atol=1e-5)
     p = torch.randn(100, 3)
     assert torch.allclose(O.quaternion_apply(q, p), (m @ p[..., None])[..., 0], atol=1e-5)
+
+
+def test_aggl_glue_oracle_vs_reference_golden(golden):
+    """oracle restatements of the auto-agglomerative glue == the reference's own functions (fixture written by
+    tools/make_goldens.py from utils/node_merge_utils.py:16-53,62-89,225-306 and auto_aggl.py:195-201,385-389)"""
+    from oracle import pfpp_oracle as O
+
+    g = golden("aggl_glue")
+    T = torch.from_numpy
+    assert torch.equal(O.get_final_pose_pts(T(g["pts"]), T(g["trans"]), T(g["rots"])), T(g["final_pts"]))
+    pose = torch.cat([T(g["dyn_trans"]), T(g["dyn_rots"])], -1)
+    dyn = O.pose_apply_points(T(g["area"]), T(g["pose_idx"]), pose)
+    assert torch.equal(dyn, T(g["dyn_pts"]))
+    hist = O.edge_histogram(dyn, T(g["idx_a"]), T(g["idx_b"]), T(g["edge_off"]))
+    assert np.array_equal(hist.numpy(), g["bins"])
+    ef, eidx = O.edge_features_from_hist(T(g["hist_pp"]))
+    assert np.array_equal(ef.numpy(), g["edge_features"]) and np.array_equal(eidx.numpy(), g["edge_indices"])
+    P = g["pivots"].shape[0]
+    nodes = {i: dict(pivot=int(g["pivots"][i]), init_pose=None) for i in range(P)}
+    for comp, cen, tr, ro in zip(g["merge_components"], g["merge_centroids"], g["merge_trans"], g["merge_rots"]):
+        O.assign_init_pose(nodes, T(tr), T(ro), T(cen), [int(c) for c in comp if c >= 0])
+    init = torch.stack([nodes[i]["init_pose"] if nodes[i]["init_pose"] is not None else torch.zeros(4, 4) for i in range(P)])
+    assert np.abs(init.numpy() - g["init_pose"]).max() == 0
+    comp = O.pose_compose(T(g["param"]), g["pivots"].tolist(), init.reshape(P, 16), T(g["has_init"]))
+    assert np.abs(comp.numpy() - g["composed"]).max() < 1e-6

@@ -197,6 +197,7 @@ def install_standins():
     p3t.quaternion_apply = _O.quaternion_apply
     p3t.quaternion_to_matrix = _O.quaternion_to_matrix
     p3t.matrix_to_euler_angles = matrix_to_euler_angles
+    p3t.matrix_to_quaternion = _O.matrix_to_quaternion
     p3d.transforms = p3t
     p3o = types.ModuleType("pytorch3d.ops")
     p3o.estimate_pointcloud_normals = lambda pts, neighborhood_size=50, **kw: _O.estimate_normals(pts, neighborhood_size)
@@ -248,14 +249,15 @@ def main():
     # ============================ encoder =======================================================
     data = synthetic.make_batch(7, 1, num_points=512, num_parts=3)
     dataq = synthetic.make_batch(7, 1, num_points=512, num_parts=3, quantise_bits=9)
+    data_ref = synthetic.make_batch(11, 1, num_points=1000, num_parts=4)          # the reference's own shape: N = 1000 (pn2.py:16-18), F = 4
     x = torch.randn(1, 20, 7)
     enc_ref = VQVAE(cfg)
     enc_sd = weights.vqvae_state_dict()
     enc_ref.load_state_dict(enc_sd, strict=True)
     enc_ref.eval()
-    for tag, d in (("float", data), ("grid", dataq)):
+    for tag, d in (("float", data), ("grid", dataq), ("ref", data_ref)):
         valid = d["part_valids"].bool()
-        pts = O.apply_rots(d["part_pcs"], x)[valid] if tag == "float" else d["part_pcs"][valid]
+        pts = O.apply_rots(d["part_pcs"], x)[valid] if tag != "grid" else d["part_pcs"][valid]
         # stage-level reference outputs straight from the reference functions
         cap = {}
         xyz_l, feats_cf = pts, None
@@ -456,6 +458,122 @@ def main():
           f"{ds_ref.shape[0]} points")
     np.savez_compressed(GOLD / "merge.npz", parts=mparts.numpy(), start=np.int64(start_used), merged=ds_ref.numpy(),
                         normals=nrm_o.numpy())
+
+    # ============================ a19 / 8f-1: the reference's own glue of the auto-agglomerative loop ============
+    # utils/node_merge_utils.py:16-53 (pose application), :62-89 (matched-point distances), :225-306 (init-pose bookkeeping,
+    # composed poses) and auto_aggl.py:195-201,385-389 (bins, normalisation) run verbatim on the pytorch3d / chamferdist
+    # stand-ins; what the fixture pins is everything the reference owns around those calls: pivot indexing, the order of the
+    # affine products, normalise-or-not, index arithmetic of the matching data, bin edges, the count column.
+    import networkx as nx
+    import inspect
+    import textwrap
+    for name in ("lightning", "lightning.pytorch", "hydra"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.LightningModule = nn.Module
+            sys.modules[name] = m
+    sys.modules["lightning"].pytorch = sys.modules["lightning.pytorch"]
+    import puzzlefusion_plusplus.auto_aggl as ref_aggl
+    gg = torch.Generator().manual_seed(4242)
+    Bg, Pg, Ng = 2, 5, 40
+    pts_g = torch.rand(Bg, Pg, Ng, 3, generator=gg) - 0.5
+    tr_g = torch.randn(Bg, Pg, 3, generator=gg) * 0.3
+    ro_g = torch.randn(Bg, Pg, 4, generator=gg)                                  # not normalised on purpose
+    fin_ref = ref_merge.get_final_pose_pts(pts_g, tr_g, ro_g)
+    assert maxdiff(O.get_final_pose_pts(pts_g, tr_g, ro_g), fin_ref) == 0
+    # by-area cloud of one puzzle: 5 parts, merged nodes share a pivot
+    n_pcs = torch.tensor([[30, 50, 20, 60, 40]])
+    pivots = [0, 0, 2, 3, 3]
+    G = nx.Graph()
+    for i, pv in enumerate(pivots):
+        G.add_node(i, pivot=pv, valids=True, ref_part=False, init_pose=None, trans_and_rots=[])
+    ptr_g = torch.randn(1, Pg, 3, generator=gg) * 0.2
+    pro_g = torch.nn.functional.normalize(torch.randn(1, Pg, 4, generator=gg), dim=-1) * 1.3     # quaternion_apply does not normalise
+    # world-frame points with neighbours at every distance scale the bins separate (squared distances 1e-4 .. 0.3), pulled back
+    # through the inverse poses: x = conj(q) (w - t) q / |q|^4
+    world = (torch.rand(int(n_pcs.sum()), 3, generator=gg) - 0.5) * 0.5
+    wst = [0] + n_pcs[0].cumsum(0).tolist()
+    for (dst_part, src_part) in ((1, 0), (3, 2), (4, 3)):
+        m = min(int(n_pcs[0, dst_part]), int(n_pcs[0, src_part]))
+        scale = torch.tensor([0.004, 0.02, 0.05, 0.12, 0.25])[torch.arange(m) % 5].unsqueeze(-1)
+        world[wst[dst_part]: wst[dst_part] + m] = world[wst[src_part]: wst[src_part] + m] + torch.nn.functional.normalize(
+            torch.randn(m, 3, generator=gg), dim=-1) * scale
+    piv_of_pt = torch.cat([torch.full((int(n),), pivots[i]) for i, n in enumerate(n_pcs[0])])
+    qv = pro_g[0][piv_of_pt].double()
+    qinv = qv * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=torch.float64) / (qv * qv).sum(-1, keepdim=True)
+    area = O.quaternion_apply(qinv, world.double() - ptr_g[0][piv_of_pt].double()).float().unsqueeze(0)
+    dyn_ref = ref_merge.get_final_pose_pts_dynamic(area, n_pcs, ptr_g, pro_g, torch.tensor([Pg]), G.nodes)
+    pose_idx = torch.cat([torch.full((int(n),), pivots[i], dtype=torch.int32) for i, n in enumerate(n_pcs[0])])
+    dyn_o = O.pose_apply_points(area[0], pose_idx, torch.cat([ptr_g[0], pro_g[0]], -1))
+    assert maxdiff(dyn_o, dyn_ref) == 0, "oracle pose_apply_points != reference get_final_pose_pts_dynamic"
+    # matched points of three candidate edges
+    n_crit = torch.tensor([[12, 20, 9, 25, 16]])
+    starts = [0] + n_pcs[0].cumsum(0).tolist()[:-1]
+    crit_idx = torch.zeros(1, int(n_pcs.sum()), dtype=torch.int64)
+    for i in range(Pg):
+        crit_idx[0, starts[i]: starts[i] + int(n_crit[0, i])] = torch.arange(int(n_crit[0, i]))      # the first points of a part are its critical ones
+    edges_g = [(1, 0), (3, 2), (4, 3)]                                          # (idx2, idx1) as stored in matching_data
+    corr_g = [torch.stack([torch.randint(0, int(n_crit[0, e[1]]), (m,), generator=gg),
+                           torch.randint(0, int(n_crit[0, e[0]]), (m,), generator=gg)], -1) for e, m in zip(edges_g, (17, 6, 31))]
+    cds, bins_ref = [], []
+    fake_self = NS(device="cpu")
+    for (i2, i1), cr in zip(edges_g, corr_g):
+        cd = ref_merge.get_distance_for_matching_pts(i1, i2, dyn_ref, n_pcs, n_crit, crit_idx, [cr], None, _CD())
+        cds.append(cd[0])
+        bins_ref.append(ref_aggl.AutoAgglomerative._make_cd_to_bins(fake_self, cd))
+    bins_ref = torch.stack(bins_ref)
+    idx_a = torch.cat([starts[i1] + crit_idx[0, starts[i1]: starts[i1] + int(n_crit[0, i1])][cr[:, 0]] for (i2, i1), cr in zip(edges_g, corr_g)]).to(torch.int32)
+    idx_b = torch.cat([starts[i2] + crit_idx[0, starts[i2]: starts[i2] + int(n_crit[0, i2])][cr[:, 1]] for (i2, i1), cr in zip(edges_g, corr_g)]).to(torch.int32)
+    edge_off = torch.tensor([0] + torch.tensor([c.shape[0] for c in corr_g]).cumsum(0).tolist(), dtype=torch.int32)
+    hist_o = O.edge_histogram(dyn_ref, idx_a, idx_b, edge_off)
+    assert torch.equal(hist_o.long(), bins_ref.long()), "oracle edge_histogram != reference get_distance_for_matching_pts + _make_cd_to_bins"
+    # flatten / normalise / count column: auto_aggl.py:195-201 executed from the reference's own source text
+    src_lines = inspect.getsource(ref_aggl.AutoAgglomerative.test_step).splitlines()
+    first = next(i for i, l in enumerate(src_lines) if "mat_mask = torch.triu" in l)
+    last = next(i for i, l in enumerate(src_lines) if "edge_features = torch.cat((edge_features, num_points)" in l)
+    block = textwrap.dedent("\n".join(src_lines[first:last + 1]))
+    ef = torch.zeros(1, Pg, Pg, 6, dtype=torch.int32)
+    for (i2, i1), b in zip(edges_g, bins_ref):
+        ef[0, i1, i2] = b.to(torch.int32)
+    ns = dict(torch=torch, P=Pg, B=1, edge_features=ef.clone(), num_parts=torch.tensor([Pg]),
+              self=NS(device="cpu", _get_edge_mask=lambda num_parts, P: torch.ones(1, P * (P - 1) // 2, dtype=torch.bool)))
+    exec(block, ns)
+    ef_ref, eidx_ref = ns["edge_features"], ns["edge_indices"]
+    ef_o, eidx_o = O.edge_features_from_hist(ef)
+    assert maxdiff(ef_o, ef_ref) == 0 and torch.equal(eidx_o, eidx_ref)
+    # three merges, then the composed poses of get_param / extract_final_pred_trans_rots
+    nodes_ref = {i: dict(pivot=pv, init_pose=None) for i, pv in enumerate(pivots)}
+    nodes_o = {i: dict(pivot=pv, init_pose=None) for i, pv in enumerate(pivots)}
+    merges = [([0, 1], torch.tensor([0.05, -0.02, 0.01])), ([3, 4], torch.tensor([-0.1, 0.0, 0.03])), ([0, 1, 2], torch.tensor([0.02, 0.04, -0.06]))]
+    merge_tr = [torch.randn(Pg, 3, generator=gg) * 0.2 for _ in merges]
+    merge_ro = [torch.nn.functional.normalize(torch.randn(Pg, 4, generator=gg), dim=-1) for _ in merges]
+    for (comp, cen), t_, r_ in zip(merges, merge_tr, merge_ro):
+        ref_merge.assign_init_pose(nodes_ref, t_, r_, cen, comp)
+        O.assign_init_pose(nodes_o, t_, r_, cen, comp)
+    init_ref = torch.stack([nodes_ref[i]["init_pose"] if nodes_ref[i]["init_pose"] is not None else torch.zeros(4, 4) for i in range(Pg)])
+    has_init = torch.tensor([nodes_ref[i]["init_pose"] is not None for i in range(Pg)])
+    init_o = torch.stack([nodes_o[i]["init_pose"] if nodes_o[i]["init_pose"] is not None else torch.zeros(4, 4) for i in range(Pg)])
+    assert maxdiff(init_o, init_ref) == 0, "oracle assign_init_pose != reference"
+
+    class _Nodes:                                   # networkx NodeView call signature: nodes(data=True) -> (index, attributes)
+        def __init__(self, d): self.d = d
+        def __call__(self, data=True): return list(self.d.items())
+    param = torch.cat([torch.randn(Pg, 3, generator=gg) * 0.2, torch.nn.functional.normalize(torch.randn(Pg, 4, generator=gg), dim=-1)], -1)
+    gp_ref = ref_merge.get_param(param, _Nodes(nodes_ref))
+    ft_ref, fr_ref = ref_merge.extract_final_pred_trans_rots(param[:, :3], param[:, 3:], _Nodes(nodes_ref))
+    gp_o = O.pose_compose(param, pivots, init_ref.reshape(Pg, 16), has_init)
+    assert maxdiff(gp_o, gp_ref) < 1e-6 and maxdiff(gp_o, torch.cat([ft_ref, fr_ref], -1)) < 1e-6, "oracle pose_compose != reference get_param"
+    print(f"[aggl glue] oracle == reference: get_final_pose_pts(_dynamic), matched-point bins {bins_ref.tolist()}, edge-feature "
+          f"normalisation, 3-merge init_pose chain, get_param / extract_final_pred_trans_rots (max diff {maxdiff(gp_o, gp_ref):.1e})")
+    np.savez_compressed(
+        GOLD / "aggl_glue.npz", pts=pts_g.numpy(), trans=tr_g.numpy(), rots=ro_g.numpy(), final_pts=fin_ref.numpy(),
+        area=area[0].numpy(), n_pcs=n_pcs.numpy(), pivots=np.array(pivots, dtype=np.int32), dyn_trans=ptr_g[0].numpy(), dyn_rots=pro_g[0].numpy(),
+        dyn_pts=dyn_ref.numpy(), pose_idx=pose_idx.numpy(), idx_a=idx_a.numpy(), idx_b=idx_b.numpy(), edge_off=edge_off.numpy(),
+        cd_per_point=torch.cat(cds).numpy(), bins=bins_ref.numpy().astype(np.int32), hist_pp=ef.numpy(), edge_features=ef_ref.numpy(),
+        edge_indices=eidx_ref.numpy(), merge_components=np.array([c + [-1] * (3 - len(c)) for c, _ in merges], dtype=np.int32),
+        merge_centroids=torch.stack([c for _, c in merges]).numpy(), merge_trans=torch.stack(merge_tr).numpy(),
+        merge_rots=torch.stack(merge_ro).numpy(), init_pose=init_ref.numpy(), has_init=has_init.numpy(), param=param.numpy(),
+        composed=gp_ref.numpy(), final_trans=ft_ref.numpy(), final_rots=fr_ref.numpy())
 
     # ============================ 8f-4: dataset classes on the reference's on-disk formats ======================
     import subprocess, tempfile
