@@ -37,11 +37,17 @@ def instantiate(node, *args):
     an importlib lookup when hydra is absent."""
     try:  # pragma: no cover
         import hydra
+    except ImportError:
+        hydra = None
+    if hydra is not None:  # pragma: no cover
+        return hydra.utils.instantiate(node, *args)         # constructor / config errors propagate as they are
+    import importlib
 
-        return hydra.utils.instantiate(node, *args)
-    except Exception:  # noqa: BLE001
-        import importlib
-
-        target = getattr(node, "_target_", None) or node["_target_"]
-        mod, _, name = target.rpartition(".")
-        return getattr(importlib.import_module(mod), name)(*args)
+    get = node.get if hasattr(node, "get") else (lambda k, d=None: getattr(node, k, d))
+    target = get("_target_")
+    if target is None:
+        raise ValueError("instantiate: the config node has no _target_")
+    keys = list(node.keys()) if hasattr(node, "keys") else [k for k in vars(node)]
+    kwargs = {k: get(k) for k in keys if not str(k).startswith("_")}
+    mod, _, name = target.rpartition(".")
+    return getattr(importlib.import_module(mod), name)(*args, **kwargs)

@@ -73,12 +73,16 @@ class GradExchange:
         # gradients in only `batch` of their 3072 rows per step, so the ranks exchange those rows instead (gather_rows)
         self.sparse_range = sparse_range
         self._handles: List[object] = []
+        self.enabled = True          # False: the owner accumulates locally (DenoiserTrainEngine.no_sync), nothing is reduced
 
     @staticmethod
     def active() -> bool:
         import torch.distributed as dist
 
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def reducing(self) -> bool:
+        return self.enabled and self.active()
 
     def _reduce(self, a: int, b: int) -> None:
         import torch.distributed as dist
@@ -87,14 +91,16 @@ class GradExchange:
             self._handles.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def layer_done(self, i: int) -> None:
-        if self.active():
+        if self.reducing():
             self._reduce(*self.layer_ranges[i])
 
-    def all_done(self) -> None:
-        if self.active():
+    def all_done(self, dense: bool = False) -> None:
+        """the slices outside the layers.  dense = True also reduces the sparse range (gradient accumulation: the table rows of
+        several micro-batches were scatter-added locally, there is no single (rows, index) pair to exchange)"""
+        if self.reducing():
             a, b = self.sparse_range
             first = self.layer_ranges[0][0]
-            if b > a:
+            if b > a and not dense:
                 self._reduce(0, a)
                 self._reduce(b, first)
             else:
@@ -117,6 +123,9 @@ class GradExchange:
     def finish(self) -> float:
         import torch.distributed as dist
 
+        """wait for the reductions; returns the factor that turns the summed gradients into the mean.  Call it (through
+        DenoiserTrainEngine.finish_grad_exchange) before reading gradients for clipping / logging: until then they are summed,
+        not averaged, and reductions may still be in flight."""
         for h in self._handles:
             h.wait()
         self._handles = []

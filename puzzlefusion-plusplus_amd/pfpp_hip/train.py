@@ -119,7 +119,15 @@ class FlatParams:
         return flat[self.offset[first]: self.offset[first] + n].view(shape)
 
     def attach_grads(self) -> None:
-        """(re-)point every .grad at its slice of the flat gradient buffer (zero_grad(set_to_none) detaches them)"""
+        """(re-)point every .grad at its slice of the flat gradient buffer.  A parameter whose .grad is None was cleared by
+        someone else (module.zero_grad(), a foreign optimizer's zero_grad(set_to_none=True)): its slice still holds the previous
+        iteration's gradient and is zeroed here — the backward accumulates, and a silently doubled gradient is the alternative."""
+        dropped = [n for n in self.order if self.named[n].grad is None]
+        if len(dropped) == len(self.order):
+            self.grads.zero_()
+        else:
+            for n in dropped:
+                self.view(self.grads, n).zero_()
         for n in self.order:
             p = self.named[n]
             g = self.view(self.grads, n)
@@ -255,6 +263,9 @@ class DenoiserTrainEngine:
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
+        self._sync = True                            # False inside no_sync(): this backward does not start the gradient exchange
+        self._exchanged = False                      # the gradients in the flat buffer have been all-reduced since the last step
+        self._accumulated = False                    # a no_sync backward has accumulated into the buffer since the last step
 
     def single_stream(self) -> None:
         """everything on the caller's stream from now on (profiling / per-kernel timing)"""
@@ -466,8 +477,30 @@ class DenoiserTrainEngine:
         return ops.gemm(att, wo, M=M, N=C, K=C, lda=C, ldc=C, bias=bo, residual=h, ldr=C)
 
     # ------------------------------------------------------------------------------------------ backward
+    def no_sync(self):
+        """context manager for gradient accumulation across ranks: backwards inside it only accumulate locally; the first backward
+        outside it all-reduces the accumulated sum (same contract as DistributedDataParallel.no_sync)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = prev
+        return cm()
+
     def backward(self, ctx: TrainContext, dpred: torch.Tensor) -> None:
         """accumulate d(loss)/d(parameter) into the flat gradient buffer (= every parameter's .grad)"""
+        if self._exchange.active() and self._exchanged:
+            raise RuntimeError("DenoiserTrainEngine.backward: the flat gradient buffer was already all-reduced in place by a previous "
+                               "backward of this step; a second backward would reduce the summed micro-batch again.  Accumulate with "
+                               "`with engine.no_sync():` around every backward but the last, or call optimizer_step() in between")
+        self._exchange.enabled = self._sync
+        self._exchanged = self._exchange.active() and self._sync
+        if self._exchange.active() and not self._sync:
+            self._accumulated = True             # this step's table gradients are no longer "the rows of one batch": exchange them densely
         self.flat.attach_grads()
         ops_ = self.flat.operands()
         w, g = ops_["w"], ops_["g"]
@@ -532,7 +565,7 @@ class DenoiserTrainEngine:
         dse = torch.empty_like(se)
         T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
                     sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
-        if self._sparse_tables and self._exchange.active():
+        if self._sparse_tables and self._exchange.reducing() and not self._accumulated:
             dse_all, t_all = self._exchange.gather_rows(dse, s["t64"], dim=1)       # [n_ada, world*B, C], [world*B]
             T.silu_embed_bwd(w["ada.tables"], t_all, dse_all, g["ada.tables"])
         else:
@@ -753,7 +786,7 @@ class DenoiserTrainEngine:
             with torch.cuda.stream(self._side):
                 self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, **self._armed)
             self._early.append(i)
-        if self._exchange.active():
+        if self._exchange.reducing():
             if self._side is None:
                 self._exchange.layer_done(i)
                 return
@@ -767,7 +800,7 @@ class DenoiserTrainEngine:
         self._flush_dw()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-        self._exchange.all_done()
+        self._exchange.all_done(dense=self._accumulated)
 
     def finish_grad_exchange(self) -> float:
         """wait for the gradient all-reduces; returns the factor that turns the summed gradients into the mean"""
@@ -792,6 +825,8 @@ class DenoiserTrainEngine:
         """AdamW over the flat buffer (configure_optimizers, denoiser.py:230-237) — one launch, or the ranges that an armed
         backward (arm_optimizer) has not updated yet"""
         g_scale = self.finish_grad_exchange()
+        self._exchanged = False
+        self._accumulated = False
         self.step_count += 1
         f = self.flat
         hp = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))

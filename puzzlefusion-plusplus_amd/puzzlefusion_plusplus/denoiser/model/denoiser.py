@@ -141,12 +141,27 @@ class Denoiser(LightningModule):
         self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list = [], [], [], []
         return tuple(total)
 
+    def on_fit_start(self):
+        """the training forward writes parameter gradients through its own kernels (one autograd node, pfpp_hip.train): torch
+        DistributedDataParallel sees no gradient hooks fire and would report unused parameters / skip the reduction.  The
+        data-parallel exchange is pfpp_hip.parallel.GradExchange (per-layer all-reduce of the flat gradient buffer during the
+        backward) — run one process per GPU with torch.distributed initialised and a single-device Lightning strategy."""
+        strategy = getattr(getattr(self, "trainer", None), "strategy", None)
+        name = type(strategy).__name__.lower() if strategy is not None else ""
+        if "ddp" in name or "fsdp" in name or "deepspeed" in name:
+            raise RuntimeError(f"Denoiser: Lightning strategy {type(strategy).__name__} wraps the module in a gradient-hook based "
+                               "reducer, which never sees the gradients of the HIP training path; use strategy='auto' per process — "
+                               "the gradient exchange is built in (pfpp_hip.parallel.GradExchange over torch.distributed / RCCL)")
+
     def configure_optimizers(self):
         # same hyper-parameters as the reference (denoiser.py:230-237) on the fused kernel; the frozen encoder
         # (train_denoiser.py:33-35) has no gradients and therefore no optimizer state in either implementation
         from pfpp_hip.optim import FusedAdamW
 
-        optimizer = FusedAdamW(self.denoiser.train_engine(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08)
+        # params = the whole module's parameter list, like the reference's AdamW(self.parameters()): same group order and
+        # length, so the optimizer state of a reference checkpoint loads positionally onto the right parameters
+        optimizer = FusedAdamW(self.denoiser.train_engine(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08,
+                               params=list(self.parameters()))
         sched_cfg = getattr(self.cfg.model, "lr_scheduler", None)
         if sched_cfg is None:
             return optimizer

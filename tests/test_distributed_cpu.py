@@ -21,14 +21,18 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 def _run_two_ranks(worker, timeout=120):
-    """spawn two ranks of `worker(rank, world, port, queue)` and return what rank 0 put on the queue; one retry on a fresh
+    return _run_ranks(worker, 2, timeout)
+
+
+def _run_ranks(worker, world, timeout=120):
+    """spawn `world` ranks of `worker(rank, world, port, queue)` and return what rank 0 put on the queue; one retry on a fresh
     port if the rendezvous fails (another process can grab the port between _free_port() and the bind of the store)"""
     last = None
     for attempt in range(2):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
         for p in procs:
             p.start()
         try:
@@ -44,7 +48,7 @@ def _run_two_ranks(worker, timeout=120):
             if p.is_alive():
                 p.terminate()
             p.join(timeout=30)
-    raise AssertionError(f"two-rank run failed twice: {last!r}")
+    raise AssertionError(f"{world}-rank run failed twice: {last!r}")
 
 
 def _worker(rank, world, port, out):
@@ -155,3 +159,87 @@ def test_grad_exchange_is_a_no_op_without_a_process_group():
     ex = GradExchange(g, [(2, 5)])
     ex.layer_done(0); ex.all_done()
     assert ex.finish() == 1.0 and torch.equal(g, torch.ones(10))
+
+
+def _eight_worker(rank, world, port, out):
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip.parallel import GradExchange, balanced_assignment, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # uneven "layers" (a gap between the head slice and the first layer, a tail behind the last), a sparse table in front
+    n = 4096
+    ranges = [(1000, 1700), (1700, 1701), (1701, 3000), (3000, 3900)]
+    grads = torch.zeros(n)
+    grads[640:] = (torch.arange(n - 640, dtype=torch.float32) % 97) * (rank + 1)
+    ex = GradExchange(grads, ranges, sparse_range=(0, 640))
+    idx = torch.tensor([rank, 20 + rank, 159 - rank])               # rows of a 160 x 4 table touched by this rank's batch
+    rows = torch.full((1, 3, 4), float(rank + 1))
+    for i in reversed(range(len(ranges))):
+        ex.layer_done(i)
+    rows_all, idx_all = ex.gather_rows(rows, idx, dim=1)
+    grads[:640].view(160, 4).index_add_(0, idx_all, rows_all[0])
+    ex.all_done()
+    scale = ex.finish()
+    a, b = shard_range(37, rank, world)
+    spans = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(spans, torch.tensor([a, b]))
+    if rank == 0:
+        out.put((grads.clone(), scale, [t.tolist() for t in spans], balanced_assignment([20, 2, 3, 19, 8, 8, 2, 5, 11, 4, 6, 2, 2, 3, 17, 9], world)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradient_exchange():
+    """BASELINE configs[3]'s world size on CPU (gloo): uneven layer slices, a one-element layer, sparse table rows from 8 ranks,
+    contiguous puzzle shards that cover 37 puzzles exactly once, fragment-balanced assignment"""
+    grads, scale, spans, assign = _run_ranks(_eight_worker, 8, timeout=240)
+    assert scale == 0.125
+    want = torch.zeros(4096)
+    want[640:] = (torch.arange(4096 - 640, dtype=torch.float32) % 97) * 36           # sum of (rank + 1) over 8 ranks
+    t = want[:640].view(160, 4)
+    for r in range(8):
+        for row in (r, 20 + r, 159 - r):
+            t[row] += r + 1
+    assert torch.equal(grads, want)
+    assert spans[0][0] == 0 and spans[-1][1] == 37 and all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    assert sorted(sum(assign, [])) == list(range(16))
+    counts = [20, 2, 3, 19, 8, 8, 2, 5, 11, 4, 6, 2, 2, 3, 17, 9]
+    loads = [sum(counts[i] for i in a) for a in assign]
+    assert max(loads) <= 20 and max(loads) - min(loads) <= 8        # no rank carries more than the largest puzzle's worth above the mean
+
+
+def _accum_worker(rank, world, port, out):
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip.parallel import GradExchange
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grads = torch.zeros(100)
+    ex = GradExchange(grads, [(40, 80)], sparse_range=(0, 20))
+    # micro-batch 1: accumulate locally (what DenoiserTrainEngine.no_sync() sets)
+    ex.enabled = False
+    grads += float(rank + 1)
+    ex.layer_done(0); ex.all_done(dense=True)
+    local_after_first = grads.clone()
+    # micro-batch 2: the syncing backward reduces the accumulated sum once, the table range densely
+    ex.enabled = True
+    grads += 10.0 * (rank + 1)
+    ex.layer_done(0); ex.all_done(dense=True)
+    scale = ex.finish()
+    if rank == 0:
+        out.put((local_after_first, grads.clone(), scale))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_accumulation_reduces_once():
+    """gradient accumulation across ranks: micro-batches before the last one only accumulate (no_sync), the last backward
+    all-reduces the accumulated buffer exactly once — including the otherwise row-exchanged table range"""
+    first, final, scale = _run_two_ranks(_accum_worker)
+    assert torch.equal(first, torch.ones(100))                      # rank 0's own first micro-batch, untouched by rank 1
+    assert torch.equal(final, torch.full((100,), 33.0)) and scale == 0.5      # (1 + 10) + (2 + 20)

@@ -220,6 +220,75 @@ def test_module_train_mode_autograd_and_optimizer(golden, weights_sd, dev):
     assert (e1 - t1).abs().max() > 0
 
 
+def test_reference_optimizer_checkpoint_loads_by_position(weights_sd, dev):
+    """the reference builds torch.optim.AdamW(self.parameters()) over the WHOLE Denoiser module (denoiser.py:230-237): transformer
+    parameters in registration order, then the frozen encoder's without state.  An optimizer state_dict of that layout loads into
+    Denoiser.configure_optimizers()'s FusedAdamW and every moment lands on the parameter of the same NAME (torch maps state by
+    position; norm1 / norm2 tables have identical shapes, so a permuted group would go unnoticed without this check)"""
+    from pfpp_hip import config
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev).train()
+    for p_ in model.encoder.parameters():
+        p_.requires_grad = False
+    names = [n for n, _ in model.named_parameters()]
+    # a "reference" optimizer state: plain torch AdamW over the module's parameters, one step on synthetic gradients
+    ref_opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for n, p_ in model.named_parameters():
+        if p_.requires_grad:
+            p_.grad = torch.randn(p_.shape, device=dev, generator=gen) * 1e-3
+    ref_opt.step()
+    sd = ref_opt.state_dict()
+    want = {names[i]: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in sd["state"].items()}
+    assert len(sd["param_groups"][0]["params"]) == len(names) and all(n.startswith("denoiser.") for n in want)
+    for p_ in model.parameters():
+        p_.grad = None
+    opt = model.configure_optimizers()
+    opt = opt["optimizer"] if isinstance(opt, dict) else opt
+    assert len(opt.param_groups[0]["params"]) == len(names)
+    opt.load_state_dict(sd)
+    flat = model.denoiser.train_engine().flat
+    for n in flat.order:
+        full = "denoiser." + n
+        assert torch.equal(flat.view(flat.exp_avg, n), want[full]["exp_avg"]), n
+        assert torch.equal(flat.view(flat.exp_avg_sq, n), want[full]["exp_avg_sq"]), n
+    assert model.denoiser.train_engine().step_count == 1
+    # and back: the state_dict written by the fused optimizer has the same positional layout
+    sd2 = opt.state_dict()
+    assert sd2["param_groups"][0]["params"] == sd["param_groups"][0]["params"] and sorted(sd2["state"]) == sorted(sd["state"])
+    # an optimizer over the transformer's parameters only refuses the reference layout loudly
+    from pfpp_hip.optim import FusedAdamW
+
+    with pytest.raises(ValueError, match="parameters"):
+        FusedAdamW(model.denoiser.train_engine()).load_state_dict(sd)
+
+
+def test_foreign_zero_grad_does_not_leave_stale_gradients(golden, weights_sd, dev):
+    """module.zero_grad() / another optimizer's zero_grad(set_to_none=True) sets every .grad to None; the next backward re-points
+    them at the flat buffer — which must then start from zero, not from the previous iteration's gradients"""
+    inp, noise, _ = golden_inputs(golden, dev)
+    m = make_module(weights_sd, dev)
+    eng = m.train_engine()
+    eng.loss_and_grads(*inp, noise, seed=3, train=False)
+    torch.cuda.synchronize()
+    g1 = eng.flat.grads.clone()
+    m.zero_grad(set_to_none=True)                       # what a generic training loop does
+    assert all(p.grad is None for p in m.parameters())
+    eng.loss_and_grads(*inp, noise, seed=3, train=False)
+    torch.cuda.synchronize()
+    assert rel(eng.flat.grads.cpu(), g1.cpu()) < 1e-5   # not 2 x g1
+    # dropping only some gradients clears only their slices: the others keep accumulating, like torch parameters do
+    m.ref_part_emb.weight.grad = None
+    eng.loss_and_grads(*inp, noise, seed=3, train=False)
+    torch.cuda.synchronize()
+    assert rel(eng.flat.view(eng.flat.grads, "ref_part_emb.weight").cpu(), eng.flat.view(g1, "ref_part_emb.weight").cpu()) < 1e-5
+    assert rel(eng.flat.view(eng.flat.grads, "shape_embedding.bias").cpu(), 2 * eng.flat.view(g1, "shape_embedding.bias").cpu()) < 1e-5
+
+
 def test_encoder_train_mode_batchnorm_vs_reference_golden(golden, weights_sd, dev):
     """the frozen encoder in .train() (batch-statistics BatchNorm, running buffers updated) against the reference
     module's outputs and buffers after two passes (tests/golden/encoder_train.npz)"""
@@ -295,9 +364,24 @@ def _ddp_worker(rank, world, port, out_q):
     inp = [torch.from_numpy(g[k])[rank:rank + 1].to(dev) for k in keys]          # rank r trains on puzzle r
     noise = torch.from_numpy(t["noise"])[rank:rank + 1].to(dev)
     eng.loss_and_grads(*inp, noise, train=False)
+    # a second backward on the already all-reduced buffer would reduce the first micro-batch twice: refused loudly
+    raised = False
+    try:
+        eng.loss_and_grads(*inp, noise, train=False)
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
     scale = eng.finish_grad_exchange()
+    mean = (eng.flat.grads.cpu() * scale).numpy()
+    eng.optimizer_step(lr=0.0, weight_decay=0.0)       # closes the step (lr 0: parameters unchanged)
+    # gradient accumulation: two micro-batches, the first under no_sync -> one exchange of the accumulated sum
+    eng.flat.zero_grad()
+    with eng.no_sync():
+        eng.loss_and_grads(*inp, noise, train=False)
+    eng.loss_and_grads(*inp, noise, train=False)
+    scale = eng.finish_grad_exchange()
+    accum = (eng.flat.grads.cpu() * scale).numpy()
     if rank == 0:
-        out_q.put((eng.flat.grads.cpu() * scale).numpy())
+        out_q.put(dict(mean=mean, accum=accum, raised=raised))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -317,7 +401,8 @@ def test_two_rank_data_parallel_gradients(golden, weights_sd, dev):
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
-    got = torch.from_numpy(q.get(timeout=600))
+    res = q.get(timeout=600)
+    got = torch.from_numpy(res["mean"])
     for p_ in procs:
         p_.join(timeout=120)
         assert p_.exitcode == 0
@@ -329,6 +414,10 @@ def test_two_rank_data_parallel_gradients(golden, weights_sd, dev):
         want = eng.flat.grads.cpu() if want is None else want + eng.flat.grads.cpu()
         del eng
     assert rel(got, want / 2) < 1e-5
+    # accumulation over two identical micro-batches per rank, exchanged once: twice the mean (in-place reduction of an
+    # accumulating buffer), and the un-flagged second backward was refused
+    assert res["raised"]
+    assert rel(torch.from_numpy(res["accum"]), want) < 1e-5
 
 
 def test_full_size_training_iteration_properties(weights_sd, dev):
