@@ -27,8 +27,6 @@
 #include "gemm_common.h"
 
 namespace pfpp_gemm_detail {
-int launch_f16x3_ring(const GemmP& p, int batch, hipStream_t st, int group_m);   // gemm_ring.hip
-int launch_f16x3_ws(const GemmP& p, int batch, hipStream_t st, int group_m);     // gemm_ws.hip
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant);   // gemm_pl.hip
 int launch_f16x3_planes_af32(const GemmP& p, int batch, hipStream_t st, int group_m);
 }
@@ -925,10 +923,6 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)
   const bool wide = a->N > 64 || a->act == PFPP_ACT_GEGLU;
   if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
-    // LDS-DMA ring variant (gemm_ring.hip): correct, but issue-bound by the per-wave A split (measured
-    // 151 vs 184 TFLOP/s on 16000x4096x512) — opt-in until activations arrive pre-split
-    static const bool apre_ring = getenv("PFPP_GEMM_APRE_RING") && atoi(getenv("PFPP_GEMM_APRE_RING")) == 1;
-    if (apre && apre_ring) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());   // all-DMA loop (measured slower)
     // LDS-DMA staged, software-pipelined plane kernel (gemm_pl.hip).  PFPP_GEMM_PL: 0 = off, 1..3 = force a tile, unset / -1 = by shape
     if (apre && !fused_bn && true) {
       const char* e = getenv("PFPP_GEMM_PL");
@@ -950,10 +944,6 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
     if (af32 && pre && !apre && !a->gather_idx && a->batch == 1 && a->M >= 65536 && a->K % 32 == 0 && a->K <= 256 && a->lda % 4 == 0 &&
         a->act != PFPP_ACT_GEGLU && !a->c_hi && (a->pool == 0 || a->pool == 32 || a->N > 64))
       return launch_f16x3_planes_af32(p, a->batch, st, gemm_group_m());
-    static const bool use_ring = getenv("PFPP_GEMM_RING") && atoi(getenv("PFPP_GEMM_RING")) == 1;
-    if (pre && wide && use_ring && a->K % 32 == 0 && !fused_bn && !a->gather_idx) return launch_f16x3_ring(p, a->batch, st, gemm_group_m());
-    static const bool use_ws = getenv("PFPP_GEMM_WS") && atoi(getenv("PFPP_GEMM_WS")) == 1;
-    if (pre && wide && use_ws && !fused_bn && !a->gather_idx) return launch_f16x3_ws(p, a->batch, st, gemm_group_m());
     static const bool big_tile = !(getenv("PFPP_GEMM_BIG") && atoi(getenv("PFPP_GEMM_BIG")) == 0);
     // 256x128 tile (8 waves): 1.33x more matrix work per byte staged; worth it when there are enough
     // row panels to fill the chip several times over

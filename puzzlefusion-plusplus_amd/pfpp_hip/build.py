@@ -26,8 +26,6 @@ SOURCES = {
     "attention.hip": [],
     "edgefeat.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
-    "gemm_ring.hip": [],
-    "gemm_ws.hip": [],
     "gemm_pl.hip": ["-munsafe-fp-atomics"] + (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
     "sa_fused.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],

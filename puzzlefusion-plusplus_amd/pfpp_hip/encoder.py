@@ -118,6 +118,7 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
                     feats: Optional[torch.Tensor], capture: Optional[dict] = None):
     """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3]"""
     F = xyz.shape[0]
+    ops.check_fps_ratio(npoint, xyz.shape[1])
     fps_idx, new_xyz = ops.fps(xyz, npoint)
     ball = ops.ball_query(xyz, new_xyz, radius, nsample)
     fused = GATHER_FUSED and ops.GEMM_MODE == "f16x3" and (feats is None or feats.shape[2] % 32 == 0)

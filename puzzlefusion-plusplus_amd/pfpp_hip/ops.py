@@ -96,6 +96,18 @@ def fps(xyz: torch.Tensor, npoint: int, start: Optional[torch.Tensor] = None):
     return idx, new_xyz
 
 
+def check_fps_ratio(npoint: int, N: int) -> None:
+    """The reference does not ask torch_cluster.fps for `npoint` samples but for the RATIO npoint / N as a float64 tensor
+    (utils/pn2_utils.py:131-134), and torch_cluster takes ceil(ratio * N) points per cloud.  For the
+    reference's shapes the round trip is exact (256/1000, 128/256, 25/128; also N in {512, 1024, 2048}); for an N where it is
+    not, the reference would sample a different number of points than `npoint` and everything downstream would change shape —
+    refuse instead of silently diverging."""
+    m = int(torch.ceil(torch.tensor(npoint / N, dtype=torch.float64) * N).item())
+    if m != npoint:
+        raise ValueError(f"fps: ceil(float64({npoint}/{N}) * {N}) = {m} != {npoint}: the reference's torch_cluster.fps(ratio=npoint/N) "
+                         f"call would return {m} points per cloud for this N")
+
+
 def ball_query(xyz: torch.Tensor, new_xyz: torch.Tensor, radius: float, nsample: int) -> torch.Tensor:
     """-> idx int32 [F,S,nsample]  (include/pfpp.h a3).  r^2 is rounded to fp32 exactly as the
     reference's `sqrdists > radius ** 2` comparison does (python double -> float32 scalar)."""
@@ -146,7 +158,7 @@ PRECISION = {"f32": 0, "f16x3": 1}
 class SplitAct:
     """an activation travelling as split-f16 planes (hi, lo = x - hi), each fp16 [rows, C]: produced by the
     LayerNorm / attention kernels and GEMM epilogues, consumed as the A operand of the split-f16 GEMM with
-    no conversion work (csrc/gemm_ring.hip)"""
+    no conversion work (csrc/gemm_pl.hip)"""
 
     __slots__ = ("hi", "lo")
 

@@ -59,6 +59,7 @@ def sample_and_group(npoint: int, radius: float, nsample: int, xyz: torch.Tensor
     """xyz [B,N,3], points [B,N,D] -> new_xyz [B,S,3], new_points [B,S,ns,3+D] (rel_xyz first) (:115-152)"""
     xyz = xyz.contiguous()
     B, N, _ = xyz.shape
+    ops.check_fps_ratio(npoint, N)            # the reference samples ceil(float64(npoint / N) * N) points (:131-134)
     fps_idx, new_xyz = ops.fps(xyz, npoint)
     ball = ops.ball_query(xyz, new_xyz, radius, nsample)
     feats = points.contiguous() if points is not None else None
@@ -75,7 +76,9 @@ class PointNetSetAbstraction(nn.Module):
     """PointNet++ set-abstraction level (:175-216).  Parameters are the reference's
     (mlp_convs.{i}: Conv2d 1x1, mlp_bns.{i}: BatchNorm2d); forward runs
     FPS -> ball query -> grouping -> 3 x GEMM(+BN scale/shift, ReLU) -> max over nsample on the GPU.
-    BatchNorm uses its running statistics (eval mode): the encoder is frozen on this path."""
+    .eval(): BatchNorm folded into the GEMM epilogue from its running statistics.  .train(): batch statistics with the running
+    buffers updated in place (what the reference's frozen-but-train-mode encoder does, train_denoiser.py:33-35) through the
+    same fused-BatchNorm GEMM chain as pfpp_hip.encoder; forward only — parameters stay frozen on this path."""
 
     def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all=False):
         super().__init__()
@@ -107,17 +110,53 @@ class PointNetSetAbstraction(nn.Module):
 
         return self._cache.get(srcs, build)
 
+    def _train_pack(self):
+        """operands of the batch-statistics chain (pfpp_hip.encoder._sa_mlp_train): raw 1x1-conv weights as split planes and the
+        module's own BatchNorm tensors — the running buffers are updated in place through these references"""
+        srcs = [t for c in self.mlp_convs for t in (c.weight, c.bias)]
+
+        def build():
+            pk = {}
+            for i, c in enumerate(self.mlp_convs):
+                w = c.weight.detach().reshape(c.weight.shape[0], -1)
+                if i == 0:
+                    w = pack_sa_first(w, w.shape[1] - 3)
+                pk[f"sa.w{i}"] = PW(w.contiguous())
+                pk[f"sa.b{i}"] = c.bias.detach().contiguous()
+            return pk
+
+        if not hasattr(self, "_train_cache"):
+            self._train_cache = PackCache()
+        pk = dict(self._train_cache.get(srcs, build))
+        for i, b in enumerate(self.mlp_bns):
+            pk[f"sa.g{i}"], pk[f"sa.be{i}"] = b.weight.detach(), b.bias.detach()
+            pk[f"sa.rm{i}"], pk[f"sa.rv{i}"], pk[f"sa.nbt{i}"] = b.running_mean, b.running_var, b.num_batches_tracked
+        if not hasattr(self, "_train_stats"):
+            self._train_stats = {}
+        pk.update(self._train_stats)
+        return pk
+
     def forward_channels_last(self, xyz: torch.Tensor, feats: Optional[torch.Tensor]):
         """xyz [B,N,3], feats [B,N,D] -> new_xyz [B,S,3], new_feats [B,S,C] (the layout the kernels use)"""
-        if self.training and any(b.track_running_stats for b in self.mlp_bns):
-            raise RuntimeError("PointNetSetAbstraction (HIP): BatchNorm batch statistics are not implemented; "
-                               "call .eval() on the (frozen) encoder")
-        pk = self._packed()
         B = xyz.shape[0]
+        ops.check_fps_ratio(self.npoint, xyz.shape[1])
         _, new_xyz = ops.fps(xyz, self.npoint)
         ball = ops.ball_query(xyz, new_xyz, self.radius, self.nsample)
         h = ops.group_gather(xyz, new_xyz, feats, ball)
         n = len(self.mlp_convs)
+        if self.training:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise RuntimeError("PointNetSetAbstraction (HIP): the train-mode path is forward only (frozen encoder, "
+                                   "train_denoiser.py:33-35): set requires_grad=False on its parameters or run under no_grad")
+            if n != 3 or not all(b.track_running_stats for b in self.mlp_bns):
+                raise RuntimeError("PointNetSetAbstraction (HIP): train mode needs three conv/BatchNorm pairs with running statistics")
+            from pfpp_hip.encoder import _sa_mlp_train
+
+            pk = self._train_pack()
+            out = _sa_mlp_train(pk, "sa", h, self.nsample)
+            self._train_stats.update({k: v for k, v in pk.items() if ".stats" in k})      # statistics accumulators: allocated once
+            return new_xyz, out.view(B, self.npoint, -1)
+        pk = self._packed()
         for i in range(n):
             h = ops.linear(h, pk[f"w{i}"], scale=pk[f"s{i}"], shift=pk[f"t{i}"], act="relu",
                            pool=self.nsample if i == n - 1 else 0)

@@ -236,3 +236,50 @@ def test_on_disk_formats_round_trip(tmp_path):
                                      gt=np.zeros((pv, 7), np.float32), init_pose=np.zeros(7, np.float32), mesh_file_path="a/b", acc=0.5)
     assert [Path(f).name for f in files] == ["predict_0.5.npy", "gt.npy", "init_pose.npy", "mesh_file_path.txt"]
     assert np.load(files[0]).shape == (6, pv, 7)
+
+
+def test_dataset_dropins_equal_the_reference_loaders(golden, tmp_path):
+    """the drop-in GeometryLatentDataset / VerifierDataset read the reference's on-disk formats and return what
+    the REFERENCE's own dataset classes return on the same files and numpy seed (tests/golden/dataset.npz, written by
+    tools/make_goldens.py from puzzlefusion_plusplus/denoiser/dataset/dataset.py and verifier/dataset/dataset.py of the reference)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from types import SimpleNamespace as NS
+
+    import numpy as np
+
+    root = Path(__file__).resolve().parents[1]
+    subprocess.run([sys.executable, str(root / "tools" / "make_synthetic_dataset.py"), str(tmp_path), "--n", "3", "--points", "64"],
+                   check=True, capture_output=True)
+    from puzzlefusion_plusplus.denoiser.dataset.dataset import GeometryLatentDataset
+    from puzzlefusion_plusplus.verifier.dataset.dataset import VerifierDataset
+
+    g = golden("dataset")
+    cfg = NS(data=NS(max_num_part=20, matching_data_path=str(tmp_path / "matching_data")), model=NS(multiple_ref_parts=False))
+    checked = 0
+    for mode in ("test", "train"):
+        ds = GeometryLatentDataset(cfg, str(tmp_path / "pc_data" / "train"), -1, mode)
+        assert len(ds) == int(g[f"len_{mode}"])
+        for i in range(len(ds)):
+            np.random.seed(100 + i)
+            item = ds[i]
+            for k, v in item.items():
+                if k == "correspondences":
+                    cat = np.concatenate([np.asarray(c).reshape(-1, 2) for c in v]) if len(v) else np.zeros((0, 2), np.int64)
+                    assert np.array_equal(cat, g[f"{mode}{i}_corr_cat"]) and [len(c) for c in v] == g[f"{mode}{i}_corr_len"].tolist()
+                    checked += 1
+                elif f"{mode}{i}_{k}" in g:
+                    want = g[f"{mode}{i}_{k}"]
+                    got = np.asarray(v)
+                    assert got.shape == want.shape, (mode, i, k)
+                    assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1e-6, (mode, i, k)
+                    checked += 1
+            assert all(key.split("_", 1)[1] in item or key.endswith(("corr_cat", "corr_len")) for key in g if key.startswith(f"{mode}{i}_"))
+    vd = VerifierDataset(str(tmp_path / "verifier_data"), -1, "train")
+    assert len(vd) == int(g["len_verifier"])
+    for i in range(len(vd)):
+        for k, val in vd[i].items():
+            assert np.array_equal(np.asarray(val), g[f"v{i}_{k}"]), (i, k)
+            checked += 1
+    assert checked >= 60

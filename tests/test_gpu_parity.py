@@ -511,6 +511,45 @@ def test_pn2_utils_dropin_api(weights_sd, dev, oracle_lib):
     assert torch.equal(pu.index_points(feats.to(dev), idx).cpu(), O.index_points(feats, idx.cpu()))
 
 
+def test_pn2_set_abstraction_dropin_train_mode(golden, weights_sd, dev):
+    """utils.pn2_utils.PointNetSetAbstraction in .train(): batch-statistics BatchNorm with the running buffers updated (the
+    frozen-but-train-mode encoder of train_denoiser.py:33-35), same kernels and results as pfpp_hip.encoder's train path; the
+    FPS count check of the reference's ratio arithmetic (pn2_utils.py:131-134)"""
+    import utils.pn2_utils as pu
+    from pfpp_hip import encoder as E
+    from pfpp_hip import ops
+
+    sd = dsd(weights_sd("vqvae"), dev)
+    sa = pu.PointNetSetAbstraction(256, 0.2, 32, 3, [64, 64, 128]).to(dev)
+    sa.load_state_dict({k[len("pn2.sa1."):]: v for k, v in sd.items() if k.startswith("pn2.sa1.")}, strict=True)
+    for p_ in sa.parameters():
+        p_.requires_grad = False
+    pts = T(golden("encoder_float")["pts"]).to(dev)                       # [3, 512, 3]
+    sa.train()
+    rm0, nbt0 = sa.mlp_bns[1].running_mean.clone(), int(sa.mlp_bns[1].num_batches_tracked)
+    new_xyz, feats = sa(pts.permute(0, 2, 1).contiguous(), None)
+    assert new_xyz.shape == (3, 3, 256) and feats.shape == (3, 128, 256) and torch.isfinite(feats).all()
+    assert not torch.equal(sa.mlp_bns[1].running_mean, rm0) and int(sa.mlp_bns[1].num_batches_tracked) == nbt0 + 1
+    pk = E.pack_encoder_train({k: v.clone() for k, v in sd.items()})
+    xyz2, f2 = E.set_abstraction(pk, "sa1", 256, 0.2, 32, pts, None)
+    assert torch.equal(new_xyz.permute(0, 2, 1), xyz2)
+    assert (feats.permute(0, 2, 1) - f2).abs().max() < 1e-5
+    assert (sa.mlp_bns[1].running_mean - pk["sa1.rm1"]).abs().max() < 1e-6 and (sa.mlp_bns[2].running_var - pk["sa1.rv2"]).abs().max() < 1e-6
+    sa.eval()
+    _, feats_eval = sa(pts.permute(0, 2, 1).contiguous(), None)
+    assert (feats_eval - feats).abs().max() > 1e-3                          # folded running statistics != batch statistics
+    sa.train()
+    for p_ in sa.parameters():
+        p_.requires_grad = True
+    with pytest.raises(RuntimeError, match="forward only"):
+        sa(pts.permute(0, 2, 1).contiguous(), None)
+    # ceil(float64(npoint / N) * N) must reproduce npoint, as it does for the reference's shapes
+    for npoint, n in ((256, 1000), (128, 256), (25, 128), (256, 512), (256, 1024), (256, 2048)):
+        ops.check_fps_ratio(npoint, n)
+    with pytest.raises(ValueError, match="torch_cluster"):
+        ops.check_fps_ratio(7, 25)            # float64(7 / 25) * 25 = 7.000000000000001: torch_cluster would return 8 points
+
+
 def test_aggl_glue_vs_reference_golden(golden, dev):
     """the pose / matching / bookkeeping helpers of the auto-agglomerative loop against outputs of the reference's OWN functions
     (tests/golden/aggl_glue.npz: utils/node_merge_utils.py:16-53,62-89,225-306 and auto_aggl.py:195-201,385-389 run by

@@ -610,6 +610,33 @@ def main():
         print(f"[datasets] drop-in GeometryLatentDataset / VerifierDataset == the reference's on the same files and numpy seed "
               f"({len(ref_ds)} puzzles, test mode): max abs diff {worst:.2e}")
         assert worst < 1e-5
+    # fixture for the CPU test (tests/test_abi_and_host.py): what the REFERENCE's dataset classes return on the files
+    # `tools/make_synthetic_dataset.py <dir> --n 3 --points 64` writes (deterministic generator), numpy seed 100 + i per item
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([sys.executable, str(ROOT / "tools" / "make_synthetic_dataset.py"), td, "--n", "3", "--points", "64"], check=True)
+        dcfg = NS(data=NS(max_num_part=20, matching_data_path=td + "/matching_data"), model=NS(multiple_ref_parts=False))
+        fx = {}
+        for mode in ("test", "train"):
+            ref_ds = RefDS(dcfg, td + "/pc_data/train", -1, mode)
+            fx[f"len_{mode}"] = np.int64(len(ref_ds))
+            for i in range(len(ref_ds)):
+                np.random.seed(100 + i)
+                item = ref_ds[i]
+                for k, v in item.items():
+                    if k == "correspondences":
+                        fx[f"{mode}{i}_corr_cat"] = np.concatenate([np.asarray(c).reshape(-1, 2) for c in v]) if len(v) else np.zeros((0, 2), np.int64)
+                        fx[f"{mode}{i}_corr_len"] = np.array([len(c) for c in v], dtype=np.int64)
+                    elif isinstance(v, np.ndarray) and v.dtype != object:
+                        fx[f"{mode}{i}_{k}"] = v
+                    elif isinstance(v, (int, float, np.integer, np.floating, bool, np.bool_)):
+                        fx[f"{mode}{i}_{k}"] = np.asarray(v)
+        rv = RefVDS(td + "/verifier_data", -1, "train")
+        fx["len_verifier"] = np.int64(len(rv))
+        for i in range(len(rv)):
+            for k, val in rv[i].items():
+                fx[f"v{i}_{k}"] = np.asarray(val)
+        np.savez_compressed(GOLD / "dataset.npz", **fx)
+        print(f"[datasets] fixture: {len(fx)} arrays from the reference's GeometryLatentDataset (test + train mode) and VerifierDataset")
 
     # ============================ scheduler =====================================================
     sch_ref = PiecewiseScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
