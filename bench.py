@@ -13,11 +13,19 @@ reported under "extra" in the default mode.
 Workload shape on every GPU: 32 puzzles x 20 fragment slots x 1024 points, valid-fragment counts from
 SURVEY.md §8d's distribution.  N > 1: one process per GPU, different puzzles per rank (weak scaling).
 
+--mode stress: BASELINE configs[4] — 100 fragments per puzzle x 2048 points, one joint step = rotate + encode + DenoiserTransformer
++ scheduler step + VerifierTransformer on the 4,950 candidate edges, single-pass fp16 MFMA (PFPP_GEMM_F16) wherever both GEMM
+operands travel as split planes; the line carries max |pred_noise(single pass) - pred_noise(f16x3)| next to the throughput.
+Beyond the reference's max_len = 20: no reference parity exists for this shape, roofline only.
+
 Prints ONE JSON line (rank 0) with the extra objects:
-  roofline     — dominant kernel (fp32-MFMA GEMM): algorithmic FLOPs of its launches / their
-                 HIP-event durations, against the 157.3 TFLOP/s dense fp32 matrix peak
-  cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host on
-                 BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points), bounded sample
+  roofline     — dominant GEMM kernel of the step: algorithmic FLOPs of its launches / their HIP-event durations against the
+                 matrix-core ceiling of its arithmetic (f16 dense peak / 3 for the split-f16 kernels)
+  roofline_hbm — the bandwidth / latency regime (reported separately): FPS, ball query, rotate, VQ, LayerNorm,
+                 AdamW, scheduler step timed alone at the workload's shapes, algorithmic bytes / time against 8 TB/s, and the
+                 time per dependent argmax step of FPS
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host on BASELINE.json configs[0]
+                 (1 puzzle, 8 fragments x 512 points) following BASELINE.md §3 within a bounded budget
 """
 from __future__ import annotations
 
@@ -73,7 +81,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="puzzles per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=None, help="fix the number of valid fragments per puzzle")
-    ap.add_argument("--mode", choices=("train", "sample"), default="train")
+    ap.add_argument("--mode", choices=("train", "sample", "stress"), default="train")
+    ap.add_argument("--stress-batch", type=int, default=8, help="stress mode: puzzles per GPU (100 fragments x 2048 points each)")
     ap.add_argument("--latents-given", action="store_true",
                     help="train mode: skip the encoder (latents of the clean pose precomputed; not a reference mode)")
     ap.add_argument("--serial", action="store_true",
@@ -206,6 +215,237 @@ class TrainWorkload:
         self.i += 1
 
 
+class StressWorkload:
+    """BASELINE configs[4]: B puzzles x 100 fragments x 2048 points; one step = rotate + encode + denoise + scheduler step +
+    verifier forward on all 4,950 candidate edges of every puzzle (joint denoiser + verifier)"""
+
+    def __init__(self, batch: int, first_id: int, dev: torch.device, parts: int = 100, points: int = 2048):
+        from pfpp_hip import config, synthetic
+        from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+        from puzzlefusion_plusplus.verifier.model.modules.verifier_transformer import VerifierTransformer
+
+        torch.manual_seed(1234)
+        self.model = Denoiser(config.denoiser_config(model=dict(max_len=parts))).to(dev).eval()
+        self.verifier = VerifierTransformer(config.verifier_config(model=dict(max_len=parts))).to(dev).eval()
+        with torch.no_grad():
+            self.model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+        data = synthetic.make_batch(first_id, batch, num_points=points, max_parts=parts, num_parts=parts)
+        self.data = {k: v.to(dev) for k, v in data.items()}
+        self.n_frag = int(self.data["part_valids"].sum().item())
+        gt = torch.cat([self.data["part_trans"], self.data["part_rots"]], dim=-1).float().contiguous()
+        self.ref = self.data["ref_part"]
+        self.reference = torch.zeros_like(gt)
+        self.reference[self.ref] = gt[self.ref]
+        g = torch.Generator(device=dev).manual_seed(99 + first_id)
+        self.x0 = torch.randn(gt.shape, device=dev, generator=g)
+        self.x0[self.ref] = self.reference[self.ref]
+        self.noise = [torch.randn(gt.shape, device=dev, generator=g) for _ in range(20)]
+        self.timesteps = self.model.noise_scheduler.timesteps.tolist()
+        self.ts_dev = {t: torch.full((batch,), t, dtype=torch.int64, device=dev) for t in self.timesteps}
+        E = parts * (parts - 1) // 2
+        self.edge_idx = torch.triu(torch.ones(parts, parts, dtype=torch.bool), diagonal=1).nonzero()[None].expand(batch, E, 2).contiguous().to(dev)
+        self.edge_feat = torch.rand(batch, E, 7, device=dev, generator=g)
+        self.edge_valid = torch.ones(batch, E, device=dev)
+        self.x = self.x0.clone()
+        self.i = 0
+        self.last_eps = None
+
+    @torch.no_grad()
+    def step(self):
+        m, d = self.model, self.data
+        k = self.i % len(self.timesteps)
+        if k == 0:
+            self.x = self.x0.clone()
+        t = self.timesteps[k]
+        latent, xyz = m._extract_features(d["part_pcs"], d["part_valids"], self.x)
+        eps = m.denoiser(self.x, self.ts_dev[t], latent, xyz, d["part_valids"], d["part_scale"], self.ref)
+        self.x = m.noise_scheduler.step(eps, t, self.x, variance_noise=self.noise[k], ref_part=self.ref,
+                                        reference=self.reference).prev_sample
+        self.last_logits = self.verifier(self.edge_feat, self.edge_idx, self.edge_valid)
+        self.last_eps = eps
+        self.i += 1
+
+    @torch.no_grad()
+    def pred_noise_at_start(self):
+        m, d = self.model, self.data
+        t = self.timesteps[0]
+        latent, xyz = m._extract_features(d["part_pcs"], d["part_valids"], self.x0)
+        return m.denoiser(self.x0, self.ts_dev[t], latent, xyz, d["part_valids"], d["part_scale"], self.ref)
+
+
+def hbm_regime(dev, n_frag: int, points: int, tokens: int, n_params: int = 57_618_183, iters: int = 20):
+    """SURVEY.md §8d's second regime: the bandwidth / latency-bound kernels of the step timed alone at the workload's shapes (HIP
+    events on the launch stream), algorithmic bytes = what the kernel must read and write once"""
+    from pfpp_hip import ops
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = []
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e3 / iters          # us
+
+    def add(name, us, nbytes, **kw):
+        out.append(dict(kernel=name, us=round(us, 2), bytes=int(nbytes), GBps=round(nbytes / us * 1e-3, 1),
+                        frac=round(nbytes / us * 1e-3 / PEAK_HBM_GBS, 4), **kw))
+
+    pts = (torch.rand(n_frag, points, 3, device=dev, generator=g) * 2 - 1).contiguous()
+    pose = torch.randn(n_frag, 7, device=dev, generator=g)
+    slot = torch.arange(n_frag, dtype=torch.int32, device=dev)
+    add("se3_rotate_gather", timed(lambda: ops.se3_rotate_gather(pts, pose, slot)), n_frag * points * 24 + n_frag * 28)
+    levels = ((points, 256, 0.2, 32), (256, 128, 0.4, 64), (128, 25, 0.8, 64))
+    cur = pts
+    for n_in, s_out, radius, ns in levels:
+        us = timed(lambda: ops.fps(cur, s_out))
+        add(f"fps N={n_in}->{s_out}", us, n_frag * (n_in * 12 + s_out * 16), us_per_argmax_step=round(us / s_out, 4),
+            note="serial chain of dependent argmax steps per fragment: latency-bound by construction")
+        _, new_xyz = ops.fps(cur, s_out)
+        add(f"ball_query N={n_in} S={s_out} ns={ns}", timed(lambda: ops.ball_query(cur, new_xyz, radius, ns)),
+            n_frag * (n_in * 12 + s_out * 12 + s_out * ns * 4))
+        cur = new_xyz
+    z_e = torch.randn(n_frag, 25, 64, device=dev, generator=g)
+    cb = torch.rand(1024, 16, device=dev, generator=g) * 2 - 1
+    add("vq_encode", timed(lambda: ops.vq_encode(z_e, cb, slot, n_frag)), n_frag * 25 * 64 * 8 + 1024 * 16 * 4)
+    h = torch.randn(tokens, 512, device=dev, generator=g)
+    gam, bet = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+    add("layernorm [tokens, 512]", timed(lambda: ops.layernorm(h, gamma=gam, beta=bet)), tokens * 512 * 8)
+    xs = [torch.randn(max(1, tokens // 25), 7, device=dev, generator=g) for _ in range(4)]
+    coef = (0.5, 0.9, 0.3, 0.6, 0.1)
+    add("ddpm_step [fragments, 7]", timed(lambda: ops.ddpm_step(xs[0], xs[1], xs[2], None, None, coef)), xs[0].numel() * 16,
+        note="launch-latency bound: a few KB per call")
+    n8 = (n_params + 7) // 8 * 8
+    p_, g_, m_, v_ = (torch.randn(n8, device=dev, generator=g) * 0.01 for _ in range(4))
+    v_.abs_()
+    hi, lo = torch.empty(n8, dtype=torch.float16, device=dev), torch.empty(n8, dtype=torch.float16, device=dev)
+    add("adamw (57.6 M parameters, planes refreshed)",
+        timed(lambda: T.adamw(p_, g_, m_, v_, lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=3, hi=hi, lo=lo)),
+        n8 * 32)          # reads p, g, m, v; writes p, m, v and the two fp16 planes
+    return out
+
+
+def cpu_protocol(kind: str, budget_s: float = 45.0):
+    """BASELINE.md §3 on BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points, 20-step schedule, fixed injected noise) with the
+    CPU oracle (a port of the reference path, validated against the imported reference: tools/make_goldens.py): thread count
+    swept upward over {16, 32, physical cores} while it keeps paying off (1 warm-up + 2 timed steps each), then 3 warm-up + up to 10 timed steps at the best
+    setting (median and min), a one-step single-thread figure, and the encoder / transformer / scheduler split — all inside
+    `budget_s` of CPU time; whatever the budget cut short is said in `sample`."""
+    from oracle import pfpp_oracle as O
+    from oracle import weights
+    from pfpp_hip import synthetic
+
+    t_begin = time.perf_counter()
+    enc_sd, den_sd = weights.vqvae_state_dict(), weights.denoiser_state_dict()
+    batch = synthetic.make_batch(0, 1, num_points=512, num_parts=8)
+    g = torch.Generator().manual_seed(0)
+    sched = O.PiecewiseSchedule()
+    sched.set_timesteps(20)
+    ts_list = sched.timesteps.tolist()
+    ref = batch["ref_part"].bool()
+    gt = torch.cat([batch["part_trans"], batch["part_rots"]], dim=-1).float()
+    x0 = torch.randn(1, 20, 7, generator=g)
+    noises = [torch.randn(1, 20, 7, generator=g) for _ in range(20)]
+    train = kind == "train"
+    if train:
+        names = [k for k, v in den_sd.items() if v.dtype.is_floating_point and k != "pos_encoding.pe"]
+        sd = {k: v.clone() for k, v in den_sd.items()}
+        mom = [torch.zeros_like(sd[n]) for n in names]
+        var = [torch.zeros_like(sd[n]) for n in names]
+    state = {"x": x0.clone(), "i": 0}
+    split = {"encoder": 0.0, "transformer": 0.0, "scheduler": 0.0}
+
+    def one():
+        i = state["i"]
+        t0 = time.perf_counter()
+        if train:
+            noise = noises[i % 20]
+            t = torch.tensor([ts_list[i % 20]])
+            noisy = sched.add_noise(gt, noise, t)
+            noisy[ref] = gt[ref]
+            with torch.no_grad():
+                lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], noisy)
+            t1 = time.perf_counter()
+            req = {k: (w.clone().requires_grad_(True) if k in names else w) for k, w in sd.items()}
+            loss = O.denoiser_loss(O.denoiser_forward(req, noisy, t, lat, xyz, batch["part_valids"], batch["part_scale"], ref),
+                                   noise, batch["part_valids"], ref)
+            loss.backward()
+            t2 = time.perf_counter()
+            with torch.no_grad():
+                O.adamw_step([sd[n] for n in names], [req[n].grad for n in names], mom, var, i + 1)
+            t3 = time.perf_counter()
+        else:
+            t = ts_list[i % 20]
+            x = state["x"]
+            lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], x)
+            t1 = time.perf_counter()
+            eps = O.denoiser_forward(den_sd, x, torch.full((1,), t, dtype=torch.int64), lat, xyz, batch["part_valids"], batch["part_scale"], ref)
+            t2 = time.perf_counter()
+            state["x"] = sched.step(eps, t, x, noises[i % 20])
+            t3 = time.perf_counter()
+        split["encoder"] += t1 - t0; split["transformer"] += t2 - t1; split["scheduler"] += t3 - t2
+        state["i"] = i + 1
+        return t3 - t0
+
+    ncpu = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or ncpu
+    except Exception:  # noqa: BLE001
+        phys = ncpu
+    # ascending; a larger count is only tried while the previous one still paid off and the budget allows (oversubscribing a
+    # 1-puzzle step with hundreds of threads costs tens of seconds per step)
+    cands = sorted({c for c in (16, 32, phys) if 1 <= c <= ncpu})
+    sweep = {}
+    for c in cands:
+        if sweep and (time.perf_counter() - t_begin > 0.3 * budget_s or sweep[max(sweep)] > 1.2 * min(sweep.values())):
+            break
+        torch.set_num_threads(c)
+        one()
+        sweep[c] = min(one(), one())
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for k in split:
+        split[k] = 0.0
+    warm = 0
+    while warm < 3 and time.perf_counter() - t_begin < 0.45 * budget_s:
+        one(); warm += 1
+    for k in split:
+        split[k] = 0.0
+    times = []
+    while len(times) < 10 and time.perf_counter() - t_begin < 0.8 * budget_s:
+        times.append(one())
+    tot = sum(split.values()) or 1.0
+    shares = {k: round(v / tot, 3) for k, v in split.items()}
+    single = None
+    if time.perf_counter() - t_begin < 0.85 * budget_s:
+        torch.set_num_threads(1)
+        single = one()
+    torch.set_num_threads(best)
+    times.sort()
+    median = times[len(times) // 2] if times else sweep[best]
+    tmin = times[0] if times else sweep[best]
+    what = "training iterations (forward, autograd backward, AdamW)" if train else "DDPM sampler steps"
+    return {
+        "value": round(8 / median, 3), "unit": "fragment*steps/s", "cores": best, "kind": "port",
+        "median_s_per_step": round(median, 4), "min_s_per_step": round(tmin, 4), "best_value": round(8 / tmin, 3),
+        "thread_sweep_s_per_step": {str(c): round(v, 4) for c, v in sweep.items()},
+        "single_thread": None if single is None else {"s_per_step": round(single, 3), "value": round(8 / single, 3)},
+        "split": shares,
+        "sample": f"{warm} warm-up + {len(times)} timed {what} of 1 puzzle, 8 fragments x 512 pts (BASELINE configs[0]) at the best of "
+                  f"{sorted(sweep)} torch threads (= {best}; candidates {cands}) on {ncpu} logical CPUs; BASELINE.md §3 asks for 3 + 10, the {budget_s:.0f} s budget "
+                  f"allowed {warm} + {len(times)}; median over the timed steps; split = share of "
+                  + ("encode / forward+backward / AdamW" if train else "encode / transformer / scheduler step") + " time",
+    }
+
+
 def aggl_puzzles_per_s(dev, n_puzzles: int = 3, points: int = 1000, in_flight: int = 1):
     """BASELINE configs[2]-shaped: the full auto-agglomerative loop (denoise -> edge features -> verify -> promote/merge,
     auto_aggl.py:86-318) on single puzzles (batch 1 like the reference's test.py), 20 DDPM steps per outer iteration,
@@ -246,89 +486,6 @@ def aggl_puzzles_per_s(dev, n_puzzles: int = 3, points: int = 1000, in_flight: i
                     + "; full loop incl. verifier, promotion, merges and metrics"}
 
 
-def cpu_baseline_train(budget_s: float = 20.0, max_steps: int = 3):
-    """the CPU oracle on BASELINE.json configs[0] (1 puzzle, 8 fragments x 512 points): training iterations
-    (add_noise, encode, forward, loss, autograd backward, AdamW) in the reference's op order"""
-    from oracle import pfpp_oracle as O
-    from oracle import weights
-    from pfpp_hip import synthetic
-
-    enc_sd, den_sd = weights.vqvae_state_dict(), weights.denoiser_state_dict()
-    batch = synthetic.make_batch(0, 1, num_points=512, num_parts=8)
-    g = torch.Generator().manual_seed(0)
-    sched = O.PiecewiseSchedule()
-    gt = torch.cat([batch["part_trans"], batch["part_rots"]], dim=-1).float()
-    ref = batch["ref_part"].bool()
-    names = [k for k, v in den_sd.items() if v.dtype.is_floating_point and k != "pos_encoding.pe"]
-    sd = {k: v.clone() for k, v in den_sd.items()}
-    m = [torch.zeros_like(sd[n]) for n in names]
-    v = [torch.zeros_like(sd[n]) for n in names]
-
-    def one(step):
-        noise = torch.randn(1, 20, 7, generator=g)
-        t = torch.randint(0, 1000, (1,), generator=g)
-        noisy = sched.add_noise(gt, noise, t)
-        noisy[ref] = gt[ref]
-        with torch.no_grad():
-            lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], noisy)
-        req = {k: (w.clone().requires_grad_(True) if k in names else w) for k, w in sd.items()}
-        loss = O.denoiser_loss(O.denoiser_forward(req, noisy, t, lat, xyz, batch["part_valids"], batch["part_scale"], ref),
-                               noise, batch["part_valids"], ref)
-        loss.backward()
-        with torch.no_grad():
-            O.adamw_step([sd[n] for n in names], [req[n].grad for n in names], m, v, step)
-
-    one(1)   # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and (time.perf_counter() - t0) < budget_s:
-        one(n + 2)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {
-        "value": 8 * n / dt, "unit": "fragment*steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{n} training iterations (forward, autograd backward, AdamW) of 1 puzzle, 8 fragments x 512 pts "
-                  f"(BASELINE configs[0]), {dt:.1f} s on {os.cpu_count()} logical CPUs, torch threads {torch.get_num_threads()}",
-    }
-
-
-def cpu_baseline(budget_s: float = 12.0, max_steps: int = 4):
-    """the CPU oracle on BASELINE.json configs[0]: 1 puzzle, 8 fragments x 512 points, sampler steps"""
-    from oracle import pfpp_oracle as O
-    from oracle import weights
-    from pfpp_hip import synthetic
-
-    enc_sd, den_sd = weights.vqvae_state_dict(), weights.denoiser_state_dict()
-    batch = synthetic.make_batch(0, 1, num_points=512, num_parts=8)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 20, 7, generator=g)
-    noises = [torch.randn(1, 20, 7, generator=g) for _ in range(20)]
-    sched = O.PiecewiseSchedule()
-    sched.set_timesteps(20)
-    ref = batch["ref_part"].bool()
-    ts_list = sched.timesteps.tolist()
-
-    def one(i, x):
-        t = ts_list[i % 20]
-        lat, xyz = O.extract_features(enc_sd, batch["part_pcs"], batch["part_valids"], x)
-        eps = O.denoiser_forward(den_sd, x, torch.full((1,), t, dtype=torch.int64), lat, xyz, batch["part_valids"],
-                                 batch["part_scale"], ref)
-        return sched.step(eps, t, x, noises[i % 20])
-
-    x = one(0, x)  # warm-up (thread pools, allocator)
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and (time.perf_counter() - t0) < budget_s:
-        x = one(n + 1, x)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {
-        "value": 8 * n / dt, "unit": "fragment*steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{n} DDPM sampler steps of 1 puzzle, 8 fragments x 512 pts (BASELINE configs[0]), "
-                  f"{dt:.1f} s on {os.cpu_count()} logical CPUs, torch threads {torch.get_num_threads()}",
-    }
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -356,7 +513,11 @@ def main():
     from pfpp_hip import ops
 
     train = args.mode == "train"
-    if train:
+    stress = args.mode == "stress"
+    if stress:
+        ops.SINGLE_PASS = os.environ.get("PFPP_STRESS_F16X3", "0") != "1"       # single-pass fp16 on the plane GEMMs (configs[4])
+        wl = StressWorkload(args.stress_batch, first_id=1000 * rank, dev=dev)
+    elif train:
         wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given,
                            pipeline=not (args.no_pipeline or args.serial))
         if args.serial:
@@ -415,16 +576,17 @@ def main():
                 print(f"  {ms_ / args.steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // args.steps:3d}  {key}", file=sys.stderr)
         name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
-        split = "f16x3" in name or "gemm_grad" in name
+        single = "gemm_pl_kernel" in name and name.split(">")[0].rstrip().endswith("true")      # last template flag: single-pass fp16
+        split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name) and not single
         # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
         # FLOPs is the f16 dense peak / 3
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_src = pmc_traffic(name, "train" if train else "sampler")
+        peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)
+        traffic, traffic_src = pmc_traffic(name.split("+")[0].split("(")[0], "train" if train else ("stress" if stress else "sampler"))
         roofline = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product"
-                          if split else "fp32 MFMA dense peak"),
+            "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s (single-pass fp16)" if single else
+                          "f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product" if split else "fp32 MFMA dense peak"),
             "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
             "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
             "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if train else ""),
@@ -436,6 +598,24 @@ def main():
         }
 
     extra = {}
+    roofline_hbm = None
+    if rank == 0 and not args.no_roofline:
+        if stress:
+            roofline_hbm = hbm_regime(dev, wl.n_frag, 2048, wl.n_frag * 25)
+        else:
+            roofline_hbm = hbm_regime(dev, wl.n_frag, args.points, wl.n_frag * 25 if (train or args.compact) else args.batch * 20 * 25)
+    if stress and rank == 0:
+        # accuracy of the perf mode: the same first sampler step in the parity arithmetic (split-f16, 3 matrix instructions per product)
+        eps_fast = wl.pred_noise_at_start()
+        ops.SINGLE_PASS = False
+        eps_ref = wl.pred_noise_at_start()
+        ops.SINGLE_PASS = os.environ.get("PFPP_STRESS_F16X3", "0") != "1"
+        v = wl.data["part_valids"].bool()
+        extra["single_pass_vs_f16x3"] = {"max_abs_diff_pred_noise": float((eps_fast - eps_ref)[v].abs().max()),
+                                         "max_abs_pred_noise": float(eps_ref[v].abs().max()),
+                                         "note": "first sampler step, same inputs and weights; f16x3 is the parity mode (1e-4 vs the CPU oracle), "
+                                                 "single-pass fp16 the perf mode of BASELINE configs[4]"}
+        extra["verifier_edges_per_puzzle"] = int(wl.edge_feat.shape[1])
     if train and rank == 0:
         extra["final_loss"] = round(float(wl.last_loss), 5)
     if train and rank == 0 and world == 1 and not args.no_roofline and not args.latents_given:
@@ -477,7 +657,7 @@ def main():
         del swl
         extra["auto_aggl_full_loop"] = aggl_puzzles_per_s(dev)
         extra["auto_aggl_full_loop_batched"] = aggl_puzzles_per_s(dev, n_puzzles=64, in_flight=32)
-    if not train and rank == 0 and world == 1 and not args.compact and not args.no_roofline:
+    if not train and not stress and rank == 0 and world == 1 and not args.compact and not args.no_roofline:
         # the same K steps with the padded fragment slots dropped (outputs of valid fragments unchanged)
         wl.model.denoiser.compact_padded = True
         for _ in range(args.warmup):
@@ -494,7 +674,7 @@ def main():
                                  "note": "padded fragment slots dropped in the transformer; identical predictions for valid fragments"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_train() if train else cpu_baseline()
+        cpu = cpu_protocol("train" if train else "sample")
 
     if rank == 0:
         line = {
@@ -502,9 +682,14 @@ def main():
             "value": round(frag_steps / elapsed, 2), "unit": "fragment*steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (GEMMs: %s)" % ops.GEMM_MODE, "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 I/O (plane GEMMs: single-pass f16, fp32 accumulate; others f16x3)" if (stress and ops.SINGLE_PASS) else
+                      "f32 (GEMMs: %s)" % ops.GEMM_MODE), "data": "synthetic",
             "config": {
-                "workload": ("DDPM training iteration, BASELINE configs[1]: add_noise + rotate + frozen PointNet++/VQ encode"
+                "workload": "stress, BASELINE configs[4]: joint step = rotate + PointNet++/VQ encode + DenoiserTransformer + scheduler step + "
+                            "VerifierTransformer on all candidate edges; 100 fragments per puzzle x 2048 points (beyond the reference's "
+                            "max_len = 20: no reference parity, roofline only)" if stress else
+                            ("DDPM training iteration, BASELINE configs[1]: add_noise + rotate + frozen PointNet++/VQ encode"
                              + (" (skipped: latents given)" if args.latents_given else " (in the loop)") +
                              " + DenoiserTransformer forward (dropouts on) + MSE + full backward + "
                              + ("" if args.no_pipeline or args.latents_given else "[encoder of iteration i+1 issued on its own stream during iteration i] ")
@@ -513,14 +698,17 @@ def main():
                              "scheduler step), BASELINE configs[1] shape, inference forward"),
                 "padded_slots": ("not evaluated (their gradient contribution is exactly zero)" if train else
                                  "dropped (compact mode)" if args.compact else "evaluated like the reference"),
-                "puzzles_per_gpu": args.batch, "fragment_slots": 20, "points_per_fragment": args.points,
-                "valid_fragments_per_gpu": wl.n_frag, "puzzle_steps_per_s": round(args.batch * world * args.steps / elapsed, 2),
+                "puzzles_per_gpu": args.stress_batch if stress else args.batch, "fragment_slots": 100 if stress else 20,
+                "points_per_fragment": 2048 if stress else args.points,
+                "valid_fragments_per_gpu": wl.n_frag,
+                "puzzle_steps_per_s": round((args.stress_batch if stress else args.batch) * world * args.steps / elapsed, 2),
                 "weights": "random init, reference architecture (57.6M denoiser + 0.6M encoder params)",
                 "parallelism": (f"data parallel x {world} GPU(s): puzzles sharded, gradients all-reduced (RCCL) per layer "
                                 "during the backward" if train else
                                 f"independent puzzles x {world} GPU(s), no data-path collective"),
             },
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "cpu_baseline": cpu,
             "extra": extra,
         }

@@ -134,8 +134,10 @@ enum {
  *                   needs |x| < 65504; not available with w_kmajor.
  *                   W may be handed over pre-split (w_hi/w_lo: fp16 [N, ldw] planes, ldw = K rounded
  *                   up to 8 and zero padded) or as fp32 (split on the fly). */
-enum { PFPP_GEMM_F32 = 0, PFPP_GEMM_F16X3 = 1 };
+enum { PFPP_GEMM_F32 = 0, PFPP_GEMM_F16X3 = 1, PFPP_GEMM_F16 = 2 };
 
+/*   PFPP_GEMM_F16   single-pass fp16 on pre-split operands (a_hi / w_hi planes only, ONE v_mfma_f32_32x32x16_f16 per product,
+ *                   fp32 accumulate): the perf mode of BASELINE.json configs[4].  ~1e-3 relative error: not the parity mode. */
 typedef struct pfpp_gemm_args {
   const float* A; const float* W; float* C;
   const void* w_hi; const void* w_lo;   /* pre-split fp16 planes of W, or NULL */
@@ -250,6 +252,7 @@ typedef struct pfpp_gemm_planes_args {
   int32_t accumulate;
   int32_t splits, variant;
   float alpha;
+  int32_t single_pass;                  /* 1: PFPP_GEMM_F16 arithmetic (hi planes only); forward layout only */
   float* ws; int64_t ws_bytes;          /* optional K-split workspace (>= splits * M * N floats): chunks write dense slabs, a second
                                            launch adds them in chunk order (deterministic); without it a K split uses atomics   */
 } pfpp_gemm_planes_args;

@@ -848,7 +848,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31), "sizes exceed int32");
   const bool apre = a->a_hi != nullptr;
   if (apre) {
-    PFPP_REQUIRE(a->a_lo && a->w_hi && a->w_lo && a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor,
+    PFPP_REQUIRE(a->a_lo && a->w_hi && a->w_lo && (a->precision == PFPP_GEMM_F16X3 || a->precision == PFPP_GEMM_F16) && !a->w_kmajor,
                  "pre-split A needs the f16x3 path with a pre-split [N,K] W");
     PFPP_REQUIRE(a->K % 32 == 0 && a->lda % 8 == 0 && a->lda >= a->K, "pre-split A: K % 32 == 0, lda % 8 == 0");
     PFPP_REQUIRE(pfpp::aligned16(a->a_hi) && pfpp::aligned16(a->a_lo) && a->sA0 % 8 == 0 && a->sA1 % 8 == 0,
@@ -874,7 +874,8 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a->act >= PFPP_ACT_NONE && a->act <= PFPP_ACT_GEGLU, "unknown activation");
   PFPP_REQUIRE(a->act != PFPP_ACT_GEGLU || (a->N % 64 == 0 && a->pool == 0 && !a->scale && !a->residual),
                "GEGLU: N % 64 != 0 or unsupported epilogue combination");
-  PFPP_REQUIRE(a->precision == PFPP_GEMM_F32 || a->precision == PFPP_GEMM_F16X3, "unknown precision");
+  PFPP_REQUIRE(a->precision == PFPP_GEMM_F32 || a->precision == PFPP_GEMM_F16X3 || a->precision == PFPP_GEMM_F16, "unknown precision");
+  PFPP_REQUIRE(a->precision != PFPP_GEMM_F16 || (a->a_hi && a->w_hi), "PFPP_GEMM_F16 needs both operands as pre-split planes");
   const bool fused_bn = a->a_mul || a->stats || a->c_min;
   if (fused_bn) {
     PFPP_REQUIRE(!a->a_mul == !a->a_add, "a_mul and a_add go together");
@@ -887,7 +888,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   }
   const bool pre = a->w_hi != nullptr;
   if (pre) {
-    PFPP_REQUIRE(a->precision == PFPP_GEMM_F16X3 && a->w_lo && !a->w_kmajor, "pre-split W needs the f16x3 path, [N,K] layout");
+    PFPP_REQUIRE((a->precision == PFPP_GEMM_F16X3 || a->precision == PFPP_GEMM_F16) && a->w_lo && !a->w_kmajor, "pre-split W needs the f16x3 path, [N,K] layout");
     PFPP_REQUIRE(a->ldw % 8 == 0 && a->ldw >= ((a->K + 7) & ~7ll), "pre-split W: ldw (halfs) must be K rounded up to 8");
     PFPP_REQUIRE(pfpp::aligned16(a->w_hi) && pfpp::aligned16(a->w_lo) && a->sW0 % 8 == 0 && a->sW1 % 8 == 0,
                  "pre-split W planes must be 16-byte aligned");
@@ -917,12 +918,13 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.tiles_n = 0;
   p.dbg = 0;
   p.accum = 0;
+  p.x1 = a->precision == PFPP_GEMM_F16 ? 1 : 0;
   p.k_valid = (int)a->K;
   hipStream_t st = pfpp::as_stream(stream);
 
   // 128x128 tiles unless N is narrow (GEGLU and pool=64 need the 2-tile wave shape)
   const bool wide = a->N > 64 || a->act == PFPP_ACT_GEGLU;
-  if (a->precision == PFPP_GEMM_F16X3 && !a->w_kmajor) {
+  if ((a->precision == PFPP_GEMM_F16X3 || a->precision == PFPP_GEMM_F16) && !a->w_kmajor) {
     // LDS-DMA staged, software-pipelined plane kernel (gemm_pl.hip).  PFPP_GEMM_PL: 0 = off, 1..3 = force a tile, unset / -1 = by shape
     if (apre && !fused_bn && true) {
       const char* e = getenv("PFPP_GEMM_PL");

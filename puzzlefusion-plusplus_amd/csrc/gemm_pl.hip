@@ -101,8 +101,9 @@ __device__ __forceinline__ half4 lds_rd_tr(uint32_t addr) {
   return v;
 }
 
-template <int MT, int NT, int WM, int WN, int NS>
+template <int MT, int NT, int WM, int WN, int NS, bool X1 = false>
 struct Cfg {
+  static constexpr int NPL = X1 ? 1 : 2;                  // planes per operand in LDS: single-pass fp16 stages the hi planes only
   static constexpr int HS = (MT == 4 && NT == 2) ? 2 : MT;
   static constexpr int WPS = (MT * NT >= 16) ? 1 : 2;     // waves per SIMD the register budget allows (512 / 256 registers)
   static constexpr int NW = WM * WN;
@@ -111,7 +112,7 @@ struct Cfg {
   static constexpr int BN = 32 * NT * WN;
   static constexpr int PLANE_A = BM * 64;                 // bytes: BM rows of 32 halfs
   static constexpr int PLANE_W = BN * 64;
-  static constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;
+  static constexpr int STAGE = NPL * (PLANE_A + PLANE_W);
   static constexpr int NP = STAGE / 1024;                 // 1 KiB DMA pieces (16 rows of one plane) per stage
   static constexpr int NPW = NP / NW;                     // pieces per wave
   static constexpr size_t SMEM = (size_t)NS * STAGE;
@@ -229,15 +230,17 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
 }
 
 // One workgroup = one output tile.  NS-stage DMA ring; see the header for the schedule.
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false>
 __device__ __forceinline__ void pl_body(const GemmP& p) {
   static_assert(!(AF && AK), "an fp32 A operand is row-major");
-  using C = Cfg<MT, NT, WM, WN, NS>;
+  static_assert(!(AF && X1), "the single-pass mode takes pre-split operands");
+  using C = Cfg<MT, NT, WM, WN, NS, X1>;
+  constexpr int NPL = C::NPL;
   constexpr int BM = C::BM, BN = C::BN, NPW = C::NPW, STAGE = C::STAGE;
   constexpr int HS = C::HS;
   constexpr int NH = MT / HS;         // half-steps per 16-deep step
-  constexpr int NMMA = 3 * HS * NT;   // MFMAs per half-step
-  constexpr int RA = (AK ? 4 : 2) * HS, RB = (WK ? 4 : 2) * NT;   // fragment reads of a half-step's A tiles / a step's W tiles
+  constexpr int NMMA = (X1 ? 1 : 3) * HS * NT;   // MFMAs per half-step (single pass: hi.hi only)
+  constexpr int RA = (AK ? 2 : 1) * NPL * HS, RB = (WK ? 2 : 1) * NPL * NT;   // fragment reads of a half-step's A tiles / a step's W tiles
   constexpr int CPR_A = BM / 8, CPR_W = BN / 8;                  // 16-byte chunks per contraction row of a k-major tile
   extern __shared__ __align__(1024) char pl_smem[];
 
@@ -283,11 +286,11 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   for (int j = 0; j < NPW; ++j) {
     const int q = wave + C::NW * j;
     const int o = q * 1024;
-    const bool is_a = o < 2 * C::PLANE_A;
+    const bool is_a = o < (AF ? 2 : NPL) * C::PLANE_A;
     piece_a[j] = is_a;
-    const int o2 = is_a ? o : o - 2 * C::PLANE_A;
+    const int o2 = is_a ? o : o - (AF ? 2 : NPL) * C::PLANE_A;
     const int psz = is_a ? C::PLANE_A : C::PLANE_W;
-    const bool lo = o2 >= psz;
+    const bool lo = NPL == 2 && o2 >= psz;
     const int ci = ((lo ? o2 - psz : o2) >> 4) + lane;           // 16-byte chunk index within the plane
     const _Float16* base = reinterpret_cast<const _Float16*>(is_a ? (lo ? p.Alo : p.Ahi) : (lo ? p.Wlo : p.Whi));
     int64_t eoff;
@@ -380,10 +383,10 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   }
   if constexpr (WK) {
 #pragma unroll
-    for (int jj = 0; jj < NT; ++jj) w_ad[jj] = lds0 + 2 * C::PLANE_A + kmajor_ad(CPR_W, wn * NT + jj);
+    for (int jj = 0; jj < NT; ++jj) w_ad[jj] = lds0 + (AF ? 2 : NPL) * C::PLANE_A + kmajor_ad(CPR_W, wn * NT + jj);
   } else {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) w_ad[s2] = lds0 + 2 * C::PLANE_A + (wn * 32 * NT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
+    for (int s2 = 0; s2 < 2; ++s2) w_ad[s2] = lds0 + (AF ? 2 : NPL) * C::PLANE_A + (wn * 32 * NT + l31) * 64 + (((2 * s2 + lhi) ^ sw) << 4);
   }
   // a k-major fragment arrives as two 8-byte halves (contraction rows +0..3 and +4..7)
   struct FA { half8 h[HS], l[HS]; half4 h2[AK ? HS : 1][2], l2[AK ? HS : 1][2]; f32x4 r[AF ? HS : 1][2]; f32x4 am[2], aa[2]; };
@@ -400,7 +403,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     constexpr int s = decltype(s_c)::value, mh = decltype(mh_c)::value, q = decltype(q_c)::value;
     if constexpr (dbg_noread) return;
     if constexpr (AK) {
-      constexpr int t = q / 4, pl_ = (q >> 1) & 1, hf = q & 1;
+      constexpr int t = q / (2 * NPL), pl_ = (q >> 1) % NPL, hf = q & 1;
       constexpr int off = pl_ * C::PLANE_A + (16 * s + 4 * hf) * CPR_A * 16;
       const uint32_t ad = a_ad[HS * mh + t] + st;
       if constexpr (pl_ == 0) f.h2[t][hf] = lds_rd_tr<off>(ad); else f.l2[t][hf] = lds_rd_tr<off>(ad);
@@ -424,7 +427,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     constexpr int s = decltype(s_c)::value, q = decltype(q_c)::value;
     if constexpr (dbg_noread) return;
     if constexpr (WK) {
-      constexpr int t = q / 4, pl_ = (q >> 1) & 1, hf = q & 1;
+      constexpr int t = q / (2 * NPL), pl_ = (q >> 1) % NPL, hf = q & 1;
       constexpr int off = pl_ * C::PLANE_W + (16 * s + 4 * hf) * CPR_W * 16;
       const uint32_t ad = w_ad[t] + st;
       if constexpr (pl_ == 0) f.h2[t][hf] = lds_rd_tr<off>(ad); else f.l2[t][hf] = lds_rd_tr<off>(ad);
@@ -439,7 +442,17 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   auto join = [](const half4 x, const half4 y) { return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7); };
   auto wait_a = [&](FA& a) {
     if constexpr (dbg_nowait) return;
-    if constexpr (AK) {
+    if constexpr (X1 && AK) {
+      static_for<HS>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h2[t][0]), "+v"(a.h2[t][1]));
+        a.h[t] = join(a.h2[t][0], a.h2[t][1]);
+      });
+    } else if constexpr (X1) {
+      if constexpr (HS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]));
+      else if constexpr (HS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]), "+v"(a.h[1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h[0]), "+v"(a.h[1]), "+v"(a.h[2]), "+v"(a.h[3]));
+    } else if constexpr (AK) {
       static_for<HS>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.h2[t][0]), "+v"(a.h2[t][1]), "+v"(a.l2[t][0]), "+v"(a.l2[t][1]));
@@ -470,7 +483,17 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   };
   auto wait_b = [&](FB& b) {
     if constexpr (dbg_nowait) return;
-    if constexpr (WK) {
+    if constexpr (X1 && WK) {
+      static_for<NT>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h2[t][0]), "+v"(b.h2[t][1]));
+        b.h[t] = join(b.h2[t][0], b.h2[t][1]);
+      });
+    } else if constexpr (X1) {
+      if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h[0]));
+      else if constexpr (NT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h[0]), "+v"(b.h[1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h[0]), "+v"(b.h[1]), "+v"(b.h[2]), "+v"(b.h[3]));
+    } else if constexpr (WK) {
       static_for<NT>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.h2[t][0]), "+v"(b.h2[t][1]), "+v"(b.l2[t][0]), "+v"(b.l2[t][1]));
@@ -490,7 +513,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   // are HS*NT instructions apart
   auto mma1 = [&](const FA& a, const FB& b, auto mh_c, auto m_c) {
     constexpr int mh = decltype(mh_c)::value, m = decltype(m_c)::value;
-    constexpr int term = m / (HS * NT), ii = (m % (HS * NT)) / NT, j = m % NT;
+    constexpr int term = X1 ? 2 : m / (HS * NT), ii = (m % (HS * NT)) / NT, j = m % NT;
     f32x16& c = acc[HS * mh + ii][j];
     if constexpr (term == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l[ii], b.h[j], c, 0, 0, 0);
     if constexpr (term == 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[ii], b.l[j], c, 0, 0, 0);
@@ -680,16 +703,16 @@ __global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* 
   *dstp = s;
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
-  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF>(p);
+  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1>(p);
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false, bool X1 = false>
 int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits = 1) {
-  using C = Cfg<MT, NT, WM, WN, NS>;
+  using C = Cfg<MT, NT, WM, WN, NS, X1>;
 #ifdef PFPP_PL_LAB
-  if constexpr (DBG == 0) {
+  if constexpr (DBG == 0 && !AF && !X1) {
     const char* e = getenv("PFPP_GEMM_DBG");
     switch (e ? atoi(e) : 0) {
       case 1: return launch_pl<MT, NT, WM, WN, NS, AK, WK, 1>(p0, batch, st, group_m, splits);
@@ -703,7 +726,7 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
 #endif
   static bool attr_set = false;
-  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG, AF>;
+  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -722,8 +745,8 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
   p.k_chunk = 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
-  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
-           WK ? "true" : "false", DBG, AF ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
+           WK ? "true" : "false", DBG, AF ? "true" : "false", X1 ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM + (AF ? 2048 : 0), st, p);
   if (slabs) {
     const int64_t n4 = (int64_t)p.M * (p.N >> 2);
@@ -737,6 +760,16 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
 
 // variant: 0 = pick by shape, 1 = 256x256 (8 waves of 128x64, 2 stages), 2 = 256x128 (8 waves, 3 stages), 3 = 128x128 (4 waves,
 // 2 stages, two workgroups per CU), 6 = 128x64 (3 stages): small tiles for narrow outputs
+// single-pass fp16 (hi planes only, one MFMA per product): the perf mode of BASELINE configs[4] — no fp32-grade guarantee
+static int launch_variant_x1(const GemmP& p, int batch, hipStream_t st, int group_m, int variant, int splits) {
+  switch (variant) {
+    case 1: return pl::launch_pl<4, 2, 2, 4, 2, false, false, 0, false, true>(p, batch, st, group_m, splits);
+    case 2: return pl::launch_pl<2, 2, 4, 2, 3, false, false, 0, false, true>(p, batch, st, group_m, splits);
+    case 6: return pl::launch_pl<2, 1, 2, 2, 3, false, false, 0, false, true>(p, batch, st, group_m, splits);
+    default: return pl::launch_pl<2, 2, 2, 2, 2, false, false, 0, false, true>(p, batch, st, group_m, splits);
+  }
+}
+
 template <bool AK, bool WK>
 static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m, int variant, int splits) {
   switch (variant) {
@@ -775,6 +808,7 @@ int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, 
   // GEGLU gates pairs of column tiles (two per wave at least); the pool = 64 epilogue needs two row tiles per wave
   if (variant == 6 && p.act == PFPP_ACT_GEGLU) variant = 3;
   if (variant == 1 && p.pool == 64) variant = 2;
+  if (p.x1) return launch_variant_x1(p, batch, st, group_m, variant, 1);
   return launch_variant<false, false>(p, batch, st, group_m, variant, 1);
 }
 
@@ -849,6 +883,11 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
     if (splits == 0) splits = best_s;
   }
   const int gm = 8;
+  if (a->single_pass) {
+    PFPP_SUPPORTED(!a->a_kmajor && !a->w_kmajor, "single-pass fp16 with k-major operands");
+    p.x1 = 1;
+    return launch_variant_x1(p, 1, st, gm, variant, splits);
+  }
   if (a->a_kmajor) return launch_variant<true, true>(p, 1, st, gm, variant, splits);
   if (a->w_kmajor) return launch_variant<false, true>(p, 1, st, gm, variant, splits);
   return launch_variant<false, false>(p, 1, st, gm, variant, splits);

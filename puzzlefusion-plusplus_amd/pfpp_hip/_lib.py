@@ -70,7 +70,7 @@ class GemmPlanesArgs(C.Structure):
         ("M", _i64), ("N", _i64), ("K", _i64),
         ("lda", _i64), ("ldw", _i64), ("ldc", _i64), ("ldr", _i64),
         ("a_kmajor", _i32), ("w_kmajor", _i32), ("act", _i32), ("accumulate", _i32), ("splits", _i32), ("variant", _i32),
-        ("alpha", _f32),
+        ("alpha", _f32), ("single_pass", _i32),
         ("ws", _p), ("ws_bytes", _i64),
     ]
 

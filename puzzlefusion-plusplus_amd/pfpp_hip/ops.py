@@ -153,7 +153,10 @@ def group_gather(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch
 import os as _os
 
 GEMM_MODE = _os.environ.get("PFPP_GEMM", "f16x3")
-PRECISION = {"f32": 0, "f16x3": 1}
+PRECISION = {"f32": 0, "f16x3": 1, "f16": 2}
+# single-pass fp16 (PFPP_GEMM_F16: hi planes only, one MFMA per product) for every GEMM whose operands both arrive as split planes
+# — the perf mode of BASELINE configs[4] (bench.py --mode stress), ~1e-3 relative error; the parity mode is f16x3
+SINGLE_PASS = _os.environ.get("PFPP_GEMM_SINGLE_PASS", "0") == "1"
 
 class SplitAct:
     """an activation travelling as split-f16 planes (hi, lo = x - hi), each fp16 [rows, C]: produced by the
@@ -310,7 +313,8 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     args.W = W.data_ptr() + w_off * es
     args.w_hi = 0 if planes is None else planes[0].data_ptr() + w_off * 2
     args.w_lo = 0 if planes is None else planes[1].data_ptr() + w_off * 2
-    args.precision = PRECISION["f16x3" if f16x3 else "f32"]
+    args.precision = PRECISION["f16" if (f16x3 and SINGLE_PASS and a_planes is not None and planes is not None) else
+                               "f16x3" if f16x3 else "f32"]
     args.C = 0 if c_planes is not None else out.data_ptr() + c_off * es
     args.c_hi = 0 if c_planes is None else c_planes[0].data_ptr() + c_off * 2
     args.c_lo = 0 if c_planes is None else c_planes[1].data_ptr() + c_off * 2

@@ -87,7 +87,8 @@ def _workspace(device):
 
 def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_kmajor: bool = False, w_kmajor: bool = False,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
-         accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True) -> torch.Tensor:
+         accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True,
+         single_pass: bool = False) -> torch.Tensor:
     """pfpp_gemm_planes: out [M, N] = act(alpha * A.W + bias) + residual, or += with accumulate.
        forward  : A [M, K],              W [N, K]
        dX       : A = dY [M, K],         W [K, N] (w_kmajor)
@@ -108,6 +109,7 @@ def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_k
     a.accumulate = int(accumulate)
     a.splits, a.variant = splits, variant
     a.alpha = (1.0 / (A.scale * W.scale)) if alpha is None else alpha
+    a.single_pass = int(single_pass)
     if use_ws:
         ws = _workspace(out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -49,13 +49,29 @@ def verifier_forward(pk, edge_features: torch.Tensor, edge_indices: torch.Tensor
     h = ops.verifier_embed(fe, edge_indices.reshape(M, 2).to(torch.int64).contiguous(), pk["pe"])
     key_valid = mask.reshape(B, E).to(torch.bool).to(torch.uint8).contiguous()
     scale = 1.0 / math.sqrt(dh)
-    att = torch.empty_like(h)
+    # thousands of edges (the 4,950 of a 100-fragment puzzle, BASELINE configs[4]): the layer's GEMM operands travel as split-f16
+    # planes (LDS-DMA staged plane kernel, and PFPP_GEMM_F16 when ops.SINGLE_PASS is set); the 190 edges of the reference's
+    # 20-fragment puzzles are latency-bound launches and keep the fp32 hand-over
+    planes = ops.split_mode() and M >= 1024
+    att = ops.SplitAct.empty(M, C, h.device) if planes else torch.empty_like(h)
     for i in range(num_layers):
-        qkv = ops.linear(h, pk[f"{i}.wqkv"], pk[f"{i}.bqkv"])
+        if planes:
+            from . import planes as P_
+
+            hp = P_.split(h)
+            hs = ops.SplitAct(hp.hi, hp.lo)
+            qkv = ops.linear(hs, pk[f"{i}.wqkv"], pk[f"{i}.bqkv"])
+        else:
+            qkv = ops.linear(h, pk[f"{i}.wqkv"], pk[f"{i}.bqkv"])
         dense_attention(qkv, B, E, num_heads, dh, key_valid, scale, out=att)
         ops.gemm(att, pk[f"{i}.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C, bias=pk[f"{i}.bo"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.g1"], beta=pk[f"{i}.be1"], out=h)
-        f = ops.linear(h, pk[f"{i}.w1"], pk[f"{i}.b1"], act="gelu")
+        if planes:
+            hp = P_.split(h)
+            f = ops.linear(ops.SplitAct(hp.hi, hp.lo), pk[f"{i}.w1"], pk[f"{i}.b1"], act="gelu",
+                           out=ops.SplitAct.empty(M, pk[f"{i}.w1"].N, h.device))
+        else:
+            f = ops.linear(h, pk[f"{i}.w1"], pk[f"{i}.b1"], act="gelu")
         ops.gemm(f, pk[f"{i}.w2"], M=M, N=C, K=f.shape[1], lda=f.shape[1], out=h, ldc=C,
                  bias=pk[f"{i}.b2"], residual=h, ldr=C)
         ops.layernorm(h, gamma=pk[f"{i}.g2"], beta=pk[f"{i}.be2"], out=h)

@@ -226,6 +226,37 @@ def test_gemm_split_activation_planes(dev, M, N, K, act):
         assert (h.cpu().double() - (ref + R.double())).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (4096, 1536, 512), (777, 512, 2048)])
+def test_gemm_single_pass_fp16_mode(dev, M, N, K):
+    """PFPP_GEMM_F16 (perf mode of BASELINE configs[4]): one MFMA per product on the hi planes only — equals the fp64 product of the
+    fp16-rounded operands to fp32 accumulation error, and stays within fp16 operand rounding (2^-11 relative per factor) of the
+    fp32-grade result"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, split_f16
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    hi, lo = split_f16(A.to(dev))
+    a_split = ops.SplitAct(hi, lo)
+    pw = PW(W.to(dev))
+    exact = A.double() @ W.double().t() + b.double()
+    rounded = A.half().double() @ W.half().double().t() + b.double()
+    assert not ops.SINGLE_PASS
+    try:
+        ops.SINGLE_PASS = True
+        out = ops.linear(a_split, pw, b.to(dev), mode="f16x3")
+    finally:
+        ops.SINGLE_PASS = False
+    full = ops.linear(a_split, pw, b.to(dev), mode="f16x3")
+    assert (out.cpu().double() - rounded).abs().max() < 2e-5 * max(1.0, rounded.abs().max().item())
+    err1 = (out.cpu().double() - exact).abs().max().item()
+    err3 = (full.cpu().double() - exact).abs().max().item()
+    assert err3 < 2e-5 * max(1.0, exact.abs().max().item())
+    assert 10 * err3 < err1 < 5e-3 * K ** 0.5 / 16          # the single pass really dropped the lo terms, and only those
+
+
 def test_layernorm_and_attention_split_outputs(dev):
     """LayerNorm / attention kernels writing split planes == their fp32 outputs re-split"""
     from pfpp_hip import ops
@@ -364,6 +395,31 @@ def test_verifier_vs_golden(golden, weights_sd, dev):
                             T(g["edge_valids"]).to(dev), num_layers=6, num_heads=8)
     m = g["edge_valids"].astype(bool)
     assert np.abs(lo.cpu().numpy() - g["logits"])[m].max() < TOL
+
+
+def test_verifier_many_edges_plane_path(dev, monkeypatch):
+    """the 1,225 candidate edges of a 50-fragment puzzle (M >= 1024: layer operands handed over as split planes) == the fp32
+    hand-over of the same forward; the CPU oracle pins that forward (test_verifier_vs_golden and the max_len = 50 oracle below)"""
+    from oracle import pfpp_oracle as O
+    from oracle import weights
+    from pfpp_hip import verifier as V
+
+    P, B = 50, 2
+    sd = weights.verifier_state_dict(max_len=P)
+    E = P * (P - 1) // 2
+    g = torch.Generator().manual_seed(3)
+    idx = torch.triu(torch.ones(P, P, dtype=torch.bool), diagonal=1).nonzero()[None].expand(B, E, 2).contiguous()
+    feat = torch.rand(B, E, 7, generator=g)
+    valid = torch.ones(B, E)
+    valid[1, 900:] = 0
+    pk = V.pack_verifier(dsd(sd, dev), 6)
+    out = V.verifier_forward(pk, feat.to(dev), idx.to(dev), valid.to(dev), num_layers=6, num_heads=8)
+    monkeypatch.setenv("PFPP_SPLIT_ACT", "0")
+    out_f32 = V.verifier_forward(pk, feat.to(dev), idx.to(dev), valid.to(dev), num_layers=6, num_heads=8)
+    m = valid.bool()
+    assert (out - out_f32).abs().cpu()[m].max() < 2e-5
+    ref = O.verifier_forward(sd, feat, idx, valid)
+    assert (out.cpu() - ref).abs()[m].max() < TOL
 
 
 # ----------------------------------------------------------------------------- end to end vs oracle
