@@ -255,6 +255,9 @@ typedef struct pfpp_gemm_planes_args {
   int32_t single_pass;                  /* 1: PFPP_GEMM_F16 arithmetic (hi planes only); forward layout only */
   float* ws; int64_t ws_bytes;          /* optional K-split workspace (>= splits * M * N floats): chunks write dense slabs, a second
                                            launch adds them in chunk order (deterministic); without it a K split uses atomics   */
+  float* colsum; float colsum_alpha;    /* dW form only (both operands k-major): colsum[m] += colsum_alpha * sum_k A[k][m], i.e. the bias
+                                           gradient sum over rows of dY (nn.Linear backward) computed from the fragments the GEMM reads
+                                           anyway; with a workspace K split it needs room for splits * M more floats             */
 } pfpp_gemm_planes_args;
 
 int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);

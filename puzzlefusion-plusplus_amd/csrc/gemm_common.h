@@ -35,6 +35,7 @@ struct GemmP {
   const int* g_idx; const float* g_xyz; const float* g_ctr; int g_N, g_S, g_ns;
   int k_valid; // gemm_pl.hip: contraction rows that exist (k-major operands; K is rounded up to the K-tile, the rest reads zeros)
   int x1;     // gemm_pl.hip: single-pass fp16 (hi planes only) — PFPP_GEMM_F16
+  float* csum; float* csum_ws; float csum_alpha;   // gemm_pl.hip (k-major A): csum[m] += csum_alpha * sum_k A[k][m] — the bias gradient riding in dW = dY^T . X
   int accum;  // gemm_pl.hip: C += alpha * acc with fp32 atomics (set by the launcher for split-K / gradient accumulation)
   int dbg;    // gemm_pl.hip ablation switches (PFPP_GEMM_DBG; developer runs only): 1 no epilogue, 2 no DMA after the prologue, 4 no barrier / DMA wait
 };

@@ -189,11 +189,19 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
         asm volatile("ds_write_b32 %0, %1" ::"v"(patch + r * ROWB + pc * 4), "v"(t[e]) : "memory");
       }
     }
+    // all row reads of the tile in flight, one wait (the fragment buffers are dead here: registers are free)
+    f32x4 vv[32 / RPI];
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; ++k)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(vv[k]) : "v"(patch + (rrow + k * RPI) * ROWB + rcol * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; k += 4)        // the wait orders the uses: name every destination behind it
+      asm volatile("" : "+v"(vv[k]), "+v"(vv[k + 1]), "+v"(vv[k + 2]), "+v"(vv[k + 3]));
 #pragma unroll
     for (int k = 0; k < 32 / RPI; ++k) {
       const int r = rrow + k * RPI;
-      float4 v;
-      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(patch + r * ROWB + rcol * 4) : "memory");
+      float4 v = make_float4(vv[k][0], vv[k][1], vv[k][2], vv[k][3]);
       const int row = row_w + i * 32 + r;
       const int col = ocol0 + rcol;
       if (row < p.M && rcol < out_cols && col < n_out) {
@@ -230,9 +238,10 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
 }
 
 // One workgroup = one output tile.  NS-stage DMA ring; see the header for the schedule.
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false>
 __device__ __forceinline__ void pl_body(const GemmP& p) {
   static_assert(!(AF && AK), "an fp32 A operand is row-major");
+  static_assert(!CS || (AK && !X1), "column sums ride with a k-major split A operand (dW = dY^T . X)");
   static_assert(!(AF && X1), "the single-pass mode takes pre-split operands");
   using C = Cfg<MT, NT, WM, WN, NS, X1>;
   constexpr int NPL = C::NPL;
@@ -341,6 +350,12 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  // CS: the workgroups of tile column 0 also sum their A operand over the contraction (sum_k dY[k][m] = the bias gradient):
+  // v_dot2c_f32_f16 with ones on the fragments the MFMAs consume anyway, issued in the shadow of the first MFMAs of a half-step
+  const bool do_cs = CS && tn == 0 && wn == 0;
+  float bsum[CS ? MT : 1];
+#pragma unroll
+  for (int i = 0; i < (CS ? MT : 1); ++i) bsum[i] = 0.0f;
 
   // ---- fragment addressing -----------------------------------------------------------------------------------------------
   // row-major: lane (l31, lhi) reads row l31 of a 32-row tile, logical chunk 2*s + lhi; one address per 16-deep step s
@@ -527,6 +542,19 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       constexpr int m = decltype(m_c)::value;
       mma1(a, b, mh_c, m_c);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CS && m < 2 * HS) {
+        if (do_cs) {
+          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+          constexpr int ii = m >> 1;
+          const half8 v = (m & 1) ? a.l[ii] : a.h[ii];
+          const half2v one = {(_Float16)1.0f, (_Float16)1.0f};
+          float& s_ = bsum[HS * decltype(mh_c)::value + ii];
+          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), one, s_, false);
+          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 2, 3), one, s_, false);
+          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 4, 5), one, s_, false);
+          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), one, s_, false);
+        }
+      }
       constexpr int f0 = m * NF / NMMA, f1 = (m + 1) * NF / NMMA;
       static_for<f1 - f0>([&](auto k_c) { fill(std::integral_constant<int, f0 + decltype(k_c)::value>{}); });
       __builtin_amdgcn_sched_barrier(0);
@@ -630,6 +658,20 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   tile_body(nk - 1, cur, 0u, prv, std::true_type{});
 
   if ((DBG & 1) && acc[0][0][0] != 12345.678f) return;
+  if constexpr (CS) {
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float v = (bsum[i] + __shfl_xor(bsum[i], 32)) * p.csum_alpha;
+        const int row = m0 + wm * 32 * MT + i * 32 + l31;
+        if (lhi == 0 && row < p.M) {
+          if (p.split_k == 1) p.csum[row] += v;                                        // one writer per row
+          else if (p.csum_ws) p.csum_ws[(size_t)split * p.M + row] = v;                // pl_reduce_kernel adds the chunks in order
+          else unsafeAtomicAdd(p.csum + row, v);
+        }
+      }
+    }
+  }
   if (p.split_ws && p.split_k > 1) {
     // K split with a workspace: this chunk's alpha * acc goes to its own dense [M, N] slab with 16-byte stores; pl_reduce_kernel
     // adds the slabs in chunk order afterwards (deterministic; fp32 atomics on a shared C measured 1.2 TB/s: every chunk of a
@@ -680,9 +722,15 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
 
 // second pass of a workspace K split: C = [C +] act(sum of the slabs + bias) + residual, four columns per thread
 __global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* C, const float* bias, const float* residual, int M,
-                                                        int N, int64_t ldc, int64_t ldr, int splits, int accumulate, int act) {
+                                                        int N, int64_t ldc, int64_t ldr, int splits, int accumulate, int act,
+                                                        const float* csum_ws, float* csum) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n4 = N >> 2;
+  if (csum_ws && i < M) {        // the column sums of the A operand, one partial per K chunk
+    float s = csum_ws[i];
+    for (int k = 1; k < splits; ++k) s += csum_ws[(size_t)k * M + i];
+    csum[i] += s;
+  }
   if (i >= (int64_t)M * n4) return;
   const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
   const size_t slab = (size_t)M * N;
@@ -703,12 +751,12 @@ __global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* 
   *dstp = s;
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
-  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1>(p);
+  pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1, CS>(p);
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false, bool X1 = false>
+template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false, bool X1 = false, bool CS = false>
 int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits = 1) {
   using C = Cfg<MT, NT, WM, WN, NS, X1>;
 #ifdef PFPP_PL_LAB
@@ -726,7 +774,7 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   }
 #endif
   static bool attr_set = false;
-  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1>;
+  auto kern = gemm_pl_kernel<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1, CS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -738,20 +786,23 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   const int nk_all = p.K / BK;
   p.split_k = splits < 1 ? 1 : (splits > nk_all ? nk_all : splits);
   const bool slabs = p.split_k > 1 && p.split_ws && batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
-                     (int64_t)p.split_k * p.M * p.N * (int64_t)sizeof(float) <= p_ws_bytes;
+                     (int64_t)p.split_k * p.M * (p.N + 1) * (int64_t)sizeof(float) <= p_ws_bytes;
   if (!slabs) p.split_ws = nullptr;
+  if constexpr (!CS) p.csum = nullptr;
+  // partial column sums of the chunks live behind the C slabs (the capacity check of the caller includes them)
+  p.csum_ws = (CS && slabs && p.csum) ? p.split_ws + (size_t)p.split_k * p.M * p.N : nullptr;
   if (p.split_k > 1 && !slabs) {
     if (p.act != PFPP_ACT_NONE || !p.accum) { p.split_k = 1; }     // atomics need an accumulating, activation-free epilogue
   }
   p.k_chunk = 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
-  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
-           WK ? "true" : "false", DBG, AF ? "true" : "false", X1 ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s, %s, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
+           WK ? "true" : "false", DBG, AF ? "true" : "false", X1 ? "true" : "false", CS ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM + (AF ? 2048 : 0), st, p);
   if (slabs) {
     const int64_t n4 = (int64_t)p.M * (p.N >> 2);
     hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.split_ws, p.C, p.bias, p.residual, p.M,
-                       p.N, p.ldc, p.ldr, p.split_k, p.accum, p.act);
+                       p.N, p.ldc, p.ldr, p.split_k, p.accum, p.act, p.csum_ws, p.csum);
   }
   return pfpp::check_launch("pfpp_gemm");
 }
@@ -772,6 +823,15 @@ static int launch_variant_x1(const GemmP& p, int batch, hipStream_t st, int grou
 
 template <bool AK, bool WK>
 static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m, int variant, int splits) {
+  if constexpr (AK && WK) {
+    if (p.csum) {      // dW = dY^T . X with the bias gradient (column sums of dY) computed on the way
+      switch (variant) {
+        case 1: case 2: return pl::launch_pl<2, 2, 4, 2, 3, AK, WK, 0, false, false, true>(p, batch, st, group_m, splits);
+        case 6: return pl::launch_pl<2, 1, 2, 2, 3, AK, WK, 0, false, false, true>(p, batch, st, group_m, splits);
+        default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK, 0, false, false, true>(p, batch, st, group_m, splits);
+      }
+    }
+  }
   switch (variant) {
     case 1:
       if constexpr (!AK && !WK) return pl::launch_pl<4, 2, 2, 4, 2, AK, WK>(p, batch, st, group_m, splits);
@@ -842,6 +902,8 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   p.act = a->act; p.zdiv = 1; p.alpha = a->alpha; p.accum = a->accumulate ? 1 : 0;
   p.split_ws = a->ws;
   pl::p_ws_bytes = a->ws ? a->ws_bytes : 0;
+  PFPP_SUPPORTED(!a->colsum || (a->a_kmajor && a->w_kmajor && !a->single_pass), "colsum rides with the k-major pair (dW = dY^T . X) only");
+  p.csum = a->colsum; p.csum_alpha = a->colsum_alpha;
   hipStream_t st = pfpp::as_stream(stream);
   int variant = a->variant, splits = a->splits;
   const int nk = p.K / 32;
@@ -863,7 +925,7 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
         const int sp = cand_s[si];
         if (a->splits != 0 && sp != a->splits) continue;
         if (sp > 1 && (sp > nk / 2 || !(a->ws || a->accumulate))) continue;
-        const bool slabs = sp > 1 && a->ws && (double)sp * p.M * p.N * 4.0 <= (double)a->ws_bytes;
+        const bool slabs = sp > 1 && a->ws && (double)sp * p.M * (p.N + 1.0) * 4.0 <= (double)a->ws_bytes;
         if (sp > 1 && !slabs && !a->accumulate) continue;
         const double wgs = tiles * sp;
         const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;                  // co-resident workgroups share the CU's bandwidth

@@ -72,6 +72,7 @@ class GemmPlanesArgs(C.Structure):
         ("a_kmajor", _i32), ("w_kmajor", _i32), ("act", _i32), ("accumulate", _i32), ("splits", _i32), ("variant", _i32),
         ("alpha", _f32), ("single_pass", _i32),
         ("ws", _p), ("ws_bytes", _i64),
+        ("colsum", _p), ("colsum_alpha", _f32),
     ]
 
 

@@ -88,12 +88,13 @@ def _workspace(device):
 def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_kmajor: bool = False, w_kmajor: bool = False,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
          accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True,
-         single_pass: bool = False) -> torch.Tensor:
+         single_pass: bool = False, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pfpp_gemm_planes: out [M, N] = act(alpha * A.W + bias) + residual, or += with accumulate.
        forward  : A [M, K],              W [N, K]
        dX       : A = dY [M, K],         W [K, N] (w_kmajor)
        dW       : A = dY [K, M] (a_kmajor), W = X [K, N] (w_kmajor)
-    alpha defaults to 1 / (A.scale * W.scale)."""
+    alpha defaults to 1 / (A.scale * W.scale).  colsum (dW form): colsum[m] += sum over rows of the tensor A stands for (the bias
+    gradient), computed inside the same kernel."""
     _chk(out, _f32, "out")
     a = GemmPlanesArgs()
     a.a_hi, a.a_lo, a.w_hi, a.w_lo = A.hi.data_ptr(), A.lo.data_ptr(), W.hi.data_ptr(), W.lo.data_ptr()
@@ -110,6 +111,11 @@ def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_k
     a.splits, a.variant = splits, variant
     a.alpha = (1.0 / (A.scale * W.scale)) if alpha is None else alpha
     a.single_pass = int(single_pass)
+    if colsum is not None:
+        _chk(colsum, _f32, "colsum")
+        if colsum.numel() != M or not colsum.is_contiguous():
+            raise ValueError("colsum: contiguous fp32 [M] expected")
+        a.colsum, a.colsum_alpha = colsum.data_ptr(), 1.0 / A.scale
     if use_ws:
         ws = _workspace(out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4

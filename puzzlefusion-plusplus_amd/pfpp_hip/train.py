@@ -631,8 +631,10 @@ class DenoiserTrainEngine:
         from . import planes as P
 
         def issue():
-            P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True)
-            if gb is not None:
+            fused = gb is not None and self._fuse_colsum and gb.is_contiguous()      # the bias gradient rides in the dW kernel
+            P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True,
+                   colsum=gb if fused else None)
+            if gb is not None and not fused:
                 P.colsum(dyp, gb)
 
         if self._side is None:

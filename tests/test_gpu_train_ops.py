@@ -31,6 +31,47 @@ def test_grad_input_gemm(dev, M, N, K):
     assert rel_err(got, want) <= rel_err(got0, want) * 1.5 + 1e-9
 
 
+@pytest.mark.parametrize("rows,n_out,n_in", [(3850, 512, 512), (3850, 1536, 512), (3850, 4096, 512), (3850, 512, 2048), (777, 512, 512),
+                                             (154, 256, 512)])
+@pytest.mark.parametrize("splits,variant", [(0, 0), (1, 3), (4, 6), (3, 2)])
+def test_plane_gemm_layouts_and_fused_bias_gradient(dev, rows, n_out, n_in, splits, variant):
+    """pfpp_gemm_planes in its three forms on one linear layer of the training step (include/pfpp.h): y = x.W^T, dX = dY.W (W read in
+    place as the k-major operand), dW += dY^T.X (both k-major, ragged contraction = token count) with the bias gradient
+    db += colsum(dY) computed by the same kernel — against fp64 of the values the planes stand for"""
+    from pfpp_hip import planes as P
+
+    g = torch.Generator().manual_seed(rows + n_out + n_in)
+    G = 4096.0
+    x = torch.randn(rows, n_in, generator=g)
+    W = torch.randn(n_out, n_in, generator=g) / math.sqrt(n_in)
+    dY = torch.randn(rows, n_out, generator=g) * 1e-4
+    xp, wp, dyp = P.split(x.to(dev)), P.split(W.to(dev)), P.split(dY.to(dev), G)
+    xv, wv, dyv = xp.float().double().cpu(), wp.float().double().cpu(), dyp.float().double().cpu()
+    # forward and dX (non-accumulating: the split goes through the slab workspace)
+    y = torch.empty(rows, n_out, device=dev)
+    P.gemm(xp, wp, y, M=rows, N=n_out, K=n_in, splits=min(splits, 2), variant=variant)
+    assert rel_err(y, xv @ wv.t()) < 2e-6
+    dx = torch.empty(rows, n_in, device=dev)
+    P.gemm(dyp, wp, dx, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=splits, variant=variant)
+    assert rel_err(dx, dyv @ wv) < 2e-6
+    # dW and db accumulate onto what is there
+    dW0 = torch.randn(n_out, n_in, generator=g) * 1e-3
+    db0 = torch.randn(n_out, generator=g) * 1e-3
+    dW, db = dW0.to(dev), db0.to(dev)
+    P.gemm(dyp, xp, dW, M=n_out, N=n_in, K=rows, a_kmajor=True, w_kmajor=True, accumulate=True, splits=splits, variant=variant, colsum=db)
+    want_dW = dW0.double() + dyv.t() @ xv
+    want_db = db0.double() + dyv.sum(0)
+    assert rel_err(dW, want_dW) < 2e-6
+    assert rel_err(db, want_db) < 2e-6
+    # the stand-alone column-sum kernel agrees; and the fused form is deterministic
+    db2 = db0.to(dev)
+    P.colsum(dyp, db2)
+    assert rel_err(db2, want_db) < 2e-6
+    dW_b, db_b = dW0.to(dev), db0.to(dev)
+    P.gemm(dyp, xp, dW_b, M=n_out, N=n_in, K=rows, a_kmajor=True, w_kmajor=True, accumulate=True, splits=splits, variant=variant, colsum=db_b)
+    assert torch.equal(dW_b, dW) and torch.equal(db_b, db)
+
+
 @pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (16000, 1536, 512), (1234 * 4, 512, 2048), (640, 512, 148), (32, 1024, 512)])
 def test_grad_weight_gemm(dev, M, N, K):
     """dW [N,K] = dY[M,N]^T . X[M,K]  (both operands k-major, split-K atomics)"""
