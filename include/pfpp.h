@@ -288,6 +288,13 @@ int pfpp_sa_mlp2_fused(const float* feats, const float* xyz, const float* new_xy
                        const float* s0, const float* t0, const float* s1, const float* t1, float* out,
                        int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
                        pfpp_stream_t stream);
+/* the same with the result (also / only) as split-f16 planes of scale 1 — the A operand of the third convolution's plane GEMM
+ * (csrc/gemm_pl.hip) with no conversion pass; `out` may then be NULL */
+int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_xyz, const int32_t* idx,
+                         const void* w0_hi, const void* w0_lo, const void* w1_hi, const void* w1_lo,
+                         const float* s0, const float* t0, const float* s1, const float* t1, float* out,
+                         const pfpp_planes* out_planes, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1,
+                         int64_t C2, pfpp_stream_t stream);
 
 /* ---- a7/a8: vector quantisation + scatter ----------------------------------
  * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by

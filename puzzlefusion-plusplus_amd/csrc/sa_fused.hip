@@ -246,7 +246,8 @@ struct Sa2P {
   const float* feats; const float* xyz; const float* ctr; const int32_t* idx;
   const _Float16* w0h; const _Float16* w0l; const _Float16* w1h; const _Float16* w1l;
   const float* s0; const float* t0; const float* s1; const float* t1;
-  float* out;        // [G*64, C2]
+  float* out;        // [G*64, C2] (or null)
+  _Float16* out_hi; _Float16* out_lo;   // the same rows as split-f16 planes (operand of the plane GEMM of layer 3), or null
   int N, S, G;
 };
 
@@ -439,10 +440,22 @@ __global__ __launch_bounds__(256, 1) void sa_mlp2_kernel(const Sa2P p) {
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         const f32x16 y = bn_relu_t(a2[st], S1, T1, t * 32);
-        float* orow = p.out + ((int64_t)g * 64 + st * 32 + l31) * C2 + t * 32 + 4 * lhi;
+        const int64_t o = ((int64_t)g * 64 + st * 32 + l31) * C2 + t * 32 + 4 * lhi;
+        if (p.out_hi) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(orow + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+          for (int q = 0; q < 4; ++q) {
+            half4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { _Float16 a, b; split1(y[4 * q + r], a, b); hi[r] = a; lo[r] = b; }
+            *reinterpret_cast<half4*>(p.out_hi + o + 8 * q) = hi;
+            *reinterpret_cast<half4*>(p.out_lo + o + 8 * q) = lo;
+          }
+        }
+        if (p.out) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(p.out + o + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        }
       }
     }
   }
@@ -480,14 +493,25 @@ extern "C" int pfpp_sa_mlp2_fused(const float* feats, const float* xyz, const fl
                                   const float* s0, const float* t0, const float* s1, const float* t1, float* out,
                                   int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
                                   pfpp_stream_t stream) {
-  PFPP_REQUIRE(feats && xyz && new_xyz && idx && w0_hi && w0_lo && w1_hi && w1_lo && s0 && t0 && s1 && t1 && out, "null pointer");
+  return pfpp_sa_mlp2_fused_p(feats, xyz, new_xyz, idx, w0_hi, w0_lo, w1_hi, w1_lo, s0, t0, s1, t1, out, nullptr, F, N, S, ns, D, C1, C2, stream);
+}
+
+extern "C" int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_xyz, const int32_t* idx,
+                                    const void* w0_hi, const void* w0_lo, const void* w1_hi, const void* w1_lo,
+                                    const float* s0, const float* t0, const float* s1, const float* t1, float* out,
+                                    const pfpp_planes* out_planes, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1,
+                                    int64_t C2, pfpp_stream_t stream) {
+  PFPP_REQUIRE(feats && xyz && new_xyz && idx && w0_hi && w0_lo && w1_hi && w1_lo && s0 && t0 && s1 && t1 && (out || out_planes), "null pointer");
+  PFPP_REQUIRE(pfpp_planes_ok(out_planes) && (!out_planes || out_planes->scale == 1.0f), "out_planes: 8-byte aligned hi / lo, scale 1");
   PFPP_REQUIRE(F >= 0 && N > 0 && S > 0, "bad sizes");
   PFPP_SUPPORTED(ns == 64 && D == 128 && C1 == 128 && C2 == 128, "fused set-abstraction layers 1+2: nsample 64, 128 features, widths 128/128 only");
   PFPP_REQUIRE(F * S < (1ll << 25), "too many neighbourhoods");
   PFPP_REQUIRE(pfpp::aligned16(feats) && pfpp::aligned16(w0_hi) && pfpp::aligned16(w0_lo) && pfpp::aligned16(w1_hi) && pfpp::aligned16(w1_lo) &&
-               pfpp::aligned16(out), "16-byte alignment");
+               (!out || pfpp::aligned16(out)), "16-byte alignment");
   if (F == 0) return PFPP_OK;
   Sa2P p;
+  p.out_hi = out_planes ? reinterpret_cast<_Float16*>(out_planes->hi) : nullptr;
+  p.out_lo = out_planes ? reinterpret_cast<_Float16*>(out_planes->lo) : nullptr;
   p.feats = feats; p.xyz = xyz; p.ctr = new_xyz; p.idx = idx;
   p.w0h = (const _Float16*)w0_hi; p.w0l = (const _Float16*)w0_lo; p.w1h = (const _Float16*)w1_hi; p.w1l = (const _Float16*)w1_lo;
   p.s0 = s0; p.t0 = t0; p.s1 = s1; p.t1 = t1;

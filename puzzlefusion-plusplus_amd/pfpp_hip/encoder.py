@@ -143,8 +143,10 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
     elif (SA_FUSED and fused and feats is not None and nsample == 64 and feats.shape[2] == 128
           and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N) == (128, 128)):
         # level 2: grouping + layers 1 and 2 in one kernel, layer 3 (+ max over nsample) as a GEMM
+        # the activation goes to layer 3 as split-f16 planes (same bytes as fp32): layer 3 is then the LDS-DMA plane GEMM with no
+        # conversion work in its loop
         h = ops.sa_mlp2_fused(xyz, new_xyz, grp[2], ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.s0"], pk[f"{name}.t0"],
-                              pk[f"{name}.s1"], pk[f"{name}.t1"])
+                              pk[f"{name}.s1"], pk[f"{name}.t1"], as_planes=ops.split_mode())
         h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
         new_feats = h.view(F, npoint, -1)
         if capture is not None:
@@ -154,12 +156,17 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             capture[f"{name}.new_points"] = new_feats
         return new_xyz, new_feats
     else:
+        rows = F * npoint * nsample
+        sp = ops.split_mode() and ops.GEMM_MODE == "f16x3"      # activations between the layers as split-f16 planes
         if fused:
-            h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+            h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu",
+                                   out=ops.SplitAct.empty(rows, pk[f"{name}.w0"].N, xyz.device) if sp else None)
         else:
-            h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu")
+            h = ops.linear(A, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu",
+                           out=ops.SplitAct.empty(rows, pk[f"{name}.w0"].N, xyz.device) if sp else None)
         del A
-        h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu")
+        h = ops.linear(h, pk[f"{name}.w1"], scale=pk[f"{name}.s1"], shift=pk[f"{name}.t1"], act="relu",
+                       out=ops.SplitAct.empty(rows, pk[f"{name}.w1"].N, xyz.device) if sp else None)
         h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
     new_feats = h.view(F, npoint, -1)
     if capture is not None:

@@ -396,7 +396,7 @@ def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, act: str 
 
 
 def grouped_linear(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, w, bias=None, *,
-                   act: str = "none", scale=None, shift=None, pool: int = 0, stats=None) -> torch.Tensor:
+                   act: str = "none", scale=None, shift=None, pool: int = 0, stats=None, out=None) -> torch.Tensor:
     """first 1x1 convolution of a set-abstraction level applied to the grouped neighbourhoods WITHOUT materialising them:
     linear(group_gather(xyz, new_xyz, feats, idx), w, ...) with the gather done by the GEMM's A loader
     (pfpp_gemm_args.gather_*; f16x3 mode, w = packing.PW)."""
@@ -406,7 +406,7 @@ def grouped_linear(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[tor
     if feats is not None and (feats.shape[:2] != (F, N) or not feats.is_contiguous()):
         raise ValueError("grouped_linear: feats must be a contiguous [F,N,D]")
     return gemm(None if feats is None else feats.view(F * N, D), w, M=F * S * ns, N=w.N, K=D + 4, lda=D, bias=bias, scale=scale,
-                shift=shift, act=act, pool=pool, stats=stats, gather=(idx, xyz, new_xyz), mode="f16x3")
+                shift=shift, act=act, pool=pool, stats=stats, gather=(idx, xyz, new_xyz), mode="f16x3", out=out)
 
 
 def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w0, w1, w2, s0, t0, s1, t1, s2, t2) -> torch.Tensor:
@@ -426,9 +426,10 @@ def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w
     return out
 
 
-def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, w1, s0, t0, s1, t1) -> torch.Tensor:
+def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, w1, s0, t0, s1, t1,
+                  as_planes: bool = False):
     """grouping + the first two folded [conv, BN, ReLU] of a set-abstraction level with input features in one kernel
-    (pfpp_sa_mlp2_fused) -> [F*S*ns, C2], the input of the level's third convolution"""
+    (pfpp_sa_mlp2_fused) -> [F*S*ns, C2], the input of the level's third convolution; as_planes: a SplitAct (split-f16 planes)"""
     _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx"); _chk(feats, torch.float32, "feats")
     F, N, _ = xyz.shape
     _, S, ns = idx.shape
@@ -437,6 +438,13 @@ def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor,
         _chk(t, torch.float32, nm)
     if feats.shape[:2] != (F, N) or w0.hi.shape != (w0.N, D + 8) or w1.hi.shape != (w1.N, w0.N):
         raise ValueError("sa_mlp2_fused: shapes do not chain (feats [F,N,D], w0 planes [C1,D+8], w1 planes [C2,C1])")
+    if as_planes:
+        sp = SplitAct.empty(F * S * ns, w1.N, xyz.device)
+        pc = _lib.PlanesC(sp.hi.data_ptr(), sp.lo.data_ptr(), 1.0)
+        check(_lib.load().pfpp_sa_mlp2_fused_p(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi),
+                                               _ptr(w1.lo), _ptr(s0), _ptr(t0), _ptr(s1), _ptr(t1), None, C.byref(pc), F, N, S, ns, D, w0.N,
+                                               w1.N, _stream()), "pfpp_sa_mlp2_fused_p")
+        return sp
     out = torch.empty((F * S * ns, w1.N), dtype=torch.float32, device=xyz.device)
     check(_lib.load().pfpp_sa_mlp2_fused(_ptr(feats), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi), _ptr(w1.lo),
                                          _ptr(s0), _ptr(t0), _ptr(s1), _ptr(t1), _ptr(out), F, N, S, ns, D, w0.N, w1.N, _stream()),
