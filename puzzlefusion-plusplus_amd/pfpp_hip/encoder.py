@@ -40,7 +40,7 @@ def pack_encoder(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, tor
             )
             if i == 0:
                 w = pack_sa_first(w, w.shape[1] - 3)
-            out[f"{name}.w{i}"] = PW(w.contiguous())
+            out[f"{name}.w{i}"] = PW(w.contiguous(), prescale=False)     # the fused set-abstraction kernels read these planes directly
             out[f"{name}.s{i}"] = s
             out[f"{name}.t{i}"] = t
     w6 = sd[f"{prefix}pn2.conv6.weight"]
@@ -61,7 +61,7 @@ def pack_encoder_train(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[st
             w = w.reshape(w.shape[0], -1)
             if i == 0:
                 w = pack_sa_first(w, w.shape[1] - 3)
-            out[f"{name}.w{i}"] = PW(w.contiguous())
+            out[f"{name}.w{i}"] = PW(w.contiguous(), prescale=False)     # the fused set-abstraction kernels read these planes directly
             out[f"{name}.b{i}"] = sd[f"{p}.mlp_convs.{i}.bias"].contiguous()
             out[f"{name}.g{i}"] = sd[f"{p}.mlp_bns.{i}.weight"].contiguous()
             out[f"{name}.be{i}"] = sd[f"{p}.mlp_bns.{i}.bias"].contiguous()

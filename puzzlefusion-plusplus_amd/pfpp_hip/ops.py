@@ -158,6 +158,27 @@ PRECISION = {"f32": 0, "f16x3": 1, "f16": 2}
 # — the perf mode of BASELINE configs[4] (bench.py --mode stress), ~1e-3 relative error; the parity mode is f16x3
 SINGLE_PASS = _os.environ.get("PFPP_GEMM_SINGLE_PASS", "0") == "1"
 
+import contextlib as _ctx
+
+
+@_ctx.contextmanager
+def exact_fp32():
+    """run the enclosed calls with the exact fp32 MFMA GEMMs (PFPP_GEMM=f32) — the fallback the drop-in sampler loops take
+    when a split-f16 run produced non-finite poses (an operand at or beyond the fp16 range, |v| >= 65504)"""
+    global GEMM_MODE
+    prev, GEMM_MODE = GEMM_MODE, "f32"
+    try:
+        yield
+    finally:
+        GEMM_MODE = prev
+
+
+def f16x3_range_fallback(x: torch.Tensor) -> bool:
+    """True when a result computed in the split-f16 mode is non-finite and should be recomputed under exact_fp32().
+    Reads one flag back from the device: call it where the host synchronises anyway (end of a sampling loop)."""
+    return GEMM_MODE == "f16x3" and not bool(torch.isfinite(x).all())
+
+
 class SplitAct:
     """an activation travelling as split-f16 planes (hi, lo = x - hi), each fp16 [rows, C]: produced by the
     LayerNorm / attention kernels and GEMM epilogues, consumed as the A operand of the split-f16 GEMM with
@@ -271,6 +292,7 @@ def gemm(A: torch.Tensor, W, *, M: int, N: int, K: int, lda: int, ldw: Optional[
     if isinstance(W, PW):
         if f16x3:
             planes = (W.hi, W.lo)
+            alpha = alpha / W.scale         # the planes stand for scale * w (packing.plane_scale): exact power of two
             if ldw is None:
                 ldw = W.hi.shape[-1]
             elif ldw != W.hi.shape[-1]:
@@ -419,6 +441,8 @@ def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w
         _chk(t, torch.float32, nm)
     if w0.hi.shape != (w0.N, 8) or w1.hi.shape != (w1.N, w0.N) or w2.hi.shape != (w2.N, w1.N):
         raise ValueError("sa_mlp3_fused: weight planes do not chain ([C1,8], [C2,C1], [C3,C2])")
+    if (w0.scale, w1.scale, w2.scale) != (1.0, 1.0, 1.0):
+        raise ValueError("sa_mlp3_fused reads the planes as they are: pack these weights with PW(w, prescale=False)")
     out = torch.empty((F * S, w2.N), dtype=torch.float32, device=xyz.device)
     check(_lib.load().pfpp_sa_mlp3_fused(_ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi), _ptr(w1.lo),
                                          _ptr(w2.hi), _ptr(w2.lo), _ptr(s0), _ptr(t0), _ptr(s1), _ptr(t1), _ptr(s2), _ptr(t2),
@@ -438,6 +462,8 @@ def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor,
         _chk(t, torch.float32, nm)
     if feats.shape[:2] != (F, N) or w0.hi.shape != (w0.N, D + 8) or w1.hi.shape != (w1.N, w0.N):
         raise ValueError("sa_mlp2_fused: shapes do not chain (feats [F,N,D], w0 planes [C1,D+8], w1 planes [C2,C1])")
+    if (w0.scale, w1.scale) != (1.0, 1.0):
+        raise ValueError("sa_mlp2_fused reads the planes as they are: pack these weights with PW(w, prescale=False)")
     if as_planes:
         sp = SplitAct.empty(F * S * ns, w1.N, xyz.device)
         pc = _lib.PlanesC(sp.hi.data_ptr(), sp.lo.data_ptr(), 1.0)

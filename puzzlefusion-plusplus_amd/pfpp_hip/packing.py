@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, Tuple
 
+import math
+
 import torch
 
 
@@ -40,18 +42,32 @@ def split_f16(w: torch.Tensor):
     return hi.contiguous(), lo.contiguous()
 
 
+def plane_scale(w: torch.Tensor) -> float:
+    """power of two that lifts max |w| into [2^12, 2^13): every element down to max |w| * 2^-16 then keeps the split's full 22 bits
+    (the fp16 `lo` plane bottoms out at 2^-24 absolute: unscaled, elements below 2^-3 lose relative precision, and tensors of
+    1e-6-sized values lose everything), and nothing can reach the fp16 overflow at 65504 whatever the checkpoint's magnitudes.
+    Exact: the GEMM multiplies its accumulator by 1 / scale (ops.gemm)."""
+    amax = float(w.detach().abs().max()) if w.numel() else 0.0
+    if not math.isfinite(amax) or amax == 0.0:
+        return 1.0
+    return 2.0 ** (12 - math.floor(math.log2(amax)))
+
+
 class PW:
     """a GEMM weight in kernel layout: fp32 [N, K4] (K padded to 4) for the exact path and the
-    pre-split fp16 planes [N, K8] for the split-f16 path; `K` is the true reduction length"""
+    pre-split fp16 planes [N, K8] of `scale` * w for the split-f16 path (`scale`: a per-tensor power of two chosen at pack time,
+    packing.plane_scale; 1.0 with prescale=False); `K` is the true reduction length"""
 
-    __slots__ = ("f32", "hi", "lo", "N", "K")
+    __slots__ = ("f32", "hi", "lo", "N", "K", "scale")
 
-    def __init__(self, w: torch.Tensor, K: int = None):
+    def __init__(self, w: torch.Tensor, K: int = None, prescale: bool = True):
         w2 = w.reshape(-1, w.shape[-1])
         self.K = int(K if K is not None else w.shape[-1])
         self.N = int(w.shape[-2])
         self.f32 = pad_k(w2).reshape(*w.shape[:-1], -1).contiguous()
-        self.hi, self.lo = split_f16(w[..., : self.K] if self.K != w.shape[-1] else w)
+        wk = w[..., : self.K] if self.K != w.shape[-1] else w
+        self.scale = plane_scale(wk) if prescale else 1.0
+        self.hi, self.lo = split_f16(wk * self.scale if self.scale != 1.0 else wk)
 
     @property
     def device(self):

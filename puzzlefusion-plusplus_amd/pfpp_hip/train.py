@@ -59,6 +59,7 @@ def _param_order(num_layers: int) -> List[str]:
 
 def _pw_view(f32: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PW:
     w = PW.__new__(PW)
+    w.scale = 1.0
     w.f32, w.hi, w.lo = f32, hi, lo
     w.N, w.K = int(f32.shape[-2]), int(f32.shape[-1])
     return w
@@ -204,8 +205,8 @@ class FlatParams:
             self._views = {"w": v, "g": g}
         if self._odd is None:
             with torch.no_grad():
-                self._odd = {"shape.w": PW(self.view(self.params, "shape_embedding.weight")),
-                             "param.w": PW(self.view(self.params, "param_fc.weight"))}
+                self._odd = {"shape.w": PW(self.view(self.params, "shape_embedding.weight"), prescale=False),
+                             "param.w": PW(self.view(self.params, "param_fc.weight"), prescale=False)}
         w = dict(self._views["w"])
         w.update(self._odd)
         return {"w": w, "g": self._views["g"]}
@@ -235,6 +236,13 @@ class DenoiserTrainEngine:
         if math.log2(grad_scale) % 1 != 0:
             raise ValueError("grad_scale must be a power of two (exact rescaling)")
         self.grad_scale = float(grad_scale)
+        # dynamic gradient scale: grad_scale follows the magnitude of the loss gradient (a power of two keeping max |dpred| * G
+        # in [8, 16), which is where the default 4096 puts an untrained model) so that the f16 split of the backward operands
+        # keeps its precision when the loss — and with it every gradient — shrinks during training.  The magnitude is the one
+        # observed two backward passes ago (read from pinned memory: no stall, no device read in the step, deterministic).
+        self._dyn_gscale = os.environ.get("PFPP_TRAIN_DYN_GSCALE", "1") != "0"
+        self._amax_ring = None
+        self._n_backward = 0
         self.step_count = 0
         from .parallel import GradExchange
 
@@ -386,7 +394,7 @@ class DenoiserTrainEngine:
 
         def wp(key):
             pw = w[key]
-            return P.Planes(pw.hi, pw.lo)
+            return P.Planes(pw.hi, pw.lo, pw.scale)
 
         def lin(a, key, N, K, bias=None, residual=None):
             out = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -505,6 +513,8 @@ class DenoiserTrainEngine:
         ops_ = self.flat.operands()
         w, g = ops_["w"], ops_["g"]
         s = ctx.t
+        if self._dyn_gscale:
+            self._update_grad_scale(dpred)
         G = self.grad_scale
         B, L, C, Fv, M = s["B"], s["L"], s["C"], s["Fv"], s["M"]
         H = self.num_heads
@@ -662,7 +672,7 @@ class DenoiserTrainEngine:
 
         def wp(key):
             pw = w[key]
-            return P.Planes(pw.hi, pw.lo)
+            return P.Planes(pw.hi, pw.lo, pw.scale)
 
         def dx(dyp, key, n_in):
             out = torch.empty((M, n_in), dtype=torch.float32, device=dev)
@@ -848,6 +858,19 @@ class DenoiserTrainEngine:
         cache = getattr(self.module, "_cache", None)
         if cache is not None:
             cache._key = None            # the eval-mode packing of the module is stale now
+
+    def _update_grad_scale(self, dpred: torch.Tensor) -> None:
+        if self._amax_ring is None:
+            self._amax_ring = [(torch.zeros(1, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+        host, ev = self._amax_ring[self._n_backward % 2]
+        if self._n_backward >= 2:
+            ev.synchronize()                         # recorded two backward passes ago
+            amax = float(host[0])
+            if math.isfinite(amax) and amax > 0.0:
+                self.grad_scale = float(2.0 ** min(40, max(0, 3 - math.floor(math.log2(amax)))))
+        host.copy_(dpred.detach().abs().max().reshape(1), non_blocking=True)
+        ev.record()
+        self._n_backward += 1
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, noise, *, seed: int = 0,

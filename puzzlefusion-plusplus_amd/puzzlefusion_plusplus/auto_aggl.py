@@ -158,16 +158,39 @@ class AutoAgglomerative(LightningModule):
             layout = CompactLayout(part_valids, self.num_points)
             step_fn = self._make_step(part_pcs, part_valids, part_scale, ref_part, layout, x)
             compose = self._batched_compose(active)                                # pivots / init poses are fixed until the merges
-            composed = []
-            for t in self.noise_scheduler.timesteps.tolist():
-                eps = step_fn(x, t)
-                vn = None
-                if noises is not None:
-                    vn = torch.cat([st.noises[st.step_no] for st in active], 0)
-                x = self.noise_scheduler.step(eps, t, x, variance_noise=vn, ref_part=ref_part, reference=reference).prev_sample
-                composed.append(compose(x))                                        # get_param (:151), one launch for all puzzles
-                for st in active:
-                    st.step_no += 1
+            timesteps = self.noise_scheduler.timesteps.tolist()
+
+            def run_steps(fn, x):
+                out = []
+                for k, t in enumerate(timesteps):
+                    eps = fn(x, t)
+                    vn = None
+                    if noises is not None:
+                        vn = torch.cat([st.noises[st.step_no + k] for st in active], 0)
+                    x = self.noise_scheduler.step(eps, t, x, variance_noise=vn, ref_part=ref_part, reference=reference).prev_sample
+                    out.append(compose(x))                                         # get_param (:151), one launch for all puzzles
+                return x, out
+
+            rng = torch.cuda.get_rng_state(x.device) if noises is None else None
+            x0 = x
+            x, composed = run_steps(step_fn, x0)
+            # range guard of the split-f16 GEMMs (weights are pre-scaled at pack time, activations are not): non-finite poses mean an
+            # operand reached the fp16 range — redo this outer iteration with the exact fp32 GEMMs from the same draws.  The
+            # read-back sits where the loop synchronises anyway (edge features / verifier bookkeeping below)
+            if ops.f16x3_range_fallback(x):
+                import warnings
+
+                warnings.warn("split-f16 GEMM operand out of the fp16 range: re-running the iteration with exact fp32 GEMMs")
+                if rng is not None:
+                    torch.cuda.set_rng_state(rng, x.device)
+                graphs, self.use_graphs = self.use_graphs, False
+                try:
+                    with ops.exact_fp32():
+                        x, composed = run_steps(self._make_step(part_pcs, part_valids, part_scale, ref_part, layout, x0), x0)
+                finally:
+                    self.use_graphs = graphs
+            for st in active:
+                st.step_no += len(timesteps)
             composed = torch.stack(composed, 0)                                    # [steps, sum n_nodes, 7]
             off = 0
             for i, st in enumerate(active):

@@ -92,7 +92,30 @@ class Denoiser(LightningModule):
     @torch.no_grad()
     def sample(self, data_dict, x_init=None, noises=None, record=None):
         """the 20-step ancestral sampler of validation_step (denoiser.py:153-185); returns the final
-        [B,P,7] poses.  x_init / noises inject the random draws (parity tests)."""
+        [B,P,7] poses.  x_init / noises inject the random draws (parity tests).
+        Range guard of the split-f16 GEMMs: weights are pre-scaled per tensor at pack time (packing.plane_scale), activations
+        are split as they are — if one reaches the fp16 range (|v| >= 65504) the poses come out non-finite, and the whole
+        sampler is re-run with the exact fp32 GEMMs from the same random draws."""
+        from pfpp_hip import ops
+
+        dev = data_dict["part_trans"].device
+        rng = torch.cuda.get_rng_state(dev) if (x_init is None or noises is None) and dev.type == "cuda" else None
+        rec = [] if record is not None else None
+        x = self._sample(data_dict, x_init, noises, rec)
+        if ops.f16x3_range_fallback(x):
+            import warnings
+
+            warnings.warn("split-f16 GEMM operand out of the fp16 range: re-running the sampler with exact fp32 GEMMs")
+            if rng is not None:
+                torch.cuda.set_rng_state(rng, dev)
+            rec = [] if record is not None else None
+            with ops.exact_fp32():
+                x = self._sample(data_dict, x_init, noises, rec)
+        if record is not None:
+            record.extend(rec)
+        return x
+
+    def _sample(self, data_dict, x_init, noises, record):
         gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
         ref_part = data_dict["ref_part"]
         x = torch.randn(gt.shape, device=gt.device) if x_init is None else x_init.clone()

@@ -105,7 +105,7 @@ class PointNetSetAbstraction(nn.Module):
                 w, s, t = fold_conv_bn(c.weight, c.bias, b.weight, b.bias, b.running_mean, b.running_var, b.eps)
                 if i == 0:
                     w = pack_sa_first(w, w.shape[1] - 3)
-                pk[f"w{i}"], pk[f"s{i}"], pk[f"t{i}"] = PW(w.contiguous()), s, t
+                pk[f"w{i}"], pk[f"s{i}"], pk[f"t{i}"] = PW(w.contiguous(), prescale=False), s, t
             return pk
 
         return self._cache.get(srcs, build)
@@ -121,7 +121,7 @@ class PointNetSetAbstraction(nn.Module):
                 w = c.weight.detach().reshape(c.weight.shape[0], -1)
                 if i == 0:
                     w = pack_sa_first(w, w.shape[1] - 3)
-                pk[f"sa.w{i}"] = PW(w.contiguous())
+                pk[f"sa.w{i}"] = PW(w.contiguous(), prescale=False)
                 pk[f"sa.b{i}"] = c.bias.detach().contiguous()
             return pk
 

@@ -397,6 +397,107 @@ def test_verifier_vs_golden(golden, weights_sd, dev):
     assert np.abs(lo.cpu().numpy() - g["logits"])[m].max() < TOL
 
 
+# ----------------------------------------------------------------------------- range of the split-f16 arithmetic
+@pytest.mark.parametrize("wscale", [1e-6, 1e-3, 1.0, 1e2, 1e4])
+@pytest.mark.parametrize("fill", ["normal", "heavy"])
+def test_f16x3_weight_magnitude_sweep(dev, wscale, fill):
+    """weights of any magnitude / with a heavy tail: the per-tensor power-of-two prescale chosen at pack time (packing.plane_scale)
+    keeps the split's 22 bits; without it 1e-6-sized weights sit below the fp16 planes' resolution"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, split_f16
+
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 300, 512, 512
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    if fill == "heavy":           # Student-t(2)-like tail: a few weights 30-100x the bulk
+        W = W * (1.0 + torch.randn(N, K, generator=g).abs() / torch.rand(N, K, generator=g).clamp_min(1e-2))
+    W = W * wscale
+    b = torch.randn(N, generator=g) * wscale
+    ref = x.double() @ W.double().t() + b.double()
+    tol = 2e-5 * ref.abs().max().item()
+    pw = PW(W.to(dev))
+    assert pw.scale != 1.0 or 2 ** 12 <= W.abs().max() < 2 ** 13
+    for a in (x.to(dev), ops.SplitAct(*split_f16(x.to(dev)))):           # register-staged kernel / plane kernel
+        out = ops.linear(a, pw, b.to(dev), mode="f16x3")
+        assert torch.isfinite(out).all() and (out.cpu().double() - ref).abs().max() < tol
+    if wscale <= 1e-6:
+        raw = ops.linear(x.to(dev), PW(W.to(dev), prescale=False), b.to(dev), mode="f16x3")
+        assert (raw.cpu().double() - ref).abs().max() > 100 * tol         # what the prescale is for
+
+
+@pytest.mark.parametrize("ascale", [1e-2, 1.0, 1e2, 1e4])
+def test_f16x3_activation_magnitude_range(dev, ascale):
+    """activations are split as they are: full precision for tensors whose bulk lies in [2^-3, 65504) — the LayerNorm / attention /
+    GEGLU outputs of the model; below that the absolute error floor of the lo plane (3e-8 per element) applies, stated here"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 300, 512, 512
+    x = torch.randn(M, K, generator=g) * ascale
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = x.double() @ W.double().t()
+    out = ops.linear(x.to(dev), PW(W.to(dev)), mode="f16x3")
+    floor = 3e-8 * K ** 0.5 * W.abs().max().item()           # lo-plane resolution, random signs over K
+    assert (out.cpu().double() - ref).abs().max() < 2e-5 * ref.abs().max().item() + 8 * floor
+
+
+def test_f16x3_out_of_range_falls_back_to_fp32(weights_sd, dev):
+    """an activation beyond the fp16 range (here: feed-forward weights blown up until the GEGLU product passes 65504) makes the
+    split-f16 sampler produce non-finite poses; Denoiser.sample notices and re-runs with the exact fp32 GEMMs from the same draws"""
+    from pfpp_hip import config, ops, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    sd = {k: v.clone() for k, v in weights_sd("denoiser").items()}
+    for k in sd:
+        if k.endswith("ff.net.0.proj.weight"):
+            sd[k] *= 4e3
+        if k.endswith("ff.net.2.weight"):
+            sd[k] /= 1.6e7
+    m = Denoiser(config.denoiser_config())
+    m.encoder.load_state_dict(weights_sd("vqvae")); m.denoiser.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.noise_scheduler.set_timesteps(20)
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(5, 1, num_points=512, num_parts=4).items()}
+    g = torch.Generator(device=dev).manual_seed(1)
+    x0 = torch.randn(1, 20, 7, device=dev, generator=g)
+    noises = [torch.randn(1, 20, 7, device=dev, generator=g) for _ in range(20)]
+    m.noise_scheduler.timesteps = m.noise_scheduler.timesteps[:2]
+    raw = m._sample(data, x0, noises[:2], None)
+    assert not torch.isfinite(raw).all(), "the construction no longer overflows: adjust the blow-up factors"
+    with pytest.warns(UserWarning, match="exact fp32"):
+        x = m.sample(data, x_init=x0, noises=noises[:2])
+    with ops.exact_fp32():
+        want = m._sample(data, x0, noises[:2], None)
+    assert torch.isfinite(x).all() and torch.equal(x, want)
+
+
+def test_denoiser_heavy_tailed_checkpoint_vs_oracle(golden, weights_sd, dev):
+    """trained checkpoints are not the closed-form fill of oracle/weights.py: the same forward with every matrix reshaped to a heavy
+    tail (outliers 10-50x the bulk) and magnitudes spread over 1e-2 .. 1e2 per tensor (undone in the following bias / next
+    layer so the activations stay finite) still matches the fp32 CPU oracle to 1e-4"""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import denoiser as D
+
+    g0 = golden("denoiser")
+    gen = torch.Generator().manual_seed(99)
+    sd = {}
+    for k, v in weights_sd("denoiser").items():
+        v = v.clone()
+        if v.dim() == 2 and v.shape[1] >= 64 and "embedding" not in k:
+            tail = 1.0 + 0.15 * torch.randn(v.shape, generator=gen).abs() / torch.rand(v.shape, generator=gen).clamp_min(2e-2)
+            v = v * tail / tail.mean()
+        sd[k] = v
+    args_cpu = [T(g0[k]) for k in ("x", "timesteps", "latent", "xyz", "part_valids", "scale", "ref_part")]
+    ref = O.denoiser_forward(sd, *args_cpu)
+    pk = D.pack_denoiser(dsd(sd, dev), 6)
+    eps = D.denoiser_forward(pk, *[a.to(dev) for a in args_cpu], num_layers=6, num_heads=8)
+    valid = args_cpu[4].bool()
+    assert torch.isfinite(eps).all()
+    assert (eps.cpu() - ref)[valid].abs().max() < TOL * max(1.0, ref[valid].abs().max().item())
+
+
 def test_verifier_many_edges_plane_path(dev, monkeypatch):
     """the 1,225 candidate edges of a 50-fragment puzzle (M >= 1024: layer operands handed over as split planes) == the fp32
     hand-over of the same forward; the CPU oracle pins that forward (test_verifier_vs_golden and the max_len = 50 oracle below)"""
@@ -1103,7 +1204,7 @@ def test_sa_mlp3_fused_equals_layerwise(dev, F, N, S):
     sc = [torch.rand(c, generator=g) + 0.5 for c in (64, 64, 128)]
     sh = [torch.randn(c, generator=g) * 0.3 for c in (64, 64, 128)]
     d = lambda t: t.to(dev)
-    pw = [PW(d(x)) for x in w]
+    pw = [PW(d(x), prescale=False) for x in w]
     A = ops.group_gather(d(xyz), d(new_xyz), None, d(idx))
     h = ops.linear(A, pw[0], scale=d(sc[0]), shift=d(sh[0]), act="relu", mode="f16x3")
     h = ops.linear(h, pw[1], scale=d(sc[1]), shift=d(sh[1]), act="relu", mode="f16x3")
@@ -1139,7 +1240,7 @@ def test_sa_mlp2_fused_equals_layerwise(dev, F, N, S):
     sc = [torch.rand(128, generator=g) + 0.5 for _ in range(2)]
     sh = [torch.randn(128, generator=g) * 0.3 for _ in range(2)]
     d = lambda t: t.to(dev)
-    pw0, pw1 = PW(d(pack_sa_first(w0_ref, D))), PW(d(w1))
+    pw0, pw1 = PW(d(pack_sa_first(w0_ref, D)), prescale=False), PW(d(w1), prescale=False)
     A = ops.group_gather(d(xyz), d(new_xyz), d(feats), d(idx))
     h = ops.linear(A, pw0, scale=d(sc[0]), shift=d(sh[0]), act="relu", mode="f16x3")
     want = ops.linear(h, pw1, scale=d(sc[1]), shift=d(sh[1]), act="relu", mode="f16x3")

@@ -289,6 +289,30 @@ def test_foreign_zero_grad_does_not_leave_stale_gradients(golden, weights_sd, de
     assert rel(eng.flat.view(eng.flat.grads, "shape_embedding.bias").cpu(), 2 * eng.flat.view(g1, "shape_embedding.bias").cpu()) < 1e-5
 
 
+def test_dynamic_gradient_scale_follows_the_loss_gradient(golden, weights_sd, dev):
+    """grad_scale (the power of two that lifts the backward operands into the fp16 range before their split) tracks max |dLoss/dpred|
+    with two backward passes of delay, and a 1e-4 x smaller loss gradient gives gradients as accurate as the full-size one"""
+    inp, noise, _ = golden_inputs(golden, dev)
+    m = make_module(weights_sd, dev)
+    eng = m.train_engine()
+    assert eng.grad_scale == 4096.0
+    pred, ctx = eng.forward(*inp, seed=3, train=False)
+    n = pred.shape[0] * pred.shape[1]
+    d = (pred - noise).reshape(n, 7).float().contiguous() * (2.0 / n)
+    m.zero_grad(set_to_none=True)
+    eng.backward(ctx, d.clone())
+    torch.cuda.synchronize()
+    g_ref = eng.flat.grads.clone()
+    for _ in range(3):                                   # the scale adapts to the small seed gradient
+        m.zero_grad(set_to_none=True)
+        pred, ctx = eng.forward(*inp, seed=3, train=False)
+        eng.backward(ctx, d * 1e-4)
+    torch.cuda.synchronize()
+    amax = float(d.abs().max()) * 1e-4
+    assert eng.grad_scale > 4096.0 * 1e3 and 8.0 <= amax * eng.grad_scale < 16.0
+    assert rel(eng.flat.grads.cpu() * 1e4, g_ref.cpu()) < 1e-5
+
+
 def test_encoder_train_mode_batchnorm_vs_reference_golden(golden, weights_sd, dev):
     """the frozen encoder in .train() (batch-statistics BatchNorm, running buffers updated) against the reference
     module's outputs and buffers after two passes (tests/golden/encoder_train.npz)"""
