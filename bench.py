@@ -100,7 +100,7 @@ def parse():
 class SamplerWorkload:
     """device-resident state of the sampler loop for one batch of puzzles"""
 
-    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, compact: bool = False):
+    def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, compact: bool = False, ids=None):
         from pfpp_hip import config, synthetic
         from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
 
@@ -109,7 +109,7 @@ class SamplerWorkload:
         self.model.denoiser.compact_padded = compact
         with torch.no_grad():   # a codebook on the scale of the latents (a trained one is)
             self.model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
-        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts)
+        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts, ids=ids)
         self.data = {k: v.to(dev) for k, v in data.items()}
         self.n_frag = int(self.data["part_valids"].sum().item())
         gt = torch.cat([self.data["part_trans"], self.data["part_rots"]], dim=-1).float().contiguous()
@@ -143,7 +143,7 @@ class TrainWorkload:
     """device-resident state of the training loop for one batch of puzzles"""
 
     def __init__(self, batch: int, points: int, parts, first_id: int, dev: torch.device, latents_given: bool = False,
-                 pipeline: bool = True):
+                 pipeline: bool = True, ids=None):
         from pfpp_hip import config, synthetic
         from pfpp_hip.train import DenoiserTrainEngine
         from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
@@ -156,7 +156,7 @@ class TrainWorkload:
             p_.requires_grad = False
         self.model.train()
         self.engine = DenoiserTrainEngine(self.model.denoiser)
-        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts)
+        data = synthetic.make_batch(first_id, batch, num_points=points, num_parts=parts, ids=ids)
         self.data = {k: v.to(dev) for k, v in data.items()}
         self.n_frag = int(self.data["part_valids"].sum().item())
         self.gt = torch.cat([self.data["part_trans"], self.data["part_rots"]], dim=-1).float().contiguous()
@@ -514,16 +514,30 @@ def main():
 
     train = args.mode == "train"
     stress = args.mode == "stress"
+    # N > 1: the job's puzzles (the same 1000 * r + i ids the ranks used to take in order) are dealt to the ranks by valid-fragment
+    # count — the encoder's work per puzzle varies ~10x with it and the step ends with the slowest rank
+    ids, balance = None, None
+    if world > 1 and not stress and args.parts is None and os.environ.get("PFPP_BENCH_BALANCE", "1") == "1":
+        from pfpp_hip import synthetic
+        from pfpp_hip.parallel import balanced_assignment
+
+        pool = [1000 * r + i for r in range(world) for i in range(args.batch)]
+        counts = [synthetic.num_parts_of(i) for i in pool]
+        assign = balanced_assignment(counts, world, equal_count=True)
+        ids = [pool[j] for j in assign[rank]]
+        loads = [sum(counts[j] for j in a) for a in assign]
+        naive = [sum(counts[r * args.batch:(r + 1) * args.batch]) for r in range(world)]
+        balance = {"fragments_per_rank": loads, "in_order_would_be": naive}
     if stress:
         ops.SINGLE_PASS = os.environ.get("PFPP_STRESS_F16X3", "0") != "1"       # single-pass fp16 on the plane GEMMs (configs[4])
         wl = StressWorkload(args.stress_batch, first_id=1000 * rank, dev=dev)
     elif train:
         wl = TrainWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, latents_given=args.latents_given,
-                           pipeline=not (args.no_pipeline or args.serial))
+                           pipeline=not (args.no_pipeline or args.serial), ids=ids)
         if args.serial:
             wl.engine.single_stream()
     else:
-        wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact)
+        wl = SamplerWorkload(args.batch, args.points, args.parts, first_id=1000 * rank, dev=dev, compact=args.compact, ids=ids)
     for _ in range(args.warmup):
         wl.step()
 
@@ -576,7 +590,8 @@ def main():
                 print(f"  {ms_ / args.steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // args.steps:3d}  {key}", file=sys.stderr)
         name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
-        single = "gemm_pl_kernel" in name and name.split(">")[0].rstrip().endswith("true")      # last template flag: single-pass fp16
+        flags = name.split("<")[1].split(">")[0].split(", ") if "gemm_pl_kernel<" in name else []
+        single = len(flags) > 9 and flags[9] == "true"                     # template flag X1: single-pass fp16
         split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name) and not single
         # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
         # FLOPs is the f16 dense peak / 3
@@ -598,6 +613,24 @@ def main():
         }
 
     extra = {}
+    if balance is not None:
+        extra["rank_balance"] = balance
+    if dist is not None and train and world > 1:
+        # the step's one exchange, alone: all-reduce of the flat gradient buffer (what GradExchange sends in 6 layer slices + 2)
+        gbuf = wl.engine.flat.grads
+        for _ in range(2):
+            dist.all_reduce(gbuf)
+        sync_all()
+        t_ar = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(gbuf)
+        sync_all()
+        t_ar = (time.perf_counter() - t_ar) / 5
+        nbytes = gbuf.numel() * 4
+        extra["gradient_all_reduce"] = {"bytes": nbytes, "ms": round(t_ar * 1e3, 3),
+                                        "algbw_GBps": round(nbytes / t_ar * 1e-9, 1),
+                                        "busbw_GBps": round(nbytes / t_ar * 1e-9 * 2 * (world - 1) / world, 1),
+                                        "note": "stand-alone, not overlapped; in the step it runs per layer under the backward"}
     roofline_hbm = None
     if rank == 0 and not args.no_roofline:
         if stress:

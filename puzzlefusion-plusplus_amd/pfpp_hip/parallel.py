@@ -23,14 +23,21 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def balanced_assignment(fragment_counts: List[int], world: int) -> List[List[int]]:
+def balanced_assignment(fragment_counts: List[int], world: int, equal_count: bool = False) -> List[List[int]]:
     """greedy longest-processing-time assignment of puzzles to ranks by valid-fragment count
-    (encoder work per puzzle varies ~10x with the fragment count)"""
-    order = sorted(range(len(fragment_counts)), key=lambda i: -fragment_counts[i])
+    (encoder work per puzzle varies ~10x with the fragment count).
+    equal_count: every rank gets the same number of puzzles (training: the per-rank batch size is fixed, and the sparse
+    embedding-gradient exchange needs equal shapes) — the heaviest unassigned puzzle goes to the least-loaded rank that still
+    has a free slot; len(fragment_counts) must then be a multiple of world."""
+    n = len(fragment_counts)
+    if equal_count and n % world:
+        raise ValueError("balanced_assignment(equal_count=True): the number of puzzles must be a multiple of the world size")
+    cap = n // world if equal_count else n
+    order = sorted(range(n), key=lambda i: (-fragment_counts[i], i))
     loads = [0] * world
     out: List[List[int]] = [[] for _ in range(world)]
     for i in order:
-        r = min(range(world), key=lambda k: (loads[k], k))
+        r = min((k for k in range(world) if len(out[k]) < cap), key=lambda k: (loads[k], k))
         out[r].append(i)
         loads[r] += fragment_counts[i]
     return out
@@ -66,13 +73,20 @@ class GradExchange:
     the factor that turns the summed gradients into the mean (folded into the optimizer kernel, no extra pass).
     Works on any backend (tested with gloo on CPU tensors)."""
 
-    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]], sparse_range: Tuple[int, int] = (0, 0)):
+    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]], sparse_range: Tuple[int, int] = (0, 0),
+                 zero1: bool = False):
         self.grads = grads
+        # ZeRO-1 (opt-in): a slice is reduce-SCATTERED — rank r ends up with the sum of the r-th 1/world of it, updates only that
+        # part of the parameters (optimizer work / world) and the ranks all-gather the updated parameters afterwards
+        # (gather_params).  Same bytes on the links as the all-reduce; the gather is not hidden under the backward.
+        self.zero1 = zero1
+        self._segments: List[Tuple[int, int, bool]] = []     # (a, b, sharded) in issue order, for the optimizer
         self.layer_ranges = list(layer_ranges)
         # [a, b) of the head slice that is NOT all-reduced: the timestep-embedding tables (a third of all parameters) get
         # gradients in only `batch` of their 3072 rows per step, so the ranks exchange those rows instead (gather_rows)
         self.sparse_range = sparse_range
         self._handles: List[object] = []
+        self._early: List[Tuple[int, int]] = []      # ranges of the head slice already reduced with a layer (AdaLN linears)
         self.enabled = True          # False: the owner accumulates locally (DenoiserTrainEngine.no_sync), nothing is reduced
 
     @staticmethod
@@ -84,15 +98,68 @@ class GradExchange:
     def reducing(self) -> bool:
         return self.enabled and self.active()
 
+    def _shardable(self, a: int, b: int) -> bool:
+        import torch.distributed as dist
+
+        return (b - a) % (8 * dist.get_world_size()) == 0        # every part 16-byte aligned in the fp16 planes too
+
+    def own_part(self, a: int, b: int) -> Tuple[int, int]:
+        import torch.distributed as dist
+
+        n = (b - a) // dist.get_world_size()
+        return a + dist.get_rank() * n, a + (dist.get_rank() + 1) * n
+
     def _reduce(self, a: int, b: int) -> None:
         import torch.distributed as dist
 
-        if b > a:
-            self._handles.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        if b <= a:
+            return
+        if self.zero1 and self._shardable(a, b):
+            self._segments.append((a, b, True))
+            x, y = self.own_part(a, b)
+            try:
+                self._handles.append(dist.reduce_scatter_tensor(self.grads[x:y], self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                return
+            except (RuntimeError, NotImplementedError):      # gloo has no reduce-scatter: the all-reduce leaves the same sum in the own part
+                pass
+        elif self.zero1:
+            self._segments.append((a, b, False))
+        self._handles.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
-    def layer_done(self, i: int) -> None:
+    def note_replicated(self, a: int, b: int) -> None:
+        """[a, b) already holds the summed gradient on every rank (the sparse table rows after gather_rows)"""
+        if self.zero1 and self.reducing() and b > a:
+            self._segments.append((a, b, self._shardable(a, b)))
+
+    def take_segments(self) -> List[Tuple[int, int, bool]]:
+        segs, self._segments = self._segments, []
+        return segs
+
+    def gather_params(self, params: torch.Tensor, segs) -> None:
+        """after the sharded optimizer step: every sharded segment's parameters from their owners, in place"""
+        import torch.distributed as dist
+
+        handles = []
+        for a, b, sharded in segs:
+            if not sharded:
+                continue
+            x, y = self.own_part(a, b)
+            try:
+                handles.append(dist.all_gather_into_tensor(params[a:b], params[x:y], async_op=True))
+            except (RuntimeError, NotImplementedError):
+                parts = [torch.empty_like(params[x:y]) for _ in range(dist.get_world_size())]
+                dist.all_gather(parts, params[x:y].contiguous())
+                params[a:b].copy_(torch.cat(parts))
+        for h in handles:
+            h.wait()
+
+    def layer_done(self, i: int, extra=()) -> None:
+        """reduce layer i's slice, plus `extra` [a, b) ranges of the head slice whose gradients are final with this layer"""
         if self.reducing():
             self._reduce(*self.layer_ranges[i])
+            for a, b in extra:
+                self._reduce(a, b)
+                self._early.append((a, b))
 
     def all_done(self, dense: bool = False) -> None:
         """the slices outside the layers.  dense = True also reduces the sparse range (gradient accumulation: the table rows of
@@ -100,12 +167,15 @@ class GradExchange:
         if self.reducing():
             a, b = self.sparse_range
             first = self.layer_ranges[0][0]
+            skip = sorted(self._early + ([(a, b)] if (b > a and not dense) else []))
             if b > a and not dense:
-                self._reduce(0, a)
-                self._reduce(b, first)
-            else:
-                self._reduce(0, first)
+                self.note_replicated(a, b)
+            pos = 0
+            for x, y in skip + [(first, first)]:          # the head slice minus what went with the layers / goes as rows
+                self._reduce(pos, min(x, first))
+                pos = max(pos, y)
             self._reduce(self.layer_ranges[-1][1], self.grads.numel())
+        self._early = []
 
     def gather_rows(self, rows: torch.Tensor, index: torch.Tensor, dim: int = 1):
         """every rank's (rows, index) concatenated along `dim` / 0 — the sparse form of an embedding-gradient exchange: the

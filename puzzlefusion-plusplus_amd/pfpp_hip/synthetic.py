@@ -94,10 +94,18 @@ def make_puzzle(puzzle_id: int, num_points: int = 1000, max_parts: int = 20, num
     return out
 
 
+def num_parts_of(puzzle_id: int, max_parts: int = 20) -> int:
+    """valid-fragment count make_puzzle(puzzle_id) will draw — without building the puzzle (load balancing over ranks)"""
+    rng = np.random.default_rng(1234 + puzzle_id)
+    return max(2, min(sample_num_parts(rng, max_parts), max_parts))
+
+
 def make_batch(first_id: int, batch: int, num_points: int = 1000, max_parts: int = 20,
                num_parts: Optional[int] = None, quantise_bits: Optional[int] = None,
-               device: str | torch.device = "cpu") -> Dict[str, torch.Tensor]:
-    items = [make_puzzle(first_id + i, num_points, max_parts, num_parts, quantise_bits) for i in range(batch)]
+               device: str | torch.device = "cpu", ids: Optional[list] = None) -> Dict[str, torch.Tensor]:
+    """puzzles first_id .. first_id + batch - 1, or the explicit list `ids`"""
+    ids = [first_id + i for i in range(batch)] if ids is None else list(ids)
+    items = [make_puzzle(i, num_points, max_parts, num_parts, quantise_bits) for i in ids]
     out = {}
     for k in items[0]:
         arr = np.stack([it[k] for it in items], 0)

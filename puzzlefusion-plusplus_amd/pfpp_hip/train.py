@@ -241,6 +241,8 @@ class DenoiserTrainEngine:
         # keeps its precision when the loss — and with it every gradient — shrinks during training.  The magnitude is the one
         # observed two backward passes ago (read from pinned memory: no stall, no device read in the step, deterministic).
         self._dyn_gscale = os.environ.get("PFPP_TRAIN_DYN_GSCALE", "1") != "0"
+        self._ada_per_layer = os.environ.get("PFPP_TRAIN_ADA_PER_LAYER", "1") != "0"
+        self._ada_layerwise = None
         self._amax_ring = None
         self._n_backward = 0
         self.step_count = 0
@@ -249,7 +251,8 @@ class DenoiserTrainEngine:
         # the 12 AdaLN timestep tables open the flat buffer (see _param_order): exchanged as rows, not as 75 MB of zeros
         self._sparse_tables = os.environ.get("PFPP_SPARSE_TABLE_GRADS", "1") == "1"
         n_tab = self.flat.offset[f"transformer_layers.0.norm1.linear.weight"]       # the tables are the first group of the layout
-        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges, (0, n_tab) if self._sparse_tables else (0, 0))
+        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges, (0, n_tab) if self._sparse_tables else (0, 0),
+                                      zero1=os.environ.get("PFPP_ZERO1", "0") == "1")
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
         self._side = (torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
@@ -546,6 +549,9 @@ class DenoiserTrainEngine:
         self._flush_dw()                                                                  # the heads' four small weight gradients
 
         dmods = torch.zeros_like(s["mods"])
+        # multi-rank: the two AdaLN linears of a block get their gradients as soon as the block's backward is through and travel with
+        # the block's slice (otherwise 25 MB of dense gradient would be left for the exposed tail after the backward)
+        self._ada_layerwise = (dmods, s["se"], g, B, C, G) if (self._exchange.reducing() and self._ada_per_layer) else None
         if self._planes:
             dtok = self._backward_layers_planes(s, w, g, dh_, dmods)
         else:
@@ -569,9 +575,11 @@ class DenoiserTrainEngine:
         # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
         n_ada = 2 * self.num_layers
         se = s["se"]
-        T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
-        T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
-                    accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+        if self._ada_layerwise is None:
+            T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
+            T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                        accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+        self._ada_layerwise = None
         dse = torch.empty_like(se)
         T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
                     sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
@@ -799,14 +807,25 @@ class DenoiserTrainEngine:
                 self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, **self._armed)
             self._early.append(i)
         if self._exchange.reducing():
+            extra = ()
+            if self._ada_layerwise is not None:
+                dmods, se, g, B, C, G = self._ada_layerwise
+                j = 2 * i
+                T.colsum(dmods[j:j + 2], g["ada.b"][j:j + 2], rows=B, cols=2 * C, ld=2 * C, batch=2, sx=B * 2 * C, so=2 * C)
+                T.gemm_grad(dmods[j:j + 2], se[j:j + 2], g["ada.w"][j:j + 2], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True,
+                            w_kmajor=True, accumulate=True, batch=2, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+                f = self.flat
+                t0 = "transformer_layers.0"
+                aw, ab = f.offset[f"{t0}.norm1.linear.weight"], f.offset[f"{t0}.norm1.linear.bias"]
+                extra = ((aw + j * 2 * C * C, aw + (j + 2) * 2 * C * C), (ab + j * 2 * C, ab + (j + 2) * 2 * C))
             if self._side is None:
-                self._exchange.layer_done(i)
+                self._exchange.layer_done(i, extra)
                 return
             # the layer's slice holds gradients from BOTH streams (weights / biases: side stream; LayerNorm gamma / beta:
             # main stream), so the collective is ordered after everything queued on either of them so far
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._exchange.layer_done(i)
+                self._exchange.layer_done(i, extra)
 
     def _all_done(self) -> None:
         self._flush_dw()
@@ -844,7 +863,20 @@ class DenoiserTrainEngine:
         hp = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         early, self._early = self._early, []
         armed, self._armed = self._armed, None
-        if early:
+        segs = self._exchange.take_segments() if self._exchange.zero1 else []
+        if segs:
+            # ZeRO-1: this rank updates its part of every reduce-scattered slice, then the ranks exchange the updated parameters
+            # and re-split them into the planes the GEMMs read (one 0.1 ms pass instead of gathering the planes too)
+            from . import planes as P
+
+            if early or sum(b - a for a, b, _ in segs) != f.params.numel():
+                raise RuntimeError("optimizer_step (ZeRO-1): the exchanged slices do not tile the parameter buffer")
+            for a, b, sharded in segs:
+                x, y = self._exchange.own_part(a, b) if sharded else (a, b)
+                self._adamw_range(x, y, step=self.step_count, g_scale=g_scale, **hp)
+            self._exchange.gather_params(f.params, segs)
+            P.split(f.params, 1.0, out=P.Planes(f.hi, f.lo))
+        elif early:
             if armed != hp:
                 raise RuntimeError("optimizer_step: hyper-parameters differ from the ones the backward was armed with")
             pos, total = 0, f.params.numel()

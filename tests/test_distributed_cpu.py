@@ -179,7 +179,8 @@ def _eight_worker(rank, world, port, out):
     idx = torch.tensor([rank, 20 + rank, 159 - rank])               # rows of a 160 x 4 table touched by this rank's batch
     rows = torch.full((1, 3, 4), float(rank + 1))
     for i in reversed(range(len(ranges))):
-        ex.layer_done(i)
+        # two pieces of the head slice (the AdaLN linears of a block) are final with their layer and travel with it
+        ex.layer_done(i, extra=((660 + 40 * i, 680 + 40 * i), (900 + 10 * i, 905 + 10 * i)))
     rows_all, idx_all = ex.gather_rows(rows, idx, dim=1)
     grads[:640].view(160, 4).index_add_(0, idx_all, rows_all[0])
     ex.all_done()
@@ -188,14 +189,16 @@ def _eight_worker(rank, world, port, out):
     spans = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(spans, torch.tensor([a, b]))
     if rank == 0:
-        out.put((grads.clone(), scale, [t.tolist() for t in spans], balanced_assignment([20, 2, 3, 19, 8, 8, 2, 5, 11, 4, 6, 2, 2, 3, 17, 9], world)))
+        counts = [20, 2, 3, 19, 8, 8, 2, 5, 11, 4, 6, 2, 2, 3, 17, 9]
+        out.put((grads.clone(), scale, [t.tolist() for t in spans], balanced_assignment(counts, world),
+                 balanced_assignment(counts, world, equal_count=True)))
     dist.destroy_process_group()
 
 
 def test_eight_rank_gradient_exchange():
     """BASELINE configs[3]'s world size on CPU (gloo): uneven layer slices, a one-element layer, sparse table rows from 8 ranks,
     contiguous puzzle shards that cover 37 puzzles exactly once, fragment-balanced assignment"""
-    grads, scale, spans, assign = _run_ranks(_eight_worker, 8, timeout=240)
+    grads, scale, spans, assign, assign_eq = _run_ranks(_eight_worker, 8, timeout=240)
     assert scale == 0.125
     want = torch.zeros(4096)
     want[640:] = (torch.arange(4096 - 640, dtype=torch.float32) % 97) * 36           # sum of (rank + 1) over 8 ranks
@@ -209,6 +212,11 @@ def test_eight_rank_gradient_exchange():
     counts = [20, 2, 3, 19, 8, 8, 2, 5, 11, 4, 6, 2, 2, 3, 17, 9]
     loads = [sum(counts[i] for i in a) for a in assign]
     assert max(loads) <= 20 and max(loads) - min(loads) <= 8        # no rank carries more than the largest puzzle's worth above the mean
+    # fixed per-rank batch size (training): two puzzles each, and still far tighter than dealing them in order (22 .. 26 vs 5 .. 23)
+    assert sorted(sum(assign_eq, [])) == list(range(16)) and all(len(a) == 2 for a in assign_eq)
+    loads_eq = [sum(counts[i] for i in a) for a in assign_eq]
+    in_order = [counts[2 * r] + counts[2 * r + 1] for r in range(8)]
+    assert max(loads_eq) - min(loads_eq) < max(in_order) - min(in_order) and max(loads_eq) <= 22
 
 
 def _accum_worker(rank, world, port, out):
