@@ -914,6 +914,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   p.g_idx = a->gather_idx; p.g_xyz = a->gather_xyz; p.g_ctr = a->gather_ctr;
   p.g_N = a->gather_N; p.g_S = a->gather_S; p.g_ns = a->gather_ns;
   p_split_ws_bytes = a->split_ws ? a->split_ws_bytes : 0;
+  p.ws_bytes = p_split_ws_bytes;
   p_split_cnt_len = a->split_cnt ? a->split_cnt_len : 0;
   p.tiles_n = 0;
   p.dbg = 0;

@@ -33,6 +33,7 @@ struct GemmP {
   float* split_ws; int* split_cnt; int split_k; int k_chunk;
   // fused grouping: row r of A is [A[f*g_N + g_idx[r]] (lda = D floats) | g_xyz[f, idx] - g_ctr[r / g_ns] | 0]
   const int* g_idx; const float* g_xyz; const float* g_ctr; int g_N, g_S, g_ns;
+  int64_t ws_bytes;   // capacity of split_ws in bytes
   int k_valid; // gemm_pl.hip: contraction rows that exist (k-major operands; K is rounded up to the K-tile, the rest reads zeros)
   int x1;     // gemm_pl.hip: single-pass fp16 (hi planes only) — PFPP_GEMM_F16
   float* csum; float* csum_ws; float csum_alpha;   // gemm_pl.hip (k-major A): csum[m] += csum_alpha * sum_k A[k][m] — the bias gradient riding in dW = dY^T . X

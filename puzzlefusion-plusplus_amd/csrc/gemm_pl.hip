@@ -575,7 +575,8 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
 #pragma unroll
   for (int s = 0; s < NS; ++s)
     if (s < nk) issue(s, s * STAGE);
-  if (NS >= 3 && nk >= 3) wait_vmcnt<(NS >= 3 ? 2 : 0) * NPW>();
+  if (nk >= NS) wait_vmcnt<(NS - 1) * NPW>();             // tile 0 has landed, NS - 1 tiles stay in flight
+  else if (NS >= 3 && nk >= 3) wait_vmcnt<(NS >= 3 ? 2 : 0) * NPW>();
   else if (nk >= 2) wait_vmcnt<NPW>();
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
@@ -858,12 +859,69 @@ int launch_f16x3_planes_af32(const GemmP& p0, int batch, hipStream_t st, int gro
   return pl::launch_pl<2, 2, 2, 2, 2, false, false, 0, true>(p, batch, st, group_m, 1);                      // 128 x 128, two per CU
 }
 
+// Tile and K split from a small cost model fitted to tools/gemm_lab measurements on 3,850-row shapes: a workgroup's main
+// loop is bound by operand delivery (~45 GB/s of L2 -> LDS DMA per CU, shared by co-resident workgroups) or by its MFMAs
+// (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
+// slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.  fix_variant / fix_splits != 0 pin a choice.
+static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool have_ws, int64_t ws_bytes, bool accumulate, bool no_v6,
+                      int* out_v, int* out_s) {
+  const int nk = K / 32;
+  const int cand_v[3] = {2, 3, 6};
+  const int cand_s[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+  double best = 1e30;
+  int best_v = 3, best_s = 1;
+  for (int vi = 0; vi < 3; ++vi) {
+    const int v = cand_v[vi];
+    if (fix_variant != 0 && v != fix_variant) continue;
+    if (no_v6 && v == 6) continue;
+    const int bm = v == 2 ? 256 : 128, bn = v == 6 ? 64 : 128;
+    const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    for (int si = 0; si < 9; ++si) {
+      const int sp = cand_s[si];
+      if (fix_splits != 0 && sp != fix_splits) continue;
+      if (sp > 1 && (sp > nk / 2 || !(have_ws || accumulate))) continue;
+      const bool slabs = sp > 1 && have_ws && (double)sp * M * (N + 1.0) * 4.0 <= (double)ws_bytes;
+      if (sp > 1 && !slabs && !accumulate) continue;
+      const double wgs = tiles * sp;
+      const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;                  // co-resident workgroups share the CU's bandwidth
+      const double kc = (double)K / sp;
+      const double t_bw = rounds * kc * (bm + bn) * 4.0 / 45e9;
+      const double t_mma = rounds * (bm / 32.0) * (bn / 32.0) * (kc / 16.0) * 3.0 * 32.0 / 4.0 / 2.1e9 / 0.75;
+      const double cbytes = (double)M * N * 4.0;
+      double t_epi;
+      if (slabs) t_epi = (2.0 * sp * cbytes + (accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 2e-6;
+      else if (accumulate) t_epi = sp * cbytes / 1.2e12;
+      else t_epi = cbytes / 3.5e12;
+      const double t = (t_bw > t_mma ? t_bw : t_mma) + t_epi + 4e-6;
+      if (t < best) { best = t; best_v = v; best_s = sp; }
+    }
+  }
+  *out_v = best_v;
+  *out_s = best_s;
+}
+
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant) {
+  pl::p_ws_bytes = p.split_ws ? p.ws_bytes : 0;
+  // few output tiles and an epilogue the slab reduction can express (bias / activation / residual, fp32 out): split the
+  // contraction over the idle CUs — the 100..500-row GEMMs of a single puzzle's DDPM step (16 tiles x 16 K-tiles otherwise)
+  if (variant == 0 && batch == 1 && p.split_ws && !p.x1 && p.pool == 0 && !p.stats && !p.scale && !p.Chi && !p.Cmin &&
+      p.act != PFPP_ACT_GEGLU && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
+      (int64_t)((p.M + 127) / 128) * ((p.N + 63) / 64) <= 96) {
+    // measured on the single-puzzle loop (bench.aggl_puzzles_per_s, one puzzle in flight): 5.28 -> 4.86 puzzles/s — the slab epilogues
+    // and the second launch cost more than the shorter K loops save; off unless asked for
+    static const bool on = getenv("PFPP_GEMM_SMALL_SPLIT") && atoi(getenv("PFPP_GEMM_SMALL_SPLIT")) == 1;
+    if (on) {
+      int v = 3, sp = 1;
+      pl_choose(p.M, p.N, p.K, 0, 0, true, pl::p_ws_bytes, false, false, &v, &sp);
+      if (sp > 1) return launch_variant<false, false>(p, batch, st, group_m, v, sp);
+    }
+  }
   if (variant == 0) {
     const int64_t t256 = ((int64_t)(p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
     const int64_t t21 = ((int64_t)(p.M + 255) / 256) * ((p.N + 127) / 128) * batch;
     const int64_t t11 = ((int64_t)(p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     variant = t256 >= 512 ? 1 : (t21 >= 160 ? 2 : (t11 >= 200 ? 3 : 6));
+    // (a six-stage ring for grids of a few workgroups was tried for the single-puzzle loop: 5.50 -> 5.55 puzzles/s, not kept)
   }
   // GEGLU gates pairs of column tiles (two per wave at least); the pool = 64 epilogue needs two row tiles per wave
   if (variant == 6 && p.act == PFPP_ACT_GEGLU) variant = 3;
@@ -901,46 +959,16 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldr = a->ldr;
   p.act = a->act; p.zdiv = 1; p.alpha = a->alpha; p.accum = a->accumulate ? 1 : 0;
   p.split_ws = a->ws;
-  pl::p_ws_bytes = a->ws ? a->ws_bytes : 0;
+  p.ws_bytes = a->ws ? a->ws_bytes : 0;
+  pl::p_ws_bytes = p.ws_bytes;
   PFPP_SUPPORTED(!a->colsum || (a->a_kmajor && a->w_kmajor && !a->single_pass), "colsum rides with the k-major pair (dW = dY^T . X) only");
   p.csum = a->colsum; p.csum_alpha = a->colsum_alpha;
   hipStream_t st = pfpp::as_stream(stream);
   int variant = a->variant, splits = a->splits;
   const int nk = p.K / 32;
   if (variant == 0 || splits == 0) {
-    // Tile and K split from a small cost model fitted to tools/gemm_lab measurements on 3,850-row shapes: a workgroup's main
-    // loop is bound by operand delivery (~45 GB/s of L2 -> LDS DMA per CU, shared by co-resident workgroups) or by its MFMAs
-    // (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
-    // slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.
-    const int cand_v[3] = {2, 3, 6};
-    const int cand_s[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
-    double best = 1e30;
     int best_v = 3, best_s = 1;
-    for (int vi = 0; vi < 3; ++vi) {
-      const int v = cand_v[vi];
-      if (a->variant != 0 && v != a->variant) continue;
-      const int bm = v == 2 ? 256 : 128, bn = v == 6 ? 64 : 128;
-      const double tiles = (double)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-      for (int si = 0; si < 9; ++si) {
-        const int sp = cand_s[si];
-        if (a->splits != 0 && sp != a->splits) continue;
-        if (sp > 1 && (sp > nk / 2 || !(a->ws || a->accumulate))) continue;
-        const bool slabs = sp > 1 && a->ws && (double)sp * p.M * (p.N + 1.0) * 4.0 <= (double)a->ws_bytes;
-        if (sp > 1 && !slabs && !a->accumulate) continue;
-        const double wgs = tiles * sp;
-        const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;                  // co-resident workgroups share the CU's bandwidth
-        const double kc = (double)p.K / sp;
-        const double t_bw = rounds * kc * (bm + bn) * 4.0 / 45e9;
-        const double t_mma = rounds * (bm / 32.0) * (bn / 32.0) * (kc / 16.0) * 3.0 * 32.0 / 4.0 / 2.1e9 / 0.75;
-        const double cbytes = (double)p.M * p.N * 4.0;
-        double t_epi;
-        if (slabs) t_epi = (2.0 * sp * cbytes + (a->accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 2e-6;
-        else if (a->accumulate) t_epi = sp * cbytes / 1.2e12;
-        else t_epi = cbytes / 3.5e12;
-        const double t = (t_bw > t_mma ? t_bw : t_mma) + t_epi + 4e-6;
-        if (t < best) { best = t; best_v = v; best_s = sp; }
-      }
-    }
+    pl_choose(p.M, p.N, p.K, a->variant, a->splits, a->ws != nullptr, a->ws ? a->ws_bytes : 0, a->accumulate != 0, false, &best_v, &best_s);
     if (variant == 0) variant = best_v;
     if (splits == 0) splits = best_s;
   }
