@@ -88,6 +88,21 @@ int pfpp_ball_query(const float* xyz, const float* new_xyz, int32_t* idx,
                     int64_t F, int64_t N, int64_t S, int64_t nsample,
                     float r2, pfpp_stream_t stream);
 
+/* ---- a2 + a3 for the three set-abstraction levels at once ------------------
+ * PN2.encode (vqvae/model/modules/pn2.py:57-68) runs sample_and_group (utils/pn2_utils.py:127-151) three times; the
+ * sampling part (farthest_point_sample :131-134 + query_ball_point :92-111) depends on the coordinates only.  One
+ * launch, one workgroup per fragment: level l samples S_l points out of the S_(l-1) centroids of the level above (level 0: the
+ * N input points) and ball-queries them with radius^2 r2_l.  Outputs exactly what pfpp_fps / pfpp_ball_query return for
+ * each level (bit-identical).  N <= 2048, levels[0].S <= 256, levels[1].S <= 128, nsample <= 64.                        */
+typedef struct pfpp_sample_level {
+  int64_t S, nsample;
+  float r2;
+  int32_t* fps_idx;    /* [F, S] or NULL */
+  float* new_xyz;      /* [F, S, 3] */
+  int32_t* ball_idx;   /* [F, S, nsample] */
+} pfpp_sample_level;
+int pfpp_sample_levels(const float* xyz, int64_t F, int64_t N, const pfpp_sample_level* levels /* [3] */, pfpp_stream_t stream);
+
 /* ---- a4: grouping --------------------------------------------------------
  * index_points x3 + concat, utils/pn2_utils.py:139-146, written channels-last
  * as the A operand of the first set-abstraction GEMM:

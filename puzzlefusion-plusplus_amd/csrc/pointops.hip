@@ -275,6 +275,171 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// a2 + a3 for all three set-abstraction levels of one fragment in ONE kernel (PN2.encode's sampling chain, pn2.py:57-68:
+// sample_and_group of sa1, sa2, sa3 depends on coordinates only, never on the features).  One 16-wave workgroup per
+// fragment, the fragment's points as SoA (+ |p|^2) in LDS:
+//   phase A  FPS of level 1 on four waves (the same blocked-ownership argmax chain as fps_kernel);
+//   phase B  wave 0 runs the FPS chains of levels 2 and 3 on the level-1 / level-2 centroids (they fit one wave: no barrier),
+//            while the other 15 waves scan the ball queries of level 1;
+//   phase C  all waves: ball queries of levels 2 and 3.
+// Same arithmetic, in the same order, as fps_kernel / ball_query_kernel: indices are bit-identical (tested).  Six launches
+// and their gaps become one, and the ball queries of level 1 run in the shadow of the later FPS chains.
+// ---------------------------------------------------------------------------
+struct SampleLevelP {
+  int S, ns;
+  float r2;
+  int32_t* fps_idx;   // [F, S] or null
+  float* new_xyz;     // [F, S, 3]
+  int32_t* ball;      // [F, S, ns]
+};
+struct SampleP {
+  const float* xyz;
+  int N;
+  SampleLevelP lv[3];
+};
+
+// FPS over N points held as SoA in LDS by G * 64 threads (thread t of the group owns [t * PPT, (t + 1) * PPT)); writes the S
+// selected indices / coordinates to global memory and the coordinates (+ |c|^2) to the LDS arrays of the next level.
+// G > 1: every thread of the workgroup must call it (one __syncthreads per selected point).
+template <int G, int PPT>
+__device__ __forceinline__ void fps_chain(const float* xs, const float* ys, const float* zs, int N, int S, int t, int32_t* o_idx,
+                                          float* o_xyz, float* nx, float* ny, float* nz, float* npp, float* slot_d, int* slot_i) {
+  const int lane = t & 63, wave = t >> 6;
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = t * PPT + k;
+    const bool ok = i < N;
+    px[k] = ok ? xs[i] : 0.0f;
+    py[k] = ok ? ys[i] : 0.0f;
+    pz[k] = ok ? zs[i] : 0.0f;
+    dist[k] = ok ? __builtin_huge_valf() : -1.0f;
+  }
+  int sel = 0;
+  float cx = xs[0], cy = ys[0], cz = zs[0];
+  for (int s = 0;;) {
+    if (t == 0) {
+      if (o_idx) o_idx[s] = sel;
+      o_xyz[3 * s + 0] = cx; o_xyz[3 * s + 1] = cy; o_xyz[3 * s + 2] = cz;
+      nx[s] = cx; ny[s] = cy; nz[s] = cz;
+      npp[s] = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
+    }
+    if (++s >= S) break;
+    float best = -2.0f;
+    int bi = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = __fsub_rn(px[k], cx);
+      const float dy = __fsub_rn(py[k], cy);
+      const float dz = __fsub_rn(pz[k], cz);
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const float nd = fminf(dist[k], d);
+      dist[k] = nd;
+      if (nd > best) { best = nd; bi = t * PPT + k; }
+    }
+    const float wmax = wave_max_f32(best);
+    const unsigned long long m = __ballot(best == wmax);
+    const int widx = __builtin_amdgcn_readlane(bi, __builtin_ctzll(m));
+    if (G > 1) {
+      const int par = (s & 1) * G;
+      if (lane == 0) { slot_d[par + wave] = wmax; slot_i[par + wave] = widx; }
+      __syncthreads();
+      float bm = slot_d[par];
+      int bidx = slot_i[par];
+#pragma unroll
+      for (int w = 1; w < G; ++w) {
+        const float d2 = slot_d[par + w];
+        const int i2 = slot_i[par + w];
+        if (d2 > bm) { bm = d2; bidx = i2; }
+      }
+      sel = bidx;
+    } else {
+      sel = widx;
+    }
+    cx = xs[sel]; cy = ys[sel]; cz = zs[sel];
+  }
+}
+
+// one wave: ball query of centroid (cx, cy, cz) over N points (SoA + |p|^2 in LDS) -> out[ns]
+__device__ __forceinline__ void ball_scan(const float* xs, const float* ys, const float* zs, const float* pp, int N, float cx, float cy,
+                                          float cz, int ns, float r2, int32_t* out, int lane) {
+  const float nn = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
+  int cnt = 0;
+  int first = N;
+  for (int base = 0; base < N && cnt < ns; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < N;
+    const float x = ok ? xs[i] : 0.0f;
+    const float y = ok ? ys[i] : 0.0f;
+    const float z = ok ? zs[i] : 0.0f;
+    const float q = ok ? pp[i] : 0.0f;
+    const float dot = __fmaf_rn(cz, z, __fmaf_rn(cy, y, __fmul_rn(cx, x)));
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), nn), q);
+    const bool keep = ok && !(d > r2);
+    const unsigned long long m = __ballot(keep);
+    if (m != 0ull) {
+      if (cnt == 0) first = base + __builtin_ctzll(m);
+      const int prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+      const int pos = cnt + prefix;
+      if (keep && pos < ns) out[pos] = i;
+      cnt += __builtin_popcountll(m);
+    }
+  }
+  const int total = cnt < ns ? cnt : ns;
+  if (lane >= total && lane < ns) out[lane] = first;
+}
+
+constexpr int SL_WAVES = 16;      // waves per fragment: 4 run the level-1 FPS chain, all of them share the ball queries
+template <int PPT>
+__global__ __launch_bounds__(SL_WAVES * 64) void sample_levels_kernel(const SampleP p) {
+  extern __shared__ __align__(16) float sl_smem[];
+  const int N = p.N, S1 = p.lv[0].S, S2 = p.lv[1].S, S3 = p.lv[2].S;
+  float* xs = sl_smem;          float* ys = xs + N;  float* zs = ys + N;  float* pp = zs + N;
+  float* c1x = pp + N;          float* c1y = c1x + S1; float* c1z = c1y + S1; float* c1p = c1z + S1;
+  float* c2x = c1p + S1;        float* c2y = c2x + S2; float* c2z = c2y + S2; float* c2p = c2z + S2;
+  float* c3x = c2p + S2;        float* c3y = c3x + S3; float* c3z = c3y + S3; float* c3p = c3z + S3;
+  float* slot_d = c3p + S3;     int* slot_i = reinterpret_cast<int*>(slot_d + 8);
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = p.xyz + (size_t)f * N * 3;
+  for (int i = tid; i < N; i += SL_WAVES * 64) {
+    const float x = src[3 * i + 0], y = src[3 * i + 1], z = src[3 * i + 2];
+    xs[i] = x; ys[i] = y; zs[i] = z;
+    pp[i] = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  }
+  __syncthreads();
+  // phase A: level-1 FPS on waves 0-3; the others only keep the barrier count (one per selected point)
+  if (wave < 4) {
+    fps_chain<4, PPT>(xs, ys, zs, N, S1, tid, p.lv[0].fps_idx ? p.lv[0].fps_idx + (size_t)f * S1 : nullptr,
+                      p.lv[0].new_xyz + (size_t)f * S1 * 3, c1x, c1y, c1z, c1p, slot_d, slot_i);
+  } else {
+    for (int s = 1; s < S1; ++s) __syncthreads();
+  }
+  __syncthreads();
+  // phase B: wave 0 -> FPS of levels 2 and 3; waves 1-3 -> ball queries of level 1
+  if (wave == 0) {
+    fps_chain<1, 4>(c1x, c1y, c1z, S1, S2, lane, p.lv[1].fps_idx ? p.lv[1].fps_idx + (size_t)f * S2 : nullptr,
+                    p.lv[1].new_xyz + (size_t)f * S2 * 3, c2x, c2y, c2z, c2p, nullptr, nullptr);
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): lane 0's LDS writes of c2 before the wave reads them back
+    fps_chain<1, 2>(c2x, c2y, c2z, S2, S3, lane, p.lv[2].fps_idx ? p.lv[2].fps_idx + (size_t)f * S3 : nullptr,
+                    p.lv[2].new_xyz + (size_t)f * S3 * 3, c3x, c3y, c3z, c3p, nullptr, nullptr);
+  } else {
+    int32_t* out = p.lv[0].ball + (size_t)f * S1 * p.lv[0].ns;
+    for (int c = wave - 1; c < S1; c += SL_WAVES - 1)
+      ball_scan(xs, ys, zs, pp, N, c1x[c], c1y[c], c1z[c], p.lv[0].ns, p.lv[0].r2, out + (size_t)c * p.lv[0].ns, lane);
+  }
+  __syncthreads();
+  // phase C: ball queries of levels 2 and 3, all waves
+  {
+    int32_t* out = p.lv[1].ball + (size_t)f * S2 * p.lv[1].ns;
+    for (int c = wave; c < S2; c += SL_WAVES)
+      ball_scan(c1x, c1y, c1z, c1p, S1, c2x[c], c2y[c], c2z[c], p.lv[1].ns, p.lv[1].r2, out + (size_t)c * p.lv[1].ns, lane);
+    out = p.lv[2].ball + (size_t)f * S3 * p.lv[2].ns;
+    for (int c = wave; c < S3; c += SL_WAVES)
+      ball_scan(c2x, c2y, c2z, c2p, S2, c3x[c], c3y[c], c3z[c], p.lv[2].ns, p.lv[2].r2, out + (size_t)c * p.lv[2].ns, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // a4: grouping.  One thread per float4 of the output row
 //   [ feats[f, id, 0:D] | xyz[f,id] - new_xyz[f,s] | 0 ]
 // ---------------------------------------------------------------------------
@@ -479,6 +644,32 @@ extern "C" int pfpp_ball_query(const float* xyz, const float* new_xyz, int32_t* 
   const size_t smem = (size_t)N * 4 * sizeof(float);
   hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), smem, pfpp::as_stream(stream), xyz,
                      new_xyz, idx, (int)N, (int)S, (int)nsample, r2, cpb);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_sample_levels(const float* xyz, int64_t F, int64_t N, const pfpp_sample_level* levels, pfpp_stream_t stream) {
+  PFPP_REQUIRE(xyz && levels, "null pointer");
+  PFPP_REQUIRE(F >= 0 && N >= 1, "bad sizes");
+  SampleP p;
+  p.xyz = xyz; p.N = (int)N;
+  int64_t prev = N;
+  for (int l = 0; l < 3; ++l) {
+    const pfpp_sample_level& v = levels[l];
+    PFPP_REQUIRE(v.new_xyz && v.ball_idx, "level outputs: new_xyz and ball_idx are required");
+    PFPP_REQUIRE(v.S >= 1 && v.S <= prev && v.nsample >= 1, "need 1 <= S <= points of the level above, nsample >= 1");
+    PFPP_SUPPORTED(v.nsample <= 64, "nsample > 64");
+    p.lv[l].S = (int)v.S; p.lv[l].ns = (int)v.nsample; p.lv[l].r2 = v.r2;
+    p.lv[l].fps_idx = v.fps_idx; p.lv[l].new_xyz = v.new_xyz; p.lv[l].ball = v.ball_idx;
+    prev = v.S;
+  }
+  PFPP_SUPPORTED(N <= 2048 && levels[0].S <= 256 && levels[1].S <= 128, "fused sampling: N <= 2048, S1 <= 256, S2 <= 128 (levels 2 and 3 run on one wave)");
+  if (F == 0) return PFPP_OK;
+  const size_t smem = ((size_t)4 * (N + levels[0].S + levels[1].S + levels[2].S) + 16) * sizeof(float);
+  hipStream_t st = pfpp::as_stream(stream);
+  const dim3 grid((unsigned)F), block(SL_WAVES * 64);
+  if (N <= 512) hipLaunchKernelGGL(sample_levels_kernel<2>, grid, block, smem, st, p);
+  else if (N <= 1024) hipLaunchKernelGGL(sample_levels_kernel<4>, grid, block, smem, st, p);
+  else hipLaunchKernelGGL(sample_levels_kernel<8>, grid, block, smem, st, p);
   return pfpp::check_launch(__func__);
 }
 

@@ -62,6 +62,12 @@ class PlanesC(C.Structure):
     _fields_ = [("hi", _p), ("lo", _p), ("scale", _f32)]
 
 
+class SampleLevel(C.Structure):
+    """mirror of struct pfpp_sample_level (include/pfpp.h)"""
+
+    _fields_ = [("S", _i64), ("nsample", _i64), ("r2", _f32), ("fps_idx", _p), ("new_xyz", _p), ("ball_idx", _p)]
+
+
 class GemmPlanesArgs(C.Structure):
     """mirror of struct pfpp_gemm_planes_args (include/pfpp.h)"""
 
@@ -84,6 +90,7 @@ SIGNATURES = {
     "pfpp_pose_apply": [_p, _p, _p, _p, _i64, _i64, C.c_int, _p],
     "pfpp_fps": [_p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_ball_query": [_p, _p, _p, _i64, _i64, _i64, _i64, _f32, _p],
+    "pfpp_sample_levels": [_p, _i64, _i64, C.POINTER(SampleLevel), _p],
     "pfpp_group_gather": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "pfpp_gemm": [C.POINTER(GemmArgs), _p],
     "pfpp_sa_mlp3_fused": [_p] * 16 + [_i64] * 7 + [_p],

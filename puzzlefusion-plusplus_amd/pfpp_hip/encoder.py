@@ -23,6 +23,8 @@ GATHER_FUSED = _os.environ.get("PFPP_GATHER_FUSED", "1") == "1"
 # eval mode, first level (no input features): grouping + the three folded conv/BN/ReLU + the max in one kernel
 SA_FUSED = _os.environ.get("PFPP_SA_FUSED", "1") == "1"
 
+SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
+
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
 
@@ -115,12 +117,16 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
 
 
 def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz: torch.Tensor,
-                    feats: Optional[torch.Tensor], capture: Optional[dict] = None):
-    """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3]"""
+                    feats: Optional[torch.Tensor], capture: Optional[dict] = None, sampled=None):
+    """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3].  sampled = (fps_idx, new_xyz, ball_idx) when the
+    sampling of all levels was done up front (ops.sample_levels)"""
     F = xyz.shape[0]
-    ops.check_fps_ratio(npoint, xyz.shape[1])
-    fps_idx, new_xyz = ops.fps(xyz, npoint)
-    ball = ops.ball_query(xyz, new_xyz, radius, nsample)
+    if sampled is not None:
+        fps_idx, new_xyz, ball = sampled
+    else:
+        ops.check_fps_ratio(npoint, xyz.shape[1])
+        fps_idx, new_xyz = ops.fps(xyz, npoint)
+        ball = ops.ball_query(xyz, new_xyz, radius, nsample)
     fused = GATHER_FUSED and ops.GEMM_MODE == "f16x3" and (feats is None or feats.shape[2] % 32 == 0)
     A = None if fused else ops.group_gather(xyz, new_xyz, feats, ball)
     grp = (xyz, new_xyz, None if feats is None else feats.contiguous(), ball)
@@ -180,8 +186,11 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
 def pn2_encode(pk, pts: torch.Tensor, num_point: int = 25, capture: Optional[dict] = None):
     """pts [F,N,3] (already rotated) -> z_e [F,L,64], xyz [F,L,3]   (pn2.py:57-68)"""
     xyz, feats = pts, None
-    for name, npoint, radius, nsample in SA_LEVELS:
-        xyz, feats = set_abstraction(pk, name, npoint or num_point, radius, nsample, xyz, feats, capture)
+    # the sampling chain of all three levels depends on coordinates only: one launch (FPS x 3 + ball query x 3 per fragment)
+    lv = tuple((npoint or num_point, radius, nsample) for _, npoint, radius, nsample in SA_LEVELS)
+    sampled = ops.sample_levels(pts, lv) if (SAMPLE_FUSED and ops.sample_levels_supported(pts.shape[1], lv)) else (None,) * 3
+    for (name, npoint, radius, nsample), smp in zip(SA_LEVELS, sampled):
+        xyz, feats = set_abstraction(pk, name, npoint or num_point, radius, nsample, xyz, feats, capture, sampled=smp)
     F, L, C3 = feats.shape
     z_e = ops.linear(feats.view(F * L, C3), pk["conv6.w"], pk["conv6.b"]).view(F, L, -1)
     return z_e, xyz

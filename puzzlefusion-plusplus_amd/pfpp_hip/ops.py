@@ -128,6 +128,34 @@ def ball_query(xyz: torch.Tensor, new_xyz: torch.Tensor, radius: float, nsample:
     return idx
 
 
+def sample_levels(xyz: torch.Tensor, levels):
+    """FPS + ball query of the three set-abstraction levels in one launch (pfpp_sample_levels).  levels = ((S, radius, nsample),) * 3
+    -> [(fps_idx int32 [F,S], new_xyz [F,S,3], ball_idx int32 [F,S,nsample])] * 3, bit-identical to fps() + ball_query() per level"""
+    _chk(xyz, torch.float32, "xyz")
+    F, N, three = xyz.shape
+    if three != 3 or len(levels) != 3:
+        raise ValueError("sample_levels: xyz [F,N,3] and exactly three levels expected")
+    arr = (_lib.SampleLevel * 3)()
+    out = []
+    prev = N
+    for l, (S, radius, ns) in enumerate(levels):
+        check_fps_ratio(S, prev)
+        fi = torch.empty((F, S), dtype=torch.int32, device=xyz.device)
+        nx = torch.empty((F, S, 3), dtype=torch.float32, device=xyz.device)
+        bi = torch.empty((F, S, ns), dtype=torch.int32, device=xyz.device)
+        arr[l].S, arr[l].nsample = S, ns
+        arr[l].r2 = torch.tensor(radius ** 2, dtype=torch.float64).to(torch.float32).item()
+        arr[l].fps_idx, arr[l].new_xyz, arr[l].ball_idx = fi.data_ptr(), nx.data_ptr(), bi.data_ptr()
+        out.append((fi, nx, bi))
+        prev = S
+    check(_lib.load().pfpp_sample_levels(_ptr(xyz), F, N, arr, _stream()), "pfpp_sample_levels")
+    return out
+
+
+def sample_levels_supported(N: int, levels) -> bool:
+    return len(levels) == 3 and N <= 2048 and levels[0][0] <= 256 and levels[1][0] <= 128 and all(ns <= 64 for _, _, ns in levels)
+
+
 def group_gather(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor],
                  idx: torch.Tensor) -> torch.Tensor:
     """-> A operand [F*S*ns, D+4] = [feats | rel_xyz | 0]  (include/pfpp.h a4)"""

@@ -397,6 +397,31 @@ def test_verifier_vs_golden(golden, weights_sd, dev):
     assert np.abs(lo.cpu().numpy() - g["logits"])[m].max() < TOL
 
 
+@pytest.mark.parametrize("F,N", [(5, 1000), (3, 512), (2, 1024), (2, 2048), (1, 777)])
+def test_fused_sampling_equals_per_level_kernels(dev, F, N):
+    """pfpp_sample_levels (FPS x 3 + ball query x 3 of a fragment in one workgroup) == pfpp_fps / pfpp_ball_query level by level,
+    bit for bit: indices, centroids, neighbour lists (including the pad-with-first rule and empty balls)"""
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(N + F)
+    pts = (torch.rand(F, N, 3, generator=g) * 2 - 1)
+    pts[0, : N // 2] *= 0.05                               # a dense clump: balls that fill up early and ties in the distance
+    pts = pts.to(dev)
+    S1 = 256 if N != 777 else 111
+    levels = ((S1, 0.2, 32), (128 if S1 == 256 else 37, 0.4, 64), (25, 0.8, 64))
+    try:
+        got = ops.sample_levels(pts, levels)
+    except ValueError:
+        assert N == 777                                    # ceil(float64(S/N) * N) != S: the reference would sample another count
+        return
+    xyz = pts
+    for (S, r, ns), (fi, nx, bi) in zip(levels, got):
+        fi0, nx0 = ops.fps(xyz, S)
+        bi0 = ops.ball_query(xyz, nx0, r, ns)
+        assert torch.equal(fi, fi0) and torch.equal(nx, nx0) and torch.equal(bi, bi0)
+        xyz = nx0
+
+
 # ----------------------------------------------------------------------------- range of the split-f16 arithmetic
 @pytest.mark.parametrize("wscale", [1e-6, 1e-3, 1.0, 1e2, 1e4])
 @pytest.mark.parametrize("fill", ["normal", "heavy"])
