@@ -211,7 +211,8 @@ class TrainWorkload:
             self.engine.arm_optimizer(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
         self.last_loss = self.engine.loss_and_grads(noisy, t, latent, xyz, d["part_valids"], d["part_scale"], self.ref, noise,
                                                     seed=1000 + self.i, train=True)
-        self.engine.optimizer_step(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
+        self.engine.optimizer_step(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,
+                                   zero_grad=True)      # optimizer.step() + optimizer.zero_grad() in one pass over the buffers
         self.i += 1
 
 

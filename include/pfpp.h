@@ -659,6 +659,11 @@ int pfpp_mse_loss(const float* pred, const float* target, const uint8_t* sel, fl
 int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo, int64_t n,
                float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
                float bc2, float g_scale, pfpp_stream_t stream);
+/* the same, and with zero_grad != 0 the gradient buffer is cleared in the same pass (optimizer.step() + optimizer.zero_grad(),
+ * the pair a training loop issues back to back) */
+int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                    float bc2, float g_scale, int zero_grad, pfpp_stream_t stream);
 
 /* ---- train-mode BatchNorm of the (frozen, but .train()) encoder (utils/pn2_utils.py:211-214) -------------
  * The reference freezes the encoder's parameters only (train_denoiser.py:33-35); under Lightning's

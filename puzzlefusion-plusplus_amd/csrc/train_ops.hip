@@ -493,14 +493,15 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // AdamW
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n,
                                                     float decay, float w1, float beta2, float w2, float eps,
-                                                    float step_size, float inv_sqrt_bc2, float g_scale) {
+                                                    float step_size, float inv_sqrt_bc2, float g_scale, int zero_g) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float gr = g[i] * g_scale;
+  if (zero_g) g[i] = 0.0f;                            // optimizer.zero_grad() in the same pass (no separate 230 MB memset)
   float pp = p[i] * decay;
   float mm = m[i];
   mm = mm + w1 * (gr - mm);                         // exp_avg.lerp_(grad, 1 - beta1)
@@ -794,12 +795,18 @@ extern "C" int pfpp_mse_loss(const float* pred, const float* target, const uint8
 extern "C" int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,
                           float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
                           float g_scale, pfpp_stream_t stream) {
+  return pfpp_adamw_zero(p, const_cast<float*>(g), m, v, hi, lo, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, 0, stream);
+}
+
+extern "C" int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                               float g_scale, int zero_grad, pfpp_stream_t stream) {
   PFPP_REQUIRE(p && g && m && v, "null pointer");
   PFPP_REQUIRE(!hi == !lo, "hi and lo go together");
   PFPP_REQUIRE(bc1 > 0.0f && bc2 > 0.0f, "bias corrections must be positive");
   if (n == 0) return PFPP_OK;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), p, g, m, v,
                      (_Float16*)hi, (_Float16*)lo, n, 1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, eps,
-                     lr / bc1, 1.0f / sqrtf(bc2), g_scale);
+                     lr / bc1, 1.0f / sqrtf(bc2), g_scale, zero_grad ? 1 : 0);
   return pfpp::check_launch(__func__);
 }

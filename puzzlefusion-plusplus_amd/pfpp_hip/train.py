@@ -91,6 +91,7 @@ class FlatParams:
         self.hi = torch.zeros(total, dtype=torch.float16, device=dev)
         self.lo = torch.zeros(total, dtype=torch.float16, device=dev)
         self.named = named
+        self._clean = False
         with torch.no_grad():
             for n in self.order:
                 p = named[n]
@@ -148,7 +149,9 @@ class FlatParams:
         return tuple(self.named[n]._version for n in self.order)
 
     def zero_grad(self) -> None:
-        self.grads.zero_()
+        if not self._clean:                # optimizer_step(zero_grad=True) already cleared the buffer in its own pass
+            self.grads.zero_()
+        self._clean = False                # whoever asks for zeros is about to accumulate into them
 
     # -- kernel-side operands ------------------------------------------------------------------------
     def operands(self) -> Dict[str, object]:
@@ -513,6 +516,7 @@ class DenoiserTrainEngine:
         if self._exchange.active() and not self._sync:
             self._accumulated = True             # this step's table gradients are no longer "the rows of one batch": exchange them densely
         self.flat.attach_grads()
+        self.flat._clean = False                 # gradients are about to be accumulated
         ops_ = self.flat.operands()
         w, g = ops_["w"], ops_["g"]
         s = ctx.t
@@ -847,14 +851,16 @@ class DenoiserTrainEngine:
         self._armed = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         self._early = []
 
-    def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay) -> None:
+    def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay, zero_grad: bool = False) -> None:
         f = self.flat
         T.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
-                weight_decay=weight_decay, step=step, hi=f.hi[a:b], lo=f.lo[a:b], g_scale=g_scale)
+                weight_decay=weight_decay, step=step, hi=f.hi[a:b], lo=f.lo[a:b], g_scale=g_scale, zero_grad=zero_grad)
 
-    def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:
+    def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6,
+                       zero_grad: bool = False) -> None:
         """AdamW over the flat buffer (configure_optimizers, denoiser.py:230-237) — one launch, or the ranges that an armed
-        backward (arm_optimizer) has not updated yet"""
+        backward (arm_optimizer) has not updated yet.  zero_grad: also clear the gradients in that launch (the
+        optimizer.step(); optimizer.zero_grad() pair of a training loop as one pass; the next flat.zero_grad() is then free)"""
         g_scale = self.finish_grad_exchange()
         self._exchanged = False
         self._accumulated = False
@@ -885,7 +891,8 @@ class DenoiserTrainEngine:
                     self._adamw_range(pos, a, step=self.step_count, g_scale=g_scale, **hp)
                 pos = max(pos, b)
         else:
-            self._adamw_range(0, f.params.numel(), step=self.step_count, g_scale=g_scale, **hp)
+            self._adamw_range(0, f.params.numel(), step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
+            f._clean = bool(zero_grad)
         f.after_optimizer_step()
         cache = getattr(self.module, "_cache", None)
         if cache is not None:

@@ -289,6 +289,30 @@ def test_foreign_zero_grad_does_not_leave_stale_gradients(golden, weights_sd, de
     assert rel(eng.flat.view(eng.flat.grads, "shape_embedding.bias").cpu(), 2 * eng.flat.view(g1, "shape_embedding.bias").cpu()) < 1e-5
 
 
+def test_optimizer_step_with_fused_zero_grad(golden, weights_sd, dev):
+    """optimizer_step(zero_grad=True) == optimizer_step() followed by zero_grad(): same parameters, cleared gradients, and a
+    backward that follows without any zero_grad() accumulates onto zeros (the buffer is marked dirty again)"""
+    inp, noise, _ = golden_inputs(golden, dev)
+    res = []
+    for fused in (False, True):
+        m = make_module(weights_sd, dev)
+        eng = m.train_engine()
+        eng.loss_and_grads(*inp, noise, seed=3, train=False)
+        eng.optimizer_step(lr=1e-3, weight_decay=1e-2, zero_grad=fused)
+        if fused:
+            assert float(eng.flat.grads.abs().max()) == 0.0
+        eng.flat.zero_grad()
+        eng.loss_and_grads(*inp, noise, seed=3, train=False)      # step 2
+        g2 = eng.flat.grads.clone()
+        eng.optimizer_step(lr=1e-3, weight_decay=1e-2, zero_grad=fused)
+        eng.loss_and_grads(*inp, noise, seed=3, train=False)      # no zero_grad() in between: accumulates onto whatever is there
+        torch.cuda.synchronize()
+        res.append((eng.flat.params.clone(), g2, eng.flat.grads.clone()))
+    (p0, g0, a0), (p1, g1, a1) = res
+    assert rel(p0.cpu(), p1.cpu()) < 2e-4 and rel(g0.cpu(), g1.cpu()) < 1e-4      # two runs differ by atomics-order noise only
+    assert rel(a0.cpu(), (g0 + a1).cpu()) < 1e-5          # unfused: old gradient still there; fused: started from zero
+
+
 def test_dynamic_gradient_scale_follows_the_loss_gradient(golden, weights_sd, dev):
     """grad_scale (the power of two that lifts the backward operands into the fp16 range before their split) tracks max |dLoss/dpred|
     with two backward passes of delay, and a 1e-4 x smaller loss gradient gives gradients as accurate as the full-size one"""
