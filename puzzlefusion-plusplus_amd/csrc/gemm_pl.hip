@@ -864,17 +864,18 @@ int launch_f16x3_planes_af32(const GemmP& p0, int batch, hipStream_t st, int gro
 // (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
 // slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.  fix_variant / fix_splits != 0 pin a choice.
 static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool have_ws, int64_t ws_bytes, bool accumulate, bool no_v6,
-                      int* out_v, int* out_s) {
+                      int* out_v, int* out_s, bool allow_v1 = false) {
   const int nk = K / 32;
-  const int cand_v[3] = {2, 3, 6};
+  const int cand_v[4] = {2, 3, 6, 1};
   const int cand_s[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
   double best = 1e30;
   int best_v = 3, best_s = 1;
-  for (int vi = 0; vi < 3; ++vi) {
+  for (int vi = 0; vi < 4; ++vi) {
     const int v = cand_v[vi];
     if (fix_variant != 0 && v != fix_variant) continue;
     if (no_v6 && v == 6) continue;
-    const int bm = v == 2 ? 256 : 128, bn = v == 6 ? 64 : 128;
+    if (v == 1 && !allow_v1 && fix_variant != 1) continue;          // 256 x 256: row-major operands only
+    const int bm = (v == 2 || v == 1) ? 256 : 128, bn = v == 6 ? 64 : (v == 1 ? 256 : 128);
     const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     for (int si = 0; si < 9; ++si) {
       const int sp = cand_s[si];
@@ -968,7 +969,8 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   const int nk = p.K / 32;
   if (variant == 0 || splits == 0) {
     int best_v = 3, best_s = 1;
-    pl_choose(p.M, p.N, p.K, a->variant, a->splits, a->ws != nullptr, a->ws ? a->ws_bytes : 0, a->accumulate != 0, false, &best_v, &best_s);
+    pl_choose(p.M, p.N, p.K, a->variant, a->splits, a->ws != nullptr, a->ws ? a->ws_bytes : 0, a->accumulate != 0, false, &best_v, &best_s,
+              !a->a_kmajor && !a->w_kmajor && !a->single_pass);
     if (variant == 0) variant = best_v;
     if (splits == 0) splits = best_s;
   }
