@@ -171,7 +171,10 @@ class TrainWorkload:
                 self.fixed = self.model._extract_features(self.data["part_pcs"], self.data["part_valids"], self.gt)
         self.i = 0
         self.last_loss = None
-        self._opt_in_bwd = os.environ.get("PFPP_BENCH_OPT_IN_BWD", "0") == "1"   # AdamW per layer under the backward (engine.arm_optimizer): measured slower, 8.14 -> 8.24 ms
+        # AdamW per layer under the backward (engine.arm_optimizer): each layer's slice is updated on the weight-gradient stream as soon as
+        # its gradients are final, only embeddings / AdaLN / heads are left for the end.  Round 1 measured it slower (8.14 -> 8.24 ms);
+        # with the faster weight-gradient kernels of round 2 the side stream has room: 8.28-8.39 -> 8.08 ms on the same box
+        self._opt_in_bwd = os.environ.get("PFPP_BENCH_OPT_IN_BWD", "1") == "1"
         from pfpp_hip.train import FeaturePipeline
 
         self.pipeline = FeaturePipeline(self.model, dev) if (pipeline and not latents_given) else None
@@ -208,7 +211,7 @@ class TrainWorkload:
                 latent, xyz = self.fixed if self.latents_given else m._extract_features(d["part_pcs"], d["part_valids"], noisy)
         self.engine.flat.zero_grad()
         if self._opt_in_bwd:
-            self.engine.arm_optimizer(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
+            self.engine.arm_optimizer(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6, zero_grad=True)
         self.last_loss = self.engine.loss_and_grads(noisy, t, latent, xyz, d["part_valids"], d["part_scale"], self.ref, noise,
                                                     seed=1000 + self.i, train=True)
         self.engine.optimizer_step(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,

@@ -275,6 +275,7 @@ class DenoiserTrainEngine:
         # as split-f16 planes, gradients lifted by grad_scale.  PFPP_TRAIN_PLANES=0 restores the register-staged kernels.
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
+        self._armed_zero = False
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
         self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
         self._sync = True                            # False inside no_sync(): this backward does not start the gradient exchange
@@ -808,7 +809,8 @@ class DenoiserTrainEngine:
             # stream under the remaining backward instead of in the 0.3 ms AdamW launch that runs alone at the iteration's end
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, **self._armed)
+                self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, zero_grad=self._armed_zero,
+                                  **self._armed)
             self._early.append(i)
         if self._exchange.reducing():
             extra = ()
@@ -842,13 +844,15 @@ class DenoiserTrainEngine:
         return self._exchange.finish()
 
     # ------------------------------------------------------------------------------------------ optimizer
-    def arm_optimizer(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6) -> None:
+    def arm_optimizer(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6,
+                      zero_grad: bool = False) -> None:
         """optimizer-in-backward for the NEXT backward: every transformer layer's parameters take their AdamW update as soon as
         the layer's gradients are final (on the weight-gradient stream, under the rest of the backward); optimizer_step() with
         the same hyper-parameters then updates only what is left (embeddings, AdaLN tables and linears, output heads) and
         closes the step.  Same arithmetic per element as one launch over the flat buffer.  One-shot; ignored (everything
         happens in optimizer_step) without a second stream or when gradients are exchanged between ranks first."""
         self._armed = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
+        self._armed_zero = bool(zero_grad)          # the per-layer updates also clear their gradients (optimizer_step(zero_grad=True))
         self._early = []
 
     def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay, zero_grad: bool = False) -> None:
@@ -885,11 +889,14 @@ class DenoiserTrainEngine:
         elif early:
             if armed != hp:
                 raise RuntimeError("optimizer_step: hyper-parameters differ from the ones the backward was armed with")
+            if zero_grad != self._armed_zero:
+                raise RuntimeError("optimizer_step: zero_grad differs from what the backward was armed with")
             pos, total = 0, f.params.numel()
             for a, b in sorted(f.layer_ranges[i] for i in early) + [(total, total)]:
                 if a > pos:
-                    self._adamw_range(pos, a, step=self.step_count, g_scale=g_scale, **hp)
+                    self._adamw_range(pos, a, step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
                 pos = max(pos, b)
+            f._clean = bool(zero_grad)
         else:
             self._adamw_range(0, f.params.numel(), step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
             f._clean = bool(zero_grad)
