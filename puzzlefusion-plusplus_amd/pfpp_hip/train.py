@@ -274,6 +274,10 @@ class DenoiserTrainEngine:
         # LDS-DMA staged plane kernel (csrc/gemm_pl.hip); the LayerNorm / attention / GEGLU kernels hand their results over
         # as split-f16 planes, gradients lifted by grad_scale.  PFPP_TRAIN_PLANES=0 restores the register-staged kernels.
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
+        self._side2 = (torch.cuda.Stream(device=self.flat.params.device)
+                       if (self._side is not None and os.environ.get("PFPP_TRAIN_DW_STREAMS", "1") == "2") else None)
+        self._dw_flip = False
+        self._side2_used = False
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
@@ -285,6 +289,7 @@ class DenoiserTrainEngine:
     def single_stream(self) -> None:
         """everything on the caller's stream from now on (profiling / per-kernel timing)"""
         self._side = None
+        self._side2 = None
         self._aux = None
 
     # ------------------------------------------------------------------------------------------ forward
@@ -663,11 +668,24 @@ class DenoiserTrainEngine:
         if self._side is None:
             issue()
             return
-        self._side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side):
+        st = self._side
+        if self._side2 is not None:
+            # two weight-gradient streams, alternating: the GEMM + slab reduction pairs of independent layers overlap (each stream
+            # has its own K-split workspace); the first stream joins the second before anything that needs "all weight gradients"
+            self._dw_flip = not self._dw_flip
+            if self._dw_flip:
+                st = self._side2
+                self._side2_used = True
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
             issue()
-        dyp.record_stream(self._side)
-        xp.record_stream(self._side)
+        dyp.record_stream(st)
+        xp.record_stream(st)
+
+    def _join_side2(self) -> None:
+        if self._side2 is not None and self._side2_used:
+            self._side.wait_stream(self._side2)
+            self._side2_used = False
 
     def _backward_layers_planes(self, s, w, g, dh_, dmods):
         """transformer blocks on the plane GEMM: dX = dY . W reads the weight planes in place as the k-major operand, dW = dY^T . X
@@ -803,6 +821,7 @@ class DenoiserTrainEngine:
         """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
         from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
         self._flush_dw()
+        self._join_side2()
         if self._armed is not None and self._side is not None and not self._exchange.active():
             # optimizer in the backward (arm_optimizer): this layer's slice of the flat buffer is final once its weight
             # gradients (side stream) and LayerNorm gradients (main stream, all queued by now) have run — update it on the side
@@ -835,6 +854,7 @@ class DenoiserTrainEngine:
 
     def _all_done(self) -> None:
         self._flush_dw()
+        self._join_side2()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._exchange.all_done(dense=self._accumulated)
