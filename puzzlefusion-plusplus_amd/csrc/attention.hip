@@ -230,12 +230,13 @@ __device__ __forceinline__ void score_to_fragments(const f32x16 y, int lhi, ad_h
 // 4-5 of the dim (the 16 lanes that write one key pair for dims 4*c4 + j then hit 16 different banks)
 __device__ __forceinline__ int ad_toff(int dim, int key) { return dim * (32 + 8) + ((((key >> 3) ^ (dim >> 4)) & 3) << 3) + (key & 7); }
 
+template <int DH>
 __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
     _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
     int H, float scale, float* __restrict__ lse) {
-  constexpr int DH = 64, KT = 32;
+  constexpr int KT = 32, NDT = DH / 32;      // NDT: 32-wide tiles of the head dimension
   constexpr int LDKH = DH + 8;          // halfs per K row  (16-byte fragment reads conflict-free)
   constexpr int LDVH = KT + 8;          // halfs per V^T row
   constexpr int F4 = KT * DH / 4 / 256;
@@ -271,9 +272,9 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     }
   }
 
-  f32x16 o_acc[2];
+  f32x16 o_acc[NDT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.0f;
   float m_run = -1e30f, l_run = 0.0f;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
       const bool odd = r & 1;
       const int keep_h = odd ? uh.i.y : uh.i.x, send_h = odd ? uh.i.x : uh.i.y;
       const int keep_l = odd ? ul.i.y : ul.i.x, send_l = odd ? ul.i.x : ul.i.y;
-      const int got_h = __shfl_xor(send_h, 16), got_l = __shfl_xor(send_l, 16);
+      const int got_h = __shfl_xor(send_h, DH / 4), got_l = __shfl_xor(send_l, DH / 4);      // rows r and r + 1 are DH / 4 lanes apart
       const int a_h = odd ? got_h : keep_h, b_h = odd ? keep_h : got_h;
       const int a_l = odd ? got_l : keep_l, b_l = odd ? keep_l : got_l;
       const int d0 = c4 * 4 + (odd ? 2 : 0), r0 = r & ~1;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
 
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     ad_half8 ph[2], pl[2];
     score_to_fragments(s, lhi, ph, pl);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   if (q_row < T) {
     const int64_t off = (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float v0 = o_acc[dt][4 * g + 0] * inv, v1 = o_acc[dt][4 * g + 1] * inv;
@@ -482,7 +483,12 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
   const bool f16x3 = f16_mode != 0;
   if (dh == 64 && f16x3)
-    hipLaunchKernelGGL(attn_dense_f16_kernel, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+    hipLaunchKernelGGL(attn_dense_f16_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                       key_valid, kv_stride, (int)H, scale, lse);
+  else if (dh == 32 && f16x3 && max_len >= 1024)
+    // the verifier's attention over thousands of candidate edges (100-fragment puzzles: 4,950 keys per query): 3 f16 MFMAs per
+    // 16-deep step instead of 8 fp32 ones; the 190 edges of the reference's 20-fragment puzzles keep the exact-fp32 kernel
+    hipLaunchKernelGGL(attn_dense_f16_kernel<32>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                        key_valid, kv_stride, (int)H, scale, lse);
   else if (dh == 64)
     hipLaunchKernelGGL(attn_dense_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
