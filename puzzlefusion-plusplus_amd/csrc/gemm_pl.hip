@@ -864,7 +864,7 @@ int launch_f16x3_planes_af32(const GemmP& p0, int batch, hipStream_t st, int gro
 // (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
 // slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.  fix_variant / fix_splits != 0 pin a choice.
 static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool have_ws, int64_t ws_bytes, bool accumulate, bool no_v6,
-                      int* out_v, int* out_s, bool allow_v1 = false) {
+                      int* out_v, int* out_s, bool allow_v1 = false, bool tn_form = false) {
   const int nk = K / 32;
   const int cand_v[4] = {2, 3, 6, 1};
   const int cand_s[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
@@ -884,7 +884,10 @@ static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool
       const bool slabs = sp > 1 && have_ws && (double)sp * M * (N + 1.0) * 4.0 <= (double)ws_bytes;
       if (sp > 1 && !slabs && !accumulate) continue;
       const double wgs = tiles * sp;
-      const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;                  // co-resident workgroups share the CU's bandwidth
+      // co-resident workgroups share the CU's bandwidth; a grid that is not a multiple of the CU count leaves some CUs with one
+      // workgroup more than the others (measured: between the fractional and the rounded-up count)
+      const double frac = wgs / 256.0;
+      const double rounds = wgs <= 256.0 ? 1.0 : 0.5 * (frac + ceil(frac));
       const double kc = (double)K / sp;
       const double t_bw = rounds * kc * (bm + bn) * 4.0 / 45e9;
       const double t_mma = rounds * (bm / 32.0) * (bn / 32.0) * (kc / 16.0) * 3.0 * 32.0 / 4.0 / 2.1e9 / 0.75;
@@ -893,12 +896,21 @@ static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool
       if (slabs) t_epi = (2.0 * sp * cbytes + (accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 2e-6;
       else if (accumulate) t_epi = sp * cbytes / 1.2e12;
       else t_epi = cbytes / 3.5e12;
-      const double t = (t_bw > t_mma ? t_bw : t_mma) + t_epi + 4e-6;
+      double t_loop = t_bw > t_mma ? t_bw : t_mma;
+      // dW form (both operands k-major: two transposing LDS reads per MFMA operand): the two-stage 128 x 128 tile measures 20-25 %
+      // above its delivery bound there (1536x512x3850: 40.3 us vs 32.1 us for the three-stage 128 x 64 tile at the same split)
+      // (off by default: stand-alone it is right — serial iteration 9.55 -> 9.33 ms — but it moves the weight gradients to the
+      // 144 KB-LDS 256 x 128 tile, which then owns whole CUs next to the main chain: overlapped iteration 8.30 -> 8.57 ms)
+      static const bool tn_pen = getenv("PFPP_PL_TN_PENALTY") && atoi(getenv("PFPP_PL_TN_PENALTY")) == 1;
+      if (tn_form && v == 3 && tn_pen) t_loop *= 1.25;
+      const double t = t_loop + t_epi + 4e-6;
       if (t < best) { best = t; best_v = v; best_s = sp; }
     }
   }
   *out_v = best_v;
   *out_s = best_s;
+  static const bool dbg = getenv("PFPP_GEMM_CHOICE_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "pl_choose M%d N%d K%d -> variant %d splits %d (model %.1f us)\n", M, N, K, best_v, best_s, best * 1e6);
 }
 
 int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, int variant) {
@@ -916,6 +928,13 @@ int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, 
       pl_choose(p.M, p.N, p.K, 0, 0, true, pl::p_ws_bytes, false, false, &v, &sp);
       if (sp > 1) return launch_variant<false, false>(p, batch, st, group_m, v, sp);
     }
+  }
+  static const int chooser = getenv("PFPP_GEMM_CHOOSER") ? atoi(getenv("PFPP_GEMM_CHOOSER")) : 1;      // 0: tile-count rule; 2: no 256 x 256
+  if (chooser && variant == 0 && batch == 1 && !p.x1 && p.pool == 0 && !p.stats && p.M <= 16384) {
+    // token-sized GEMMs of the transformer: the same cost model as pfpp_gemm_planes (tile only; no K split on this path)
+    int v = 3, sp = 1;
+    pl_choose(p.M, p.N, p.K, 0, 1, false, 0, false, p.act == PFPP_ACT_GEGLU, &v, &sp, chooser != 2);
+    variant = v;
   }
   if (variant == 0) {
     const int64_t t256 = ((int64_t)(p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
@@ -970,7 +989,7 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   if (variant == 0 || splits == 0) {
     int best_v = 3, best_s = 1;
     pl_choose(p.M, p.N, p.K, a->variant, a->splits, a->ws != nullptr, a->ws ? a->ws_bytes : 0, a->accumulate != 0, false, &best_v, &best_s,
-              !a->a_kmajor && !a->w_kmajor && !a->single_pass);
+              !a->a_kmajor && !a->w_kmajor && !a->single_pass, a->a_kmajor && a->w_kmajor);
     if (variant == 0) variant = best_v;
     if (splits == 0) splits = best_s;
   }

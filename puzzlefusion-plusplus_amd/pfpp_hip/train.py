@@ -276,6 +276,7 @@ class DenoiserTrainEngine:
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._side2 = (torch.cuda.Stream(device=self.flat.params.device)
                        if (self._side is not None and os.environ.get("PFPP_TRAIN_DW_STREAMS", "1") == "2") else None)
+        self._dw_variant = int(os.environ.get("PFPP_TRAIN_DW_VARIANT", "0"))     # tile of the weight-gradient GEMMs (0: cost model)
         self._dw_flip = False
         self._side2_used = False
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
@@ -661,7 +662,7 @@ class DenoiserTrainEngine:
         def issue():
             fused = gb is not None and self._fuse_colsum and gb.is_contiguous()      # the bias gradient rides in the dW kernel
             P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True,
-                   colsum=gb if fused else None)
+                   colsum=gb if fused else None, variant=self._dw_variant)
             if gb is not None and not fused:
                 P.colsum(dyp, gb)
 
