@@ -276,6 +276,7 @@ class DenoiserTrainEngine:
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._side2 = (torch.cuda.Stream(device=self.flat.params.device)
                        if (self._side is not None and os.environ.get("PFPP_TRAIN_DW_STREAMS", "1") == "2") else None)
+        self.after_forward = None          # optional callable run between forward and backward of loss_and_grads (stream scheduling hooks)
         self._dw_variant = int(os.environ.get("PFPP_TRAIN_DW_VARIANT", "0"))     # tile of the weight-gradient GEMMs (0: cost model)
         self._dw_flip = False
         self._side2_used = False
@@ -944,6 +945,8 @@ class DenoiserTrainEngine:
                        train: bool = True) -> torch.Tensor:
         """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1]"""
         pred, ctx = self.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=train)
+        if self.after_forward is not None:
+            self.after_forward()
         n = pred.shape[0] * pred.shape[1]
         sel = (part_valids.reshape(n).to(torch.bool) & ~ref_part.reshape(n).to(torch.bool)).to(torch.uint8).contiguous()
         loss, dpred = T.mse_loss(pred.reshape(n, 7), noise.reshape(n, 7).contiguous().float(), sel)
@@ -965,6 +968,13 @@ class FeaturePipeline:
         self.model = denoiser_module                  # puzzlefusion_plusplus...Denoiser (encoder + noise_scheduler)
         self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
         self.pending = None
+        self.defer = False
+        self._args = None
+
+    def issue_next(self) -> None:
+        if self.defer and self.pending is None and self._args is not None:
+            data, gt, ref, draw = self._args
+            self.pending = self._issue(data, gt, ref, *draw())
 
     def _issue(self, data, gt, ref, noise, t):
         main = torch.cuda.current_stream()
@@ -982,7 +992,13 @@ class FeaturePipeline:
         `draw()` returns (noise, timesteps) for a batch."""
         if self.pending is None:
             self.pending = self._issue(data, gt, ref, *draw())
-        cur, self.pending = self.pending, self._issue(data, gt, ref, *draw())
+        if self.defer:
+            # the following batch's encoder is issued later by the caller (issue_next: e.g. between the transformer's forward and
+            # backward, so that it shares the chip with the backward + weight gradients instead of with the forward)
+            cur, self.pending = self.pending, None
+            self._args = (data, gt, ref, draw)
+        else:
+            cur, self.pending = self.pending, self._issue(data, gt, ref, *draw())
         main = torch.cuda.current_stream()
         main.wait_event(cur["event"])
         for k in ("noisy", "latent", "xyz"):
