@@ -615,6 +615,9 @@ def main():
             "variants": {k: {"launches_per_step": round(v[2] / args.steps, 1), "avg_launch_ms": round(v[1] / v[2], 4),
                              "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
                          for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
+            # the other roof of the same kernel: counter traffic per launch / its duration against the 8 TB/s HBM peak (short-K GEMMs on
+            # fp32 activations of 1.26 M rows sit between the two roofs)
+            "hbm_frac_of_traffic": (round(traffic / (ms / cnt * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None),
             "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
             "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
         }
