@@ -862,7 +862,7 @@ int launch_f16x3_planes_af32(const GemmP& p0, int batch, hipStream_t st, int gro
 // Tile and K split from a small cost model fitted to tools/gemm_lab measurements on 3,850-row shapes: a workgroup's main
 // loop is bound by operand delivery (~45 GB/s of L2 -> LDS DMA per CU, shared by co-resident workgroups) or by its MFMAs
 // (32 cycles each, ~75 % sustained); the epilogue streams C once (3.5 TB/s) — or, for a K split, writes and re-reads one
-// slab per chunk plus a second launch; atomics onto a shared C run at 1.2 TB/s.  fix_variant / fix_splits != 0 pin a choice.
+// slab per chunk plus a second launch (6 us); atomics onto a shared C run at 1.2 TB/s.  fix_variant / fix_splits != 0 pin a choice.
 static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool have_ws, int64_t ws_bytes, bool accumulate, bool no_v6,
                       int* out_v, int* out_s, bool allow_v1 = false, bool tn_form = false) {
   const int nk = K / 32;
@@ -893,7 +893,7 @@ static void pl_choose(int M, int N, int K, int fix_variant, int fix_splits, bool
       const double t_mma = rounds * (bm / 32.0) * (bn / 32.0) * (kc / 16.0) * 3.0 * 32.0 / 4.0 / 2.1e9 / 0.75;
       const double cbytes = (double)M * N * 4.0;
       double t_epi;
-      if (slabs) t_epi = (2.0 * sp * cbytes + (accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 2e-6;
+      if (slabs) t_epi = (2.0 * sp * cbytes + (accumulate ? 2.0 : 1.0) * cbytes) / 3.5e12 + 6e-6;      // + the reduction launch (6.6 us measured)
       else if (accumulate) t_epi = sp * cbytes / 1.2e12;
       else t_epi = cbytes / 3.5e12;
       double t_loop = t_bw > t_mma ? t_bw : t_mma;
