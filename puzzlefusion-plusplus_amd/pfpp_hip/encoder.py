@@ -104,7 +104,7 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
                 mx = ops.linear(h, pk[f"{name}.w{i}"], pk[f"{name}.b{i}"], a_affine=aff, stats=st, pool=nsample, c_min=mn)
             aff = T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
                                 momentum=0.1, eps=1e-5)
-            pk[f"{name}.nbt{i}"] += 1
+        torch._foreach_add_([pk[f"{name}.nbt{i}"] for i in range(3)], 1)          # num_batches_tracked of the level: one launch
         return T.bn_minmax_apply(mx, mn, aff[0], aff[1])
     h = A
     for i in range(3):

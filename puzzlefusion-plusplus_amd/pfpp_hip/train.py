@@ -91,6 +91,7 @@ class FlatParams:
         self.hi = torch.zeros(total, dtype=torch.float16, device=dev)
         self.lo = torch.zeros(total, dtype=torch.float16, device=dev)
         self.named = named
+        self._odd_buf = None
         self._clean = False
         with torch.no_grad():
             for n in self.order:
@@ -207,9 +208,28 @@ class FlatParams:
             v["pe"] = self.module.pos_encoding.pe[0].contiguous()
             self._views = {"w": v, "g": g}
         if self._odd is None:
+            # the two embeddings with 148 / 147 input features: K-padded copies (fp32 to 4, planes to 8 columns), re-packed after every
+            # optimizer step into persistent buffers — one strided copy + one split launch each instead of a dozen torch kernels
+            from . import planes as P_
+
             with torch.no_grad():
-                self._odd = {"shape.w": PW(self.view(self.params, "shape_embedding.weight"), prescale=False),
-                             "param.w": PW(self.view(self.params, "param_fc.weight"), prescale=False)}
+                if self._odd_buf is None:
+                    self._odd_buf = {}
+                    for key, name in (("shape.w", "shape_embedding.weight"), ("param.w", "param_fc.weight")):
+                        wv = self.view(self.params, name)
+                        n_, k_ = wv.shape
+                        pad8 = torch.zeros((n_, round_up(k_, 8)), dtype=torch.float32, device=wv.device)
+                        pl_ = P_.Planes.empty(n_, round_up(k_, 8), wv.device)
+                        self._odd_buf[key] = (name, pad8, pl_)
+                odd = {}
+                for key, (name, pad8, pl_) in self._odd_buf.items():
+                    wv = self.view(self.params, name)
+                    pad8[:, : wv.shape[1]].copy_(wv)
+                    P_.split(pad8, 1.0, out=pl_)
+                    pw = _pw_view(pad8, pl_.hi, pl_.lo)          # fp32 rows padded to 8 as well (any multiple of 4 serves the fp32 path)
+                    pw.K = int(wv.shape[1])
+                    odd[key] = pw
+                self._odd = odd
         w = dict(self._views["w"])
         w.update(self._odd)
         return {"w": w, "g": self._views["g"]}
@@ -538,14 +558,25 @@ class DenoiserTrainEngine:
         seed, p_lay, p_tok, fuse = s["seed"], s["p_lay"], s["p_tok"], s["fuse"]
         dout_c = dpred.reshape(s["n_slots"], 7)[s["slot"]].contiguous().float()         # [Fv, 7]
 
+        # every small zero-initialised buffer of the backward out of ONE zeroed arena (one fill launch instead of eight)
+        ld_sf, ld_pf = s["sf"].shape[1], s["pf"].shape[1]
+        h1 = s["heads"]["mlp_out_trans"][3].shape[1]
+        sizes = [Fv * C, Fv * 4, Fv * 4, 4 * h1, 4 * h1, s["mods"].numel(), C * ld_sf, C * ld_pf]
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + (n_ + 3) // 4 * 4)
+        arena = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        carve = lambda k, *shape: arena[offs[k]: offs[k] + sizes[k]].view(*shape)
+        dpads, dw4s = [carve(1, Fv, 4), carve(2, Fv, 4)], [carve(3, 4, h1), carve(4, 4, h1)]
+
         # ---- output heads (denoiser_transformer.py:138-147)
-        dpooled = torch.zeros((Fv, C), dtype=torch.float32, device=dev)
-        for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
+        dpooled = carve(0, Fv, C)
+        for hi_, (name, c0, width) in enumerate((("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4))):
             a0, v0, a1, v1 = s["heads"][name]
-            dpad = torch.zeros((Fv, 4), dtype=torch.float32, device=dev)
+            dpad = dpads[hi_]
             dpad[:, :width] = dout_c[:, c0:c0 + width]
             T.colsum(dout_c, g[f"{name}.4.b"], rows=Fv, cols=width, ld=7, x_off=c0)
-            dw4 = torch.zeros((4, v1.shape[1]), dtype=torch.float32, device=dev)
+            dw4 = dw4s[hi_]
             T.grad_weight(dpad, v1, dw4, g_scale=G)
             g[f"{name}.4.w"].add_(dw4[:width])
             dv1 = T.gemm_grad(dpad, w[f"{name}.4.w"].f32, torch.empty_like(v1), M=Fv, N=v1.shape[1], K=width, lda=4,
@@ -560,7 +591,7 @@ class DenoiserTrainEngine:
         dh_ = T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
         self._flush_dw()                                                                  # the heads' four small weight gradients
 
-        dmods = torch.zeros_like(s["mods"])
+        dmods = carve(5, *s["mods"].shape)
         # multi-rank: the two AdaLN linears of a block get their gradients as soon as the block's backward is through and travel with
         # the block's slice (otherwise 25 MB of dense gradient would be left for the exposed tail after the backward)
         self._ada_layerwise = (dmods, s["se"], g, B, C, G) if (self._exchange.reducing() and self._ada_per_layer) else None
@@ -572,14 +603,12 @@ class DenoiserTrainEngine:
         # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
         if p_tok > 0.0 and not fuse:
             dtok = T.dropout(dh_, p_tok, seed, 0)
-        ld_sf = s["sf"].shape[1]
-        dws = torch.zeros((C, ld_sf), dtype=torch.float32, device=dev)
+        dws = carve(6, C, ld_sf)
         T.grad_weight(dtok, s["sf"], dws, g_scale=G)
         g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
         T.colsum(dtok, g["shape.b"])
         dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L)
-        ld_pf = s["pf"].shape[1]
-        dwp = torch.zeros((C, ld_pf), dtype=torch.float32, device=dev)
+        dwp = carve(7, C, ld_pf)
         T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
         g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
         T.colsum(dx_emb, g["param.b"])
