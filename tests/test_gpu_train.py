@@ -2,6 +2,8 @@
 AdamW against (1) the gradients of the REFERENCE module's autograd committed in tests/golden/train.npz and
 (2) torch autograd through the CPU oracle on the same inputs, including the train-mode dropouts (the masks
 are read back from the kernel's counter-based generator and handed to the oracle)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -311,6 +313,30 @@ def test_optimizer_step_with_fused_zero_grad(golden, weights_sd, dev):
     (p0, g0, a0), (p1, g1, a1) = res
     assert rel(p0.cpu(), p1.cpu()) < 2e-4 and rel(g0.cpu(), g1.cpu()) < 1e-4      # two runs differ by atomics-order noise only
     assert rel(a0.cpu(), (g0 + a1).cpu()) < 1e-5          # unfused: old gradient still there; fused: started from zero
+
+
+def test_training_loop_as_benchmarked_converges(dev):
+    """the loop bench.py times (next iteration's encoder on its own stream, per-layer AdamW under the backward with the gradient clear
+    fused in, dynamic gradient scale) on one small fixed batch: the loss stays finite and falls, parameters stay finite"""
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parents[1])
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+
+    wl = bench.TrainWorkload(4, 512, None, 0, dev)
+    losses = []
+    for i in range(120):
+        wl.step()
+        if i % 10 == 0 or i == 119:
+            torch.cuda.synchronize()                      # the step runs on its own stream
+            losses.append(float(wl.last_loss))
+    assert all(math.isfinite(v) for v in losses)
+    assert sum(losses[-3:]) / 3 < 0.9 * (sum(losses[:3]) / 3), losses
+    assert bool(torch.isfinite(wl.engine.flat.params).all())
+    assert wl.engine.step_count == 120
 
 
 def test_dynamic_gradient_scale_follows_the_loss_gradient(golden, weights_sd, dev):
