@@ -188,7 +188,10 @@ def pn2_encode(pk, pts: torch.Tensor, num_point: int = 25, capture: Optional[dic
     xyz, feats = pts, None
     # the sampling chain of all three levels depends on coordinates only: one launch (FPS x 3 + ball query x 3 per fragment)
     lv = tuple((npoint or num_point, radius, nsample) for _, npoint, radius, nsample in SA_LEVELS)
-    sampled = ops.sample_levels(pts, lv) if (SAMPLE_FUSED and ops.sample_levels_supported(pts.shape[1], lv)) else (None,) * 3
+    # (a handful of fragments — one puzzle in flight — is latency-bound either way; there the per-level kernels' wider ball-query grids
+    # win: 171 vs 189 us at F = 8)
+    sampled = (ops.sample_levels(pts, lv) if (SAMPLE_FUSED and pts.shape[0] >= 32 and ops.sample_levels_supported(pts.shape[1], lv))
+               else (None,) * 3)
     for (name, npoint, radius, nsample), smp in zip(SA_LEVELS, sampled):
         xyz, feats = set_abstraction(pk, name, npoint or num_point, radius, nsample, xyz, feats, capture, sampled=smp)
     F, L, C3 = feats.shape
