@@ -76,8 +76,8 @@ def pmc_traffic(kernel: str, mode: str = "train"):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="puzzles per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=None, help="fix the number of valid fragments per puzzle")
