@@ -993,7 +993,8 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
     if (variant == 0) variant = best_v;
     if (splits == 0) splits = best_s;
   }
-  const int gm = 8;
+  static const int gm_env = getenv("PFPP_GEMM_GROUP_M") ? atoi(getenv("PFPP_GEMM_GROUP_M")) : 8;
+  const int gm = gm_env;
   if (a->single_pass) {
     PFPP_SUPPORTED(!a->a_kmajor && !a->w_kmajor, "single-pass fp16 with k-major operands");
     p.x1 = 1;
