@@ -122,6 +122,8 @@ class SamplerWorkload:
         self.noise = [torch.randn(gt.shape, device=dev, generator=g) for _ in range(20)]
         self.timesteps = self.model.noise_scheduler.timesteps.tolist()
         self.ts_dev = {t: torch.full((batch,), t, dtype=torch.int64, device=dev) for t in self.timesteps}
+        for t_, v_ in self.ts_dev.items():
+            v_._pfpp_t = int(t_)          # as Denoiser.sample / AutoAgglomerative tag them: AdaLN rows cached per (t, batch)
         self.x = self.x0.clone()
         self.i = 0
 
@@ -249,6 +251,8 @@ class StressWorkload:
         self.noise = [torch.randn(gt.shape, device=dev, generator=g) for _ in range(20)]
         self.timesteps = self.model.noise_scheduler.timesteps.tolist()
         self.ts_dev = {t: torch.full((batch,), t, dtype=torch.int64, device=dev) for t in self.timesteps}
+        for t_, v_ in self.ts_dev.items():
+            v_._pfpp_t = int(t_)          # as Denoiser.sample / AutoAgglomerative tag them: AdaLN rows cached per (t, batch)
         E = parts * (parts - 1) // 2
         self.edge_idx = torch.triu(torch.ones(parts, parts, dtype=torch.bool), diagonal=1).nonzero()[None].expand(batch, E, 2).contiguous().to(dev)
         self.edge_feat = torch.rand(batch, E, 7, device=dev, generator=g)

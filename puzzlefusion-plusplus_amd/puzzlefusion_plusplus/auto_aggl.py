@@ -235,7 +235,12 @@ class AutoAgglomerative(LightningModule):
             return self.denoiser(x, ts, latent, xyz, part_valids, part_scale, ref_part, layout=layout)
 
         if not self.use_graphs:
-            return lambda x, t: eager(x, torch.full((B,), t, dtype=torch.int64, device=dev))
+            def step(x, t):
+                ts = torch.full((B,), t, dtype=torch.int64, device=dev)
+                ts._pfpp_t = int(t)      # one timestep for the whole batch: AdaLN rows cached per (t, B)
+                return eager(x, ts)
+
+            return step
         state = {"graph": None, "calls": 0}
         x_buf = torch.empty_like(x_like)
         ts_buf = torch.zeros((B,), dtype=torch.int64, device=dev)

@@ -125,6 +125,7 @@ class Denoiser(LightningModule):
         B = x.shape[0]
         for i, t in enumerate(self.noise_scheduler.timesteps.tolist()):
             ts = torch.full((B,), t, dtype=torch.int64, device=x.device)
+            ts._pfpp_t = int(t)          # every puzzle at the same timestep: the AdaLN rows of (t, B) are computed once (pfpp_hip.denoiser.ada_mods)
             latent, xyz = self._extract_features(data_dict["part_pcs"], data_dict["part_valids"], x)
             eps = self.denoiser(x, ts, latent, xyz, data_dict["part_valids"], data_dict["part_scale"], ref_part)
             x = self.noise_scheduler.step(eps, t, x, variance_noise=None if noises is None else noises[i],
