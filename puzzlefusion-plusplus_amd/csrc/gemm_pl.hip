@@ -839,6 +839,16 @@ static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m
       [[fallthrough]];
     case 2: return pl::launch_pl<2, 2, 4, 2, 3, AK, WK>(p, batch, st, group_m, splits);
     case 6: return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    case 9:       // 64 x 64 (4 waves of 32 x 32, three stages): grids of a few dozen workgroups — twice the workgroups per output, half
+                  // the bytes per K-tile of each: a single puzzle's 200-row GEMMs are bound by the per-workgroup DMA rate
+      if constexpr (!AK && !WK) return pl::launch_pl<1, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+      return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    case 10:      // 128 x 32, two waves: twice the workgroups along N, each streaming half the weight columns
+      if constexpr (!AK && !WK) return pl::launch_pl<2, 1, 2, 1, 3, AK, WK>(p, batch, st, group_m, splits);
+      return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    case 11:      // 64 x 32, two waves
+      if constexpr (!AK && !WK) return pl::launch_pl<1, 1, 2, 1, 3, AK, WK>(p, batch, st, group_m, splits);
+      return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
     default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK>(p, batch, st, group_m, splits);
   }
 }
@@ -943,6 +953,13 @@ int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, 
     variant = t256 >= 512 ? 1 : (t21 >= 160 ? 2 : (t11 >= 200 ? 3 : 6));
     // (a six-stage ring for grids of a few workgroups was tried for the single-puzzle loop: 5.50 -> 5.55 puzzles/s, not kept)
   }
+  // a single puzzle's GEMMs (200 rows): each workgroup streams its weight columns cold (57.6 M parameters do not stay in L2 between
+  // steps) at the per-workgroup DMA rate, so narrower tiles = more workgroups pulling in parallel: one puzzle in flight 5.1-5.3 ->
+  // 5.4-5.5 puzzles/s with the 64 x 32 tile (9 = 64 x 64: no gain, same columns per workgroup; 0 = keep 128 x 64)
+  static const int tiny = getenv("PFPP_GEMM_TINY_TILE") ? atoi(getenv("PFPP_GEMM_TINY_TILE")) : 11;
+  if (tiny && variant == 6 && batch == 1 && !p.x1 && p.pool == 0 && p.act != PFPP_ACT_GEGLU &&
+      (int64_t)((p.M + 127) / 128) * ((p.N + 63) / 64) <= 48)
+    variant = tiny;
   // GEGLU gates pairs of column tiles (two per wave at least); the pool = 64 epilogue needs two row tiles per wave
   if (variant == 6 && p.act == PFPP_ACT_GEGLU) variant = 3;
   if (variant == 1 && p.pool == 64) variant = 2;
