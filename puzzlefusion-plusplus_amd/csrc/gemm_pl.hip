@@ -849,6 +849,9 @@ static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m
     case 11:      // 64 x 32, two waves
       if constexpr (!AK && !WK) return pl::launch_pl<1, 1, 2, 1, 3, AK, WK>(p, batch, st, group_m, splits);
       return pl::launch_pl<2, 1, 2, 2, 3, AK, WK>(p, batch, st, group_m, splits);
+    case 12:      // 64 x 64 as two waves of 32 x 64: the GEGLU form (value | gate column tiles in one wave) of the above
+      if constexpr (!AK && !WK) return pl::launch_pl<1, 2, 2, 1, 3, AK, WK>(p, batch, st, group_m, splits);
+      return pl::launch_pl<2, 2, 2, 2, 2, AK, WK>(p, batch, st, group_m, splits);
     default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK>(p, batch, st, group_m, splits);
   }
 }
@@ -960,6 +963,9 @@ int launch_f16x3_planes(const GemmP& p, int batch, hipStream_t st, int group_m, 
   if (tiny && variant == 6 && batch == 1 && !p.x1 && p.pool == 0 && p.act != PFPP_ACT_GEGLU &&
       (int64_t)((p.M + 127) / 128) * ((p.N + 63) / 64) <= 48)
     variant = tiny;
+  static const int tiny_g = getenv("PFPP_GEMM_TINY_GEGLU") ? atoi(getenv("PFPP_GEMM_TINY_GEGLU")) : 0;
+  if (tiny_g && batch == 1 && !p.x1 && p.pool == 0 && p.act == PFPP_ACT_GEGLU && (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 96)
+    variant = 12;
   // GEGLU gates pairs of column tiles (two per wave at least); the pool = 64 epilogue needs two row tiles per wave
   if (variant == 6 && p.act == PFPP_ACT_GEGLU) variant = 3;
   if (variant == 1 && p.pool == 64) variant = 2;
