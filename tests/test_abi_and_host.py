@@ -4,6 +4,8 @@ import ctypes
 import re
 from pathlib import Path
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -92,6 +94,47 @@ def test_packing_geglu_and_sa_first():
     w_, s, t = fold_conv_bn(conv.weight.data, conv.bias.data, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var)
     got = torch.einsum("oc,bchw->bohw", w_, x) * s[None, :, None, None] + t[None, :, None, None]
     assert torch.allclose(got, bn(conv(x)), atol=1e-5)
+
+
+def test_plane_scale_and_prescaled_weight_planes():
+    """packing.plane_scale: a power of two that lifts max |w| into [2^12, 2^13); PW planes then stand for scale * w to 22 bits whatever
+    the tensor's magnitude, and nothing reaches the fp16 overflow"""
+    from pfpp_hip.packing import PW, plane_scale
+
+    g = torch.Generator().manual_seed(0)
+    for mag in (1e-7, 3e-3, 1.0, 77.0, 6e4, 3e8):
+        w = torch.randn(64, 48, generator=g) * mag
+        s = plane_scale(w)
+        assert math.log2(s) % 1 == 0 and 2 ** 12 <= float(w.abs().max()) * s < 2 ** 13
+        pw = PW(w)
+        assert pw.scale == s and torch.isfinite(pw.hi.float()).all() and torch.isfinite(pw.lo.float()).all()
+        back = (pw.hi.double() + pw.lo.double()) / s
+        big = w.abs() >= w.abs().max() * 2.0 ** -16                      # elements within 16 octaves of the largest: full 22 bits
+        assert ((back - w.double()).abs()[big] <= w.double().abs()[big] * 2.0 ** -21).all()
+    assert plane_scale(torch.zeros(4, 8)) == 1.0 and PW(torch.zeros(4, 8)).scale == 1.0
+    assert PW(torch.randn(4, 8, generator=g), prescale=False).scale == 1.0
+
+
+def test_balanced_assignment_and_fragment_counts():
+    """what bench.py --gpus N deals out: synthetic.num_parts_of == the count make_puzzle draws; equal-count assignment keeps the
+    per-rank batch size and tightens the spread of valid fragments"""
+    from pfpp_hip import synthetic
+    from pfpp_hip.parallel import balanced_assignment
+
+    for pid in (0, 7, 1003, 2031):
+        assert synthetic.num_parts_of(pid) == int(synthetic.make_puzzle(pid, num_points=64)["part_valids"].sum())
+    pool = [1000 * r + i for r in range(4) for i in range(8)]
+    counts = [synthetic.num_parts_of(i) for i in pool]
+    assign = balanced_assignment(counts, 4, equal_count=True)
+    assert sorted(sum(assign, [])) == list(range(32)) and all(len(a) == 8 for a in assign)
+    loads = [sum(counts[j] for j in a) for a in assign]
+    in_order = [sum(counts[8 * r: 8 * r + 8]) for r in range(4)]
+    assert max(loads) - min(loads) <= max(in_order) - min(in_order) and max(loads) - min(loads) <= max(counts)
+    with pytest.raises(ValueError):
+        balanced_assignment(counts[:-1], 4, equal_count=True)
+    ids = [3, 1001]
+    b = synthetic.make_batch(0, 2, num_points=64, ids=ids)
+    assert int(b["part_valids"][1].sum()) == synthetic.num_parts_of(1001)
 
 
 def test_scheduler_host_tables_match_golden(golden):
