@@ -1,10 +1,9 @@
 """CPU: the C-ABI library loads and exports every symbol include/pfpp.h declares; host-side logic
 (packing, scheduler tables, state_dict layout, configs, synthetic data, error behaviour)."""
 import ctypes
+import math
 import re
 from pathlib import Path
-
-import math
 
 import numpy as np
 import pytest
