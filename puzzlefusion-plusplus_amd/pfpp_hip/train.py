@@ -278,7 +278,8 @@ class DenoiserTrainEngine:
                                       zero1=os.environ.get("PFPP_ZERO1", "0") == "1")
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
-        self._side = (torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
+        self._side = ((_masked_stream(self.flat.params.device, int(os.environ.get("PFPP_SIDE_CU_FRACTION_PCT", "0"))) or
+                       torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0"))))
                       if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None)
         # the two passes of the dense attention backward (dq | dk, dv) are independent and can run on two streams
         # (pfpp_attn_dense_bwd_parts) — measured: no gain (9.76 vs 9.75 ms; 8.36 vs 8.10 with the latents given: both are
@@ -983,6 +984,32 @@ class DenoiserTrainEngine:
         return loss
 
 
+def _masked_stream(device, pct: int):
+    """experiment (PFPP_ENC_CU_FRACTION_PCT): a HIP stream restricted to the first pct % of every XCD's CUs (hipExtStreamCreateWithCUMask),
+    wrapped for torch — the encoder then cannot take the whole chip from the transformer's dependency chain.  None when pct is 0."""
+    if pct <= 0 or pct >= 100:
+        return None
+    import ctypes
+
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count          # 256: CU i lives on XCD i % 8
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    per_xcd = n_cu // 8
+    keep = max(1, per_xcd * pct // 100)
+    by_xcd = os.environ.get("PFPP_CU_MASK_MODE", "slots") == "xcd"      # experiment: whole XCDs instead of the same slots of every XCD
+    for cu in range(n_cu):
+        take = (cu % 8) < max(1, 8 * pct // 100) if by_xcd else (cu // 8) < keep      # CU index -> (slot = cu // 8, XCD = cu % 8)
+        if take:
+            mask[cu // 32] |= 1 << (cu % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        return None
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class FeaturePipeline:
     """Runs the frozen encoder of the NEXT training batch on its own HIP stream while the transformer forward / backward
     / optimizer of the current batch occupy the main stream.
@@ -995,7 +1022,8 @@ class FeaturePipeline:
 
     def __init__(self, denoiser_module, device):
         self.model = denoiser_module                  # puzzlefusion_plusplus...Denoiser (encoder + noise_scheduler)
-        self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
+        self.stream = _masked_stream(device, int(os.environ.get("PFPP_ENC_CU_FRACTION_PCT", "70"))) or \
+            torch.cuda.Stream(device=device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
         self.pending = None
         self.defer = False
         self._args = None
