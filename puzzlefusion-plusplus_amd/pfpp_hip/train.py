@@ -278,7 +278,7 @@ class DenoiserTrainEngine:
                                       zero1=os.environ.get("PFPP_ZERO1", "0") == "1")
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
-        self._side = ((_masked_stream(self.flat.params.device, int(os.environ.get("PFPP_SIDE_CU_FRACTION_PCT", "0"))) or
+        self._side = ((_masked_stream(self.flat.params.device, int(os.environ.get("PFPP_SIDE_CU_FRACTION_PCT", "0")), from_top=True) or
                        torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0"))))
                       if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None)
         # the two passes of the dense attention backward (dq | dk, dv) are independent and can run on two streams
@@ -984,7 +984,7 @@ class DenoiserTrainEngine:
         return loss
 
 
-def _masked_stream(device, pct: int):
+def _masked_stream(device, pct: int, from_top: bool = False):
     """experiment (PFPP_ENC_CU_FRACTION_PCT): a HIP stream restricted to the first pct % of every XCD's CUs (hipExtStreamCreateWithCUMask),
     wrapped for torch — the encoder then cannot take the whole chip from the transformer's dependency chain.  None when pct is 0."""
     if pct <= 0 or pct >= 100:
@@ -999,7 +999,8 @@ def _masked_stream(device, pct: int):
     keep = max(1, per_xcd * pct // 100)
     by_xcd = os.environ.get("PFPP_CU_MASK_MODE", "slots") == "xcd"      # experiment: whole XCDs instead of the same slots of every XCD
     for cu in range(n_cu):
-        take = (cu % 8) < max(1, 8 * pct // 100) if by_xcd else (cu // 8) < keep      # CU index -> (slot = cu // 8, XCD = cu % 8)
+        slot = cu // 8                                # CU index -> (slot = cu // 8, XCD = cu % 8)
+        take = (cu % 8) < max(1, 8 * pct // 100) if by_xcd else ((per_xcd - 1 - slot) < keep if from_top else slot < keep)
         if take:
             mask[cu // 32] |= 1 << (cu % 32)
     st = ctypes.c_void_p()
