@@ -991,8 +991,14 @@ def _masked_stream(device, pct: int, from_top: bool = False):
         return None
     import ctypes
 
-    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    try:
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipExtStreamCreateWithCUMask
+    except (OSError, AttributeError):                 # another HIP runtime layout: fall back to an ordinary stream
+        return None
     n_cu = torch.cuda.get_device_properties(device).multi_processor_count          # 256: CU i lives on XCD i % 8
+    if n_cu % 8 or n_cu < 64:
+        return None
     words = (n_cu + 31) // 32
     mask = (ctypes.c_uint32 * words)()
     per_xcd = n_cu // 8
