@@ -1029,8 +1029,8 @@ class FeaturePipeline:
 
     def __init__(self, denoiser_module, device):
         self.model = denoiser_module                  # puzzlefusion_plusplus...Denoiser (encoder + noise_scheduler)
-        self.stream = _masked_stream(device, int(os.environ.get("PFPP_ENC_CU_FRACTION_PCT", "70"))) or \
-            torch.cuda.Stream(device=device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
+        self.device = device
+        self.stream = None                            # chosen at the first issue (see _pick_stream)
         self.pending = None
         self.defer = False
         self._args = None
@@ -1040,7 +1040,18 @@ class FeaturePipeline:
             data, gt, ref, draw = self._args
             self.pending = self._issue(data, gt, ref, *draw())
 
+    def _pick_stream(self):
+        """the encoder's stream, once: CU-masked (PFPP_ENC_CU_FRACTION_PCT % of every XCD's CUs) when the caller's loop runs on a stream
+        of its own.  hipExtStreamCreateWithCUMask makes a BLOCKING stream — it synchronises implicitly with the legacy default
+        stream — so a loop that runs on the default stream gets an ordinary non-blocking stream instead (measured with the mask and the
+        loop on the default stream: 11.7 ms instead of 8.0)."""
+        on_default = torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device)
+        st = None if on_default else _masked_stream(self.device, int(os.environ.get("PFPP_ENC_CU_FRACTION_PCT", "70")))
+        return st or torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
+
     def _issue(self, data, gt, ref, noise, t):
+        if self.stream is None:
+            self.stream = self._pick_stream()
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)                 # inputs were produced on the main stream
         with torch.cuda.stream(self.stream), torch.no_grad():
