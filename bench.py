@@ -497,8 +497,34 @@ def aggl_puzzles_per_s(dev, n_puzzles: int = 3, points: int = 1000, in_flight: i
                     + "; full loop incl. verifier, promotion, merges and metrics"}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, the launch of
+    scripts/train_denoiser.sh:6-7 `+trainer.devices=N +trainer.strategy=ddp`) by re-running this file under
+    torch.distributed.run on 127.0.0.1; rank 0 of the children prints the one JSON line.  Fails loudly when the box
+    has fewer than N devices (PFPP_BENCH_BACKEND=gloo lets ranks share devices: the single-GPU test of this path)."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("PFPP_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; one rank per GPU is required "
+                         "(RCCL cannot place two ranks on one device)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -518,8 +544,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)")
 
     from pfpp_hip import ops
 
@@ -627,6 +653,15 @@ def main():
         }
 
     extra = {}
+    if dist is not None:
+        # proof that the collective library saw every rank: sum of ones over the job's ranks and the set of devices they sit on
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        devs = [None] * world
+        dist.all_gather_object(devs, (torch.cuda.current_device(), torch.cuda.get_device_properties(dev).name))
+        extra["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = int(ones.item())
+        extra["rank_devices"] = [f"cuda:{d} {n}" for d, n in devs]
+        extra["backend"] = backend
     if balance is not None:
         extra["rank_balance"] = balance
     if dist is not None and train and world > 1:

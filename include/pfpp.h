@@ -664,6 +664,14 @@ int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi, void* lo,
 int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
                     float bc2, float g_scale, int zero_grad, pfpp_stream_t stream);
+/* the same with the overflow guard of a loss-scaled optimizer (what torch.cuda.amp.GradScaler.step does around
+ * configure_optimizers' AdamW, denoiser.py:230-241, when the backward runs on fp16 operands), entirely on the device:
+ * overflow (int32[2], device memory): [0] = flag, [1] = count.  An element whose (scaled) gradient is inf / NaN is left untouched
+ * (p, m, v, planes unchanged), sets the flag and adds to the count; a launch that finds the flag already set updates nothing
+ * (its gradients are still cleared when zero_grad != 0).  The caller clears overflow[] between steps and reads it when it likes. */
+int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                       float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);
 
 /* ---- train-mode BatchNorm of the (frozen, but .train()) encoder (utils/pn2_utils.py:211-214) -------------
  * The reference freezes the encoder's parameters only (train_denoiser.py:33-35); under Lightning's

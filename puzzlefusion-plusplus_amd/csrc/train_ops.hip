@@ -493,15 +493,33 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // AdamW
 // ---------------------------------------------------------------------------------------------------
+// GUARD: the loss-scaling guard of a mixed-precision optimizer, on the device (no host read): `overflow[0]` is the step's
+// "a non-finite gradient was seen" flag, `overflow[1]` counts such elements.  A launch that finds the flag set leaves its range
+// untouched (gradients still cleared when asked); an element whose own gradient is inf / NaN is left untouched and raises the flag
+// for the launches that follow — parameters and both moments can never be poisoned by an overflowed split-f16 gradient plane.
+template <bool GUARD>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t n,
                                                     float decay, float w1, float beta2, float w2, float eps,
-                                                    float step_size, float inv_sqrt_bc2, float g_scale, int zero_g) {
+                                                    float step_size, float inv_sqrt_bc2, float g_scale, int zero_g,
+                                                    int* __restrict__ overflow) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float gr = g[i] * g_scale;
-  if (zero_g) g[i] = 0.0f;                            // optimizer.zero_grad() in the same pass (no separate 230 MB memset)
+  bool skip_all = false;
+  if (GUARD) skip_all = __builtin_nontemporal_load(overflow) != 0;
+  const bool in = i < n;
+  float gr = in ? g[i] * g_scale : 0.0f;
+  if (in && zero_g) g[i] = 0.0f;                      // optimizer.zero_grad() in the same pass (no separate 230 MB memset)
+  if (GUARD) {
+    const bool bad = !(fabsf(gr) <= 3.0e38f);         // inf or NaN
+    const unsigned long long mask = __ballot(bad);
+    if (mask != 0ull && (threadIdx.x & 63) == 0) {
+      atomicOr(overflow, 1);
+      atomicAdd(overflow + 1, __popcll(mask));
+    }
+    if (skip_all || bad) return;
+  }
+  if (!in) return;
   float pp = p[i] * decay;
   float mm = m[i];
   mm = mm + w1 * (gr - mm);                         // exp_avg.lerp_(grad, 1 - beta1)
@@ -801,12 +819,25 @@ extern "C" int pfpp_adamw(float* p, const float* g, float* m, float* v, void* hi
 extern "C" int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
                                float g_scale, int zero_grad, pfpp_stream_t stream) {
+  return pfpp_adamw_guarded(p, g, m, v, hi, lo, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, zero_grad, nullptr, stream);
+}
+
+extern "C" int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                                  float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream) {
   PFPP_REQUIRE(p && g && m && v, "null pointer");
   PFPP_REQUIRE(!hi == !lo, "hi and lo go together");
   PFPP_REQUIRE(bc1 > 0.0f && bc2 > 0.0f, "bias corrections must be positive");
   if (n == 0) return PFPP_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, pfpp::as_stream(stream), p, g, m, v,
-                     (_Float16*)hi, (_Float16*)lo, n, 1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, eps,
-                     lr / bc1, 1.0f / sqrtf(bc2), g_scale, zero_grad ? 1 : 0);
+  const dim3 grid(blocks_for(n, 256));
+  hipStream_t st = pfpp::as_stream(stream);
+  if (overflow)
+    hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, st, p, g, m, v, (_Float16*)hi, (_Float16*)lo, n,
+                       1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, eps, lr / bc1, 1.0f / sqrtf(bc2), g_scale,
+                       zero_grad ? 1 : 0, (int*)overflow);
+  else
+    hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, st, p, g, m, v, (_Float16*)hi, (_Float16*)lo, n,
+                       1.0f - lr * weight_decay, 1.0f - beta1, beta2, 1.0f - beta2, eps, lr / bc1, 1.0f / sqrtf(bc2), g_scale,
+                       zero_grad ? 1 : 0, (int*)nullptr);
   return pfpp::check_launch(__func__);
 }

@@ -151,6 +151,7 @@ SIGNATURES = {
     "pfpp_bn_apply": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i64, _i64, _p],
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
     "pfpp_adamw_zero": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p],
+    "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
     "pfpp_split_planes": [_p, _i64, _pl, _p],

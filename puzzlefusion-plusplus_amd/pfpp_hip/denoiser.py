@@ -106,7 +106,10 @@ def ada_mods(pk, timesteps: torch.Tensor, n_ada: int, C: int) -> torch.Tensor:
     cache = None
     if t_host is not None:
         cache = pk.setdefault("_mods_cache", {})
-        hit = cache.get((int(t_host), B))
+        # the arithmetic mode is part of the key: the exact-fp32 rerun after a non-finite f16x3 result (ops.exact_fp32) must not
+        # reuse rows computed in the mode that overflowed
+        key = (int(t_host), B, ops.GEMM_MODE, ops.SINGLE_PASS)
+        hit = cache.get(key)
         if hit is not None:
             return hit
     se = ops.silu_embed(pk["ada.tables"], timesteps.to(torch.int64).contiguous())
@@ -114,7 +117,7 @@ def ada_mods(pk, timesteps: torch.Tensor, n_ada: int, C: int) -> torch.Tensor:
     ops.gemm(se, pk["ada.w"], M=B, N=2 * C, K=C, lda=C, out=mods, ldc=2 * C, bias=pk["ada.b"],
              batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
     if cache is not None and len(cache) < 512:
-        cache[(int(t_host), B)] = mods
+        cache[key] = mods
     return mods
 
 

@@ -50,7 +50,9 @@ def plane_scale(w: torch.Tensor) -> float:
     amax = float(w.detach().abs().max()) if w.numel() else 0.0
     if not math.isfinite(amax) or amax == 0.0:
         return 1.0
-    return 2.0 ** (12 - math.floor(math.log2(amax)))
+    # exponent clamped to 2^±100: a (near-)denormal tensor would otherwise ask for a scale beyond the fp32 range (w * scale = inf,
+    # alpha = 1 / scale = 0 -> NaN); such a tensor contributes nothing at fp32 precision either way
+    return 2.0 ** max(-100, min(100, 12 - math.floor(math.log2(amax))))
 
 
 class PW:

@@ -73,14 +73,8 @@ class GradExchange:
     the factor that turns the summed gradients into the mean (folded into the optimizer kernel, no extra pass).
     Works on any backend (tested with gloo on CPU tensors)."""
 
-    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]], sparse_range: Tuple[int, int] = (0, 0),
-                 zero1: bool = False):
+    def __init__(self, grads: torch.Tensor, layer_ranges: List[Tuple[int, int]], sparse_range: Tuple[int, int] = (0, 0)):
         self.grads = grads
-        # ZeRO-1 (opt-in): a slice is reduce-SCATTERED — rank r ends up with the sum of the r-th 1/world of it, updates only that
-        # part of the parameters (optimizer work / world) and the ranks all-gather the updated parameters afterwards
-        # (gather_params).  Same bytes on the links as the all-reduce; the gather is not hidden under the backward.
-        self.zero1 = zero1
-        self._segments: List[Tuple[int, int, bool]] = []     # (a, b, sharded) in issue order, for the optimizer
         self.layer_ranges = list(layer_ranges)
         # [a, b) of the head slice that is NOT all-reduced: the timestep-embedding tables (a third of all parameters) get
         # gradients in only `batch` of their 3072 rows per step, so the ranks exchange those rows instead (gather_rows)
@@ -98,60 +92,12 @@ class GradExchange:
     def reducing(self) -> bool:
         return self.enabled and self.active()
 
-    def _shardable(self, a: int, b: int) -> bool:
-        import torch.distributed as dist
-
-        return (b - a) % (8 * dist.get_world_size()) == 0        # every part 16-byte aligned in the fp16 planes too
-
-    def own_part(self, a: int, b: int) -> Tuple[int, int]:
-        import torch.distributed as dist
-
-        n = (b - a) // dist.get_world_size()
-        return a + dist.get_rank() * n, a + (dist.get_rank() + 1) * n
-
     def _reduce(self, a: int, b: int) -> None:
         import torch.distributed as dist
 
         if b <= a:
             return
-        if self.zero1 and self._shardable(a, b):
-            self._segments.append((a, b, True))
-            x, y = self.own_part(a, b)
-            try:
-                self._handles.append(dist.reduce_scatter_tensor(self.grads[x:y], self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
-                return
-            except (RuntimeError, NotImplementedError):      # gloo has no reduce-scatter: the all-reduce leaves the same sum in the own part
-                pass
-        elif self.zero1:
-            self._segments.append((a, b, False))
         self._handles.append(dist.all_reduce(self.grads[a:b], op=dist.ReduceOp.SUM, async_op=True))
-
-    def note_replicated(self, a: int, b: int) -> None:
-        """[a, b) already holds the summed gradient on every rank (the sparse table rows after gather_rows)"""
-        if self.zero1 and self.reducing() and b > a:
-            self._segments.append((a, b, self._shardable(a, b)))
-
-    def take_segments(self) -> List[Tuple[int, int, bool]]:
-        segs, self._segments = self._segments, []
-        return segs
-
-    def gather_params(self, params: torch.Tensor, segs) -> None:
-        """after the sharded optimizer step: every sharded segment's parameters from their owners, in place"""
-        import torch.distributed as dist
-
-        handles = []
-        for a, b, sharded in segs:
-            if not sharded:
-                continue
-            x, y = self.own_part(a, b)
-            try:
-                handles.append(dist.all_gather_into_tensor(params[a:b], params[x:y], async_op=True))
-            except (RuntimeError, NotImplementedError):
-                parts = [torch.empty_like(params[x:y]) for _ in range(dist.get_world_size())]
-                dist.all_gather(parts, params[x:y].contiguous())
-                params[a:b].copy_(torch.cat(parts))
-        for h in handles:
-            h.wait()
 
     def layer_done(self, i: int, extra=()) -> None:
         """reduce layer i's slice, plus `extra` [a, b) ranges of the head slice whose gradients are final with this layer"""
@@ -168,8 +114,6 @@ class GradExchange:
             a, b = self.sparse_range
             first = self.layer_ranges[0][0]
             skip = sorted(self._early + ([(a, b)] if (b > a and not dense) else []))
-            if b > a and not dense:
-                self.note_replicated(a, b)
             pos = 0
             for x, y in skip + [(first, first)]:          # the head slice minus what went with the layers / goes as rows
                 self._reduce(pos, min(x, first))

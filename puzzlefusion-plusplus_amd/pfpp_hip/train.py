@@ -274,8 +274,18 @@ class DenoiserTrainEngine:
         # the 12 AdaLN timestep tables open the flat buffer (see _param_order): exchanged as rows, not as 75 MB of zeros
         self._sparse_tables = os.environ.get("PFPP_SPARSE_TABLE_GRADS", "1") == "1"
         n_tab = self.flat.offset[f"transformer_layers.0.norm1.linear.weight"]       # the tables are the first group of the layout
-        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges, (0, n_tab) if self._sparse_tables else (0, 0),
-                                      zero1=os.environ.get("PFPP_ZERO1", "0") == "1")
+        self._exchange = GradExchange(self.flat.grads, self.flat.layer_ranges, (0, n_tab) if self._sparse_tables else (0, 0))
+        # overflow guard (the GradScaler of this engine): the backward's operands are fp16 planes of grad_scale * dY, written without
+        # saturation — a batch whose gradients outgrow the lagged scale estimate yields inf / NaN gradients.  The AdamW launches
+        # skip and flag such elements on the device (pfpp_adamw_guarded: parameters and moments are never poisoned, no host read);
+        # the flag travels to the host through pinned memory two steps later and backs the scale off (x 1/16, regrown x 2 per
+        # 200 clean steps).  PFPP_TRAIN_OVERFLOW_GUARD=0 removes the guard.
+        self._guard = os.environ.get("PFPP_TRAIN_OVERFLOW_GUARD", "1") != "0"
+        self._overflow = torch.zeros(2, dtype=torch.int32, device=self.flat.params.device) if self._guard else None
+        self._ovf_ring = None
+        self._backoff = 1.0                          # power of two <= 1 applied on top of the dpred-tracking scale
+        self._clean_steps = 0
+        self.overflow_steps = 0                      # optimizer steps in which non-finite gradients were seen (and skipped)
         # weight / bias gradients are off the critical path (only the optimizer needs them): they run on a second
         # HIP stream next to the dX chain, which by itself launches too few workgroups to fill 256 CUs
         self._side = ((_masked_stream(self.flat.params.device, int(os.environ.get("PFPP_SIDE_CU_FRACTION_PCT", "0")), from_top=True) or
@@ -910,7 +920,8 @@ class DenoiserTrainEngine:
     def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay, zero_grad: bool = False) -> None:
         f = self.flat
         T.adamw(f.params[a:b], f.grads[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], lr=lr, beta1=betas[0], beta2=betas[1], eps=eps,
-                weight_decay=weight_decay, step=step, hi=f.hi[a:b], lo=f.lo[a:b], g_scale=g_scale, zero_grad=zero_grad)
+                weight_decay=weight_decay, step=step, hi=f.hi[a:b], lo=f.lo[a:b], g_scale=g_scale, zero_grad=zero_grad,
+                overflow=self._overflow)
 
     def optimizer_step(self, *, lr: float = 2e-4, betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6,
                        zero_grad: bool = False) -> None:
@@ -925,20 +936,7 @@ class DenoiserTrainEngine:
         hp = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         early, self._early = self._early, []
         armed, self._armed = self._armed, None
-        segs = self._exchange.take_segments() if self._exchange.zero1 else []
-        if segs:
-            # ZeRO-1: this rank updates its part of every reduce-scattered slice, then the ranks exchange the updated parameters
-            # and re-split them into the planes the GEMMs read (one 0.1 ms pass instead of gathering the planes too)
-            from . import planes as P
-
-            if early or sum(b - a for a, b, _ in segs) != f.params.numel():
-                raise RuntimeError("optimizer_step (ZeRO-1): the exchanged slices do not tile the parameter buffer")
-            for a, b, sharded in segs:
-                x, y = self._exchange.own_part(a, b) if sharded else (a, b)
-                self._adamw_range(x, y, step=self.step_count, g_scale=g_scale, **hp)
-            self._exchange.gather_params(f.params, segs)
-            P.split(f.params, 1.0, out=P.Planes(f.hi, f.lo))
-        elif early:
+        if early:
             if armed != hp:
                 raise RuntimeError("optimizer_step: hyper-parameters differ from the ones the backward was armed with")
             if zero_grad != self._armed_zero:
@@ -952,10 +950,39 @@ class DenoiserTrainEngine:
         else:
             self._adamw_range(0, f.params.numel(), step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
             f._clean = bool(zero_grad)
+        self._after_step_overflow()
         f.after_optimizer_step()
         cache = getattr(self.module, "_cache", None)
         if cache is not None:
             cache._key = None            # the eval-mode packing of the module is stale now
+
+    def _after_step_overflow(self) -> None:
+        """end of an optimizer step (main stream, every AdamW launch of the step queued): hand the step's overflow flag to the host
+        through pinned memory and clear it for the next step; the flag of the step before last is read here (its copy has long
+        finished: no stall) and drives the back-off of the gradient scale"""
+        if self._overflow is None:
+            return
+        if self._ovf_ring is None:
+            self._ovf_ring = [(torch.zeros(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+        host, ev = self._ovf_ring[self.step_count % 2]
+        if self.step_count > 2:
+            ev.synchronize()
+            if int(host[0]) != 0:
+                self.overflow_steps += 1
+                self._backoff = max(2.0 ** -24, self._backoff / 16.0)
+                self._clean_steps = 0
+                self._apply_backoff()
+            else:
+                self._clean_steps += 1
+                if self._clean_steps >= 200 and self._backoff < 1.0:
+                    self._backoff, self._clean_steps = self._backoff * 2.0, 0
+        host.copy_(self._overflow, non_blocking=True)
+        ev.record()
+        self._overflow.zero_()
+
+    def _apply_backoff(self) -> None:
+        if not self._dyn_gscale:                     # a pinned scale is lowered directly (the dynamic one is recomputed every backward)
+            self.grad_scale = max(1.0, self.grad_scale / 16.0)
 
     def _update_grad_scale(self, dpred: torch.Tensor) -> None:
         if self._amax_ring is None:
@@ -965,7 +992,7 @@ class DenoiserTrainEngine:
             ev.synchronize()                         # recorded two backward passes ago
             amax = float(host[0])
             if math.isfinite(amax) and amax > 0.0:
-                self.grad_scale = float(2.0 ** min(40, max(0, 3 - math.floor(math.log2(amax)))))
+                self.grad_scale = max(1.0, float(2.0 ** min(40, max(0, 3 - math.floor(math.log2(amax))))) * self._backoff)
         host.copy_(dpred.detach().abs().max().reshape(1), non_blocking=True)
         ev.record()
         self._n_backward += 1

@@ -370,15 +370,21 @@ def mse_loss(pred: torch.Tensor, target: torch.Tensor, sel_u8: torch.Tensor, gra
 
 def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, beta1: float, beta2: float,
           eps: float, weight_decay: float, step: int, hi: Optional[torch.Tensor] = None,
-          lo: Optional[torch.Tensor] = None, g_scale: float = 1.0, zero_grad: bool = False) -> None:
+          lo: Optional[torch.Tensor] = None, g_scale: float = 1.0, zero_grad: bool = False,
+          overflow: Optional[torch.Tensor] = None) -> None:
     """one fused AdamW step over flat buffers (torch.optim.AdamW arithmetic); refreshes the split planes; zero_grad: clears g in
-    the same pass"""
+    the same pass; overflow (int32 [2] on the device: flag, count): elements with a non-finite gradient are skipped and flagged,
+    a launch that finds the flag set updates nothing (pfpp_adamw_guarded)"""
+    if overflow is not None:
+        _chk(overflow, torch.int32, "overflow")
+        if overflow.numel() < 2:
+            raise ValueError("adamw: overflow must hold [flag, count]")
     for t_, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t_, _f32, nm)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    check(_lib.load().pfpp_adamw_zero(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), p.numel(), lr, beta1, beta2, eps,
-                                      weight_decay, bc1, bc2, g_scale, int(zero_grad), _stream()), "pfpp_adamw_zero")
+    check(_lib.load().pfpp_adamw_guarded(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), p.numel(), lr, beta1, beta2, eps,
+                                         weight_decay, bc1, bc2, g_scale, int(zero_grad), _ptr(overflow), _stream()), "pfpp_adamw_guarded")
 
 
 def bn_stats(x: torch.Tensor, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,

@@ -111,6 +111,12 @@ def test_plane_scale_and_prescaled_weight_planes():
         big = w.abs() >= w.abs().max() * 2.0 ** -16                      # elements within 16 octaves of the largest: full 22 bits
         assert ((back - w.double()).abs()[big] <= w.double().abs()[big] * 2.0 ** -21).all()
     assert plane_scale(torch.zeros(4, 8)) == 1.0 and PW(torch.zeros(4, 8)).scale == 1.0
+    # (near-)denormal tensors: the exponent is clamped, scale and 1 / scale stay finite fp32 numbers, the planes finite
+    tiny = torch.full((4, 8), 1e-42)
+    s = plane_scale(tiny)
+    assert s == 2.0 ** 100 and torch.isfinite(torch.tensor(s, dtype=torch.float32)) and float(torch.tensor(1.0 / s, dtype=torch.float32)) > 0
+    pw = PW(tiny)
+    assert torch.isfinite(pw.hi.float()).all() and torch.isfinite(pw.lo.float()).all()
     assert PW(torch.randn(4, 8, generator=g), prescale=False).scale == 1.0
 
 
@@ -317,7 +323,7 @@ def test_dataset_dropins_equal_the_reference_loaders(golden, tmp_path):
                     assert got.shape == want.shape, (mode, i, k)
                     assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1e-6, (mode, i, k)
                     checked += 1
-            assert all(key.split("_", 1)[1] in item or key.endswith(("corr_cat", "corr_len")) for key in g if key.startswith(f"{mode}{i}_"))
+            assert all(key.split("_", 1)[1] in item or key.endswith(("corr_cat", "corr_len", "drawn_quats_f64")) for key in g if key.startswith(f"{mode}{i}_"))
     vd = VerifierDataset(str(tmp_path / "verifier_data"), -1, "train")
     assert len(vd) == int(g["len_verifier"])
     for i in range(len(vd)):

@@ -1152,6 +1152,86 @@ def test_stress_shapes_beyond_reference_limits(dev):
     assert lo.shape == (1, E, 1) and torch.isfinite(lo[ev.bool()]).all()
 
 
+def test_fp16_mfma_joint_step_configs4_vs_f16x3(dev):
+    """BASELINE configs[4] in its fp16-MFMA mode (ops.SINGLE_PASS: one fp16 matrix instruction per product on the plane GEMMs):
+    the joint step at the stress shape — 2 puzzles x 100 fragments x 2048 points: rotate -> PointNet++/VQ encode -> DenoiserTransformer
+    -> scheduler step -> edge features of the stepped poses (pose_apply_points + per-edge matched-point histograms, auto_aggl.py:153-201)
+    -> VerifierTransformer on all 4,950 candidate edges — against the same step in the parity arithmetic (f16x3) on the same inputs.
+    No reference parity exists at this shape (max_len 100 != 20); the perf mode is bounded against the parity mode instead:
+    |d pred_noise| <= 2e-4 (bench.py reports 9.4e-5 at max |pred| 0.26), stepped poses likewise, finite verifier logits."""
+    from pfpp_hip import config, ops, synthetic
+    from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative, normalise_edge_hist
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+    from puzzlefusion_plusplus.verifier.model.modules.verifier_transformer import VerifierTransformer
+
+    torch.manual_seed(1234)
+    B, P, N = 2, 100, 2048
+    model = Denoiser(config.denoiser_config(model=dict(max_len=P))).to(dev).eval()
+    ver = VerifierTransformer(config.verifier_config(model=dict(max_len=P))).to(dev).eval()
+    with torch.no_grad():
+        model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(7000, B, num_points=N, max_parts=P, num_parts=P).items()}
+    match = []
+    for b in range(B):
+        one = {k: v[b:b + 1] for k, v in data.items()}
+        md = synthetic.make_matching(one, seed=b)
+        match.append((md, AutoAgglomerative.prepare_matching(md, dev)))
+    gt = torch.cat([data["part_trans"], data["part_rots"]], dim=-1).float()
+    ref = data["ref_part"]
+    reference = torch.zeros_like(gt)
+    reference[ref] = gt[ref]
+    g = torch.Generator(device=dev).manual_seed(5)
+    x0 = torch.randn(gt.shape, device=dev, generator=g)
+    x0[ref] = reference[ref]
+    noise = torch.randn(gt.shape, device=dev, generator=g)
+    t = int(model.noise_scheduler.timesteps[0])
+    ts = torch.full((B,), t, dtype=torch.int64, device=dev)
+    E = P * (P - 1) // 2
+    edge_idx = AutoAgglomerative._edge_pairs(P, dev)[None].expand(B, E, 2).contiguous()
+    edge_valid = torch.ones(B, E, device=dev)
+    pivot = torch.arange(P, dtype=torch.int32, device=dev)
+
+    @torch.no_grad()
+    def joint_step():
+        latent, xyz = model._extract_features(data["part_pcs"], data["part_valids"], x0)
+        eps = model.denoiser(x0, ts, latent, xyz, data["part_valids"], data["part_scale"], ref)
+        x1 = model.noise_scheduler.step(eps, t, x0, variance_noise=noise, ref_part=ref, reference=reference).prev_sample
+        ef = torch.zeros(B, E, 6, dtype=torch.int32, device=dev)
+        for b, (md, mt) in enumerate(match):
+            pts_t = ops.pose_apply_points(md["part_pcs_by_area"][0].float().contiguous(), pivot[mt["point_part"].long()].contiguous(),
+                                          x1[b].contiguous(), normalise=False)
+            ef[b, mt["pair_pos"]] = ops.edge_histogram(pts_t, mt["idx_a"], mt["idx_b"], mt["edge_off"], mt["max_m"])
+        feats = normalise_edge_hist(ef)
+        return eps, x1, feats, ver(feats, edge_idx, edge_valid), latent
+
+    prev = ops.SINGLE_PASS
+    try:
+        ops.SINGLE_PASS = False
+        eps_r, x1_r, ef_r, lg_r, lat_r = joint_step()
+        ops.SINGLE_PASS = True
+        eps_f, x1_f, ef_f, lg_f, lat_f = joint_step()
+        lg_same = ver(ef_r, edge_idx, edge_valid)            # the verifier alone in fp16 mode on the parity run's features
+    finally:
+        ops.SINGLE_PASS = prev
+    torch.cuda.synchronize()
+    assert eps_f.shape == (B, P, 7) and lg_f.shape == (B, E, 1)
+    for a in (eps_r, eps_f, x1_f, lg_r, lg_f, lg_same):
+        assert torch.isfinite(a).all()
+    d_eps = float((eps_f - eps_r).abs().max())
+    d_x = float((x1_f - x1_r).abs().max())
+    d_lg = float((lg_same - lg_r).abs().max())
+    print(f"fp16-MFMA joint step vs f16x3: |d pred_noise| {d_eps:.2e} (max |pred| {float(eps_r.abs().max()):.3f}), |d x'| {d_x:.2e}, "
+          f"|d logit| same features {d_lg:.2e} (max |logit| {float(lg_r.abs().max()):.3f}), matched points {int(ef_r[..., 6].sum())}")
+    assert float(eps_r.abs().max()) > 0.05                 # a non-trivial prediction
+    assert d_eps <= 2e-4 and d_x <= 2e-4
+    # the encoder's first layers do not run on planes: VQ codes may flip only at near-ties
+    assert float((lat_f != lat_r).float().mean()) < 1e-3
+    # matched-point counts do not depend on the pose; the bins may move for points within 2e-4 of a bin edge
+    assert torch.equal(ef_f[..., 6], ef_r[..., 6]) and int(ef_r[..., 6].sum()) > 10000
+    assert float(((ef_f[..., :6] - ef_r[..., :6]).abs() * ef_r[..., 6:]).sum()) <= 0.002 * float(ef_r[..., 6].sum())
+    assert d_lg <= 5e-3 * max(1.0, float(lg_r.abs().max()))
+
+
 def test_auto_aggl_batched_equals_single(weights_sd, dev):
     """throughput mode: several puzzles through the loop at once give each puzzle the result of its own test_step"""
     from pfpp_hip import config, synthetic
@@ -1281,3 +1361,26 @@ def test_sa_mlp2_fused_equals_layerwise(dev, F, N, S):
     y = torch.relu(y @ w0_ref.double().t() * sc[0].double() + sh[0].double())
     y = torch.relu(y @ w1.double().t() * sc[1].double() + sh[1].double())
     assert (got.double().cpu() - y).abs().max().item() < 2e-5 * y.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_fragment_prepare_vs_reference_dataset_golden(golden, dev):
+    """8f-4: the GPU augmentation kernel against what the reference's GeometryLatentDataset.__getitem__ itself returned
+    (tests/golden/dataset.npz; denoiser/dataset/dataset.py:163-222) on the rotations it drew.  The kernel takes fp32 quaternions (the
+    reference's stored part_rots / init_pose_r are fp32 / fp64), hence 2e-6 instead of the oracle's 5e-7 on unit-scale coordinates."""
+    from pfpp_hip import augment
+    from test_oracle_golden import _augmentation_cases
+
+    n = 0
+    for gt, num, ref, qg, qp, want in _augmentation_cases(golden("dataset")):
+        pcs, trans, scale, init_t = augment.fragment_prepare(
+            torch.as_tensor(gt).to(dev), torch.as_tensor(num, dtype=torch.int32).to(dev), torch.as_tensor(ref, dtype=torch.int32).to(dev),
+            torch.as_tensor(qg, dtype=torch.float32).to(dev), torch.as_tensor(qp, dtype=torch.float32).to(dev).contiguous())
+        pv = int(num[0])
+        assert np.abs(pcs[0].cpu().numpy() - want["part_pcs"]).max() < 2e-6
+        assert np.abs(trans[0].cpu().numpy() - want["part_trans"]).max() < 1e-6
+        assert np.abs(scale[0, :pv].cpu().numpy() - want["part_scale"][:pv]).max() < 1e-6
+        assert np.abs(init_t[0].cpu().numpy().astype(np.float64) - want["init_pose_t"]).max() < 1e-6
+        assert float(pcs[0, pv:].abs().max()) == 0 if pv < pcs.shape[1] else True
+        n += 1
+    assert n == 4

@@ -143,3 +143,32 @@ def test_aggl_glue_oracle_vs_reference_golden(golden):
     assert np.abs(init.numpy() - g["init_pose"]).max() == 0
     comp = O.pose_compose(T(g["param"]), g["pivots"].tolist(), init.reshape(P, 16), T(g["has_init"]))
     assert np.abs(comp.numpy() - g["composed"]).max() < 1e-6
+
+
+def _augmentation_cases(g):
+    """(inputs, recorded rotations, reference outputs) per item of the dataset fixture (tests/golden/dataset.npz: what the
+    reference's GeometryLatentDataset.__getitem__ returned, with the scipy rotations it drew recorded in float64)"""
+    for mode in ("test", "train"):
+        for i in range(int(g[f"len_{mode}"])):
+            k = f"{mode}{i}_"
+            q = g[k + "drawn_quats_f64"]
+            P = g[k + "part_pcs_gt"].shape[0]
+            qp = np.zeros((1, P, 4)); qp[0, :, 0] = 1.0; qp[0, :len(q) - 1] = q[1:]
+            yield (g[k + "part_pcs_gt"][None], np.array([int(g[k + "num_parts"])]), np.array([int(np.argmax(g[k + "ref_part"]))]), q[:1], qp,
+                   {n: g[k + n] for n in ("part_pcs", "part_trans", "part_scale", "init_pose_t", "part_rots", "init_pose_r")})
+
+
+def test_fragment_prepare_oracle_vs_reference_dataset_golden(golden):
+    """8f-4 pin: oracle.fragment_prepare against the outputs of the reference's own __getitem__ (denoiser/dataset/dataset.py:163-222:
+    _rotate_whole_part, _recenter_ref, _recenter_pc, _rotate_pc, max-abs scale) on the rotations it drew"""
+    n = 0
+    for gt, num, ref, qg, qp, want in _augmentation_cases(golden("dataset")):
+        pcs, trans, scale, init_t = O.fragment_prepare(gt, num, ref, qg, qp)
+        pv = int(num[0])
+        assert np.abs(pcs[0] - want["part_pcs"]).max() < 5e-7
+        assert np.abs(trans[0] - want["part_trans"]).max() < 5e-7
+        assert np.abs(scale[0][:pv] - want["part_scale"][:pv]).max() < 5e-7
+        assert np.abs(init_t[0].astype(np.float64) - want["init_pose_t"]).max() < 5e-7
+        assert np.array_equal(want["part_rots"][:pv], qp[0, :pv].astype(np.float32)) and np.array_equal(want["init_pose_r"], qg[0])
+        n += 1
+    assert n == 4

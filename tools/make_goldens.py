@@ -616,12 +616,44 @@ def main():
         subprocess.run([sys.executable, str(ROOT / "tools" / "make_synthetic_dataset.py"), td, "--n", "3", "--points", "64"], check=True)
         dcfg = NS(data=NS(max_num_part=20, matching_data_path=td + "/matching_data"), model=NS(multiple_ref_parts=False))
         fx = {}
+        # the rotations __getitem__ draws (dataset.py:126, 140: scipy Rotation.random(), first the whole-assembly one, then one per
+        # fragment) are recorded in float64 as the quaternions the reference derives from them (dataset.py:128-130, 142-144) —
+        # the pin of oracle.fragment_prepare and, through it, of the GPU augmentation kernel
+        import puzzlefusion_plusplus.denoiser.dataset.dataset as ref_ds_mod
+        from scipy.spatial.transform import Rotation as SciR
+        drawn = []
+
+        class RecordingR:
+            from_quat = staticmethod(SciR.from_quat)
+            from_matrix = staticmethod(SciR.from_matrix)
+
+            @staticmethod
+            def random(*a, **k):
+                r = SciR.random(*a, **k)
+                drawn.append(SciR.from_matrix(r.as_matrix().T).as_quat()[[3, 0, 1, 2]])
+                return r
+
+        ref_ds_mod.R = RecordingR
         for mode in ("test", "train"):
             ref_ds = RefDS(dcfg, td + "/pc_data/train", -1, mode)
             fx[f"len_{mode}"] = np.int64(len(ref_ds))
             for i in range(len(ref_ds)):
                 np.random.seed(100 + i)
+                drawn.clear()
                 item = ref_ds[i]
+                assert len(drawn) == 1 + int(item["num_parts"])
+                fx[f"{mode}{i}_drawn_quats_f64"] = np.stack(drawn)          # [1 + num_parts, 4], scalar first
+                P_ = item["part_pcs_gt"].shape[0]
+                qp = np.zeros((1, P_, 4)); qp[0, :, 0] = 1.0; qp[0, :len(drawn) - 1] = np.stack(drawn[1:])
+                got = O.fragment_prepare(item["part_pcs_gt"][None], np.array([item["num_parts"]]), np.array([int(np.argmax(item["ref_part"]))]),
+                                         np.stack(drawn[:1]), qp)
+                pv_ = int(item["num_parts"])
+                for name, g_, w_ in (("part_pcs", got[0][0], item["part_pcs"]), ("part_trans", got[1][0], item["part_trans"]),
+                                   ("part_scale", got[2][0][:pv_], item["part_scale"][:pv_]), ("init_pose_t", got[3][0], item["init_pose_t"])):
+                    dd = float(np.abs(np.asarray(g_, np.float64) - np.asarray(w_, np.float64)).max())
+                    assert dd < 5e-7, (mode, i, name, dd)
+                assert np.abs(item["part_rots"][:pv_] - np.stack(drawn[1:]).astype(np.float32)).max() == 0
+                assert np.abs(item["init_pose_r"] - drawn[0]).max() == 0
                 for k, v in item.items():
                     if k == "correspondences":
                         fx[f"{mode}{i}_corr_cat"] = np.concatenate([np.asarray(c).reshape(-1, 2) for c in v]) if len(v) else np.zeros((0, 2), np.int64)
@@ -635,6 +667,8 @@ def main():
         for i in range(len(rv)):
             for k, val in rv[i].items():
                 fx[f"v{i}_{k}"] = np.asarray(val)
+        ref_ds_mod.R = SciR
+        print("[datasets] oracle.fragment_prepare == the reference's __getitem__ augmentation (dataset.py:163-222) on the recorded rotations (< 5e-7)")
         np.savez_compressed(GOLD / "dataset.npz", **fx)
         print(f"[datasets] fixture: {len(fx)} arrays from the reference's GeometryLatentDataset (test + train mode) and VerifierDataset")
 
