@@ -311,6 +311,39 @@ int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_
                          const pfpp_planes* out_planes, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1,
                          int64_t C2, pfpp_stream_t stream);
 
+/* ---- a5 in TRAIN mode (the frozen encoder stays in .train(): train_denoiser.py:33-35, utils/pn2_utils.py:203-216 with
+ * BatchNorm2d on BATCH statistics) without writing the layers' activations: one launch per layer ("stage") of the chain.
+ * Stage k recomputes the chain from the level's input (grouping by ball-query index included, pn2_utils.py:127-151) through
+ * layers 1..k-1 — normalised with their already finalised statistics: relu(fma(conv + bias, a_mul, a_add)), the (a_mul, a_add)
+ * of pfpp_bn_finalize — and accumulates sum(y_k), sum(y_k^2) of the raw layer-k output y_k = conv + bias into `stats`
+ * ([stats_copies][2][C_k] doubles, the buffer pfpp_bn_finalize reads and clears).
+ *   feats == NULL (sa1, pn2.py:16): ns == 32, (C1, C2, C3) == (64, 64, 128), stages 1..3; stage 3 also writes the
+ *     per-neighbourhood max and min of y_3 (out_max, out_min [F*S, C3]; then pfpp_bn_minmax_apply).
+ *   feats != NULL (sa2, pn2.py:17): ns == 64, D == C1 == C2 == 128, stages 1..2; stage 2 also writes the raw rows y_2
+ *     (y_out [F*S*ns, C2]) — the A operand of the third convolution's GEMM (pfpp_gemm with a_mul / a_add / stats / pool).
+ * Weight planes as for pfpp_sa_mlp3_fused / pfpp_sa_mlp2_fused (raw conv weights, BatchNorm NOT folded).
+ * max_workgroups: persistent grid size (0 = 256, one workgroup per CU; pass the CU count of a CU-masked stream). */
+typedef struct pfpp_sa_train_args {
+  const float* xyz;            /* [F, N, 3] */
+  const float* new_xyz;        /* [F, S, 3] */
+  const float* feats;          /* [F, N, D] or NULL */
+  const int32_t* idx;          /* [F, S, ns] */
+  const void* w_hi[3];         /* fp16 planes of the conv weights, layers 1..3 (those beyond `stage` may be NULL) */
+  const void* w_lo[3];
+  const float* bias[3];        /* conv biases */
+  const float* a_mul[2];       /* finalised BatchNorm affine of layers 1, 2 (needed for layers < stage) */
+  const float* a_add[2];
+  double* stats;               /* [stats_copies][2][C_stage] */
+  int64_t stats_copies;
+  float* y_out;                /* feats != NULL, stage 2 */
+  float* out_max;              /* feats == NULL, stage 3 */
+  float* out_min;
+  int64_t F, N, S, ns, D, C1, C2, C3;
+  int32_t stage;
+  int64_t max_workgroups;
+} pfpp_sa_train_args;
+int pfpp_sa_train_stage(const pfpp_sa_train_args* args, pfpp_stream_t stream);
+
 /* ---- a7/a8: vector quantisation + scatter ----------------------------------
  * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by
  * VQVAE.encode (denoiser/model/modules/encoder.py:20-38): for every

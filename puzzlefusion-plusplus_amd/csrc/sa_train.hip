@@ -1,0 +1,552 @@
+// Train-mode set abstraction WITHOUT the HBM round trips of its activations (a5 under train_denoiser.py:33-35: the frozen encoder
+// stays in .train(), so utils/pn2_utils.py:203-216 runs conv -> BatchNorm(BATCH statistics) -> ReLU x3 -> max over nsample).
+//
+// Batch statistics put a global barrier between the layers: layer k's normalisation needs sum(y_k), sum(y_k^2) over ALL rows
+// (1.26 M at the benchmark shape).  The layer-wise form therefore writes every layer's [rows, C] fp32 pre-activation and reads
+// it back (sa1: 1.3 GB, sa2: 2.6 GB per encoder pass).  Here a level is a sequence of STAGES of the persistent chain kernels of
+// sa_fused.hip; stage k recomputes the chain from the level's input through the already finalised layers 1..k-1 (registers
+// only, as in eval mode) and runs layer k in the GEMM's orientation (samples x channels: a lane owns one channel), where the
+// column sums are in-lane additions:
+//   sa1 (no input features, 3 -> 64 -> 64 -> 128, nsample 32): stage 1 / 2 write NOTHING but the sums; stage 3 writes the sums and
+//       the per-neighbourhood max and min of y_3 (max_p relu(a y_p + b) = relu(a (a >= 0 ? max y : min y) + b)): 42.8 GFLOP
+//       instead of 31.5, no activation traffic at all;
+//   sa2 (128 features + 3 -> 128 -> 128 -> 256, nsample 64): stage 1 = gather + layer 1 -> sums; stage 2 = gather + layer 1
+//       + BN/ReLU + layer 2 -> sums + the raw y_2 rows (layer 3's weights do not fit next to the others in LDS: it stays the
+//       fp32-A plane GEMM with the normalisation applied while it stages its A tiles): y_1 is never written or read.
+// Arithmetic per layer = the layer-wise path's: split-f16 contraction (lo.hi, hi.lo, hi.hi per 16-deep step), y = acc + bias,
+// activation relu(fma(y, a_mul, a_add)); sums of 16 / 32 values in fp32, then fp64 per lane, fp64 atomics into the
+// [copies][2][C] buffer pfpp_bn_finalize reads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pfpp.h"
+#include "pfpp_common.h"
+#include "sa_common.h"
+
+namespace {
+
+struct SaTP {
+  const float* xyz; const float* ctr; const float* feats; const int32_t* idx;
+  const _Float16* wh[3]; const _Float16* wl[3];
+  const float* bias[3];
+  const float* am[2]; const float* aa[2];
+  double* stats; int copies;
+  float* y_out; float* out_max; float* out_min;
+  int N, S, G;
+};
+
+// train-mode BatchNorm + ReLU of a transposed tile (lane = sample): channel of register e is c0 + (e&3) + 8*(e>>2) + 4*lhi;
+// y = acc + bias (the stored pre-activation of the layer-wise path), then relu(fma(y, a_mul, a_add))
+__device__ __forceinline__ f32x16 bn_train_relu_t(const f32x16 acc, const float* B, const float* M, const float* A, int c0, int lhi) {
+  f32x16 y;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = *reinterpret_cast<const float4*>(B + c0 + 8 * q + 4 * lhi);
+    const float4 m4 = *reinterpret_cast<const float4*>(M + c0 + 8 * q + 4 * lhi);
+    const float4 a4 = *reinterpret_cast<const float4*>(A + c0 + 8 * q + 4 * lhi);
+    const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = __builtin_fmaf(acc[4 * q + r] + bv[r], mv[r], av[r]);
+      y[4 * q + r] = v > 0.0f ? v : 0.0f;
+    }
+  }
+  return y;
+}
+
+__device__ __forceinline__ void flush_stats(double* stats, int copies, int C, int c, int lhi, double s, double q) {
+  const double a = s + __shfl_xor(s, 32), b = q + __shfl_xor(q, 32);
+  if (lhi == 0) {
+    double* st = stats + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % copies) * 2 * C;
+    unsafeAtomicAdd(st + c, a);
+    unsafeAtomicAdd(st + C + c, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// level without input features (sa1): STAGE = index of the layer whose batch statistics this launch produces
+template <int C1, int C2, int C3, int STAGE>
+__global__ __launch_bounds__(256, 1) void sa1_train_kernel(const SaTP p) {
+  constexpr int CS = STAGE == 1 ? C1 : (STAGE == 2 ? C2 : C3);
+  constexpr int NT1 = C1 / 32, NT2 = STAGE >= 2 ? C2 / 32 : 1, NT3 = STAGE >= 3 ? C3 / 32 : 1;
+  __shared__ __align__(16) float B0[C1], M0[C1], A0[C1], B1[C2], M1[C2], A1[C2];
+  // stage 3 holds every weight fragment in registers (208) and has none left for the fp64 running sums: they live in LDS, one
+  // private slot per lane (no conflicts: consecutive lanes, consecutive 8-byte words)
+  constexpr bool LDS_SUMS = STAGE == 3;
+  __shared__ double SUMS[LDS_SUMS ? 2 * (CS / 32) : 1][LDS_SUMS ? 256 : 1];
+  const int tid = threadIdx.x;
+  if (LDS_SUMS)
+    for (int i = 0; i < 2 * (CS / 32); ++i) SUMS[i][tid] = 0.0;
+  if (STAGE >= 2)
+    for (int i = tid; i < C1; i += 256) { B0[i] = p.bias[0][i]; M0[i] = p.am[0][i]; A0[i] = p.aa[0][i]; }
+  if (STAGE >= 3)
+    for (int i = tid; i < C2; i += 256) { B1[i] = p.bias[1][i]; M1[i] = p.am[1][i]; A1[i] = p.aa[1][i]; }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  half8 w0h[NT1], w0l[NT1];
+  half8 w1h[NT2][C1 / 16], w1l[NT2][C1 / 16];
+  half8 w2h[NT3][C2 / 16], w2l[NT3][C2 / 16];
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { w0h[t][q] = (_Float16)0.0f; w0l[t][q] = (_Float16)0.0f; }
+    if (lhi == 0) {      // K = 3 (+ a zero) of 16: only the first 8-half group is populated
+      w0h[t] = *reinterpret_cast<const half8*>(p.wh[0] + (t * 32 + l31) * 8);
+      w0l[t] = *reinterpret_cast<const half8*>(p.wl[0] + (t * 32 + l31) * 8);
+    }
+  }
+  if (STAGE >= 2) {
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < C1 / 16; ++ks) {
+        w1h[t][ks] = *reinterpret_cast<const half8*>(p.wh[1] + (t * 32 + l31) * C1 + ks * 16 + lhi * 8);
+        w1l[t][ks] = *reinterpret_cast<const half8*>(p.wl[1] + (t * 32 + l31) * C1 + ks * 16 + lhi * 8);
+      }
+  }
+  if (STAGE >= 3) {
+#pragma unroll
+    for (int n = 0; n < NT3; ++n)
+#pragma unroll
+      for (int ks = 0; ks < C2 / 16; ++ks) {
+        w2h[n][ks] = *reinterpret_cast<const half8*>(p.wh[2] + (n * 32 + l31) * C2 + ks * 16 + lhi * 8);
+        w2l[n][ks] = *reinterpret_cast<const half8*>(p.wl[2] + (n * 32 + l31) * C2 + ks * 16 + lhi * 8);
+      }
+  }
+  float bs[CS / 32];
+  double ss[CS / 32], sq[CS / 32];
+#pragma unroll
+  for (int n = 0; n < CS / 32; ++n) { bs[n] = p.bias[STAGE - 1][n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+
+  // the statistics layer, GEMM orientation: lane = channel n*32 + l31, register e = sample (e&3) + 8*(e>>2) + 4*lhi
+  auto stat = [&](const f32x16& acc, int n, int g) {
+    float s = 0.0f, q = 0.0f, mx = -__builtin_huge_valf(), mn = __builtin_huge_valf();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float y = acc[e] + bs[n];
+      s += y;
+      q = __builtin_fmaf(y, y, q);
+      if (STAGE == 3) { mx = fmaxf(mx, y); mn = fminf(mn, y); }
+    }
+    if (LDS_SUMS) {
+      SUMS[2 * n][tid] += (double)s;
+      SUMS[2 * n + 1][tid] += (double)q;
+    } else {
+      ss[n] += (double)s;
+      sq[n] += (double)q;
+    }
+    if (STAGE == 3) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mn = fminf(mn, __shfl_xor(mn, 32));
+      if (lhi == 0) {
+        p.out_max[(int64_t)g * C3 + n * 32 + l31] = mx;
+        p.out_min[(int64_t)g * C3 + n * 32 + l31] = mn;
+      }
+    }
+  };
+
+  const int stride = gridDim.x * 4;
+  const int g0 = blockIdx.x * 4 + wave;
+  auto load_id = [&](int g) {
+    const int gc = g < p.G ? g : p.G - 1;
+    const int id = p.idx[(int64_t)gc * 32 + l31];
+    return id < p.N ? id : p.N - 1;                   // memory safety only, as in group_gather_kernel
+  };
+  auto load_pt = [&](int g, int id, float (&q)[3], float (&c)[3]) {
+    const int gc = g < p.G ? g : p.G - 1;
+    const int f = gc / p.S;
+    const float* q3 = p.xyz + ((int64_t)f * p.N + id) * 3;
+    const float* c3 = p.ctr + (int64_t)gc * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { q[d] = q3[d]; c[d] = c3[d]; }
+  };
+  float q_cur[3], c_cur[3], q_nxt[3], c_nxt[3];
+  int id_nxt;
+  load_pt(g0, load_id(g0), q_cur, c_cur);
+  id_nxt = load_id(g0 + stride);
+
+  for (int g = g0; g < p.G; g += stride) {
+    load_pt(g + stride, id_nxt, q_nxt, c_nxt);
+    id_nxt = load_id(g + 2 * stride);
+
+    half8 xh, xl;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { xh[q] = (_Float16)0.0f; xl[q] = (_Float16)0.0f; }
+    if (lhi == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        _Float16 a, b;
+        split1(__fsub_rn(q_cur[d], c_cur[d]), a, b);
+        xh[d] = a; xl[d] = b;
+      }
+    }
+
+    if (STAGE == 1) {
+#pragma unroll
+      for (int n = 0; n < NT1; ++n) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, w0h[n], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, w0l[n], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, w0h[n], acc, 0, 0, 0);
+        stat(acc, n, g);
+      }
+    } else {
+      // ---- layer 1 (transposed, normalised with its finalised statistics) -> operand fragments ----
+      half8 f1h[C1 / 16], f1l[C1 / 16];
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[t], xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l[t], xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[t], xh, acc, 0, 0, 0);
+        const f32x16 y = bn_train_relu_t(acc, B0, M0, A0, t * 32, lhi);
+        half8 fh[2], fl[2];
+        tile_to_fragments(y, lhi, fh, fl);
+        f1h[2 * t] = fh[0]; f1h[2 * t + 1] = fh[1];
+        f1l[2 * t] = fl[0]; f1l[2 * t + 1] = fl[1];
+      }
+      if (STAGE == 2) {
+#pragma unroll
+        for (int n = 0; n < NT2; ++n) {
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < C1 / 16; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1l[ks], w1h[n][ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1h[ks], w1l[n][ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1h[ks], w1h[n][ks], acc, 0, 0, 0);
+          }
+          stat(acc, n, g);
+        }
+      } else {
+        // scheduling fence: without it the compiler overlaps the layers' accumulators and spills 41 of the 512 registers
+        asm volatile("" ::: "memory");
+        half8 f2h[C2 / 16], f2l[C2 / 16];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < C1 / 16; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[t][ks], f1l[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[t][ks], f1h[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[t][ks], f1h[ks], acc, 0, 0, 0);
+          }
+          const f32x16 y = bn_train_relu_t(acc, B1, M1, A1, t * 32, lhi);
+          half8 fh[2], fl[2];
+          tile_to_fragments(y, lhi, fh, fl);
+          f2h[2 * t] = fh[0]; f2h[2 * t + 1] = fh[1];
+          f2l[2 * t] = fl[0]; f2l[2 * t + 1] = fl[1];
+        }
+#pragma unroll
+        for (int n = 0; n < NT3; ++n) {
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < C2 / 16; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2l[ks], w2h[n][ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2h[ks], w2l[n][ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2h[ks], w2h[n][ks], acc, 0, 0, 0);
+          }
+          stat(acc, n, g);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { q_cur[d] = q_nxt[d]; c_cur[d] = c_nxt[d]; }
+  }
+#pragma unroll
+  for (int n = 0; n < CS / 32; ++n)
+    flush_stats(p.stats, p.copies, CS, n * 32 + l31, lhi, LDS_SUMS ? SUMS[LDS_SUMS ? 2 * n : 0][LDS_SUMS ? tid : 0] : ss[n],
+                LDS_SUMS ? SUMS[LDS_SUMS ? 2 * n + 1 : 0][LDS_SUMS ? tid : 0] : sq[n]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// level with D input features (sa2), nsample 64.  STAGE 1: gather + layer 1 -> sums.  STAGE 2: gather + layer 1 + BN/ReLU +
+// layer 2 -> sums + raw y_2 rows [G*64, C2].
+template <int D, int C1, int C2, int STAGE>
+__global__ __launch_bounds__(256, 1) void sa2_train_kernel(const SaTP p) {
+  constexpr int KS0 = D / 16 + 1;
+  constexpr int KP0 = D + 8;
+  constexpr int LD0 = KS0 * 16 + 8, LD1 = C1 + 8;
+  constexpr int CS = STAGE == 1 ? C1 : C2;
+  extern __shared__ __align__(16) unsigned char sa2t_smem[];
+  _Float16* W0h = reinterpret_cast<_Float16*>(sa2t_smem);
+  _Float16* W0l = W0h + C1 * LD0;
+  _Float16* W1h = W0l + C1 * LD0;
+  _Float16* W1l = W1h + C2 * LD1;
+  float* B0 = reinterpret_cast<float*>(W1l + C2 * LD1);
+  float* M0 = B0 + C1;
+  float* A0 = M0 + C1;
+
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C1 * (LD0 / 8); i += 256) {
+    const int r = i / (LD0 / 8), c8 = i - r * (LD0 / 8);
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+    if (c8 * 8 < KP0) {
+      vh = *reinterpret_cast<const uint4*>(p.wh[0] + (size_t)r * KP0 + c8 * 8);
+      vl = *reinterpret_cast<const uint4*>(p.wl[0] + (size_t)r * KP0 + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(W0h + r * LD0 + c8 * 8) = vh;
+    *reinterpret_cast<uint4*>(W0l + r * LD0 + c8 * 8) = vl;
+  }
+  if (STAGE == 2) {
+    for (int i = tid; i < C2 * (C1 / 8); i += 256) {
+      const int r = i / (C1 / 8), c8 = i - r * (C1 / 8);
+      *reinterpret_cast<uint4*>(W1h + r * LD1 + c8 * 8) = *reinterpret_cast<const uint4*>(p.wh[1] + (size_t)r * C1 + c8 * 8);
+      *reinterpret_cast<uint4*>(W1l + r * LD1 + c8 * 8) = *reinterpret_cast<const uint4*>(p.wl[1] + (size_t)r * C1 + c8 * 8);
+    }
+    for (int i = tid; i < C1; i += 256) { B0[i] = p.bias[0][i]; M0[i] = p.am[0][i]; A0[i] = p.aa[0][i]; }
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  float bs[CS / 32];
+  double ss[CS / 32], sq[CS / 32];
+#pragma unroll
+  for (int n = 0; n < CS / 32; ++n) { bs[n] = p.bias[STAGE - 1][n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+
+  auto split8 = [&](const float4 a, const float4 b, half8& hi, half8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      _Float16 h, l;
+      split1(x[q], h, l);
+      hi[q] = h; lo[q] = l;
+    }
+  };
+
+  const int stride = gridDim.x * 4;
+  const int g0 = blockIdx.x * 4 + wave;
+  auto load_ids = [&](int g, int (&id)[2]) {
+    const int gc = g < p.G ? g : p.G - 1;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int v = p.idx[(int64_t)gc * 64 + st * 32 + l31];
+      id[st] = v < p.N ? v : p.N - 1;
+    }
+  };
+  auto load_rows = [&](int g, const int (&id)[2], float4 (&raw)[2][D / 16][2], float (&q)[2][3], float (&c)[3]) {
+    const int gc = g < p.G ? g : p.G - 1;
+    const int f = gc / p.S;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const float* row = p.feats + ((int64_t)f * p.N + id[st]) * D + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        raw[st][ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[st][ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+      const float* q3 = p.xyz + ((int64_t)f * p.N + id[st]) * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) q[st][d] = q3[d];
+    }
+    const float* c3 = p.ctr + (int64_t)gc * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = c3[d];
+  };
+
+  float4 raw[2][D / 16][2];
+  float qx[2][3], cx[3];
+  int id_nxt[2];
+  {
+    int id0[2];
+    load_ids(g0, id0);
+    load_rows(g0, id0, raw, qx, cx);
+    load_ids(g0 + stride, id_nxt);
+  }
+
+  for (int g = g0; g < p.G; g += stride) {
+    asm volatile("" ::: "memory");      // keeps the loop-invariant LDS weight reads inside the loop (sa_fused.hip)
+    // ---- layer 1: STAGE 1 in the GEMM's orientation (lane = channel: in-lane sums), STAGE 2 transposed (lane = sample) ----
+    f32x16 acc[C1 / 32][2];
+#pragma unroll
+    for (int t = 0; t < C1 / 32; ++t)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][st][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS0; ++ks) {
+      half8 xh[2], xl[2];
+      if (ks < D / 16) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) split8(raw[st][ks < D / 16 ? ks : 0][0], raw[st][ks < D / 16 ? ks : 0][1], xh[st], xl[st]);
+      } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { xh[st][q] = (_Float16)0.0f; xl[st][q] = (_Float16)0.0f; }
+          if (lhi == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              _Float16 a, b;
+              split1(__fsub_rn(qx[st][d], cx[d]), a, b);
+              xh[st][d] = a; xl[st][d] = b;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < C1 / 32; ++t) {
+        const half8 wh = *reinterpret_cast<const half8*>(W0h + (t * 32 + l31) * LD0 + ks * 16 + lhi * 8);
+        const half8 wl = *reinterpret_cast<const half8*>(W0l + (t * 32 + l31) * LD0 + ks * 16 + lhi * 8);
+        if (STAGE == 1) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[st], wh, acc[t][st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[st], wl, acc[t][st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[st], wh, acc[t][st], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[st], acc[t][st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[st], acc[t][st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) acc[t][st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[st], acc[t][st], 0, 0, 0);
+        }
+      }
+    }
+    // the feature rows are consumed: fetch the next neighbourhood's
+    {
+      int id_cur[2] = {id_nxt[0], id_nxt[1]};
+      load_rows(g + stride, id_cur, raw, qx, cx);
+      load_ids(g + 2 * stride, id_nxt);
+    }
+    if (STAGE == 1) {
+#pragma unroll
+      for (int n = 0; n < C1 / 32; ++n) {
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float y = acc[n][st][e] + bs[n];
+            s += y;
+            q = __builtin_fmaf(y, y, q);
+          }
+        ss[n] += (double)s;
+        sq[n] += (double)q;
+      }
+    } else {
+      half8 f1h[C1 / 16][2], f1l[C1 / 16][2];
+#pragma unroll
+      for (int t = 0; t < C1 / 32; ++t)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const f32x16 y = bn_train_relu_t(acc[t][st], B0, M0, A0, t * 32, lhi);
+          half8 fh[2], fl[2];
+          tile_to_fragments(y, lhi, fh, fl);
+          f1h[2 * t][st] = fh[0]; f1h[2 * t + 1][st] = fh[1];
+          f1l[2 * t][st] = fl[0]; f1l[2 * t + 1][st] = fl[1];
+        }
+      // ---- layer 2 in the GEMM's orientation: lane = channel n*32 + l31, register e = sample row; raw rows out + sums ----
+#pragma unroll
+      for (int n = 0; n < C2 / 32; ++n) {
+        f32x16 a2[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a2[st][e] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < C1 / 16; ++ks) {
+          const half8 wh = *reinterpret_cast<const half8*>(W1h + (n * 32 + l31) * LD1 + ks * 16 + lhi * 8);
+          const half8 wl = *reinterpret_cast<const half8*>(W1l + (n * 32 + l31) * LD1 + ks * 16 + lhi * 8);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1l[ks][st], wh, a2[st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1h[ks][st], wl, a2[st], 0, 0, 0);
+#pragma unroll
+          for (int st = 0; st < 2; ++st) a2[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1h[ks][st], wh, a2[st], 0, 0, 0);
+        }
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          float* orow = p.y_out + ((int64_t)g * 64 + st * 32 + 4 * lhi) * C2 + n * 32 + l31;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float y = a2[st][e] + bs[n];
+            s += y;
+            q = __builtin_fmaf(y, y, q);
+            orow[(int64_t)((e & 3) + 8 * (e >> 2)) * C2] = y;       // 128 contiguous bytes per half wave
+          }
+        }
+        ss[n] += (double)s;
+        sq[n] += (double)q;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < CS / 32; ++n) flush_stats(p.stats, p.copies, CS, n * 32 + l31, lhi, ss[n], sq[n]);
+}
+
+}  // namespace
+
+extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
+  PFPP_REQUIRE(a, "null args");
+  PFPP_REQUIRE(a->xyz && a->new_xyz && a->idx && a->stats, "null pointer");
+  PFPP_REQUIRE(a->F >= 0 && a->N > 0 && a->S > 0 && a->stats_copies >= 1, "bad sizes");
+  const bool lvl1 = a->feats == nullptr;
+  const int n_layers = lvl1 ? 3 : 2;
+  PFPP_REQUIRE(a->stage >= 1 && a->stage <= n_layers, "stage out of range (1..3 without input features, 1..2 with)");
+  for (int i = 0; i < a->stage; ++i) {
+    PFPP_REQUIRE(a->w_hi[i] && a->w_lo[i] && a->bias[i], "weights / bias of a layer this stage computes are missing");
+    PFPP_REQUIRE(pfpp::aligned16(a->w_hi[i]) && pfpp::aligned16(a->w_lo[i]), "planes must be 16-byte aligned");
+  }
+  for (int i = 0; i + 1 < a->stage; ++i) PFPP_REQUIRE(a->a_mul[i] && a->a_add[i], "finalised BatchNorm affine of an earlier layer is missing");
+  if (lvl1) {
+    PFPP_SUPPORTED(a->ns == 32 && a->C1 == 64 && a->C2 == 64 && a->C3 == 128, "train-mode chain without features: nsample 32, widths 64/64/128 only");
+    PFPP_REQUIRE(a->stage < 3 || (a->out_max && a->out_min), "stage 3 writes the per-neighbourhood max and min");
+    PFPP_REQUIRE(a->F * a->S < (1ll << 31), "too many neighbourhoods");
+  } else {
+    PFPP_SUPPORTED(a->ns == 64 && a->D == 128 && a->C1 == 128 && a->C2 == 128, "train-mode chain with features: nsample 64, 128 features, widths 128/128 only");
+    PFPP_REQUIRE(a->stage < 2 || a->y_out, "stage 2 writes the raw layer-2 rows");
+    PFPP_REQUIRE(pfpp::aligned16(a->feats), "16-byte alignment");
+    PFPP_REQUIRE(a->F * a->S < (1ll << 25), "too many neighbourhoods");
+  }
+  if (a->F == 0) return PFPP_OK;
+  SaTP p;
+  p.xyz = a->xyz; p.ctr = a->new_xyz; p.feats = a->feats; p.idx = a->idx;
+  for (int i = 0; i < 3; ++i) {
+    p.wh[i] = (const _Float16*)a->w_hi[i]; p.wl[i] = (const _Float16*)a->w_lo[i]; p.bias[i] = a->bias[i];
+  }
+  for (int i = 0; i < 2; ++i) { p.am[i] = a->a_mul[i]; p.aa[i] = a->a_add[i]; }
+  p.stats = a->stats; p.copies = (int)a->stats_copies;
+  p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
+  p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
+  const int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;       // persistent: one 4-wave workgroup per CU the stream may use
+  const int64_t wgs_needed = (p.G + 3) / 4;
+  const unsigned grid = (unsigned)(wgs_needed < cap ? wgs_needed : cap);
+  hipStream_t st = pfpp::as_stream(stream);
+  if (lvl1) {
+    if (a->stage == 1) hipLaunchKernelGGL((sa1_train_kernel<64, 64, 128, 1>), dim3(grid), dim3(256), 0, st, p);
+    else if (a->stage == 2) hipLaunchKernelGGL((sa1_train_kernel<64, 64, 128, 2>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((sa1_train_kernel<64, 64, 128, 3>), dim3(grid), dim3(256), 0, st, p);
+  } else {
+    constexpr int d = 128, c1 = 128, c2 = 128;
+    constexpr size_t smem1 = (size_t)2 * c1 * ((d / 16 + 1) * 16 + 8) * sizeof(_Float16);
+    constexpr size_t smem2 = smem1 + (size_t)2 * c2 * (c1 + 8) * sizeof(_Float16) + (size_t)3 * c1 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      attr_set = true;
+    }
+    if (a->stage == 1) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 1>), dim3(grid), dim3(256), smem1, st, p);
+    else hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 2>), dim3(grid), dim3(256), smem2, st, p);
+  }
+  return pfpp::check_launch("pfpp_sa_train_stage");
+}

@@ -56,6 +56,19 @@ _u64 = C.c_uint64
 _u32 = C.c_uint32
 
 
+class SaTrainArgs(C.Structure):
+    """mirror of struct pfpp_sa_train_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("xyz", _p), ("new_xyz", _p), ("feats", _p), ("idx", _p),
+        ("w_hi", _p * 3), ("w_lo", _p * 3), ("bias", _p * 3), ("a_mul", _p * 2), ("a_add", _p * 2),
+        ("stats", _p), ("stats_copies", _i64),
+        ("y_out", _p), ("out_max", _p), ("out_min", _p),
+        ("F", _i64), ("N", _i64), ("S", _i64), ("ns", _i64), ("D", _i64), ("C1", _i64), ("C2", _i64), ("C3", _i64),
+        ("stage", _i32), ("max_workgroups", _i64),
+    ]
+
+
 class PlanesC(C.Structure):
     """mirror of struct pfpp_planes (include/pfpp.h)"""
 
@@ -151,6 +164,7 @@ SIGNATURES = {
     "pfpp_bn_apply": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i64, _i64, _p],
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
     "pfpp_adamw_zero": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p],
+    "pfpp_sa_train_stage": [C.POINTER(SaTrainArgs), _p],
     "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],

@@ -28,6 +28,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_pl.hip": ["-munsafe-fp-atomics"] + (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
     "sa_fused.hip": [],
+    "sa_train.hip": ["-munsafe-fp-atomics"],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],
@@ -58,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
-    headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h", CSRC / "gemm_common.h"]
+    headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h", CSRC / "gemm_common.h", CSRC / "sa_common.h"]
     objs = []
     for src, extra in SOURCES.items():
         s = CSRC / src

@@ -478,6 +478,67 @@ def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w
     return out
 
 
+# persistent-kernel grid cap: the number of CUs the current stream may use (None = all 256).  The train-mode chain kernels run one
+# workgroup per CU with a static stride over the neighbourhoods; on a CU-masked stream (pfpp_hip.train.FeaturePipeline) a 256-wide
+# grid would run as two unequal rounds
+PERSISTENT_WGS: Optional[int] = None
+
+
+def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, ws, biases,
+                   affines, stats: torch.Tensor, y_out: Optional[torch.Tensor] = None, out_max: Optional[torch.Tensor] = None,
+                   out_min: Optional[torch.Tensor] = None) -> None:
+    """one stage of the train-mode set-abstraction chain (pfpp_sa_train_stage): batch statistics of layer `stage` by recomputation
+    of layers 1..stage-1 with their finalised BatchNorm affines; ws / biases = packing.PW / conv bias per layer (at least `stage` of
+    them), affines = [(a_mul, a_add)] of the finalised layers (stage - 1 of them), stats = train_ops.bn_stats_buffer(C_stage)"""
+    _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    if stats.dtype != torch.float64 or not stats.is_cuda or not stats.is_contiguous():
+        raise ValueError("sa_train_stage: stats must be a contiguous float64 CUDA tensor [copies, 2, C]")
+    if len(ws) < stage or len(biases) < stage or len(affines) < stage - 1:
+        raise ValueError("sa_train_stage: weights / biases for layers 1..stage and affines for layers 1..stage-1 are needed")
+    a = _lib.SaTrainArgs()
+    a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+    D = 0
+    if feats is not None:
+        _chk(feats, torch.float32, "feats")
+        D = feats.shape[2]
+        if feats.shape[:2] != (F, N):
+            raise ValueError("sa_train_stage: feats [F, N, D] expected")
+        a.feats = feats.data_ptr()
+    widths = [0, 0, 0]
+    k_in = D + 8 if feats is not None else 8
+    for i in range(stage):
+        w = ws[i]
+        if w.scale != 1.0:
+            raise ValueError("sa_train_stage reads the planes as they are: pack these weights with PW(w, prescale=False)")
+        if w.hi.shape != (w.N, k_in):
+            raise ValueError(f"sa_train_stage: layer {i + 1} weight planes {tuple(w.hi.shape)} do not chain ({w.N}, {k_in})")
+        _chk(biases[i], torch.float32, "bias")
+        a.w_hi[i], a.w_lo[i], a.bias[i] = w.hi.data_ptr(), w.lo.data_ptr(), biases[i].data_ptr()
+        widths[i] = k_in = w.N
+    for i in range(stage - 1):
+        am, aa = affines[i]
+        _chk(am, torch.float32, "a_mul"); _chk(aa, torch.float32, "a_add")
+        a.a_mul[i], a.a_add[i] = am.data_ptr(), aa.data_ptr()
+    if stats.shape[1:] != (2, widths[stage - 1]):
+        raise ValueError("sa_train_stage: stats [copies, 2, C_stage] expected")
+    a.stats, a.stats_copies = stats.data_ptr(), stats.shape[0]
+    for t, nm, rows in ((y_out, "y_out", F * S * ns), (out_max, "out_max", F * S), (out_min, "out_min", F * S)):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            if t.shape != (rows, widths[stage - 1]):
+                raise ValueError(f"sa_train_stage: {nm} must be [{rows}, {widths[stage - 1]}]")
+            setattr(a, nm, t.data_ptr())
+    # the ABI fixes the supported widths; layers beyond `stage` are reported with the level's known widths
+    full = (64, 64, 128) if feats is None else (128, 128, 256)
+    a.F, a.N, a.S, a.ns, a.D = F, N, S, ns, D
+    a.C1, a.C2, a.C3 = (widths[0] or full[0]), (widths[1] or full[1]), (widths[2] or full[2])
+    a.stage = stage
+    a.max_workgroups = int(PERSISTENT_WGS or 0)
+    check(_lib.load().pfpp_sa_train_stage(C.byref(a), _stream()), "pfpp_sa_train_stage")
+
+
 def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, w1, s0, t0, s1, t1,
                   as_planes: bool = False):
     """grouping + the first two folded [conv, BN, ReLU] of a set-abstraction level with input features in one kernel

@@ -453,6 +453,50 @@ def test_encoder_train_mode_batchnorm_vs_reference_golden(golden, weights_sd, de
         enc.encode(pts)
 
 
+def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev):
+    """train-mode set abstraction by recomputation (csrc/sa_train.hip: per-layer chain launches that write only the batch sums,
+    level 2's raw second-layer rows and level 1's pooled max / min) against the layer-wise fused-BatchNorm GEMMs on the same
+    fragments (F = 12 x N = 1024): same sampling, pre-quantisation features within 2e-5 of their scale, running statistics and
+    counters moved identically — the two differ only in the summation order of the fp64 batch sums"""
+    from pfpp_hip import config, encoder, ops
+    from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
+
+    gen = torch.Generator().manual_seed(77)
+    pts = (torch.rand(12, 1024, 3, generator=gen) * 2 - 1) * torch.rand(12, 1, 3, generator=gen)
+    res = {}
+    prev = encoder.SA_TRAIN_CHAIN
+    try:
+        for chain in (False, True):
+            encoder.SA_TRAIN_CHAIN = chain
+            enc = VQVAE(config.denoiser_config())
+            enc.load_state_dict(weights_sd("vqvae"), strict=True)
+            enc = enc.to(dev).train()
+            for p in enc.parameters():
+                p.requires_grad = False
+            cap = {}
+            from pfpp_hip.encoder import pn2_encode
+
+            pk = enc.packed_train()
+            z_e, xyz = pn2_encode(pk, pts.to(dev), 25, cap)
+            z_e2, _ = pn2_encode(pk, pts.to(dev) * 0.5, 25)              # second pass: the running buffers move again
+            torch.cuda.synchronize()
+            res[chain] = dict(z_e=z_e.cpu(), z_e2=z_e2.cpu(), xyz=xyz.cpu(), feats={k: v.cpu() for k, v in cap.items() if k.endswith("new_points")},
+                              stats={k: v.detach().cpu().clone() for k, v in enc.state_dict().items() if "running" in k or "tracked" in k})
+    finally:
+        encoder.SA_TRAIN_CHAIN = prev
+    a, b = res[True], res[False]
+    assert torch.equal(a["xyz"], b["xyz"])
+    for k in b["feats"]:
+        assert (a["feats"][k] - b["feats"][k]).abs().max() <= 2e-5 * b["feats"][k].abs().max(), k
+    assert (a["z_e"] - b["z_e"]).abs().max() <= 2e-5 * b["z_e"].abs().max()
+    assert (a["z_e2"] - b["z_e2"]).abs().max() <= 2e-5 * b["z_e2"].abs().max()
+    for k in b["stats"]:
+        if "tracked" in k:
+            assert int(a["stats"][k]) == int(b["stats"][k]) == 2, k
+        else:
+            assert (a["stats"][k] - b["stats"][k]).abs().max() <= 1e-6 * max(1.0, float(b["stats"][k].abs().max())), k
+
+
 def _ddp_worker(rank, world, port, out_q):
     import os
     import sys
