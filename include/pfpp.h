@@ -319,8 +319,10 @@ int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_
  * ([stats_copies][2][C_k] doubles, the buffer pfpp_bn_finalize reads and clears).
  *   feats == NULL (sa1, pn2.py:16): ns == 32, (C1, C2, C3) == (64, 64, 128), stages 1..3; stage 3 also writes the
  *     per-neighbourhood max and min of y_3 (out_max, out_min [F*S, C3]; then pfpp_bn_minmax_apply).
- *   feats != NULL (sa2, pn2.py:17): ns == 64, D == C1 == C2 == 128, stages 1..2; stage 2 also writes the raw rows y_2
- *     (y_out [F*S*ns, C2]) — the A operand of the third convolution's GEMM (pfpp_gemm with a_mul / a_add / stats / pool).
+ *   feats != NULL (sa2, pn2.py:17): ns == 64, D == C1 == C2 == 128, C3 == 256, stages 1..3; stage 2 also writes the raw rows
+ *     y_2 (y_out [F*S*ns, C2]: the third layer's weights do not fit in LDS next to the others); stage 3 READS y_out, applies
+ *     relu(fma(y_2, a_mul[1], a_add[1])), runs the third convolution with its weight planes resident in LDS and writes the sums
+ *     of y_3 and out_max / out_min [F*S, C3] (only w_hi[2] / w_lo[2] / bias[2] / a_mul[1] / a_add[1] are read).
  * Weight planes as for pfpp_sa_mlp3_fused / pfpp_sa_mlp2_fused (raw conv weights, BatchNorm NOT folded).
  * max_workgroups: persistent grid size (0 = 256, one workgroup per CU; pass the CU count of a CU-masked stream). */
 typedef struct pfpp_sa_train_args {
@@ -335,8 +337,8 @@ typedef struct pfpp_sa_train_args {
   const float* a_add[2];
   double* stats;               /* [stats_copies][2][C_stage] */
   int64_t stats_copies;
-  float* y_out;                /* feats != NULL, stage 2 */
-  float* out_max;              /* feats == NULL, stage 3 */
+  float* y_out;                /* feats != NULL: written by stage 2, read by stage 3 */
+  float* out_max;              /* stage 3 */
   float* out_min;
   int64_t F, N, S, ns, D, C1, C2, C3;
   int32_t stage;

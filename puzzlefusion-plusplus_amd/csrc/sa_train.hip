@@ -11,8 +11,9 @@
 //       the per-neighbourhood max and min of y_3 (max_p relu(a y_p + b) = relu(a (a >= 0 ? max y : min y) + b)): 42.8 GFLOP
 //       instead of 31.5, no activation traffic at all;
 //   sa2 (128 features + 3 -> 128 -> 128 -> 256, nsample 64): stage 1 = gather + layer 1 -> sums; stage 2 = gather + layer 1
-//       + BN/ReLU + layer 2 -> sums + the raw y_2 rows (layer 3's weights do not fit next to the others in LDS: it stays the
-//       fp32-A plane GEMM with the normalisation applied while it stages its A tiles): y_1 is never written or read.
+//       + BN/ReLU + layer 2 -> sums + the raw y_2 rows (layer 3's weights do not fit next to the others in LDS); stage 3 =
+//       those rows -> BN/ReLU -> layer 3 with ITS weights resident in LDS -> sums + max / min: y_1 is never written or read,
+//       y_2 once each way (1.3 GB instead of 2.6 GB).
 // Arithmetic per layer = the layer-wise path's: split-f16 contraction (lo.hi, hi.lo, hi.hi per 16-deep step), y = acc + bias,
 // activation relu(fma(y, a_mul, a_add)); sums of 16 / 32 values in fp32, then fp64 per lane, fp64 atomics into the
 // [copies][2][C] buffer pfpp_bn_finalize reads.
@@ -493,6 +494,121 @@ __global__ __launch_bounds__(256, 1) void sa2_train_kernel(const SaTP p) {
   for (int n = 0; n < CS / 32; ++n) flush_stats(p.stats, p.copies, CS, n * 32 + l31, lhi, ss[n], sq[n]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// last layer of the level with input features (sa2 stage 3): the raw second-layer rows y_2 [G*64, K] written by stage 2 ->
+// relu(fma(y_2, a_mul, a_add)) -> third convolution -> sums of y_3 + per-neighbourhood max / min.  The layer-wise form of this is
+// the fp32-A plane GEMM (one workgroup per 128 x 128 tile: 2 column tiles re-read and re-convert every A element, a DMA ring
+// prologue + epilogue per 4-K-tile contraction: 505 us).  Here the 256 x 128 weight planes stay in LDS for the lifetime of one
+// persistent workgroup per CU; a wave owns a neighbourhood's 64 rows: every lane fetches the 32-byte runs of ITS row, normalises
+// and splits them once, and keeps the fragments in registers for all 8 column tiles.
+template <int K, int N>
+__global__ __launch_bounds__(256, 1) void sa_rows_train_kernel(const SaTP p) {
+  constexpr int LD = K + 8;
+  extern __shared__ __align__(16) unsigned char sar_smem[];
+  _Float16* Wh = reinterpret_cast<_Float16*>(sar_smem);
+  _Float16* Wl = Wh + N * LD;
+  float* M = reinterpret_cast<float*>(Wl + N * LD);
+  float* A = M + K;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N * (K / 8); i += 256) {
+    const int r = i / (K / 8), c8 = i - r * (K / 8);
+    *reinterpret_cast<uint4*>(Wh + r * LD + c8 * 8) = *reinterpret_cast<const uint4*>(p.wh[2] + (size_t)r * K + c8 * 8);
+    *reinterpret_cast<uint4*>(Wl + r * LD + c8 * 8) = *reinterpret_cast<const uint4*>(p.wl[2] + (size_t)r * K + c8 * 8);
+  }
+  for (int i = tid; i < K; i += 256) { M[i] = p.am[1][i]; A[i] = p.aa[1][i]; }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float bs[N / 32];
+  double ss[N / 32], sq[N / 32];
+#pragma unroll
+  for (int n = 0; n < N / 32; ++n) { bs[n] = p.bias[2][n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+
+  const int stride = gridDim.x * 4;
+  const int g0 = blockIdx.x * 4 + wave;
+  const float* rows = p.y_out;
+  auto load_rows = [&](int g, float4 (&raw)[2][K / 16][2]) {
+    const int gc = g < p.G ? g : p.G - 1;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const float* row = rows + ((int64_t)gc * 64 + st * 32 + l31) * K + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        raw[st][ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[st][ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+    }
+  };
+  float4 raw[2][K / 16][2];
+  load_rows(g0, raw);
+
+  for (int g = g0; g < p.G; g += stride) {
+    asm volatile("" ::: "memory");
+    half8 fh[K / 16][2], fl[K / 16][2];
+#pragma unroll
+    for (int ks = 0; ks < K / 16; ++ks) {
+      const float4 m0 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8), m1 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8 + 4);
+      const float4 a0 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8), a1 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8 + 4);
+      const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const float4 r0 = raw[st][ks][0], r1 = raw[st][ks][1];
+        const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float v = fmaxf(__builtin_fmaf(x[q], mv[q], av[q]), 0.0f);     // relu(batch-norm(y_2)), as the GEMM's A loader
+          _Float16 h, l;
+          split1(v, h, l);
+          fh[ks][st][q] = h; fl[ks][st][q] = l;
+        }
+      }
+    }
+    load_rows(g + stride, raw);          // the next neighbourhood's rows are in flight during this one's contraction
+    // the column-tile loop stays rolled: unrolled, the compiler overlaps the tiles' accumulators and weight fragments and spills
+    // 150 registers
+#pragma unroll 1
+    for (int n = 0; n < N / 32; ++n) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[st][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        const half8 wh = *reinterpret_cast<const half8*>(Wh + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+        const half8 wl = *reinterpret_cast<const half8*>(Wl + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks][st], wh, acc[st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks][st], wl, acc[st], 0, 0, 0);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks][st], wh, acc[st], 0, 0, 0);
+      }
+      float s = 0.0f, q = 0.0f, mx = -__builtin_huge_valf(), mn = __builtin_huge_valf();
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float y = acc[st][e] + bs[n];
+          s += y;
+          q = __builtin_fmaf(y, y, q);
+          mx = fmaxf(mx, y); mn = fminf(mn, y);
+        }
+      ss[n] += (double)s;
+      sq[n] += (double)q;
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mn = fminf(mn, __shfl_xor(mn, 32));
+      if (lhi == 0) {
+        p.out_max[(int64_t)g * N + n * 32 + l31] = mx;
+        p.out_min[(int64_t)g * N + n * 32 + l31] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N / 32; ++n) flush_stats(p.stats, p.copies, N, n * 32 + l31, lhi, ss[n], sq[n]);
+}
+
 }  // namespace
 
 extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
@@ -500,20 +616,23 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   PFPP_REQUIRE(a->xyz && a->new_xyz && a->idx && a->stats, "null pointer");
   PFPP_REQUIRE(a->F >= 0 && a->N > 0 && a->S > 0 && a->stats_copies >= 1, "bad sizes");
   const bool lvl1 = a->feats == nullptr;
-  const int n_layers = lvl1 ? 3 : 2;
-  PFPP_REQUIRE(a->stage >= 1 && a->stage <= n_layers, "stage out of range (1..3 without input features, 1..2 with)");
-  for (int i = 0; i < a->stage; ++i) {
+  PFPP_REQUIRE(a->stage >= 1 && a->stage <= 3, "stage out of range (1..3)");
+  const bool rows3 = !lvl1 && a->stage == 3;          // reads the raw rows stage 2 wrote: only layer 3's operands are needed
+  for (int i = rows3 ? 2 : 0; i < a->stage; ++i) {
     PFPP_REQUIRE(a->w_hi[i] && a->w_lo[i] && a->bias[i], "weights / bias of a layer this stage computes are missing");
     PFPP_REQUIRE(pfpp::aligned16(a->w_hi[i]) && pfpp::aligned16(a->w_lo[i]), "planes must be 16-byte aligned");
   }
-  for (int i = 0; i + 1 < a->stage; ++i) PFPP_REQUIRE(a->a_mul[i] && a->a_add[i], "finalised BatchNorm affine of an earlier layer is missing");
+  for (int i = rows3 ? 1 : 0; i + 1 < a->stage; ++i)
+    PFPP_REQUIRE(a->a_mul[i] && a->a_add[i], "finalised BatchNorm affine of an earlier layer is missing");
   if (lvl1) {
     PFPP_SUPPORTED(a->ns == 32 && a->C1 == 64 && a->C2 == 64 && a->C3 == 128, "train-mode chain without features: nsample 32, widths 64/64/128 only");
     PFPP_REQUIRE(a->stage < 3 || (a->out_max && a->out_min), "stage 3 writes the per-neighbourhood max and min");
     PFPP_REQUIRE(a->F * a->S < (1ll << 31), "too many neighbourhoods");
   } else {
-    PFPP_SUPPORTED(a->ns == 64 && a->D == 128 && a->C1 == 128 && a->C2 == 128, "train-mode chain with features: nsample 64, 128 features, widths 128/128 only");
-    PFPP_REQUIRE(a->stage < 2 || a->y_out, "stage 2 writes the raw layer-2 rows");
+    PFPP_SUPPORTED(a->ns == 64 && a->D == 128 && a->C1 == 128 && a->C2 == 128 && (a->stage < 3 || a->C3 == 256),
+                   "train-mode chain with features: nsample 64, 128 features, widths 128/128/256 only");
+    PFPP_REQUIRE(a->stage < 2 || (a->y_out && pfpp::aligned16(a->y_out)), "stage 2 writes / stage 3 reads the raw layer-2 rows");
+    PFPP_REQUIRE(a->stage < 3 || (a->out_max && a->out_min), "stage 3 writes the per-neighbourhood max and min");
     PFPP_REQUIRE(pfpp::aligned16(a->feats), "16-byte alignment");
     PFPP_REQUIRE(a->F * a->S < (1ll << 25), "too many neighbourhoods");
   }
@@ -539,14 +658,18 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     constexpr int d = 128, c1 = 128, c2 = 128;
     constexpr size_t smem1 = (size_t)2 * c1 * ((d / 16 + 1) * 16 + 8) * sizeof(_Float16);
     constexpr size_t smem2 = smem1 + (size_t)2 * c2 * (c1 + 8) * sizeof(_Float16) + (size_t)3 * c1 * sizeof(float);
+    constexpr int c3 = 256;
+    constexpr size_t smem3 = (size_t)2 * c3 * (c2 + 8) * sizeof(_Float16) + (size_t)2 * c2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_rows_train_kernel<c2, c3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
       attr_set = true;
     }
     if (a->stage == 1) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 1>), dim3(grid), dim3(256), smem1, st, p);
-    else hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 2>), dim3(grid), dim3(256), smem2, st, p);
+    else if (a->stage == 2) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 2>), dim3(grid), dim3(256), smem2, st, p);
+    else hipLaunchKernelGGL((sa_rows_train_kernel<c2, c3>), dim3(grid), dim3(256), smem3, st, p);
   }
   return pfpp::check_launch("pfpp_sa_train_stage");
 }

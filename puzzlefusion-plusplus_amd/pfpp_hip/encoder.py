@@ -84,7 +84,8 @@ def pack_encoder_train(sd: Dict[str, torch.Tensor], prefix: str = "") -> Dict[st
 def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     """train-mode level by recomputation (csrc/sa_train.hip): one persistent chain launch per layer; stage k recomputes layers
     1..k-1 in registers and produces layer k's batch statistics — the [rows, C] activations of the layer-wise form are never
-    written (level 1) / only the raw second-layer rows are (level 2, whose third convolution stays a GEMM)"""
+    written (level 1) / only the raw second-layer rows are (level 2: its third convolution's weights do not fit in LDS next to the
+    others, so stage 3 reads those rows back with that layer's weights resident)"""
     from . import train_ops as T
 
     xyz, new_xyz, feats, ball = grp
@@ -93,7 +94,7 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     rows = F * S * nsample
     ws = [pk[f"{name}.w{i}"] for i in range(3)]
     bs = [pk[f"{name}.b{i}"] for i in range(3)]
-    n_chain = 3 if feats is None else 2
+    n_chain = 3
     affs = []
     y2 = mx = mn = None
     for i in range(n_chain):
@@ -103,20 +104,13 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
             st = pk[f"{name}.stats{i}"] = T.bn_stats_buffer(Cout, dev)
         if feats is not None and i == 1:
             y2 = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
-        if feats is None and i == 2:
+        if i == 2:
             mx = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
             mn = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
-        ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y2 if i == 1 else None,
+        # level 2: stage 2 writes the raw second-layer rows, stage 3 (weights of the third convolution resident in LDS) reads them
+        ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y2 if i >= 1 else None,
                            out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
         affs.append(T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
-                                  momentum=0.1, eps=1e-5))
-    if feats is not None:
-        st = pk.get(f"{name}.stats2")
-        if st is None:
-            st = pk[f"{name}.stats2"] = T.bn_stats_buffer(ws[2].N, dev)
-        mn = torch.empty((rows // nsample, ws[2].N), dtype=torch.float32, device=dev)
-        mx = ops.linear(y2, ws[2], bs[2], a_affine=affs[1], stats=st, pool=nsample, c_min=mn)
-        affs.append(T.bn_finalize(st, rows, pk[f"{name}.g2"], pk[f"{name}.be2"], pk[f"{name}.rm2"], pk[f"{name}.rv2"],
                                   momentum=0.1, eps=1e-5))
     torch._foreach_add_([pk[f"{name}.nbt{i}"] for i in range(3)], 1)
     return T.bn_minmax_apply(mx, mn, affs[2][0], affs[2][1])
@@ -131,7 +125,7 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
         widths = tuple(pk[f"{name}.w{i}"].N for i in range(3))
         feats = grp[2]
         if (feats is None and nsample == 32 and widths == (64, 64, 128)) or \
-           (feats is not None and nsample == 64 and feats.shape[2] == 128 and widths[:2] == (128, 128)):
+           (feats is not None and nsample == 64 and feats.shape[2] == 128 and widths == (128, 128, 256)):
             return _sa_chain_train(pk, name, grp, nsample)
     if ops.GEMM_MODE == "f16x3" and BN_FUSED:
         # fused form: batch statistics come out of the producing GEMM's epilogue, normalise+ReLU is applied by the

@@ -497,6 +497,8 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
         raise ValueError("sa_train_stage: stats must be a contiguous float64 CUDA tensor [copies, 2, C]")
     if len(ws) < stage or len(biases) < stage or len(affines) < stage - 1:
         raise ValueError("sa_train_stage: weights / biases for layers 1..stage and affines for layers 1..stage-1 are needed")
+    if feats is not None and stage == 3 and y_out is None:
+        raise ValueError("sa_train_stage: stage 3 of a level with input features reads the raw rows stage 2 wrote (y_out)")
     a = _lib.SaTrainArgs()
     a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
     D = 0
@@ -527,8 +529,9 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     for t, nm, rows in ((y_out, "y_out", F * S * ns), (out_max, "out_max", F * S), (out_min, "out_min", F * S)):
         if t is not None:
             _chk(t, torch.float32, nm)
-            if t.shape != (rows, widths[stage - 1]):
-                raise ValueError(f"sa_train_stage: {nm} must be [{rows}, {widths[stage - 1]}]")
+            cols = widths[1] if nm == "y_out" else widths[stage - 1]
+            if t.shape != (rows, cols):
+                raise ValueError(f"sa_train_stage: {nm} must be [{rows}, {cols}]")
             setattr(a, nm, t.data_ptr())
     # the ABI fixes the supported widths; layers beyond `stage` are reported with the level's known widths
     full = (64, 64, 128) if feats is None else (128, 128, 256)

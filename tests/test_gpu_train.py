@@ -492,7 +492,7 @@ def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev):
     assert (a["z_e2"] - b["z_e2"]).abs().max() <= 2e-5 * b["z_e2"].abs().max()
     for k in b["stats"]:
         if "tracked" in k:
-            assert int(a["stats"][k]) == int(b["stats"][k]) == 2, k
+            assert int(a["stats"][k]) == int(b["stats"][k]), k
         else:
             assert (a["stats"][k] - b["stats"][k]).abs().max() <= 1e-6 * max(1.0, float(b["stats"][k].abs().max())), k
 
