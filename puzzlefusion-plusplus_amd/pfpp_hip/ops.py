@@ -539,6 +539,19 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     a.C1, a.C2, a.C3 = (widths[0] or full[0]), (widths[1] or full[1]), (widths[2] or full[2])
     a.stage = stage
     a.max_workgroups = int(PERSISTENT_WGS or 0)
+    if GEMM_TRACE is not None:            # bench.py: HIP events around the launch; FLOPs = the layers this launch actually computes
+        rows = F * S * ns
+        kin = [D + 3 if feats is not None else 3, full[0], full[1]]
+        layers = [2] if (feats is not None and stage == 3) else range(stage)
+        flops = sum(2.0 * rows * kin[i] * full[i] for i in layers)
+        name = (f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else
+                "sa_rows_train_kernel<128, 256>" if stage == 3 else f"sa2_train_kernel<128, 128, 128, {stage}>")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_sa_train_stage(C.byref(a), _stream()), "pfpp_sa_train_stage")
+        e1.record()
+        GEMM_TRACE.append((e0, e1, flops, name, (rows, full[stage - 1], kin[stage - 1], 1, f"chain{stage}", ns)))
+        return
     check(_lib.load().pfpp_sa_train_stage(C.byref(a), _stream()), "pfpp_sa_train_stage")
 
 

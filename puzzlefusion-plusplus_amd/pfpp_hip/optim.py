@@ -35,6 +35,10 @@ class FusedAdamW(torch.optim.Optimizer):
                                  "only updates the engine's flat buffer (freeze it, as train_denoiser.py:33-35 does, or give it "
                                  "its own optimizer)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # in_backward: arm() before a backward lets every layer take its update (and gradient clear) as soon as its gradients are final
+        # (DenoiserTrainEngine.arm_optimizer); step() then closes the step with the same hyper-parameters.  One backward per step only.
+        self.in_backward = False
+        self._armed = False
         self._bind_state()
 
     def _bind_state(self) -> None:
@@ -53,11 +57,18 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
-        self.engine.optimizer_step(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"])
+        armed, self._armed = self._armed, False
+        self.engine.optimizer_step(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], zero_grad=armed)
         for st in self.state.values():
             if "step" in st:
                 st["step"] += 1
         return loss
+
+    def arm(self) -> None:
+        """optimizer-in-backward for the next backward pass (ignored by the engine when gradients are exchanged between ranks first)"""
+        g = self.param_groups[0]
+        self.engine.arm_optimizer(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], zero_grad=True)
+        self._armed = True
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """gradients stay views of the flat buffer (set_to_none would detach them from the kernels)"""

@@ -1041,7 +1041,11 @@ def _masked_stream(device, pct: int, from_top: bool = False):
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
     if rc != 0 or not st.value:
         return None
+    _STREAM_CUS[int(st.value)] = sum(bin(int(w)).count("1") for w in mask)
     return torch.cuda.ExternalStream(st.value, device=device)
+
+
+_STREAM_CUS = {}          # HIP stream handle -> number of CUs its mask leaves it (persistent kernels size their grid by it)
 
 
 class FeaturePipeline:
@@ -1073,7 +1077,7 @@ class FeaturePipeline:
         stream — so a loop that runs on the default stream gets an ordinary non-blocking stream instead (measured with the mask and the
         loop on the default stream: 11.7 ms instead of 8.0)."""
         on_default = torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device)
-        st = None if on_default else _masked_stream(self.device, int(os.environ.get("PFPP_ENC_CU_FRACTION_PCT", "70")))
+        st = None if on_default else _masked_stream(self.device, int(os.environ.get("PFPP_ENC_CU_FRACTION_PCT", "50")))
         return st or torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0")))
 
     def _issue(self, data, gt, ref, noise, t):
@@ -1081,10 +1085,17 @@ class FeaturePipeline:
             self.stream = self._pick_stream()
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)                 # inputs were produced on the main stream
-        with torch.cuda.stream(self.stream), torch.no_grad():
-            noisy = self.model.noise_scheduler.add_noise(gt, noise, t)
-            noisy = torch.where(ref.bool().unsqueeze(-1), gt, noisy)     # noisy[ref] = gt[ref] without the host sync of mask indexing
-            latent, xyz = self.model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+        prev_wgs = ops.PERSISTENT_WGS
+        if os.environ.get("PFPP_ENC_WGS_AUTO", "1") == "1":
+            ops.PERSISTENT_WGS = _STREAM_CUS.get(int(self.stream.cuda_stream))   # one persistent workgroup per CU the stream may use
+        try:
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                noisy = self.model.noise_scheduler.add_noise(gt, noise, t)
+                noisy = torch.where(ref.bool().unsqueeze(-1), gt, noisy)     # noisy[ref] = gt[ref] without the host sync of mask indexing
+                latent, xyz = self.model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+        finally:
+            ops.PERSISTENT_WGS = prev_wgs
+        with torch.cuda.stream(self.stream):
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return dict(noisy=noisy, latent=latent, xyz=xyz, noise=noise, t=t, event=ev)
@@ -1106,3 +1117,69 @@ class FeaturePipeline:
         for k in ("noisy", "latent", "xyz"):
             cur[k].record_stream(main)                # allocated on the encoder stream, consumed on the main stream
         return cur
+
+
+class TrainingSchedule:
+    """The benchmarked execution of the training iteration (bench.py TrainWorkload) behind the module surface:
+    iterate the batches through this wrapper and run the usual loop body on what it yields —
+
+        for batch in model.training_schedule(loader):          # or trainer.fit(model, train_dataloaders=model.training_schedule(loader))
+            loss = model.training_step(batch, i); loss.backward(); optimizer.step(); optimizer.zero_grad()
+
+    * the loop body runs on a HIGH-PRIORITY stream (the transformer's dependency chain sets the length of the iteration);
+    * every batch is moved to the device with its valid-fragment layout derived on the host (no device read in the step);
+    * the frozen encoder of batch i+1 (its own noise / timestep draw, add_noise, rotate, PointNet++/VQ encode) is issued on the
+      CU-masked encoder stream BEFORE batch i is handed out, so it runs underneath batch i's transformer work; Denoiser.forward
+      finds the result in batch["_pfpp_features"] and waits for it there (a consumer that prefetches one batch, like
+      Lightning's data fetcher, therefore does not pull the encoder onto the critical path).
+    Same arithmetic as the in-line path: the encoder depends on the batch and its random draw only (train_denoiser.py:33-35
+    freezes it); only the ORDER of the BatchNorm running-statistics updates relative to the optimizer steps differs (none)."""
+
+    def __init__(self, model, batches, device=None):
+        self.model = model
+        self.batches = batches
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _prepare(self, batch, pipe):
+        if batch is None:
+            return None
+        m, dev = self.model, self.device
+        batch = m.on_before_batch_transfer(dict(batch))
+        batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        batch = m.on_after_batch_transfer(batch)
+        gt = torch.cat([batch["part_trans"], batch["part_rots"]], dim=-1).float().contiguous()
+        noise = torch.randn(gt.shape, device=dev)
+        t = torch.randint(0, m.noise_scheduler.config.num_train_timesteps, (gt.shape[0],), device=dev).long()
+        batch["_pfpp_features"] = pipe._issue(batch, gt, batch["ref_part"], noise, t)
+        return batch
+
+    def __iter__(self):
+        dev = self.device
+        chain = torch.cuda.Stream(device=dev, priority=-1)
+        pipe = FeaturePipeline(self.model, dev)
+        it = iter(self.batches)
+        outer = torch.cuda.current_stream(dev)
+        chain.wait_stream(outer)
+        try:
+            with torch.cuda.stream(chain):
+                nxt = self._prepare(next(it, None), pipe)
+                while nxt is not None:
+                    cur, nxt = nxt, self._prepare(next(it, None), pipe)
+                    yield cur
+        finally:
+            outer.wait_stream(chain)
+
+
+def take_features(batch):
+    """the encoder results TrainingSchedule attached to a batch, made visible to the current stream (or None)"""
+    f = batch.pop("_pfpp_features", None) if isinstance(batch, dict) else None
+    if f is None:
+        return None
+    cur = torch.cuda.current_stream()
+    cur.wait_event(f["event"])
+    for k in ("noisy", "latent", "xyz"):
+        f[k].record_stream(cur)               # allocated on the encoder stream, consumed here
+    return f

@@ -9,6 +9,8 @@ validation_step computes the reference's four metrics with denoiser/evaluation/e
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from pfpp_hip.lightning_compat import LightningModule, instantiate
@@ -60,8 +62,16 @@ class Denoiser(LightningModule):
 
     def forward(self, data_dict, noise=None, timesteps=None):
         """training-style forward (denoiser.py:80-115); `noise` / `timesteps` may be injected"""
-        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
         ref_part = data_dict["ref_part"]
+        if self.training and noise is None and timesteps is None and "_pfpp_features" in data_dict:
+            # the batch came through training_schedule(): its noise draw, add_noise and encoder pass were issued one batch ahead
+            # on the encoder stream (pfpp_hip.train.TrainingSchedule)
+            from pfpp_hip.train import take_features
+
+            f = take_features(data_dict)
+            pred = self.denoiser(f["noisy"], f["t"], f["latent"], f["xyz"], data_dict["part_valids"], data_dict["part_scale"], ref_part)
+            return {"pred_noise": pred, "gt_noise": f["noise"]}
+        gt = torch.cat([data_dict["part_trans"], data_dict["part_rots"]], dim=-1).float().contiguous()
         B = gt.shape[0]
         if noise is None:
             noise = torch.randn(gt.shape, device=gt.device)
@@ -80,7 +90,17 @@ class Denoiser(LightningModule):
         d = (output_dict["pred_noise"] - output_dict["gt_noise"]) * sel.unsqueeze(-1)
         return {"mse_loss": (d * d).sum() / (sel.sum() * d.shape[-1])}
 
+    def training_schedule(self, batches, device=None):
+        """iterate `batches` (a DataLoader or any iterable of batch dicts) in the benchmarked schedule: loop body on a high-priority
+        stream, next batch's frozen-encoder pass one iteration ahead on the CU-masked stream (pfpp_hip.train.TrainingSchedule)"""
+        from pfpp_hip.train import TrainingSchedule
+
+        return TrainingSchedule(self, batches, device)
+
     def training_step(self, data_dict, idx):
+        opt = getattr(self, "_fused_opt", None)
+        if opt is not None and opt.in_backward and torch.is_grad_enabled():
+            opt.arm()                      # AdamW per layer under the backward (single rank, no gradient accumulation)
         out = self(data_dict)
         total = 0
         for name, value in self._loss(data_dict, out).items():
@@ -186,6 +206,10 @@ class Denoiser(LightningModule):
         # length, so the optimizer state of a reference checkpoint loads positionally onto the right parameters
         optimizer = FusedAdamW(self.denoiser.train_engine(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08,
                                params=list(self.parameters()))
+        # optimizer-in-backward (the benchmarked form of the step) when nothing accumulates gradients over several backward passes
+        accumulate = getattr(getattr(self, "trainer", None), "accumulate_grad_batches", 1) or 1
+        optimizer.in_backward = os.environ.get("PFPP_OPT_IN_BWD", "1") == "1" and accumulate == 1
+        object.__setattr__(self, "_fused_opt", optimizer)
         sched_cfg = getattr(self.cfg.model, "lr_scheduler", None)
         if sched_cfg is None:
             return optimizer

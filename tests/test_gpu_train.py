@@ -770,6 +770,81 @@ def test_host_side_layout_and_no_device_read_in_the_step(weights_sd, dev):
 
 
 @pytest.mark.gpu
+def test_module_surface_runs_the_benchmarked_schedule(dev):
+    """the schedule bench.py times (loop body on a high-priority stream, next batch's frozen encoder one iteration
+    ahead on the CU-masked stream, AdamW per layer under the backward with the gradient clear) is what a plain loop over the
+    MODULE surface gets — `for batch in model.training_schedule(loader): training_step / backward / optimizer.step / zero_grad`,
+    called from the default stream — within 6 % of the engine-level iteration of bench.TrainWorkload at BASELINE configs[1]'s size;
+    and the features it hands over are the ones the in-line path computes (same draw -> same loss)."""
+    import time
+
+    import bench
+    from pfpp_hip import config, synthetic
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    wl = bench.TrainWorkload(32, 1024, None, first_id=0, dev=dev)
+    for _ in range(6):
+        wl.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        wl.step()
+    torch.cuda.synchronize()
+    t_engine = (time.perf_counter() - t0) / 20
+    del wl
+
+    torch.manual_seed(1234)
+    model = Denoiser(config.denoiser_config()).to(dev)
+    with torch.no_grad():
+        model.encoder.vector_quantization.embedding.weight.uniform_(-1.0, 1.0)
+    for p_ in model.encoder.parameters():
+        p_.requires_grad = False
+    model.train()
+    opt = model.configure_optimizers()
+    assert opt.in_backward
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(0, 32, num_points=1024).items()}
+    losses = []
+
+    def loop(n):
+        for i, batch in enumerate(model.training_schedule([data] * n)):
+            loss = model.training_step(batch, i)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.detach())
+
+    loop(6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(20)
+    torch.cuda.synchronize()
+    t_module = (time.perf_counter() - t0) / 20
+    print(f"engine-level iteration {t_engine * 1e3:.3f} ms, module-surface iteration {t_module * 1e3:.3f} ms")
+    ls = torch.stack(losses).cpu()
+    assert torch.isfinite(ls).all() and float(ls[-5:].mean()) < float(ls[:5].mean())          # it trains
+    assert t_module <= 1.06 * t_engine, (t_module, t_engine)
+    # same draw -> the prefetched features equal the in-line ones: forward with injected (noise, t) == forward through the schedule
+    from pfpp_hip.train import FeaturePipeline
+
+    torch.manual_seed(7)
+    gt = torch.cat([data["part_trans"], data["part_rots"]], dim=-1).float().contiguous()
+    noise = torch.randn(gt.shape, device=dev)
+    t = torch.randint(0, 1000, (32,), device=dev).long()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        pipe = FeaturePipeline(model, dev)
+        f = pipe._issue(data, gt, data["ref_part"], noise, t)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        noisy = model.noise_scheduler.add_noise(gt, noise, t)
+        noisy = torch.where(data["ref_part"].bool().unsqueeze(-1), gt, noisy)
+        lat, xyz = model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+    torch.cuda.synchronize()
+    # train-mode BatchNorm uses the batch's own statistics: the two passes differ only by the order of the fp64 atomics behind them,
+    # which may flip a VQ code at a near-tie
+    assert torch.equal(f["xyz"], xyz) and float((f["latent"] != lat).float().mean()) < 0.01
+
+
 def test_bench_multi_rank_path_with_gloo(dev):
     """bench.py under torch.distributed.run with 2 ranks (both on this GPU, PFPP_BENCH_BACKEND=gloo): the N > 1 branch —
     barriers, max-over-ranks clock, per-layer gradient exchange inside the timed step, one JSON line from rank 0"""
