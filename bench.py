@@ -457,6 +457,51 @@ def cpu_protocol(kind: str, budget_s: float = 45.0):
     }
 
 
+def roofline_from_trace(trace, steps: int, mode: str, serialised: bool = False):
+    """`roofline` object of the JSON line from HIP-event timed MFMA-kernel launches (ops.GEMM_TRACE entries: start / end event,
+    algorithmic FLOPs, kernel name, shape): the variant with the largest summed duration against its MFMA ceiling"""
+    from pfpp_hip import ops  # noqa: F401
+
+    per = {}
+    shapes = {}
+    for e0, e1, flops, name, shape in trace:
+        ms = e0.elapsed_time(e1)
+        sa = shapes.setdefault((name,) + shape, [0.0, 0.0, 0])
+        sa[0] += flops; sa[1] += ms; sa[2] += 1
+        a = per.setdefault(name, [0.0, 0.0, 0])
+        a[0] += flops; a[1] += ms; a[2] += 1
+    if os.environ.get("BENCH_GEMM_SHAPES"):
+        for key, (fl, ms_, n_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {ms_ / steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // steps:3d}  {key}", file=sys.stderr)
+    name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
+    flags = name.split("<")[1].split(">")[0].split(", ") if "gemm_pl_kernel<" in name else []
+    single = len(flags) > 9 and flags[9] == "true"                     # template flag X1: single-pass fp16
+    split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name or "_train_kernel" in name) and not single
+    # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
+    # FLOPs is the f16 dense peak / 3
+    peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)
+    traffic, traffic_src = pmc_traffic(name.split("+")[0].split("(")[0], mode)
+    roofline = {
+        "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s (single-pass fp16)" if single else
+                      "f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product" if split else "fp32 MFMA dense peak"),
+        "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
+        "launches_per_step": cnt / steps, "avg_launch_ms": round(ms / cnt, 4),
+        "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if serialised else ""),
+        "variants": {k: {"launches_per_step": round(v[2] / steps, 1), "avg_launch_ms": round(v[1] / v[2], 4),
+                         "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
+                     for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
+        # the other roof of the same kernel: counter traffic per launch / its duration against the 8 TB/s HBM peak (short-K GEMMs on
+        # fp32 activations of 1.26 M rows sit between the two roofs)
+        "hbm_frac_of_traffic": (round(traffic / (ms / cnt * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None),
+        "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / steps, 3),
+        "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
+    }
+    return roofline
+
+
 def aggl_puzzles_per_s(dev, n_puzzles: int = 3, points: int = 1000, in_flight: int = 1):
     """BASELINE configs[2]-shaped: the full auto-agglomerative loop (denoise -> edge features -> verify -> promote/merge,
     auto_aggl.py:86-318) on single puzzles (batch 1 like the reference's test.py), 20 DDPM steps per outer iteration,
@@ -614,43 +659,7 @@ def main():
             wl.step()
         torch.cuda.synchronize(dev)
         trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
-        per = {}
-        shapes = {}
-        for e0, e1, flops, name, shape in trace:
-            ms = e0.elapsed_time(e1)
-            sa = shapes.setdefault((name,) + shape, [0.0, 0.0, 0])
-            sa[0] += flops; sa[1] += ms; sa[2] += 1
-            a = per.setdefault(name, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += ms; a[2] += 1
-        if os.environ.get("BENCH_GEMM_SHAPES"):
-            for key, (fl, ms_, n_) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                print(f"  {ms_ / args.steps:8.3f} ms/step  {fl / (ms_ * 1e-3) / 1e12:7.1f} TF/s  x{n_ // args.steps:3d}  {key}", file=sys.stderr)
-        name, (flops, ms, cnt) = max(per.items(), key=lambda kv: kv[1][1])
-        achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
-        flags = name.split("<")[1].split(">")[0].split(", ") if "gemm_pl_kernel<" in name else []
-        single = len(flags) > 9 and flags[9] == "true"                     # template flag X1: single-pass fp16
-        split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name or "_train_kernel" in name) and not single
-        # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
-        # FLOPs is the f16 dense peak / 3
-        peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)
-        traffic, traffic_src = pmc_traffic(name.split("+")[0].split("(")[0], "train" if train else ("stress" if stress else "sampler"))
-        roofline = {
-            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "peak_note": ("f16 dense MFMA peak 2500 TFLOP/s (single-pass fp16)" if single else
-                          "f16 dense MFMA peak 2500 TFLOP/s / 3 matrix instructions per fp32-grade product" if split else "fp32 MFMA dense peak"),
-            "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
-            "launches_per_step": cnt / args.steps, "avg_launch_ms": round(ms / cnt, 4),
-            "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if train else ""),
-            "variants": {k: {"launches_per_step": round(v[2] / args.steps, 1), "avg_launch_ms": round(v[1] / v[2], 4),
-                             "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
-                         for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
-            # the other roof of the same kernel: counter traffic per launch / its duration against the 8 TB/s HBM peak (short-K GEMMs on
-            # fp32 activations of 1.26 M rows sit between the two roofs)
-            "hbm_frac_of_traffic": (round(traffic / (ms / cnt * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None),
-            "gemm_ms_per_step_all_variants": round(sum(v[1] for v in per.values()) / args.steps, 3),
-            "gemm_tflops_all_variants": round(sum(v[0] for v in per.values()) / (sum(v[1] for v in per.values()) * 1e-3) / 1e12, 2),
-        }
+        roofline = roofline_from_trace(trace, args.steps, "train" if train else ("stress" if stress else "sampler"), serialised=train)
 
     extra = {}
     if dist is not None:
@@ -736,7 +745,52 @@ def main():
             extra[name] = {"value": round(swl.n_frag * args.steps / dt, 2), "unit": "fragment*steps/s",
                            "ms_per_step": round(dt / args.steps * 1e3, 3),
                            "padded_slots": "dropped" if compact else "evaluated like the reference"}
+        # roofline of the sampler step's dominant MFMA kernel (instrumented pass, all slots evaluated like the reference)
+        swl.model.denoiser.compact_padded = False
+        ops.GEMM_TRACE = []
+        n_r = max(2, min(args.steps, 8))
+        for _ in range(n_r):
+            swl.step()
+        torch.cuda.synchronize(dev)
+        trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        extra["sampler_roofline"] = roofline_from_trace(trace, n_r, "sampler")
         del swl
+        # BASELINE configs[4] on this one GPU: the joint denoiser + verifier step at 100 fragments x 2048 points in its fp16-MFMA mode
+        # (python bench.py --mode stress is the same workload as the headline line)
+        prev_sp = ops.SINGLE_PASS
+        try:
+            ops.SINGLE_PASS = True
+            st = StressWorkload(args.stress_batch, first_id=0, dev=dev)
+            for _ in range(2):
+                st.step()
+            torch.cuda.synchronize(dev)
+            n_s = 6
+            t1 = time.perf_counter()
+            for _ in range(n_s):
+                st.step()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            ops.GEMM_TRACE = []
+            for _ in range(n_s):
+                st.step()
+            torch.cuda.synchronize(dev)
+            trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+            eps_fast = st.pred_noise_at_start()
+            ops.SINGLE_PASS = False
+            eps_ref = st.pred_noise_at_start()
+            v = st.data["part_valids"].bool()
+            extra["stress"] = {
+                "workload": f"BASELINE configs[4], 1 GPU: {args.stress_batch} puzzles x 100 fragments x 2048 points, rotate + encode + "
+                            "DenoiserTransformer + scheduler step + VerifierTransformer on 4,950 edges per puzzle; plane GEMMs single-pass fp16",
+                "ms_per_step": round(dt / n_s * 1e3, 3), "value": round(st.n_frag * n_s / dt, 2), "unit": "fragment*steps/s",
+                "roofline": roofline_from_trace(trace, n_s, "stress"),
+                "max_abs_diff_pred_noise_vs_f16x3": float((eps_fast - eps_ref)[v].abs().max()),
+                "max_abs_pred_noise": float(eps_ref[v].abs().max()),
+            }
+            del st
+        finally:
+            ops.SINGLE_PASS = prev_sp
+            ops.GEMM_TRACE = None
         extra["auto_aggl_full_loop"] = aggl_puzzles_per_s(dev)
         extra["auto_aggl_full_loop_batched"] = aggl_puzzles_per_s(dev, n_puzzles=64, in_flight=32)
     if not train and not stress and rank == 0 and world == 1 and not args.compact and not args.no_roofline:

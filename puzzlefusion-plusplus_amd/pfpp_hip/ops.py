@@ -22,9 +22,28 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 def _stream() -> C.c_void_p:
     """torch's current HIP stream of the current device (raw handle; torch.cuda.current_stream() costs ~8 us of
     Python per call, and every kernel wrapper asks)"""
+    if STREAM_OVERRIDE is not None:
+        return C.c_void_p(STREAM_OVERRIDE)
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
+        return C.c_void_p(_raw_stream(_cur_dev()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# raw stream handle every wrapper launches on instead of torch's current stream (pfpp_hip.hipstream: side-stream regions of the
+# training engine that only launch kernels into existing buffers); None = torch's current stream
+STREAM_OVERRIDE: Optional[int] = None
+
+
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device      # the C call, without torch.cuda's lazy-init wrapper
+
+
+def raw_stream_id(device_index: int) -> int:
+    """raw handle of torch's current stream on a device (a cheap dictionary key for per-stream workspaces)"""
+    if STREAM_OVERRIDE is not None:
+        return STREAM_OVERRIDE
+    if _raw_stream is not None:
+        return int(_raw_stream(device_index))
+    return int(torch.cuda.current_stream(device_index).cuda_stream)
 
 
 def _chk(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
@@ -249,11 +268,13 @@ _SPLIT_WS = {}
 def _split_workspace(device):
     """split-K workspace lent to pfpp_gemm: one (fp32 partials, int32 tickets) pair per (device, stream) — launches on one
     stream are ordered, launches on different streams must not share it"""
-    key = (device.index, _raw_stream(device.index) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, raw_stream_id(device.index))
     ws = _SPLIT_WS.get(key)
     if ws is None:
         ws = (torch.empty((16 * 1024 * 1024,), dtype=torch.float32, device=device),        # 64 MB
               torch.zeros((1024,), dtype=torch.int32, device=device))
+        if STREAM_OVERRIDE is not None:
+            torch.cuda.synchronize(device)        # the fill ran on torch's current stream, the first use is on the override stream
         _SPLIT_WS[key] = ws
     return ws
 

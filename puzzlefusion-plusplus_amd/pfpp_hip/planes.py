@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import ACT, GemmPlanesArgs, PlanesC, check
-from .ops import _chk, _ptr, _stream
+from .ops import _chk, _ptr, _stream, raw_stream_id
 
 _f32 = torch.float32
 _f16 = torch.float16
@@ -77,7 +77,7 @@ _WS = {}
 
 def _workspace(device):
     """K-split workspace per (device, stream): launches on one stream are ordered, different streams must not share it"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, raw_stream_id(device.index))
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty((24 * 1024 * 1024,), dtype=_f32, device=device)       # 96 MB

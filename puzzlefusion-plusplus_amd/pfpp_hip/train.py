@@ -125,16 +125,19 @@ class FlatParams:
         """(re-)point every .grad at its slice of the flat gradient buffer.  A parameter whose .grad is None was cleared by
         someone else (module.zero_grad(), a foreign optimizer's zero_grad(set_to_none=True)): its slice still holds the previous
         iteration's gradient and is zeroed here — the backward accumulates, and a silently doubled gradient is the alternative."""
-        dropped = [n for n in self.order if self.named[n].grad is None]
-        if len(dropped) == len(self.order):
+        views = getattr(self, "_grad_views", None)
+        if views is None:                  # (parameter, its view of the flat gradient buffer), built once
+            views = self._grad_views = [(self.named[n], self.view(self.grads, n)) for n in self.order]
+        if all(p.grad is g for p, g in views):          # the common case: nothing touched them since the last call
+            return
+        dropped = [g for p, g in views if p.grad is None]
+        if len(dropped) == len(views):
             self.grads.zero_()
         else:
-            for n in dropped:
-                self.view(self.grads, n).zero_()
-        for n in self.order:
-            p = self.named[n]
-            g = self.view(self.grads, n)
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+            for g in dropped:
+                g.zero_()
+        for p, g in views:
+            if p.grad is not g:
                 p.grad = g
 
     def refresh_planes(self) -> None:
@@ -718,11 +721,23 @@ class DenoiserTrainEngine:
             if self._dw_flip:
                 st = self._side2
                 self._side2_used = True
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            issue()
+        self._run_on(st, issue)
         dyp.record_stream(st)
         xp.record_stream(st)
+
+    def _run_on(self, st, fn) -> None:
+        """fn() only launches pfpp kernels into existing buffers: send them to stream `st`, ordered after everything queued on the
+        current stream so far — two direct HIP calls and the wrappers' stream override instead of torch's wait_stream + stream
+        context (pfpp_hip.hipstream: ~30 us of Python per use, ~50 uses per backward)"""
+        from . import hipstream as HS
+
+        h = st.cuda_stream
+        HS.wait_for(h, ops.raw_stream_id(self.flat.params.device.index))
+        prev, ops.STREAM_OVERRIDE = ops.STREAM_OVERRIDE, h
+        try:
+            fn()
+        finally:
+            ops.STREAM_OVERRIDE = prev
 
     def _join_side2(self) -> None:
         if self._side2 is not None and self._side2_used:
@@ -868,10 +883,9 @@ class DenoiserTrainEngine:
             # optimizer in the backward (arm_optimizer): this layer's slice of the flat buffer is final once its weight
             # gradients (side stream) and LayerNorm gradients (main stream, all queued by now) have run — update it on the side
             # stream under the remaining backward instead of in the 0.3 ms AdamW launch that runs alone at the iteration's end
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0, zero_grad=self._armed_zero,
-                                  **self._armed)
+            armed = self._armed
+            self._run_on(self._side, lambda: self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0,
+                                                               zero_grad=self._armed_zero, **armed))
             self._early.append(i)
         if self._exchange.reducing():
             extra = ()
@@ -1158,8 +1172,13 @@ class TrainingSchedule:
 
     def __iter__(self):
         dev = self.device
-        chain = torch.cuda.Stream(device=dev, priority=-1)
-        pipe = FeaturePipeline(self.model, dev)
+        # one chain stream and one encoder pipeline per model: the caching allocator keeps a pool per stream, a fresh stream per epoch
+        # would start every epoch with hipMalloc calls
+        state = getattr(self.model, "_pfpp_schedule_state", None)
+        if state is None or state[0] != dev:
+            state = (dev, torch.cuda.Stream(device=dev, priority=-1), FeaturePipeline(self.model, dev))
+            object.__setattr__(self.model, "_pfpp_schedule_state", state)
+        _, chain, pipe = state
         it = iter(self.batches)
         outer = torch.cuda.current_stream(dev)
         chain.wait_stream(outer)
