@@ -29,6 +29,7 @@ SOURCES = {
     "gemm_pl.hip": ["-munsafe-fp-atomics"] + (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
     "sa_fused.hip": [],
     "sa_train.hip": ["-munsafe-fp-atomics"],
+    "tblock_small.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],

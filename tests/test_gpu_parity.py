@@ -1235,6 +1235,52 @@ def test_fp16_mfma_joint_step_configs4_vs_f16x3(dev):
     assert d_lg <= 5e-3 * max(1.0, float(lg_r.abs().max()))
 
 
+@pytest.mark.parametrize("parts", [(1,), (8,), (20,), (3, 7), (2, 2, 5, 1)])
+def test_small_token_transformer_kernel_equals_layerwise(weights_sd, dev, parts):
+    """one puzzle in flight (<= 512 tokens): the six transformer blocks as ONE persistent kernel (csrc/tblock_small.hip: grid
+    barrier between the phases, agent-coherent exchange buffers) against the layer-wise kernels on the same inputs — predicted noise
+    within 1e-5 (same split-f16 contraction, different reduction orders in LayerNorm / softmax); 1, 8 and 20 fragments, several
+    short puzzles in one call (ragged sequences), repeated launches on one barrier buffer."""
+    from pfpp_hip import config, ops, synthetic
+    from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+
+    m = DenoiserTransformer(config.denoiser_config())
+    m.load_state_dict(weights_sd("denoiser"), strict=True)
+    m = m.to(dev).eval()
+    m.compact_padded = True
+    B = len(parts)
+    gen = torch.Generator().manual_seed(sum(parts) + 17 * B)
+    valid = torch.zeros(B, 20)
+    for b, n in enumerate(parts):
+        valid[b, :n] = 1
+    x = torch.randn(B, 20, 7, generator=gen).to(dev)
+    latent = torch.randn(B, 20, 25, 64, generator=gen).to(dev) * valid[:, :, None, None].to(dev)
+    xyz = (torch.rand(B, 20, 25, 3, generator=gen) * 2 - 1).to(dev) * valid[:, :, None, None].to(dev)
+    scale = (torch.rand(B, 20, 1, generator=gen) + 0.5).to(dev)
+    ref = torch.zeros(B, 20, dtype=torch.bool)
+    ref[:, 0] = True
+    ts = torch.randint(0, 1000, (B,), generator=gen).to(dev)
+    valid_d, ref_d = valid.to(dev), ref.to(dev)
+    assert sum(parts) * 25 <= 512
+    prev = ops.TBLOCK_SMALL
+    try:
+        ops.TBLOCK_SMALL = False
+        with torch.no_grad():
+            want = m(x, ts, latent, xyz, valid_d, scale, ref_d)
+        ops.TBLOCK_SMALL = True
+        assert ops.tblock_small_supported(sum(parts) * 25, 512, 8, 2048, 25, 6)
+        with torch.no_grad():
+            got = [m(x, ts, latent, xyz, valid_d, scale, ref_d) for _ in range(3)]
+    finally:
+        ops.TBLOCK_SMALL = prev
+    torch.cuda.synchronize()
+    v = valid_d.bool()
+    assert torch.isfinite(got[0]).all() and float(want[v].abs().max()) > 1e-3
+    assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])          # deterministic, barrier generations carry over
+    assert (got[0][v] - want[v]).abs().max() <= 1e-5 * max(1.0, float(want[v].abs().max()))
+    assert float(got[0][~v].abs().max() if (~v).any() else 0.0) == 0.0
+
+
 def test_auto_aggl_batched_equals_single(weights_sd, dev):
     """throughput mode: several puzzles through the loop at once give each puzzle the result of its own test_step"""
     from pfpp_hip import config, synthetic
