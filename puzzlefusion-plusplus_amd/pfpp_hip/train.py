@@ -248,6 +248,9 @@ class TrainContext:
         self.t: Dict[str, object] = {}
 
 
+_DIAG_HOST_DELAY_US = float(os.environ.get("PFPP_DIAG_HOST_DELAY_US", "0"))
+
+
 class DenoiserTrainEngine:
     """forward (train mode) / backward / optimizer step of a DenoiserTransformer on the HIP kernels"""
 
@@ -553,6 +556,11 @@ class DenoiserTrainEngine:
             raise RuntimeError("DenoiserTrainEngine.backward: the flat gradient buffer was already all-reduced in place by a previous "
                                "backward of this step; a second backward would reduce the summed micro-batch again.  Accumulate with "
                                "`with engine.no_sync():` around every backward but the last, or call optimizer_step() in between")
+        if _DIAG_HOST_DELAY_US:                 # diagnostic: is the iteration host-bound? (busy-wait on the host before the backward is enqueued)
+            import time
+            t_end = time.perf_counter() + _DIAG_HOST_DELAY_US * 1e-6
+            while time.perf_counter() < t_end:
+                pass
         self._exchange.enabled = self._sync
         self._exchanged = self._exchange.active() and self._sync
         if self._exchange.active() and not self._sync:
