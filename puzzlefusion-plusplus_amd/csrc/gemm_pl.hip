@@ -819,9 +819,9 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
 //   BN * 2 >= 128 bytes already).  One raw barrier per 64-deep tile, NS stages, counted vmcnt; fragment reads through inline
 //   asm, double-buffered per 16-deep step with counted lgkmcnt.  Same products in the same order as pl_body / gemm_f16x3_kernel
 //   (lo.hi, hi.lo, hi.hi per 16-deep step): bit-identical to them without a K split.
-template <int MT, int NT, int WM, int WN, int NS, bool WK>
+template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG = 1>
 struct Cfg64 {
-  static constexpr int NW = WM * WN;
+  static constexpr int NW = WM * WN * KG;                 // KG wave groups share every output tile and split the 16-deep steps of a K-tile
   static constexpr int NTHR = 64 * NW;
   static constexpr int BM = 32 * MT * WM;
   static constexpr int BN = 32 * NT * WN;
@@ -834,18 +834,21 @@ struct Cfg64 {
   static_assert(NP % NW == 0, "pieces must divide over the waves");
   static_assert(MT == 2 && (NT == 1 || NT == 2), "wave tile: 64 rows x 32 or 64 columns");
   static_assert(NS == 2 || NS == 3, "two or three stages");
+  static_assert(KG == 1 || KG == 2, "one or two wave groups along K");
 };
 
-template <int MT, int NT, int WM, int WN, int NS, bool WK>
+template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG>
 __device__ __forceinline__ void pl64_body(const GemmP& p) {
-  using C = Cfg64<MT, NT, WM, WN, NS, WK>;
+  using C = Cfg64<MT, NT, WM, WN, NS, WK, KG>;
   constexpr int BM = C::BM, BN = C::BN, NPW = C::NPW, STAGE = C::STAGE, BK64 = 64;
   constexpr int CPR_W = BN / 8;                           // 16-byte chunks per contraction row of a k-major W tile
   extern __shared__ __align__(1024) char pl_smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int kg = wave / (WM * WN);                        // wave group along K: takes the 16-deep steps kg, kg + KG, ... of every K-tile
+  const int wt = wave - kg * (WM * WN);
+  const int wm = wt / WN, wn = wt % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int wg = remap_tile(blockIdx.x, gridDim.x);
@@ -1008,20 +1011,58 @@ __device__ __forceinline__ void pl64_body(const GemmP& p) {
       const uint32_t fill = cur == 0 ? (NS - 1) * STAGE : cur - STAGE;       // the stage of tile kt - 1
       issue(kt + NS - 1, fill);
     }
-    rd(fr[0], cur, std::integral_constant<int, 0>{});
-    static_for<4>([&](auto s_c) {
-      constexpr int s4 = decltype(s_c)::value;
-      if constexpr (s4 < 3) {
-        rd(fr[(s4 + 1) & 1], cur, std::integral_constant<int, s4 + 1>{});
-        wait_fr(fr[s4 & 1], std::integral_constant<int, NRD>{});
+    if constexpr (KG == 1) {
+      rd(fr[0], cur, std::integral_constant<int, 0>{});
+      static_for<4>([&](auto s_c) {
+        constexpr int s4 = decltype(s_c)::value;
+        if constexpr (s4 < 3) {
+          rd(fr[(s4 + 1) & 1], cur, std::integral_constant<int, s4 + 1>{});
+          wait_fr(fr[s4 & 1], std::integral_constant<int, NRD>{});
+        } else {
+          wait_fr(fr[s4 & 1], std::integral_constant<int, 0>{});
+        }
+        mma(fr[s4 & 1]);
+      });
+    } else {
+      // two wave groups: group 0 takes steps 0 and 2, group 1 steps 1 and 3 — two waves per SIMD, one group's MFMAs run
+      // under the other's fragment reads
+      if (kg == 0) {
+        rd(fr[0], cur, std::integral_constant<int, 0>{});
+        rd(fr[1], cur, std::integral_constant<int, 2>{});
       } else {
-        wait_fr(fr[s4 & 1], std::integral_constant<int, 0>{});
+        rd(fr[0], cur, std::integral_constant<int, 1>{});
+        rd(fr[1], cur, std::integral_constant<int, 3>{});
       }
-      mma(fr[s4 & 1]);
-    });
+      wait_fr(fr[0], std::integral_constant<int, NRD>{});
+      mma(fr[0]);
+      wait_fr(fr[1], std::integral_constant<int, 0>{});
+      mma(fr[1]);
+    }
     cur = (cur + STAGE == NS * STAGE) ? 0u : cur + STAGE;
   }
 
+  if constexpr (KG == 2) {
+    // group 1 hands its accumulators to group 0 through LDS (the DMA ring is dead; the patches of the wide epilogue start at byte 0,
+    // the hand-over area behind them)
+    __builtin_amdgcn_s_barrier();
+    float* xch = reinterpret_cast<float*>(pl_smem + 65536) + (size_t)wt * (MT * NT * 16 * 64);
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) xch[((i * NT + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * NT + j) * 16 + e) * 64 + lane];
+  }
   if (p.split_ws && p.split_k > 1) {
     GemmP q = p;
     q.C = p.split_ws + (size_t)split * p.M * p.N;
@@ -1029,8 +1070,8 @@ __device__ __forceinline__ void pl64_body(const GemmP& p) {
     q.bias = q.scale = q.shift = q.residual = nullptr;
     q.act = PFPP_ACT_NONE;
     q.Chi = q.Clo = nullptr;
-    __builtin_amdgcn_s_barrier();
-    epilogue_wide<MT, NT>(q, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, 0, 0, lds0 + wave * (32 * NT * 128));
+    if constexpr (KG == 1) __builtin_amdgcn_s_barrier();
+    epilogue_wide<MT, NT>(q, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, 0, 0, lds0 + wt * (32 * NT * 128));
     return;
   }
   if (p.accum) {
@@ -1059,23 +1100,23 @@ __device__ __forceinline__ void pl64_body(const GemmP& p) {
   const bool wide_ok = p.pool == 0 && (p.ldc & 3) == 0 && (p.N & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
                        (p.act != PFPP_ACT_GEGLU || (p.N & 7) == 0);
   if (wide_ok) {
-    __builtin_amdgcn_s_barrier();
-    epilogue_wide<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, c_off, v_off, lds0 + wave * (32 * NT * 128));
+    if constexpr (KG == 1) __builtin_amdgcn_s_barrier();
+    epilogue_wide<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, c_off, v_off, lds0 + wt * (32 * NT * 128));
   } else {
     epilogue<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
   }
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool WK>
-__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_pl64_kernel(const GemmP p) {
-  pl64_body<MT, NT, WM, WN, NS, WK>(p);
+template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG>
+__global__ __launch_bounds__(64 * WM * WN * KG, 1) void gemm_pl64_kernel(const GemmP p) {
+  pl64_body<MT, NT, WM, WN, NS, WK, KG>(p);
 }
 
-template <int MT, int NT, int WM, int WN, int NS, bool WK>
+template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG = 1>
 int launch_pl64(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits) {
-  using C = Cfg64<MT, NT, WM, WN, NS, WK>;
+  using C = Cfg64<MT, NT, WM, WN, NS, WK, KG>;
   static bool attr_set = false;
-  auto kern = gemm_pl64_kernel<MT, NT, WM, WN, NS, WK>;
+  auto kern = gemm_pl64_kernel<MT, NT, WM, WN, NS, WK, KG>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -1095,7 +1136,7 @@ int launch_pl64(const GemmP& p0, int batch, hipStream_t st, int group_m, int spl
   }
   p.k_chunk = 0;
   const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
-  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl64_kernel<%d, %d, %d, %d, %d, %s>%s", MT, NT, WM, WN, NS, WK ? "true" : "false",
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl64_kernel<%d, %d, %d, %d, %d, %s, %d>%s", MT, NT, WM, WN, NS, WK ? "true" : "false", KG,
            slabs ? "+pl_reduce_kernel" : "");
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, p);
   if (slabs) {
@@ -1141,6 +1182,10 @@ static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m
     const bool ok64 = !p.x1 && !p.stats && !p.a_mul && !p.g_idx && p.pool == 0 && !p.Cmin && p.K % 64 == 0 && p.k_valid == p.K && p.K >= 128;
     if (ok64 && (variant == 15 || (bk64 && variant == 6))) return pl::launch_pl64<2, 1, 2, 2, 3, WK>(p, batch, st, group_m, splits);
     if (ok64 && (variant == 16 || (bk64 && variant == 3))) return pl::launch_pl64<2, 2, 2, 2, 2, WK>(p, batch, st, group_m, splits);
+    if (ok64 && variant == 17) return pl::launch_pl64<2, 1, 2, 2, 3, WK, 2>(p, batch, st, group_m, splits);      // 128 x 64, 8 waves in two K groups
+    if (ok64 && variant == 18) return pl::launch_pl64<2, 2, 2, 2, 2, WK, 2>(p, batch, st, group_m, splits);      // 128 x 128, 8 waves in two K groups
+    if (variant == 17) variant = 6;
+    if (variant == 18) variant = 3;
     if (variant == 15) variant = 6;
     if (variant == 16) variant = 3;
   }

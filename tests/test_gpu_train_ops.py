@@ -106,6 +106,16 @@ def test_plane_gemm_k_tile_64_is_bit_identical_to_k_tile_32(dev, rows, n_out, n_
                 P.gemm(dyp, wp, c, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=3, variant=v64)
                 assert rel_err(c, dyp.float().double().cpu() @ wp.float().double().cpu()) < 2e-6
     assert "gemm_pl64_kernel" in P._lib.load().pfpp_last_gemm_kernel().decode() or n_out < 512
+    # two wave groups along K (variants 17 / 18: 8 waves, the groups' accumulators meet in LDS): another summation order -> fp64 bar
+    for v in (17, 18):
+        a = torch.empty(rows, n_out, device=dev)
+        P.gemm(xp, wp, a, M=rows, N=n_out, K=n_in, splits=1, variant=v, bias=bias if n_out % 4 == 0 else None)
+        want = xp.float().double().cpu() @ wp.float().double().cpu().t() + (bias.double().cpu() if n_out % 4 == 0 else 0.0)
+        assert rel_err(a, want) < 2e-6
+        if n_in % 8 == 0 and n_out % 64 == 0:
+            b = torch.empty(rows, n_in, device=dev)
+            P.gemm(dyp, wp, b, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=2 if n_out >= 512 else 1, variant=v)
+            assert rel_err(b, dyp.float().double().cpu() @ wp.float().double().cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (16000, 1536, 512), (1234 * 4, 512, 2048), (640, 512, 148), (32, 1024, 512)])

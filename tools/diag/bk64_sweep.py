@@ -22,6 +22,6 @@ for N in (512, 1536):
             w = P.split(torch.randn(N, K, device=dev)) if form == "nt" else P.split(torch.randn(K, N, device=dev))
             out = torch.empty(M, N, device=dev)
             row = []
-            for v in (15, 6, 16, 3):
+            for v in (15, 6, 16, 3, 17, 18):
                 row.append(t(lambda: P.gemm(x, w, out, M=M, N=N, K=K, w_kmajor=(form == "nn"), splits=1, variant=v)))
-            print(f"{form} M{M} N{N:5d} K{K:5d}:  128x64 BK64 {row[0]:6.1f}  BK32 {row[1]:6.1f} | 128x128 BK64 {row[2]:6.1f}  BK32 {row[3]:6.1f} us", flush=True)
+            print(f"{form} M{M} N{N:5d} K{K:5d}:  128x64 BK64 {row[0]:6.1f}  BK32 {row[1]:6.1f}  2 K-groups {row[4]:6.1f} | 128x128 BK64 {row[2]:6.1f}  BK32 {row[3]:6.1f}  2 K-groups {row[5]:6.1f} us", flush=True)
