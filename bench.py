@@ -180,9 +180,6 @@ class TrainWorkload:
         from pfpp_hip.train import FeaturePipeline
 
         self.pipeline = FeaturePipeline(self.model, dev) if (pipeline and not latents_given) else None
-        if self.pipeline is not None and os.environ.get("PFPP_BENCH_ENC_AFTER_FWD", "0") == "1":
-            self.pipeline.defer = True            # issue the next iteration's encoder after this iteration's forward (experiment)
-            self.engine.after_forward = self.pipeline.issue_next
         # the transformer's dependency chain sets the length of the iteration; the encoder and the weight gradients fill
         # the chip underneath it from their own streams — so the chain runs on a high-priority stream (10.05 -> 9.9 ms)
         self._hi = (torch.cuda.Stream(device=dev, priority=-1)

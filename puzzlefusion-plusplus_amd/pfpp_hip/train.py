@@ -297,13 +297,6 @@ class DenoiserTrainEngine:
         self._side = ((_masked_stream(self.flat.params.device, int(os.environ.get("PFPP_SIDE_CU_FRACTION_PCT", "0")), from_top=True) or
                        torch.cuda.Stream(device=self.flat.params.device, priority=int(os.environ.get("PFPP_SIDE_PRIORITY", "0"))))
                       if os.environ.get("PFPP_TRAIN_SIDE_STREAM", "1") == "1" else None)
-        # the two passes of the dense attention backward (dq | dk, dv) are independent and can run on two streams
-        # (pfpp_attn_dense_bwd_parts) — measured: no gain (9.76 vs 9.75 ms; 8.36 vs 8.10 with the latents given: both are
-        # 1024-workgroup launches that already fill the chip, the extra D kernel and events cost more), so opt-in
-        self._aux = (torch.cuda.Stream(device=self.flat.params.device)
-                     if (self._side is not None and os.environ.get("PFPP_TRAIN_ATTN_SPLIT", "0") == "1") else None)
-        self._group_dw = os.environ.get("PFPP_TRAIN_GROUP_DW", "0") == "1"
-        self._group_split = os.environ.get("PFPP_TRAIN_GROUP_SPLIT", "0") == "1"
         # every dropout site is followed by a LayerNorm (forward) / follows a LayerNorm backward: one launch for both
         self._fuse_drop = os.environ.get("PFPP_TRAIN_FUSE_DROP", "1") != "0"
         self._fuse_colsum = os.environ.get("PFPP_TRAIN_FUSE_COLSUM", "1") != "0"   # bias gradients from the weight-gradient GEMM's dY tiles
@@ -311,16 +304,9 @@ class DenoiserTrainEngine:
         # LDS-DMA staged plane kernel (csrc/gemm_pl.hip); the LayerNorm / attention / GEGLU kernels hand their results over
         # as split-f16 planes, gradients lifted by grad_scale.  PFPP_TRAIN_PLANES=0 restores the register-staged kernels.
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
-        self._side2 = (torch.cuda.Stream(device=self.flat.params.device)
-                       if (self._side is not None and os.environ.get("PFPP_TRAIN_DW_STREAMS", "1") == "2") else None)
-        self.after_forward = None          # optional callable run between forward and backward of loss_and_grads (stream scheduling hooks)
-        self._dw_variant = int(os.environ.get("PFPP_TRAIN_DW_VARIANT", "0"))     # tile of the weight-gradient GEMMs (0: cost model)
-        self._dw_flip = False
-        self._side2_used = False
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
         self._early: List[int] = []                   # layers whose slice the armed backward has already updated
-        self._pending = []                           # (dy, x, dW, db) noted by _linear_bwd, issued by _flush_dw
         self._sync = True                            # False inside no_sync(): this backward does not start the gradient exchange
         self._exchanged = False                      # the gradients in the flat buffer have been all-reduced since the last step
         self._accumulated = False                    # a no_sync backward has accumulated into the buffer since the last step
@@ -328,8 +314,6 @@ class DenoiserTrainEngine:
     def single_stream(self) -> None:
         """everything on the caller's stream from now on (profiling / per-kernel timing)"""
         self._side = None
-        self._side2 = None
-        self._aux = None
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, *, seed: int = 0,
@@ -611,7 +595,6 @@ class DenoiserTrainEngine:
             T.gemm_grad(da0, w[f"{name}.0.w"].f32, dpooled, M=Fv, N=C, K=da0.shape[1], lda=da0.shape[1], ldw=C, ldc=C,
                         w_kmajor=True, accumulate=True, split_k=1, a_scale=G)
         dh_ = T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
-        self._flush_dw()                                                                  # the heads' four small weight gradients
 
         dmods = carve(5, *s["mods"].shape)
         # multi-rank: the two AdaLN linears of a block get their gradients as soon as the block's backward is through and travel with
@@ -671,8 +654,6 @@ class DenoiserTrainEngine:
             self._linear_bwd(dz, lay["n3"], w[f"{i}.ff1.w"], g[f"{i}.ff1.w"], g[f"{i}.ff1.b"])
             dn = T.grad_input(dz, w[f"{i}.ff1.w"].f32, g_scale=G, zeroed=self._take_zeroed(pool, dz.shape[0], C, dz.shape[1]))
             del dz
-            if self._group_split:
-                self._flush_dw()                     # the two feed-forward weight gradients go now, the four attention ones at the layer's end
             self._before_inplace_update()
             dy = T.layernorm_bwd(lay["h2"], dn, dh_, gamma=w[f"{i}.norm3.g"], group_rows=32, dmult=g[f"{i}.norm3.g"],
                                  dadd=g[f"{i}.norm3.b"], ld_d=0, drop=(p_lay, seed, 2 + 3 * i) if fuse and p_lay > 0.0 else None)
@@ -683,7 +664,7 @@ class DenoiserTrainEngine:
                              guard=dy is dh_)
             datt = T.grad_input(dy, w[f"{i}.global_attn.o.w"].f32, g_scale=G)
             dqkv = T.attn_dense_bwd(lay["qkv2"], lay["att2"], datt, lay["lse"], s["seq_off"], s["seq_len"], s["max_len"], H, dh,
-                                    s["att_scale"], aux_stream=self._aux)
+                                    s["att_scale"])
             self._linear_bwd(dqkv, lay["n2"], None, g[f"{i}.global_attn.qkv.w"], None)
             dn = T.grad_input(dqkv, w[f"{i}.global_attn.qkv.w"].f32, g_scale=G, zeroed=self._take_zeroed(pool, dqkv.shape[0], C, 3 * C))
             self._before_inplace_update()
@@ -714,7 +695,7 @@ class DenoiserTrainEngine:
         def issue():
             fused = gb is not None and self._fuse_colsum and gb.is_contiguous()      # the bias gradient rides in the dW kernel
             P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True,
-                   colsum=gb if fused else None, variant=self._dw_variant)
+                   colsum=gb if fused else None)
             if gb is not None and not fused:
                 P.colsum(dyp, gb)
 
@@ -722,13 +703,6 @@ class DenoiserTrainEngine:
             issue()
             return
         st = self._side
-        if self._side2 is not None:
-            # two weight-gradient streams, alternating: the GEMM + slab reduction pairs of independent layers overlap (each stream
-            # has its own K-split workspace); the first stream joins the second before anything that needs "all weight gradients"
-            self._dw_flip = not self._dw_flip
-            if self._dw_flip:
-                st = self._side2
-                self._side2_used = True
         self._run_on(st, issue)
         dyp.record_stream(st)
         xp.record_stream(st)
@@ -746,11 +720,6 @@ class DenoiserTrainEngine:
             fn()
         finally:
             ops.STREAM_OVERRIDE = prev
-
-    def _join_side2(self) -> None:
-        if self._side2 is not None and self._side2_used:
-            self._side.wait_stream(self._side2)
-            self._side2_used = False
 
     def _backward_layers_planes(self, s, w, g, dh_, dmods):
         """transformer blocks on the plane GEMM: dX = dY . W reads the weight planes in place as the k-major operand, dW = dY^T . X
@@ -822,15 +791,7 @@ class DenoiserTrainEngine:
 
     def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:
         """dW += dy^T x, db += colsum(dy) — on the side stream when there is one.  `guard`: the caller goes on to update
-        dy in place on the main stream.  With PFPP_TRAIN_GROUP_DW=1 the request is only noted here and `_flush_dw` issues
-        all of a layer's weight gradients as one grouped launch (pfpp_gemm_grad_group): 6 % less GPU work per iteration
-        (12.7 -> 12.0 ms with everything on one stream), but the weight gradients then start later and the step, whose
-        length is set by the main stream's dependency chain when they overlap it, does not get shorter — off by default."""
-        if self._group_dw:
-            if guard:
-                dy = dy.clone()                      # the grouped launch runs after the in-place update: keep this version
-            self._pending.append((dy, x, gw, gb))
-            return
+        dy in place on the main stream."""
         fused_db = gb if (self._fuse_colsum and gb is not None and gb.is_contiguous()) else None    # bias sums ride in the dW GEMM
         if self._side is None:
             T.grad_weight(dy, x, gw, g_scale=self.grad_scale, db=fused_db)
@@ -849,29 +810,6 @@ class DenoiserTrainEngine:
             self._dy_read = torch.cuda.Event()
             self._dy_read.record(self._side)
 
-    def _flush_dw(self) -> None:
-        """issue the noted weight / bias gradients: one grouped GEMM launch per (at most) 8 problems + the column sums"""
-        pend, self._pending = self._pending, []
-        if not pend:
-            return
-
-        def issue():
-            for k in range(0, len(pend), 8):
-                T.grad_weight_group([(dy, x, gw) for dy, x, gw, _ in pend[k:k + 8]], g_scale=self.grad_scale)
-            for dy, _, _, gb in pend:
-                if gb is not None:
-                    T.colsum(dy, gb)
-
-        if self._side is None:
-            issue()
-            return
-        self._side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._side):
-            issue()
-        for dy, x, _, _ in pend:
-            dy.record_stream(self._side)
-            x.record_stream(self._side)
-
     def _before_inplace_update(self) -> None:
         """the running residual-stream gradient is read by weight-gradient GEMMs on the side stream and then updated in
         place (dx += LayerNorm backward) on the main stream: the update waits for those reads (write-after-read across
@@ -885,8 +823,6 @@ class DenoiserTrainEngine:
     def _layer_done(self, i: int) -> None:
         """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
         from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
-        self._flush_dw()
-        self._join_side2()
         if self._armed is not None and self._side is not None and not self._exchange.active():
             # optimizer in the backward (arm_optimizer): this layer's slice of the flat buffer is final once its weight
             # gradients (side stream) and LayerNorm gradients (main stream, all queued by now) have run — update it on the side
@@ -917,8 +853,6 @@ class DenoiserTrainEngine:
                 self._exchange.layer_done(i, extra)
 
     def _all_done(self) -> None:
-        self._flush_dw()
-        self._join_side2()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._exchange.all_done(dense=self._accumulated)
@@ -1024,8 +958,6 @@ class DenoiserTrainEngine:
                        train: bool = True) -> torch.Tensor:
         """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1]"""
         pred, ctx = self.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=train)
-        if self.after_forward is not None:
-            self.after_forward()
         n = pred.shape[0] * pred.shape[1]
         sel = (part_valids.reshape(n).to(torch.bool) & ~ref_part.reshape(n).to(torch.bool)).to(torch.uint8).contiguous()
         loss, dpred = T.mse_loss(pred.reshape(n, 7), noise.reshape(n, 7).contiguous().float(), sel)
@@ -1085,13 +1017,6 @@ class FeaturePipeline:
         self.device = device
         self.stream = None                            # chosen at the first issue (see _pick_stream)
         self.pending = None
-        self.defer = False
-        self._args = None
-
-    def issue_next(self) -> None:
-        if self.defer and self.pending is None and self._args is not None:
-            data, gt, ref, draw = self._args
-            self.pending = self._issue(data, gt, ref, *draw())
 
     def _pick_stream(self):
         """the encoder's stream, once: CU-masked (PFPP_ENC_CU_FRACTION_PCT % of every XCD's CUs) when the caller's loop runs on a stream
@@ -1127,13 +1052,7 @@ class FeaturePipeline:
         `draw()` returns (noise, timesteps) for a batch."""
         if self.pending is None:
             self.pending = self._issue(data, gt, ref, *draw())
-        if self.defer:
-            # the following batch's encoder is issued later by the caller (issue_next: e.g. between the transformer's forward and
-            # backward, so that it shares the chip with the backward + weight gradients instead of with the forward)
-            cur, self.pending = self.pending, None
-            self._args = (data, gt, ref, draw)
-        else:
-            cur, self.pending = self.pending, self._issue(data, gt, ref, *draw())
+        cur, self.pending = self.pending, self._issue(data, gt, ref, *draw())
         main = torch.cuda.current_stream()
         main.wait_event(cur["event"])
         for k in ("noisy", "latent", "xyz"):

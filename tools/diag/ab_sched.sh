@@ -6,8 +6,6 @@ run "PFPP_X=0"
 run "PFPP_SIDE_CU_FRACTION_PCT=30"
 run "PFPP_SIDE_CU_FRACTION_PCT=50"
 run "PFPP_SIDE_CU_FRACTION_PCT=70"
-run "PFPP_TRAIN_DW_STREAMS=2"
-run "PFPP_BENCH_ENC_AFTER_FWD=1"
 run "PFPP_ENC_CU_FRACTION_PCT=45"
 run "PFPP_ENC_CU_FRACTION_PCT=55"
 run "PFPP_BENCH_OPT_IN_BWD=0"
