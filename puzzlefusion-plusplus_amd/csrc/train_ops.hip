@@ -264,12 +264,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   for (int64_t row = r_begin + wave; row < r_end; row += 4) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * C);
     const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
-    float4 v[VPL], d[VPL];
+    float4 v[VPL], d[VPL], o0[VPL];
+    float4* dxr = reinterpret_cast<float4*>(dx + row * C);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
       v[k] = xr[lane + 64 * k];
       d[k] = dr[lane + 64 * k];
+      o0[k] = dxr[lane + 64 * k];          // the running gradient this row is added to: fetched with the inputs, not after the four reductions
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
     const float mean = wave_sum(s) / (float)C;
@@ -294,10 +296,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
     const float c1 = wave_sum(s1) / (float)C;
     const float c2 = wave_sum(s2) / (float)C;
-    float4* dxr = reinterpret_cast<float4*>(dx + row * C);
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-      float4 o = dxr[lane + 64 * k];
+      float4 o = o0[k];
       o.x += rstd * (g[k].x - c1 - v[k].x * c2);
       o.y += rstd * (g[k].y - c1 - v[k].y * c2);
       o.z += rstd * (g[k].z - c1 - v[k].z * c2);
@@ -350,6 +351,20 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float4 v[VPL];
+  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the inputs
+  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
+  float4 m_a[VPL], m_b[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    if (mod) {
+      m_a[k] = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
+      m_b[k] = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+    } else if (gamma) {
+      m_a[k] = reinterpret_cast<const float4*>(gamma)[c4];
+      m_b[k] = reinterpret_cast<const float4*>(beta)[c4];
+    }
+  }
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
@@ -374,7 +389,6 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
   }
   const float var = wave_sum(q) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
-  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int c4 = lane + 64 * k;
@@ -384,15 +398,13 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
     o.z = (v[k].z - mean) * rstd;
     o.w = (v[k].w - mean) * rstd;
     if (mod) {
-      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
-      const float4 sh = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+      const float4 sc = m_a[k], sh = m_b[k];
       o.x = o.x * (1.0f + sc.x) + sh.x;
       o.y = o.y * (1.0f + sc.y) + sh.y;
       o.z = o.z * (1.0f + sc.z) + sh.z;
       o.w = o.w * (1.0f + sc.w) + sh.w;
     } else if (gamma) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
-      const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+      const float4 g = m_a[k], be = m_b[k];
       o.x = o.x * g.x + be.x;
       o.y = o.y * g.y + be.y;
       o.z = o.z * g.z + be.z;

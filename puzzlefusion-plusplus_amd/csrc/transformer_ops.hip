@@ -121,6 +121,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   if (row >= rows) return;
   const float4* xr = reinterpret_cast<const float4*>(x + row * C);
   float4 v[VPL];
+  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the input row
+  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
+  float4 m_a[VPL], m_b[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = lane + 64 * k;
+    if (mod) {
+      m_a[k] = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
+      m_b[k] = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+    } else if (gamma) {
+      m_a[k] = reinterpret_cast<const float4*>(gamma)[c4];
+      m_b[k] = reinterpret_cast<const float4*>(beta)[c4];
+    }
+  }
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
@@ -136,7 +150,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
   const float var = wave_sum(q) / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
-  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int c4 = lane + 64 * k;
@@ -146,15 +159,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     o.z = (v[k].z - mean) * rstd;
     o.w = (v[k].w - mean) * rstd;
     if (mod) {
-      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
-      const float4 sh = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
+      const float4 sc = m_a[k], sh = m_b[k];
       o.x = o.x * (1.0f + sc.x) + sh.x;
       o.y = o.y * (1.0f + sc.y) + sh.y;
       o.z = o.z * (1.0f + sc.z) + sh.z;
       o.w = o.w * (1.0f + sc.w) + sh.w;
     } else if (gamma) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
-      const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+      const float4 g = m_a[k], be = m_b[k];
       o.x = o.x * g.x + be.x;
       o.y = o.y * g.y + be.y;
       o.z = o.z * g.z + be.z;
