@@ -497,6 +497,46 @@ def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev):
             assert (a["stats"][k] - b["stats"][k]).abs().max() <= 1e-6 * max(1.0, float(b["stats"][k].abs().max())), k
 
 
+def test_encoder_train_chain_full_size_properties(weights_sd, dev):
+    """BASELINE configs[1] size (154 fragments x 1024 points, 1.26 M rows per level): the recomputing chain launches against the layer-wise
+    fused-BatchNorm GEMMs — identical sampling, features within 2e-5 of their scale, the batch statistics the two paths hand to
+    BatchNorm (running buffers after one pass) within 1e-6; a second run of the chain path reproduces its own features to 1e-6 (the only
+    run-to-run freedom is the order of the fp64 atomics behind the batch sums)."""
+    from pfpp_hip import config, encoder, synthetic
+    from pfpp_hip.encoder import pn2_encode
+    from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
+
+    data = synthetic.make_batch(0, 32, num_points=1024)
+    v = data["part_valids"].bool()
+    pts = data["part_pcs"][v].contiguous().to(dev)
+    assert pts.shape[0] == 154
+    res = {}
+    prev = encoder.SA_TRAIN_CHAIN
+    try:
+        for tag, chain in (("layer", False), ("chain", True), ("chain2", True)):
+            encoder.SA_TRAIN_CHAIN = chain
+            enc = VQVAE(config.denoiser_config())
+            enc.load_state_dict(weights_sd("vqvae"), strict=True)
+            enc = enc.to(dev).train()
+            for p in enc.parameters():
+                p.requires_grad = False
+            cap = {}
+            z_e, xyz = pn2_encode(enc.packed_train(), pts, 25, cap)
+            torch.cuda.synchronize()
+            res[tag] = dict(z_e=z_e.cpu(), xyz=xyz.cpu(), f2=cap["sa2.new_points"].cpu(), f1=cap["sa1.new_points"].cpu(),
+                            stats={k: t.detach().cpu().clone() for k, t in enc.state_dict().items() if "running" in k})
+    finally:
+        encoder.SA_TRAIN_CHAIN = prev
+    a, b, c = res["chain"], res["layer"], res["chain2"]
+    assert torch.equal(a["xyz"], b["xyz"])
+    for k in ("f1", "f2", "z_e"):
+        assert torch.isfinite(a[k]).all()
+        assert (a[k] - b[k]).abs().max() <= 2e-5 * b[k].abs().max(), k
+        assert (a[k] - c[k]).abs().max() <= 1e-6 * a[k].abs().max(), k
+    for k in b["stats"]:
+        assert (a["stats"][k] - b["stats"][k]).abs().max() <= 1e-6 * max(1.0, float(b["stats"][k].abs().max())), k
+
+
 def _ddp_worker(rank, world, port, out_q):
     import os
     import sys
