@@ -323,6 +323,10 @@ int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_
  *     y_2 (y_out [F*S*ns, C2]: the third layer's weights do not fit in LDS next to the others); stage 3 READS y_out, applies
  *     relu(fma(y_2, a_mul[1], a_add[1])), runs the third convolution with its weight planes resident in LDS and writes the sums
  *     of y_3 and out_max / out_min [F*S, C3] (only w_hi[2] / w_lo[2] / bias[2] / a_mul[1] / a_add[1] are read).
+ *   feats != NULL with D == 256 (sa3, pn2.py:18): ns == 64, widths 256 / 256 / 512.  No two of its weight matrices fit in LDS together,
+ *     so every stage is ONE layer: stage 1 gathers and writes the raw rows y_1 (y_out [F*S*ns, 256]), stage 2 reads them (y_in),
+ *     normalises with a_mul[0] / a_add[0] and writes y_2 (y_out), stage 3 reads y_2 (y_in, a_mul[1] / a_add[1]) and writes the sums and
+ *     out_max / out_min [F*S, 512]; a workgroup keeps a 128-column slice of the layer's weight planes in LDS.
  * Weight planes as for pfpp_sa_mlp3_fused / pfpp_sa_mlp2_fused (raw conv weights, BatchNorm NOT folded).
  * max_workgroups: persistent grid size (0 = 256, one workgroup per CU; pass the CU count of a CU-masked stream). */
 typedef struct pfpp_sa_train_args {
@@ -337,7 +341,8 @@ typedef struct pfpp_sa_train_args {
   const float* a_add[2];
   double* stats;               /* [stats_copies][2][C_stage] */
   int64_t stats_copies;
-  float* y_out;                /* feats != NULL: written by stage 2, read by stage 3 */
+  float* y_out;                /* feats != NULL: written by stage 2, read by stage 3 (D == 256: written by stages 1 and 2) */
+  const float* y_in;           /* D == 256 only: the raw rows of the previous layer (stages 2 and 3) */
   float* out_max;              /* stage 3 */
   float* out_min;
   int64_t F, N, S, ns, D, C1, C2, C3;

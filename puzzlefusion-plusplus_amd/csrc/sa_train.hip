@@ -609,6 +609,179 @@ __global__ __launch_bounds__(256, 1) void sa_rows_train_kernel(const SaTP p) {
   for (int n = 0; n < N / 32; ++n) flush_stats(p.stats, p.copies, N, n * 32 + l31, lhi, ss[n], sq[n]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide level (sa3: 256 features + 3 -> 256 -> 256 -> 512, nsample 64, 246 K rows): no two of its weight matrices fit in LDS together,
+// so it stays one launch per layer with the [rows, 256] pre-activations between them — but each layer as a ROWS kernel like the one
+// above instead of a tiled GEMM: a workgroup keeps a 128-column slice of the layer's weight planes (135-143 KB) in LDS for its
+// lifetime; a wave owns 32 rows at a time: every lane fetches the 32-byte runs of ITS row (gathered by ball-query index for layer 1,
+// contiguous raw rows of the previous layer otherwise), applies relu(fma(y, a_mul, a_add)) of the previous layer's finalised
+// statistics, splits once and keeps the 16 (17) operand fragments in registers for the slice's four column tiles.  The column
+// slices of a row group run in workgroups of the same XCD (ids a multiple of 8 apart), so the rows are fetched from HBM once.
+//   LAYER 1: gather + conv -> raw rows + sums;  LAYER 2: rows -> conv -> raw rows + sums;  LAYER 3: rows -> conv -> sums + max / min.
+template <int K, int LAYER>
+__global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, const float* __restrict__ y_in, int n_total) {
+  constexpr bool GATHER = LAYER == 1;
+  constexpr int KS = K / 16 + (GATHER ? 1 : 0);          // 16-deep steps: the features, then [dx dy dz 0 ...]
+  constexpr int KP = GATHER ? K + 8 : K;                 // row length of the weight planes in memory
+  constexpr int LD = KS * 16 + 8;                        // LDS row stride in halfs
+  constexpr int NSL = 128;                               // columns per workgroup
+  extern __shared__ __align__(16) unsigned char saw_smem[];
+  _Float16* Wh = reinterpret_cast<_Float16*>(saw_smem);
+  _Float16* Wl = Wh + NSL * LD;
+  float* M = reinterpret_cast<float*>(Wl + NSL * LD);
+  float* A = M + K;
+  const int tid = threadIdx.x;
+  const int n_slices = n_total / NSL;
+  const int row_wgs = gridDim.x / n_slices;               // workgroups per column slice
+  const int slice = blockIdx.x / row_wgs, wg_row = blockIdx.x - slice * row_wgs;
+  const _Float16* wh_g = p.wh[LAYER - 1] + (size_t)slice * NSL * KP;
+  const _Float16* wl_g = p.wl[LAYER - 1] + (size_t)slice * NSL * KP;
+  for (int i = tid; i < NSL * (LD / 8); i += 256) {
+    const int r = i / (LD / 8), c8 = i - r * (LD / 8);
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+    if (c8 * 8 < KP) {
+      vh = *reinterpret_cast<const uint4*>(wh_g + (size_t)r * KP + c8 * 8);
+      vl = *reinterpret_cast<const uint4*>(wl_g + (size_t)r * KP + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(Wh + r * LD + c8 * 8) = vh;
+    *reinterpret_cast<uint4*>(Wl + r * LD + c8 * 8) = vl;
+  }
+  if (!GATHER)
+    for (int i = tid; i < K; i += 256) { M[i] = p.am[LAYER - 2][i]; A[i] = p.aa[LAYER - 2][i]; }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int col0 = slice * NSL;
+  float bs[4];
+  double ss[4], sq[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { bs[n] = p.bias[LAYER - 1][col0 + n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+
+  // a wave walks neighbourhoods (64 rows) in two halves of 32 rows
+  const int stride = row_wgs * 4;
+  const int g0 = wg_row * 4 + wave;
+  auto load_half = [&](int g, int half, float4 (&raw)[K / 16][2], float (&q)[3], float (&c)[3]) {
+    const int gc = g < p.G ? g : p.G - 1;
+    if (GATHER) {
+      const int f = gc / p.S;
+      int id = p.idx[(int64_t)gc * 64 + half * 32 + l31];
+      id = id < p.N ? id : p.N - 1;
+      const float* row = p.feats + ((int64_t)f * p.N + id) * K + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+      const float* q3 = p.xyz + ((int64_t)f * p.N + id) * 3;
+      const float* c3 = p.ctr + (int64_t)gc * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { q[d] = q3[d]; c[d] = c3[d]; }
+    } else {
+      const float* row = y_in + ((int64_t)gc * 64 + half * 32 + l31) * K + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+    }
+  };
+  float4 raw[K / 16][2];
+  float qx[3] = {0.f, 0.f, 0.f}, cx[3] = {0.f, 0.f, 0.f};
+  load_half(g0, 0, raw, qx, cx);
+
+  for (int g = g0; g < p.G; g += stride) {
+    float mx[4], mn[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { mx[n] = -__builtin_huge_valf(); mn[n] = __builtin_huge_valf(); }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      asm volatile("" ::: "memory");
+      half8 fh[KS], fl[KS];
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        const float4 r0 = raw[ks][0], r1 = raw[ks][1];
+        float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        if (!GATHER) {
+          const float4 m0 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8), m1 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8 + 4);
+          const float4 a0 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8), a1 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8 + 4);
+          const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) x[q8] = fmaxf(__builtin_fmaf(x[q8], mv[q8], av[q8]), 0.0f);      // relu(batch-norm(y)), as the GEMM's A loader
+        }
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+          _Float16 h, l;
+          split1(x[q8], h, l);
+          fh[ks][q8] = h; fl[ks][q8] = l;
+        }
+      }
+      if (GATHER) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) { fh[KS - 1][q8] = (_Float16)0.0f; fl[KS - 1][q8] = (_Float16)0.0f; }
+        if (lhi == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            _Float16 a, b;
+            split1(__fsub_rn(qx[d], cx[d]), a, b);
+            fh[KS - 1][d] = a; fl[KS - 1][d] = b;
+          }
+        }
+      }
+      // the rows of the next half (or of the next neighbourhood) travel during this half's contraction
+      if (half == 0) load_half(g, 1, raw, qx, cx); else load_half(g + stride, 0, raw, qx, cx);
+      f32x16 acc[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8 wh[4], wl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          wh[n] = *reinterpret_cast<const half8*>(Wh + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+          wl[n] = *reinterpret_cast<const half8*>(Wl + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+        }
+        // term-major: consecutive MFMAs on different accumulators (the three products of one accumulator keep their order)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], wh[n], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wl[n], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wh[n], acc[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float s = 0.0f, q = 0.0f;
+        float* orow = LAYER < 3 ? p.y_out + ((int64_t)g * 64 + half * 32 + 4 * lhi) * n_total + col0 + n * 32 + l31 : nullptr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float y = acc[n][e] + bs[n];
+          s += y;
+          q = __builtin_fmaf(y, y, q);
+          if (LAYER == 3) { mx[n] = fmaxf(mx[n], y); mn[n] = fminf(mn[n], y); }
+          else orow[(int64_t)((e & 3) + 8 * (e >> 2)) * n_total] = y;
+        }
+        ss[n] += (double)s;
+        sq[n] += (double)q;
+      }
+    }
+    if (LAYER == 3) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float a = fmaxf(mx[n], __shfl_xor(mx[n], 32)), b = fminf(mn[n], __shfl_xor(mn[n], 32));
+        if (lhi == 0) {
+          p.out_max[(int64_t)g * n_total + col0 + n * 32 + l31] = a;
+          p.out_min[(int64_t)g * n_total + col0 + n * 32 + l31] = b;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) flush_stats(p.stats, p.copies, n_total, col0 + n * 32 + l31, lhi, ss[n], sq[n]);
+}
+
 }  // namespace
 
 extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
@@ -617,6 +790,44 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   PFPP_REQUIRE(a->F >= 0 && a->N > 0 && a->S > 0 && a->stats_copies >= 1, "bad sizes");
   const bool lvl1 = a->feats == nullptr;
   PFPP_REQUIRE(a->stage >= 1 && a->stage <= 3, "stage out of range (1..3)");
+  if (!lvl1 && a->D == 256) {
+    // wide level (sa3): one rows launch per layer, the [rows, 256] pre-activations in between
+    PFPP_SUPPORTED(a->ns == 64 && a->C1 == 256 && a->C2 == 256 && a->C3 == 512, "wide train-mode level: nsample 64, 256 features, widths 256/256/512 only");
+    const int L = a->stage;
+    PFPP_REQUIRE(a->w_hi[L - 1] && a->w_lo[L - 1] && a->bias[L - 1] && pfpp::aligned16(a->w_hi[L - 1]) && pfpp::aligned16(a->w_lo[L - 1]),
+                 "weights / bias of the layer this stage computes are missing");
+    PFPP_REQUIRE(L == 1 || (a->a_mul[L - 2] && a->a_add[L - 2] && a->y_in && pfpp::aligned16(a->y_in)), "the previous layer's rows / affine are missing");
+    PFPP_REQUIRE(L == 3 ? (a->out_max && a->out_min) : (a->y_out != nullptr), "output missing");
+    PFPP_REQUIRE(pfpp::aligned16(a->feats) && a->F * a->S < (1ll << 25), "alignment / too many neighbourhoods");
+    if (a->F == 0) return PFPP_OK;
+    SaTP p;
+    p.xyz = a->xyz; p.ctr = a->new_xyz; p.feats = a->feats; p.idx = a->idx;
+    for (int i = 0; i < 3; ++i) { p.wh[i] = (const _Float16*)a->w_hi[i]; p.wl[i] = (const _Float16*)a->w_lo[i]; p.bias[i] = a->bias[i]; }
+    for (int i = 0; i < 2; ++i) { p.am[i] = a->a_mul[i]; p.aa[i] = a->a_add[i]; }
+    p.stats = a->stats; p.copies = (int)a->stats_copies;
+    p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
+    p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
+    const int n_total = L == 3 ? 512 : 256;
+    const int n_slices = n_total / 128;
+    int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;
+    cap = cap / (8 * n_slices) * (8 * n_slices);           // a whole number of 8-workgroup rounds per column slice: the slices of a row group share an XCD
+    if (cap < n_slices) cap = n_slices;
+    const unsigned grid = (unsigned)cap;
+    constexpr size_t smem_g = (size_t)2 * 128 * ((256 / 16 + 1) * 16 + 8) * sizeof(_Float16) + 2 * 256 * sizeof(float);
+    constexpr size_t smem_r = (size_t)2 * 128 * (256 + 8) * sizeof(_Float16) + 2 * 256 * sizeof(float);
+    static bool attr_w = false;
+    if (!attr_w) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<256, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r);
+      attr_w = true;
+    }
+    hipStream_t st = pfpp::as_stream(stream);
+    if (L == 1) hipLaunchKernelGGL((sa_wide_train_kernel<256, 1>), dim3(grid), dim3(256), smem_g, st, p, a->y_in, n_total);
+    else if (L == 2) hipLaunchKernelGGL((sa_wide_train_kernel<256, 2>), dim3(grid), dim3(256), smem_r, st, p, a->y_in, n_total);
+    else hipLaunchKernelGGL((sa_wide_train_kernel<256, 3>), dim3(grid), dim3(256), smem_r, st, p, a->y_in, n_total);
+    return pfpp::check_launch("pfpp_sa_train_stage");
+  }
   const bool rows3 = !lvl1 && a->stage == 3;          // reads the raw rows stage 2 wrote: only layer 3's operands are needed
   for (int i = rows3 ? 2 : 0; i < a->stage; ++i) {
     PFPP_REQUIRE(a->w_hi[i] && a->w_lo[i] && a->bias[i], "weights / bias of a layer this stage computes are missing");

@@ -26,6 +26,8 @@ SA_FUSED = _os.environ.get("PFPP_SA_FUSED", "1") == "1"
 # train mode: levels 1 and 2 as recomputing chain launches (csrc/sa_train.hip) instead of layer-wise GEMMs over [rows, C] activations
 SA_TRAIN_CHAIN = _os.environ.get("PFPP_SA_TRAIN_CHAIN", "1") == "1"
 
+SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 in train mode as rows launches (sa_wide_train_kernel)
+
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
@@ -97,19 +99,27 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     n_chain = 3
     affs = []
     y2 = mx = mn = None
+    wide = feats is not None and feats.shape[2] == 256       # level 3: one rows launch per layer (no two weight matrices fit in LDS)
+    y_prev = None
     for i in range(n_chain):
         Cout = ws[i].N
         st = pk.get(f"{name}.stats{i}")
         if st is None:
             st = pk[f"{name}.stats{i}"] = T.bn_stats_buffer(Cout, dev)
-        if feats is not None and i == 1:
-            y2 = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
         if i == 2:
             mx = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
             mn = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
-        # level 2: stage 2 writes the raw second-layer rows, stage 3 (weights of the third convolution resident in LDS) reads them
-        ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y2 if i >= 1 else None,
-                           out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
+        if wide:
+            y_cur = torch.empty((rows, Cout), dtype=torch.float32, device=dev) if i < 2 else None
+            ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, y_in=y_prev,
+                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
+            y_prev = y_cur
+        else:
+            if feats is not None and i == 1:
+                y2 = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
+            # level 2: stage 2 writes the raw second-layer rows, stage 3 (weights of the third convolution resident in LDS) reads them
+            ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y2 if i >= 1 else None,
+                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
         affs.append(T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
                                   momentum=0.1, eps=1e-5))
     torch._foreach_add_([pk[f"{name}.nbt{i}"] for i in range(3)], 1)
@@ -125,7 +135,8 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
         widths = tuple(pk[f"{name}.w{i}"].N for i in range(3))
         feats = grp[2]
         if (feats is None and nsample == 32 and widths == (64, 64, 128)) or \
-           (feats is not None and nsample == 64 and feats.shape[2] == 128 and widths == (128, 128, 256)):
+           (feats is not None and nsample == 64 and feats.shape[2] == 128 and widths == (128, 128, 256)) or \
+           (SA_TRAIN_WIDE and feats is not None and nsample == 64 and feats.shape[2] == 256 and widths == (256, 256, 512)):
             return _sa_chain_train(pk, name, grp, nsample)
     if ops.GEMM_MODE == "f16x3" and BN_FUSED:
         # fused form: batch statistics come out of the producing GEMM's epilogue, normalise+ReLU is applied by the

@@ -507,7 +507,7 @@ PERSISTENT_WGS: Optional[int] = None
 
 def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, ws, biases,
                    affines, stats: torch.Tensor, y_out: Optional[torch.Tensor] = None, out_max: Optional[torch.Tensor] = None,
-                   out_min: Optional[torch.Tensor] = None) -> None:
+                   out_min: Optional[torch.Tensor] = None, y_in: Optional[torch.Tensor] = None) -> None:
     """one stage of the train-mode set-abstraction chain (pfpp_sa_train_stage): batch statistics of layer `stage` by recomputation
     of layers 1..stage-1 with their finalised BatchNorm affines; ws / biases = packing.PW / conv bias per layer (at least `stage` of
     them), affines = [(a_mul, a_add)] of the finalised layers (stage - 1 of them), stats = train_ops.bn_stats_buffer(C_stage)"""
@@ -518,7 +518,10 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
         raise ValueError("sa_train_stage: stats must be a contiguous float64 CUDA tensor [copies, 2, C]")
     if len(ws) < stage or len(biases) < stage or len(affines) < stage - 1:
         raise ValueError("sa_train_stage: weights / biases for layers 1..stage and affines for layers 1..stage-1 are needed")
-    if feats is not None and stage == 3 and y_out is None:
+    if feats is not None and feats.shape[-1] == 256:
+        if stage > 1 and y_in is None:
+            raise ValueError("sa_train_stage: stages 2 and 3 of the wide level read the previous layer's raw rows (y_in)")
+    elif feats is not None and stage == 3 and y_out is None:
         raise ValueError("sa_train_stage: stage 3 of a level with input features reads the raw rows stage 2 wrote (y_out)")
     a = _lib.SaTrainArgs()
     a.xyz, a.new_xyz, a.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
@@ -547,15 +550,21 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     if stats.shape[1:] != (2, widths[stage - 1]):
         raise ValueError("sa_train_stage: stats [copies, 2, C_stage] expected")
     a.stats, a.stats_copies = stats.data_ptr(), stats.shape[0]
+    wide = feats is not None and D == 256          # sa3: one layer per stage, y_out = this layer's raw rows, y_in = the previous layer's
+    if y_in is not None:
+        _chk(y_in, torch.float32, "y_in")
+        if not wide or y_in.shape != (F * S * ns, widths[stage - 2]):
+            raise ValueError("sa_train_stage: y_in is the wide level's previous-layer rows [F*S*ns, C]")
+        a.y_in = y_in.data_ptr()
     for t, nm, rows in ((y_out, "y_out", F * S * ns), (out_max, "out_max", F * S), (out_min, "out_min", F * S)):
         if t is not None:
             _chk(t, torch.float32, nm)
-            cols = widths[1] if nm == "y_out" else widths[stage - 1]
+            cols = (widths[stage - 1] if wide else widths[1]) if nm == "y_out" else widths[stage - 1]
             if t.shape != (rows, cols):
                 raise ValueError(f"sa_train_stage: {nm} must be [{rows}, {cols}]")
             setattr(a, nm, t.data_ptr())
     # the ABI fixes the supported widths; layers beyond `stage` are reported with the level's known widths
-    full = (64, 64, 128) if feats is None else (128, 128, 256)
+    full = (64, 64, 128) if feats is None else ((256, 256, 512) if D == 256 else (128, 128, 256))
     a.F, a.N, a.S, a.ns, a.D = F, N, S, ns, D
     a.C1, a.C2, a.C3 = (widths[0] or full[0]), (widths[1] or full[1]), (widths[2] or full[2])
     a.stage = stage
@@ -563,9 +572,9 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     if GEMM_TRACE is not None:            # bench.py: HIP events around the launch; FLOPs = the layers this launch actually computes
         rows = F * S * ns
         kin = [D + 3 if feats is not None else 3, full[0], full[1]]
-        layers = [2] if (feats is not None and stage == 3) else range(stage)
+        layers = [stage - 1] if wide else ([2] if (feats is not None and stage == 3) else range(stage))
         flops = sum(2.0 * rows * kin[i] * full[i] for i in layers)
-        name = (f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else
+        name = (f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else f"sa_wide_train_kernel<256, {stage}>" if wide else
                 "sa_rows_train_kernel<128, 256>" if stage == 3 else f"sa2_train_kernel<128, 128, 128, {stage}>")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
