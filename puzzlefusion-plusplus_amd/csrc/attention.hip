@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int k0 = t * KT;
-    if (t + 1 < nt) load_tile(k0 + KT);
+    load_tile(min(k0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
 
     // validity of the 32 keys of this tile as a bit mask (uniform)
     const int kidx = k0 + l31;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int k0 = t * KT;
-    if (t + 1 < nt) load_tile(k0 + KT);
+    load_tile(min(k0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
 
     const int kidx = k0 + l31;
     const bool kval = kidx < T && (!kv || kv[kidx] != 0);

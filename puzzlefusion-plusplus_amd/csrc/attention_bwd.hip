@@ -24,6 +24,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KT = 32;
 
+// tools/lab/attn_bwd_probe.hip compiles this file with AB_PROBE: shader-clock stamps between the phases of the dk/dv tile loop,
+// summed over the walk of workgroup (0, 0, 0) wave 0 and left in ab_probe_out
+#ifdef AB_PROBE
+__device__ long long ab_probe_out[16];
+#define AB_STAMP_(i, W)                                                        \
+  do {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    long long now_;                                                            \
+    asm volatile(W "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    ab_t[i] += now_ - ab_last;                                                 \
+    ab_last = now_;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  } while (0)
+#define AB_STAMP(i) AB_STAMP_(i, "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+#define AB_STAMP_NOWAIT(i) AB_STAMP_(i, "")
+#else
+#define AB_STAMP(i)
+#define AB_STAMP_NOWAIT(i)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // pass 1: dQ (and D)
 // ---------------------------------------------------------------------------------------------------
@@ -104,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dq_kernel(
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int k0 = t * KT;
-    if (t + 1 < nt) load_tile(k0 + KT);
+    load_tile(min(k0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
     const int kidx = k0 + l31;
     const bool kval = kidx < T && (!kv || kv[kidx] != 0);
     const unsigned kmask = (unsigned)(__ballot(kval) & 0xffffffffull);
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_kernel(
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int q0 = t * KT;
-    if (t + 1 < nt) load_tile(q0 + KT);
+    load_tile(min(q0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
 
     // S[q][key] = Q.K^T,  dP[q][key] = dO.V^T
     f32x16 s, dp;
@@ -490,7 +510,10 @@ __device__ __forceinline__ void ab_dq_f16_body(
     Dq = dpart + __shfl_xor(dpart, 32);
     if (dvec && q_row < T && lhi == 0) dvec[(row0 + q_row) * H + h] = Dq;
   }
-  const float lse_q = lse[(row0 + q_cl) * H + h];
+  // P = exp2(S * (scale log2 e) - lse log2 e): one fma + v_exp_f32 per entry
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float lse_q = lse[(row0 + q_cl) * H + h] * LOG2E;
+  const float sc2 = scale * LOG2E;
   ab_half8 qh[4], ql[4], gh[4], gl[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -504,22 +527,28 @@ __device__ __forceinline__ void ab_dq_f16_body(
     for (int e = 0; e < 16; ++e) dq_acc[dt][e] = 0.0f;
 
   float4 rk[F4], rv[F4];
+  int tile_k0 = 0;
+  const float* kbase = base + C;
+  const uint32_t ld32 = (uint32_t)ld;
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < F4; ++it) {
       const int idx = tid + 256 * it;
       const int r = idx / (DH / 4), c4 = idx % (DH / 4);
-      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      const float* src = kbase + (uint32_t)min(k0 + r, T - 1) * ld32 + c4 * 4;      // 32-bit offsets inside the sequence
       rk[it] = *reinterpret_cast<const float4*>(src);
       rv[it] = *reinterpret_cast<const float4*>(src + C);
     }
+    tile_k0 = k0;
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < F4; ++it) {
       const int idx = tid + 256 * it;
       const int r = idx / (DH / 4), c4 = idx % (DH / 4);
-      ab_store4(rk[it], 1.0f, r, c4, Kh[buf], Kl[buf], Kth[buf], Ktl[buf]);
+      // rows past the end of the sequence are staged as zero keys: S = 0 -> a finite P, and K^T . dS^T gets nothing from them,
+      // so the tile loop needs no per-entry key mask
+      ab_store4(rk[it], tile_k0 + r < T ? 1.0f : 0.0f, r, c4, Kh[buf], Kl[buf], Kth[buf], Ktl[buf]);
       ab_store4(rv[it], 1.0f, r, c4, Vh[buf], Vl[buf], nullptr, nullptr);
     }
   };
@@ -531,8 +560,7 @@ __device__ __forceinline__ void ab_dq_f16_body(
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int k0 = t * KT;
-    if (t + 1 < nt) load_tile(k0 + KT);
-    const unsigned kmask = (unsigned)(__ballot(k0 + l31 < T) & 0xffffffffull);
+    load_tile(min(k0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
 
     f32x16 s, dp;
 #pragma unroll
@@ -545,8 +573,7 @@ __device__ __forceinline__ void ab_dq_f16_body(
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      const float pv = (kmask >> key) & 1u ? __expf(s[e] * scale - lse_q) : 0.0f;
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[e], sc2, -lse_q));
       s[e] = pv * (dp[e] * (1.0f / AB_GS) - Dq) * (scale * AB_DS);      // dS^T * 2^14
     }
     ab_half8 sh[2], sl[2];
@@ -576,7 +603,7 @@ __device__ __forceinline__ void ab_dq_f16_body(
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dense_bwd_dq_f16_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_dense_bwd_dq_f16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
@@ -615,7 +642,6 @@ __device__ __forceinline__ void ab_dkv_f16_body(
   const float* base = qkv + row0 * ld + h * DH;
 
   const int k_row = k_base + wave * 32 + l31;
-  const bool key_ok = k_row < T;
   const float* kp = base + (int64_t)min(k_row, T - 1) * ld + C + lhi * 8;
   ab_half8 kh[4], kl[4], vh[4], vl[4];
 #pragma unroll
@@ -631,19 +657,28 @@ __device__ __forceinline__ void ab_dkv_f16_body(
 
   float4 rq[F4], rg[F4];
   float rl = 0.0f, rd = 0.0f;
+  bool rl_ok = false;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sc2 = scale * LOG2E;
+  const uint32_t ld32 = (uint32_t)ld;
+  const float* gbase = dout + row0 * (int64_t)C + h * DH;
+  const float* lbase = lse + row0 * H + h;
+  const float* dbase = dvec + row0 * H + h;
   auto load_tile = [&](int q0) {
 #pragma unroll
     for (int it = 0; it < F4; ++it) {
       const int idx = tid + 256 * it;
       const int r = idx / (DH / 4), c4 = idx % (DH / 4);
-      const int64_t qr = min(q0 + r, T - 1);
-      rq[it] = *reinterpret_cast<const float4*>(base + qr * ld + c4 * 4);
-      rg[it] = *reinterpret_cast<const float4*>(dout + (row0 + qr) * (int64_t)C + h * DH + c4 * 4);
+      const uint32_t qr = (uint32_t)min(q0 + r, T - 1);                             // 32-bit offsets inside the sequence
+      rq[it] = *reinterpret_cast<const float4*>(base + qr * ld32 + c4 * 4);
+      rg[it] = *reinterpret_cast<const float4*>(gbase + qr * (uint32_t)C + c4 * 4);
     }
     if (tid < KT) {
-      const int64_t qr = min(q0 + tid, T - 1);
-      rl = lse[(row0 + qr) * H + h];
-      rd = dvec[(row0 + qr) * H + h];
+      const uint32_t qr = (uint32_t)min(q0 + tid, T - 1);
+      // query rows past the end are staged with lse = +inf: P = exp2(-inf) = 0 without a per-entry mask
+      rl = lbase[qr * (uint32_t)H];
+      rd = dbase[qr * (uint32_t)H];
+      rl_ok = q0 + tid < T;
     }
   };
   auto store_tile = [&](int buf) {
@@ -654,17 +689,25 @@ __device__ __forceinline__ void ab_dkv_f16_body(
       ab_store4(rq[it], 1.0f, r, c4, Qh[buf], Ql[buf], Qth[buf], Qtl[buf]);
       ab_store4(rg[it], AB_GS, r, c4, Gh[buf], Gl[buf], Gth[buf], Gtl[buf]);
     }
-    if (tid < KT) { Ls[buf][tid] = rl; Ds[buf][tid] = rd; }
+    if (tid < KT) { Ls[buf][tid] = rl_ok ? rl * LOG2E : __builtin_huge_valf(); Ds[buf][tid] = rd; }
   };
 
   const int nt = (T + KT - 1) / KT;
+#ifdef AB_PROBE
+  long long ab_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long ab_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ab_last)::"memory");
+  const long long ab_first = ab_last;
+#endif
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  AB_STAMP(0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int q0 = t * KT;
-    if (t + 1 < nt) load_tile(q0 + KT);
+    load_tile(min(q0 + KT, (nt - 1) * KT));   // unconditional (a conditional load makes the compiler wait for it right here)
+    AB_STAMP_NOWAIT(1);
 
     f32x16 s, dp;
 #pragma unroll
@@ -675,17 +718,27 @@ __device__ __forceinline__ void ab_dkv_f16_body(
       s = ab_mma3(&Qh[buf][off], &Ql[buf][off], kh[c], kl[c], s);        // S[query][key]
       dp = ab_mma3(&Gh[buf][off], &Gl[buf][off], vh[c], vl[c], dp);      // dP * 2^12
     }
+    AB_STAMP_NOWAIT(2);
+    // no masks here: rows past the end carry lse = +inf (P = 0), and a key lane past the end only feeds its own columns of
+    // dK / dV, which are never stored
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      const bool ok = key_ok && (q0 + qi) < T;
-      const float pv = ok ? __expf(s[e] * scale - Ls[buf][qi]) : 0.0f;
-      s[e] = pv;
-      dp[e] = pv * (dp[e] * (1.0f / AB_GS) - Ds[buf][qi]) * (scale * AB_DS);     // dS * 2^14
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&Ls[buf][8 * g + 4 * lhi]);     // rows (e & 3) + 8 (e >> 2) + 4 lhi
+      const float4 d4 = *reinterpret_cast<const float4*>(&Ds[buf][8 * g + 4 * lhi]);
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * g + j;
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[e], sc2, -lq[j]));
+        s[e] = pv;
+        dp[e] = pv * (dp[e] * (1.0f / AB_GS) - dq_[j]) * (scale * AB_DS);     // dS * 2^14
+      }
     }
+    AB_STAMP_NOWAIT(3);
     ab_half8 ph[2], pl[2], sh[2], sl[2];
     ab_acc_to_fragments(s, lhi, ph, pl);
     ab_acc_to_fragments(dp, lhi, sh, sl);
+    AB_STAMP_NOWAIT(4);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -694,8 +747,11 @@ __device__ __forceinline__ void ab_dkv_f16_body(
         dv_acc[dt] = ab_mma3(&Gth[buf][off], &Gtl[buf][off], ph[g], pl[g], dv_acc[dt]);   // dV^T[d][key] * 2^12
         dk_acc[dt] = ab_mma3(&Qth[buf][off], &Qtl[buf][off], sh[g], sl[g], dk_acc[dt]);   // dK^T[d][key] * 2^14
       }
+    AB_STAMP_NOWAIT(5);
     if (t + 1 < nt) store_tile(buf ^ 1);
+    AB_STAMP(6);
     __syncthreads();
+    AB_STAMP(7);
   }
 
   if (k_row < T) {
@@ -717,9 +773,17 @@ __device__ __forceinline__ void ab_dkv_f16_body(
         }
       }
   }
+#ifdef AB_PROBE
+  AB_STAMP(8);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    for (int i = 0; i < 9; ++i) ab_probe_out[i] = ab_t[i];
+    ab_probe_out[9] = ab_last - ab_first;
+    ab_probe_out[10] = nt;
+  }
+#endif
 }
 
-__global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_dense_bwd_dkv_f16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
@@ -730,14 +794,14 @@ __global__ __launch_bounds__(256) void attn_dense_bwd_dkv_f16_kernel(
 // Both passes in ONE launch (D comes from attn_dense_bwd_d_kernel): workgroups [0, nblk) of a (sequence, head) take the key
 // blocks (dK, dV — the longer pass, dispatched first), [nblk, 2 nblk) the query blocks (dQ).  The two passes are independent
 // and each is as long as the longest sequence's tile walk: back to back they cost the sum, together the maximum.
-__global__ __launch_bounds__(256) void attn_dense_bwd_f16_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_dense_bwd_f16_kernel(
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, const float* __restrict__ dvec, float* __restrict__ dqkv,
-    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale) {
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
   __shared__ __align__(16) char smem[AB_DKV_SMEM > AB_DQ_SMEM ? AB_DKV_SMEM : AB_DQ_SMEM];
   const int nblk = gridDim.x >> 1;
-  if ((int)blockIdx.x < nblk) ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale);
-  else ab_dq_f16_body(smem, blockIdx.x - nblk, qkv, out, dout, lse, nullptr, dqkv, seq_off, seq_len, H, scale);
+  if ((int)blockIdx.x < nblk) ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
+  else ab_dq_f16_body(smem, blockIdx.x - nblk, qkv, out, dout, lse, nullptr, dqkv, seq_off, seq_len, H, scale, po);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1011,12 +1075,12 @@ extern "C" int pfpp_attn_dense_bwd_p(const float* qkv, const float* out, const f
     // opt-in: measured slower (training iteration 8.43 -> 8.50 ms) — the longest sequence's workgroups of the two passes
     // then share SIMDs and each walks its tiles more slowly than alone
     static const bool merged = getenv("PFPP_ATTN_BWD_MERGED") && atoi(getenv("PFPP_ATTN_BWD_MERGED")) == 1;
-    if (merged && !dqkv_planes) {
+    if (merged) {
       const int Hi = (int)H;
       hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
       const dim3 grid2(2 * grid.x, grid.y, grid.z);
       hipLaunchKernelGGL(attn_dense_bwd_f16_kernel, grid2, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
-                         Hi, scale);
+                         Hi, scale, po);
       return pfpp::check_launch(__func__);
     }
     hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,

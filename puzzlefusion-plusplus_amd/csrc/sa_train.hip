@@ -609,6 +609,115 @@ __global__ __launch_bounds__(256, 1) void sa_rows_train_kernel(const SaTP p) {
   for (int n = 0; n < N / 32; ++n) flush_stats(p.stats, p.copies, N, n * 32 + l31, lhi, ss[n], sq[n]);
 }
 
+// The same stage with EIGHT waves per workgroup, two per SIMD: a wave takes half a neighbourhood (32 rows) at a time, so its raw rows,
+// operand fragments and one accumulator tile fit in 256 registers and the split / statistics arithmetic of one wave runs under the
+// matrix instructions of the other wave of its SIMD (with one wave per SIMD they alternate: 37 % of the matrix peak).  The weight
+// fragments are read from LDS once per 32 rows instead of once per 64; the neighbourhood's max / min are carried across its two halves.
+template <int K, int N>
+__global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
+  constexpr int LD = K + 8;
+  constexpr int NWAVE = 8;
+  extern __shared__ __align__(16) unsigned char sar_smem[];
+  _Float16* Wh = reinterpret_cast<_Float16*>(sar_smem);
+  _Float16* Wl = Wh + N * LD;
+  float* M = reinterpret_cast<float*>(Wl + N * LD);
+  float* A = M + K;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N * (K / 8); i += 64 * NWAVE) {
+    const int r = i / (K / 8), c8 = i - r * (K / 8);
+    *reinterpret_cast<uint4*>(Wh + r * LD + c8 * 8) = *reinterpret_cast<const uint4*>(p.wh[2] + (size_t)r * K + c8 * 8);
+    *reinterpret_cast<uint4*>(Wl + r * LD + c8 * 8) = *reinterpret_cast<const uint4*>(p.wl[2] + (size_t)r * K + c8 * 8);
+  }
+  for (int i = tid; i < K; i += 64 * NWAVE) { M[i] = p.am[1][i]; A[i] = p.aa[1][i]; }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float bs[N / 32];
+  double ss[N / 32], sq[N / 32];
+#pragma unroll
+  for (int n = 0; n < N / 32; ++n) { bs[n] = p.bias[2][n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+
+  const int stride = gridDim.x * NWAVE;
+  const int g0 = blockIdx.x * NWAVE + wave;
+  const float* rows = p.y_out;
+  // half-neighbourhood h (0, 1) of neighbourhood g: rows g * 64 + 32 h + l31
+  auto load_rows = [&](int g, int h, float4 (&raw)[K / 16][2]) {
+    const int gc = g < p.G ? g : p.G - 1;
+    const float* row = rows + ((int64_t)gc * 64 + h * 32 + l31) * K + lhi * 8;
+#pragma unroll
+    for (int ks = 0; ks < K / 16; ++ks) {
+      raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+      raw[ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+    }
+  };
+  float4 raw[K / 16][2];
+  load_rows(g0, 0, raw);
+  float mx[N / 32], mn[N / 32];
+
+  for (int g = g0; g < p.G; g += stride) {
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      asm volatile("" ::: "memory");
+      half8 fh[K / 16], fl[K / 16];
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        const float4 m0 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8), m1 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8 + 4);
+        const float4 a0 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8), a1 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8 + 4);
+        const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float4 r0 = raw[ks][0], r1 = raw[ks][1];
+        const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float v = fmaxf(__builtin_fmaf(x[q], mv[q], av[q]), 0.0f);     // relu(batch-norm(y_2)), as the GEMM's A loader
+          _Float16 hh, ll;
+          split1(v, hh, ll);
+          fh[ks][q] = hh; fl[ks][q] = ll;
+        }
+      }
+      // the next half's rows are in flight during this one's contraction
+      if (h == 0) load_rows(g, 1, raw);
+      else load_rows(g + stride, 0, raw);
+#pragma unroll 1
+      for (int n = 0; n < N / 32; ++n) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) {
+          const half8 wh = *reinterpret_cast<const half8*>(Wh + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+          const half8 wl = *reinterpret_cast<const half8*>(Wl + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], wh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wh, acc, 0, 0, 0);
+        }
+        float s = 0.0f, q = 0.0f, hi = -__builtin_huge_valf(), lo = __builtin_huge_valf();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float y = acc[e] + bs[n];
+          s += y;
+          q = __builtin_fmaf(y, y, q);
+          hi = fmaxf(hi, y); lo = fminf(lo, y);
+        }
+        ss[n] += (double)s;
+        sq[n] += (double)q;
+        if (h == 0) { mx[n] = hi; mn[n] = lo; }
+        else {
+          hi = fmaxf(hi, mx[n]); lo = fminf(lo, mn[n]);
+          hi = fmaxf(hi, __shfl_xor(hi, 32));
+          lo = fminf(lo, __shfl_xor(lo, 32));
+          if (lhi == 0) {
+            p.out_max[(int64_t)g * N + n * 32 + l31] = hi;
+            p.out_min[(int64_t)g * N + n * 32 + l31] = lo;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N / 32; ++n) flush_stats(p.stats, p.copies, N, n * 32 + l31, lhi, ss[n], sq[n]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Wide level (sa3: 256 features + 3 -> 256 -> 256 -> 512, nsample 64, 246 K rows): no two of its weight matrices fit in LDS together,
 // so it stays one launch per layer with the [rows, 256] pre-activations between them — but each layer as a ROWS kernel like the one
@@ -874,13 +983,20 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_rows_train_kernel<c2, c3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_rows8_train_kernel<c2, c3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
       attr_set = true;
     }
     if (a->stage == 1) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 1>), dim3(grid), dim3(256), smem1, st, p);
     else if (a->stage == 2) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 2>), dim3(grid), dim3(256), smem2, st, p);
-    else hipLaunchKernelGGL((sa_rows_train_kernel<c2, c3>), dim3(grid), dim3(256), smem3, st, p);
+    else {
+      // two waves per SIMD (8-wave workgroups, half a neighbourhood per wave step) unless PFPP_SA_ROWS8=0
+      static const bool rows8 = !(getenv("PFPP_SA_ROWS8") && atoi(getenv("PFPP_SA_ROWS8")) == 0);
+      const int64_t need8 = (p.G + 7) / 8;
+      if (rows8) hipLaunchKernelGGL((sa_rows8_train_kernel<c2, c3>), dim3((unsigned)(need8 < cap ? need8 : cap)), dim3(512), smem3, st, p);
+      else hipLaunchKernelGGL((sa_rows_train_kernel<c2, c3>), dim3(grid), dim3(256), smem3, st, p);
+    }
   }
   return pfpp::check_launch("pfpp_sa_train_stage");
 }
