@@ -1012,6 +1012,179 @@ __global__ __launch_bounds__(256) void attn_blockdiag_bwd_mfma_kernel(const floa
   second(base, ld, dp, gb + C);                                                // dK^T = Q^T . dS   -> dk rows
 }
 
+
+// The same with the split-f16 contraction (three v_mfma_f32_32x32x16_f16 per 16-deep step: 84 matrix instructions of 32 cycles per
+// pair instead of 224 of 64).  One wave = one workgroup = one (fragment, head).  The lane's row pieces of q, k, v, dO are split
+// once into operand fragments that serve both orientations of the four first-stage products; the second-stage products need
+// q, k, dO TRANSPOSED (dims on lanes, tokens along the contraction): their row-major planes go to LDS once and come back
+// through ds_read_b64_tr_b16 (each lane of a 16-lane group gets the 4 token-consecutive halfs of its own dim).  Gradient
+// operands are lifted like in the dense passes (dO by 2^12, dS by 2^14).
+constexpr int BDF_LD = BD_DH + 8;                      // halfs per token row of an LDS plane
+constexpr int BDF_PLANE = BD_L * BDF_LD * 2;           // bytes
+
+// 8 transposed operand fragments (2 dim tiles x 2 token halves, hi and lo) of the planes at LDS byte address `ad` (hi; lo one plane up)
+__device__ __forceinline__ void bdf_read_tr(uint32_t ad, ab_half8 (&ah)[2][2], ab_half8 (&al)[2][2]) {
+  ab_half4 h[2][2][2], l[2][2][2];      // [tile][g][t]
+#define BDF_OFF(tile, g, t, pl) ((pl) * BDF_PLANE + ((16 * (g) + 4 * (t)) * BDF_LD + 32 * (tile)) * 2)
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16 offset:%17\n\tds_read_b64_tr_b16 %1, %16 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:%19\n\tds_read_b64_tr_b16 %3, %16 offset:%20\n\t"
+      "ds_read_b64_tr_b16 %4, %16 offset:%21\n\tds_read_b64_tr_b16 %5, %16 offset:%22\n\t"
+      "ds_read_b64_tr_b16 %6, %16 offset:%23\n\tds_read_b64_tr_b16 %7, %16 offset:%24\n\t"
+      "ds_read_b64_tr_b16 %8, %16 offset:%25\n\tds_read_b64_tr_b16 %9, %16 offset:%26\n\t"
+      "ds_read_b64_tr_b16 %10, %16 offset:%27\n\tds_read_b64_tr_b16 %11, %16 offset:%28\n\t"
+      "ds_read_b64_tr_b16 %12, %16 offset:%29\n\tds_read_b64_tr_b16 %13, %16 offset:%30\n\t"
+      "ds_read_b64_tr_b16 %14, %16 offset:%31\n\tds_read_b64_tr_b16 %15, %16 offset:%32\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(h[0][0][0]), "=&v"(h[0][0][1]), "=&v"(h[0][1][0]), "=&v"(h[0][1][1]), "=&v"(h[1][0][0]), "=&v"(h[1][0][1]),
+        "=&v"(h[1][1][0]), "=&v"(h[1][1][1]), "=&v"(l[0][0][0]), "=&v"(l[0][0][1]), "=&v"(l[0][1][0]), "=&v"(l[0][1][1]),
+        "=&v"(l[1][0][0]), "=&v"(l[1][0][1]), "=&v"(l[1][1][0]), "=&v"(l[1][1][1])
+      : "v"(ad), "n"(BDF_OFF(0, 0, 0, 0)), "n"(BDF_OFF(0, 0, 1, 0)), "n"(BDF_OFF(0, 1, 0, 0)), "n"(BDF_OFF(0, 1, 1, 0)),
+        "n"(BDF_OFF(1, 0, 0, 0)), "n"(BDF_OFF(1, 0, 1, 0)), "n"(BDF_OFF(1, 1, 0, 0)), "n"(BDF_OFF(1, 1, 1, 0)),
+        "n"(BDF_OFF(0, 0, 0, 1)), "n"(BDF_OFF(0, 0, 1, 1)), "n"(BDF_OFF(0, 1, 0, 1)), "n"(BDF_OFF(0, 1, 1, 1)),
+        "n"(BDF_OFF(1, 0, 0, 1)), "n"(BDF_OFF(1, 0, 1, 1)), "n"(BDF_OFF(1, 1, 0, 1)), "n"(BDF_OFF(1, 1, 1, 1))
+      : "memory");
+#undef BDF_OFF
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ah[tile][g][q] = h[tile][g][0][q]; ah[tile][g][4 + q] = h[tile][g][1][q];
+        al[tile][g][q] = l[tile][g][0][q]; al[tile][g][4 + q] = l[tile][g][1][q];
+      }
+}
+
+__device__ __forceinline__ f32x16 bdf_mma3(const ab_half8 ah, const ab_half8 al, const ab_half8 bh, const ab_half8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  return acc;
+}
+
+__global__ __launch_bounds__(64) void attn_blockdiag_bwd_f16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                    float* __restrict__ dqkv, int64_t n_pairs, int L, int H,
+                                                                    float scale, pfpp_planes_out po) {
+  __shared__ __align__(16) _Float16 planes[3][2][BD_L * BDF_LD];      // q, k, dO x (hi, lo), row-major [token][dim]
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t pair = blockIdx.x;
+  const int64_t frag = pair / H;
+  const int h = (int)(pair - frag * H);
+  const int C = H * BD_DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + frag * L * ld + h * BD_DH;                     // q of row 0; k at +C, v at +2C
+  const float* dob = dout + frag * L * (int64_t)C + h * BD_DH;
+  const int64_t gb = frag * L * ld + h * BD_DH;           // element offset of this pair's dq rows in dqkv (dk at +C, dv at +2C)
+  const int row = l31 < L ? l31 : L - 1;
+
+  // ---- this lane's row pieces -> operand fragments (registers) and, for q / k / dO, row-major planes in LDS ----
+  ab_half8 qh[4], ql[4], kh[4], kl[4], vh[4], vl[4], gh[4], gl[4];
+  {
+    const float* qrow = base + row * ld + lhi * 8;
+    const float* grow = dob + row * (int64_t)C + lhi * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ab_frag8(qrow + c * 16, 1.0f, qh[c], ql[c]);
+      ab_frag8(qrow + C + c * 16, 1.0f, kh[c], kl[c]);
+      ab_frag8(qrow + 2 * C + c * 16, 1.0f, vh[c], vl[c]);
+      ab_frag8(grow + c * 16, AB_GS, gh[c], gl[c]);
+      const int off = l31 * BDF_LD + c * 16 + lhi * 8;
+      *reinterpret_cast<ab_half8*>(&planes[0][0][off]) = qh[c];
+      *reinterpret_cast<ab_half8*>(&planes[0][1][off]) = ql[c];
+      *reinterpret_cast<ab_half8*>(&planes[1][0][off]) = kh[c];
+      *reinterpret_cast<ab_half8*>(&planes[1][1][off]) = kl[c];
+      *reinterpret_cast<ab_half8*>(&planes[2][0][off]) = gh[c];
+      *reinterpret_cast<ab_half8*>(&planes[2][1][off]) = gl[c];
+    }
+  }
+  // transposing reads: lane (q4 = lane >> 4, j = lane & 15) supplies token row 8 (q4 >> 1) + (j >> 2), dims 16 (q4 & 1) + 4 (j & 3)
+  const int q4 = lane >> 4, j = lane & 15;
+  const uint32_t tr_off = (uint32_t)(((8 * (q4 >> 1) + (j >> 2)) * BDF_LD + 16 * (q4 & 1) + 4 * (j & 3)) * 2);
+  const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&planes[0][0][0] + tr_off;
+  const uint32_t lds_k = lds_q + 2 * BDF_PLANE, lds_g = lds_q + 4 * BDF_PLANE;
+
+  auto prod = [&](const ab_half8 (&ah)[4], const ab_half8 (&al)[4], const ab_half8 (&bh)[4], const ab_half8 (&bl)[4]) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = bdf_mma3(ah[c], al[c], bh[c], bl[c], acc);
+    return acc;
+  };
+  // out^T[dim][lane] = sum_t plane[t][dim] * b[t][lane], written to the rows of dqkv at dst; b comes as accumulator (token rows t >= L
+  // carry zeros there, so the clamped duplicates in the planes do not count)
+  auto second = [&](uint32_t lds_ad, const f32x16& b, float out_scale, int64_t dst) {
+    ab_half8 bh[2], bl[2], ah[2][2], al[2][2];
+    ab_acc_to_fragments(b, lhi, bh, bl);
+    bdf_read_tr(lds_ad, ah, al);
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+      f32x16 o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) o = bdf_mma3(ah[tile][g], al[tile][g], bh[g], bl[g], o);
+      if (l31 < L) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(o[4 * q] * out_scale, o[4 * q + 1] * out_scale, o[4 * q + 2] * out_scale, o[4 * q + 3] * out_scale);
+          const int64_t idx = dst + l31 * ld + tile * 32 + 8 * q + 4 * lhi;
+          if (dqkv) *reinterpret_cast<float4*>(dqkv + idx) = v;
+          if (po.hi) pfpp_store4_planes(po, idx, v);
+        }
+      }
+    }
+  };
+
+  // ---- queries on lanes ----
+  f32x16 st = prod(kh, kl, qh, ql);            // st[e]: key (e&3)+8*(e>>2)+4*lhi, query l31
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    st[e] = key < L ? st[e] * scale : -__builtin_huge_valf();
+    mx = fmaxf(mx, st[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    st[e] = __expf(st[e] - mx);                 // masked keys: exp(-inf) = 0
+    sum += st[e];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  f32x16 dpt = prod(vh, vl, gh, gl);           // dP^T * 2^12: key x query
+  float dsum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    st[e] *= inv;                          // P^T
+    dpt[e] *= 1.0f / AB_GS;
+    dsum += st[e] * dpt[e];
+  }
+  dsum += __shfl_xor(dsum, 32);            // D[query]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dpt[e] = st[e] * (dpt[e] - dsum) * (scale * AB_DS);      // dS^T * 2^14 (0 at masked keys)
+  second(lds_k, dpt, 1.0f / AB_DS, gb);                                        // dQ^T = K^T . dS^T  -> dq rows
+
+  // ---- keys on lanes ----
+  f32x16 sk = prod(qh, ql, kh, kl);            // sk[e]: query (e&3)+8*(e>>2)+4*lhi, key l31
+  f32x16 dp = prod(gh, gl, vh, vl);            // dP * 2^12: query x key
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int qi = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    const float m_q = __shfl(mx, qi), i_q = __shfl(inv, qi), d_q = __shfl(dsum, qi);
+    const float ev = __expf(sk[e] * scale - m_q) * i_q;
+    const float pv = qi < L ? ev : 0.0f;                                        // queries >= L do not exist
+    sk[e] = pv;
+    dp[e] = pv * (dp[e] * (1.0f / AB_GS) - d_q) * (scale * AB_DS);              // dS * 2^14
+  }
+  second(lds_g, sk, 1.0f / AB_GS, gb + 2 * C);                                 // dV^T = dO^T . P   -> dv rows
+  second(lds_q, dp, 1.0f / AB_DS, gb + C);                                     // dK^T = Q^T . dS   -> dk rows
+}
+
 }  // namespace
 
 extern "C" int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L,
@@ -1030,6 +1203,14 @@ extern "C" int pfpp_attn_blockdiag_bwd_p(const float* qkv, const float* dout, fl
   const int64_t pairs = n_frag * H;
   if (pairs == 0) return PFPP_OK;
   static const bool use_mfma = !(getenv("PFPP_ATTN_BD_MFMA") && atoi(getenv("PFPP_ATTN_BD_MFMA")) == 0);
+  // split-f16 contraction unless PFPP_ATTN_BD_F16X3=0 (then the exact fp32 matrix instructions)
+  static const bool use_f16 = !(getenv("PFPP_ATTN_BD_F16X3") && atoi(getenv("PFPP_ATTN_BD_F16X3")) == 0);
+  if (use_f16 && (use_mfma || dqkv_planes)) {
+    PFPP_SUPPORTED(pairs <= 0x7fffffff, "too many (fragment, head) pairs for one launch");
+    hipLaunchKernelGGL(attn_blockdiag_bwd_f16_kernel, dim3((unsigned)pairs), dim3(64), 0, pfpp::as_stream(stream), qkv, dout, dqkv,
+                       pairs, (int)L, (int)H, scale, pfpp_planes_arg(dqkv_planes));
+    return pfpp::check_launch("pfpp_attn_blockdiag_bwd");
+  }
   if (use_mfma || dqkv_planes) {
     hipLaunchKernelGGL(attn_blockdiag_bwd_mfma_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, pfpp::as_stream(stream), qkv,
                        dout, dqkv, pairs, (int)L, (int)H, scale, pfpp_planes_arg(dqkv_planes));

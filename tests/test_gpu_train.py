@@ -311,7 +311,12 @@ def test_optimizer_step_with_fused_zero_grad(golden, weights_sd, dev):
         torch.cuda.synchronize()
         res.append((eng.flat.params.clone(), g2, eng.flat.grads.clone()))
     (p0, g0, a0), (p1, g1, a1) = res
-    assert rel(p0.cpu(), p1.cpu()) < 1.5e-3 and rel(g0.cpu(), g1.cpu()) < 1e-4      # two runs differ by atomics-order noise only
+    # two runs differ by atomics-order noise only.  Adam normalises: a gradient element that is zero up to that noise can move its
+    # parameter by +lr in one run and -lr in the other, so the parameters are compared in the 2-norm, with the largest single
+    # difference bounded by what two such steps can produce (2 steps x 2 lr)
+    dp = (p0 - p1).double()
+    assert float(dp.norm() / p0.double().norm()) < 2e-4 and float(dp.abs().max()) <= 4.1e-3
+    assert rel(g0.cpu(), g1.cpu()) < 1e-4
     assert rel(a0.cpu(), (g0 + a1).cpu()) < 1e-5          # unfused: old gradient still there; fused: started from zero
 
 
