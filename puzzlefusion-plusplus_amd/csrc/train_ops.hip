@@ -245,35 +245,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   if (r_begin >= r_end) return;
   const int64_t b = group_batch ? (int64_t)group_batch[blockIdx.x] : (mod ? g_begin / rows_per_batch : 0);
 
-  float4 mult[VPL], accA[VPL], accB[VPL];
-#pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int c4 = lane + 64 * k;
-    if (mod) {
-      const float4 sc = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
-      mult[k] = make_float4(1.0f + sc.x, 1.0f + sc.y, 1.0f + sc.z, 1.0f + sc.w);
-    } else if (gamma) {
-      mult[k] = reinterpret_cast<const float4*>(gamma)[c4];
-    } else {
-      mult[k] = make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-    accA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    accB[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+  // a wave's rows are 4 apart; the next row's three inputs are requested before this row's four reductions (unconditionally, clamped
+  // to the wave's last row: a conditional load makes the compiler wait for it on the spot)
+  float4 nv[VPL], nd[VPL], no[VPL];
+  auto fetch = [&](int64_t row) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * C);
     const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+    const float4* dxr = reinterpret_cast<const float4*>(dx + row * C);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      nv[k] = xr[lane + 64 * k];
+      nd[k] = dr[lane + 64 * k];
+      no[k] = dxr[lane + 64 * k];          // the running gradient this row is added to
+    }
+  };
+  fetch(r_begin + wave < r_end ? r_begin + wave : r_begin);       // first, so that it is in flight under the multiplier loads below
+
+  // multipliers: ONE branch-free load sequence (per-k branches on mod / gamma serialise the loads, each with its own wait)
+  float4 mult[VPL], accA[VPL], accB[VPL];
+  {
+    const float* mp = mod ? mod + b * ld_mod : gamma;
+    const float one = mod ? 1.0f : 0.0f;
+    float4 raw[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) raw[k] = mp ? reinterpret_cast<const float4*>(mp)[lane + 64 * k] : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      mult[k] = make_float4(one + raw[k].x, one + raw[k].y, one + raw[k].z, one + raw[k].w);
+      accA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      accB[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int64_t row = r_begin + wave; row < r_end; row += 4) {
     float4 v[VPL], d[VPL], o0[VPL];
     float4* dxr = reinterpret_cast<float4*>(dx + row * C);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-      v[k] = xr[lane + 64 * k];
-      d[k] = dr[lane + 64 * k];
-      o0[k] = dxr[lane + 64 * k];          // the running gradient this row is added to: fetched with the inputs, not after the four reductions
+      v[k] = nv[k]; d[k] = nd[k]; o0[k] = no[k];
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
+    fetch(row + 4 < r_end ? row + 4 : row);
     const float mean = wave_sum(s) / (float)C;
     float q = 0.0f;
 #pragma unroll
@@ -351,26 +363,38 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float4 v[VPL];
-  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the inputs
-  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
-  float4 m_a[VPL], m_b[VPL];
+  // the row's inputs first (all of them before any arithmetic): the batch index / modulation rows are a dependent chain of their own
+  float4 ya[VPL], ra[VPL];
+  {
+    const float* rp = res ? res : y;        // uniform; without a residual the second load is a repeat that is not used
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int c4 = lane + 64 * k;
-    if (mod) {
-      m_a[k] = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
-      m_b[k] = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
-    } else if (gamma) {
-      m_a[k] = reinterpret_cast<const float4*>(gamma)[c4];
-      m_b[k] = reinterpret_cast<const float4*>(beta)[c4];
+    for (int k = 0; k < VPL; ++k) {
+      ya[k] = reinterpret_cast<const float4*>(y + row * C)[lane + 64 * k];
+      ra[k] = reinterpret_cast<const float4*>(rp + row * C)[lane + 64 * k];
+    }
+  }
+  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the inputs, in one branch-free sequence
+  const int64_t grp = rows <= 0x7fffffffll ? (int64_t)((uint32_t)row / (uint32_t)(group_batch ? group_rows : rows_per_batch))
+                                           : row / (group_batch ? group_rows : rows_per_batch);
+  const int64_t b = group_batch ? (int64_t)group_batch[grp] : grp;
+  float4 m_a[VPL], m_b[VPL];
+  {
+    const float* pa = mod ? mod + b * ld_mod : gamma;
+    const float* pb = mod ? mod + b * ld_mod + C : beta;
+    if (pa) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        m_a[k] = reinterpret_cast<const float4*>(pa)[lane + 64 * k];
+        m_b[k] = reinterpret_cast<const float4*>(pb)[lane + 64 * k];
+      }
     }
   }
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int c4 = lane + 64 * k;
-    const float4 a = reinterpret_cast<const float4*>(y + row * C)[c4];
-    float4 r = res ? reinterpret_cast<const float4*>(res + row * C)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = ya[k];
+    float4 r = res ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
     const uint64_t i4 = (uint64_t)row * C + (uint64_t)c4 * 4;
     r.x += pfpp_rng_u32(seed, site, i4 + 0) >= thresh ? a.x * inv_keep : 0.0f;
     r.y += pfpp_rng_u32(seed, site, i4 + 1) >= thresh ? a.y * inv_keep : 0.0f;

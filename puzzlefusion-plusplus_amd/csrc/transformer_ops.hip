@@ -121,26 +121,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   if (row >= rows) return;
   const float4* xr = reinterpret_cast<const float4*>(x + row * C);
   float4 v[VPL];
-  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the input row
-  const int64_t b = group_batch ? (int64_t)group_batch[row / group_rows] : row / rows_per_batch;
-  float4 m_a[VPL], m_b[VPL];
+  // the row first: nothing below depends on it until the reductions, and the batch index / modulation rows are a dependent chain
+  // of their own (index load -> address -> rows) that would otherwise sit in front of it
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int c4 = lane + 64 * k;
-    if (mod) {
-      m_a[k] = reinterpret_cast<const float4*>(mod + b * ld_mod)[c4];
-      m_b[k] = reinterpret_cast<const float4*>(mod + b * ld_mod + C)[c4];
-    } else if (gamma) {
-      m_a[k] = reinterpret_cast<const float4*>(gamma)[c4];
-      m_b[k] = reinterpret_cast<const float4*>(beta)[c4];
+  for (int k = 0; k < VPL; ++k) v[k] = xr[lane + 64 * k];
+  // the (scale, shift) / (gamma, beta) rows do not depend on the reductions: fetched with the input row, in one branch-free sequence
+  const int64_t grp = rows <= 0x7fffffffll ? (int64_t)((uint32_t)row / (uint32_t)(group_batch ? group_rows : rows_per_batch))
+                                           : row / (group_batch ? group_rows : rows_per_batch);
+  const int64_t b = group_batch ? (int64_t)group_batch[grp] : grp;
+  float4 m_a[VPL], m_b[VPL];
+  {
+    const float* pa = mod ? mod + b * ld_mod : gamma;
+    const float* pb = mod ? mod + b * ld_mod + C : beta;
+    if (pa) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        m_a[k] = reinterpret_cast<const float4*>(pa)[lane + 64 * k];
+        m_b[k] = reinterpret_cast<const float4*>(pb)[lane + 64 * k];
+      }
     }
   }
   float s = 0.0f;
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    v[k] = xr[lane + 64 * k];
-    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-  }
+  for (int k = 0; k < VPL; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   const float mean = wave_sum(s) / (float)C;
   float q = 0.0f;
 #pragma unroll
