@@ -343,6 +343,11 @@ typedef struct pfpp_sa_train_args {
   int64_t stats_copies;
   float* y_out;                /* feats != NULL: written by stage 2, read by stage 3 (D == 256: written by stages 1 and 2) */
   const float* y_in;           /* D == 256 only: the raw rows of the previous layer (stages 2 and 3) */
+  const float* u_in;           /* optional, levels with features: U [F*N, C1] = the first conv applied PER POINT ([feats | xyz] . W1^T + b1,
+                                  i.e. pfpp_gemm's fused grouping with the identity index and zero centroids).  conv1 is linear, so on a
+                                  grouped row it equals U[idx] - W1_xyz . centroid: with u_in stage 1 only takes the statistics of that
+                                  (no matrix work) and stage 2 gathers its input rows from U (writes y_out [F*S*ns, C2]); stage 3 is
+                                  unchanged */
   float* out_max;              /* stage 3 */
   float* out_min;
   int64_t F, N, S, ns, D, C1, C2, C3;

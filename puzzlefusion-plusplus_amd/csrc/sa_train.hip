@@ -34,6 +34,7 @@ struct SaTP {
   double* stats; int copies;
   float* y_out; float* out_max; float* out_min;
   int N, S, G;
+  const float* u; int D;       // first layer applied per point (pfpp_sa_train_args.u_in); feature count of the level
 };
 
 // train-mode BatchNorm + ReLU of a transposed tile (lane = sample): channel of register e is c0 + (e&3) + 8*(e>>2) + 4*lhi;
@@ -727,8 +728,13 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
 // statistics, splits once and keeps the 16 (17) operand fragments in registers for the slice's four column tiles.  The column
 // slices of a row group run in workgroups of the same XCD (ids a multiple of 8 apart), so the rows are fetched from HBM once.
 //   LAYER 1: gather + conv -> raw rows + sums;  LAYER 2: rows -> conv -> raw rows + sums;  LAYER 3: rows -> conv -> sums + max / min.
-template <int K, int LAYER>
+// UG (LAYER 2 only): the layer's input rows are not read back but GATHERED from the per-point table U = conv1([feats | xyz]) + b1
+// (p.u, [F * N, K]): conv1 is linear, so its value on a grouped row is U[point] - W1_xyz . centroid, and relu(bn(.)) of it is
+// relu(fma(U[point], a_mul, a_add - a_mul * (W1_xyz . centroid))) — the same fma as the rows path with a per-NEIGHBOURHOOD add
+// vector, which every wave keeps in its own LDS slot.  The first layer's grouped convolution is never computed.
+template <int K, int LAYER, bool UG = false>
 __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, const float* __restrict__ y_in, int n_total) {
+  static_assert(!UG || LAYER == 2, "the per-point table feeds the second layer");
   constexpr bool GATHER = LAYER == 1;
   constexpr int KS = K / 16 + (GATHER ? 1 : 0);          // 16-deep steps: the features, then [dx dy dz 0 ...]
   constexpr int KP = GATHER ? K + 8 : K;                 // row length of the weight planes in memory
@@ -757,11 +763,23 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   }
   if (!GATHER)
     for (int i = tid; i < K; i += 256) { M[i] = p.am[LAYER - 2][i]; A[i] = p.aa[LAYER - 2][i]; }
+  if (UG) {
+    const int kp1 = p.D + 8;
+    for (int i = tid; i < 3 * K; i += 256) {
+      const int d = i / K, ch = i - d * K;
+      const size_t o = (size_t)ch * kp1 + p.D + d;
+      (A + 5 * K)[i] = (float)p.wh[0][o] + (float)p.wl[0][o];
+    }
+  }
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int col0 = slice * NSL;
+  // UG: this lane's channels of the add vector (K / 64 of them): multiplier, add and the three xyz weights of the first layer
+  constexpr int CPL = K / 64;
+  float* AS = UG ? A + K + wave * K : A;             // the wave's add vector of the current neighbourhood
+  float* WX = A + 5 * K;                             // UG: [3][K] xyz weights of the first layer (shared, read-only after the barrier)
   float bs[4];
   double ss[4], sq[4];
 #pragma unroll
@@ -786,6 +804,21 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
       const float* c3 = p.ctr + (int64_t)gc * 3;
 #pragma unroll
       for (int d = 0; d < 3; ++d) { q[d] = q3[d]; c[d] = c3[d]; }
+    } else if (UG) {
+      const int f = gc / p.S;
+      int id = p.idx[(int64_t)gc * 64 + half * 32 + l31];
+      id = id < p.N ? id : p.N - 1;
+      const float* row = p.u + ((int64_t)f * p.N + id) * K + lhi * 8;
+#pragma unroll
+      for (int ks = 0; ks < K / 16; ++ks) {
+        raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
+        raw[ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
+      }
+      if (half == 0) {
+        const float* c3 = p.ctr + (int64_t)gc * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) c[d] = c3[d];
+      }
     } else {
       const float* row = y_in + ((int64_t)gc * 64 + half * 32 + l31) * K + lhi * 8;
 #pragma unroll
@@ -803,6 +836,15 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
     float mx[4], mn[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { mx[n] = -__builtin_huge_valf(); mn[n] = __builtin_huge_valf(); }
+    if (UG) {
+      // this neighbourhood's add vector a_add - a_mul * (W1_xyz . centroid) (cx = its centroid, fetched with the rows of its first half)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane * CPL + c;
+        const float v = __builtin_fmaf(WX[2 * K + ch], cx[2], __builtin_fmaf(WX[K + ch], cx[1], WX[ch] * cx[0]));
+        AS[ch] = __builtin_fmaf(-M[ch], v, A[ch]);
+      }
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       asm volatile("" ::: "memory");
@@ -813,7 +855,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         if (!GATHER) {
           const float4 m0 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8), m1 = *reinterpret_cast<const float4*>(M + ks * 16 + lhi * 8 + 4);
-          const float4 a0 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8), a1 = *reinterpret_cast<const float4*>(A + ks * 16 + lhi * 8 + 4);
+          const float4 a0 = *reinterpret_cast<const float4*>(AS + ks * 16 + lhi * 8), a1 = *reinterpret_cast<const float4*>(AS + ks * 16 + lhi * 8 + 4);
           const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
           for (int q8 = 0; q8 < 8; ++q8) x[q8] = fmaxf(__builtin_fmaf(x[q8], mv[q8], av[q8]), 0.0f);      // relu(batch-norm(y)), as the GEMM's A loader
@@ -891,6 +933,65 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   for (int n = 0; n < 4; ++n) flush_stats(p.stats, p.copies, n_total, col0 + n * 32 + l31, lhi, ss[n], sq[n]);
 }
 
+// Batch statistics of the FIRST layer of a level with input features, from the per-point table (see UG above): the layer's value on
+// the grouped row (neighbourhood s, neighbour j) is U[idx[s, j]] - W1_xyz . centroid_s.  One wave per neighbourhood, lanes over the
+// channels (K / 64 each), 64 gathered rows of K floats (contiguous per row: every load instruction is one full row), nothing written
+// but the sums.  646 MB of L2 / MALL reads at level 2 instead of 42 GFLOP of split-f16 matrix work.
+template <int K>
+__global__ __launch_bounds__(256) void sa_first_stats_kernel(const SaTP p) {
+  constexpr int CPL = K / 64;
+  typedef float vecf __attribute__((ext_vector_type(CPL)));
+  __shared__ double red[2][4][K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kp1 = p.D + 8;
+  float uw[CPL][3];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const size_t o = (size_t)(lane * CPL + c) * kp1 + p.D + d;
+      uw[c][d] = (float)p.wh[0][o] + (float)p.wl[0][o];
+    }
+  double ss[CPL], sq[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { ss[c] = 0.0; sq[c] = 0.0; }
+  for (int g = blockIdx.x * 4 + wave; g < p.G; g += gridDim.x * 4) {
+    const int f = g / p.S;
+    int id = p.idx[(int64_t)g * 64 + lane];
+    id = id < p.N ? id : p.N - 1;
+    const float* c3 = p.ctr + (int64_t)g * 3;
+    const float cx = c3[0], cy = c3[1], cz = c3[2];
+    float v[CPL], s[CPL], q[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      v[c] = __builtin_fmaf(uw[c][2], cz, __builtin_fmaf(uw[c][1], cy, uw[c][0] * cx));      // the order of the UG add vector
+      s[c] = 0.0f; q[c] = 0.0f;
+    }
+    const float* ub = p.u + (int64_t)f * p.N * K + lane * CPL;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) {
+      const int idj = __shfl(id, j);
+      const vecf r = *reinterpret_cast<const vecf*>(ub + (int64_t)idj * K);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const float y = r[c] - v[c];
+        s[c] += y;
+        q[c] = __builtin_fmaf(y, y, q[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { ss[c] += (double)s[c]; sq[c] += (double)q[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { red[0][wave][lane * CPL + c] = ss[c]; red[1][wave][lane * CPL + c] = sq[c]; }
+  __syncthreads();
+  double* st = p.stats + (size_t)(blockIdx.x % p.copies) * 2 * K;
+  for (int i = tid; i < 2 * K; i += 256) {
+    const int w = i / K, c = i - w * K;
+    unsafeAtomicAdd(st + w * K + c, (red[w][0][c] + red[w][1][c]) + (red[w][2][c] + red[w][3][c]));
+  }
+}
+
 }  // namespace
 
 extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
@@ -899,6 +1000,49 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   PFPP_REQUIRE(a->F >= 0 && a->N > 0 && a->S > 0 && a->stats_copies >= 1, "bad sizes");
   const bool lvl1 = a->feats == nullptr;
   PFPP_REQUIRE(a->stage >= 1 && a->stage <= 3, "stage out of range (1..3)");
+  if (a->u_in && a->stage <= 2) {
+    // first layer by linearity: stage 1 = statistics of U[idx] - W1_xyz . centroid, stage 2 = second layer from the gathered rows
+    PFPP_REQUIRE(!lvl1, "the per-point table belongs to a level with input features");
+    PFPP_SUPPORTED(a->ns == 64 && ((a->D == 128 && a->C1 == 128 && a->C2 == 128) || (a->D == 256 && a->C1 == 256 && a->C2 == 256)),
+                   "per-point first layer: nsample 64, (128 -> 128 -> 128) or (256 -> 256 -> 256) only");
+    PFPP_REQUIRE(a->w_hi[0] && a->w_lo[0] && pfpp::aligned16(a->u_in), "first-layer planes / table alignment");
+    PFPP_REQUIRE(a->F * a->S < (1ll << 25), "too many neighbourhoods");
+    if (a->F == 0) return PFPP_OK;
+    SaTP p;
+    p.xyz = a->xyz; p.ctr = a->new_xyz; p.feats = a->feats; p.idx = a->idx;
+    for (int i = 0; i < 3; ++i) { p.wh[i] = (const _Float16*)a->w_hi[i]; p.wl[i] = (const _Float16*)a->w_lo[i]; p.bias[i] = a->bias[i]; }
+    for (int i = 0; i < 2; ++i) { p.am[i] = a->a_mul[i]; p.aa[i] = a->a_add[i]; }
+    p.stats = a->stats; p.copies = (int)a->stats_copies;
+    p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
+    p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
+    p.u = a->u_in; p.D = (int)a->D;
+    hipStream_t st = pfpp::as_stream(stream);
+    int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;
+    if (a->stage == 1) {
+      const int64_t need = (p.G + 3) / 4;
+      const unsigned grid = (unsigned)(need < 4 * cap ? need : 4 * cap);          // light workgroups: four per CU
+      if (a->D == 128) hipLaunchKernelGGL((sa_first_stats_kernel<128>), dim3(grid), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((sa_first_stats_kernel<256>), dim3(grid), dim3(256), 0, st, p);
+      return pfpp::check_launch("pfpp_sa_train_stage");
+    }
+    PFPP_REQUIRE(a->w_hi[1] && a->w_lo[1] && a->bias[1] && pfpp::aligned16(a->w_hi[1]) && pfpp::aligned16(a->w_lo[1]) && a->a_mul[0] &&
+                 a->a_add[0] && a->y_out && pfpp::aligned16(a->y_out), "second-layer operands / first-layer affine / y_out missing");
+    const int n_total = (int)a->C2;
+    const int n_slices = n_total / 128;
+    cap = cap / (8 * n_slices) * (8 * n_slices);
+    if (cap < n_slices) cap = n_slices;
+    constexpr size_t smem_128 = (size_t)2 * 128 * (128 + 8) * sizeof(_Float16) + (2 + 4 + 3) * 128 * sizeof(float);
+    constexpr size_t smem_256 = (size_t)2 * 128 * (256 + 8) * sizeof(_Float16) + (2 + 4 + 3) * 256 * sizeof(float);
+    static bool attr_u = false;
+    if (!attr_u) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<128, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_128);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<256, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_256);
+      attr_u = true;
+    }
+    if (a->D == 128) hipLaunchKernelGGL((sa_wide_train_kernel<128, 2, true>), dim3((unsigned)cap), dim3(256), smem_128, st, p, (const float*)nullptr, n_total);
+    else hipLaunchKernelGGL((sa_wide_train_kernel<256, 2, true>), dim3((unsigned)cap), dim3(256), smem_256, st, p, (const float*)nullptr, n_total);
+    return pfpp::check_launch("pfpp_sa_train_stage");
+  }
   if (!lvl1 && a->D == 256) {
     // wide level (sa3): one rows launch per layer, the [rows, 256] pre-activations in between
     PFPP_SUPPORTED(a->ns == 64 && a->C1 == 256 && a->C2 == 256 && a->C3 == 512, "wide train-mode level: nsample 64, 256 features, widths 256/256/512 only");
@@ -916,6 +1060,7 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     p.stats = a->stats; p.copies = (int)a->stats_copies;
     p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
     p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
+    p.u = nullptr; p.D = (int)a->D;
     const int n_total = L == 3 ? 512 : 256;
     const int n_slices = n_total / 128;
     int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;
@@ -966,6 +1111,7 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   p.stats = a->stats; p.copies = (int)a->stats_copies;
   p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
   p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
+  p.u = nullptr; p.D = (int)a->D;
   const int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;       // persistent: one 4-wave workgroup per CU the stream may use
   const int64_t wgs_needed = (p.G + 3) / 4;
   const unsigned grid = (unsigned)(wgs_needed < cap ? wgs_needed : cap);

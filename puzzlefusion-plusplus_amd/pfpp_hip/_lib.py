@@ -63,7 +63,7 @@ class SaTrainArgs(C.Structure):
         ("xyz", _p), ("new_xyz", _p), ("feats", _p), ("idx", _p),
         ("w_hi", _p * 3), ("w_lo", _p * 3), ("bias", _p * 3), ("a_mul", _p * 2), ("a_add", _p * 2),
         ("stats", _p), ("stats_copies", _i64),
-        ("y_out", _p), ("y_in", _p), ("out_max", _p), ("out_min", _p),
+        ("y_out", _p), ("y_in", _p), ("u_in", _p), ("out_max", _p), ("out_min", _p),
         ("F", _i64), ("N", _i64), ("S", _i64), ("ns", _i64), ("D", _i64), ("C1", _i64), ("C2", _i64), ("C3", _i64),
         ("stage", _i32), ("max_workgroups", _i64),
     ]

@@ -26,6 +26,9 @@ SA_FUSED = _os.environ.get("PFPP_SA_FUSED", "1") == "1"
 # train mode: levels 1 and 2 as recomputing chain launches (csrc/sa_train.hip) instead of layer-wise GEMMs over [rows, C] activations
 SA_TRAIN_CHAIN = _os.environ.get("PFPP_SA_TRAIN_CHAIN", "1") == "1"
 
+# first layer of the levels with features by linearity: conv1 per POINT once (ops.sa_first_table), its value on a grouped row is
+# U[point] - W_xyz . centroid — the grouped first convolution (42 / 33 GFLOP at levels 2 / 3) is never computed in train mode
+SA_TRAIN_UTAB = _os.environ.get("PFPP_SA_TRAIN_UTAB", "1") == "1"
 SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 in train mode as rows launches (sa_wide_train_kernel)
 
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
@@ -101,6 +104,7 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     y2 = mx = mn = None
     wide = feats is not None and feats.shape[2] == 256       # level 3: one rows launch per layer (no two weight matrices fit in LDS)
     y_prev = None
+    utab = ops.sa_first_table(xyz, feats, ws[0], bs[0]) if (SA_TRAIN_UTAB and feats is not None) else None
     for i in range(n_chain):
         Cout = ws[i].N
         st = pk.get(f"{name}.stats{i}")
@@ -109,7 +113,12 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
         if i == 2:
             mx = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
             mn = torch.empty((F * S, Cout), dtype=torch.float32, device=dev)
-        if wide:
+        if utab is not None and i < 2:
+            # first layer by linearity: statistics of U[idx] - W_xyz . centroid (no matrix work), then the second layer from gathered rows
+            y_cur = torch.empty((rows, Cout), dtype=torch.float32, device=dev) if i == 1 else None
+            ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, u_in=utab)
+            y_prev = y2 = y_cur
+        elif wide:
             y_cur = torch.empty((rows, Cout), dtype=torch.float32, device=dev) if i < 2 else None
             ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, y_in=y_prev,
                                out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)

@@ -480,6 +480,22 @@ def grouped_linear(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[tor
                 shift=shift, act=act, pool=pool, stats=stats, gather=(idx, xyz, new_xyz), mode="f16x3", out=out)
 
 
+_IDENT_IDX = {}
+
+
+def sa_first_table(xyz: torch.Tensor, feats: torch.Tensor, w, bias: torch.Tensor) -> torch.Tensor:
+    """U [F*N, C1] = the first 1x1 convolution of a set-abstraction level applied PER POINT: [feats | xyz] . W1^T + b1 — the fused
+    grouping of grouped_linear with the identity index and zero centroids.  conv1 is linear, so its value on the grouped row
+    (neighbourhood s, point p) is U[p] - W1_xyz . centroid_s (pfpp_sa_train_args.u_in)"""
+    F, N, _ = xyz.shape
+    key = (F, N, xyz.device.index)
+    t = _IDENT_IDX.get(key)
+    if t is None:
+        idx = torch.arange(N, dtype=torch.int32, device=xyz.device).view(1, 1, N).expand(F, 1, N).contiguous()
+        t = _IDENT_IDX[key] = (idx, torch.zeros((F, 1, 3), dtype=torch.float32, device=xyz.device))
+    return grouped_linear(xyz, t[1], feats, t[0], w, bias=bias)
+
+
 def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w0, w1, w2, s0, t0, s1, t1, s2, t2) -> torch.Tensor:
     """grouping + three folded [conv, BN, ReLU] + max over nsample of a feature-less set-abstraction level in one kernel
     (pfpp_sa_mlp3_fused); w* = packing.PW, s*/t* the folded BatchNorm scale / shift -> [F*S, C3]"""
@@ -507,10 +523,13 @@ PERSISTENT_WGS: Optional[int] = None
 
 def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, ws, biases,
                    affines, stats: torch.Tensor, y_out: Optional[torch.Tensor] = None, out_max: Optional[torch.Tensor] = None,
-                   out_min: Optional[torch.Tensor] = None, y_in: Optional[torch.Tensor] = None) -> None:
+                   out_min: Optional[torch.Tensor] = None, y_in: Optional[torch.Tensor] = None,
+                   u_in: Optional[torch.Tensor] = None) -> None:
     """one stage of the train-mode set-abstraction chain (pfpp_sa_train_stage): batch statistics of layer `stage` by recomputation
     of layers 1..stage-1 with their finalised BatchNorm affines; ws / biases = packing.PW / conv bias per layer (at least `stage` of
-    them), affines = [(a_mul, a_add)] of the finalised layers (stage - 1 of them), stats = train_ops.bn_stats_buffer(C_stage)"""
+    them), affines = [(a_mul, a_add)] of the finalised layers (stage - 1 of them), stats = train_ops.bn_stats_buffer(C_stage).
+    u_in (levels with features, stages 1 and 2): the first convolution applied per point (sa_first_table) — stage 1 then only takes
+    statistics, stage 2 gathers its rows from the table and writes y_out [F*S*ns, C2]"""
     _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx")
     F, N, _ = xyz.shape
     _, S, ns = idx.shape
@@ -518,7 +537,10 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
         raise ValueError("sa_train_stage: stats must be a contiguous float64 CUDA tensor [copies, 2, C]")
     if len(ws) < stage or len(biases) < stage or len(affines) < stage - 1:
         raise ValueError("sa_train_stage: weights / biases for layers 1..stage and affines for layers 1..stage-1 are needed")
-    if feats is not None and feats.shape[-1] == 256:
+    if u_in is not None and stage <= 2:
+        if feats is None or (stage == 2 and y_out is None):
+            raise ValueError("sa_train_stage: the per-point table belongs to a level with features; stage 2 writes y_out")
+    elif feats is not None and feats.shape[-1] == 256:
         if stage > 1 and y_in is None:
             raise ValueError("sa_train_stage: stages 2 and 3 of the wide level read the previous layer's raw rows (y_in)")
     elif feats is not None and stage == 3 and y_out is None:
@@ -551,6 +573,12 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
         raise ValueError("sa_train_stage: stats [copies, 2, C_stage] expected")
     a.stats, a.stats_copies = stats.data_ptr(), stats.shape[0]
     wide = feats is not None and D == 256          # sa3: one layer per stage, y_out = this layer's raw rows, y_in = the previous layer's
+    utab = u_in is not None and stage <= 2
+    if utab:
+        _chk(u_in, torch.float32, "u_in")
+        if u_in.shape != (F * N, widths[0]):
+            raise ValueError("sa_train_stage: u_in must be [F*N, C1]")
+        a.u_in = u_in.data_ptr()
     if y_in is not None:
         _chk(y_in, torch.float32, "y_in")
         if not wide or y_in.shape != (F * S * ns, widths[stage - 2]):
@@ -572,9 +600,10 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     if GEMM_TRACE is not None:            # bench.py: HIP events around the launch; FLOPs = the layers this launch actually computes
         rows = F * S * ns
         kin = [D + 3 if feats is not None else 3, full[0], full[1]]
-        layers = [stage - 1] if wide else ([2] if (feats is not None and stage == 3) else range(stage))
+        layers = ([] if stage == 1 else [1]) if utab else [stage - 1] if wide else ([2] if (feats is not None and stage == 3) else range(stage))
         flops = sum(2.0 * rows * kin[i] * full[i] for i in layers)
-        name = (f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else f"sa_wide_train_kernel<256, {stage}>" if wide else
+        name = ((f"sa_first_stats_kernel<{D}>" if stage == 1 else f"sa_wide_train_kernel<{D}, 2, true>") if utab else
+                f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else f"sa_wide_train_kernel<256, {stage}>" if wide else
                 "sa_rows_train_kernel<128, 256>" if stage == 3 else f"sa2_train_kernel<128, 128, 128, {stage}>")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
