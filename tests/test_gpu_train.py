@@ -458,21 +458,24 @@ def test_encoder_train_mode_batchnorm_vs_reference_golden(golden, weights_sd, de
         enc.encode(pts)
 
 
-def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev):
+@pytest.mark.parametrize("flag", ["SA_TRAIN_CHAIN", "SA_TRAIN_UTAB", "SA_TRAIN_WIDE"])
+def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev, flag):
     """train-mode set abstraction by recomputation (csrc/sa_train.hip: per-layer chain launches that write only the batch sums,
     level 2's raw second-layer rows and level 1's pooled max / min) against the layer-wise fused-BatchNorm GEMMs on the same
     fragments (F = 12 x N = 1024): same sampling, pre-quantisation features within 2e-5 of their scale, running statistics and
-    counters moved identically — the two differ only in the summation order of the fp64 batch sums"""
+    counters moved identically — the two differ only in the summation order of the fp64 batch sums.
+    flag = the switch that is turned off for the comparison run: SA_TRAIN_CHAIN (everything layer-wise), SA_TRAIN_UTAB (first layer of
+    levels 2-3 as a grouped convolution instead of the per-point table: U[p] - W_xyz . centroid), SA_TRAIN_WIDE (level 3 layer-wise)"""
     from pfpp_hip import config, encoder, ops
     from puzzlefusion_plusplus.vqvae.model.modules.vq_vae import VQVAE
 
     gen = torch.Generator().manual_seed(77)
     pts = (torch.rand(12, 1024, 3, generator=gen) * 2 - 1) * torch.rand(12, 1, 3, generator=gen)
     res = {}
-    prev = encoder.SA_TRAIN_CHAIN
+    prev = getattr(encoder, flag)
     try:
         for chain in (False, True):
-            encoder.SA_TRAIN_CHAIN = chain
+            setattr(encoder, flag, chain)
             enc = VQVAE(config.denoiser_config())
             enc.load_state_dict(weights_sd("vqvae"), strict=True)
             enc = enc.to(dev).train()
@@ -488,7 +491,7 @@ def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev):
             res[chain] = dict(z_e=z_e.cpu(), z_e2=z_e2.cpu(), xyz=xyz.cpu(), feats={k: v.cpu() for k, v in cap.items() if k.endswith("new_points")},
                               stats={k: v.detach().cpu().clone() for k, v in enc.state_dict().items() if "running" in k or "tracked" in k})
     finally:
-        encoder.SA_TRAIN_CHAIN = prev
+        setattr(encoder, flag, prev)
     a, b = res[True], res[False]
     assert torch.equal(a["xyz"], b["xyz"])
     for k in b["feats"]:
