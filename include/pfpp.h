@@ -310,6 +310,15 @@ int pfpp_sa_mlp2_fused_p(const float* feats, const float* xyz, const float* new_
                          const float* s0, const float* t0, const float* s1, const float* t1, float* out,
                          const pfpp_planes* out_planes, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1,
                          int64_t C2, pfpp_stream_t stream);
+/* The same level with its FIRST convolution taken per point instead of per grouped row (it is linear): u [F*N, C1] = [feats | xyz] .
+ * W1^T without bias (pfpp_gemm's fused grouping with the identity index and zero centroids; the folded shift t0 carries the bias), and
+ * the value on the grouped row (s, p) is u[p] - W1_xyz . new_xyz[s].  out = the planes pfpp_sa_mlp2_fused_p writes, within fp32 rounding
+ * of W1_xyz . (x - c) against W1_xyz . x - W1_xyz . c; 42 GFLOP of grouped first-layer work at F = 154 are not computed.
+ * w0 planes are read for their three xyz columns only.  max_workgroups: 0 or the CU count the stream may use. */
+int pfpp_sa_mlp2_table_p(const float* u, const float* new_xyz, const int32_t* idx, const void* w0_hi, const void* w0_lo,
+                         const void* w1_hi, const void* w1_lo, const float* s0, const float* t0, const float* s1, const float* t1,
+                         const pfpp_planes* out, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
+                         int64_t max_workgroups, pfpp_stream_t stream);
 
 /* ---- a5 in TRAIN mode (the frozen encoder stays in .train(): train_denoiser.py:33-35, utils/pn2_utils.py:203-216 with
  * BatchNorm2d on BATCH statistics) without writing the layers' activations: one launch per layer ("stage") of the chain.

@@ -35,6 +35,7 @@ struct SaTP {
   float* y_out; float* out_max; float* out_min;
   int N, S, G;
   const float* u; int D;       // first layer applied per point (pfpp_sa_train_args.u_in); feature count of the level
+  _Float16* e_hi; _Float16* e_lo;      // eval form: output planes
 };
 
 // train-mode BatchNorm + ReLU of a transposed tile (lane = sample): channel of register e is c0 + (e&3) + 8*(e>>2) + 4*lhi;
@@ -732,9 +733,12 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
 // (p.u, [F * N, K]): conv1 is linear, so its value on a grouped row is U[point] - W1_xyz . centroid, and relu(bn(.)) of it is
 // relu(fma(U[point], a_mul, a_add - a_mul * (W1_xyz . centroid))) — the same fma as the rows path with a per-NEIGHBOURHOOD add
 // vector, which every wave keeps in its own LDS slot.  The first layer's grouped convolution is never computed.
-template <int K, int LAYER, bool UG = false>
+// EVAL (with UG): the eval-mode form of the same launch (pfpp_sa_mlp2_table_p) — the affines are the FOLDED BatchNorm scale / shift of
+// layers 1 and 2, no statistics; the output is relu(fma(y2, s1, t1)) as split-f16 planes for the third layer's plane GEMM.
+template <int K, int LAYER, bool UG = false, bool EVAL = false>
 __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, const float* __restrict__ y_in, int n_total) {
   static_assert(!UG || LAYER == 2, "the per-point table feeds the second layer");
+  static_assert(!EVAL || UG, "the eval form exists for the table-fed second layer only");
   constexpr bool GATHER = LAYER == 1;
   constexpr int KS = K / 16 + (GATHER ? 1 : 0);          // 16-deep steps: the features, then [dx dy dz 0 ...]
   constexpr int KP = GATHER ? K + 8 : K;                 // row length of the weight planes in memory
@@ -783,7 +787,12 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   float bs[4];
   double ss[4], sq[4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) { bs[n] = p.bias[LAYER - 1][col0 + n * 32 + l31]; ss[n] = 0.0; sq[n] = 0.0; }
+  for (int n = 0; n < 4; ++n) { bs[n] = p.bias[LAYER - 1] ? p.bias[LAYER - 1][col0 + n * 32 + l31] : 0.0f; ss[n] = 0.0; sq[n] = 0.0; }
+  float es[EVAL ? 4 : 1], et[EVAL ? 4 : 1];
+  if (EVAL) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { es[n] = p.am[1][col0 + n * 32 + l31]; et[n] = p.aa[1][col0 + n * 32 + l31]; }
+  }
 
   // a wave walks neighbourhoods (64 rows) in two halves of 32 rows
   const int stride = row_wgs * 4;
@@ -902,6 +911,21 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wh[n], acc[n], 0, 0, 0);
       }
+      if (EVAL) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int64_t o0 = ((int64_t)g * 64 + half * 32 + 4 * lhi) * n_total + col0 + n * 32 + l31;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = fmaxf(__builtin_fmaf(acc[n][e] + bs[n], es[n], et[n]), 0.0f);
+            _Float16 h, l;
+            split1(v, h, l);
+            const int64_t o = o0 + (int64_t)((e & 3) + 8 * (e >> 2)) * n_total;
+            p.e_hi[o] = h; p.e_lo[o] = l;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         float s = 0.0f, q = 0.0f;
@@ -930,7 +954,8 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
     }
   }
 #pragma unroll
-  for (int n = 0; n < 4; ++n) flush_stats(p.stats, p.copies, n_total, col0 + n * 32 + l31, lhi, ss[n], sq[n]);
+  for (int n = 0; n < 4; ++n)
+    if (!EVAL) flush_stats(p.stats, p.copies, n_total, col0 + n * 32 + l31, lhi, ss[n], sq[n]);
 }
 
 // Batch statistics of the FIRST layer of a level with input features, from the per-point table (see UG above): the layer's value on
@@ -1145,4 +1170,41 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     }
   }
   return pfpp::check_launch("pfpp_sa_train_stage");
+}
+
+// Eval-mode level with features (sa2), layers 1 and 2 from the per-point table: u [F*N, C1] = [feats | xyz] . W1^T (NO bias: the folded
+// shift t0 carries it), (s0, t0) / (s1, t1) the folded BatchNorm scale / shift of layers 1 / 2 (utils/pn2_utils.py:210-216 in .eval()).
+// out = relu(s1 * conv2(relu(s0 * (u[idx] - W1_xyz . centroid) + t0)) + t1) as split-f16 planes [F*S*ns, C2] — what pfpp_sa_mlp2_fused_p
+// produces from the grouped first convolution, without computing it.
+extern "C" int pfpp_sa_mlp2_table_p(const float* u, const float* new_xyz, const int32_t* idx, const void* w0_hi, const void* w0_lo,
+                                    const void* w1_hi, const void* w1_lo, const float* s0, const float* t0, const float* s1,
+                                    const float* t1, const pfpp_planes* out, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D,
+                                    int64_t C1, int64_t C2, int64_t max_workgroups, pfpp_stream_t stream) {
+  PFPP_REQUIRE(u && new_xyz && idx && w0_hi && w0_lo && w1_hi && w1_lo && s0 && t0 && s1 && t1 && pfpp_planes_ok(out) && out, "null pointer");
+  PFPP_SUPPORTED(ns == 64 && D == 128 && C1 == 128 && C2 == 128, "table-fed eval level: nsample 64, 128 features, widths 128/128 only");
+  PFPP_SUPPORTED(out->scale == 1.0f, "unit plane scale only");
+  PFPP_REQUIRE(pfpp::aligned16(u) && pfpp::aligned16(w1_hi) && pfpp::aligned16(w1_lo) && F >= 0 && N > 0 && S > 0 && F * S < (1ll << 25),
+               "alignment / sizes");
+  if (F == 0) return PFPP_OK;
+  SaTP p = {};
+  p.ctr = new_xyz; p.idx = idx;
+  p.wh[0] = (const _Float16*)w0_hi; p.wl[0] = (const _Float16*)w0_lo;
+  p.wh[1] = (const _Float16*)w1_hi; p.wl[1] = (const _Float16*)w1_lo;
+  p.am[0] = s0; p.aa[0] = t0; p.am[1] = s1; p.aa[1] = t1;
+  p.N = (int)N; p.S = (int)S; p.G = (int)(F * S);
+  p.u = u; p.D = (int)D;
+  p.e_hi = (_Float16*)out->hi; p.e_lo = (_Float16*)out->lo;
+  int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
+  cap = cap / 8 * 8;
+  if (cap < 1) cap = 1;
+  const int64_t need = (p.G + 3) / 4;
+  if (need < cap) cap = need;
+  constexpr size_t smem = (size_t)2 * 128 * (128 + 8) * sizeof(_Float16) + (2 + 4 + 3) * 128 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_wide_train_kernel<128, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL((sa_wide_train_kernel<128, 2, true, true>), dim3((unsigned)cap), dim3(256), smem, pfpp::as_stream(stream), p, (const float*)nullptr, 128);
+  return pfpp::check_launch("pfpp_sa_mlp2_table_p");
 }

@@ -29,6 +29,7 @@ SA_TRAIN_CHAIN = _os.environ.get("PFPP_SA_TRAIN_CHAIN", "1") == "1"
 # first layer of the levels with features by linearity: conv1 per POINT once (ops.sa_first_table), its value on a grouped row is
 # U[point] - W_xyz . centroid — the grouped first convolution (42 / 33 GFLOP at levels 2 / 3) is never computed in train mode
 SA_TRAIN_UTAB = _os.environ.get("PFPP_SA_TRAIN_UTAB", "1") == "1"
+SA_EVAL_UTAB = _os.environ.get("PFPP_SA_EVAL_UTAB", "1") == "1"       # the same for eval-mode level 2 (ops.sa_mlp2_table)
 SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 in train mode as rows launches (sa_wide_train_kernel)
 
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
@@ -215,8 +216,13 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
         # level 2: grouping + layers 1 and 2 in one kernel, layer 3 (+ max over nsample) as a GEMM
         # the activation goes to layer 3 as split-f16 planes (same bytes as fp32): layer 3 is then the LDS-DMA plane GEMM with no
         # conversion work in its loop
-        h = ops.sa_mlp2_fused(xyz, new_xyz, grp[2], ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.s0"], pk[f"{name}.t0"],
-                              pk[f"{name}.s1"], pk[f"{name}.t1"], as_planes=ops.split_mode())
+        if SA_EVAL_UTAB and ops.split_mode() and ops.GEMM_MODE == "f16x3":
+            # first layer per point (linear): the grouped first convolution is not computed (ops.sa_mlp2_table)
+            h = ops.sa_mlp2_table(xyz, new_xyz, grp[2], ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.s0"], pk[f"{name}.t0"],
+                                  pk[f"{name}.s1"], pk[f"{name}.t1"])
+        else:
+            h = ops.sa_mlp2_fused(xyz, new_xyz, grp[2], ball, pk[f"{name}.w0"], pk[f"{name}.w1"], pk[f"{name}.s0"], pk[f"{name}.t0"],
+                                  pk[f"{name}.s1"], pk[f"{name}.t1"], as_planes=ops.split_mode())
         h = ops.linear(h, pk[f"{name}.w2"], scale=pk[f"{name}.s2"], shift=pk[f"{name}.t2"], act="relu", pool=nsample)
         new_feats = h.view(F, npoint, -1)
         if capture is not None:

@@ -642,6 +642,28 @@ def sa_mlp2_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor,
     return out
 
 
+def sa_mlp2_table(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, w1, s0, t0, s1, t1):
+    """sa_mlp2_fused(as_planes=True) with the first convolution taken per point (pfpp_sa_mlp2_table_p): u = sa_first_table without bias,
+    then one launch that gathers u[idx], subtracts W_xyz . centroid inside the folded affine and runs the second layer -> SplitAct"""
+    _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx"); _chk(feats, torch.float32, "feats")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    D = feats.shape[2]
+    for t, nm in ((s0, "s0"), (t0, "t0"), (s1, "s1"), (t1, "t1")):
+        _chk(t, torch.float32, nm)
+    if feats.shape[:2] != (F, N) or w0.hi.shape != (w0.N, D + 8) or w1.hi.shape != (w1.N, w0.N):
+        raise ValueError("sa_mlp2_table: shapes do not chain (feats [F,N,D], w0 planes [C1,D+8], w1 planes [C2,C1])")
+    if (w0.scale, w1.scale) != (1.0, 1.0):
+        raise ValueError("sa_mlp2_table reads the planes as they are: pack these weights with PW(w, prescale=False)")
+    u = sa_first_table(xyz, feats, w0, None)
+    sp = SplitAct.empty(F * S * ns, w1.N, xyz.device)
+    pc = _lib.PlanesC(sp.hi.data_ptr(), sp.lo.data_ptr(), 1.0)
+    check(_lib.load().pfpp_sa_mlp2_table_p(_ptr(u), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(w1.hi), _ptr(w1.lo), _ptr(s0),
+                                           _ptr(t0), _ptr(s1), _ptr(t1), C.byref(pc), F, N, S, ns, D, w0.N, w1.N,
+                                           int(PERSISTENT_WGS or 0), _stream()), "pfpp_sa_mlp2_table_p")
+    return sp
+
+
 # --------------------------------------------------------------------------- VQ
 def vq_encode(z_e: torch.Tensor, codebook: torch.Tensor, slot: torch.Tensor, n_slots: int,
               z_q: Optional[torch.Tensor] = None, return_codes: bool = False):
