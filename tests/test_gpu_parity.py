@@ -1410,6 +1410,13 @@ def test_sa_mlp2_fused_equals_layerwise(dev, F, N, S):
     y = torch.relu(y @ w0_ref.double().t() * sc[0].double() + sh[0].double())
     y = torch.relu(y @ w1.double().t() * sc[1].double() + sh[1].double())
     assert (got.double().cpu() - y).abs().max().item() < 2e-5 * y.abs().max().item()
+    # the same level with its first convolution taken per point (linear: u[p] - W_xyz . centroid; pfpp_sa_mlp2_table_p): split planes
+    # of the same activation, within fp32 rounding of the grouped form and of the float64 restatement
+    sp = ops.sa_mlp2_table(d(xyz), d(new_xyz), d(feats), d(idx), pw0, pw1, d(sc[0]), d(sh[0]), d(sc[1]), d(sh[1]))
+    tab = sp.hi.float() + sp.lo.float()
+    assert tab.shape == want.shape
+    assert (tab.double().cpu() - y).abs().max().item() < 2e-5 * y.abs().max().item()
+    assert (tab - want).abs().max().item() < 2e-5 * y.abs().max().item()
 
 
 @pytest.mark.gpu
