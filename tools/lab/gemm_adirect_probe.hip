@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define XCD 0      // 1: 1-D grid, workgroup ids dealt to the 8 XCDs round-robin are remapped so that an XCD owns consecutive tiles (row-major: the
 #endif             //    column tiles of a row panel share an XCD's L2)
 #ifndef ABL
-#define ABL 0      // ablations (probe only): 1 no MFMA, 2 no A loads after the first, 4 no weight loads / staging, 8 no barrier, 16 term-major MFMA order
+#define ABL 0      // ablations (probe only): 1 no MFMA, 2 no A loads after the first, 4 no weight loads / staging, 8 no barrier, 16 term-major MFMA order, 32 no epilogue stores
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void adirect_kernel(const _Float16* __restrict
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      if (row < M && col < N) C[(size_t)row * N + col] = acc[j][e];
+      if ((ABL & 32) ? (acc[j][e] == 12345.678f) : (row < M && col < N)) C[(size_t)row * N + col] = acc[j][e];      // 32: no stores
     }
   }
 }
