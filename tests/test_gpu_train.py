@@ -300,6 +300,7 @@ def test_optimizer_step_with_fused_zero_grad(golden, weights_sd, dev):
         m = make_module(weights_sd, dev)
         eng = m.train_engine()
         eng.loss_and_grads(*inp, noise, seed=3, train=False)
+        g1 = eng.flat.grads.clone()
         eng.optimizer_step(lr=1e-3, weight_decay=1e-2, zero_grad=fused)
         if fused:
             assert float(eng.flat.grads.abs().max()) == 0.0
@@ -309,15 +310,18 @@ def test_optimizer_step_with_fused_zero_grad(golden, weights_sd, dev):
         eng.optimizer_step(lr=1e-3, weight_decay=1e-2, zero_grad=fused)
         eng.loss_and_grads(*inp, noise, seed=3, train=False)      # no zero_grad() in between: accumulates onto whatever is there
         torch.cuda.synchronize()
-        res.append((eng.flat.params.clone(), g2, eng.flat.grads.clone()))
-    (p0, g0, a0), (p1, g1, a1) = res
-    # two runs differ by atomics-order noise only.  Adam normalises: a gradient element that is zero up to that noise can move its
-    # parameter by +lr in one run and -lr in the other, so the parameters are compared in the 2-norm, with the largest single
-    # difference bounded by what two such steps can produce (2 steps x 2 lr)
-    dp = (p0 - p1).double()
-    assert float(dp.norm() / p0.double().norm()) < 2e-4 and float(dp.abs().max()) <= 4.1e-3
-    assert rel(g0.cpu(), g1.cpu()) < 1e-4
-    assert rel(a0.cpu(), (g0 + a1).cpu()) < 1e-5          # unfused: old gradient still there; fused: started from zero
+        res.append((eng.flat.params.clone(), g2, eng.flat.grads.clone(), g1))
+    (p0, g0, a0, f0), (p1, g1, a1, f1) = res
+    # The two runs differ by atomics-order noise only (most of the time not at all).  Adam normalises: where a gradient element is zero
+    # up to that noise (parameters the loss does not depend on) the parameter moves by +lr in one run and -lr in the other, so the
+    # parameters are compared where both steps' gradients stand clear of the noise floor, and only bounded elsewhere (2 steps x 2 lr)
+    dp = (p0 - p1).double().abs()
+    clear = (f0.abs() > 1e-3 * f0.abs().max()) & (g0.abs() > 1e-3 * g0.abs().max())
+    assert float(clear.double().mean()) > 0.02, float(clear.double().mean())
+    assert float(dp[clear].max()) <= 2e-5, (float(dp[clear].max()), int((dp[clear] > 2e-5).sum()))
+    assert float(dp.max()) <= 4.1e-3, float(dp.max())
+    assert rel(f0.cpu(), f1.cpu()) < 1e-4 and rel(g0.cpu(), g1.cpu()) < 2e-3, (rel(f0.cpu(), f1.cpu()), rel(g0.cpu(), g1.cpu()))
+    assert rel(a0.cpu(), (g0 + a1).cpu()) < 2e-3, rel(a0.cpu(), (g0 + a1).cpu())      # unfused: old gradient still there; fused: started from zero
 
 
 def test_training_loop_as_benchmarked_converges(dev):
