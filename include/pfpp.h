@@ -319,6 +319,12 @@ int pfpp_sa_mlp2_table_p(const float* u, const float* new_xyz, const int32_t* id
                          const void* w1_hi, const void* w1_lo, const float* s0, const float* t0, const float* s1, const float* t1,
                          const pfpp_planes* out, int64_t F, int64_t N, int64_t S, int64_t ns, int64_t D, int64_t C1, int64_t C2,
                          int64_t max_workgroups, pfpp_stream_t stream);
+/* First layer alone, for the levels whose second layer is a plane GEMM (sa3 in eval mode): out = relu(s0 * (u[idx] - W1_xyz . new_xyz) + t0)
+ * as split-f16 planes [F*S*ns, C1] — what pfpp_gemm's fused grouping with the folded BatchNorm epilogue writes, as an elementwise pass over
+ * the per-point table (no matrix work on the F*S*ns grouped rows).  ns == 64; (D, C1) = (256, 256) or (128, 128). */
+int pfpp_sa_table_planes(const float* u, const float* new_xyz, const int32_t* idx, const void* w0_hi, const void* w0_lo,
+                         const float* s0, const float* t0, const pfpp_planes* out, int64_t F, int64_t N, int64_t S, int64_t ns,
+                         int64_t D, int64_t C1, pfpp_stream_t stream);
 
 /* ---- a5 in TRAIN mode (the frozen encoder stays in .train(): train_denoiser.py:33-35, utils/pn2_utils.py:203-216 with
  * BatchNorm2d on BATCH statistics) without writing the layers' activations: one launch per layer ("stage") of the chain.

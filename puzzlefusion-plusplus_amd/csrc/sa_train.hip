@@ -1017,6 +1017,60 @@ __global__ __launch_bounds__(256) void sa_first_stats_kernel(const SaTP p) {
   }
 }
 
+// Eval-mode first layer of a level with features as an ELEMENTWISE pass over the per-point table: planes of
+// relu(s0 * (u[idx] - W1_xyz . centroid) + t0) for every grouped row — what the fused-grouping GEMM with the folded BatchNorm epilogue
+// writes for the next layer's plane GEMM, without the matrix work.  One wave per neighbourhood, lanes over the channels.
+template <int K>
+__global__ __launch_bounds__(256) void sa_table_apply_kernel(const SaTP p) {
+  constexpr int CPL = K / 64;
+  typedef float vecf __attribute__((ext_vector_type(CPL)));
+  typedef _Float16 vech __attribute__((ext_vector_type(CPL)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kp1 = p.D + 8;
+  float uw[CPL][3], s0[CPL], t0[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane * CPL + c;
+    s0[c] = p.am[0][ch]; t0[c] = p.aa[0][ch];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const size_t o = (size_t)ch * kp1 + p.D + d;
+      uw[c][d] = (float)p.wh[0][o] + (float)p.wl[0][o];
+    }
+  }
+  for (int g = blockIdx.x * 4 + wave; g < p.G; g += gridDim.x * 4) {
+    const int f = g / p.S;
+    int id = p.idx[(int64_t)g * 64 + lane];
+    id = id < p.N ? id : p.N - 1;
+    const float* c3 = p.ctr + (int64_t)g * 3;
+    const float cx = c3[0], cy = c3[1], cz = c3[2];
+    float ad[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const float v = __builtin_fmaf(uw[c][2], cz, __builtin_fmaf(uw[c][1], cy, uw[c][0] * cx));
+      ad[c] = __builtin_fmaf(-s0[c], v, t0[c]);
+    }
+    const float* ub = p.u + (int64_t)f * p.N * K + lane * CPL;
+    _Float16* oh = p.e_hi + (int64_t)g * 64 * K + lane * CPL;
+    _Float16* ol = p.e_lo + (int64_t)g * 64 * K + lane * CPL;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      const int idj = __shfl(id, j);
+      const vecf r = *reinterpret_cast<const vecf*>(ub + (int64_t)idj * K);
+      vech h, l;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const float y = fmaxf(__builtin_fmaf(r[c], s0[c], ad[c]), 0.0f);
+        _Float16 a, b;
+        split1(y, a, b);
+        h[c] = a; l[c] = b;
+      }
+      *reinterpret_cast<vech*>(oh + (int64_t)j * K) = h;
+      *reinterpret_cast<vech*>(ol + (int64_t)j * K) = l;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
@@ -1207,4 +1261,30 @@ extern "C" int pfpp_sa_mlp2_table_p(const float* u, const float* new_xyz, const 
   }
   hipLaunchKernelGGL((sa_wide_train_kernel<128, 2, true, true>), dim3((unsigned)cap), dim3(256), smem, pfpp::as_stream(stream), p, (const float*)nullptr, 128);
   return pfpp::check_launch("pfpp_sa_mlp2_table_p");
+}
+
+// Eval-mode first layer of a level with features from the per-point table (see pfpp_sa_mlp2_table_p for u): out = relu(s0 * (u[idx] -
+// W1_xyz . new_xyz) + t0) as split-f16 planes [F*S*ns, C1] — the A operand of the level's second convolution.  (D, C1) = (256, 256) or
+// (128, 128), ns == 64.
+extern "C" int pfpp_sa_table_planes(const float* u, const float* new_xyz, const int32_t* idx, const void* w0_hi, const void* w0_lo,
+                                    const float* s0, const float* t0, const pfpp_planes* out, int64_t F, int64_t N, int64_t S, int64_t ns,
+                                    int64_t D, int64_t C1, pfpp_stream_t stream) {
+  PFPP_REQUIRE(u && new_xyz && idx && w0_hi && w0_lo && s0 && t0 && out && pfpp_planes_ok(out), "null pointer");
+  PFPP_SUPPORTED(ns == 64 && ((D == 256 && C1 == 256) || (D == 128 && C1 == 128)), "table-fed first layer: nsample 64, (256 -> 256) or (128 -> 128)");
+  PFPP_SUPPORTED(out->scale == 1.0f, "unit plane scale only");
+  PFPP_REQUIRE(pfpp::aligned16(u) && F >= 0 && N > 0 && S > 0 && F * S < (1ll << 25), "alignment / sizes");
+  if (F == 0) return PFPP_OK;
+  SaTP p = {};
+  p.ctr = new_xyz; p.idx = idx;
+  p.wh[0] = (const _Float16*)w0_hi; p.wl[0] = (const _Float16*)w0_lo;
+  p.am[0] = s0; p.aa[0] = t0;
+  p.N = (int)N; p.S = (int)S; p.G = (int)(F * S);
+  p.u = u; p.D = (int)D;
+  p.e_hi = (_Float16*)out->hi; p.e_lo = (_Float16*)out->lo;
+  const int64_t need = (p.G + 3) / 4;
+  const unsigned grid = (unsigned)(need < 2048 ? need : 2048);
+  hipStream_t st = pfpp::as_stream(stream);
+  if (D == 256) hipLaunchKernelGGL((sa_table_apply_kernel<256>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((sa_table_apply_kernel<128>), dim3(grid), dim3(256), 0, st, p);
+  return pfpp::check_launch("pfpp_sa_table_planes");
 }

@@ -127,6 +127,7 @@ SIGNATURES = {
     "pfpp_sa_mlp2_fused": [_p] * 13 + [_i64] * 7 + [_p],
     "pfpp_sa_mlp2_fused_p": [_p] * 13 + [_pl] + [_i64] * 7 + [_p],
     "pfpp_sa_mlp2_table_p": [_p] * 11 + [_pl] + [_i64] * 8 + [_p],
+    "pfpp_sa_table_planes": [_p] * 7 + [_pl] + [_i64] * 6 + [_p],
     "pfpp_vq_encode": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_scatter_rows": [_p, _p, _p, _i64, _i64, _p],
     "pfpp_token_features": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],

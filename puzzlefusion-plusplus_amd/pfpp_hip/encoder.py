@@ -29,7 +29,8 @@ SA_TRAIN_CHAIN = _os.environ.get("PFPP_SA_TRAIN_CHAIN", "1") == "1"
 # first layer of the levels with features by linearity: conv1 per POINT once (ops.sa_first_table), its value on a grouped row is
 # U[point] - W_xyz . centroid — the grouped first convolution (42 / 33 GFLOP at levels 2 / 3) is never computed in train mode
 SA_TRAIN_UTAB = _os.environ.get("PFPP_SA_TRAIN_UTAB", "1") == "1"
-SA_EVAL_UTAB = _os.environ.get("PFPP_SA_EVAL_UTAB", "1") == "1"       # the same for eval-mode level 2 (ops.sa_mlp2_table)
+# the same in eval mode: 0 off, 1 level 2 (ops.sa_mlp2_table), 2 levels 2 and 3 (ops.sa_table_planes feeds level 3's plane GEMMs)
+SA_EVAL_UTAB = int(_os.environ.get("PFPP_SA_EVAL_UTAB", "2"))
 SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 in train mode as rows launches (sa_wide_train_kernel)
 
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
@@ -234,7 +235,11 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
     else:
         rows = F * npoint * nsample
         sp = ops.split_mode() and ops.GEMM_MODE == "f16x3"      # activations between the layers as split-f16 planes
-        if fused:
+        if (fused and sp and SA_EVAL_UTAB >= 2 and feats is not None and nsample == 64
+                and (feats.shape[2], pk[f"{name}.w0"].N) in ((256, 256), (128, 128))):
+            # first layer per point (linear), then an elementwise pass over the grouped rows (ops.sa_table_planes)
+            h = ops.sa_table_planes(grp[0], grp[1], grp[2], grp[3], pk[f"{name}.w0"], pk[f"{name}.s0"], pk[f"{name}.t0"])
+        elif fused:
             h = ops.grouped_linear(*grp, pk[f"{name}.w0"], scale=pk[f"{name}.s0"], shift=pk[f"{name}.t0"], act="relu",
                                    out=ops.SplitAct.empty(rows, pk[f"{name}.w0"].N, xyz.device) if sp else None)
         else:

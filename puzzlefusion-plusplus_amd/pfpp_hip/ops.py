@@ -664,6 +664,24 @@ def sa_mlp2_table(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor,
     return sp
 
 
+def sa_table_planes(xyz: torch.Tensor, new_xyz: torch.Tensor, feats: torch.Tensor, idx: torch.Tensor, w0, s0, t0):
+    """first folded [conv, BN, ReLU] of a level with features on every grouped row, from the per-point table (pfpp_sa_table_planes):
+    grouped_linear(..., scale=s0, shift=t0, act="relu") as a SplitAct without the grouped matrix work"""
+    _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx"); _chk(feats, torch.float32, "feats")
+    _chk(s0, torch.float32, "s0"); _chk(t0, torch.float32, "t0")
+    F, N, _ = xyz.shape
+    _, S, ns = idx.shape
+    D = feats.shape[2]
+    if feats.shape[:2] != (F, N) or w0.hi.shape != (w0.N, D + 8) or w0.scale != 1.0:
+        raise ValueError("sa_table_planes: feats [F,N,D], w0 planes [C1, D+8] packed with PW(w, prescale=False)")
+    u = sa_first_table(xyz, feats, w0, None)
+    sp = SplitAct.empty(F * S * ns, w0.N, xyz.device)
+    pc = _lib.PlanesC(sp.hi.data_ptr(), sp.lo.data_ptr(), 1.0)
+    check(_lib.load().pfpp_sa_table_planes(_ptr(u), _ptr(new_xyz), _ptr(idx), _ptr(w0.hi), _ptr(w0.lo), _ptr(s0), _ptr(t0), C.byref(pc),
+                                           F, N, S, ns, D, w0.N, _stream()), "pfpp_sa_table_planes")
+    return sp
+
+
 # --------------------------------------------------------------------------- VQ
 def vq_encode(z_e: torch.Tensor, codebook: torch.Tensor, slot: torch.Tensor, n_slots: int,
               z_q: Optional[torch.Tensor] = None, return_codes: bool = False):

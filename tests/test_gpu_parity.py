@@ -1420,6 +1420,36 @@ def test_sa_mlp2_fused_equals_layerwise(dev, F, N, S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F,N,S,D", [(3, 128, 25, 256), (2, 192, 7, 128)])
+def test_sa_table_planes_equals_grouped_first_layer(dev, F, N, S, D):
+    """first folded conv/BN/ReLU of a level with features from the per-point table (pfpp_sa_table_planes: u[idx] - W_xyz . centroid inside
+    the affine, elementwise) against the fused-grouping GEMM with the same epilogue and a float64 restatement"""
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, pack_sa_first
+
+    g = torch.Generator().manual_seed(F * 31 + S)
+    ns = 64
+    xyz = torch.rand(F, N, 3, generator=g)
+    feats = torch.randn(F, N, D, generator=g)
+    new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
+    idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32)
+    w0_ref = torch.randn(D, D + 3, generator=g) * 0.1              # reference column order: [xyz | feats]
+    sc, sh = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.3
+    d = lambda t: t.to(dev)
+    pw0 = PW(d(pack_sa_first(w0_ref, D)), prescale=False)
+    want = ops.grouped_linear(d(xyz), d(new_xyz), d(feats), d(idx), pw0, scale=d(sc), shift=d(sh), act="relu")
+    sp = ops.sa_table_planes(d(xyz), d(new_xyz), d(feats), d(idx), pw0, d(sc), d(sh))
+    got = sp.hi.float() + sp.lo.float()
+    ii = idx.long()
+    gx = torch.gather(xyz.double().unsqueeze(1).expand(F, S, N, 3), 2, ii.unsqueeze(-1).expand(F, S, ns, 3)) - new_xyz.double().unsqueeze(2)
+    gf = torch.gather(feats.double().unsqueeze(1).expand(F, S, N, D), 2, ii.unsqueeze(-1).expand(F, S, ns, D))
+    y = torch.relu(torch.cat([gx, gf], -1).reshape(-1, D + 3) @ w0_ref.double().t() * sc.double() + sh.double())
+    assert got.shape == want.shape == (F * S * ns, D)
+    assert (got.double().cpu() - y).abs().max().item() < 2e-5 * y.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * y.abs().max().item()
+
+
+@pytest.mark.gpu
 def test_fragment_prepare_vs_reference_dataset_golden(golden, dev):
     """8f-4: the GPU augmentation kernel against what the reference's GeometryLatentDataset.__getitem__ itself returned
     (tests/golden/dataset.npz; denoiser/dataset/dataset.py:163-222) on the rotations it drew.  The kernel takes fp32 quaternions (the
