@@ -368,6 +368,10 @@ constexpr int AB_LDR = 64 + 8;          // halfs per row of a [row][dim] tile
 constexpr int AB_LDT = KT + 8;          // halfs per row of a transposed [dim][row] tile
 
 __device__ __forceinline__ void ab_split(float x, _Float16& hi, _Float16& lo) {
+  // x is pinned as a ROUNDED fp32 value first: when x is a product, the compiler may otherwise take hi from a fused multiply-convert
+  // (one rounding of the exact product) and lo from x - fp16(RN32(product)) (two roundings) — two different hi's, and in the rare
+  // double-rounding case (about 1e-4 of the values) hi + lo is off by a whole fp16 ulp of hi
+  asm("" : "+v"(x));
   const _Float16 h = (_Float16)x;
   hi = h;
   lo = (_Float16)(x - (float)h);
@@ -1185,6 +1189,96 @@ __global__ __launch_bounds__(64) void attn_blockdiag_bwd_f16_kernel(const float*
   second(lds_q, dp, 1.0f / AB_DS, gb + C);                                     // dK^T = Q^T . dS   -> dk rows
 }
 
+// Forward of the same attention with the split-f16 contraction (attention.py:77-85 per fragment; the exact-fp32 form is
+// attn_blockdiag_mfma_kernel in transformer_ops.hip: 64 matrix instructions of 64 cycles, this one 24 of 32).  One wave = one workgroup =
+// one (fragment, head): S^T = K . Q^T from the lanes' row fragments, softmax over the keys in registers, O^T = V^T . P^T with V^T read
+// back transposed from its row-major LDS planes and P^T taken from the accumulator.  The probabilities are lifted by 2^11 before the
+// split (unlifted, the lo halves of every p < 1/8 are fp16 subnormals: twice the mean error).
+constexpr float BDF_PS = 2048.0f;
+__global__ __launch_bounds__(64) void attn_blockdiag_f16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                                int64_t n_pairs, int L, int H, float scale) {
+  __shared__ __align__(16) _Float16 planes[2][BD_L * BDF_LD];       // v (hi, lo), row-major [token][dim]
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t pair = blockIdx.x;
+  const int64_t frag = pair / H;
+  const int h = (int)(pair - frag * H);
+  const int C = H * BD_DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + frag * L * ld + h * BD_DH;
+  const int row = l31 < L ? l31 : L - 1;
+  ab_half8 qh[4], ql[4], kh[4], kl[4];
+  {
+    const float* qrow = base + row * ld + lhi * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ab_half8 vh, vl;
+      ab_frag8(qrow + c * 16, 1.0f, qh[c], ql[c]);
+      ab_frag8(qrow + C + c * 16, 1.0f, kh[c], kl[c]);
+      ab_frag8(qrow + 2 * C + c * 16, 1.0f, vh, vl);
+      const int off = l31 * BDF_LD + c * 16 + lhi * 8;
+      *reinterpret_cast<ab_half8*>(&planes[0][off]) = vh;
+      *reinterpret_cast<ab_half8*>(&planes[1][off]) = vl;
+    }
+  }
+  const int q4 = lane >> 4, j = lane & 15;
+  const uint32_t lds_v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&planes[0][0] +
+                         (uint32_t)(((8 * (q4 >> 1) + (j >> 2)) * BDF_LD + 16 * (q4 & 1) + 4 * (j & 3)) * 2);
+  f32x16 st;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) st = bdf_mma3(kh[c], kl[c], qh[c], ql[c], st);      // st[e]: key (e&3)+8*(e>>2)+4*lhi, query l31
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    st[e] = key < L ? st[e] * scale : -__builtin_huge_valf();
+    mx = fmaxf(mx, st[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    st[e] = __expf(st[e] - mx);                 // masked keys: exp(-inf) = 0
+    sum += st[e];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = BDF_PS / sum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) st[e] *= inv;
+  ab_half8 bh[2], bl[2], ah[2][2], al[2][2];
+  ab_acc_to_fragments(st, lhi, bh, bl);
+  bdf_read_tr(lds_v, ah, al);
+  const int64_t orow = (frag * L + l31) * (int64_t)C + h * BD_DH;
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) o = bdf_mma3(ah[tile][g], al[tile][g], bh[g], bl[g], o);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] *= 1.0f / BDF_PS;
+    if (l31 < L) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t off = orow + tile * 32 + 8 * q + 4 * lhi;
+        if (out_hi) {
+          ab_half4 hi4, lo4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { _Float16 a, b; ab_split(o[4 * q + r], a, b); hi4[r] = a; lo4[r] = b; }
+          *reinterpret_cast<ab_half4*>(out_hi + off) = hi4;
+          *reinterpret_cast<ab_half4*>(out_lo + off) = lo4;
+        } else {
+          *reinterpret_cast<float4*>(out + off) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pfpp_attn_blockdiag_bwd(const float* qkv, const float* dout, float* dqkv, int64_t n_frag, int64_t L,
@@ -1326,3 +1420,10 @@ extern "C" int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, con
   return pfpp::check_launch(__func__);
 }
 
+// internal: the split-f16 forward of the per-fragment attention (called by pfpp_attn_blockdiag / _split in transformer_ops.hip)
+int pfpp_attn_blockdiag_f16_launch(const float* qkv, float* out, void* out_hi, void* out_lo, int64_t pairs, int64_t L, int64_t H, float scale,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(attn_blockdiag_f16_kernel, dim3((unsigned)pairs), dim3(64), 0, st, qkv, out, (_Float16*)out_hi, (_Float16*)out_lo, pairs,
+                     (int)L, (int)H, scale);
+  return pfpp::check_launch("pfpp_attn_blockdiag");
+}

@@ -27,6 +27,10 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace pfpp
 
+// internal (attention_bwd.hip): split-f16 forward of the per-fragment attention, launched by pfpp_attn_blockdiag / _split
+int pfpp_attn_blockdiag_f16_launch(const float* qkv, float* out, void* out_hi, void* out_lo, int64_t pairs, int64_t L, int64_t H, float scale,
+                                   hipStream_t st);
+
 // x = hi + lo with hi = f16(x), lo = f16(x - hi): x - hi is exact in fp32, so the pair carries 22 bits of
 // x for |x| >= 2^-3 and an absolute error <= 3e-8 below that (f16 subnormal spacing 6e-8) — the operand
 // format of the PFPP_GEMM_F16X3 path (csrc/gemm.hip).  lo is NOT pre-scaled, so hi.hi, hi.lo and lo.hi
