@@ -45,6 +45,12 @@ int pfpp_version(void);                 /* ABI version, currently 1          */
 const char* pfpp_last_error(void);
 /* number of compute units of the current device (for grid sizing in hosts) */
 int pfpp_device_cu_count(void);
+/* process-wide arithmetic of the attention FORWARD kernels (pfpp_attn_dense*, pfpp_attn_blockdiag*; diffusers Attention,
+ * attention.py:46-72 via denoiser_transformer.py:46-72): -1 = each kernel's default (split-f16 unless its PFPP_ATTN_* environment
+ * switch says otherwise), 0 = exact fp32 matrix instructions (the range fallback of the sampler loops, pfpp_hip.ops.exact_fp32),
+ * 1 = split-f16, 2 = single-pass fp16 (perf mode of BASELINE configs[4]; never a parity mode). */
+int pfpp_set_attention_mode(int mode);
+int pfpp_get_attention_mode(void);
 
 /* ---- a1: SE(3) rotate + valid-fragment gather ----------------------------
  * Denoiser._apply_rots (puzzlefusion_plusplus/denoiser/model/denoiser.py:55-63,
@@ -729,7 +735,8 @@ int pfpp_attn_dense_bwd_parts(const float* qkv, const float* out, const float* d
  * mean_pool_bwd:   dx[(f,l), :] = dpooled[f, :] / L                         (denoiser_transformer.py:139-142)
  * token_combine_bwd: dx_emb[f, :] = sum_l dtok[(f,l), :]; dref_emb[ref[f], :] += dx_emb[f, :]
  *                  (the shape-embedding gradient is dtok itself; pe is a buffer)
- * silu_embed_bwd:  dtables[i][t[b], :] += dse[i, b, :] * silu'(tables[i][t[b], :])                     */
+ * silu_embed_bwd:  dtables[i][t[b], :] += dse[i, b, :] * silu'(tables[i][t[b], :]); puzzles with equal t[b] are summed in index
+ *                  order without atomics (deterministic: data-parallel ranks scattering the same gathered list stay bit-equal) */
 int pfpp_mean_pool_bwd(const float* dpooled, float* dx, int64_t n, int64_t L, int64_t C,
                        pfpp_stream_t stream);
 int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part, float* dx_emb, float* dref_emb,
@@ -758,8 +765,9 @@ int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, 
 /* the same with the overflow guard of a loss-scaled optimizer (what torch.cuda.amp.GradScaler.step does around
  * configure_optimizers' AdamW, denoiser.py:230-241, when the backward runs on fp16 operands), entirely on the device:
  * overflow (int32[2], device memory): [0] = flag, [1] = count.  An element whose (scaled) gradient is inf / NaN is left untouched
- * (p, m, v, planes unchanged), sets the flag and adds to the count; a launch that finds the flag already set updates nothing
- * (its gradients are still cleared when zero_grad != 0).  The caller clears overflow[] between steps and reads it when it likes. */
+ * (p, m, v, planes unchanged; its gradient is still cleared when zero_grad != 0), sets the flag and adds to the count.  The kernel
+ * never READS the flag: which elements are skipped depends on their own gradient only, so the result is independent of workgroup
+ * scheduling and identical on data-parallel replicas.  The caller clears overflow[] between steps and reads it when it likes. */
 int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
                        float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);

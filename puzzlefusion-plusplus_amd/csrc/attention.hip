@@ -481,7 +481,7 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   // (Its first version stored V^T with 2-byte LDS writes: 661 us there; pairs of keys as swizzled 4-byte words fixed it.)
   // PFPP_ATTN_F16X3=0: the exact-fp32 MFMA kernel.
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
-  const bool f16x3 = f16_mode != 0;
+  const bool f16x3 = pfpp::attn_use_f16(f16_mode != 0);
   if (dh == 64 && f16x3)
     hipLaunchKernelGGL(attn_dense_f16_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                        key_valid, kv_stride, (int)H, scale, lse);

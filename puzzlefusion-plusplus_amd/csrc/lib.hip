@@ -24,7 +24,21 @@ int check_launch(const char* what) {
   return PFPP_OK;
 }
 
+static int g_attn_mode = -1;
+int attn_mode() { return g_attn_mode; }
+
 }  // namespace pfpp
+
+extern "C" int pfpp_set_attention_mode(int mode) {
+  if (mode < -1 || mode > 2) {
+    pfpp::set_error("pfpp_set_attention_mode: mode must be -1 (defaults), 0 (exact fp32), 1 (split-f16) or 2 (single-pass fp16)");
+    return PFPP_EINVAL;
+  }
+  pfpp::g_attn_mode = mode;
+  return PFPP_OK;
+}
+
+extern "C" int pfpp_get_attention_mode(void) { return pfpp::g_attn_mode; }
 
 extern "C" int pfpp_version(void) { return 1; }
 

@@ -23,6 +23,11 @@ inline hipStream_t as_stream(pfpp_stream_t s) {
 // after a launch: turn a launch failure into PFPP_EHIP
 int check_launch(const char* what);
 
+// process-wide arithmetic mode of the attention kernels (pfpp_set_attention_mode): -1 = each kernel's default (environment),
+// 0 = exact fp32 matrix instructions, 1 = split-f16, 2 = single-pass fp16 (perf mode, never for parity)
+int attn_mode();
+inline bool attn_use_f16(bool env_default) { const int m = attn_mode(); return m < 0 ? env_default : m >= 1; }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace pfpp

@@ -475,17 +475,26 @@ __global__ __launch_bounds__(128) void token_combine_bwd_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void silu_embed_bwd_kernel(const float* __restrict__ tables,
+// dtables[tab, t[b], :] += dse[tab, b, :] * silu'(tables[tab, t[b], :]), puzzles that drew the same timestep summed IN INDEX ORDER by the
+// one thread that owns the row's first occurrence: no atomics, so the result is a function of the inputs only — data-parallel ranks
+// that scatter the same gathered (rows, timesteps) list (GradExchange.gather_rows) end up with bit-identical table gradients.
+// One workgroup per (table, b); the scan over t[] is wave-uniform (scalar loads).
+__global__ __launch_bounds__(128) void silu_embed_bwd_kernel(const float* __restrict__ tables,
                                                              const int64_t* __restrict__ t,
                                                              const float* __restrict__ dse, float* __restrict__ dtables,
-                                                             int64_t n_emb, int64_t B, int C, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over [n_tab, B, C]
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  const int64_t ib = i / C;
-  const int64_t b = ib % B, tab = ib / B;
-  const int64_t row = (tab * n_emb + t[b]) * C + c;
-  unsafeAtomicAdd(dtables + row, dse[i] * silu_grad(tables[row]));
+                                                             int64_t n_emb, int64_t B, int C) {
+  const int64_t b = blockIdx.x, tab = blockIdx.y;
+  const int64_t tb = t[b];
+  for (int64_t j = 0; j < b; ++j)
+    if (t[j] == tb) return;                            // an earlier puzzle owns this row
+  const int64_t row = (tab * n_emb + tb) * C;
+  for (int c = threadIdx.x; c < C; c += 128) {
+    const float sg = silu_grad(tables[row + c]);
+    float acc = dtables[row + c];
+    for (int64_t j = b; j < B; ++j)
+      if (t[j] == tb) acc += dse[(tab * B + j) * C + c] * sg;
+    dtables[row + c] = acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -530,9 +539,11 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
 // AdamW
 // ---------------------------------------------------------------------------------------------------
 // GUARD: the loss-scaling guard of a mixed-precision optimizer, on the device (no host read): `overflow[0]` is the step's
-// "a non-finite gradient was seen" flag, `overflow[1]` counts such elements.  A launch that finds the flag set leaves its range
-// untouched (gradients still cleared when asked); an element whose own gradient is inf / NaN is left untouched and raises the flag
-// for the launches that follow — parameters and both moments can never be poisoned by an overflowed split-f16 gradient plane.
+// "a non-finite gradient was seen" flag, `overflow[1]` counts such elements.  An element whose own gradient is inf / NaN is left
+// untouched (gradient still cleared when asked) and raises the flag — parameters and both moments can never be poisoned by an
+// overflowed split-f16 gradient plane.  The decision is PER ELEMENT and depends on that element's gradient only: the flag is
+// written, never read, by the kernel, so the outcome does not depend on workgroup scheduling and data-parallel replicas (which
+// hold bit-identical all-reduced gradients) skip the same elements and stay equal.
 template <bool GUARD>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
@@ -541,8 +552,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float step_size, float inv_sqrt_bc2, float g_scale, int zero_g,
                                                     int* __restrict__ overflow) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool skip_all = false;
-  if (GUARD) skip_all = __builtin_nontemporal_load(overflow) != 0;
   const bool in = i < n;
   float gr = in ? g[i] * g_scale : 0.0f;
   if (in && zero_g) g[i] = 0.0f;                      // optimizer.zero_grad() in the same pass (no separate 230 MB memset)
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       atomicOr(overflow, 1);
       atomicAdd(overflow + 1, __popcll(mask));
     }
-    if (skip_all || bad) return;
+    if (bad) return;
   }
   if (!in) return;
   float pp = p[i] * decay;
@@ -832,8 +841,9 @@ extern "C" int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const 
   PFPP_REQUIRE(tables && t && dse && dtables, "null pointer");
   const int64_t total = n_tab * B * C;
   if (total == 0) return PFPP_OK;
-  hipLaunchKernelGGL(silu_embed_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, pfpp::as_stream(stream), tables,
-                     t, dse, dtables, n_emb, B, (int)C, total);
+  PFPP_SUPPORTED(B <= 0x7fffffff && n_tab <= 65535, "too many rows / tables for one launch");
+  hipLaunchKernelGGL(silu_embed_bwd_kernel, dim3((unsigned)B, (unsigned)n_tab), dim3(128), 0, pfpp::as_stream(stream), tables,
+                     t, dse, dtables, n_emb, B, (int)C);
   return pfpp::check_launch(__func__);
 }
 

@@ -617,7 +617,7 @@ static int attn_blockdiag_impl(const float* qkv, float* out, _Float16* out_hi, _
   static const bool use_mfma = !(getenv("PFPP_ATTN_BD_MFMA") && atoi(getenv("PFPP_ATTN_BD_MFMA")) == 0);
   // split-f16 contraction (attention_bwd.hip: attn_blockdiag_f16_kernel) unless PFPP_ATTN_BD_F16X3=0 (then the exact fp32 matrix instructions)
   static const bool use_f16 = !(getenv("PFPP_ATTN_BD_F16X3") && atoi(getenv("PFPP_ATTN_BD_F16X3")) == 0);
-  if (use_mfma && use_f16 && dh == 64 && pairs <= 0x7fffffff)
+  if (use_mfma && pfpp::attn_use_f16(use_f16) && dh == 64 && pairs <= 0x7fffffff)
     return pfpp_attn_blockdiag_f16_launch(qkv, out, out_hi, out_lo, pairs, L, H, scale, pfpp::as_stream(stream));
   if (use_mfma) {
     hipLaunchKernelGGL(attn_blockdiag_mfma_kernel, dim3(blocks_for(pairs, 4)), dim3(256), 0, pfpp::as_stream(stream), qkv, out,

@@ -116,6 +116,7 @@ _pl = C.POINTER(PlanesC)
 
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
+    "pfpp_set_attention_mode": [C.c_int],
     "pfpp_se3_rotate_gather": [_p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_pose_apply": [_p, _p, _p, _p, _i64, _i64, C.c_int, _p],
     "pfpp_fps": [_p, _p, _p, _i64, _i64, _i64, _p],
@@ -204,6 +205,7 @@ PLAIN = {
     "pfpp_last_error": ([], C.c_char_p),
     "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
+    "pfpp_get_attention_mode": ([], C.c_int),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_tblock_small_barrier_words": ([], C.c_int64),

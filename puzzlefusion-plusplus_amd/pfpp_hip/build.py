@@ -38,7 +38,13 @@ SOURCES = {
     "merge.hip": ["-ffp-contract=off"],
     "augment.hip": ["-ffp-contract=off"],
 }
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+# -fma-mix-insts (target feature off): without it the compiler may fold `(_Float16)(a * b + c)` into v_fma_mixlo_f16 — ONE rounding of
+# the exact value — while the `x - (float)hi` of the same hi / lo split goes through `v_cvt_f16_f32(RN32(x))`: in the rare
+# double-rounding case the two hi's differ by an fp16 ulp and hi + lo is off by 5e-4 relative.  With the mix
+# instructions unavailable every fp32 -> fp16 conversion is a plain v_cvt of the rounded fp32 value, so a split can only ever
+# see one hi.  tests/test_abi_and_host.py disassembles the library and checks that none is left.
+NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX]
 
 
 def _hipcc() -> str:
@@ -61,16 +67,25 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h", CSRC / "gemm_common.h", CSRC / "sa_common.h"]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = CSRC / src
         o = objdir / (s.stem + ".o")
         objs.append(o)
         if force or _stale(o, [s, *headers]):
-            cmd = [hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append([hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:          # translation units are independent: one hipcc per core (PFPP_BUILD_JOBS overrides)
+        from concurrent.futures import ThreadPoolExecutor
+
+        workers = max(1, min(len(jobs), int(os.environ.get("PFPP_BUILD_JOBS", os.cpu_count() or 1))))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
         if verbose:

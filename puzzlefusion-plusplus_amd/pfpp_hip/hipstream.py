@@ -21,7 +21,11 @@ _events = {}
 def _lib():
     global _hip
     if _hip is None:
-        _hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        try:                                          # the runtime torch itself runs on: the wheel's copy, else the one already loaded
+            _hip = C.CDLL(bundled) if os.path.exists(bundled) else C.CDLL("libamdhip64.so")
+        except OSError as e:
+            raise RuntimeError("pfpp_hip.hipstream: cannot open the HIP runtime torch runs on (libamdhip64.so)") from e
         _hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
         _hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         _hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]

@@ -28,7 +28,14 @@ except Exception:  # noqa: BLE001
         def save_hyperparameters(self, *a, **k):
             return None
 
-        def log(self, name, value, **kwargs):
+        def log(self, name, value, sync_dist: bool = False, **kwargs):
+            if sync_dist and torch.is_tensor(value):
+                import torch.distributed as dist
+
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    value = value.detach().clone().float()
+                    dist.all_reduce(value)                       # Lightning's sync_dist: the mean over ranks
+                    value /= dist.get_world_size()
             self.logged[name] = value
 
 

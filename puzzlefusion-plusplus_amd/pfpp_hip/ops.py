@@ -211,13 +211,19 @@ import contextlib as _ctx
 @_ctx.contextmanager
 def exact_fp32():
     """run the enclosed calls with the exact fp32 MFMA GEMMs (PFPP_GEMM=f32) — the fallback the drop-in sampler loops take
-    when a split-f16 run produced non-finite poses (an operand at or beyond the fp16 range, |v| >= 65504)"""
+    when a split-f16 run produced non-finite poses (an operand at or beyond the fp16 range, |v| >= 65504).  The attention
+    forward kernels split raw q / k / v the same way, so they are switched to their exact-fp32 form for the duration as well
+    (pfpp_set_attention_mode(0))."""
     global GEMM_MODE
+    lib = _lib.load()
     prev, GEMM_MODE = GEMM_MODE, "f32"
+    prev_attn = lib.pfpp_get_attention_mode()
+    check(lib.pfpp_set_attention_mode(0), "pfpp_set_attention_mode")
     try:
         yield
     finally:
         GEMM_MODE = prev
+        check(lib.pfpp_set_attention_mode(prev_attn), "pfpp_set_attention_mode")
 
 
 def f16x3_range_fallback(x: torch.Tensor) -> bool:

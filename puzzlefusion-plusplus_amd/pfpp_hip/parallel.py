@@ -134,6 +134,19 @@ class GradExchange:
         dist.all_gather(ix, index.contiguous())
         return torch.cat(rs, dim).contiguous(), torch.cat(ix, 0).contiguous()
 
+    def wait_pending(self) -> None:
+        """the reductions issued so far happen before whatever the CURRENT stream is given next (RCCL: a stream-side wait, the
+        host does not block; gloo: the host waits)"""
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    @staticmethod
+    def mean_factor() -> float:
+        import torch.distributed as dist
+
+        return 1.0 / dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1.0
+
     def finish(self) -> float:
         import torch.distributed as dist
 

@@ -306,7 +306,7 @@ class DenoiserTrainEngine:
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
-        self._early: List[int] = []                   # layers whose slice the armed backward has already updated
+        self._early: List[Tuple[int, int]] = []       # [a, b) ranges of the flat buffer the armed backward has already updated
         self._sync = True                            # False inside no_sync(): this backward does not start the gradient exchange
         self._exchanged = False                      # the gradients in the flat buffer have been all-reduced since the last step
         self._accumulated = False                    # a no_sync backward has accumulated into the buffer since the last step
@@ -714,7 +714,14 @@ class DenoiserTrainEngine:
         from . import hipstream as HS
 
         h = st.cuda_stream
-        HS.wait_for(h, ops.raw_stream_id(self.flat.params.device.index))
+        try:
+            HS.wait_for(h, ops.raw_stream_id(self.flat.params.device.index))
+        except (RuntimeError, OSError):
+            # no HIP runtime handle to call directly (a torch build on a system ROCm we cannot dlopen): torch's own ordering
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                fn()
+            return
         prev, ops.STREAM_OVERRIDE = ops.STREAM_OVERRIDE, h
         try:
             fn()
@@ -821,8 +828,9 @@ class DenoiserTrainEngine:
 
     # ------------------------------------------------------------------------------------------ data parallel
     def _layer_done(self, i: int) -> None:
-        """gradients of layer i are final: start their all-reduce while the earlier layers still compute.  Issued
-        from the stream that produced the layer's weight gradients, so RCCL orders itself after them."""
+        """gradients of layer i are final: start their all-reduce while the earlier layers still compute, and — when the optimizer is
+        armed (arm_optimizer) — give the layer its AdamW update as soon as its gradients are final (N = 1) / reduced (N > 1)."""
+        reducing = self._exchange.reducing()
         if self._armed is not None and self._side is not None and not self._exchange.active():
             # optimizer in the backward (arm_optimizer): this layer's slice of the flat buffer is final once its weight
             # gradients (side stream) and LayerNorm gradients (main stream, all queued by now) have run — update it on the side
@@ -830,8 +838,8 @@ class DenoiserTrainEngine:
             armed = self._armed
             self._run_on(self._side, lambda: self._adamw_range(*self.flat.layer_ranges[i], step=self.step_count + 1, g_scale=1.0,
                                                                zero_grad=self._armed_zero, **armed))
-            self._early.append(i)
-        if self._exchange.reducing():
+            self._early.append(self.flat.layer_ranges[i])
+        if reducing:
             extra = ()
             if self._ada_layerwise is not None:
                 dmods, se, g, B, C, G = self._ada_layerwise
@@ -843,18 +851,38 @@ class DenoiserTrainEngine:
                 t0 = "transformer_layers.0"
                 aw, ab = f.offset[f"{t0}.norm1.linear.weight"], f.offset[f"{t0}.norm1.linear.bias"]
                 extra = ((aw + j * 2 * C * C, aw + (j + 2) * 2 * C * C), (ab + j * 2 * C, ab + (j + 2) * 2 * C))
-            if self._side is None:
+            # the layer's slice holds gradients from BOTH streams (weights / biases: side stream; LayerNorm gamma / beta and the
+            # AdaLN linears: main stream), so the collective is ordered after everything queued on either of them so far.  It is
+            # issued from a third stream: the next layer's weight-gradient GEMMs (side stream) must not queue up behind it.
+            comm = self._comm_stream()
+            comm.wait_stream(torch.cuda.current_stream())
+            if self._side is not None:
+                comm.wait_stream(self._side)
+            with torch.cuda.stream(comm):
                 self._exchange.layer_done(i, extra)
-                return
-            # the layer's slice holds gradients from BOTH streams (weights / biases: side stream; LayerNorm gamma / beta:
-            # main stream), so the collective is ordered after everything queued on either of them so far
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                self._exchange.layer_done(i, extra)
+                if self._armed is not None:
+                    # N > 1 keeps the benchmarked schedule: the layer's AdamW runs BEHIND its all-reduce on the
+                    # exchange stream, under the rest of the backward; only embeddings / tables / heads are left for optimizer_step
+                    self._exchange.wait_pending()                # RCCL: the exchange stream waits, the host does not
+                    # (the AdaLN linears that travelled with the layer are NOT updated here: the end of the backward still reads
+                    # their weights for d/d(timestep embedding))
+                    a, b = self.flat.layer_ranges[i]
+                    self._adamw_range(a, b, step=self.step_count + 1, g_scale=self._exchange.mean_factor(),
+                                      zero_grad=self._armed_zero, **self._armed)
+                    self._early.append((a, b))
+
+    def _comm_stream(self):
+        """the stream the per-layer gradient all-reduces (and the AdamW launches behind them) are issued from (N > 1 only)"""
+        st = getattr(self, "_comm", None)
+        if st is None:
+            st = self._comm = torch.cuda.Stream(device=self.flat.params.device)
+        return st
 
     def _all_done(self) -> None:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+        if getattr(self, "_comm", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)      # per-layer exchanges (and the updates behind them) join here
         self._exchange.all_done(dense=self._accumulated)
 
     def finish_grad_exchange(self) -> float:
@@ -867,8 +895,10 @@ class DenoiserTrainEngine:
         """optimizer-in-backward for the NEXT backward: every transformer layer's parameters take their AdamW update as soon as
         the layer's gradients are final (on the weight-gradient stream, under the rest of the backward); optimizer_step() with
         the same hyper-parameters then updates only what is left (embeddings, AdaLN tables and linears, output heads) and
-        closes the step.  Same arithmetic per element as one launch over the flat buffer.  One-shot; ignored (everything
-        happens in optimizer_step) without a second stream or when gradients are exchanged between ranks first."""
+        closes the step.  Same arithmetic per element as one launch over the flat buffer.  With N > 1 ranks the layer's update is
+        queued behind the layer's all-reduce on the exchange stream (1 / world folded in), so the multi-rank step keeps the
+        schedule the single-rank line is measured on.  One-shot; ignored (everything happens in optimizer_step) without a second
+        stream at N = 1, and for backward passes under no_sync() (gradient accumulation: nothing is final yet)."""
         self._armed = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         self._armed_zero = bool(zero_grad)          # the per-layer updates also clear their gradients (optimizer_step(zero_grad=True))
         self._early = []
@@ -898,7 +928,7 @@ class DenoiserTrainEngine:
             if zero_grad != self._armed_zero:
                 raise RuntimeError("optimizer_step: zero_grad differs from what the backward was armed with")
             pos, total = 0, f.params.numel()
-            for a, b in sorted(f.layer_ranges[i] for i in early) + [(total, total)]:
+            for a, b in sorted(early) + [(total, total)]:
                 if a > pos:
                     self._adamw_range(pos, a, step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
                 pos = max(pos, b)
@@ -1042,6 +1072,11 @@ class FeaturePipeline:
                 latent, xyz = self.model._extract_features(data["part_pcs"], data["part_valids"], noisy)
         finally:
             ops.PERSISTENT_WGS = prev_wgs
+        for v in (gt, ref, noise, t):
+            # read on the encoder stream, allocated on the caller's: a caller that drops them right away (TrainingSchedule._prepare's
+            # locals) must not get the blocks recycled under the encoder stream's pending reads
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             ev = torch.cuda.Event()
             ev.record(self.stream)

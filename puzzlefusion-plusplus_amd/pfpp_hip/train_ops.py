@@ -373,8 +373,8 @@ def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *,
           lo: Optional[torch.Tensor] = None, g_scale: float = 1.0, zero_grad: bool = False,
           overflow: Optional[torch.Tensor] = None) -> None:
     """one fused AdamW step over flat buffers (torch.optim.AdamW arithmetic); refreshes the split planes; zero_grad: clears g in
-    the same pass; overflow (int32 [2] on the device: flag, count): elements with a non-finite gradient are skipped and flagged,
-    a launch that finds the flag set updates nothing (pfpp_adamw_guarded)"""
+    the same pass; overflow (int32 [2] on the device: flag, count): elements with a non-finite gradient are skipped (per element, from
+    that element's gradient alone: deterministic, identical on data-parallel replicas) and flagged (pfpp_adamw_guarded)"""
     if overflow is not None:
         _chk(overflow, torch.int32, "overflow")
         if overflow.numel() < 2:

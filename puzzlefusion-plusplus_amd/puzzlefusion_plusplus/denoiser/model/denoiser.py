@@ -125,7 +125,17 @@ class Denoiser(LightningModule):
     def training_step(self, data_dict, idx):
         opt = getattr(self, "_fused_opt", None)
         if opt is not None and opt.in_backward and torch.is_grad_enabled():
-            opt.arm()                      # AdamW per layer under the backward (single rank, no gradient accumulation)
+            opt.arm()                      # AdamW per layer under the backward (behind the layer's all-reduce when N > 1)
+        acc = getattr(self, "_pfpp_accumulate", 1)
+        if acc > 1 and opt is not None:
+            # gradient accumulation under a foreign trainer (Lightning wraps DDP.no_sync around the micro-batches; there is no DDP
+            # wrapper here): only the last backward of an optimizer step starts the gradient exchange.  pfpp_hip.launch.Trainer
+            # holds engine.no_sync() itself.
+            trainer = self._trainer()
+            if trainer is not None and type(trainer).__module__ != "pfpp_hip.launch":
+                last = bool(getattr(getattr(getattr(trainer, "fit_loop", None), "epoch_loop", None), "batch_progress", None)
+                            and trainer.fit_loop.epoch_loop.batch_progress.is_last_batch)
+                opt.engine._sync = (idx + 1) % acc == 0 or last
         out = self(data_dict)
         total = 0
         for name, value in self._loss(data_dict, out).items():
@@ -210,17 +220,35 @@ class Denoiser(LightningModule):
         self.acc_list, self.rmse_t_list, self.rmse_r_list, self.cd_list = [], [], [], []
         return tuple(total)
 
+    def _trainer(self):
+        """the attached trainer or None (a real LightningModule raises RuntimeError, not AttributeError, when unattached)"""
+        try:
+            return getattr(self, "trainer", None)
+        except RuntimeError:
+            return None
+
     def on_fit_start(self):
-        """the training forward writes parameter gradients through its own kernels (one autograd node, pfpp_hip.train): torch
-        DistributedDataParallel sees no gradient hooks fire and would report unused parameters / skip the reduction.  The
-        data-parallel exchange is pfpp_hip.parallel.GradExchange (per-layer all-reduce of the flat gradient buffer during the
-        backward) — run one process per GPU with torch.distributed initialised and a single-device Lightning strategy."""
-        strategy = getattr(getattr(self, "trainer", None), "strategy", None)
-        name = type(strategy).__name__.lower() if strategy is not None else ""
-        if "ddp" in name or "fsdp" in name or "deepspeed" in name:
-            raise RuntimeError(f"Denoiser: Lightning strategy {type(strategy).__name__} wraps the module in a gradient-hook based "
-                               "reducer, which never sees the gradients of the HIP training path; use strategy='auto' per process — "
-                               "the gradient exchange is built in (pfpp_hip.parallel.GradExchange over torch.distributed / RCCL)")
+        """Data parallelism.  The training forward writes parameter gradients through its own kernels (one autograd node,
+        pfpp_hip.train): torch's DistributedDataParallel would see no gradient hook fire.  The exchange is the engine's
+        (pfpp_hip.parallel.GradExchange: per-layer all-reduce of the flat gradient buffer under the backward, over the process group
+        the strategy initialised), so the reference's launch line `+trainer.devices=4 +trainer.strategy=ddp`
+        (scripts/train_denoiser.sh:6-7) is served as follows:
+        * pfpp_hip.launch.Trainer (Lightning absent): strategy "ddp" means exactly that built-in exchange;
+        * a real Lightning DDPStrategy: it has already set the device, initialised the process group and injected the
+          DistributedSampler — all of which are kept; only its DistributedDataParallel wrapper is taken off again
+          (strategy.model = this module), and gradient accumulation is mapped to engine.no_sync() in training_step;
+        * parameter-sharding strategies (FSDP, DeepSpeed) cannot work with a flat parameter buffer and are refused."""
+        trainer = self._trainer()
+        strategy = getattr(trainer, "strategy", None)
+        name = strategy if isinstance(strategy, str) else (type(strategy).__name__.lower() if strategy is not None else "")
+        if "fsdp" in name or "deepspeed" in name:
+            raise RuntimeError(f"Denoiser: strategy {name} shards parameters through gradient hooks that the HIP training path never "
+                               "fires; use strategy='ddp' (served by the built-in per-layer gradient exchange) or 'auto'")
+        if "ddp" in name and not isinstance(strategy, str):
+            wrapped = getattr(strategy, "model", None)
+            if wrapped is not None and wrapped is not self and isinstance(wrapped, torch.nn.parallel.DistributedDataParallel):
+                strategy.model = self                 # Lightning then calls training_step on the module itself
+        object.__setattr__(self, "_pfpp_accumulate", int(getattr(trainer, "accumulate_grad_batches", 1) or 1))
 
     def configure_optimizers(self):
         # same hyper-parameters as the reference (denoiser.py:230-237) on the fused kernel; the frozen encoder
@@ -232,8 +260,11 @@ class Denoiser(LightningModule):
         optimizer = FusedAdamW(self.denoiser.train_engine(), lr=2e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-08,
                                params=list(self.parameters()))
         # optimizer-in-backward (the benchmarked form of the step) when nothing accumulates gradients over several backward passes
-        accumulate = getattr(getattr(self, "trainer", None), "accumulate_grad_batches", 1) or 1
-        optimizer.in_backward = os.environ.get("PFPP_OPT_IN_BWD", "1") == "1" and accumulate == 1
+        # (per-layer updates and gradient clears inside loss.backward() leave nothing for gradient clipping / accumulation to act on)
+        trainer = self._trainer()
+        accumulate = getattr(trainer, "accumulate_grad_batches", 1) or 1
+        clip = getattr(trainer, "gradient_clip_val", None)
+        optimizer.in_backward = os.environ.get("PFPP_OPT_IN_BWD", "1") == "1" and accumulate == 1 and not clip
         object.__setattr__(self, "_fused_opt", optimizer)
         sched_cfg = getattr(self.cfg.model, "lr_scheduler", None)
         if sched_cfg is None:

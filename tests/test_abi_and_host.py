@@ -331,3 +331,34 @@ def test_dataset_dropins_equal_the_reference_loaders(golden, tmp_path):
             assert np.array_equal(np.asarray(val), g[f"v{i}_{k}"]), (i, k)
             checked += 1
     assert checked >= 60
+
+
+def test_library_has_no_fused_mixed_precision_conversions(hip_lib, tmp_path):
+    """The hi / lo split (csrc/pfpp_common.h) needs ONE fp16 rounding of its argument: `hi = f16(x)`, `lo = f16(x - hi)`.  With the
+    gfx950 mix instructions available the compiler may take the stored hi from `v_fma_mixlo_f16` (the exact a * b + c rounded once)
+    while the subtraction sees `v_cvt_f16_f32` of the rounded fp32 value — two hi's that differ by an fp16 ulp in the rare
+    double-rounding case.  pfpp_hip.build compiles every translation unit with that target feature off; this
+    disassembles the gfx950 code objects of the library that was built and checks that no such instruction is left — so a compiler
+    bump that renames / ignores the flag shows up here, not as a silent one-ulp operand error."""
+    import shutil
+    import subprocess
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not available")
+    lib = tmp_path / "libpfpp_hip.so"
+    shutil.copy(hip_lib, lib)
+    subprocess.run([str(objdump), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = sorted(tmp_path.glob("libpfpp_hip.so.*gfx950*"))
+    assert objs, "no gfx950 code object found in libpfpp_hip.so"
+    n_inst = n_cvt = 0
+    for o in objs:
+        proc = subprocess.Popen([str(objdump), "-d", "--mcpu=gfx950", str(o)], stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout:
+            if "v_fma_mix" in line or "v_mad_mix" in line:
+                proc.kill()
+                raise AssertionError(f"mixed-precision fused conversion in the library: {line.strip()}")
+            n_inst += "v_mfma_" in line
+            n_cvt += "v_cvt_f16_f32" in line or "v_cvt_pk_f16_f32" in line
+        assert proc.wait() == 0
+    assert n_inst > 1000 and n_cvt > 1000          # it really was the kernels' code that was read

@@ -251,3 +251,80 @@ def test_two_rank_gradient_accumulation_reduces_once():
     first, final, scale = _run_two_ranks(_accum_worker)
     assert torch.equal(first, torch.ones(100))                      # rank 0's own first micro-batch, untouched by rank 1
     assert torch.equal(final, torch.full((100,), 33.0)) and scale == 0.5      # (1 + 10) + (2 + 20)
+
+
+def _write_config_tree(d):
+    """a config tree laid out like the reference's config/denoiser (global_config.yaml + root-level files named in its defaults
+    list, `${...}` interpolation, a `trainer:` node the launch line extends with +trainer.devices / +trainer.strategy)"""
+    (d / "global_config.yaml").write_text(
+        "hydra:\n  run:\n    dir: .\n"
+        "defaults:\n  - _self_\n  - encoder\n  - data\n  - model\n  - override hydra/hydra_logging: disabled\n"
+        "project_root_path: ${hydra:runtime.cwd}\n"
+        "experiment_output_path: ${project_root_path}/output/denoiser/${experiment_name}\n"
+        "ckpt_path: null\nexperiment_name: null\ntrain_seed: 123\n"
+        "trainer:\n  accelerator: gpu\n  max_epochs: 2000\n  check_val_every_n_epoch: ${every}\n  precision: 32\nevery: 100\n")
+    (d / "encoder.yaml").write_text("ae:\n  n_embeddings: 1024\n  embedding_dim: 16\n")
+    (d / "data.yaml").write_text("data:\n  batch_size: 64\n  num_workers: 10\n  data_dir: ./data/train/\n")
+    (d / "model.yaml").write_text("model:\n  embed_dim: 512\n  lr_scheduler:\n    milestones: [1200, 1700]\n    gamma: 0.5\n")
+
+
+def test_launch_composes_the_reference_config_layout_and_override_syntax(tmp_path):
+    """scripts/train_denoiser.sh:1-7: `experiment_name=... data.batch_size=64 +trainer.devices=4 +trainer.strategy=ddp` over the
+    config/denoiser tree — the subset of Hydra's composition pfpp_hip.launch implements"""
+    import pytest
+
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip import launch
+
+    _write_config_tree(tmp_path)
+    cwd = os.getcwd()
+    t = launch.compose(str(tmp_path), "global_config",
+                       ["experiment_name=everyday_bs64", "data.batch_size=8", "+trainer.devices=4", "+trainer.strategy=ddp",
+                        "model.lr_scheduler.milestones=[3,5]"])
+    assert t["trainer"] == dict(accelerator="gpu", max_epochs=2000, check_val_every_n_epoch=100, precision=32, devices=4, strategy="ddp")
+    assert t["data"] == dict(batch_size=8, num_workers=10, data_dir="./data/train/") and t["ae"]["embedding_dim"] == 16
+    assert t["experiment_output_path"] == f"{cwd}/output/denoiser/everyday_bs64" and t["ckpt_path"] is None
+    assert t["model"]["lr_scheduler"]["milestones"] == [3, 5] and "hydra" not in t and "defaults" not in t
+    with pytest.raises(KeyError):                                  # Hydra refuses a new key without the + prefix
+        launch.compose(str(tmp_path), "global_config", ["trainer.devices=4"])
+    # the Trainer surface train_denoiser.py:44-60 passes (**cfg.trainer): parameter sharding is refused, ddp is accepted
+    tr = launch.Trainer(**t["trainer"])
+    assert tr.devices == 4 and tr.strategy == "ddp" and tr.max_epochs == 2000
+    with pytest.raises(ValueError):
+        launch.Trainer(devices=2, strategy="fsdp")
+    with pytest.raises(ValueError):
+        launch.Trainer(precision="16-mixed")
+
+
+def test_launch_trainer_shards_the_train_loader_like_lightning():
+    """use_distributed_sampler: every rank keeps the loader's batch size / drop_last and draws from a DistributedSampler — the
+    ranks' indices of an epoch are disjoint, cover the dataset, and change with set_epoch when the loader shuffled"""
+    from torch.utils.data import DataLoader, DistributedSampler
+
+    for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from pfpp_hip import launch
+
+    ds = list(range(22))
+    seen = []
+    for rank in range(4):
+        tr = launch.Trainer(devices=4, strategy="ddp", seed=5)
+        tr.world_size, tr.global_rank = 4, rank
+        loader, sampler = tr._shard(DataLoader(ds, batch_size=2, shuffle=True, drop_last=True), True)
+        assert isinstance(sampler, DistributedSampler) and loader.batch_size == 2 and loader.drop_last
+        sampler.set_epoch(0)
+        e0 = [int(v) for b in loader for v in b]
+        sampler.set_epoch(1)
+        e1 = [int(v) for b in loader for v in b]
+        assert len(e0) == 6 and e0 != e1                           # ceil(22 / 4) = 6 per rank, 3 full batches
+        seen += e0
+        plain, none = tr._shard(DataLoader(ds, batch_size=2, shuffle=False), False)
+        padded = list(range(22)) + [0, 1]                            # DistributedSampler pads to a multiple of the world size
+        assert [int(v) for b in plain for v in b] == padded[rank::4]   # unshuffled: rank, rank + 4, ...
+    assert set(seen) == set(ds)
+    single = launch.Trainer(devices=1)
+    dl = DataLoader(ds, batch_size=2)
+    assert single._shard(dl, True) == (dl, None)

@@ -952,3 +952,188 @@ def test_bench_gpus_flag_spawns_its_own_ranks(dev):
         out = subprocess.run([sys.executable, str(root / "bench.py"), *args], capture_output=True, text=True, timeout=600,
                              env=dict(env, PFPP_BENCH_BACKEND="nccl"), cwd=str(root))
         assert out.returncode != 0 and "GPU(s) visible" in out.stderr and not out.stdout.strip()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism THROUGH THE MODULE SURFACE (VERDICT r3 star row; scripts/train_denoiser.sh:6-7: +trainer.devices=4 +trainer.strategy=ddp)
+# ---------------------------------------------------------------------------------------------------------------------
+def _surface_paths():
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    for p_ in (str(root), str(root / "puzzlefusion-plusplus_amd")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    return root
+
+
+class _PuzzleList(torch.utils.data.Dataset):
+    """synthetic puzzles as a map-style dataset (what GeometryLatentDataset is to the loader)"""
+
+    def __init__(self, ids, num_points=128, num_parts=4):
+        self.ids, self.num_points, self.num_parts = list(ids), num_points, num_parts
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        from pfpp_hip import synthetic
+
+        return synthetic.make_puzzle(self.ids[i], self.num_points, 20, self.num_parts, None)
+
+
+def _surface_model(dev, seed):
+    """a Denoiser whose frozen encoder stays in eval mode (batch-statistics BatchNorm sums with fp64 atomics: run-to-run VQ code flips
+    would blur the comparison of two runs; everything else is the default training path)"""
+    from oracle import weights
+    from pfpp_hip import config
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    class DetDenoiser(Denoiser):
+        def train(self, mode=True):
+            super().train(mode)
+            self.encoder.eval()
+            return self
+
+    torch.manual_seed(seed)
+    model = DetDenoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights.vqvae_state_dict())
+    model.denoiser.load_state_dict(weights.denoiser_state_dict())
+    for p_ in model.encoder.parameters():
+        p_.requires_grad = False
+    return model.to(dev)
+
+
+def _surface_fit(model, ids, devices, out_dir, **kw):
+    from torch.utils.data import DataLoader
+
+    from pfpp_hip.launch import Trainer
+
+    loader = DataLoader(_PuzzleList(ids), batch_size=2, shuffle=False, drop_last=True)
+    tr = Trainer(devices=devices, strategy="ddp" if devices > 1 else "auto", max_epochs=1, check_val_every_n_epoch=0,
+                 default_root_dir=str(out_dir), **kw)
+    tr.fit(model, loader)
+    return tr
+
+
+def _surface_worker(rank, world, port, out_dir, steps, accumulate):
+    import os
+
+    _surface_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank), RANK=str(rank), WORLD_SIZE=str(world),
+                      PFPP_DDP_BACKEND="gloo")        # both ranks on this GPU: gloo moves the CUDA tensors through the host, same code path
+    dev = torch.device("cuda:0")
+    model = _surface_model(dev, 100 + rank)
+    tr = _surface_fit(model, range(8), world, f"{out_dir}/rank{rank}", max_steps=steps, accumulate_grad_batches=accumulate)
+    f = model.denoiser.train_engine().flat
+    torch.cuda.synchronize()
+    torch.save(dict(exp_avg=f.exp_avg.cpu(), params=f.params.cpu(), steps=tr.global_step, world=tr.world_size), f"{out_dir}/rank{rank}.pt")
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_two_rank_training_through_the_module_surface(dev, tmp_path, accumulate):
+    """`Trainer(devices=2, strategy="ddp").fit(model, loader)` — one process per rank, DistributedSampler, training_schedule ->
+    training_step -> backward -> FusedAdamW.step, gradients exchanged per layer under the backward with the layer's AdamW queued behind
+    its all-reduce (accumulate 1), or accumulated under engine.no_sync() and exchanged once (accumulate 2): after one optimizer step
+    the first Adam moment (0.05 x the averaged gradient) equals the mean of what the two ranks' shards give alone, and both replicas
+    hold bit-identical parameters."""
+    import torch.multiprocessing as mp
+
+    _surface_paths()
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_surface_worker, args=(r, 2, port, str(tmp_path), 1, accumulate)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(timeout=900)
+        assert p_.exitcode == 0
+    got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    assert got[0]["steps"] == 1 and got[0]["world"] == 2
+    assert torch.equal(got[0]["params"], got[1]["params"]) and torch.equal(got[0]["exp_avg"], got[1]["exp_avg"])
+    assert torch.isfinite(got[0]["params"]).all()
+    ck = torch.load(tmp_path / "rank0" / "last.ckpt", weights_only=False)           # Lightning's layout, written by rank 0 only
+    assert {"state_dict", "optimizer_states", "epoch", "global_step"} <= set(ck) and not (tmp_path / "rank1" / "last.ckpt").exists()
+    assert any(k.startswith("denoiser.transformer_layers.0.") for k in ck["state_dict"]) and any(k.startswith("encoder.") for k in ck["state_dict"])
+    # what each rank's shard gives alone (same seed -> same noise / timestep / dropout draws; rank r reads puzzles r, r + 2, ...)
+    want = None
+    for r in range(2):
+        model = _surface_model(dev, 100 + r)
+        ids = list(range(r, 8, 2))
+        _surface_fit(model, ids, 1, tmp_path / f"alone{r}", max_steps=1, accumulate_grad_batches=accumulate)
+        torch.cuda.synchronize()
+        m = model.denoiser.train_engine().flat.exp_avg.cpu()
+        want = m if want is None else want + m
+        del model
+    assert rel(got[0]["exp_avg"], want / 2) < 2e-5
+
+
+def _poison_worker(rank, world, port, out_q):
+    import os
+
+    import torch.distributed as dist
+
+    _surface_paths()
+    from oracle import weights
+    from pfpp_hip.train import DenoiserTrainEngine
+    from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    root = _surface_paths()
+    m = DenoiserTransformer(NS(model=NS(embed_dim=512, out_channels=7, num_layers=6, num_heads=8, num_dim=64, num_point=25)))
+    m.load_state_dict(weights.denoiser_state_dict(), strict=True)
+    eng = DenoiserTrainEngine(m.to(dev))
+    f = eng.flat
+    g, t = np.load(root / "tests" / "golden" / "denoiser.npz"), np.load(root / "tests" / "golden" / "train.npz")
+    keys = ("x", "timesteps", "latent", "xyz", "part_valids", "scale", "ref_part")
+    inp = [torch.from_numpy(g[k])[rank:rank + 1].to(dev) for k in keys]
+    noise = torch.from_numpy(t["noise"])[rank:rank + 1].to(dev)
+    hp = dict(lr=1e-3, weight_decay=1e-2)
+    a, b = f.layer_ranges[3]
+    snap = None
+    for step in range(3):
+        eng.arm_optimizer(zero_grad=True, **hp)        # per-layer AdamW behind each layer's all-reduce
+        if step == 1:
+            torch.cuda.synchronize()
+            snap = (f.params[a + 7].item(), f.exp_avg[a + 7].item(), f.params[5].item())
+            if rank == 0:                              # ONE rank overflows: the all-reduce hands inf / NaN to both
+                f.grads[a + 7] = float("inf")
+                f.grads[5] = float("nan")
+        eng.loss_and_grads(*inp, noise, train=False)
+        eng.optimizer_step(zero_grad=True, **hp)
+        if step == 1:
+            torch.cuda.synchronize()
+            kept = (f.params[a + 7].item(), f.exp_avg[a + 7].item(), f.params[5].item()) == snap
+            flagged = int(eng._overflow.sum().item()) == 0          # cleared for the next step after the copy to the host was queued
+    torch.cuda.synchronize()
+    out_q.put(dict(rank=rank, params=f.params.cpu(), m=f.exp_avg.cpu(), v=f.exp_avg_sq.cpu(), hi=f.hi.cpu(), kept=kept, flagged=flagged,
+                   overflow_steps=eng.overflow_steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicas_stay_equal_after_an_overflow(dev):
+    """the guarded AdamW decides PER ELEMENT from that element's own all-reduced gradient, never from a flag other
+    workgroups of the launch are still writing — so when one rank's backward overflows, both replicas skip exactly the same elements
+    (parameters and moments there untouched) and remain bit-identical; with the optimizer armed, i.e. on the multi-rank form of the
+    benchmarked schedule (layer updates queued behind the layer's all-reduce)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_poison_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda d: d["rank"])
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    for k in ("params", "m", "v", "hi"):
+        assert torch.equal(res[0][k], res[1][k]), k
+        assert torch.isfinite(res[0][k].float()).all(), k
+    assert res[0]["kept"] and res[1]["kept"] and res[0]["flagged"]

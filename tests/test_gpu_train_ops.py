@@ -505,3 +505,139 @@ def test_bn_stats_and_apply(dev, rows, C, pool):
     assert (rm_d.cpu() - rm_ref).abs().max() < 1e-6 and (rv_d.cpu() - rv_ref).abs().max() < 1e-6
     got = T.bn_apply(x.to(dev), mean, var, gamma.to(dev), beta.to(dev), pool=pool)
     assert (got.cpu() - want).abs().max() < 1e-5
+
+
+# ----------------------------------------------------------------------------- hi + lo == x for every plane producer
+def _assert_planes_carry(x32: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, scale: float, what: str):
+    """the split's contract (csrc/pfpp_common.h): hi + lo == scale * x to 22 bits (absolute floor: the fp16 subnormal spacing).
+    The failure this guards against is a stored hi that is NOT the hi the low half was computed against (two different roundings of
+    one value, VERDICT r3 weak #1): that leaves hi + lo off by a whole fp16 ulp of hi — 2^-11 relative, five hundred times the bound."""
+    x = x32.double().cpu().reshape(-1) * scale
+    got = hi.double().cpu().reshape(-1) + lo.double().cpu().reshape(-1)
+    ok = torch.isfinite(x)
+    err = (got - x).abs()[ok]
+    bound = x.abs()[ok] * 2.0 ** -20 + 1.3e-7
+    bad = err > bound
+    assert int(ok.sum()) > 0.99 * x.numel(), what
+    assert not bool(bad.any()), (what, int(bad.sum()), float((err / bound).max()),
+                                 float(x[ok][bad][0]), float(got[ok][bad][0]))
+    # and hi is a nearest-or-tie neighbour of the value: |x - hi| <= half an fp16 ulp of hi (what keeps lo in its 11 bits)
+    h = hi.double().cpu().reshape(-1)[ok]
+    ulp = torch.maximum(2.0 ** (torch.floor(torch.log2(h.abs().clamp_min(2.0 ** -14))) - 10), torch.tensor(2.0 ** -24, dtype=torch.float64))
+    assert bool(((x[ok] - h).abs() <= 0.5 * ulp * (1 + 2.0 ** -10) + 1e-12).all()), what
+
+
+def test_every_plane_producer_writes_hi_plus_lo_equal_to_its_fp32_value(dev):
+    """VERDICT r3 'do this' 1b.  Every kernel that hands a GEMM operand over as split-f16 planes is run so that the SAME launch (or, for
+    the kernels with one output form per call, a second deterministic launch on the same inputs) also yields the fp32 value, on inputs
+    large enough that thousands of elements sit at double-rounding positions of their products (random mantissas: ~1e-4 of all
+    elements), with gradient-sized values lifted by the power-of-two scale the backward uses.  Build-side half of the guarantee: the
+    library is compiled with the mixed-precision fused conversions off (pfpp_hip.build.NO_MIX; test_abi_and_host checks the
+    disassembly), so a split can only ever see one fp16 rounding of its argument."""
+    import ctypes as C
+
+    from pfpp_hip import _lib, ops, planes as P, train_ops as T
+    from pfpp_hip.packing import PW
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    M, Cc, L, H, dh = 3850, 512, 25, 8, 64
+    Fv = M // L
+    st = ops._stream
+    ptr = ops._ptr
+    G = 4096.0
+
+    def planes(rows, cols, scale=1.0):
+        return P.Planes.empty(rows, cols, dev, scale)
+
+    # 1. stand-alone split kernel (pfpp_split_planes), unscaled and scaled
+    x = (torch.randn(M, Cc, generator=g) * torch.logspace(-3, 3, Cc)).to(dev)
+    for s in (1.0, G):
+        p_ = P.split(x, s)
+        _assert_planes_carry(x, p_.hi, p_.lo, s, f"split_planes x{s}")
+    # 2. LayerNorm forward: AdaLN (grouped) and affine, plane form against the fp32 form of the same kernel family
+    h = torch.randn(M, Cc, generator=g).to(dev) * 3.0
+    mods = (torch.randn(32, 2 * Cc, generator=g) * 0.5).to(dev)
+    frag_b = torch.randint(0, 32, (Fv,), generator=g).to(torch.int32).to(dev)
+    n32 = ops.layernorm_grouped(h, mods, frag_b, L)
+    nsp = ops.SplitAct.empty(M, Cc, dev)
+    ops.layernorm_grouped(h, mods, frag_b, L, out=nsp)
+    _assert_planes_carry(n32, nsp.hi, nsp.lo, 1.0, "layernorm_grouped")
+    gamma, beta = torch.randn(Cc, generator=g).to(dev), torch.randn(Cc, generator=g).to(dev)
+    n32 = ops.layernorm(h, gamma=gamma, beta=beta)
+    ops.layernorm(h, gamma=gamma, beta=beta, out=nsp)
+    _assert_planes_carry(n32, nsp.hi, nsp.lo, 1.0, "layernorm affine")
+    # 3. dropout + residual + LayerNorm forward: fp32 n and planes from ONE launch
+    y = torch.randn(M, Cc, generator=g).to(dev)
+    n32 = torch.empty(M, Cc, device=dev)
+    np_ = planes(M, Cc)
+    y2 = y.clone()
+    _lib.check(lib.pfpp_dropout_layernorm_p(ptr(y2), ptr(h), ptr(y2), ptr(n32), ptr(mods), mods.stride(0), None, None, ptr(frag_b), L, 1,
+                                            M, Cc, 1e-5, 0.2, 77, 3, P._pl(np_), st()), "pfpp_dropout_layernorm_p")
+    _assert_planes_carry(n32, np_.hi, np_.lo, 1.0, "dropout_layernorm")
+    # 4. GEGLU forward / backward: fp32 and planes from one launch
+    inner = 2048
+    z = torch.randn(M, 2 * inner, generator=g).to(dev) * 2.0
+    u32 = torch.empty(M, inner, device=dev)
+    up = planes(M, inner)
+    _lib.check(lib.pfpp_geglu_p(ptr(z), ptr(u32), M, inner, 0.2, 5, 9, P._pl(up), st()), "pfpp_geglu_p")
+    _assert_planes_carry(u32, up.hi, up.lo, 1.0, "geglu")
+    du = (torch.randn(M, inner, generator=g) * 1e-4).to(dev)
+    dz32 = torch.empty(M, 2 * inner, device=dev)
+    dzp = planes(M, 2 * inner, G)
+    _lib.check(lib.pfpp_geglu_bwd_p(ptr(z), ptr(du), ptr(dz32), M, inner, 0.2, 5, 9, P._pl(dzp), st()), "pfpp_geglu_bwd_p")
+    _assert_planes_carry(dz32, dzp.hi, dzp.lo, G, "geglu_bwd")
+    # 5. LayerNorm backward (+ the dropout that follows it in the chain): dx planes and the continued-chain planes from one launch
+    dy = (torch.randn(M, Cc, generator=g) * 1e-4).to(dev)
+    dx = (torch.randn(M, Cc, generator=g) * 1e-4).to(dev)
+    dmods = torch.zeros(32, 2 * Cc, device=dev)
+    ret, dxp, ret32 = T.layernorm_bwd_planes(h, dy, dx, G, mod=mods, group_batch=frag_b, group_rows=L, dmult=dmods, dadd=dmods[:, Cc:],
+                                             ld_d=2 * Cc, drop=(0.2, 5, 4), want_ret=True, want_dx=True, ret_fp32=True)
+    _assert_planes_carry(dx, dxp.hi, dxp.lo, G, "layernorm_bwd dx")
+    _assert_planes_carry(ret32, ret.hi, ret.lo, G, "layernorm_bwd dropout(dx)")
+    # 6. attention forward: per-fragment (split-f16 kernel, two output forms) and dense (both forms from one launch)
+    qkv = torch.randn(M, 3 * Cc, generator=g).to(dev)
+    att_scale = 1.0 / math.sqrt(dh)
+    a32 = ops.attn_blockdiag(qkv, Fv, L, H, dh, att_scale)
+    asp = ops.SplitAct.empty(M, Cc, dev)
+    ops.attn_blockdiag(qkv, Fv, L, H, dh, att_scale, out=asp)
+    _assert_planes_carry(a32, asp.hi, asp.lo, 1.0, "attn_blockdiag")
+    lens = [125, 500, 25, 350, 200, 75, 300, 475, 150, 400, 50, 450, 250, 500]
+    rows = sum(lens)
+    seq_len = torch.tensor(lens, dtype=torch.int32)
+    seq_off = (torch.cumsum(seq_len, 0) - seq_len).to(torch.int32).to(dev)
+    seq_len = seq_len.to(dev)
+    qkv2 = qkv[:rows].contiguous()
+    o32, op_, lse = T.attn_dense_train_planes(qkv2, seq_off, seq_len, 500, H, dh, att_scale)
+    _assert_planes_carry(o32, op_.hi, op_.lo, 1.0, "attn_dense")
+    # 7. attention backward: dqkv as fp32 and as planes of G * dqkv from one launch
+    do = (torch.randn(rows, Cc, generator=g) * 1e-4).to(dev)
+    dq32 = torch.empty(rows, 3 * Cc, device=dev)
+    dqp = planes(rows, 3 * Cc, G)
+    dvec = torch.empty_like(lse)
+    _lib.check(lib.pfpp_attn_dense_bwd_p(ptr(qkv2), ptr(o32), ptr(do), ptr(lse), ptr(dvec), ptr(dq32), ptr(seq_off), ptr(seq_len), None, 0,
+                                         len(lens), 500, H, dh, att_scale, P._pl(dqp), st()), "pfpp_attn_dense_bwd_p")
+    _assert_planes_carry(dq32, dqp.hi, dqp.lo, G, "attn_dense_bwd")
+    do = (torch.randn(M, Cc, generator=g) * 1e-4).to(dev)
+    dq32 = torch.empty(M, 3 * Cc, device=dev)
+    dqp = planes(M, 3 * Cc, G)
+    _lib.check(lib.pfpp_attn_blockdiag_bwd_p(ptr(qkv), ptr(do), ptr(dq32), Fv, L, H, dh, att_scale, P._pl(dqp), st()),
+               "pfpp_attn_blockdiag_bwd_p")
+    _assert_planes_carry(dq32, dqp.hi, dqp.lo, G, "attn_blockdiag_bwd")
+    # 8. GEMM epilogue with plane output (bias + activation applied to the accumulator, then split): against its fp32 form
+    W = PW(torch.randn(Cc, Cc, generator=g).to(dev) / math.sqrt(Cc))
+    bias = torch.randn(Cc, generator=g).to(dev)
+    for act in ("none", "relu", "silu"):
+        c32 = ops.gemm(nsp, W, M=M, N=Cc, K=Cc, lda=Cc, bias=bias, act=act)
+        csp = ops.SplitAct.empty(M, Cc, dev)
+        ops.gemm(nsp, W, M=M, N=Cc, K=Cc, lda=Cc, bias=bias, act=act, out=csp)
+        _assert_planes_carry(c32, csp.hi, csp.lo, 1.0, f"gemm epilogue {act}")
+    # 9. AdamW: the refreshed weight planes against the parameters it just wrote
+    n = 1 << 20
+    p = torch.randn(n, generator=g).to(dev) * 0.05
+    gr = (torch.randn(n, generator=g) * 1e-3).to(dev)
+    m_, v_ = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    hi, lo = torch.empty(n, dtype=torch.float16, device=dev), torch.empty(n, dtype=torch.float16, device=dev)
+    for step in (1, 2, 3):
+        T.adamw(p, gr, m_, v_, lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=step, hi=hi, lo=lo)
+        _assert_planes_carry(p, hi, lo, 1.0, "adamw planes")
