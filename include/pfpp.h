@@ -800,6 +800,60 @@ int pfpp_bn_apply(const float* x, int64_t rows, int64_t C, int64_t ld, const flo
                   const float* var, const float* gamma, const float* beta, float eps, float* y,
                   int64_t ldy, int64_t pool, pfpp_stream_t stream);
 
+/* ---- a17: the transformer blocks of the training step, sequenced from C ------------------------------------
+ * EncoderLayer.forward (denoiser/model/modules/attention.py:74-92) for a range of the layers of
+ * DenoiserTransformer.forward (denoiser_transformer.py:187-196) in train mode, and its backward (autograd of
+ * Denoiser.training_step, denoiser.py:128-145): the SAME launches with the SAME arguments that the host issues one by
+ * one through the entry points above (pfpp_layernorm_*_split / pfpp_dropout_layernorm_p, pfpp_gemm_planes,
+ * pfpp_attn_blockdiag_split, pfpp_attn_dense_train_p, pfpp_geglu_p; backward: pfpp_gemm_planes in its dX / dW forms,
+ * pfpp_geglu_bwd_p, pfpp_layernorm_bwd_p, pfpp_attn_*_bwd_p, pfpp_adamw_guarded) — enqueued from one call, so that the
+ * ~240 launches of the six blocks cost the host what hipLaunchKernel costs, not a marshalled foreign call each.
+ * Activations live in caller-owned arenas: layer i's saved tensors at fwd_arena + i * fwd_layer_bytes (layout private to
+ * the library, pfpp_tlayers_fwd_bytes() bytes; the layer's output [M, C] fp32 sits at pfpp_tlayers_fwd_hout_offset()),
+ * the backward's temporaries in bwd_arena (pfpp_tlayers_bwd_bytes()).  Weight planes are the caller's (scale 1 unless
+ * stated in .scale).  Weight / bias gradients ACCUMULATE into the fp32 buffers of pfpp_tlayer_grads.                    */
+typedef struct pfpp_tlayer_params {
+  pfpp_planes qkv1, o1, qkv2, o2, ff1, ff2;      /* [3C,C] (to_q|to_k|to_v), [C,C], [3C,C], [C,C], [2 inner, C], [C, inner] */
+  const float *bo1, *bo2, *g3, *b3, *bff1, *bff2; /* to_out.0.bias x2, norm3.weight / bias, ff.net.0.proj.bias, ff.net.2.bias */
+} pfpp_tlayer_params;
+typedef struct pfpp_tlayer_grads {
+  float *qkv1_w, *o1_w, *o1_b, *qkv2_w, *o2_w, *o2_b, *g3, *b3, *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+} pfpp_tlayer_grads;
+typedef struct pfpp_tlayer_adamw {              /* the layer's contiguous slice of the flat parameter buffers */
+  float *p, *g, *m, *v; void *hi, *lo; int64_t n;
+} pfpp_tlayer_adamw;
+typedef struct pfpp_tlayers_args {
+  int32_t n_layers;
+  const pfpp_tlayer_params* layers;             /* [n_layers] (host memory) */
+  const pfpp_tlayer_grads* grads;               /* [n_layers], backward only */
+  const pfpp_tlayer_adamw* adamw;               /* [n_layers] or NULL: optimizer-in-backward on the side stream (needs side != NULL) */
+  int64_t M, C, H, L, inner, Fv, B;             /* tokens (= Fv * L), width, heads, latent points, GEGLU inner width, fragments, puzzles */
+  float* h_in;                                  /* [M, C] tokens; token dropout is applied IN PLACE when p_tok > 0 */
+  const float* mods;                            /* [2 n_layers, B, 2C] AdaLN (scale | shift) rows */
+  const int32_t* frag_b;                        /* [Fv] puzzle of every fragment */
+  const int32_t *seq_off, *seq_len;             /* [n_seq] token range of every puzzle */
+  int64_t n_seq, max_len;
+  float att_scale, p_tok, p_lay;
+  uint64_t seed;
+  void* fwd_arena; int64_t fwd_layer_bytes;
+  float *ws_main, *ws_side; int64_t ws_bytes;   /* K-split workspaces of pfpp_gemm_planes, one per stream */
+  /* backward */
+  void* bwd_arena; int64_t bwd_bytes;
+  float grad_scale;                             /* power of two lifting gradient planes into the fp16 range */
+  float* dh;                                    /* [M, C] running gradient of the residual stream, updated in place */
+  pfpp_planes dhp;                              /* its planes (grad_scale * dh) on entry */
+  pfpp_planes* dhp_out;                         /* optional: where the planes of the gradient leaving the range are (inside bwd_arena) */
+  float* dmods;                                 /* [2 n_layers, B, 2C] AdaLN row gradients (accumulated) */
+  float* dtok;                                  /* [M, C] gradient w.r.t. the tokens (needed when the range reaches layer 0) */
+  float lr, beta1, beta2, eps, weight_decay, bc1, bc2, opt_g_scale; int32_t opt_zero_grad; int32_t* overflow;   /* with adamw */
+} pfpp_tlayers_args;
+int64_t pfpp_tlayers_fwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner);
+int64_t pfpp_tlayers_fwd_hout_offset(int64_t M, int64_t C, int64_t H, int64_t inner);
+int64_t pfpp_tlayers_bwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner);
+int pfpp_tlayers_fwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream);
+/* layers layer_hi-1 ... layer_lo; side = stream of the weight-gradient GEMMs (NULL: the main stream) */
+int pfpp_tlayers_bwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream, pfpp_stream_t side);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,330 @@
+// Host-side sequencing of the DenoiserTransformer's blocks for the training step (a17): pfpp_tlayers_fwd / pfpp_tlayers_bwd enqueue the
+// launches of a range of transformer layers from C++, in the order — and with the arguments — that pfpp_hip/train.py's
+// _forward_layers_planes / _backward_layers_planes issue them one ctypes call at a time (that Python sequence stays as the cross-check:
+// PFPP_TRAIN_CSEQ=0).  No arithmetic of its own: every launch goes through the library's public entry points.
+//
+// Reference: EncoderLayer.forward (denoiser/model/modules/attention.py:74-92: AdaLN -> self-attention (block-diagonal mask) -> +res ->
+// AdaLN -> global attention -> +res -> LayerNorm -> GEGLU feed-forward -> +res) for the layers of DenoiserTransformer.forward
+// (denoiser_transformer.py:187-196) in train mode, and its autograd in Denoiser.training_step (denoiser.py:128-145).
+//
+// Why: the iteration issues ~360 launches; ~240 of them belong to the six blocks.  From Python (argument marshalling + one foreign call
+// each) the host needs 6.3 ms to enqueue an iteration the GPU runs in 6.7 ms — any further GPU-side gain would be
+// hidden behind the enqueue.  From here a launch costs what hipLaunchKernel costs.
+#include <vector>
+
+#include "pfpp_common.h"
+
+namespace {
+
+struct EventRing {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get() {
+    if (ev.empty()) {
+      ev.resize(64);
+      for (auto& e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    hipEvent_t e = ev[next];
+    next = (next + 1) % ev.size();
+    return e;
+  }
+};
+EventRing g_ring;      // re-recording an event does not disturb waits already enqueued on it; 64 keeps us far from any doubt
+
+// everything queued on `producer` so far happens before whatever `consumer` is given next
+int order_after(hipStream_t consumer, hipStream_t producer) {
+  hipEvent_t e = g_ring.get();
+  if (!e || hipEventRecord(e, producer) != hipSuccess || hipStreamWaitEvent(consumer, e, 0) != hipSuccess) {
+    pfpp::set_error("pfpp_tlayers: hipEventRecord / hipStreamWaitEvent failed");
+    return PFPP_EHIP;
+  }
+  return PFPP_OK;
+}
+
+// A plane buffer of the backward chain that a weight-gradient GEMM on the side stream reads while the chain moves on: before the chain
+// writes it again (one or two layers later) it waits for that read.  Dedicated events (the ring's are re-recorded by other producers).
+struct Slot {
+  char* buf = nullptr;
+  hipEvent_t read_done = nullptr;
+  bool pending = false;
+};
+enum { SLOT_DZ0, SLOT_DZ1, SLOT_QA0, SLOT_QA1, SLOT_QB0, SLOT_QB1, SLOT_DY0, SLOT_DY1, SLOT_DY2, SLOT_DY3, SLOT_DH0, SLOT_DH1, N_SLOTS };
+Slot g_slots[N_SLOTS];      // one backward at a time per process (the engine's backward is not re-entrant either)
+
+int slot_acquire(Slot& s, char* buf, hipStream_t main_s) {
+  if (s.pending && s.buf == buf && hipStreamWaitEvent(main_s, s.read_done, 0) != hipSuccess) {
+    pfpp::set_error("pfpp_tlayers_bwd: hipStreamWaitEvent failed");
+    return PFPP_EHIP;
+  }
+  s.buf = buf;
+  s.pending = false;
+  return PFPP_OK;
+}
+int slot_read_on(Slot& s, hipStream_t side_s) {
+  if (!s.read_done && hipEventCreateWithFlags(&s.read_done, hipEventDisableTiming) != hipSuccess) {
+    pfpp::set_error("pfpp_tlayers_bwd: hipEventCreate failed");
+    return PFPP_EHIP;
+  }
+  if (hipEventRecord(s.read_done, side_s) != hipSuccess) {
+    pfpp::set_error("pfpp_tlayers_bwd: hipEventRecord failed");
+    return PFPP_EHIP;
+  }
+  s.pending = true;
+  return PFPP_OK;
+}
+
+#define TL_CALL(expr) do { const int rc_ = (expr); if (rc_ != PFPP_OK) return rc_; } while (0)
+
+inline float* f32_at(void* base, int64_t off) { return reinterpret_cast<float*>(static_cast<char*>(base) + off); }
+inline pfpp_planes planes_at(void* base, int64_t off, int64_t halfs, float scale) {
+  pfpp_planes p;
+  p.hi = static_cast<char*>(base) + off;
+  p.lo = static_cast<char*>(base) + off + halfs * 2;
+  p.scale = scale;
+  return p;
+}
+
+// byte offsets of one layer's saved activations inside its slice of the forward arena
+struct FwdLayout {
+  int64_t n1, qkv1, att1, y1, n2, qkv2, att2, att2p, lse, y2, n3, z, u, hout, total;
+};
+FwdLayout fwd_layout(int64_t M, int64_t C, int64_t H, int64_t inner) {
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  FwdLayout f;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { const int64_t at = o; o += up(bytes); return at; };
+  f.n1 = take(M * C * 4);          // planes: hi + lo = 4 bytes per element
+  f.qkv1 = take(M * 3 * C * 4);
+  f.att1 = take(M * C * 4);
+  f.y1 = take(M * C * 4);          // out-projection (+ bias), then h1 in place
+  f.n2 = take(M * C * 4);
+  f.qkv2 = take(M * 3 * C * 4);
+  f.att2 = take(M * C * 4);
+  f.att2p = take(M * C * 4);
+  f.lse = take(M * H * 4);
+  f.y2 = take(M * C * 4);
+  f.n3 = take(M * C * 4);
+  f.z = take(M * 2 * inner * 4);
+  f.u = take(M * inner * 4);
+  f.hout = take(M * C * 4);
+  f.total = o;
+  return f;
+}
+
+int gemm_pl(const pfpp_planes& A, const pfpp_planes& W, float* Cout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
+            bool a_km, bool w_km, const float* bias, const float* residual, bool accumulate, float* colsum, float* ws, int64_t ws_bytes,
+            int single_pass, pfpp_stream_t st) {
+  pfpp_gemm_planes_args a = {};
+  a.a_hi = A.hi; a.a_lo = A.lo; a.w_hi = W.hi; a.w_lo = W.lo;
+  a.C = Cout; a.bias = bias; a.residual = residual;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = residual ? ldc : 0;
+  a.a_kmajor = a_km; a.w_kmajor = w_km;
+  a.act = PFPP_ACT_NONE;
+  a.accumulate = accumulate;
+  a.alpha = 1.0f / (A.scale * W.scale);
+  a.single_pass = single_pass;
+  a.ws = ws; a.ws_bytes = ws_bytes;
+  if (colsum) { a.colsum = colsum; a.colsum_alpha = 1.0f / A.scale; }
+  return pfpp_gemm_planes(&a, st);
+}
+
+}  // namespace
+
+extern "C" int64_t pfpp_tlayers_fwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner) { return fwd_layout(M, C, H, inner).total; }
+
+extern "C" int64_t pfpp_tlayers_fwd_hout_offset(int64_t M, int64_t C, int64_t H, int64_t inner) { return fwd_layout(M, C, H, inner).hout; }
+
+extern "C" int pfpp_tlayers_fwd(const pfpp_tlayers_args* a, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream) {
+  PFPP_REQUIRE(a && a->layers && a->fwd_arena && a->h_in && a->mods && a->frag_b && a->seq_off && a->seq_len, "null pointer");
+  PFPP_REQUIRE(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= a->n_layers, "bad layer range");
+  const int64_t M = a->M, C = a->C, H = a->H, L = a->L, inner = a->inner, dh = C / H;
+  PFPP_REQUIRE(M > 0 && C > 0 && H > 0 && C % H == 0 && inner > 0 && L > 0 && M == a->Fv * L, "bad sizes");
+  const FwdLayout lo = fwd_layout(M, C, H, inner);
+  PFPP_REQUIRE(a->fwd_layer_bytes >= lo.total, "fwd_layer_bytes smaller than pfpp_tlayers_fwd_bytes()");
+  const float eps = 1e-5f;
+  const int64_t ld_mod = 2 * C;
+  for (int i = layer_lo; i < layer_hi; ++i) {
+    const pfpp_tlayer_params& w = a->layers[i];
+    char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
+    // the residual stream entering the layer: the tokens for layer 0, the previous layer's output otherwise
+    float* h = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
+    const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
+    const float* mod2 = a->mods + (int64_t)(2 * i + 1) * a->B * ld_mod;
+    pfpp_planes n1 = planes_at(base, lo.n1, M * C, 1.0f), att1 = planes_at(base, lo.att1, M * C, 1.0f);
+    pfpp_planes n2 = planes_at(base, lo.n2, M * C, 1.0f), att2p = planes_at(base, lo.att2p, M * C, 1.0f);
+    pfpp_planes n3 = planes_at(base, lo.n3, M * C, 1.0f), u = planes_at(base, lo.u, M * inner, 1.0f);
+    float *qkv1 = f32_at(base, lo.qkv1), *y1 = f32_at(base, lo.y1), *qkv2 = f32_at(base, lo.qkv2), *att2 = f32_at(base, lo.att2);
+    float *lse = f32_at(base, lo.lse), *y2 = f32_at(base, lo.y2), *z = f32_at(base, lo.z), *hout = f32_at(base, lo.hout);
+    // ---- self attention (attention.py:77-80)
+    if (i == 0 && a->p_tok > 0.0f)        // PositionalEncoding's token dropout rides in the first LayerNorm (in place on the tokens)
+      TL_CALL(pfpp_dropout_layernorm_p(h, nullptr, h, nullptr, mod1, ld_mod, nullptr, nullptr, a->frag_b, L, 1, M, C, eps, a->p_tok, a->seed, 0,
+                                       &n1, stream));
+    else
+      TL_CALL(pfpp_layernorm_grouped_split(h, n1.hi, n1.lo, mod1, ld_mod, a->frag_b, L, M, C, eps, stream));
+    TL_CALL(gemm_pl(n1, w.qkv1, qkv1, M, 3 * C, C, C, C, 3 * C, false, false, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(pfpp_attn_blockdiag_split(qkv1, att1.hi, att1.lo, a->Fv, L, H, dh, a->att_scale, stream));
+    if (a->p_lay > 0.0f) {
+      TL_CALL(gemm_pl(att1, w.o1, y1, M, C, C, C, C, C, false, false, w.bo1, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(pfpp_dropout_layernorm_p(y1, h, y1, nullptr, mod2, ld_mod, nullptr, nullptr, a->frag_b, L, 1, M, C, eps, a->p_lay, a->seed,
+                                       (uint32_t)(1 + 3 * i), &n2, stream));
+    } else {
+      TL_CALL(gemm_pl(att1, w.o1, y1, M, C, C, C, C, C, false, false, w.bo1, h, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(pfpp_layernorm_grouped_split(y1, n2.hi, n2.lo, mod2, ld_mod, a->frag_b, L, M, C, eps, stream));
+    }
+    // ---- global attention (attention.py:82-85)
+    TL_CALL(gemm_pl(n2, w.qkv2, qkv2, M, 3 * C, C, C, C, 3 * C, false, false, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(pfpp_attn_dense_train_p(qkv2, att2, lse, a->seq_off, a->seq_len, nullptr, 0, a->n_seq, a->max_len, H, dh, a->att_scale, &att2p, stream));
+    if (a->p_lay > 0.0f) {
+      TL_CALL(gemm_pl(att2p, w.o2, y2, M, C, C, C, C, C, false, false, w.bo2, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(pfpp_dropout_layernorm_p(y2, y1, y2, nullptr, nullptr, 0, w.g3, w.b3, nullptr, 1, 1, M, C, eps, a->p_lay, a->seed,
+                                       (uint32_t)(2 + 3 * i), &n3, stream));
+    } else {
+      TL_CALL(gemm_pl(att2p, w.o2, y2, M, C, C, C, C, C, false, false, w.bo2, y1, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(pfpp_layernorm_split(y2, n3.hi, n3.lo, nullptr, 0, w.g3, w.b3, M, C, 1, eps, stream));
+    }
+    // ---- GEGLU feed-forward (attention.py:87-90)
+    TL_CALL(gemm_pl(n3, w.ff1, z, M, 2 * inner, C, C, C, 2 * inner, false, false, w.bff1, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(pfpp_geglu_p(z, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &u, stream));
+    TL_CALL(gemm_pl(u, w.ff2, hout, M, C, inner, inner, inner, C, false, false, w.bff2, y2, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+  }
+  return PFPP_OK;
+}
+
+// Backward of layers [layer_lo, layer_hi), last first.  dh [M, C] fp32 is the running gradient of the residual stream (updated in place),
+// dhp its planes (grad_scale * dh) — on entry the gradient of layer_hi - 1's output, on exit that of layer_lo's input (for layer_lo == 0:
+// dtok [M, C] receives the gradient with respect to the tokens instead, token dropout applied).  Weight / bias gradients go to `side`
+// (ordered after what they read; NULL = the main stream), optionally followed by the layer's AdamW update there (a->adamw).
+extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream, pfpp_stream_t side) {
+  PFPP_REQUIRE(a && a->layers && a->fwd_arena && a->bwd_arena && a->h_in && a->mods && a->frag_b && a->seq_off && a->seq_len && a->dh &&
+               a->dhp.hi && a->dhp.lo && a->dmods, "null pointer");
+  PFPP_REQUIRE(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= a->n_layers, "bad layer range");
+  PFPP_REQUIRE(layer_lo > 0 || a->dtok, "dtok is needed when the range reaches layer 0");
+  const int64_t M = a->M, C = a->C, H = a->H, L = a->L, inner = a->inner, dh = C / H;
+  const FwdLayout lo = fwd_layout(M, C, H, inner);
+  const float eps = 1e-5f, G = a->grad_scale;
+  const int64_t ld_mod = 2 * C;
+  hipStream_t main_s = pfpp::as_stream(stream);
+  hipStream_t side_s = side ? pfpp::as_stream(side) : main_s;
+  pfpp_stream_t side_t = side ? side : stream;
+  float* ws_side = side ? a->ws_side : a->ws_main;
+  // temporaries of the backward chain.  fp32 intermediates (du, dn, datt, dvec) only ever live on the main stream and are reused at
+  // once; the plane buffers are also read by weight-gradient GEMMs on the side stream: two (by layer parity) of each, and the chain
+  // waits for the side stream's read before it writes one again (Slot)
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  char* tb = static_cast<char*>(a->bwd_arena);
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) { char* p = tb + o; o += up(bytes); return p; };
+  char* du_b = take(M * inner * 4);
+  char* dn_b = take(M * C * 4);
+  char* datt_b = take(M * C * 4);
+  char* dvec_b = take(M * H * 4);
+  char* slot_buf[N_SLOTS];
+  for (int k = SLOT_DZ0; k <= SLOT_DZ1; ++k) slot_buf[k] = take(M * 2 * inner * 4);
+  for (int k = SLOT_QA0; k <= SLOT_QB1; ++k) slot_buf[k] = take(M * 3 * C * 4);
+  for (int k = SLOT_DY0; k <= SLOT_DH1; ++k) slot_buf[k] = take(M * C * 4);
+  PFPP_REQUIRE(a->bwd_bytes >= o, "bwd_bytes smaller than pfpp_tlayers_bwd_bytes()");
+
+  // planes of scale G in slot k, safe to write on the main stream
+  auto fresh = [&](int k, int64_t elems, pfpp_planes* out) -> int {
+    if (side) TL_CALL(slot_acquire(g_slots[k], slot_buf[k], main_s));
+    *out = planes_at(slot_buf[k], 0, elems, G);
+    return PFPP_OK;
+  };
+  // dW += dY^T . X, db += colsum(dY): both operands read in place as k-major planes, on the side stream; `k` = the slot dY lives in
+  auto dw = [&](const pfpp_planes& dyp, int k, const pfpp_planes& xp, int64_t n_out, int64_t n_in, float* gw, float* gb) -> int {
+    if (side) TL_CALL(order_after(side_s, main_s));
+    TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t));
+    if (side && k >= 0) TL_CALL(slot_read_on(g_slots[k], side_s));
+    return PFPP_OK;
+  };
+  auto dx = [&](const pfpp_planes& dyp, const pfpp_planes& W, float* out, int64_t n_in, int64_t n_out) -> int {
+    return gemm_pl(dyp, W, out, M, n_in, n_out, n_out, n_in, n_in, false, true, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream);
+  };
+
+  pfpp_planes dhp = a->dhp;
+  int dhp_slot = -1;                    // the caller's buffer on entry (kept alive by the caller), one of ours afterwards
+  for (int k = SLOT_DH0; k <= SLOT_DH1; ++k)
+    if (a->dhp.hi == slot_buf[k]) dhp_slot = k;      // a continued range: the previous call's dhp_out
+  for (int i = layer_hi - 1; i >= layer_lo; --i) {
+    const pfpp_tlayer_params& w = a->layers[i];
+    const pfpp_tlayer_grads& g = a->grads[i];
+    char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
+    const float* h0 = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
+    const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
+    const float* mod2 = a->mods + (int64_t)(2 * i + 1) * a->B * ld_mod;
+    float* dmod1 = a->dmods + (int64_t)(2 * i) * a->B * ld_mod;
+    float* dmod2 = a->dmods + (int64_t)(2 * i + 1) * a->B * ld_mod;
+    const pfpp_planes n1 = planes_at(base, lo.n1, M * C, 1.0f), att1 = planes_at(base, lo.att1, M * C, 1.0f);
+    const pfpp_planes n2 = planes_at(base, lo.n2, M * C, 1.0f), att2p = planes_at(base, lo.att2p, M * C, 1.0f);
+    const pfpp_planes n3 = planes_at(base, lo.n3, M * C, 1.0f), u = planes_at(base, lo.u, M * inner, 1.0f);
+    const float *qkv1 = f32_at(base, lo.qkv1), *h1 = f32_at(base, lo.y1), *qkv2 = f32_at(base, lo.qkv2), *att2 = f32_at(base, lo.att2);
+    const float *lse = f32_at(base, lo.lse), *h2 = f32_at(base, lo.y2), *z = f32_at(base, lo.z);
+    const int par = i & 1;
+    float* du = reinterpret_cast<float*>(du_b);
+    float* dn = reinterpret_cast<float*>(dn_b);
+    float* datt = reinterpret_cast<float*>(datt_b);
+    const int drop = a->p_lay > 0.0f ? 1 : 0;
+    // ---- feed-forward (attention.py:87-90)
+    TL_CALL(dw(dhp, dhp_slot, u, C, inner, g.ff2_w, g.ff2_b));
+    TL_CALL(dx(dhp, w.ff2, du, inner, C));
+    pfpp_planes dzp, dyp, dqkvp;
+    TL_CALL(fresh(SLOT_DZ0 + par, M * 2 * inner, &dzp));
+    TL_CALL(pfpp_geglu_bwd_p(z, du, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &dzp, stream));
+    TL_CALL(dw(dzp, SLOT_DZ0 + par, n3, 2 * inner, C, g.ff1_w, g.ff1_b));
+    TL_CALL(dx(dzp, w.ff1, dn, C, 2 * inner));
+    TL_CALL(fresh(SLOT_DY0 + 2 * par, M * C, &dyp));
+    TL_CALL(pfpp_layernorm_bwd_p(h2, dn, nullptr, 0, w.g3, nullptr, 32, 1, a->dh, g.g3, g.b3, 0, M, C, eps, nullptr, a->p_lay, a->seed,
+                                 (uint32_t)(2 + 3 * i), drop, &dyp, nullptr, stream));
+    // ---- global attention (attention.py:82-85)
+    TL_CALL(dw(dyp, SLOT_DY0 + 2 * par, att2p, C, C, g.o2_w, g.o2_b));
+    TL_CALL(dx(dyp, w.o2, datt, C, C));
+    TL_CALL(fresh(SLOT_QA0 + par, M * 3 * C, &dqkvp));
+    TL_CALL(pfpp_attn_dense_bwd_p(qkv2, att2, datt, lse, reinterpret_cast<float*>(dvec_b), nullptr, a->seq_off, a->seq_len, nullptr, 0, a->n_seq,
+                                  a->max_len, H, dh, a->att_scale, &dqkvp, stream));
+    TL_CALL(dw(dqkvp, SLOT_QA0 + par, n2, 3 * C, C, g.qkv2_w, nullptr));
+    TL_CALL(dx(dqkvp, w.qkv2, dn, C, 3 * C));
+    TL_CALL(fresh(SLOT_DY0 + 2 * par + 1, M * C, &dyp));
+    TL_CALL(pfpp_layernorm_bwd_p(h1, dn, mod2, ld_mod, nullptr, a->frag_b, L, 1, a->dh, dmod2, dmod2 + C, ld_mod, M, C, eps, nullptr, a->p_lay,
+                                 a->seed, (uint32_t)(1 + 3 * i), drop, &dyp, nullptr, stream));
+    // ---- self attention (attention.py:77-80)
+    TL_CALL(dw(dyp, SLOT_DY0 + 2 * par + 1, att1, C, C, g.o1_w, g.o1_b));
+    TL_CALL(dx(dyp, w.o1, datt, C, C));
+    TL_CALL(fresh(SLOT_QB0 + par, M * 3 * C, &dqkvp));
+    TL_CALL(pfpp_attn_blockdiag_bwd_p(qkv1, datt, nullptr, a->Fv, L, H, dh, a->att_scale, &dqkvp, stream));
+    TL_CALL(dw(dqkvp, SLOT_QB0 + par, n1, 3 * C, C, g.qkv1_w, nullptr));
+    TL_CALL(dx(dqkvp, w.qkv1, dn, C, 3 * C));
+    if (i > 0) {
+      // the updated running gradient is the dY of layer i - 1's second feed-forward linear
+      pfpp_planes nxt;
+      TL_CALL(fresh(SLOT_DH0 + par, M * C, &nxt));
+      TL_CALL(pfpp_layernorm_bwd_p(h0, dn, mod1, ld_mod, nullptr, a->frag_b, L, 1, a->dh, dmod1, dmod1 + C, ld_mod, M, C, eps, nullptr, 0.0f, 0, 0, 0,
+                                   nullptr, &nxt, stream));
+      dhp = nxt;
+      dhp_slot = SLOT_DH0 + par;
+    } else if (a->p_tok > 0.0f) {
+      TL_CALL(pfpp_layernorm_bwd_dropout(h0, dn, mod1, ld_mod, nullptr, a->frag_b, L, 1, a->dh, dmod1, dmod1 + C, ld_mod, M, C, eps, a->dtok,
+                                         a->p_tok, a->seed, 0, stream));
+    } else {
+      TL_CALL(pfpp_layernorm_bwd(h0, dn, mod1, ld_mod, nullptr, a->frag_b, L, 1, a->dh, dmod1, dmod1 + C, ld_mod, M, C, eps, stream));
+      if (a->dtok != a->dh && hipMemcpyAsync(a->dtok, a->dh, (size_t)M * C * 4, hipMemcpyDeviceToDevice, main_s) != hipSuccess)
+        return pfpp::check_launch(__func__);
+    }
+    if (a->adamw && side) {
+      // optimizer in the backward: the layer's slice of the flat buffer is final once its weight gradients (side stream) and its
+      // LayerNorm gradients (main stream, all queued by now) have run
+      const pfpp_tlayer_adamw& ad = a->adamw[i];
+      TL_CALL(order_after(side_s, main_s));
+      TL_CALL(pfpp_adamw_guarded(ad.p, ad.g, ad.m, ad.v, ad.hi, ad.lo, ad.n, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bc1, a->bc2,
+                                 a->opt_g_scale, a->opt_zero_grad, a->overflow, side_t));
+    }
+  }
+  if (a->dhp_out) *a->dhp_out = dhp;
+  return PFPP_OK;
+}
+
+extern "C" int64_t pfpp_tlayers_bwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner) {
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  return up(M * inner * 4) + 2 * up(M * C * 4) + up(M * H * 4) + 2 * up(M * 2 * inner * 4) + 4 * up(M * 3 * C * 4) + 6 * up(M * C * 4);
+}

@@ -114,8 +114,49 @@ class GemmPlanesArgs(C.Structure):
 
 _pl = C.POINTER(PlanesC)
 
+
+class TlayerParams(C.Structure):
+    """mirror of struct pfpp_tlayer_params (include/pfpp.h)"""
+
+    _fields_ = ([(n, PlanesC) for n in ("qkv1", "o1", "qkv2", "o2", "ff1", "ff2")] +
+                [(n, _p) for n in ("bo1", "bo2", "g3", "b3", "bff1", "bff2")])
+
+
+class TlayerGrads(C.Structure):
+    """mirror of struct pfpp_tlayer_grads (include/pfpp.h)"""
+
+    _fields_ = [(n, _p) for n in ("qkv1_w", "o1_w", "o1_b", "qkv2_w", "o2_w", "o2_b", "g3", "b3", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+
+
+class TlayerAdamw(C.Structure):
+    """mirror of struct pfpp_tlayer_adamw (include/pfpp.h)"""
+
+    _fields_ = [("p", _p), ("g", _p), ("m", _p), ("v", _p), ("hi", _p), ("lo", _p), ("n", _i64)]
+
+
+class TlayersArgs(C.Structure):
+    """mirror of struct pfpp_tlayers_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("n_layers", _i32), ("layers", C.POINTER(TlayerParams)), ("grads", C.POINTER(TlayerGrads)), ("adamw", C.POINTER(TlayerAdamw)),
+        ("M", _i64), ("C", _i64), ("H", _i64), ("L", _i64), ("inner", _i64), ("Fv", _i64), ("B", _i64),
+        ("h_in", _p), ("mods", _p), ("frag_b", _p), ("seq_off", _p), ("seq_len", _p),
+        ("n_seq", _i64), ("max_len", _i64),
+        ("att_scale", _f32), ("p_tok", _f32), ("p_lay", _f32),
+        ("seed", C.c_uint64),
+        ("fwd_arena", _p), ("fwd_layer_bytes", _i64),
+        ("ws_main", _p), ("ws_side", _p), ("ws_bytes", _i64),
+        ("bwd_arena", _p), ("bwd_bytes", _i64),
+        ("grad_scale", _f32),
+        ("dh", _p), ("dhp", PlanesC), ("dhp_out", C.POINTER(PlanesC)), ("dmods", _p), ("dtok", _p),
+        ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("bc1", _f32), ("bc2", _f32),
+        ("opt_g_scale", _f32), ("opt_zero_grad", _i32), ("overflow", _p),
+    ]
+
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
+    "pfpp_tlayers_fwd": [C.POINTER(TlayersArgs), _i32, _i32, _p],
+    "pfpp_tlayers_bwd": [C.POINTER(TlayersArgs), _i32, _i32, _p, _p],
     "pfpp_set_attention_mode": [C.c_int],
     "pfpp_se3_rotate_gather": [_p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_pose_apply": [_p, _p, _p, _p, _i64, _i64, C.c_int, _p],
@@ -206,6 +247,9 @@ PLAIN = {
     "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_get_attention_mode": ([], C.c_int),
+    "pfpp_tlayers_fwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
+    "pfpp_tlayers_fwd_hout_offset": ([_i64, _i64, _i64, _i64], C.c_int64),
+    "pfpp_tlayers_bwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_tblock_small_barrier_words": ([], C.c_int64),

@@ -85,6 +85,16 @@ def _workspace(device):
     return ws
 
 
+def workspace_for(device, stream_handle: int) -> torch.Tensor:
+    """the K-split workspace of launches on the raw stream `stream_handle` (same table as _workspace: a stream has one)"""
+    key = (device.index, int(stream_handle))
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty((24 * 1024 * 1024,), dtype=_f32, device=device)
+        _WS[key] = ws
+    return ws
+
+
 def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_kmajor: bool = False, w_kmajor: bool = False,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
          accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True,

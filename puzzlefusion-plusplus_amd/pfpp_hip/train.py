@@ -304,6 +304,10 @@ class DenoiserTrainEngine:
         # LDS-DMA staged plane kernel (csrc/gemm_pl.hip); the LayerNorm / attention / GEGLU kernels hand their results over
         # as split-f16 planes, gradients lifted by grad_scale.  PFPP_TRAIN_PLANES=0 restores the register-staged kernels.
         self._planes = os.environ.get("PFPP_TRAIN_PLANES", "1") == "1" and ops.GEMM_MODE == "f16x3"
+        # the six blocks' ~240 launches per iteration enqueued from C (csrc/tlayer.hip: pfpp_tlayers_fwd / _bwd) instead of one ctypes
+        # call each; same launches, same arguments (PFPP_TRAIN_CSEQ=0: the Python sequence below, the cross-check of the tests)
+        self._cseq = os.environ.get("PFPP_TRAIN_CSEQ", "1") == "1"
+        self._cseq_static = None
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
         self._early: List[Tuple[int, int]] = []       # [a, b) ranges of the flat buffer the armed backward has already updated
@@ -360,7 +364,9 @@ class DenoiserTrainEngine:
                       max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
                       p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse))
         layers = []
-        if self._planes:
+        if self._planes and self._use_cseq(fuse):
+            h = self._forward_layers_c(h, w, s, mods, p_tok, p_lay, seed, Fv, L, H, att_scale)
+        elif self._planes:
             h = self._forward_layers_planes(h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale)
         else:
             h = self._forward_layers(h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale, M, C)
@@ -485,6 +491,138 @@ class DenoiserTrainEngine:
             layers.append(lay)
         return h
 
+    # ------------------------------------------------------------------------------------------ blocks sequenced from C
+    def _use_cseq(self, fuse: bool) -> bool:
+        return self._cseq and fuse and ops.GEMM_TRACE is None and not ops.SINGLE_PASS
+
+    def _cseq_args(self, w, g):
+        """the per-engine part of pfpp_tlayers_args: weight planes / bias / gradient / optimizer-slice pointers into the flat buffers
+        (which never move: FlatParams.operands() checks) -> (args, keep-alive)"""
+        if self._cseq_static is not None:
+            return self._cseq_static
+        from ._lib import PlanesC, TlayerAdamw, TlayerGrads, TlayerParams, TlayersArgs
+
+        n = self.num_layers
+        f = self.flat
+        layers, grads, adam = (TlayerParams * n)(), (TlayerGrads * n)(), (TlayerAdamw * n)()
+        for i in range(n):
+            for name, key in (("qkv1", f"{i}.self_attn.qkv.w"), ("o1", f"{i}.self_attn.o.w"), ("qkv2", f"{i}.global_attn.qkv.w"),
+                              ("o2", f"{i}.global_attn.o.w"), ("ff1", f"{i}.ff1.w"), ("ff2", f"{i}.ff2.w")):
+                pw = w[key]
+                setattr(layers[i], name, PlanesC(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.scale))
+            for name, key in (("bo1", f"{i}.self_attn.o.b"), ("bo2", f"{i}.global_attn.o.b"), ("g3", f"{i}.norm3.g"), ("b3", f"{i}.norm3.b"),
+                              ("bff1", f"{i}.ff1.b"), ("bff2", f"{i}.ff2.b")):
+                setattr(layers[i], name, w[key].data_ptr())
+            for name, key in (("qkv1_w", f"{i}.self_attn.qkv.w"), ("o1_w", f"{i}.self_attn.o.w"), ("o1_b", f"{i}.self_attn.o.b"),
+                              ("qkv2_w", f"{i}.global_attn.qkv.w"), ("o2_w", f"{i}.global_attn.o.w"), ("o2_b", f"{i}.global_attn.o.b"),
+                              ("g3", f"{i}.norm3.g"), ("b3", f"{i}.norm3.b"), ("ff1_w", f"{i}.ff1.w"), ("ff1_b", f"{i}.ff1.b"),
+                              ("ff2_w", f"{i}.ff2.w"), ("ff2_b", f"{i}.ff2.b")):
+                setattr(grads[i], name, g[key].data_ptr())
+            a, b = f.layer_ranges[i]
+            adam[i] = TlayerAdamw(f.params[a:b].data_ptr(), f.grads[a:b].data_ptr(), f.exp_avg[a:b].data_ptr(), f.exp_avg_sq[a:b].data_ptr(),
+                                  f.hi[a:b].data_ptr(), f.lo[a:b].data_ptr(), b - a)
+        args = TlayersArgs()
+        args.n_layers = n
+        args.layers, args.grads = layers, grads
+        C = w["shape.b"].numel()
+        args.C, args.H, args.inner = C, self.num_heads, w["0.ff1.w"].f32.shape[0] // 2
+        self._cseq_static = (args, (layers, grads, adam))
+        return self._cseq_static
+
+    def _forward_layers_c(self, h, w, s, mods, p_tok, p_lay, seed, Fv, L, H, att_scale):
+        """_forward_layers_planes with the launches enqueued by pfpp_tlayers_fwd; the saved activations live in one arena"""
+        import ctypes as C_
+
+        from . import _lib, planes as P
+
+        args, _keep = self._cseq_args(w, self.flat.operands()["g"])
+        lib = _lib.load()
+        M, C = h.shape
+        dev = h.device
+        inner = int(args.inner)
+        layer_bytes = int(lib.pfpp_tlayers_fwd_bytes(M, C, H, inner))
+        arena = torch.empty(self.num_layers * layer_bytes, dtype=torch.uint8, device=dev)
+        if self._side is not None:
+            arena.record_stream(self._side)          # the weight-gradient GEMMs of the backward read the saved planes there
+        main_h = ops.raw_stream_id(dev.index)
+        args.M, args.L, args.Fv, args.B = M, L, Fv, mods.shape[1]
+        args.h_in, args.mods = h.data_ptr(), mods.data_ptr()
+        args.frag_b, args.seq_off, args.seq_len = s["frag_b"].data_ptr(), s["seq_off"].data_ptr(), s["seq_len"].data_ptr()
+        args.n_seq, args.max_len = s["seq_off"].numel(), s["max_len"]
+        args.att_scale, args.p_tok, args.p_lay, args.seed = att_scale, p_tok, p_lay, seed
+        args.fwd_arena, args.fwd_layer_bytes = arena.data_ptr(), layer_bytes
+        ws = P.workspace_for(dev, main_h)
+        args.ws_main, args.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        _lib.check(lib.pfpp_tlayers_fwd(C_.byref(args), 0, self.num_layers, C_.c_void_p(main_h)), "pfpp_tlayers_fwd")
+        hout = int(lib.pfpp_tlayers_fwd_hout_offset(M, C, H, inner)) + (self.num_layers - 1) * layer_bytes
+        s["cseq"] = dict(arena=arena, layer_bytes=layer_bytes, tokens=h, mods=mods)
+        return arena[hout: hout + M * C * 4].view(torch.float32).view(M, C)
+
+    def _backward_layers_c(self, s, w, g, dh_, dmods):
+        """_backward_layers_planes with the launches enqueued by pfpp_tlayers_bwd: one call for all layers (the per-layer AdamW of
+        an armed step included), or one call per layer when the ranks exchange each layer's gradients as it completes"""
+        import ctypes as C_
+
+        from . import _lib, planes as P
+        from ._lib import PlanesC
+
+        args, (layers, grads, adam) = self._cseq_args(w, g)
+        lib = _lib.load()
+        cs = s["cseq"]
+        M, C, L, Fv = s["M"], s["C"], s["L"], s["Fv"]
+        H, inner = self.num_heads, int(args.inner)
+        dev = dh_.device
+        G = self.grad_scale
+        main_h = ops.raw_stream_id(dev.index)
+        side_h = self._side.cuda_stream if self._side is not None else None
+        bwd_bytes = int(lib.pfpp_tlayers_bwd_bytes(M, C, H, inner))
+        tmp = torch.empty(bwd_bytes, dtype=torch.uint8, device=dev)
+        dhp = P.split(dh_, G)
+        p_tok = s["p_tok"]
+        dtok = torch.empty_like(dh_) if p_tok > 0.0 else dh_
+        if self._side is not None:
+            tmp.record_stream(self._side)
+            dhp.record_stream(self._side)
+        args.M, args.L, args.Fv, args.B = M, L, Fv, cs["mods"].shape[1]
+        args.h_in, args.mods = cs["tokens"].data_ptr(), cs["mods"].data_ptr()
+        args.frag_b, args.seq_off, args.seq_len = s["frag_b"].data_ptr(), s["seq_off"].data_ptr(), s["seq_len"].data_ptr()
+        args.n_seq, args.max_len = s["seq_off"].numel(), s["max_len"]
+        args.att_scale, args.p_tok, args.p_lay, args.seed = s["att_scale"], p_tok, s["p_lay"], s["seed"]
+        args.fwd_arena, args.fwd_layer_bytes = cs["arena"].data_ptr(), cs["layer_bytes"]
+        ws = P.workspace_for(dev, main_h)
+        args.ws_main, args.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        args.ws_side = P.workspace_for(dev, side_h).data_ptr() if side_h is not None else None
+        args.bwd_arena, args.bwd_bytes = tmp.data_ptr(), bwd_bytes
+        args.grad_scale = G
+        args.dh, args.dmods, args.dtok = dh_.data_ptr(), dmods.data_ptr(), dtok.data_ptr()
+        args.dhp = dhp.c()
+        nxt = PlanesC()
+        args.dhp_out = C_.pointer(nxt)
+        reducing = self._exchange.reducing()
+        in_c = self._armed is not None and self._side is not None and not self._exchange.active()
+        if in_c:
+            # optimizer in the backward (arm_optimizer), single rank: each layer's AdamW is queued on the side stream by the C sequencer
+            hp = self._armed
+            step = self.step_count + 1
+            args.adamw = adam
+            args.lr, args.beta1, args.beta2, args.eps, args.weight_decay = hp["lr"], hp["betas"][0], hp["betas"][1], hp["eps"], hp["weight_decay"]
+            args.bc1, args.bc2 = 1.0 - hp["betas"][0] ** step, 1.0 - hp["betas"][1] ** step
+            args.opt_g_scale, args.opt_zero_grad = 1.0, int(self._armed_zero)
+            args.overflow = self._overflow.data_ptr() if self._overflow is not None else None
+        else:
+            args.adamw = None
+        side_arg = C_.c_void_p(side_h) if side_h is not None else None
+        if not reducing:
+            _lib.check(lib.pfpp_tlayers_bwd(C_.byref(args), 0, self.num_layers, C_.c_void_p(main_h), side_arg), "pfpp_tlayers_bwd")
+            if in_c:
+                self._early.extend(self.flat.layer_ranges)
+        else:
+            for i in reversed(range(self.num_layers)):
+                _lib.check(lib.pfpp_tlayers_bwd(C_.byref(args), i, i + 1, C_.c_void_p(main_h), side_arg), "pfpp_tlayers_bwd")
+                args.dhp = nxt                         # the planes of the gradient entering layer i - 1 (inside the temporaries)
+                self._layer_done(i)
+        return dtok
+
     def _zeroed_dx_pool(self, M, C, w):
         """the split input-gradient GEMMs of the backward (3 per layer at token counts below ~8,000) add into zeroed outputs:
         one fill for all of them, issued on the weight-gradient stream while it has nothing else to do (the forward), instead of
@@ -600,7 +738,9 @@ class DenoiserTrainEngine:
         # multi-rank: the two AdaLN linears of a block get their gradients as soon as the block's backward is through and travel with
         # the block's slice (otherwise 25 MB of dense gradient would be left for the exposed tail after the backward)
         self._ada_layerwise = (dmods, s["se"], g, B, C, G) if (self._exchange.reducing() and self._ada_per_layer) else None
-        if self._planes:
+        if self._planes and s.get("cseq") is not None:
+            dtok = self._backward_layers_c(s, w, g, dh_, dmods)
+        elif self._planes:
             dtok = self._backward_layers_planes(s, w, g, dh_, dmods)
         else:
             dtok = self._backward_layers(s, w, g, dh_, dmods)

@@ -145,7 +145,7 @@ def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev, armed):
             eng.arm_optimizer(lr=lr)
         eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
         if armed:
-            assert sorted(eng._early) == list(range(eng.num_layers))       # every layer went early
+            assert sorted(eng._early) == sorted(eng.flat.layer_ranges)       # every layer's slice went early
         eng.optimizer_step(lr=lr)
         assert eng._armed is None and eng._early == []
     named = dict(eng.module.named_parameters())
@@ -1137,3 +1137,39 @@ def test_two_rank_replicas_stay_equal_after_an_overflow(dev):
         assert torch.equal(res[0][k], res[1][k]), k
         assert torch.isfinite(res[0][k].float()).all(), k
     assert res[0]["kept"] and res[1]["kept"] and res[0]["flagged"]
+
+
+@pytest.mark.parametrize("train,armed", [(True, False), (True, True), (False, False)])
+def test_blocks_sequenced_from_c_equal_the_python_sequence(golden, weights_sd, dev, train, armed):
+    """VERDICT r3 'do this' 3: pfpp_tlayers_fwd / pfpp_tlayers_bwd (csrc/tlayer.hip) enqueue the six blocks' launches from C — the same
+    launches with the same arguments as the Python sequence (PFPP_TRAIN_CSEQ=0 / engine._cseq = False), so the prediction is
+    bit-identical, the gradients agree to the order of the LayerNorm / AdaLN gradient atomics, and an armed step (AdamW per layer on the
+    side stream, queued by the C sequencer) leaves the same parameters."""
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    inp, noise, _ = golden_inputs(golden, dev)
+    hp = dict(lr=1e-3, weight_decay=1e-2)
+    out = []
+    for cseq in (False, True):
+        eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+        eng._cseq = cseq
+        for step in range(2):
+            eng.flat.zero_grad()
+            if armed:
+                eng.arm_optimizer(**hp)
+            pred, ctx = eng.forward(*inp, seed=11 + step, train=train)
+            assert (ctx.t.get("cseq") is not None) == cseq
+            n = pred.shape[0] * pred.shape[1]
+            dpred = ((pred - noise).reshape(n, 7).float() * (2.0 / n)).contiguous()
+            eng.backward(ctx, dpred)
+            torch.cuda.synchronize()
+            grads = eng.flat.grads.clone()
+            eng.optimizer_step(**hp)
+        torch.cuda.synchronize()
+        out.append((pred.clone(), grads, eng.flat.params.clone(), eng.flat.exp_avg.clone()))
+        del eng
+    (p0, g0, w0, m0), (p1, g1, w1, m1) = out
+    assert torch.equal(p0, p1)
+    assert rel(g1, g0.cpu()) < 2e-6 and rel(m1, m0.cpu()) < 2e-6
+    assert float((w1 - w0).abs().max()) <= 2e-3 * 1.0001 * 2        # Adam moves an element by at most ~lr per step; sign flips only at noise-level gradients
+    assert float(((w1 - w0).abs() > 1e-6).float().mean()) < 1e-3
