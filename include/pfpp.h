@@ -854,6 +854,29 @@ int pfpp_tlayers_fwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t la
 /* layers layer_hi-1 ... layer_lo; side = stream of the weight-gradient GEMMs (NULL: the main stream) */
 int pfpp_tlayers_bwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream, pfpp_stream_t side);
 
+/* ---- a15: the two output heads as one launch each way -------------------------------------------------------
+ * DenoiserTransformer._out (denoiser_transformer.py:138-147) after the mean over the L latent points: pooled [R, C] ->
+ * mlp_out_trans / mlp_out_rot (Linear(C,C) - SiLU - Linear(C,C/2) - SiLU - Linear(C/2, 3 | 4), :58-61) -> out[row, 0:3] |
+ * out[row, 3:7], row = slot ? slot[r] : r (the scatter back to the padded fragment slots).  a0 / v0 [2, R, C] and a1 / v1
+ * [2, R, C/2] (pre-activations and SiLU values of both heads, trans first) are saved for the backward when given (all or none).
+ * Weights: split-f16 planes of scale * W (row-major [out, in]) for the two wide layers, fp32 for the last.  C = 512.
+ * pfpp_heads_bwd: from dout [R, 7] (unscaled) it writes da0 [2, R, C], da1 [2, R, C/2] (the dY operands of the four wide
+ * weight-gradient GEMMs, which stay with pfpp_gemm_grad_group), accumulates dW4 / db4 / db2 / db0 of both heads with atomics,
+ * writes each head's share of d pooled to dp [2, R, C] and, when dx is given, dx [(r, l), :] = (dp[0] + dp[1])[r, :] / L
+ * (the backward of the mean pool, :139-142).  grad_scale: power of two lifting the gradient planes into the fp16 range.   */
+typedef struct pfpp_head_params {
+  pfpp_planes w0, w2;                         /* [C, C], [C/2, C] */
+  const float *w4, *b0, *b2, *b4;             /* [3 | 4, C/2], [C], [C/2], [3 | 4] */
+} pfpp_head_params;
+typedef struct pfpp_head_grads { float *w4, *b4, *b2, *b0; } pfpp_head_grads;
+int pfpp_heads_fwd(const float* pooled, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
+                   float* a0, float* v0, float* a1, float* v1, float* out, const int32_t* slot, int64_t ldo,
+                   pfpp_stream_t stream);
+int pfpp_heads_bwd(const float* dout, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
+                   const float* a0, const float* v0, const float* a1, const float* v1, float* da0, float* da1, float* dp,
+                   const pfpp_head_grads* g_trans, const pfpp_head_grads* g_rot, float grad_scale, float* dx, int64_t L,
+                   pfpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,18 @@ class GemmPlanesArgs(C.Structure):
 _pl = C.POINTER(PlanesC)
 
 
+class HeadParams(C.Structure):
+    """mirror of struct pfpp_head_params (include/pfpp.h)"""
+
+    _fields_ = [("w0", PlanesC), ("w2", PlanesC), ("w4", _p), ("b0", _p), ("b2", _p), ("b4", _p)]
+
+
+class HeadGrads(C.Structure):
+    """mirror of struct pfpp_head_grads (include/pfpp.h)"""
+
+    _fields_ = [("w4", _p), ("b4", _p), ("b2", _p), ("b0", _p)]
+
+
 class TlayerParams(C.Structure):
     """mirror of struct pfpp_tlayer_params (include/pfpp.h)"""
 
@@ -155,6 +167,9 @@ class TlayersArgs(C.Structure):
 
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
+    "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "pfpp_heads_bwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
+                       C.POINTER(HeadGrads), C.POINTER(HeadGrads), _f32, _p, _i64, _p],
     "pfpp_tlayers_fwd": [C.POINTER(TlayersArgs), _i32, _i32, _p],
     "pfpp_tlayers_bwd": [C.POINTER(TlayersArgs), _i32, _i32, _p, _p],
     "pfpp_set_attention_mode": [C.c_int],

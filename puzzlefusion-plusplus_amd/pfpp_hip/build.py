@@ -31,6 +31,7 @@ SOURCES = {
     "sa_train.hip": ["-munsafe-fp-atomics"],
     "tblock_small.hip": [],
     "tlayer.hip": [],
+    "heads.hip": ["-munsafe-fp-atomics"],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],

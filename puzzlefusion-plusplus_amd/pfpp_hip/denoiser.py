@@ -56,6 +56,23 @@ def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, tor
     return pk
 
 
+def _fused_heads(pk, pooled, out, slot32=None) -> bool:
+    """pool -> both output heads in one launch (csrc/heads.hip); False when the mode / shape is not the fused kernel's (exact-fp32
+    mode, PFPP_HEADS_FUSED=0, width != 512): the caller then runs the layer-wise GEMMs"""
+    import os
+
+    from . import train_ops as T
+
+    if ops.GEMM_MODE != "f16x3" or os.environ.get("PFPP_HEADS_FUSED", "1") != "1" or pooled.shape[1] != 512:
+        return False
+    hp = pk.get("_heads")
+    if hp is None:
+        hp = pk["_heads"] = tuple(T.head_params(pk[f"{n}.0.w"], pk[f"{n}.2.w"], pk[f"{n}.4.w"].f32, pk[f"{n}.0.b"], pk[f"{n}.2.b"],
+                                                pk[f"{n}.4.b"]) for n in ("mlp_out_trans", "mlp_out_rot"))
+    T.heads_fwd(pooled, hp[0], hp[1], out, slot=slot32)
+    return True
+
+
 def dense_attention(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, key_valid_u8: torch.Tensor,
                     scale: float, out: Optional[torch.Tensor] = None, seq=None) -> torch.Tensor:
     """softmax(Q K^T * scale + key mask) V per (sequence, head) from a packed [rows, 3*H*dh] projection —
@@ -232,6 +249,8 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
         ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=inner, lda=inner, out=h, ldc=C,
                  bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
     pooled = ops.mean_pool(h, Fv, L)
+    if _fused_heads(pk, pooled, out, lay.slot32):
+        return out.view(B, P, 7)
     out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
     for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
         v = ops.linear(pooled, pk[f"{name}.0.w"], pk[f"{name}.0.b"], act="silu")
@@ -294,6 +313,8 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
             capture[f"layer{i}"] = h.clone()
     pooled = ops.mean_pool(h, n, L)
     out = torch.empty((n, 7), dtype=torch.float32, device=h.device)
+    if _fused_heads(pk, pooled, out):
+        return out.view(B, P, 7)
     for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
         v = ops.linear(pooled, pk[f"{name}.0.w"], pk[f"{name}.0.b"], act="silu")
         v = ops.linear(v, pk[f"{name}.2.w"], pk[f"{name}.2.b"], act="silu")

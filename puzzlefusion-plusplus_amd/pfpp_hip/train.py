@@ -307,6 +307,10 @@ class DenoiserTrainEngine:
         # the six blocks' ~240 launches per iteration enqueued from C (csrc/tlayer.hip: pfpp_tlayers_fwd / _bwd) instead of one ctypes
         # call each; same launches, same arguments (PFPP_TRAIN_CSEQ=0: the Python sequence below, the cross-check of the tests)
         self._cseq = os.environ.get("PFPP_TRAIN_CSEQ", "1") == "1"
+        # pool -> both output heads as one launch, their backward as one launch + one grouped weight-gradient launch (csrc/heads.hip);
+        # 0 = the layer-wise GEMMs / activations (the cross-check of the tests)
+        self._heads_fused = os.environ.get("PFPP_HEADS_FUSED", "1") == "1" and ops.GEMM_MODE == "f16x3"
+        self._heads_static = None
         self._cseq_static = None
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
@@ -374,6 +378,11 @@ class DenoiserTrainEngine:
         s["dx_pool"] = None if self._planes else self._zeroed_dx_pool(M, C, w)
         pooled = ops.mean_pool(h, Fv, L)
         s["pooled"] = pooled
+        out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
+        if self._heads_fused and C == 512:
+            trans, rot, _, _ = self._head_structs(w, ops_["g"])
+            s["heads_saved"] = T.heads_fwd(pooled, trans, rot, out, slot=lay.slot32, save=True)
+            return out.view(B, P, 7), ctx
         out_c = torch.empty((Fv, 7), dtype=torch.float32, device=dev)
         heads = {}
         for name, c0, width in (("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4)):
@@ -385,7 +394,6 @@ class DenoiserTrainEngine:
                      bias=w[f"{name}.4.b"], c_off=c0)
             heads[name] = (a0, v0, a1, v1)
         s["heads"] = heads
-        out = torch.zeros((n_slots, 7), dtype=torch.float32, device=dev)
         ops.scatter_rows(out_c, slot.to(torch.int32).contiguous(), n_slots, out=out)
         return out.view(B, P, 7), ctx
 
@@ -704,7 +712,7 @@ class DenoiserTrainEngine:
 
         # every small zero-initialised buffer of the backward out of ONE zeroed arena (one fill launch instead of eight)
         ld_sf, ld_pf = s["sf"].shape[1], s["pf"].shape[1]
-        h1 = s["heads"]["mlp_out_trans"][3].shape[1]
+        h1 = C // 2                                     # hidden width of the heads' second linear
         sizes = [Fv * C, Fv * 4, Fv * 4, 4 * h1, 4 * h1, s["mods"].numel(), C * ld_sf, C * ld_pf]
         offs = [0]
         for n_ in sizes:
@@ -714,25 +722,10 @@ class DenoiserTrainEngine:
         dpads, dw4s = [carve(1, Fv, 4), carve(2, Fv, 4)], [carve(3, 4, h1), carve(4, 4, h1)]
 
         # ---- output heads (denoiser_transformer.py:138-147)
-        dpooled = carve(0, Fv, C)
-        for hi_, (name, c0, width) in enumerate((("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4))):
-            a0, v0, a1, v1 = s["heads"][name]
-            dpad = dpads[hi_]
-            dpad[:, :width] = dout_c[:, c0:c0 + width]
-            T.colsum(dout_c, g[f"{name}.4.b"], rows=Fv, cols=width, ld=7, x_off=c0)
-            dw4 = dw4s[hi_]
-            T.grad_weight(dpad, v1, dw4, g_scale=G)
-            g[f"{name}.4.w"].add_(dw4[:width])
-            dv1 = T.gemm_grad(dpad, w[f"{name}.4.w"].f32, torch.empty_like(v1), M=Fv, N=v1.shape[1], K=width, lda=4,
-                              ldw=v1.shape[1], ldc=v1.shape[1], w_kmajor=True, a_scale=G)
-            da1 = T.act_bwd(a1, dv1, "silu")
-            self._linear_bwd(da1, v0, w[f"{name}.2.w"], g[f"{name}.2.w"], g[f"{name}.2.b"])
-            dv0 = T.grad_input(da1, w[f"{name}.2.w"].f32, g_scale=G)
-            da0 = T.act_bwd(a0, dv0, "silu")
-            self._linear_bwd(da0, s["pooled"], w[f"{name}.0.w"], g[f"{name}.0.w"], g[f"{name}.0.b"])
-            T.gemm_grad(da0, w[f"{name}.0.w"].f32, dpooled, M=Fv, N=C, K=da0.shape[1], lda=da0.shape[1], ldw=C, ldc=C,
-                        w_kmajor=True, accumulate=True, split_k=1, a_scale=G)
-        dh_ = T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
+        if "heads_saved" in s:
+            dh_ = self._heads_backward_fused(s, w, g, dout_c, G, Fv, L)
+        else:
+            dh_ = self._heads_backward_layerwise(s, w, g, dout_c, G, Fv, L, C, carve, dpads, dw4s)
 
         dmods = carve(5, *s["mods"].shape)
         # multi-rank: the two AdaLN linears of a block get their gradients as soon as the block's backward is through and travel with
@@ -775,6 +768,56 @@ class DenoiserTrainEngine:
         else:
             T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
         self._all_done()
+
+    def _head_structs(self, w, g):
+        """(trans, rot, g_trans, g_rot) ctypes structs over the flat buffers (built once: the buffers never move)"""
+        if self._heads_static is None:
+            from ._lib import HeadGrads
+
+            hp, hg = [], []
+            for n in ("mlp_out_trans", "mlp_out_rot"):
+                hp.append(T.head_params(w[f"{n}.0.w"], w[f"{n}.2.w"], w[f"{n}.4.w"].f32, w[f"{n}.0.b"], w[f"{n}.2.b"], w[f"{n}.4.b"]))
+                hg.append(HeadGrads(g[f"{n}.4.w"].data_ptr(), g[f"{n}.4.b"].data_ptr(), g[f"{n}.2.b"].data_ptr(), g[f"{n}.0.b"].data_ptr()))
+            self._heads_static = (hp[0], hp[1], hg[0], hg[1])
+        return self._heads_static
+
+    def _heads_backward_fused(self, s, w, g, dout_c, G, Fv, L):
+        """one launch for the chain (dW4 / every bias gradient / da1 / da0 / d pooled of both heads, + the mean-pool backward), one
+        grouped launch for the four wide weight gradients (off the critical chain: on the weight-gradient stream) -> d/dh [M, C]"""
+        trans, rot, g_trans, g_rot = self._head_structs(w, g)
+        a0, v0, a1, v1 = s["heads_saved"]
+        da0, da1, dh_ = T.heads_bwd(dout_c, trans, rot, s["heads_saved"], g_trans, g_rot, G, L)
+        pooled = s["pooled"]
+        problems = [(da1[0], v0[0], g["mlp_out_trans.2.w"]), (da1[1], v0[1], g["mlp_out_rot.2.w"]),
+                    (da0[0], pooled, g["mlp_out_trans.0.w"]), (da0[1], pooled, g["mlp_out_rot.0.w"])]
+        if self._side is None:
+            T.grad_weight_group(problems, g_scale=G)
+        else:
+            self._run_on(self._side, lambda: T.grad_weight_group(problems, g_scale=G))
+            for t_ in (da0, da1, v0, pooled):
+                t_.record_stream(self._side)
+        return dh_
+
+    def _heads_backward_layerwise(self, s, w, g, dout_c, G, Fv, L, C, carve, dpads, dw4s):
+        dpooled = carve(0, Fv, C)
+        for hi_, (name, c0, width) in enumerate((("mlp_out_trans", 0, 3), ("mlp_out_rot", 3, 4))):
+            a0, v0, a1, v1 = s["heads"][name]
+            dpad = dpads[hi_]
+            dpad[:, :width] = dout_c[:, c0:c0 + width]
+            T.colsum(dout_c, g[f"{name}.4.b"], rows=Fv, cols=width, ld=7, x_off=c0)
+            dw4 = dw4s[hi_]
+            T.grad_weight(dpad, v1, dw4, g_scale=G)
+            g[f"{name}.4.w"].add_(dw4[:width])
+            dv1 = T.gemm_grad(dpad, w[f"{name}.4.w"].f32, torch.empty_like(v1), M=Fv, N=v1.shape[1], K=width, lda=4,
+                              ldw=v1.shape[1], ldc=v1.shape[1], w_kmajor=True, a_scale=G)
+            da1 = T.act_bwd(a1, dv1, "silu")
+            self._linear_bwd(da1, v0, w[f"{name}.2.w"], g[f"{name}.2.w"], g[f"{name}.2.b"])
+            dv0 = T.grad_input(da1, w[f"{name}.2.w"].f32, g_scale=G)
+            da0 = T.act_bwd(a0, dv0, "silu")
+            self._linear_bwd(da0, s["pooled"], w[f"{name}.0.w"], g[f"{name}.0.w"], g[f"{name}.0.b"])
+            T.gemm_grad(da0, w[f"{name}.0.w"].f32, dpooled, M=Fv, N=C, K=da0.shape[1], lda=da0.shape[1], ldw=C, ldc=C,
+                        w_kmajor=True, accumulate=True, split_k=1, a_scale=G)
+        return T.mean_pool_bwd(dpooled, L)                                                 # running d/dh [M, C]
 
     def _backward_layers(self, s, w, g, dh_, dmods):
         """transformer blocks, register-staged backward GEMMs (csrc/gemm_grad.hip) -> d/d(tokens)"""

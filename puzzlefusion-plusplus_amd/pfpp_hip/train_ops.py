@@ -572,3 +572,49 @@ def attn_blockdiag_bwd_planes(qkv, dout, n_frag: int, L: int, H: int, dh: int, s
     check(_lib.load().pfpp_attn_blockdiag_bwd_p(_ptr(qkv), _ptr(dout), None, n_frag, L, H, dh, scale, _pl(dq), _stream()),
           "pfpp_attn_blockdiag_bwd_p")
     return dq
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the two output heads as one launch each way (csrc/heads.hip; denoiser_transformer.py:138-147)
+# ------------------------------------------------------------------------------------------------------------------
+def head_params(w0, w2, w4: torch.Tensor, b0: torch.Tensor, b2: torch.Tensor, b4: torch.Tensor):
+    """pfpp_head_params of one head: w0 / w2 = packing.PW (planes of scale * W), the last layer and the biases in fp32"""
+    from ._lib import HeadParams, PlanesC
+
+    for t_, nm in ((w4, "w4"), (b0, "b0"), (b2, "b2"), (b4, "b4")):
+        _chk(t_, _f32, nm)
+    return HeadParams(PlanesC(w0.hi.data_ptr(), w0.lo.data_ptr(), w0.scale), PlanesC(w2.hi.data_ptr(), w2.lo.data_ptr(), w2.scale),
+                      w4.data_ptr(), b0.data_ptr(), b2.data_ptr(), b4.data_ptr())
+
+
+def heads_fwd(pooled: torch.Tensor, trans, rot, out: torch.Tensor, slot: Optional[torch.Tensor] = None, save: bool = False):
+    """out[slot[r] or r, 0:3 | 3:7] = mlp_out_trans(pooled[r]) | mlp_out_rot(pooled[r]); trans / rot = head_params(...).
+    save: also returns (a0, v0 [2, R, C], a1, v1 [2, R, C/2]) for heads_bwd"""
+    _chk(pooled, _f32, "pooled"); _chk(out, _f32, "out")
+    R, Cc = pooled.shape
+    saved = (None, None, None, None)
+    if save:
+        saved = tuple(torch.empty((2, R, n), dtype=_f32, device=pooled.device) for n in (Cc, Cc, Cc // 2, Cc // 2))
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+    check(_lib.load().pfpp_heads_fwd(_ptr(pooled), C.byref(trans), C.byref(rot), R, Cc, *(_ptr(t_) for t_ in saved), _ptr(out),
+                                     _ptr(slot), out.shape[-1], _stream()), "pfpp_heads_fwd")
+    return saved if save else None
+
+
+def heads_bwd(dout: torch.Tensor, trans, rot, saved, g_trans, g_rot, g_scale: float, L: int, want_dx: bool = True):
+    """backward of heads_fwd from dout [R, 7]: -> (da0 [2, R, C], da1 [2, R, C/2], dx [R * L, C] or None); dW4 / db4 / db2 / db0 of
+    both heads are accumulated into g_trans / g_rot (HeadGrads), the four wide weight gradients are the caller's (da0, da1 are
+    their dY operands)"""
+    _chk(dout, _f32, "dout")
+    a0, v0, a1, v1 = saved
+    _, R, Cc = a0.shape
+    dev = dout.device
+    da0 = torch.empty((2, R, Cc), dtype=_f32, device=dev)
+    da1 = torch.empty((2, R, Cc // 2), dtype=_f32, device=dev)
+    dp = torch.empty((2, R, Cc), dtype=_f32, device=dev)
+    dx = torch.empty((R * L, Cc), dtype=_f32, device=dev) if want_dx else None
+    check(_lib.load().pfpp_heads_bwd(_ptr(dout), C.byref(trans), C.byref(rot), R, Cc, _ptr(a0), _ptr(v0), _ptr(a1), _ptr(v1), _ptr(da0),
+                                     _ptr(da1), _ptr(dp), C.byref(g_trans), C.byref(g_rot), g_scale, _ptr(dx), L, _stream()),
+          "pfpp_heads_bwd")
+    return da0, da1, (dx if want_dx else dp)

@@ -641,3 +641,68 @@ def test_every_plane_producer_writes_hi_plus_lo_equal_to_its_fp32_value(dev):
     for step in (1, 2, 3):
         T.adamw(p, gr, m_, v_, lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=step, hi=hi, lo=lo)
         _assert_planes_carry(p, hi, lo, 1.0, "adamw planes")
+
+
+@pytest.mark.parametrize("R", [154, 33, 640])
+def test_fused_output_heads_forward_and_backward_vs_float64(dev, R):
+    """csrc/heads.hip (pool -> both 3-layer heads as one kernel): mlp_out_trans / mlp_out_rot of
+    DenoiserTransformer._out (denoiser_transformer.py:138-147, :58-61) and their autograd, against float64 torch on the same
+    weights — prediction rows scattered to their slots, saved activations, the chain's gradients (da0, da1, d pooled broadcast
+    over the L latent points), the last layer's weight gradient and all three bias gradients of both heads."""
+    from pfpp_hip import train_ops as T
+    from pfpp_hip._lib import HeadGrads
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(R)
+    C, C2, L, G = 512, 256, 25, 4096.0
+    pooled = torch.randn(R, C, generator=g)
+    heads, structs, grads, gstructs = [], [], [], []
+    for n_out in (3, 4):
+        W0 = torch.randn(C, C, generator=g) / math.sqrt(C)
+        W2 = torch.randn(C2, C, generator=g) / math.sqrt(C)
+        W4 = torch.randn(n_out, C2, generator=g) / math.sqrt(C2)
+        b0, b2, b4 = (torch.randn(n, generator=g) * 0.1 for n in (C, C2, n_out))
+        heads.append((W0, b0, W2, b2, W4, b4))
+        dev_t = [t.to(dev).contiguous() for t in (W0, W2, W4, b0, b2, b4)]
+        pw0, pw2 = PW(dev_t[0]), PW(dev_t[1])
+        structs.append((T.head_params(pw0, pw2, *dev_t[2:]), pw0, pw2, dev_t))
+        gb = [torch.zeros(n_out, C2, device=dev), torch.zeros(n_out, device=dev), torch.zeros(C2, device=dev), torch.zeros(C, device=dev)]
+        grads.append(gb)
+        gstructs.append(HeadGrads(*(t.data_ptr() for t in gb)))
+    perm = torch.randperm(R + 7, generator=g)[:R].to(torch.int32)
+    out = torch.zeros(R + 7, 7, device=dev)
+    saved = T.heads_fwd(pooled.to(dev), structs[0][0], structs[1][0], out, slot=perm.to(dev), save=True)
+    # float64 reference with autograd (weights as the planes carry them: hi + lo of scale * W)
+    x = pooled.double().requires_grad_(True)
+    ref_out, inter, leaves = [], [], []
+    for (W0, b0, W2, b2, W4, b4), (_, pw0, pw2, _) in zip(heads, structs):
+        W0e = ((pw0.hi.double() + pw0.lo.double()) / pw0.scale).cpu()
+        W2e = ((pw2.hi.double() + pw2.lo.double()) / pw2.scale).cpu()
+        W4d, b0d, b2d, b4d = (t.double().requires_grad_(True) for t in (W4, b0, b2, b4))
+        a0 = x @ W0e.t() + b0d
+        a0.retain_grad()
+        v0 = torch.nn.functional.silu(a0)
+        a1 = v0 @ W2e.t() + b2d
+        a1.retain_grad()
+        v1 = torch.nn.functional.silu(a1)
+        ref_out.append(v1 @ W4d.t() + b4d)
+        inter.append((a0, v0, a1, v1))
+        leaves.append((W4d, b4d, b2d, b0d))
+    want = torch.cat(ref_out, 1)
+    got = out.cpu()[perm.long()]
+    assert rel_err(got, want.detach()) < 2e-6
+    untouched = torch.ones(R + 7, dtype=torch.bool)
+    untouched[perm.long()] = False
+    assert float(out.cpu()[untouched].abs().max()) == 0.0
+    for k in range(4):
+        for hd in range(2):
+            assert rel_err(saved[k][hd], inter[hd][k].detach()) < 2e-6, (k, hd)
+    dout = torch.randn(R, 7, generator=g) * 1e-3
+    want.backward(dout.double())
+    da0, da1, dx = T.heads_bwd(dout.to(dev), structs[0][0], structs[1][0], saved, gstructs[0], gstructs[1], G, L)
+    for hd in range(2):
+        assert rel_err(da0[hd], inter[hd][0].grad) < 4e-6 and rel_err(da1[hd], inter[hd][2].grad) < 4e-6, hd
+        for got_g, leaf in zip(grads[hd], leaves[hd]):
+            assert rel_err(got_g, leaf.grad) < 4e-6, hd
+    want_dx = (x.grad / L).repeat_interleave(L, dim=0)
+    assert dx.shape == (R * L, C) and rel_err(dx, want_dx) < 4e-6
