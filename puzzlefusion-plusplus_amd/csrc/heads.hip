@@ -235,7 +235,13 @@ __device__ __forceinline__ void contract_kmajor(const _Float16* sh, const _Float
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) t[j][pl][tt] = lds_rd_tr(rd + pl * 2048 + tt * 4 * 128 + j * 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the wait names every destination register: that is what orders the uses below behind it (the compiler believes an asm's
+    // outputs are ready when the statement ends, and would otherwise assemble the fragments from registers still in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0][0][0]), "+v"(t[0][0][1]), "+v"(t[0][1][0]), "+v"(t[0][1][1]), "+v"(t[1][0][0]), "+v"(t[1][0][1]),
+                   "+v"(t[1][1][0]), "+v"(t[1][1][1])
+                 :
+                 : "memory");
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       half8 b_h, b_l;
