@@ -377,36 +377,6 @@ typedef struct pfpp_sa_train_args {
 } pfpp_sa_train_args;
 int pfpp_sa_train_stage(const pfpp_sa_train_args* args, pfpp_stream_t stream);
 
-/* ---- a11-a14 for ONE puzzle in flight: the transformer blocks as one persistent kernel --------------------------------
- * The layer loop of DenoiserTransformer.forward (denoiser_transformer.py:173-185; EncoderLayer, attention.py:77-140: AdaLN ->
- * per-fragment self-attention -> +res -> AdaLN -> key-masked global attention -> +res -> LayerNorm -> GEGLU feed-forward ->
- * +res) over the VALID fragments' tokens, M = Fv * L <= 512 (auto_aggl.py:136-151 runs the sampler on one puzzle at a time).
- * One cooperative launch of `workgroups` persistent workgroups (a multiple of 16, <= the CU count); the 8 phases of a layer
- * are separated by a software grid barrier.  h [M, C] is updated in place; qkv [M, 3C], att [M, C], u [M, inner] are
- * workspaces.  mods [2 * n_layers, B, 2C] = the AdaLN (scale | shift) rows (MyAdaLayerNorm, attention.py:21-25), frag_b [Fv] the
- * puzzle of every fragment, (seq_off, seq_len) [B] the token range of every puzzle.  barrier: pfpp_tblock_small_barrier_words()
- * zero-initialised 32-bit words that only this kernel touches; barrier_generation = the number of barriers all earlier launches
- * on this buffer executed (pfpp_tblock_small_barriers(n_layers) per launch).  Launches sharing a barrier buffer must not overlap.
- * Weights: split-f16 planes [N, K] of scale_* x the matrices in pfpp_gemm's layouts (q|k|v concatenated, GEGLU rows interleaved
- * 32 value / 32 gate).  C == 512, H == 8, inner == 2048.  Same arithmetic as the layer-wise kernels (split-f16 contraction). */
-typedef struct pfpp_tblock_layer {
-  const void *wqkv1_hi, *wqkv1_lo, *wo1_hi, *wo1_lo, *wqkv2_hi, *wqkv2_lo, *wo2_hi, *wo2_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
-  const float *bo1, *bo2, *norm3_gamma, *norm3_beta, *b1, *b2;
-  float scale_qkv1, scale_o1, scale_qkv2, scale_o2, scale_w1, scale_w2;
-} pfpp_tblock_layer;
-typedef struct pfpp_tblock_args {
-  float* h; float* qkv; float* att; float* u;
-  const float* mods;
-  const int32_t* frag_b; const int32_t* seq_off; const int32_t* seq_len;
-  void* barrier;
-  int64_t barrier_generation;
-  int64_t M, B, Fv, L, C, H, inner, n_layers, workgroups;
-  float att_scale, eps;
-  pfpp_tblock_layer layer[8];
-} pfpp_tblock_args;
-int pfpp_tblock_small(const pfpp_tblock_args* args, pfpp_stream_t stream);
-int64_t pfpp_tblock_small_barrier_words(void);
-int64_t pfpp_tblock_small_barriers(int64_t n_layers);
 
 /* ---- a7/a8: vector quantisation + scatter ----------------------------------
  * VectorQuantizer.forward, vqvae/model/modules/quantizer.py:26-71 as used by

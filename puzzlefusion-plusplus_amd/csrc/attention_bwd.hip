@@ -466,7 +466,7 @@ __device__ __forceinline__ void ab_store4(const float4 v, float sc, int r, int c
   }
 }
 
-// LDS of the two passes, carved from one buffer so that both can live in one launch (attn_dense_bwd_f16_kernel)
+// LDS of the two passes, carved from one buffer each
 typedef _Float16 AbRowTile[KT * AB_LDR];       // [row][dim] planes of a 32-row tile
 typedef _Float16 AbTrTile[64 * AB_LDT];        // [dim][row] planes
 constexpr int AB_DQ_SMEM = 8 * (int)sizeof(AbRowTile) + 4 * (int)sizeof(AbTrTile);
@@ -793,19 +793,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
   __shared__ __align__(16) char smem[AB_DKV_SMEM];
   ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
-}
-
-// Both passes in ONE launch (D comes from attn_dense_bwd_d_kernel): workgroups [0, nblk) of a (sequence, head) take the key
-// blocks (dK, dV — the longer pass, dispatched first), [nblk, 2 nblk) the query blocks (dQ).  The two passes are independent
-// and each is as long as the longest sequence's tile walk: back to back they cost the sum, together the maximum.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_dense_bwd_f16_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
-    const float* __restrict__ lse, const float* __restrict__ dvec, float* __restrict__ dqkv,
-    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
-  __shared__ __align__(16) char smem[AB_DKV_SMEM > AB_DQ_SMEM ? AB_DKV_SMEM : AB_DQ_SMEM];
-  const int nblk = gridDim.x >> 1;
-  if ((int)blockIdx.x < nblk) ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
-  else ab_dq_f16_body(smem, blockIdx.x - nblk, qkv, out, dout, lse, nullptr, dqkv, seq_off, seq_len, H, scale, po);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1347,17 +1334,8 @@ extern "C" int pfpp_attn_dense_bwd_p(const float* qkv, const float* out, const f
   // split-f16 passes for the unmasked (ragged) launches, like pfpp_attn_dense (PFPP_ATTN_F16X3: 0 never, 1 unmasked, 2 -)
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
   if (dh == 64 && f16_mode >= 1 && key_valid == nullptr) {
-    // opt-in: measured slower (training iteration 8.43 -> 8.50 ms) — the longest sequence's workgroups of the two passes
-    // then share SIMDs and each walks its tiles more slowly than alone
-    static const bool merged = getenv("PFPP_ATTN_BWD_MERGED") && atoi(getenv("PFPP_ATTN_BWD_MERGED")) == 1;
-    if (merged) {
-      const int Hi = (int)H;
-      hipLaunchKernelGGL(attn_dense_bwd_d_kernel<64>, grid, dim3(256), 0, st, out, dout, dvec, seq_off, seq_len, Hi);
-      const dim3 grid2(2 * grid.x, grid.y, grid.z);
-      hipLaunchKernelGGL(attn_dense_bwd_f16_kernel, grid2, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
-                         Hi, scale, po);
-      return pfpp::check_launch(__func__);
-    }
+    // (both passes in one launch was built and measured twice — rounds 2 and 3: no gain, the longest sequence's workgroups of the two
+    // passes then share SIMDs and each walks its tiles more slowly than alone — and removed in round 4)
     hipLaunchKernelGGL(attn_dense_bwd_dq_f16_kernel, grid, dim3(256), 0, st, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len,
                        (int)H, scale, po);
     hipLaunchKernelGGL(attn_dense_bwd_dkv_f16_kernel, grid, dim3(256), 0, st, qkv, dout, lse, dvec, dqkv, seq_off, seq_len,

@@ -809,344 +809,6 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
 }
 
 
-// =====================================================================================================================
-// K-tile of 64 for row-major operands (round 3, opt-in: see launch_variant for the measurement).  The L2 -> LDS delivery of global_load_lds is bound by the number of cache
-// lines requested, not by the bytes (tools/lab/dma_rows_probe.hip: L2-resident panels arrive at 66 GB/s per workgroup in 64-byte
-// runs and at 126-133 GB/s in 128-byte runs; the K-tile-of-32 kernel above makes every DMA instruction touch 16 rows x half a
-// line).  Here a stage holds 64 contraction values per row: a DMA instruction covers 8 rows x one full 128-byte line, and the
-// delivery-bound main loops of the token-sized GEMMs (3,850 rows: 0.44 us per 32-deep K-tile) need half the requests.
-//   A: row-major planes.  W: row-major planes (y = x.W^T) or k-major planes (dX = dY.W, the weight as stored; its rows are
-//   BN * 2 >= 128 bytes already).  One raw barrier per 64-deep tile, NS stages, counted vmcnt; fragment reads through inline
-//   asm, double-buffered per 16-deep step with counted lgkmcnt.  Same products in the same order as pl_body / gemm_f16x3_kernel
-//   (lo.hi, hi.lo, hi.hi per 16-deep step): bit-identical to them without a K split.
-template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG = 1>
-struct Cfg64 {
-  static constexpr int NW = WM * WN * KG;                 // KG wave groups share every output tile and split the 16-deep steps of a K-tile
-  static constexpr int NTHR = 64 * NW;
-  static constexpr int BM = 32 * MT * WM;
-  static constexpr int BN = 32 * NT * WN;
-  static constexpr int PLANE_A = BM * 128;                // BM rows of 64 halfs
-  static constexpr int PLANE_W = BN * 128;                // BN rows of 64 halfs, or 64 contraction rows of BN halfs
-  static constexpr int STAGE = 2 * (PLANE_A + PLANE_W);
-  static constexpr int NP = STAGE / 1024;
-  static constexpr int NPW = NP / NW;
-  static constexpr size_t SMEM = (size_t)NS * STAGE;
-  static_assert(NP % NW == 0, "pieces must divide over the waves");
-  static_assert(MT == 2 && (NT == 1 || NT == 2), "wave tile: 64 rows x 32 or 64 columns");
-  static_assert(NS == 2 || NS == 3, "two or three stages");
-  static_assert(KG == 1 || KG == 2, "one or two wave groups along K");
-};
-
-template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG>
-__device__ __forceinline__ void pl64_body(const GemmP& p) {
-  using C = Cfg64<MT, NT, WM, WN, NS, WK, KG>;
-  constexpr int BM = C::BM, BN = C::BN, NPW = C::NPW, STAGE = C::STAGE, BK64 = 64;
-  constexpr int CPR_W = BN / 8;                           // 16-byte chunks per contraction row of a k-major W tile
-  extern __shared__ __align__(1024) char pl_smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave / (WM * WN);                        // wave group along K: takes the 16-deep steps kg, kg + KG, ... of every K-tile
-  const int wt = wave - kg * (WM * WN);
-  const int wm = wt / WN, wn = wt % WN;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int wg = remap_tile(blockIdx.x, gridDim.x);
-  const int n_tiles = p.tiles_m * p.tiles_n;
-  const int split = wg / n_tiles;
-  const int tile = wg - split * n_tiles;
-  int tm, tn;
-  tile_coords(p, tile, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk_all = p.K / BK64;
-  const int nk_base = nk_all / p.split_k, nk_rem = nk_all - nk_base * p.split_k;
-  const int kt0 = split * nk_base + min(split, nk_rem);
-  const int nk = nk_base + (split < nk_rem ? 1 : 0);
-  const int z = blockIdx.z;
-  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
-  const int64_t a_offz = z0 * p.sA0 + z1 * p.sA1;
-  const int64_t w_offz = z0 * p.sW0 + z1 * p.sW1;
-  const int64_t c_off = z0 * p.sC0 + z1 * p.sC1;
-  const int64_t v_off = z0 * p.sV0 + z1 * p.sV1;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)pl_smem;
-
-  // ---- DMA sources: piece q = wave + NW * j = LDS bytes [q KiB, (q + 1) KiB) of a stage ------------------------------------
-  // row-major plane: lane i of a piece lands at row i >> 3 of the piece's 8 rows, physical 16-byte chunk i & 7, which holds the
-  //   row's logical chunk (i & 7) ^ (row & 7); the next K-tile is 128 bytes further along the row
-  // k-major W plane: chunk ci = contraction row ci / CPR_W, slot ci % CPR_W (rotated like pl_body's); next K-tile 64 rows down
-  const char* src[NPW];
-  uint32_t dst[NPW];
-  int64_t adv[NPW];
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int q = wave + C::NW * j;
-    const int o = q * 1024;
-    const bool is_a = o < 2 * C::PLANE_A;
-    const int o2 = is_a ? o : o - 2 * C::PLANE_A;
-    const int psz = is_a ? C::PLANE_A : C::PLANE_W;
-    const bool lo = o2 >= psz;
-    const int ci = ((lo ? o2 - psz : o2) >> 4) + lane;
-    const _Float16* base = reinterpret_cast<const _Float16*>(is_a ? (lo ? p.Alo : p.Ahi) : (lo ? p.Wlo : p.Whi));
-    int64_t eoff;
-    if (is_a || !WK) {
-      const int row = ci >> 3;
-      const int chunk = (ci & 7) ^ (row & 7);
-      eoff = (is_a ? a_offz : w_offz) + (int64_t)min((is_a ? m0 : n0) + row, (is_a ? p.M : p.N) - 1) * (is_a ? p.lda : p.ldw) + chunk * 8;
-      adv[j] = 128;
-    } else {
-      const int krow = ci / CPR_W, slot = ci % CPR_W;
-      const int rot = CPR_W >= 16 ? (krow & 3) : ((krow >> 1) & 1);
-      const int nc = (slot - 4 * rot + CPR_W) % CPR_W;
-      eoff = w_offz + (int64_t)krow * p.ldw + min(n0 + 8 * nc, p.N - 8);
-      adv[j] = (int64_t)64 * p.ldw * 2;
-    }
-    src[j] = reinterpret_cast<const char*>(base + eoff) + (int64_t)kt0 * adv[j];
-    dst[j] = lds0 + o;
-  }
-  auto issue = [&](int kt, uint32_t st_off) {
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) glds16(src[j] + (int64_t)kt * adv[j], dst[j] + st_off);
-  };
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  // ---- fragment addresses: row-major: row l31 of a 32-row tile, logical chunk 2 s + lhi of the row's 8 (s = 16-deep step 0..3)
-  const int sw = l31 & 7;
-  uint32_t a_ad[4], w_ad[WK ? NT : 4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) a_ad[s4] = lds0 + (wm * 32 * MT + l31) * 128 + (((2 * s4 + lhi) ^ sw) << 4);
-  if constexpr (WK) {
-    const int q = lane >> 4, j = lane & 15;
-    const int krow = 8 * (q >> 1) + (j >> 2);
-    const int rot = CPR_W >= 16 ? ((j >> 2) & 3) : (((j >> 2) >> 1) & 1);
-#pragma unroll
-    for (int jj = 0; jj < NT; ++jj) {
-      const int nc = 4 * (wn * NT + jj) + 2 * (q & 1) + ((j & 3) >> 1);
-      w_ad[jj] = lds0 + 2 * C::PLANE_A + (uint32_t)((krow * CPR_W + ((nc + 4 * rot) % CPR_W)) * 16 + (j & 1) * 8);
-    }
-  } else {
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) w_ad[s4] = lds0 + 2 * C::PLANE_A + (wn * 32 * NT + l31) * 128 + (((2 * s4 + lhi) ^ sw) << 4);
-  }
-  struct Fr { half8 ah[MT], al[MT], bh[NT], bl[NT]; half4 bh2[WK ? NT : 1][2], bl2[WK ? NT : 1][2]; };
-  Fr fr[2];
-  constexpr int NRD = 2 * MT + (WK ? 4 * NT : 2 * NT);      // LDS read instructions of one 16-deep step
-  auto rd = [&](Fr& f, uint32_t st, auto s_c) {
-    constexpr int s4 = decltype(s_c)::value;
-    static_for<MT>([&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      f.ah[t] = lds_rd<t * 4096>(a_ad[s4] + st);
-      f.al[t] = lds_rd<C::PLANE_A + t * 4096>(a_ad[s4] + st);
-    });
-    static_for<NT>([&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      if constexpr (WK) {
-        f.bh2[t][0] = lds_rd_tr<(16 * s4) * CPR_W * 16>(w_ad[t] + st);
-        f.bh2[t][1] = lds_rd_tr<(16 * s4 + 4) * CPR_W * 16>(w_ad[t] + st);
-        f.bl2[t][0] = lds_rd_tr<C::PLANE_W + (16 * s4) * CPR_W * 16>(w_ad[t] + st);
-        f.bl2[t][1] = lds_rd_tr<C::PLANE_W + (16 * s4 + 4) * CPR_W * 16>(w_ad[t] + st);
-      } else {
-        f.bh[t] = lds_rd<t * 4096>(w_ad[s4] + st);
-        f.bl[t] = lds_rd<C::PLANE_W + t * 4096>(w_ad[s4] + st);
-      }
-    });
-  };
-  auto join = [](const half4 x, const half4 y) { return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7); };
-  // the reads of `f` have landed (N later read instructions may still be in flight); names what the MFMAs consume
-  auto wait_fr = [&](Fr& f, auto n_c) {
-    constexpr int N = decltype(n_c)::value;
-    if constexpr (WK) {
-      if constexpr (NT == 1)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.bh2[0][0]), "+v"(f.bh2[0][1]),
-                     "+v"(f.bl2[0][0]), "+v"(f.bl2[0][1]) : "n"(N));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.bh2[0][0]), "+v"(f.bh2[0][1]),
-                     "+v"(f.bl2[0][0]), "+v"(f.bl2[0][1]), "+v"(f.bh2[NT - 1][0]), "+v"(f.bh2[NT - 1][1]), "+v"(f.bl2[NT - 1][0]),
-                     "+v"(f.bl2[NT - 1][1]) : "n"(N));
-      static_for<NT>([&](auto t_c) {
-        constexpr int t = decltype(t_c)::value;
-        f.bh[t] = join(f.bh2[t][0], f.bh2[t][1]);
-        f.bl[t] = join(f.bl2[t][0], f.bl2[t][1]);
-      });
-    } else {
-      if constexpr (NT == 1)
-        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.bh[0]), "+v"(f.bl[0]) : "n"(N));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f.ah[0]), "+v"(f.ah[1]), "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.bh[0]), "+v"(f.bl[0]),
-                     "+v"(f.bh[NT - 1]), "+v"(f.bl[NT - 1]) : "n"(N));
-    }
-  };
-  auto mma = [&](const Fr& f) {
-    static_for<MT>([&](auto i_c) { static_for<NT>([&](auto j_c) {
-      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-    }); });
-    static_for<MT>([&](auto i_c) { static_for<NT>([&](auto j_c) {
-      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-    }); });
-    static_for<MT>([&](auto i_c) { static_for<NT>([&](auto j_c) {
-      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-    }); });
-  };
-
-  // ---- prologue: NS - 1 tiles in flight; every iteration waits for its tile, passes the barrier (everyone is done with the
-  // previous tile: its stage is free) and refills that stage with tile kt + NS - 1 ----------------------------------------------
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) issue(s, s * STAGE);
-  uint32_t cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tiles issued so far: min(nk, kt + NS - 1); tile kt must have landed, the ones behind it may stay in flight
-    if (NS == 3 && kt + 1 < nk) wait_vmcnt<(NS == 3 ? 1 : 0) * NPW>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NS - 1 < nk) {
-      const uint32_t fill = cur == 0 ? (NS - 1) * STAGE : cur - STAGE;       // the stage of tile kt - 1
-      issue(kt + NS - 1, fill);
-    }
-    if constexpr (KG == 1) {
-      rd(fr[0], cur, std::integral_constant<int, 0>{});
-      static_for<4>([&](auto s_c) {
-        constexpr int s4 = decltype(s_c)::value;
-        if constexpr (s4 < 3) {
-          rd(fr[(s4 + 1) & 1], cur, std::integral_constant<int, s4 + 1>{});
-          wait_fr(fr[s4 & 1], std::integral_constant<int, NRD>{});
-        } else {
-          wait_fr(fr[s4 & 1], std::integral_constant<int, 0>{});
-        }
-        mma(fr[s4 & 1]);
-      });
-    } else {
-      // two wave groups: group 0 takes steps 0 and 2, group 1 steps 1 and 3 — two waves per SIMD, one group's MFMAs run
-      // under the other's fragment reads
-      if (kg == 0) {
-        rd(fr[0], cur, std::integral_constant<int, 0>{});
-        rd(fr[1], cur, std::integral_constant<int, 2>{});
-      } else {
-        rd(fr[0], cur, std::integral_constant<int, 1>{});
-        rd(fr[1], cur, std::integral_constant<int, 3>{});
-      }
-      wait_fr(fr[0], std::integral_constant<int, NRD>{});
-      mma(fr[0]);
-      wait_fr(fr[1], std::integral_constant<int, 0>{});
-      mma(fr[1]);
-    }
-    cur = (cur + STAGE == NS * STAGE) ? 0u : cur + STAGE;
-  }
-
-  if constexpr (KG == 2) {
-    // group 1 hands its accumulators to group 0 through LDS (the DMA ring is dead; the patches of the wide epilogue start at byte 0,
-    // the hand-over area behind them)
-    __builtin_amdgcn_s_barrier();
-    float* xch = reinterpret_cast<float*>(pl_smem + 65536) + (size_t)wt * (MT * NT * 16 * 64);
-    if (kg == 1) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) xch[((i * NT + j) * 16 + e) * 64 + lane] = acc[i][j][e];
-    }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * NT + j) * 16 + e) * 64 + lane];
-  }
-  if (p.split_ws && p.split_k > 1) {
-    GemmP q = p;
-    q.C = p.split_ws + (size_t)split * p.M * p.N;
-    q.ldc = p.N;
-    q.bias = q.scale = q.shift = q.residual = nullptr;
-    q.act = PFPP_ACT_NONE;
-    q.Chi = q.Clo = nullptr;
-    if constexpr (KG == 1) __builtin_amdgcn_s_barrier();
-    epilogue_wide<MT, NT>(q, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, 0, 0, lds0 + wt * (32 * NT * 128));
-    return;
-  }
-  if (p.accum) {
-    const int row_w = m0 + wm * 32 * MT, col_w = n0 + wn * 32 * NT;
-    const float* R = (p.residual && split == 0) ? p.residual + c_off : nullptr;
-    const float* bias = (p.bias && split == 0) ? p.bias + v_off : nullptr;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = col_w + j * 32 + l31;
-      if (col >= p.N) continue;
-      const float b = bias ? bias[col] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = row_w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          if (row < p.M) {
-            float v = acc[i][j][e] * p.alpha + b;
-            if (R) v += R[(int64_t)row * p.ldr + col];
-            unsafeAtomicAdd(p.C + c_off + (int64_t)row * p.ldc + col, v);
-          }
-        }
-    }
-    return;
-  }
-  const bool wide_ok = p.pool == 0 && (p.ldc & 3) == 0 && (p.N & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
-                       (p.act != PFPP_ACT_GEGLU || (p.N & 7) == 0);
-  if (wide_ok) {
-    if constexpr (KG == 1) __builtin_amdgcn_s_barrier();
-    epilogue_wide<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, lane, c_off, v_off, lds0 + wt * (32 * NT * 128));
-  } else {
-    epilogue<MT, NT>(p, acc, m0 + wm * 32 * MT, n0 + wn * 32 * NT, n0, wn, lane, c_off, v_off);
-  }
-}
-
-template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG>
-__global__ __launch_bounds__(64 * WM * WN * KG, 1) void gemm_pl64_kernel(const GemmP p) {
-  pl64_body<MT, NT, WM, WN, NS, WK, KG>(p);
-}
-
-template <int MT, int NT, int WM, int WN, int NS, bool WK, int KG = 1>
-int launch_pl64(const GemmP& p0, int batch, hipStream_t st, int group_m, int splits) {
-  using C = Cfg64<MT, NT, WM, WN, NS, WK, KG>;
-  static bool attr_set = false;
-  auto kern = gemm_pl64_kernel<MT, NT, WM, WN, NS, WK, KG>;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  GemmP p = p0;
-  p.tiles_m = (p.M + C::BM - 1) / C::BM;
-  p.tiles_n = (p.N + C::BN - 1) / C::BN;
-  p.group_m = p.tiles_n > 1 ? group_m : 0;
-  const int nk_all = p.K / 64;
-  p.split_k = splits < 1 ? 1 : (splits > nk_all ? nk_all : splits);
-  const bool slabs = p.split_k > 1 && p.split_ws && batch == 1 && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) &&
-                     (int64_t)p.split_k * p.M * (p.N + 1) * (int64_t)sizeof(float) <= p_ws_bytes;
-  if (!slabs) p.split_ws = nullptr;
-  p.csum = nullptr; p.csum_ws = nullptr;
-  if (p.split_k > 1 && !slabs) {
-    if (p.act != PFPP_ACT_NONE || !p.accum) { p.split_k = 1; }
-  }
-  p.k_chunk = 0;
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.split_k), 1, (unsigned)batch);
-  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl64_kernel<%d, %d, %d, %d, %d, %s, %d>%s", MT, NT, WM, WN, NS, WK ? "true" : "false", KG,
-           slabs ? "+pl_reduce_kernel" : "");
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM, st, p);
-  if (slabs) {
-    const int64_t n4 = (int64_t)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.split_ws, p.C, p.bias, p.residual, p.M,
-                       p.N, p.ldc, p.ldr, p.split_k, p.accum, p.act, nullptr, nullptr);
-  }
-  return pfpp::check_launch("pfpp_gemm");
-}
-
 }  // namespace pl
 
 // variant: 0 = pick by shape, 1 = 256x256 (8 waves of 128x64, 2 stages), 2 = 256x128 (8 waves, 3 stages), 3 = 128x128 (4 waves,
@@ -1171,23 +833,6 @@ static int launch_variant(const GemmP& p, int batch, hipStream_t st, int group_m
         default: return pl::launch_pl<2, 2, 2, 2, 2, AK, WK, 0, false, false, true>(p, batch, st, group_m, splits);
       }
     }
-  }
-  if constexpr (!AK) {
-    // K-tile of 64 (full 128-byte lines per DMA row) for the 128 x 64 and 128 x 128 tiles: row-major A, any W
-    // variants 15 / 16 (or PFPP_PL_BK64=1 for 6 / 3).  Measured (tools/diag/bk64_sweep.py, ab_bk64.sh): bit-identical, the same 0.5 us per
-    // 32 contraction values as the K-tile of 32 — these main loops are bound by LDS traffic + MFMA issue at one wave per SIMD, not
-    // by the delivery the probe isolates — and the 147 KB stage ring costs the co-residency the overlapped iteration lives on
-    // (7.23 -> 7.47 ms): opt-in
-    static const bool bk64 = getenv("PFPP_PL_BK64") && atoi(getenv("PFPP_PL_BK64")) == 1;
-    const bool ok64 = !p.x1 && !p.stats && !p.a_mul && !p.g_idx && p.pool == 0 && !p.Cmin && p.K % 64 == 0 && p.k_valid == p.K && p.K >= 128;
-    if (ok64 && (variant == 15 || (bk64 && variant == 6))) return pl::launch_pl64<2, 1, 2, 2, 3, WK>(p, batch, st, group_m, splits);
-    if (ok64 && (variant == 16 || (bk64 && variant == 3))) return pl::launch_pl64<2, 2, 2, 2, 2, WK>(p, batch, st, group_m, splits);
-    if (ok64 && variant == 17) return pl::launch_pl64<2, 1, 2, 2, 3, WK, 2>(p, batch, st, group_m, splits);      // 128 x 64, 8 waves in two K groups
-    if (ok64 && variant == 18) return pl::launch_pl64<2, 2, 2, 2, 2, WK, 2>(p, batch, st, group_m, splits);      // 128 x 128, 8 waves in two K groups
-    if (variant == 17) variant = 6;
-    if (variant == 18) variant = 3;
-    if (variant == 15) variant = 6;
-    if (variant == 16) variant = 3;
   }
   switch (variant) {
     case 1:

@@ -69,23 +69,6 @@ class SaTrainArgs(C.Structure):
     ]
 
 
-class TblockLayer(C.Structure):
-    """mirror of struct pfpp_tblock_layer (include/pfpp.h)"""
-
-    _fields_ = ([(n, _p) for n in ("wqkv1_hi", "wqkv1_lo", "wo1_hi", "wo1_lo", "wqkv2_hi", "wqkv2_lo", "wo2_hi", "wo2_lo", "w1_hi", "w1_lo",
-                                   "w2_hi", "w2_lo", "bo1", "bo2", "norm3_gamma", "norm3_beta", "b1", "b2")] +
-                [(n, _f32) for n in ("scale_qkv1", "scale_o1", "scale_qkv2", "scale_o2", "scale_w1", "scale_w2")])
-
-
-class TblockArgs(C.Structure):
-    """mirror of struct pfpp_tblock_args (include/pfpp.h)"""
-
-    _fields_ = [("h", _p), ("qkv", _p), ("att", _p), ("u", _p), ("mods", _p), ("frag_b", _p), ("seq_off", _p), ("seq_len", _p),
-                ("barrier", _p), ("barrier_generation", _i64),
-                ("M", _i64), ("B", _i64), ("Fv", _i64), ("L", _i64), ("C", _i64), ("H", _i64), ("inner", _i64), ("n_layers", _i64),
-                ("workgroups", _i64), ("att_scale", _f32), ("eps", _f32), ("layer", TblockLayer * 8)]
-
-
 class PlanesC(C.Structure):
     """mirror of struct pfpp_planes (include/pfpp.h)"""
 
@@ -241,7 +224,6 @@ SIGNATURES = {
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
     "pfpp_adamw_zero": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p],
     "pfpp_sa_train_stage": [C.POINTER(SaTrainArgs), _p],
-    "pfpp_tblock_small": [C.POINTER(TblockArgs), _p],
     "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
@@ -267,8 +249,6 @@ PLAIN = {
     "pfpp_tlayers_bwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),
-    "pfpp_tblock_small_barrier_words": ([], C.c_int64),
-    "pfpp_tblock_small_barriers": ([_i64], C.c_int64),
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}

@@ -29,7 +29,6 @@ SOURCES = {
     "gemm_pl.hip": ["-munsafe-fp-atomics"] + (["-DPFPP_PL_LAB"] if os.environ.get("PFPP_PL_LAB") else []),
     "sa_fused.hip": [],
     "sa_train.hip": ["-munsafe-fp-atomics"],
-    "tblock_small.hip": [],
     "tlayer.hip": [],
     "heads.hip": ["-munsafe-fp-atomics"],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],

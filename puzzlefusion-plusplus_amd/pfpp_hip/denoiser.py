@@ -224,16 +224,11 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     mods = ada_mods(pk, timesteps, n_ada, C)
     att_scale = 1.0 / math.sqrt(dh)
     inner = pk["0.ff.w2"].K
-    small = ops.tblock_small_supported(M, C, num_heads, inner, L, num_layers)
-    if small:
-        # one puzzle in flight (<= 512 tokens): the whole layer loop is one persistent kernel, its 48 phases separated by a grid
-        # barrier instead of 66 kernel boundaries (csrc/tblock_small.hip)
-        ops.tblock_small(pk, h, mods, frag_b, seq_off, seq_len, L=L, num_layers=num_layers, num_heads=num_heads, att_scale=att_scale)
-    elif ops.split_mode():      # GEMM inputs produced by our own kernels travel as pre-split fp16 planes (see ops.split_mode)
+    if ops.split_mode():      # GEMM inputs produced by our own kernels travel as pre-split fp16 planes (see ops.split_mode)
         norm, att, u_buf = (ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, inner, dev))
     else:
         norm, att, u_buf = torch.empty_like(h), torch.empty_like(h), None
-    for i in range(0 if small else num_layers):
+    for i in range(num_layers):
         ops.layernorm_grouped(h, mods[2 * i], frag_b, L, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
         ops.attn_blockdiag(qkv, Fv, L, num_heads, dh, att_scale, out=att)

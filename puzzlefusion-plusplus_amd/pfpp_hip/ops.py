@@ -940,82 +940,6 @@ def edge_histogram(pts: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor, 
     return hist
 
 
-# --------------------------------------------------------------------------- transformer blocks, one puzzle in flight
-# <= 512 tokens: the layer loop as one persistent kernel (csrc/tblock_small.hip).  Correct (tested against the layer-wise kernels), but
-# measured SLOWER than the 66 launches it replaces (800-1140 us against ~650 us for the six blocks at 50-500 tokens): a phase is a chain of
-# memory-side round trips (agent-coherent loads of what another XCD wrote, write-through stores, the barrier: ~10-16 us) where a kernel
-# boundary costs ~10 us — opt-in, kept as the measured answer to "per-block persistent kernels" 
-TBLOCK_SMALL = _os.environ.get("PFPP_TBLOCK_SMALL", "0") == "1"
-_TBLOCK_STATE = {}
-
-
-def tblock_small_supported(M: int, C: int, H: int, inner: int, L: int, n_layers: int) -> bool:
-    return (TBLOCK_SMALL and GEMM_MODE == "f16x3" and not SINGLE_PASS and 1 <= M <= 512 and C == 512 and H == 8 and inner == 2048
-            and 1 <= L <= 32 and 1 <= n_layers <= 8 and not torch.cuda.is_current_stream_capturing())      # cooperative launches do not capture
-
-
-def tblock_small(pk, h: torch.Tensor, mods: torch.Tensor, frag_b: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, *,
-                 L: int, num_layers: int, num_heads: int, att_scale: float, eps: float = 1e-5) -> torch.Tensor:
-    """the transformer blocks of pfpp_hip.denoiser.denoiser_forward_compact as ONE persistent kernel (pfpp_tblock_small,
-    csrc/tblock_small.hip): h [M, C] (token embeddings) is updated in place; mods [2 * layers, B, 2C]; frag_b int32 [Fv];
-    (seq_off, seq_len) int32 [B].  pk = pfpp_hip.denoiser.pack_denoiser's dictionary."""
-    _chk(h, torch.float32, "h"); _chk(mods, torch.float32, "mods")
-    for t, nm in ((frag_b, "frag_b"), (seq_off, "seq_off"), (seq_len, "seq_len")):
-        _chk(t, torch.int32, nm)
-    M, Cc = h.shape
-    Fv, B = frag_b.numel(), seq_off.numel()
-    inner = pk["0.ff.w2"].K
-    if Fv * L != M or mods.shape != (2 * num_layers, B, 2 * Cc) or seq_len.numel() != B:
-        raise ValueError("tblock_small: h [Fv * L, C], mods [2 * layers, B, 2C], seq_off / seq_len [B] expected")
-    dev = h.device
-    lib = _lib.load()
-    key = (dev.index, raw_stream_id(dev.index))
-    st = _TBLOCK_STATE.get(key)
-    if st is None:
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        st = _TBLOCK_STATE[key] = {
-            "bar": torch.zeros((int(lib.pfpp_tblock_small_barrier_words()),), dtype=torch.int32, device=dev), "gen": 0,
-            "wgs": max(16, min(256, n_cu) // 16 * 16),
-            "qkv": torch.empty((512, 3 * Cc), dtype=torch.float32, device=dev), "att": torch.empty((512, Cc), dtype=torch.float32, device=dev),
-            "u": torch.empty((512, inner), dtype=torch.float32, device=dev),
-        }
-        torch.cuda.synchronize(dev)             # the zero fill of the barrier words precedes the first cooperative launch on any stream
-    per = int(lib.pfpp_tblock_small_barriers(num_layers))
-    if st["gen"] + per >= (1 << 27):            # counters advance 16 per barrier: start over long before 32 bits wrap
-        st["bar"].zero_()
-        st["gen"] = 0
-    a = _lib.TblockArgs()
-    a.h, a.qkv, a.att, a.u, a.mods = h.data_ptr(), st["qkv"].data_ptr(), st["att"].data_ptr(), st["u"].data_ptr(), mods.data_ptr()
-    a.frag_b, a.seq_off, a.seq_len = frag_b.data_ptr(), seq_off.data_ptr(), seq_len.data_ptr()
-    a.barrier, a.barrier_generation = st["bar"].data_ptr(), st["gen"]
-    a.M, a.B, a.Fv, a.L, a.C, a.H, a.inner, a.n_layers, a.workgroups = M, B, Fv, L, Cc, num_heads, inner, num_layers, st["wgs"]
-    a.att_scale, a.eps = att_scale, eps
-    cache = pk.get("_tblock_layers")
-    if cache is None:                           # pointers / scales of the packed weights: fixed for the lifetime of the pack
-        cache = []
-        for i in range(num_layers):
-            ly = {}
-            for nm, k_ in (("wqkv1", f"{i}.self_attn.wqkv"), ("wo1", f"{i}.self_attn.wo"), ("wqkv2", f"{i}.global_attn.wqkv"),
-                           ("wo2", f"{i}.global_attn.wo"), ("w1", f"{i}.ff.w1"), ("w2", f"{i}.ff.w2")):
-                w = pk[k_]
-                if w.hi.shape[-1] != w.K or not (w.hi.is_contiguous() and w.lo.is_contiguous()):
-                    raise ValueError("tblock_small: weight planes must be dense [N, K]")
-                ly[nm + "_hi"], ly[nm + "_lo"] = w.hi.data_ptr(), w.lo.data_ptr()
-                ly["scale_" + {"wqkv1": "qkv1", "wo1": "o1", "wqkv2": "qkv2", "wo2": "o2", "w1": "w1", "w2": "w2"}[nm]] = float(w.scale)
-            for nm, k_ in (("bo1", f"{i}.self_attn.bo"), ("bo2", f"{i}.global_attn.bo"), ("norm3_gamma", f"{i}.norm3.g"),
-                           ("norm3_beta", f"{i}.norm3.b"), ("b1", f"{i}.ff.b1"), ("b2", f"{i}.ff.b2")):
-                _chk(pk[k_], torch.float32, k_)
-                ly[nm] = pk[k_].data_ptr()
-            cache.append(ly)
-        pk["_tblock_layers"] = cache
-    for i, ly in enumerate(cache):
-        for k_, v in ly.items():
-            setattr(a.layer[i], k_, v)
-    check(lib.pfpp_tblock_small(C.byref(a), _stream()), "pfpp_tblock_small")
-    st["gen"] += per
-    return h
-
-
 # --------------------------------------------------------------------------- evaluation metrics (8f-3)
 def nn_dist(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """src [B,n,3], dst [B,m,3] -> [B,n] squared distance to the nearest neighbour (chamferdist's KNN-1 term)"""

@@ -1236,12 +1236,12 @@ def test_fp16_mfma_joint_step_configs4_vs_f16x3(dev):
 
 
 @pytest.mark.parametrize("parts", [(1,), (8,), (20,), (3, 7), (2, 2, 5, 1)])
-def test_small_token_transformer_kernel_equals_layerwise(weights_sd, dev, parts):
-    """one puzzle in flight (<= 512 tokens): the six transformer blocks as ONE persistent kernel (csrc/tblock_small.hip: grid
-    barrier between the phases, agent-coherent exchange buffers) against the layer-wise kernels on the same inputs — predicted noise
-    within 1e-5 (same split-f16 contraction, different reduction orders in LayerNorm / softmax); 1, 8 and 20 fragments, several
-    short puzzles in one call (ragged sequences), repeated launches on one barrier buffer."""
-    from pfpp_hip import config, ops, synthetic
+def test_small_puzzle_forward_fused_heads_equal_layerwise(weights_sd, dev, parts, monkeypatch):
+    """one puzzle in flight (1 .. 20 fragments = 25 .. 500 tokens, and several short puzzles in one call): the eval forward with the
+    pool -> both-heads kernel (csrc/heads.hip, one launch for 1 .. 20 rows of a 32-row block) against the layer-wise head GEMMs
+    (PFPP_HEADS_FUSED=0) on the same inputs — predicted noise within 1e-5 (same split-f16 contraction; the last 3- / 4-column layer
+    is fp32 FMAs instead of a split-f16 GEMM), deterministic, padded slots exactly zero."""
+    from pfpp_hip import config
     from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
 
     m = DenoiserTransformer(config.denoiser_config())
@@ -1261,24 +1261,27 @@ def test_small_token_transformer_kernel_equals_layerwise(weights_sd, dev, parts)
     ref[:, 0] = True
     ts = torch.randint(0, 1000, (B,), generator=gen).to(dev)
     valid_d, ref_d = valid.to(dev), ref.to(dev)
-    assert sum(parts) * 25 <= 512
-    prev = ops.TBLOCK_SMALL
-    try:
-        ops.TBLOCK_SMALL = False
-        with torch.no_grad():
-            want = m(x, ts, latent, xyz, valid_d, scale, ref_d)
-        ops.TBLOCK_SMALL = True
-        assert ops.tblock_small_supported(sum(parts) * 25, 512, 8, 2048, 25, 6)
-        with torch.no_grad():
-            got = [m(x, ts, latent, xyz, valid_d, scale, ref_d) for _ in range(3)]
-    finally:
-        ops.TBLOCK_SMALL = prev
+    monkeypatch.setenv("PFPP_HEADS_FUSED", "0")
+    with torch.no_grad():
+        want = m(x, ts, latent, xyz, valid_d, scale, ref_d)
+    monkeypatch.setenv("PFPP_HEADS_FUSED", "1")
+    with torch.no_grad():
+        got = [m(x, ts, latent, xyz, valid_d, scale, ref_d) for _ in range(3)]
     torch.cuda.synchronize()
     v = valid_d.bool()
     assert torch.isfinite(got[0]).all() and float(want[v].abs().max()) > 1e-3
-    assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])          # deterministic, barrier generations carry over
+    assert torch.equal(got[0], got[1]) and torch.equal(got[1], got[2])
     assert (got[0][v] - want[v]).abs().max() <= 1e-5 * max(1.0, float(want[v].abs().max()))
     assert float(got[0][~v].abs().max() if (~v).any() else 0.0) == 0.0
+    # all slots evaluated (the reference's form): same bound
+    m.compact_padded = False
+    monkeypatch.setenv("PFPP_HEADS_FUSED", "0")
+    with torch.no_grad():
+        want_all = m(x, ts, latent, xyz, valid_d, scale, ref_d)
+    monkeypatch.setenv("PFPP_HEADS_FUSED", "1")
+    with torch.no_grad():
+        got_all = m(x, ts, latent, xyz, valid_d, scale, ref_d)
+    assert (got_all - want_all).abs().max() <= 1e-5 * max(1.0, float(want_all.abs().max()))
 
 
 def test_auto_aggl_batched_equals_single(weights_sd, dev):

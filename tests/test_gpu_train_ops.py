@@ -72,52 +72,6 @@ def test_plane_gemm_layouts_and_fused_bias_gradient(dev, rows, n_out, n_in, spli
     assert torch.equal(dW_b, dW) and torch.equal(db_b, db)
 
 
-@pytest.mark.parametrize("rows,n_out,n_in", [(3850, 512, 512), (3850, 1536, 512), (3850, 512, 2048), (3850, 512, 1536), (777, 512, 4096), (100, 64, 128),
-                                             (129, 200, 192)])
-def test_plane_gemm_k_tile_64_is_bit_identical_to_k_tile_32(dev, rows, n_out, n_in):
-    """round 3: the 128 x 64 / 128 x 128 tiles stage 64 contraction values per row (full 128-byte lines per DMA row:
-    tools/lab/dma_rows_probe.hip; variants 15 / 16, opt-in) — y = x.W^T and dX = dY.W (k-major W) must equal the K-tile-of-32 kernel
-    (variants 6 / 3) bit for bit, with bias / activation / residual epilogues and ragged M / N; a K split goes through the same slabs (chunk boundaries
-    differ: compared against fp64)"""
-    from pfpp_hip import planes as P
-
-    g = torch.Generator().manual_seed(rows * 3 + n_out + n_in)
-    x = torch.randn(rows, n_in, generator=g)
-    W = torch.randn(n_out, n_in, generator=g) / math.sqrt(n_in)
-    dY = torch.randn(rows, n_out, generator=g) * 1e-4
-    bias = torch.randn(n_out, generator=g).to(dev)
-    res = torch.randn(rows, n_out, generator=g).to(dev)
-    xp, wp, dyp = P.split(x.to(dev)), P.split(W.to(dev)), P.split(dY.to(dev), 4096.0)
-    for v64, v32 in ((15, 6), (16, 3)):
-        for kw in (dict(), dict(bias=bias, residual=res, act="gelu")):
-            if n_out % 4 and kw:
-                continue
-            a, b = torch.empty(rows, n_out, device=dev), torch.empty(rows, n_out, device=dev)
-            P.gemm(xp, wp, a, M=rows, N=n_out, K=n_in, splits=1, variant=v64, **kw)
-            P.gemm(xp, wp, b, M=rows, N=n_out, K=n_in, splits=1, variant=v32, **kw)
-            assert torch.equal(a, b), (v64, kw.keys())
-        if n_in % 8 == 0 and n_out % 64 == 0:
-            a, b = torch.empty(rows, n_in, device=dev), torch.empty(rows, n_in, device=dev)
-            P.gemm(dyp, wp, a, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=1, variant=v64)
-            P.gemm(dyp, wp, b, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=1, variant=v32)
-            assert torch.equal(a, b), ("nn", v64)
-            if n_out >= 512:
-                c = torch.empty(rows, n_in, device=dev)
-                P.gemm(dyp, wp, c, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=3, variant=v64)
-                assert rel_err(c, dyp.float().double().cpu() @ wp.float().double().cpu()) < 2e-6
-    assert "gemm_pl64_kernel" in P._lib.load().pfpp_last_gemm_kernel().decode() or n_out < 512
-    # two wave groups along K (variants 17 / 18: 8 waves, the groups' accumulators meet in LDS): another summation order -> fp64 bar
-    for v in (17, 18):
-        a = torch.empty(rows, n_out, device=dev)
-        P.gemm(xp, wp, a, M=rows, N=n_out, K=n_in, splits=1, variant=v, bias=bias if n_out % 4 == 0 else None)
-        want = xp.float().double().cpu() @ wp.float().double().cpu().t() + (bias.double().cpu() if n_out % 4 == 0 else 0.0)
-        assert rel_err(a, want) < 2e-6
-        if n_in % 8 == 0 and n_out % 64 == 0:
-            b = torch.empty(rows, n_in, device=dev)
-            P.gemm(dyp, wp, b, M=rows, N=n_in, K=n_out, w_kmajor=True, splits=2 if n_out >= 512 else 1, variant=v)
-            assert rel_err(b, dyp.float().double().cpu() @ wp.float().double().cpu()) < 2e-6
-
-
 @pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (16000, 1536, 512), (1234 * 4, 512, 2048), (640, 512, 148), (32, 1024, 512)])
 def test_grad_weight_gemm(dev, M, N, K):
     """dW [N,K] = dY[M,N]^T . X[M,K]  (both operands k-major, split-K atomics)"""
