@@ -230,7 +230,9 @@ __device__ __forceinline__ void score_to_fragments(const f32x16 y, int lhi, ad_h
 // 4-5 of the dim (the 16 lanes that write one key pair for dims 4*c4 + j then hit 16 different banks)
 __device__ __forceinline__ int ad_toff(int dim, int key) { return dim * (32 + 8) + ((((key >> 3) ^ (dim >> 4)) & 3) << 3) + (key & 7); }
 
-template <int DH>
+// X1: single-pass fp16 (hi planes only, one matrix instruction per product) — the perf mode of BASELINE configs[4]
+// (pfpp_set_attention_mode(2)); ~1e-3 relative error, never a parity mode
+template <int DH, bool X1 = false>
 __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
     _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   constexpr int LDKH = DH + 8;          // halfs per K row  (16-byte fragment reads conflict-free)
   constexpr int LDVH = KT + 8;          // halfs per V^T row
   constexpr int F4 = KT * DH / 4 / 256;
-  __shared__ __align__(16) _Float16 Kh[2][KT * LDKH], Kl[2][KT * LDKH];
-  __shared__ __align__(16) _Float16 Vh[2][DH * LDVH], Vl[2][DH * LDVH];
+  __shared__ __align__(16) _Float16 Kh[2][KT * LDKH], Kl[X1 ? 1 : 2][X1 ? 8 : KT * LDKH];
+  __shared__ __align__(16) _Float16 Vh[2][DH * LDVH], Vl[X1 ? 1 : 2][X1 ? 8 : DH * LDVH];
 
   const int b = blockIdx.z, h = blockIdx.y;
   const int T = seq_len[b];
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
         vh4[j] = hh; vl4[j] = ll;
       }
       *reinterpret_cast<ad_half4*>(&Kh[buf][r * LDKH + c4 * 4]) = kh4;
-      *reinterpret_cast<ad_half4*>(&Kl[buf][r * LDKH + c4 * 4]) = kl4;
+      if constexpr (!X1) *reinterpret_cast<ad_half4*>(&Kl[buf][r * LDKH + c4 * 4]) = kl4;
       // V transposed ([dim][key]): lanes r and r+1 (16 apart) swap halves, each then writes two keys of two dims as words
       union { ad_half4 h; int2 i; } uh, ul;
       uh.h = vh4; ul.h = vl4;
@@ -320,8 +322,10 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
       const int d0 = c4 * 4 + (odd ? 2 : 0), r0 = r & ~1;
       *reinterpret_cast<int*>(&Vh[buf][ad_toff(d0, r0)]) = (a_h & 0xffff) | (b_h << 16);
       *reinterpret_cast<int*>(&Vh[buf][ad_toff(d0 + 1, r0)]) = ((unsigned)a_h >> 16) | (b_h & 0xffff0000);
-      *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0, r0)]) = (a_l & 0xffff) | (b_l << 16);
-      *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0 + 1, r0)]) = ((unsigned)a_l >> 16) | (b_l & 0xffff0000);
+      if constexpr (!X1) {
+        *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0, r0)]) = (a_l & 0xffff) | (b_l << 16);
+        *reinterpret_cast<int*>(&Vl[buf][ad_toff(d0 + 1, r0)]) = ((unsigned)a_l >> 16) | (b_l & 0xffff0000);
+      }
     }
   };
 
@@ -345,9 +349,11 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
 #pragma unroll
     for (int c = 0; c < DH / 16; ++c) {
       const ad_half8 kh = *reinterpret_cast<const ad_half8*>(&Kh[buf][l31 * LDKH + c * 16 + lhi * 8]);
-      const ad_half8 kl = *reinterpret_cast<const ad_half8*>(&Kl[buf][l31 * LDKH + c * 16 + lhi * 8]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], s, 0, 0, 0);
+      if constexpr (!X1) {
+        const ad_half8 kl = *reinterpret_cast<const ad_half8*>(&Kl[buf][l31 * LDKH + c * 16 + lhi * 8]);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], s, 0, 0, 0);
+      }
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], s, 0, 0, 0);
     }
 
@@ -385,9 +391,11 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
-        const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
-        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o_acc[dt], 0, 0, 0);
-        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o_acc[dt], 0, 0, 0);
+        if constexpr (!X1) {
+          const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[buf][ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o_acc[dt], 0, 0, 0);
+          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o_acc[dt], 0, 0, 0);
+        }
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], o_acc[dt], 0, 0, 0);
       }
     if (t + 1 < nt) store_tile(buf ^ 1);
@@ -482,6 +490,15 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
   // PFPP_ATTN_F16X3=0: the exact-fp32 MFMA kernel.
   static const int f16_mode = getenv("PFPP_ATTN_F16X3") ? atoi(getenv("PFPP_ATTN_F16X3")) : 1;
   const bool f16x3 = pfpp::attn_use_f16(f16_mode != 0);
+  if (pfpp::attn_mode() == 2 && !lse) {      // single-pass fp16 (inference only: the training forward keeps its fp32-grade statistics)
+    if (dh == 64)
+      hipLaunchKernelGGL((attn_dense_f16_kernel<64, true>), grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                         key_valid, kv_stride, (int)H, scale, lse);
+    else
+      hipLaunchKernelGGL((attn_dense_f16_kernel<32, true>), grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
+                         key_valid, kv_stride, (int)H, scale, lse);
+    return pfpp::check_launch("pfpp_attn_dense");
+  }
   if (dh == 64 && f16x3)
     hipLaunchKernelGGL(attn_dense_f16_kernel<64>, grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                        key_valid, kv_stride, (int)H, scale, lse);

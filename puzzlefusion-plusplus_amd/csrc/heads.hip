@@ -22,7 +22,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HC = 512;        // width
 constexpr int HC2 = 256;       // hidden width of the second linear
 constexpr int KP = HC + 8;     // LDS row stride of an activation plane in halfs: 1040 bytes -> rows 4 banks apart
-constexpr int PF = 8;          // weight fragments in flight per wave (16-deep steps)
 constexpr int NW = 8;          // waves per workgroup
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
@@ -47,39 +46,52 @@ struct HeadsFwdP {
   int ldo, R;
 };
 
-// acc[j] += A[32 x K] (LDS planes, row stride KP) . W[n0 + 32 j + (0..31), 0..K)^T, W row-major planes with leading dimension ldw
+// acc[j] += A[32 x K] (LDS planes, row stride KP) . W[n0 + 32 j + (0..31), 0..K)^T, W row-major planes with leading dimension ldw.
+// The weights come straight from global memory into the B operand registers: lane (column n, half lhi) needs 8 contraction-consecutive
+// halfs of row n per 16-deep step.  The contraction is walked in groups of 64 (one 128-byte line of every weight row): within a
+// group lane half lhi owns the 64-byte half line [32 lhi, 32 lhi + 32) and step u of the group takes its u-th 16-byte piece — the four
+// loads that share a line are issued back to back (the second to fourth hit the L1), and A is read from LDS in the same order.  One
+// group is in flight while the previous one is multiplied; the loads are unconditional (a conditional prefetch makes the compiler
+// wait for it on the spot): past the end they re-read the last group.
 template <int NT>
 __device__ __forceinline__ void contract_rowmajor(const _Float16* sh, const _Float16* sl, const _Float16* __restrict__ wh,
                                                   const _Float16* __restrict__ wl, int K, int ldw, int n0, f32x16 (&acc)[NT]) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-  const half8* ah = reinterpret_cast<const half8*>(sh + l31 * KP + 8 * lhi);
-  const half8* al = reinterpret_cast<const half8*>(sl + l31 * KP + 8 * lhi);
+  const half8* ah = reinterpret_cast<const half8*>(sh + l31 * KP + 32 * lhi);
+  const half8* al = reinterpret_cast<const half8*>(sl + l31 * KP + 32 * lhi);
   const half8 *bh[NT], *bl[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    bh[j] = reinterpret_cast<const half8*>(wh + (size_t)(n0 + 32 * j + l31) * ldw + 8 * lhi);
-    bl[j] = reinterpret_cast<const half8*>(wl + (size_t)(n0 + 32 * j + l31) * ldw + 8 * lhi);
+    bh[j] = reinterpret_cast<const half8*>(wh + (size_t)(n0 + 32 * j + l31) * ldw + 32 * lhi);
+    bl[j] = reinterpret_cast<const half8*>(wl + (size_t)(n0 + 32 * j + l31) * ldw + 32 * lhi);
   }
-  const int S = K / 16;
-  half8 fh[PF][NT], fl[PF][NT];
+  const int NG = K / 64;                   // groups of 4 steps; a group = 8 half8 along a row
+  half8 fh[2][4][NT], fl[2][4][NT];
+  auto fetch = [&](int g, int slot) {
 #pragma unroll
-  for (int u = 0; u < PF; ++u)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { fh[u][j] = bh[j][2 * u]; fl[u][j] = bl[j][2 * u]; }
-  for (int s0 = 0; s0 < S; s0 += PF) {
+      for (int u = 0; u < 4; ++u) { fh[slot][u][j] = bh[j][8 * g + u]; fl[slot][u][j] = bl[j][8 * g + u]; }
+  };
+  fetch(0, 0);
+  for (int g = 0; g < NG; g += 2) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int s = s0 + u;
-      const half8 a_h = ah[2 * s], a_l = al[2 * s];
+    for (int half = 0; half < 2; ++half) {
+      const int gg = g + half;
+      if (gg < NG) {
+        fetch(gg + 1 < NG ? gg + 1 : NG - 1, half ^ 1);
+        __builtin_amdgcn_sched_barrier(0);         // the next group's 16 loads are issued HERE (the scheduler would sink them to their uses)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, fh[u][j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fl[u][j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fh[u][j], acc[j], 0, 0, 0);
-      }
-      if (s + PF < S) {
+        for (int u = 0; u < 4; ++u) {
+          const half8 a_h = ah[8 * gg + u], a_l = al[8 * gg + u];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { fh[u][j] = bh[j][2 * (s + PF)]; fl[u][j] = bl[j][2 * (s + PF)]; }
+          for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, fh[half][u][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fl[half][u][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fh[half][u][j], acc[j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -213,19 +225,25 @@ __device__ __forceinline__ void contract_kmajor(const _Float16* sh, const _Float
   const uint32_t rd0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)patch +
                        (uint32_t)(((8 * (q >> 1) + (jj >> 2)) * 64 + 16 * (q & 1) + 4 * (jj & 3)) * 2);
   const int S = K / 16;
-  half8 r_h[2][2], r_l[2][2];                        // two tiles in flight: [slot][chunk]
-  auto fetch = [&](int s, int slot) {
-    r_h[slot][0] = gh[s * step]; r_h[slot][1] = gh[s * step + 4];
-    r_l[slot][0] = gl[s * step]; r_l[slot][1] = gl[s * step + 4];
+  constexpr int DEPTH = 4;                           // k-tiles in flight (registers); the LDS patch is double-buffered
+  half8 r_h[DEPTH][2], r_l[DEPTH][2];                // [slot][chunk]
+  auto fetch = [&](int s, int slot) {                // unconditional: past the end the last tile is read again
+    const int sc = s < S ? s : S - 1;
+    r_h[slot][0] = gh[sc * step]; r_h[slot][1] = gh[sc * step + 4];
+    r_l[slot][0] = gl[sc * step]; r_l[slot][1] = gl[sc * step + 4];
   };
-  fetch(0, 0);
-  if (S > 1) fetch(1, 1);
-  for (int s = 0; s < S; ++s) {
-    const int slot = s & 1;
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) fetch(u, u);
+  for (int s0 = 0; s0 < S; s0 += DEPTH) {
+#pragma unroll
+   for (int u = 0; u < DEPTH; ++u) {
+    const int s = s0 + u;
+    const int slot = u & 1;
     half8* dst = pw + slot * 256;                    // buffer = 2 planes x 16 x 64 halfs = 256 half8 = 4 KB
-    dst[0] = r_h[slot][0]; dst[4] = r_h[slot][1];
-    dst[128] = r_l[slot][0]; dst[132] = r_l[slot][1];
-    if (s + 2 < S) fetch(s + 2, slot);
+    dst[0] = r_h[u][0]; dst[4] = r_h[u][1];
+    dst[128] = r_l[u][0]; dst[132] = r_l[u][1];
+    fetch(s + DEPTH, u);
+    __builtin_amdgcn_sched_barrier(0);               // keep DEPTH tiles in flight (the scheduler would sink the loads to their uses)
     const half8 a_h = ah[2 * s], a_l = al[2 * s];
     const uint32_t rd = rd0 + slot * 4096;
     half4 t[2][2][2];                                // [tile][plane][t]
@@ -251,6 +269,7 @@ __device__ __forceinline__ void contract_kmajor(const _Float16* sh, const _Float
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_l, acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_h, acc[j], 0, 0, 0);
     }
+   }
   }
 }
 

@@ -208,22 +208,36 @@ SINGLE_PASS = _os.environ.get("PFPP_GEMM_SINGLE_PASS", "0") == "1"
 import contextlib as _ctx
 
 
+_EXACT_DEPTH = 0
+_ATTN_MODE_SET = None
+
+
+def _sync_attention_mode() -> None:
+    """the library's process-wide attention arithmetic (pfpp_set_attention_mode) follows this module's state: exact fp32 inside
+    exact_fp32(), single-pass fp16 while SINGLE_PASS is on (the perf mode of BASELINE configs[4]: plane GEMMs AND attention forward
+    on one fp16 matrix instruction per product), the kernels' defaults otherwise.  Called by the attention wrappers; a foreign call
+    only when the state changed."""
+    global _ATTN_MODE_SET
+    want = 0 if _EXACT_DEPTH > 0 else (2 if (SINGLE_PASS and GEMM_MODE == "f16x3") else -1)
+    if want != _ATTN_MODE_SET:
+        check(_lib.load().pfpp_set_attention_mode(want), "pfpp_set_attention_mode")
+        _ATTN_MODE_SET = want
+
+
 @_ctx.contextmanager
 def exact_fp32():
     """run the enclosed calls with the exact fp32 MFMA GEMMs (PFPP_GEMM=f32) — the fallback the drop-in sampler loops take
     when a split-f16 run produced non-finite poses (an operand at or beyond the fp16 range, |v| >= 65504).  The attention
     forward kernels split raw q / k / v the same way, so they are switched to their exact-fp32 form for the duration as well
-    (pfpp_set_attention_mode(0))."""
-    global GEMM_MODE
-    lib = _lib.load()
+    (pfpp_set_attention_mode(0) through _sync_attention_mode)."""
+    global GEMM_MODE, _EXACT_DEPTH
     prev, GEMM_MODE = GEMM_MODE, "f32"
-    prev_attn = lib.pfpp_get_attention_mode()
-    check(lib.pfpp_set_attention_mode(0), "pfpp_set_attention_mode")
+    _EXACT_DEPTH += 1
     try:
         yield
     finally:
         GEMM_MODE = prev
-        check(lib.pfpp_set_attention_mode(prev_attn), "pfpp_set_attention_mode")
+        _EXACT_DEPTH -= 1
 
 
 def f16x3_range_fallback(x: torch.Tensor) -> bool:
@@ -815,6 +829,7 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
 
 def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float, out=None):
     _chk(qkv, torch.float32, "qkv")
+    _sync_attention_mode()
     if qkv.shape != (n_frag * L, 3 * H * dh):
         raise ValueError("attn_blockdiag: qkv must be [n_frag*L, 3*H*dh]")
     if isinstance(out, SplitAct):
@@ -832,6 +847,7 @@ def attn_dense(qkv: torch.Tensor, seq_off: torch.Tensor, seq_len: torch.Tensor, 
                scale: float, key_valid_u8: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fused softmax(QK^T*scale + key mask)V from a packed [rows, 3*H*dh] projection; sequences are row
     ranges [seq_off[s], seq_off[s]+seq_len[s]) (int32); key_valid [n_seq, max_len] uint8 or None"""
+    _sync_attention_mode()
     _chk(qkv, torch.float32, "qkv"); _chk(seq_off, torch.int32, "seq_off"); _chk(seq_len, torch.int32, "seq_len")
     rows, w = qkv.shape
     if w != 3 * H * dh:

@@ -45,3 +45,12 @@ for hd, (p0, p2, W4, b0, b2, b4) in enumerate(raw):
     e = (runs[0][0][hd].double() - da0_ref).abs()
     print("   worst columns:", torch.topk(e.max(0).values, 8).indices.tolist(), " worst rows:", torch.topk(e.max(1).values, 5).indices.tolist())
     print("   err by column block of 32:", [f"{float(e[:, 32*i:32*i+32].max()):.1e}" for i in range(16)])
+# timing (HIP events over 50 back-to-back launches)
+for name, fn in (("heads_fwd", lambda: T.heads_fwd(pooled, hs[0], hs[1], out, save=True)),
+                 ("heads_bwd", lambda: T.heads_bwd(dout, hs[0], hs[1], saved, gs[0], gs[1], G, L))):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per call (R = {R})")
