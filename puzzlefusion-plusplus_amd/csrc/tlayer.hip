@@ -10,6 +10,8 @@
 // Why: the iteration issues ~360 launches; ~240 of them belong to the six blocks.  From Python (argument marshalling + one foreign call
 // each) the host needs 6.3 ms to enqueue an iteration the GPU runs in 6.7 ms — any further GPU-side gain would be
 // hidden behind the enqueue.  From here a launch costs what hipLaunchKernel costs.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "pfpp_common.h"
@@ -114,8 +116,9 @@ FwdLayout fwd_layout(int64_t M, int64_t C, int64_t H, int64_t inner) {
 
 int gemm_pl(const pfpp_planes& A, const pfpp_planes& W, float* Cout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
             bool a_km, bool w_km, const float* bias, const float* residual, bool accumulate, float* colsum, float* ws, int64_t ws_bytes,
-            int single_pass, pfpp_stream_t st) {
+            int single_pass, pfpp_stream_t st, int splits = 0) {
   pfpp_gemm_planes_args a = {};
+  a.splits = splits;
   a.a_hi = A.hi; a.a_lo = A.lo; a.w_hi = W.hi; a.w_lo = W.lo;
   a.C = Cout; a.bias = bias; a.residual = residual;
   a.M = M; a.N = N; a.K = K;
@@ -235,7 +238,8 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   // dW += dY^T . X, db += colsum(dY): both operands read in place as k-major planes, on the side stream; `k` = the slot dY lives in
   auto dw = [&](const pfpp_planes& dyp, int k, const pfpp_planes& xp, int64_t n_out, int64_t n_in, float* gw, float* gb) -> int {
     if (side) TL_CALL(order_after(side_s, main_s));
-    TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t));
+    static const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;      // lab: 0 = the library's choice
+    TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t, dw_splits));
     if (side && k >= 0) TL_CALL(slot_read_on(g_slots[k], side_s));
     return PFPP_OK;
   };
