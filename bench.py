@@ -223,7 +223,7 @@ class TrainWorkload:
 
 class StressWorkload:
     """BASELINE configs[4]: B puzzles x 100 fragments x 2048 points; one step = rotate + encode + denoise + scheduler step +
-    verifier forward on all 4,950 candidate edges of every puzzle (joint denoiser + verifier)"""
+    edge features of the stepped poses + verifier forward on all 4,950 candidate edges of every puzzle (joint denoiser + verifier)"""
 
     def __init__(self, batch: int, first_id: int, dev: torch.device, parts: int = 100, points: int = 2048):
         from pfpp_hip import config, synthetic
@@ -257,6 +257,29 @@ class StressWorkload:
         self.x = self.x0.clone()
         self.i = 0
         self.last_eps = None
+        # edge features of the stepped poses (auto_aggl.py:153-201: transform the matched points by the current poses, nearest-
+        # neighbour histogram per candidate edge) — the stage between the scheduler step and the verifier in the joint step
+        from puzzlefusion_plusplus.auto_aggl import AutoAgglomerative
+
+        self.match = []
+        for b in range(batch):
+            one = {k: v[b:b + 1] for k, v in self.data.items()}
+            md = synthetic.make_matching(one, seed=first_id + b)
+            self.match.append((md["part_pcs_by_area"][0].float().contiguous().to(dev), AutoAgglomerative.prepare_matching(md, dev)))
+        self.pivot = torch.arange(parts, dtype=torch.int32, device=dev)
+        self.pivot_of_point = [self.pivot[mt["point_part"].long()].contiguous() for _, mt in self.match]
+        self.E = E
+
+    @torch.no_grad()
+    def edge_features(self, x):
+        from pfpp_hip import ops
+        from puzzlefusion_plusplus.auto_aggl import normalise_edge_hist
+
+        ef = torch.zeros(len(self.match), self.E, 6, dtype=torch.int32, device=x.device)
+        for b, (pts, mt) in enumerate(self.match):
+            pts_t = ops.pose_apply_points(pts, self.pivot_of_point[b], x[b].contiguous(), normalise=False)
+            ef[b, mt["pair_pos"]] = ops.edge_histogram(pts_t, mt["idx_a"], mt["idx_b"], mt["edge_off"], mt["max_m"])
+        return normalise_edge_hist(ef)
 
     @torch.no_grad()
     def step(self):
@@ -269,6 +292,7 @@ class StressWorkload:
         eps = m.denoiser(self.x, self.ts_dev[t], latent, xyz, d["part_valids"], d["part_scale"], self.ref)
         self.x = m.noise_scheduler.step(eps, t, self.x, variance_noise=self.noise[k], ref_part=self.ref,
                                         reference=self.reference).prev_sample
+        self.edge_feat = self.edge_features(self.x)
         self.last_logits = self.verifier(self.edge_feat, self.edge_idx, self.edge_valid)
         self.last_eps = eps
         self.i += 1
@@ -778,7 +802,8 @@ def main():
             v = st.data["part_valids"].bool()
             extra["stress"] = {
                 "workload": f"BASELINE configs[4], 1 GPU: {args.stress_batch} puzzles x 100 fragments x 2048 points, rotate + encode + "
-                            "DenoiserTransformer + scheduler step + VerifierTransformer on 4,950 edges per puzzle; plane GEMMs single-pass fp16",
+                            "DenoiserTransformer + scheduler step + edge features (pose apply + matched-point histograms) + VerifierTransformer on 4,950 edges "
+                            "per puzzle; plane GEMMs and attention forward single-pass fp16",
                 "ms_per_step": round(dt / n_s * 1e3, 3), "value": round(st.n_frag * n_s / dt, 2), "unit": "fragment*steps/s",
                 "roofline": roofline_from_trace(trace, n_s, "stress"),
                 "max_abs_diff_pred_noise_vs_f16x3": float((eps_fast - eps_ref)[v].abs().max()),
@@ -816,11 +841,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 I/O (plane GEMMs: single-pass f16, fp32 accumulate; others f16x3)" if (stress and ops.SINGLE_PASS) else
+            "dtype": ("f32 I/O (plane GEMMs and attention forward: single-pass f16, fp32 accumulate; others f16x3)" if (stress and ops.SINGLE_PASS) else
                       "f32 (GEMMs: %s)" % ops.GEMM_MODE), "data": "synthetic",
             "config": {
                 "workload": "stress, BASELINE configs[4]: joint step = rotate + PointNet++/VQ encode + DenoiserTransformer + scheduler step + "
-                            "VerifierTransformer on all candidate edges; 100 fragments per puzzle x 2048 points (beyond the reference's "
+                            "edge features + VerifierTransformer on all candidate edges; 100 fragments per puzzle x 2048 points (beyond the reference's "
                             "max_len = 20: no reference parity, roofline only)" if stress else
                             ("DDPM training iteration, BASELINE configs[1]: add_noise + rotate + frozen PointNet++/VQ encode"
                              + (" (skipped: latents given)" if args.latents_given else " (in the loop)") +
