@@ -414,6 +414,17 @@ int pfpp_token_combine(const float* shape_emb, const float* x_emb,
                        const float* ref_emb, const uint8_t* ref_part,
                        const float* pe, float* tok, int64_t B, int64_t P,
                        int64_t L, int64_t C, pfpp_stream_t stream);
+/* pfpp_token_features / pfpp_token_combine_list / pfpp_token_combine_bwd for a compacted fragment list that is still stored at its
+ * padded slots: listed fragment f is read from row slot[f] of latent [n_slots, L, 64], xyz, scale, x and ref_part [n_slots] — the
+ * valid-fragment gather of DenoiserTransformer.forward's inputs (denoiser.py:66-77) without the five gathered copies */
+int pfpp_token_features_slots(const float* latent, const float* xyz, const float* scale, const float* x,
+                              const int32_t* slot, float* shape_feat, float* pose_feat, int64_t n, int64_t L,
+                              pfpp_stream_t stream);
+int pfpp_token_combine_slots(const float* shape_emb, const float* x_emb, const float* ref_emb,
+                             const uint8_t* ref_part, const float* pe, const int32_t* frag_pos, const int32_t* slot,
+                             float* tok, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
+int pfpp_token_combine_bwd_slots(const float* dtok, const uint8_t* ref_part, const int32_t* slot, float* dx_emb,
+                                 float* dref_emb, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
 /* same for a compacted fragment list (padded slots dropped): n fragments, frag_pos[f] = p (row of pe) */
 int pfpp_token_combine_list(const float* shape_emb, const float* x_emb,
                             const float* ref_emb, const uint8_t* ref_part,
@@ -719,6 +730,10 @@ int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const float* dse,
  * dpred = grad_out * 2 (pred - target) / (7 * n_sel) on selected rows, 0 elsewhere.  loss [1].       */
 int pfpp_mse_loss(const float* pred, const float* target, const uint8_t* sel, float* loss,
                   float* dpred, int64_t n, int64_t width, float grad_out, pfpp_stream_t stream);
+/* the same with the selection computed in the kernel: row r counts iff valid[r] != 0 and ref[r] == 0 (part_valids & ~ref_part,
+ * denoiser.py:118-121, never materialised); amax (optional, needs dpred): receives max |dpred| of the call */
+int pfpp_mse_loss_masked(const float* pred, const float* target, const float* valid, const uint8_t* ref, float* loss,
+                         float* dpred, float* amax, int64_t n, int64_t width, float grad_out, pfpp_stream_t stream);
 
 /* ---- AdamW (configure_optimizers, denoiser.py:230-241; torch.optim.AdamW semantics) ---------------------
  * p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g^2;
@@ -830,7 +845,7 @@ int pfpp_tlayers_bwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t la
  * out[row, 3:7], row = slot ? slot[r] : r (the scatter back to the padded fragment slots).  a0 / v0 [2, R, C] and a1 / v1
  * [2, R, C/2] (pre-activations and SiLU values of both heads, trans first) are saved for the backward when given (all or none).
  * Weights: split-f16 planes of scale * W (row-major [out, in]) for the two wide layers, fp32 for the last.  C = 512.
- * pfpp_heads_bwd: from dout [R, 7] (unscaled) it writes da0 [2, R, C], da1 [2, R, C/2] (the dY operands of the four wide
+ * pfpp_heads_bwd: from dout (unscaled; row r of the heads is dout[slot ? slot[r] : r, 0:7]) it writes da0 [2, R, C], da1 [2, R, C/2] (the dY operands of the four wide
  * weight-gradient GEMMs, which stay with pfpp_gemm_grad_group), accumulates dW4 / db4 / db2 / db0 of both heads with atomics,
  * writes each head's share of d pooled to dp [2, R, C] and, when dx is given, dx [(r, l), :] = (dp[0] + dp[1])[r, :] / L
  * (the backward of the mean pool, :139-142).  grad_scale: power of two lifting the gradient planes into the fp16 range.   */
@@ -842,7 +857,7 @@ typedef struct pfpp_head_grads { float *w4, *b4, *b2, *b0; } pfpp_head_grads;
 int pfpp_heads_fwd(const float* pooled, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
                    float* a0, float* v0, float* a1, float* v1, float* out, const int32_t* slot, int64_t ldo,
                    pfpp_stream_t stream);
-int pfpp_heads_bwd(const float* dout, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
+int pfpp_heads_bwd(const float* dout, const int32_t* slot, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
                    const float* a0, const float* v0, const float* a1, const float* v1, float* da0, float* da1, float* dp,
                    const pfpp_head_grads* g_trans, const pfpp_head_grads* g_rot, float grad_scale, float* dx, int64_t L,
                    pfpp_stream_t stream);

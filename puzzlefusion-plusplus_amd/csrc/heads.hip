@@ -187,7 +187,8 @@ __global__ __launch_bounds__(64 * NW) void heads_fwd_kernel(HeadsFwdP p) {
 // backward
 // ------------------------------------------------------------------------------------------------------------------------
 struct HeadsBwdP {
-  const float* dout;                       // [R, 7] gradient of the prediction rows (unscaled)
+  const float* dout;                       // [*, 7] gradient of the prediction rows (unscaled); row r is dout[slot ? slot[r] : r]
+  const int32_t* slot;
   HeadW w[2];
   const float *a0, *v0, *a1, *v1;          // saved by the forward
   float *da0, *da1;                        // out: [2, R, HC], [2, R, HC2] (unscaled; operands of the weight-gradient GEMMs)
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64 * NW) void heads_bwd_kernel(HeadsBwdP p) {
   const float G = p.G, invG = 1.0f / G;
   if (tid < 128) {
     const int row = tid >> 2, c = tid & 3;
-    s_do[row][c] = (c < w.n_out && r0 + row < R) ? p.dout[(size_t)(r0 + row) * 7 + w.c0 + c] : 0.0f;
+    s_do[row][c] = (c < w.n_out && r0 + row < R) ? p.dout[(size_t)(p.slot ? p.slot[r0 + row] : r0 + row) * 7 + w.c0 + c] : 0.0f;
   }
   __syncthreads();
   // ---- last layer: db4, dW4 (contraction over this block's rows, then atomics), dv1 -> da1 = dv1 * silu'(a1)
@@ -429,7 +430,7 @@ extern "C" int pfpp_heads_fwd(const float* pooled, const pfpp_head_params* trans
   return pfpp::check_launch(__func__);
 }
 
-extern "C" int pfpp_heads_bwd(const float* dout, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
+extern "C" int pfpp_heads_bwd(const float* dout, const int32_t* slot, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,
                               const float* a0, const float* v0, const float* a1, const float* v1, float* da0, float* da1, float* dp,
                               const pfpp_head_grads* g_trans, const pfpp_head_grads* g_rot, float grad_scale, float* dx, int64_t L,
                               pfpp_stream_t stream) {
@@ -444,7 +445,7 @@ extern "C" int pfpp_heads_bwd(const float* dout, const pfpp_head_params* trans, 
     PFPP_REQUIRE(gs[h]->w4 && gs[h]->b4 && gs[h]->b2 && gs[h]->b0, "null gradient pointer");
     p.gw4[h] = gs[h]->w4; p.gb4[h] = gs[h]->b4; p.gb2[h] = gs[h]->b2; p.gb0[h] = gs[h]->b0;
   }
-  p.dout = dout; p.a0 = a0; p.v0 = v0; p.a1 = a1; p.v1 = v1; p.da0 = da0; p.da1 = da1; p.dp = dp; p.G = grad_scale; p.R = (int)R;
+  p.dout = dout; p.slot = slot; p.a0 = a0; p.v0 = v0; p.a1 = a1; p.v1 = v1; p.da0 = da0; p.da1 = da1; p.dp = dp; p.G = grad_scale; p.R = (int)R;
   hipStream_t st = pfpp::as_stream(stream);
   const size_t smem = (size_t)2 * 32 * KP * sizeof(_Float16) + (size_t)NW * 8192;
   static bool attr_set = false;

@@ -459,9 +459,9 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(128) void token_combine_bwd_kernel(const float* __restrict__ dtok,
                                                                 const uint8_t* __restrict__ ref,
                                                                 float* __restrict__ dx_emb, float* __restrict__ dref,
-                                                                int L, int C) {
+                                                                int L, int C, const int32_t* __restrict__ slot) {
   const int64_t f = blockIdx.x;
-  const int r = ref[f] ? 1 : 0;
+  const int r = ref[slot ? slot[f] : f] ? 1 : 0;
   for (int c = threadIdx.x * 4; c < C; c += 128 * 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 0; l < L; ++l) {
@@ -500,15 +500,21 @@ __global__ __launch_bounds__(128) void silu_embed_bwd_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------
 // loss
 // ---------------------------------------------------------------------------------------------------
+// sel[r] != 0 selects row r; with `valid` given instead, a row counts iff valid[r] != 0 and ref[r] == 0 (Denoiser._loss's
+// part_valids & ~ref_part, denoiser.py:118-126, without materialising the mask).  amax (optional): max |dpred| of this call, for the
+// gradient-scale tracking of the training engine (replaces an abs + max reduction over dpred)
 __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                         const uint8_t* __restrict__ sel, float* __restrict__ loss,
-                                                        float* __restrict__ dpred, int64_t n, int width, float grad_out) {
+                                                        float* __restrict__ dpred, int64_t n, int width, float grad_out,
+                                                        const float* __restrict__ valid, const uint8_t* __restrict__ ref,
+                                                        float* __restrict__ amax) {
   __shared__ float s_sum[16];
   __shared__ float s_cnt[16];
   __shared__ float s_tot[2];
   float sum = 0.0f, cnt = 0.0f;
+  auto picked = [&](int64_t r) { return valid ? (valid[r] != 0.0f && ref[r] == 0) : (sel[r] != 0); };
   for (int64_t r = threadIdx.x; r < n; r += 1024) {
-    if (sel[r]) {
+    if (picked(r)) {
       cnt += 1.0f;
       for (int c = 0; c < width; ++c) {
         const float d = pred[r * width + c] - target[r * width + c];
@@ -529,9 +535,23 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
   __syncthreads();
   if (!dpred) return;
   const float k = grad_out * 2.0f / (s_tot[1] * (float)width);
+  float mx = 0.0f;
   for (int64_t i = threadIdx.x; i < n * width; i += 1024) {
     const int64_t r = i / width;
-    dpred[i] = sel[r] ? k * (pred[i] - target[i]) : 0.0f;
+    const float d = picked(r) ? k * (pred[i] - target[i]) : 0.0f;
+    dpred[i] = d;
+    mx = fmaxf(mx, fabsf(d));          // fmaxf drops a NaN operand, like torch.max would not: NaN gradients surface in the overflow guard
+  }
+  if (amax) {
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __syncthreads();                                   // s_sum is free again
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.0f;
+      for (int w = 0; w < 16; ++w) m = fmaxf(m, s_sum[w]);
+      amax[0] = m;
+    }
   }
 }
 
@@ -832,7 +852,17 @@ extern "C" int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part
   PFPP_REQUIRE(C % 4 == 0 && L >= 1 && pfpp::aligned16(dtok) && pfpp::aligned16(dx_emb), "C % 4 != 0 or alignment");
   if (n == 0) return PFPP_OK;
   hipLaunchKernelGGL(token_combine_bwd_kernel, dim3((unsigned)n), dim3(128), 0, pfpp::as_stream(stream), dtok, ref_part,
-                     dx_emb, dref_emb, (int)L, (int)C);
+                     dx_emb, dref_emb, (int)L, (int)C, (const int32_t*)nullptr);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_token_combine_bwd_slots(const float* dtok, const uint8_t* ref_part, const int32_t* slot, float* dx_emb,
+                                            float* dref_emb, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(dtok && ref_part && slot && dx_emb && dref_emb, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0 && L >= 1 && pfpp::aligned16(dtok) && pfpp::aligned16(dx_emb), "C % 4 != 0 or alignment");
+  if (n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_combine_bwd_kernel, dim3((unsigned)n), dim3(128), 0, pfpp::as_stream(stream), dtok, ref_part,
+                     dx_emb, dref_emb, (int)L, (int)C, slot);
   return pfpp::check_launch(__func__);
 }
 
@@ -852,7 +882,16 @@ extern "C" int pfpp_mse_loss(const float* pred, const float* target, const uint8
   PFPP_REQUIRE(pred && target && sel && loss, "null pointer");
   PFPP_REQUIRE(n >= 0 && width >= 1, "bad sizes");
   hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, pfpp::as_stream(stream), pred, target, sel, loss, dpred, n,
-                     (int)width, grad_out);
+                     (int)width, grad_out, (const float*)nullptr, (const uint8_t*)nullptr, (float*)nullptr);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_mse_loss_masked(const float* pred, const float* target, const float* valid, const uint8_t* ref, float* loss,
+                                    float* dpred, float* amax, int64_t n, int64_t width, float grad_out, pfpp_stream_t stream) {
+  PFPP_REQUIRE(pred && target && valid && ref && loss, "null pointer");
+  PFPP_REQUIRE(n >= 0 && width >= 1 && (!amax || dpred), "bad sizes (amax needs dpred)");
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, pfpp::as_stream(stream), pred, target, (const uint8_t*)nullptr, loss, dpred,
+                     n, (int)width, grad_out, valid, ref, amax);
   return pfpp::check_launch(__func__);
 }
 

@@ -26,12 +26,14 @@ constexpr int TOK_LD = 148;
 __global__ __launch_bounds__(256) void token_features_kernel(
     const float* __restrict__ latent, const float* __restrict__ xyz,
     const float* __restrict__ scale, const float* __restrict__ x,
-    float* __restrict__ shape_feat, float* __restrict__ pose_feat, int64_t n, int L) {
+    float* __restrict__ shape_feat, float* __restrict__ pose_feat, int64_t n, int L, const int32_t* __restrict__ slot) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_shape = n * L * TOK_LD;
   if (gid < n_shape) {
-    const int64_t row = gid / TOK_LD;     // (bp, l)
-    const int c = (int)(gid - row * TOK_LD);
+    const int64_t orow = gid / TOK_LD;    // (listed fragment, l)
+    const int c = (int)(gid - orow * TOK_LD);
+    const int64_t f = orow / L;
+    const int64_t row = slot ? (int64_t)slot[f] * L + (orow - f * L) : orow;     // (source fragment slot, l)
     float v;
     if (c < 64) {
       v = latent[row * 64 + c];
@@ -48,8 +50,9 @@ __global__ __launch_bounds__(256) void token_features_kernel(
   }
   const int64_t g2 = gid - n_shape;
   if (g2 < n * TOK_LD) {
-    const int64_t row = g2 / TOK_LD;
-    const int c = (int)(g2 - row * TOK_LD);
+    const int64_t orow = g2 / TOK_LD;
+    const int c = (int)(g2 - orow * TOK_LD);
+    const int64_t row = slot ? (int64_t)slot[orow] : orow;
     pose_feat[g2] = c < 147 ? nerf_pe(x + row * 7, 7, c) : 0.0f;
   }
 }
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void token_combine_kernel(
     const float* __restrict__ shape_emb, const float* __restrict__ x_emb,
     const float* __restrict__ ref_emb, const uint8_t* __restrict__ ref_part,
     const float* __restrict__ pe, const int32_t* __restrict__ frag_pos, float* __restrict__ tok,
-    int64_t total4, int P, int L, int C4) {
+    int64_t total4, int P, int L, int C4, const int32_t* __restrict__ slot) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total4) return;
   const int64_t row = gid / C4;          // (b,p,l)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void token_combine_kernel(
   const int p = frag_pos ? frag_pos[bp] : (int)(bp % P);
   const float4 s = reinterpret_cast<const float4*>(shape_emb)[gid];
   const float4 xe = reinterpret_cast<const float4*>(x_emb)[bp * C4 + c4];
-  const float4 re = reinterpret_cast<const float4*>(ref_emb)[(ref_part[bp] ? 1 : 0) * C4 + c4];
+  const float4 re = reinterpret_cast<const float4*>(ref_emb)[(ref_part[slot ? slot[bp] : bp] ? 1 : 0) * C4 + c4];
   const float4 pp = reinterpret_cast<const float4*>(pe)[p * C4 + c4];
   float4 o;
   o.x = ((xe.x + re.x) + s.x) + pp.x;
@@ -482,6 +485,30 @@ inline unsigned blocks_for(int64_t total, int per) { return (unsigned)((total + 
 
 }  // namespace
 
+extern "C" int pfpp_token_features_slots(const float* latent, const float* xyz, const float* scale, const float* x,
+                                         const int32_t* slot, float* shape_feat, float* pose_feat, int64_t n, int64_t L,
+                                         pfpp_stream_t stream) {
+  PFPP_REQUIRE(latent && xyz && scale && x && slot && shape_feat && pose_feat, "null pointer");
+  const int64_t total = n * L * TOK_LD + n * TOK_LD;
+  if (total == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_features_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), latent, xyz, scale, x, shape_feat, pose_feat, n, (int)L, slot);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_token_combine_slots(const float* shape_emb, const float* x_emb, const float* ref_emb,
+                                        const uint8_t* ref_part, const float* pe, const int32_t* frag_pos, const int32_t* slot,
+                                        float* tok, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream) {
+  PFPP_REQUIRE(shape_emb && x_emb && ref_emb && ref_part && pe && frag_pos && slot && tok, "null pointer");
+  PFPP_REQUIRE(C % 4 == 0, "C % 4 != 0");
+  const int64_t total4 = n * L * (C / 4);
+  if (total4 == 0) return PFPP_OK;
+  hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
+                     pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, frag_pos, tok, total4, 1,
+                     (int)L, (int)(C / 4), slot);
+  return pfpp::check_launch(__func__);
+}
+
 extern "C" int pfpp_token_features(const float* latent, const float* xyz, const float* scale,
                                    const float* x, float* shape_feat, float* pose_feat, int64_t n,
                                    int64_t L, pfpp_stream_t stream) {
@@ -489,7 +516,7 @@ extern "C" int pfpp_token_features(const float* latent, const float* xyz, const 
   const int64_t total = n * L * TOK_LD + n * TOK_LD;
   if (total == 0) return PFPP_OK;
   hipLaunchKernelGGL(token_features_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
-                     pfpp::as_stream(stream), latent, xyz, scale, x, shape_feat, pose_feat, n, (int)L);
+                     pfpp::as_stream(stream), latent, xyz, scale, x, shape_feat, pose_feat, n, (int)L, (const int32_t*)nullptr);
   return pfpp::check_launch(__func__);
 }
 
@@ -502,7 +529,7 @@ extern "C" int pfpp_token_combine(const float* shape_emb, const float* x_emb, co
   if (total4 == 0) return PFPP_OK;
   hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
                      pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, nullptr, tok, total4,
-                     (int)P, (int)L, (int)(C / 4));
+                     (int)P, (int)L, (int)(C / 4), (const int32_t*)nullptr);
   return pfpp::check_launch(__func__);
 }
 
@@ -515,7 +542,7 @@ extern "C" int pfpp_token_combine_list(const float* shape_emb, const float* x_em
   if (total4 == 0) return PFPP_OK;
   hipLaunchKernelGGL(token_combine_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0,
                      pfpp::as_stream(stream), shape_emb, x_emb, ref_emb, ref_part, pe, frag_pos, tok, total4, 1,
-                     (int)L, (int)(C / 4));
+                     (int)L, (int)(C / 4), (const int32_t*)nullptr);
   return pfpp::check_launch(__func__);
 }
 

@@ -151,7 +151,7 @@ class TlayersArgs(C.Structure):
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
-    "pfpp_heads_bwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
+    "pfpp_heads_bwd": [_p, _p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
                        C.POINTER(HeadGrads), C.POINTER(HeadGrads), _f32, _p, _i64, _p],
     "pfpp_tlayers_fwd": [C.POINTER(TlayersArgs), _i32, _i32, _p],
     "pfpp_tlayers_bwd": [C.POINTER(TlayersArgs), _i32, _i32, _p, _p],
@@ -171,6 +171,10 @@ SIGNATURES = {
     "pfpp_vq_encode": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_scatter_rows": [_p, _p, _p, _i64, _i64, _p],
     "pfpp_token_features": [_p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_token_features_slots": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_token_combine_slots": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_token_combine_bwd_slots": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "pfpp_mse_loss_masked": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _p],
     "pfpp_token_combine": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_token_combine_list": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_layernorm_grouped": [_p, _p, _p, _i64, _p, _i64, _i64, _i64, _f32, _p],

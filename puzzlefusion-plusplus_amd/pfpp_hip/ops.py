@@ -736,15 +736,24 @@ def scatter_rows(src: torch.Tensor, slot: torch.Tensor, n_slots: int,
 
 
 # --------------------------------------------------------------------------- transformer pieces
-def token_features(latent, xyz, scale, x):
-    """latent [n,L,64], xyz [n,L,3], scale [n], x [n,7] -> shape_feat [n*L,148], pose_feat [n,148]"""
+def token_features(latent, xyz, scale, x, slot=None):
+    """latent [n,L,64], xyz [n,L,3], scale [n], x [n,7] -> shape_feat [n*L,148], pose_feat [n,148].
+    slot (int32 [F]): the inputs are the PADDED tensors (n = number of slots) and listed fragment f is read from slot[f] -> [F*L,148],
+    [F,148] (the valid-fragment gather inside the kernel)"""
     for t, nm in ((latent, "latent"), (xyz, "xyz"), (scale, "scale"), (x, "x")):
         _chk(t, torch.float32, nm)
     n, L, c = latent.shape
     if c != 64 or xyz.shape != (n, L, 3) or scale.numel() != n or x.shape != (n, 7):
         raise ValueError("token_features: shape mismatch")
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+        n = slot.numel()
     sf = torch.empty((n * L, 148), dtype=torch.float32, device=latent.device)
     pf = torch.empty((n, 148), dtype=torch.float32, device=latent.device)
+    if slot is not None:
+        check(_lib.load().pfpp_token_features_slots(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(slot), _ptr(sf), _ptr(pf), n, L,
+                                                    _stream()), "pfpp_token_features_slots")
+        return sf, pf
     check(_lib.load().pfpp_token_features(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(sf), _ptr(pf), n, L,
                                           _stream()), "pfpp_token_features")
     return sf, pf
@@ -761,13 +770,19 @@ def token_combine(shape_emb, x_emb, ref_emb, ref_part_u8, pe, B, P, L):
     return tok
 
 
-def token_combine_list(shape_emb, x_emb, ref_emb, ref_u8, pe, frag_pos, L):
-    """token assembly for a compacted fragment list: frag_pos[f] = index of the fragment inside its puzzle"""
+def token_combine_list(shape_emb, x_emb, ref_emb, ref_u8, pe, frag_pos, L, slot=None):
+    """token assembly for a compacted fragment list: frag_pos[f] = index of the fragment inside its puzzle; with slot, ref_u8 is the
+    padded [n_slots] flag array and fragment f reads ref_u8[slot[f]]"""
     for t, nm in ((shape_emb, "shape_emb"), (x_emb, "x_emb"), (ref_emb, "ref_emb"), (pe, "pe")):
         _chk(t, torch.float32, nm)
     _chk(ref_u8, torch.uint8, "ref_part"); _chk(frag_pos, torch.int32, "frag_pos")
     n, Cc = x_emb.shape
     tok = torch.empty((n * L, Cc), dtype=torch.float32, device=shape_emb.device)
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+        check(_lib.load().pfpp_token_combine_slots(_ptr(shape_emb), _ptr(x_emb), _ptr(ref_emb), _ptr(ref_u8), _ptr(pe), _ptr(frag_pos),
+                                                   _ptr(slot), _ptr(tok), n, L, Cc, _stream()), "pfpp_token_combine_slots")
+        return tok
     check(_lib.load().pfpp_token_combine_list(_ptr(shape_emb), _ptr(x_emb), _ptr(ref_emb), _ptr(ref_u8), _ptr(pe),
                                               _ptr(frag_pos), _ptr(tok), n, L, Cc, _stream()), "pfpp_token_combine_list")
     return tok

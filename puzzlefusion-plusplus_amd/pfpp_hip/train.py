@@ -57,6 +57,20 @@ def _param_order(num_layers: int) -> List[str]:
     return names
 
 
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """t as contiguous fp32 without a launch when it already is"""
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _u8(t: torch.Tensor) -> torch.Tensor:
+    """a flag tensor as uint8 without a launch when its storage already is one byte per element (bool)"""
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    return (t != 0).to(torch.uint8).contiguous()
+
+
 def _pw_view(f32: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PW:
     w = PW.__new__(PW)
     w.scale = 1.0
@@ -348,12 +362,14 @@ class DenoiserTrainEngine:
             raise ValueError("training forward: the batch has no valid fragment")
         seq_len, seq_off, max_len = lay.seq_len, lay.seq_off, lay.max_len
         M = Fv * L
-        sf, pf = ops.token_features(latent.reshape(n_slots, L, -1)[slot].contiguous(), xyz.reshape(n_slots, L, 3)[slot].contiguous(),
-                                    scale.reshape(n_slots)[slot].contiguous(), x.reshape(n_slots, 7)[slot].contiguous().float())
+        # the valid-fragment gather of the inputs happens inside the kernels (slot32): no gathered copies of latent / xyz / scale / x / ref
+        slot32 = lay.slot32
+        sf, pf = ops.token_features(_f32c(latent).reshape(n_slots, L, -1), _f32c(xyz).reshape(n_slots, L, 3), _f32c(scale).reshape(n_slots),
+                                    _f32c(x).reshape(n_slots, 7), slot=slot32)
         shape_emb = ops.linear(sf, w["shape.w"], w["shape.b"])
         x_emb = ops.linear(pf, w["param.w"], w["param.b"])
-        ref_u8 = ref_part.reshape(n_slots)[slot].to(torch.uint8).contiguous()
-        h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L)
+        ref_u8 = _u8(ref_part).reshape(n_slots)           # padded flags; the kernels read ref_u8[slot[f]]
+        h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L, slot=slot32)
         fuse = self._fuse_drop                        # dropout sites ride in the LayerNorm kernels that follow them
         if p_tok > 0.0 and not fuse:
             T.dropout(h, p_tok, seed, 0, out=h)
@@ -365,7 +381,7 @@ class DenoiserTrainEngine:
                  batch=n_ada, sA=(B * C, 0), sW=(2 * C * C, 0), sC=(B * 2 * C, 0), sV=(2 * C, 0))
         att_scale = 1.0 / math.sqrt(dh)
         s.update(dict(B=B, P=P, L=L, C=C, Fv=Fv, M=M, slot=slot, frag_b=frag_b, seq_len=seq_len, seq_off=seq_off,
-                      max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
+                      max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, slot32=slot32, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
                       p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse))
         layers = []
         if self._planes and self._use_cseq(fuse):
@@ -680,8 +696,9 @@ class DenoiserTrainEngine:
                 self._sync = prev
         return cm()
 
-    def backward(self, ctx: TrainContext, dpred: torch.Tensor) -> None:
-        """accumulate d(loss)/d(parameter) into the flat gradient buffer (= every parameter's .grad)"""
+    def backward(self, ctx: TrainContext, dpred: torch.Tensor, amax: Optional[torch.Tensor] = None) -> None:
+        """accumulate d(loss)/d(parameter) into the flat gradient buffer (= every parameter's .grad).  amax: max |dpred| on the device
+        when the caller has it (the fused loss kernel), for the gradient-scale tracking"""
         if self._exchange.active() and self._exchanged:
             raise RuntimeError("DenoiserTrainEngine.backward: the flat gradient buffer was already all-reduced in place by a previous "
                                "backward of this step; a second backward would reduce the summed micro-batch again.  Accumulate with "
@@ -701,14 +718,16 @@ class DenoiserTrainEngine:
         w, g = ops_["w"], ops_["g"]
         s = ctx.t
         if self._dyn_gscale:
-            self._update_grad_scale(dpred)
+            self._update_grad_scale(dpred, amax)
         G = self.grad_scale
         B, L, C, Fv, M = s["B"], s["L"], s["C"], s["Fv"], s["M"]
         H = self.num_heads
         dh = C // H
         dev = dpred.device
         seed, p_lay, p_tok, fuse = s["seed"], s["p_lay"], s["p_tok"], s["fuse"]
-        dout_c = dpred.reshape(s["n_slots"], 7)[s["slot"]].contiguous().float()         # [Fv, 7]
+        fused_heads = "heads_saved" in s
+        dpred = _f32c(dpred).reshape(s["n_slots"], 7)
+        dout_c = None if fused_heads else dpred[s["slot"]].contiguous()         # [Fv, 7] (the fused heads kernel gathers by slot itself)
 
         # every small zero-initialised buffer of the backward out of ONE zeroed arena (one fill launch instead of eight)
         ld_sf, ld_pf = s["sf"].shape[1], s["pf"].shape[1]
@@ -722,8 +741,8 @@ class DenoiserTrainEngine:
         dpads, dw4s = [carve(1, Fv, 4), carve(2, Fv, 4)], [carve(3, 4, h1), carve(4, 4, h1)]
 
         # ---- output heads (denoiser_transformer.py:138-147)
-        if "heads_saved" in s:
-            dh_ = self._heads_backward_fused(s, w, g, dout_c, G, Fv, L)
+        if fused_heads:
+            dh_ = self._heads_backward_fused(s, w, g, dpred, G, Fv, L)
         else:
             dh_ = self._heads_backward_layerwise(s, w, g, dout_c, G, Fv, L, C, carve, dpads, dw4s)
 
@@ -745,7 +764,7 @@ class DenoiserTrainEngine:
         T.grad_weight(dtok, s["sf"], dws, g_scale=G)
         g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
         T.colsum(dtok, g["shape.b"])
-        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L)
+        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L, slot=s["slot32"])
         dwp = carve(7, C, ld_pf)
         T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
         g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
@@ -786,7 +805,7 @@ class DenoiserTrainEngine:
         grouped launch for the four wide weight gradients (off the critical chain: on the weight-gradient stream) -> d/dh [M, C]"""
         trans, rot, g_trans, g_rot = self._head_structs(w, g)
         a0, v0, a1, v1 = s["heads_saved"]
-        da0, da1, dh_ = T.heads_bwd(dout_c, trans, rot, s["heads_saved"], g_trans, g_rot, G, L)
+        da0, da1, dh_ = T.heads_bwd(dout_c, trans, rot, s["heads_saved"], g_trans, g_rot, G, L, slot=s["slot32"])
         pooled = s["pooled"]
         problems = [(da1[0], v0[0], g["mlp_out_trans.2.w"]), (da1[1], v0[1], g["mlp_out_rot.2.w"]),
                     (da0[0], pooled, g["mlp_out_trans.0.w"]), (da0[1], pooled, g["mlp_out_rot.0.w"])]
@@ -1153,7 +1172,7 @@ class DenoiserTrainEngine:
         if not self._dyn_gscale:                     # a pinned scale is lowered directly (the dynamic one is recomputed every backward)
             self.grad_scale = max(1.0, self.grad_scale / 16.0)
 
-    def _update_grad_scale(self, dpred: torch.Tensor) -> None:
+    def _update_grad_scale(self, dpred: torch.Tensor, amax: Optional[torch.Tensor] = None) -> None:
         if self._amax_ring is None:
             self._amax_ring = [(torch.zeros(1, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
         host, ev = self._amax_ring[self._n_backward % 2]
@@ -1162,7 +1181,8 @@ class DenoiserTrainEngine:
             amax = float(host[0])
             if math.isfinite(amax) and amax > 0.0:
                 self.grad_scale = max(1.0, float(2.0 ** min(40, max(0, 3 - math.floor(math.log2(amax))))) * self._backoff)
-        host.copy_(dpred.detach().abs().max().reshape(1), non_blocking=True)
+        # amax: max |dpred| already on the device (pfpp_mse_loss_masked wrote it next to dpred) — otherwise an abs + max over dpred
+        host.copy_(amax if amax is not None else dpred.detach().abs().max().reshape(1), non_blocking=True)
         ev.record()
         self._n_backward += 1
 
@@ -1172,9 +1192,11 @@ class DenoiserTrainEngine:
         """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1]"""
         pred, ctx = self.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=train)
         n = pred.shape[0] * pred.shape[1]
-        sel = (part_valids.reshape(n).to(torch.bool) & ~ref_part.reshape(n).to(torch.bool)).to(torch.uint8).contiguous()
-        loss, dpred = T.mse_loss(pred.reshape(n, 7), noise.reshape(n, 7).contiguous().float(), sel)
-        self.backward(ctx, dpred)
+        # the selection (valid & ~reference) is evaluated inside the loss kernel, which also leaves max |dpred| for the gradient scale
+        amax = torch.empty(1, dtype=torch.float32, device=pred.device) if self._dyn_gscale else None
+        loss, dpred = T.mse_loss_masked(pred.reshape(n, 7), _f32c(noise).reshape(n, 7), _f32c(part_valids).reshape(n), _u8(ref_part).reshape(n),
+                                        amax=amax)
+        self.backward(ctx, dpred, amax=amax)
         return loss
 
 

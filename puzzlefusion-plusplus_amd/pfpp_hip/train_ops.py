@@ -337,12 +337,18 @@ def mean_pool_bwd(dpooled: torch.Tensor, L: int, out: Optional[torch.Tensor] = N
     return out
 
 
-def token_combine_bwd(dtok: torch.Tensor, ref_u8: torch.Tensor, dref_emb: torch.Tensor, L: int) -> torch.Tensor:
-    """-> dx_emb [n, C]; dref_emb [2, C] accumulates"""
+def token_combine_bwd(dtok: torch.Tensor, ref_u8: torch.Tensor, dref_emb: torch.Tensor, L: int,
+                      slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dx_emb [n, C]; dref_emb [2, C] accumulates.  slot: ref_u8 is the padded [n_slots] array, fragment f reads ref_u8[slot[f]]"""
     _chk(dtok, _f32, "dtok"); _chk(ref_u8, torch.uint8, "ref_part"); _chk(dref_emb, _f32, "dref_emb")
-    n = ref_u8.numel()
+    n = ref_u8.numel() if slot is None else slot.numel()
     Cc = dtok.shape[1]
     dx_emb = torch.empty((n, Cc), dtype=_f32, device=dtok.device)
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+        check(_lib.load().pfpp_token_combine_bwd_slots(_ptr(dtok), _ptr(ref_u8), _ptr(slot), _ptr(dx_emb), _ptr(dref_emb), n, L, Cc,
+                                                       _stream()), "pfpp_token_combine_bwd_slots")
+        return dx_emb
     check(_lib.load().pfpp_token_combine_bwd(_ptr(dtok), _ptr(ref_u8), _ptr(dx_emb), _ptr(dref_emb), n, L, Cc, _stream()),
           "pfpp_token_combine_bwd")
     return dx_emb
@@ -354,6 +360,21 @@ def silu_embed_bwd(tables: torch.Tensor, t: torch.Tensor, dse: torch.Tensor, dta
     check(_lib.load().pfpp_silu_embed_bwd(_ptr(tables), _ptr(t), _ptr(dse), _ptr(dtables), n_tab, n_emb, t.numel(), Cc,
                                           _stream()), "pfpp_silu_embed_bwd")
     return dtables
+
+
+def mse_loss_masked(pred: torch.Tensor, target: torch.Tensor, valid: torch.Tensor, ref_u8: torch.Tensor, grad_out: float = 1.0,
+                    amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mse_loss over the rows with valid != 0 and ref == 0, the selection never materialised (pfpp_mse_loss_masked); amax [1]
+    receives max |dpred|"""
+    _chk(pred, _f32, "pred"); _chk(target, _f32, "target"); _chk(valid, _f32, "valid"); _chk(ref_u8, torch.uint8, "ref")
+    n, width = pred.shape
+    if valid.numel() != n or ref_u8.numel() != n:
+        raise ValueError("mse_loss_masked: valid / ref must have one entry per row")
+    loss = torch.empty((1,), dtype=_f32, device=pred.device)
+    dpred = torch.empty_like(pred)
+    check(_lib.load().pfpp_mse_loss_masked(_ptr(pred), _ptr(target), _ptr(valid), _ptr(ref_u8), _ptr(loss), _ptr(dpred), _ptr(amax), n,
+                                           width, grad_out, _stream()), "pfpp_mse_loss_masked")
+    return loss, dpred
 
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor, sel_u8: torch.Tensor, grad_out: float = 1.0,
@@ -602,11 +623,14 @@ def heads_fwd(pooled: torch.Tensor, trans, rot, out: torch.Tensor, slot: Optiona
     return saved if save else None
 
 
-def heads_bwd(dout: torch.Tensor, trans, rot, saved, g_trans, g_rot, g_scale: float, L: int, want_dx: bool = True):
-    """backward of heads_fwd from dout [R, 7]: -> (da0 [2, R, C], da1 [2, R, C/2], dx [R * L, C] or None); dW4 / db4 / db2 / db0 of
-    both heads are accumulated into g_trans / g_rot (HeadGrads), the four wide weight gradients are the caller's (da0, da1 are
-    their dY operands)"""
+def heads_bwd(dout: torch.Tensor, trans, rot, saved, g_trans, g_rot, g_scale: float, L: int, want_dx: bool = True,
+              slot: Optional[torch.Tensor] = None):
+    """backward of heads_fwd from dout [R, 7] (or, with slot, from the rows slot[r] of dout [n_slots, 7]): -> (da0 [2, R, C],
+    da1 [2, R, C/2], dx [R * L, C] or None); dW4 / db4 / db2 / db0 of both heads are accumulated into g_trans / g_rot (HeadGrads),
+    the four wide weight gradients are the caller's (da0, da1 are their dY operands)"""
     _chk(dout, _f32, "dout")
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
     a0, v0, a1, v1 = saved
     _, R, Cc = a0.shape
     dev = dout.device
@@ -614,7 +638,7 @@ def heads_bwd(dout: torch.Tensor, trans, rot, saved, g_trans, g_rot, g_scale: fl
     da1 = torch.empty((2, R, Cc // 2), dtype=_f32, device=dev)
     dp = torch.empty((2, R, Cc), dtype=_f32, device=dev)
     dx = torch.empty((R * L, Cc), dtype=_f32, device=dev) if want_dx else None
-    check(_lib.load().pfpp_heads_bwd(_ptr(dout), C.byref(trans), C.byref(rot), R, Cc, _ptr(a0), _ptr(v0), _ptr(a1), _ptr(v1), _ptr(da0),
+    check(_lib.load().pfpp_heads_bwd(_ptr(dout), _ptr(slot), C.byref(trans), C.byref(rot), R, Cc, _ptr(a0), _ptr(v0), _ptr(a1), _ptr(v1), _ptr(da0),
                                      _ptr(da1), _ptr(dp), C.byref(g_trans), C.byref(g_rot), g_scale, _ptr(dx), L, _stream()),
           "pfpp_heads_bwd")
     return da0, da1, (dx if want_dx else dp)

@@ -23,12 +23,14 @@ class _MaskedMSE(torch.autograd.Function):
     """mean over the selected rows of (pred - gt)^2 with its gradient from the same kernel (pfpp_hip.train_ops.mse_loss)"""
 
     @staticmethod
-    def forward(ctx, pred, gt, sel):
+    def forward(ctx, pred, gt, valids, ref):
         from pfpp_hip import train_ops as T
+        from pfpp_hip.train import _f32c, _u8
 
-        n = sel.numel()
-        loss, dpred = T.mse_loss(pred.detach().reshape(n, -1).contiguous(), gt.reshape(n, -1).contiguous(),
-                                 sel.reshape(n).to(torch.uint8).contiguous())
+        n = valids.numel()
+        # valid & ~reference is evaluated inside the kernel (pfpp_mse_loss_masked): no mask tensors, no extra launches
+        loss, dpred = T.mse_loss_masked(pred.detach().reshape(n, -1).contiguous(), _f32c(gt).reshape(n, -1), _f32c(valids).reshape(n),
+                                        _u8(ref).reshape(n))
         ctx.save_for_backward(dpred)
         ctx.shape = pred.shape
         return loss.reshape(())
@@ -36,7 +38,7 @@ class _MaskedMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (dpred,) = ctx.saved_tensors
-        return (dpred * grad_out).view(ctx.shape), None, None
+        return (dpred * grad_out).view(ctx.shape), None, None, None
 
 
 class Denoiser(LightningModule):
@@ -106,12 +108,12 @@ class Denoiser(LightningModule):
     def _loss(self, data_dict, output_dict):
         # F.mse_loss(pred[valids & ~ref], gt[valids & ~ref]) (denoiser.py:118-126) written as a masked mean: boolean-mask
         # indexing reads the selection size back to the host, which would stall the enqueue of every iteration
-        sel = data_dict["part_valids"].bool() & ~data_dict["ref_part"].bool()
         pred, gt = output_dict["pred_noise"], output_dict["gt_noise"]
         if pred.is_cuda and pred.dtype == torch.float32 and pred.requires_grad and gt.dtype == torch.float32:
             # training: the loss and d loss / d pred in ONE launch (pfpp_mse_loss, what the training engine uses) instead of ten
             # dependent elementwise launches forward and ten backward at the turn of every iteration
-            return {"mse_loss": _MaskedMSE.apply(pred, gt, sel)}
+            return {"mse_loss": _MaskedMSE.apply(pred, gt, data_dict["part_valids"], data_dict["ref_part"])}
+        sel = data_dict["part_valids"].bool() & ~data_dict["ref_part"].bool()
         d = (pred - gt) * sel.unsqueeze(-1)
         return {"mse_loss": (d * d).sum() / (sel.sum() * d.shape[-1])}
 
