@@ -260,6 +260,18 @@ class TrainContext:
 
     def __init__(self):
         self.t: Dict[str, object] = {}
+        self._release = None          # hands the forward arena back to the engine's pool (end of the backward, or when dropped)
+
+    def release(self) -> None:
+        r, self._release = self._release, None
+        if r is not None:
+            r()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:             # interpreter shutdown
+            pass
 
 
 _DIAG_HOST_DELAY_US = float(os.environ.get("PFPP_DIAG_HOST_DELAY_US", "0"))
@@ -326,6 +338,7 @@ class DenoiserTrainEngine:
         self._heads_fused = os.environ.get("PFPP_HEADS_FUSED", "1") == "1" and ops.GEMM_MODE == "f16x3"
         self._heads_static = None
         self._cseq_static = None
+        self._arena_pool: Dict[tuple, list] = {}
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
         self._early: List[Tuple[int, int]] = []       # [a, b) ranges of the flat buffer the armed backward has already updated
@@ -386,6 +399,7 @@ class DenoiserTrainEngine:
         layers = []
         if self._planes and self._use_cseq(fuse):
             h = self._forward_layers_c(h, w, s, mods, p_tok, p_lay, seed, Fv, L, H, att_scale)
+            ctx._release = lambda ka=s.pop("_fwd_arena"): self._give_arena(*ka)
         elif self._planes:
             h = self._forward_layers_planes(h, w, s, mods, layers, p_tok, p_lay, seed, fuse, Fv, L, H, dh, att_scale)
         else:
@@ -516,6 +530,21 @@ class DenoiserTrainEngine:
         return h
 
     # ------------------------------------------------------------------------------------------ blocks sequenced from C
+    def _take_arena(self, kind: str, nbytes: int, dev) -> torch.Tensor:
+        """a persistent byte arena of the C-sequenced path.  Reuse needs no event: an arena goes back to the pool at the end of the
+        backward that read it — after the main stream was made to wait for the weight-gradient stream (_all_done) — and its next user
+        writes it from the same main stream, i.e. behind all of that in stream order.  Keyed by (kind, stream, size): a forward on
+        another stream, or a second forward before the first one's backward, simply gets another arena."""
+        key = (kind, ops.raw_stream_id(dev.index), nbytes)
+        free = self._arena_pool.setdefault(key, [])
+        buf = free.pop() if free else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return key, buf
+
+    def _give_arena(self, key, buf) -> None:
+        free = self._arena_pool.setdefault(key, [])
+        if len(free) < 3:
+            free.append(buf)
+
     def _use_cseq(self, fuse: bool) -> bool:
         return self._cseq and fuse and ops.GEMM_TRACE is None and not ops.SINGLE_PASS
 
@@ -565,9 +594,8 @@ class DenoiserTrainEngine:
         dev = h.device
         inner = int(args.inner)
         layer_bytes = int(lib.pfpp_tlayers_fwd_bytes(M, C, H, inner))
-        arena = torch.empty(self.num_layers * layer_bytes, dtype=torch.uint8, device=dev)
-        if self._side is not None:
-            arena.record_stream(self._side)          # the weight-gradient GEMMs of the backward read the saved planes there
+        key, arena = self._take_arena("fwd", self.num_layers * layer_bytes, dev)
+        s["_fwd_arena"] = (key, arena)
         main_h = ops.raw_stream_id(dev.index)
         args.M, args.L, args.Fv, args.B = M, L, Fv, mods.shape[1]
         args.h_in, args.mods = h.data_ptr(), mods.data_ptr()
@@ -600,12 +628,12 @@ class DenoiserTrainEngine:
         main_h = ops.raw_stream_id(dev.index)
         side_h = self._side.cuda_stream if self._side is not None else None
         bwd_bytes = int(lib.pfpp_tlayers_bwd_bytes(M, C, H, inner))
-        tmp = torch.empty(bwd_bytes, dtype=torch.uint8, device=dev)
+        tmp_key, tmp = self._take_arena("bwd", bwd_bytes, dev)
+        s["_bwd_tmp"] = (tmp_key, tmp)
         dhp = P.split(dh_, G)
         p_tok = s["p_tok"]
         dtok = torch.empty_like(dh_) if p_tok > 0.0 else dh_
         if self._side is not None:
-            tmp.record_stream(self._side)
             dhp.record_stream(self._side)
         args.M, args.L, args.Fv, args.B = M, L, Fv, cs["mods"].shape[1]
         args.h_in, args.mods = cs["tokens"].data_ptr(), cs["mods"].data_ptr()
@@ -787,6 +815,10 @@ class DenoiserTrainEngine:
         else:
             T.silu_embed_bwd(w["ada.tables"], s["t64"], dse, g["ada.tables"])
         self._all_done()
+        # the main stream now waits for every reader of this step's arenas: hand them back for the next step (stream order protects them)
+        if "_bwd_tmp" in s:
+            self._give_arena(*s.pop("_bwd_tmp"))
+        ctx.release()
 
     def _head_structs(self, w, g):
         """(trans, rot, g_trans, g_rot) ctypes structs over the flat buffers (built once: the buffers never move)"""
