@@ -839,6 +839,32 @@ int pfpp_tlayers_fwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t la
 /* layers layer_hi-1 ... layer_lo; side = stream of the weight-gradient GEMMs (NULL: the main stream) */
 int pfpp_tlayers_bwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t layer_hi, pfpp_stream_t stream, pfpp_stream_t side);
 
+/* The same blocks in EVAL mode for a compacted fragment list (the sampler / auto_aggl step, denoiser.py:172-185 ->
+ * DenoiserTransformer.forward, denoiser_transformer.py:187-196): h [M, C] fp32 is updated in place through n_layers blocks; the
+ * launches are those of pfpp_layernorm_grouped_split / pfpp_layernorm_split, pfpp_gemm (packed weights: planes of scale * W, the
+ * GEGLU pair interleaved 32 value / 32 gate rows, gate applied in the epilogue), pfpp_attn_blockdiag_split and pfpp_attn_dense_split,
+ * enqueued from one call.  norm / att [M, C] and u [M, inner] are scratch planes, qkv [M, 3C] scratch fp32 (caller-owned);
+ * split_ws / split_cnt: the split-K workspace of pfpp_gemm (see pfpp_gemm_args).                                              */
+typedef struct pfpp_pw { const float* f32; const void* hi; const void* lo; float scale; int64_t ldw; } pfpp_pw;
+typedef struct pfpp_elayer_params {
+  pfpp_pw qkv1, o1, qkv2, o2, ff1, ff2;            /* [3C,C], [C,C], [3C,C], [C,C], [2 inner (interleaved), C], [C, inner] */
+  const float *bo1, *bo2, *g3, *b3, *bff1, *bff2;
+} pfpp_elayer_params;
+typedef struct pfpp_tlayers_eval_args {
+  int32_t n_layers;
+  const pfpp_elayer_params* layers;
+  int64_t M, C, H, L, inner, Fv, B;
+  float* h;
+  const float* mods;                               /* [2 n_layers, B, 2C] */
+  const int32_t* frag_b; const int32_t *seq_off, *seq_len;
+  int64_t n_seq, max_len;
+  float att_scale;
+  int32_t single_pass;                             /* 1: PFPP_GEMM_F16 on the GEMMs (perf mode) */
+  pfpp_planes norm, att, u; float* qkv;
+  float* split_ws; int64_t split_ws_bytes; int32_t* split_cnt; int64_t split_cnt_len;
+} pfpp_tlayers_eval_args;
+int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
+
 /* ---- a15: the two output heads as one launch each way -------------------------------------------------------
  * DenoiserTransformer._out (denoiser_transformer.py:138-147) after the mean over the L latent points: pooled [R, C] ->
  * mlp_out_trans / mlp_out_rot (Linear(C,C) - SiLU - Linear(C,C/2) - SiLU - Linear(C/2, 3 | 4), :58-61) -> out[row, 0:3] |

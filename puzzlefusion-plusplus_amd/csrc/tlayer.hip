@@ -229,6 +229,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   for (int k = SLOT_DY0; k <= SLOT_DH1; ++k) slot_buf[k] = take(M * C * 4);
   PFPP_REQUIRE(a->bwd_bytes >= o, "bwd_bytes smaller than pfpp_tlayers_bwd_bytes()");
 
+  int cur_layer = 0;
   // planes of scale G in slot k, safe to write on the main stream
   auto fresh = [&](int k, int64_t elems, pfpp_planes* out) -> int {
     if (side) TL_CALL(slot_acquire(g_slots[k], slot_buf[k], main_s));
@@ -239,6 +240,8 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   auto dw = [&](const pfpp_planes& dyp, int k, const pfpp_planes& xp, int64_t n_out, int64_t n_in, float* gw, float* gb) -> int {
     if (side) TL_CALL(order_after(side_s, main_s));
     static const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;      // lab: 0 = the library's choice
+    static const int lab_skip = getenv("PFPP_LAB_SKIP_DW_LAYERS") ? atoi(getenv("PFPP_LAB_SKIP_DW_LAYERS")) : 0;   // lab (timing only, WRONG gradients): no dW for the last k layers
+    if (lab_skip > 0 && cur_layer >= a->n_layers - lab_skip) return PFPP_OK;
     TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t, dw_splits));
     if (side && k >= 0) TL_CALL(slot_read_on(g_slots[k], side_s));
     return PFPP_OK;
@@ -252,6 +255,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   for (int k = SLOT_DH0; k <= SLOT_DH1; ++k)
     if (a->dhp.hi == slot_buf[k]) dhp_slot = k;      // a continued range: the previous call's dhp_out
   for (int i = layer_hi - 1; i >= layer_lo; --i) {
+    cur_layer = i;
     const pfpp_tlayer_params& w = a->layers[i];
     const pfpp_tlayer_grads& g = a->grads[i];
     char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
@@ -331,4 +335,57 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
 extern "C" int64_t pfpp_tlayers_bwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner) {
   auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
   return up(M * inner * 4) + 2 * up(M * C * 4) + up(M * H * 4) + 2 * up(M * 2 * inner * 4) + 4 * up(M * 3 * C * 4) + 6 * up(M * C * 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// eval mode (the sampler / auto_aggl step on a compacted fragment list): the same blocks as pfpp_hip.denoiser.
+// denoiser_forward_compact issues them — LayerNorm -> qkv -> per-fragment attention -> out-projection (+ residual, in place) ->
+// LayerNorm -> qkv -> ragged dense attention -> out-projection -> LayerNorm -> GEGLU GEMM (packed weights, gate in the epilogue)
+// -> second feed-forward linear (+ residual) — enqueued from one call.  One puzzle in flight is ~100 launches of 5-17 us per DDPM
+// step: issued from Python the step was host-bound (1.41 ms enqueue against 1.18 ms of GPU time, tools/diag/graph_time.py).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+int gemm_ev(const pfpp_planes& A, const pfpp_pw& W, float* Cout, const pfpp_planes* Cp, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
+            const float* bias, const float* residual, int act, int precision, const pfpp_tlayers_eval_args* a, pfpp_stream_t st) {
+  pfpp_gemm_args g = {};
+  g.a_hi = A.hi; g.a_lo = A.lo;
+  g.W = W.f32; g.w_hi = W.hi; g.w_lo = W.lo;
+  g.C = Cp ? nullptr : Cout;
+  g.c_hi = Cp ? Cp->hi : nullptr; g.c_lo = Cp ? Cp->lo : nullptr;
+  g.bias = bias; g.residual = residual;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldw = W.ldw; g.ldc = ldc; g.ldr = residual ? ldc : 0;
+  g.act = act; g.batch = 1; g.zdiv = 1; g.precision = precision;
+  g.alpha = 1.0f / W.scale;
+  g.split_ws = a->split_ws; g.split_ws_bytes = a->split_ws_bytes; g.split_cnt = a->split_cnt; g.split_cnt_len = a->split_cnt_len;
+  return pfpp_gemm(&g, st);
+}
+}  // namespace
+
+extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t stream) {
+  PFPP_REQUIRE(a && a->layers && a->h && a->mods && a->frag_b && a->seq_off && a->seq_len && a->qkv && a->norm.hi && a->att.hi && a->u.hi,
+               "null pointer");
+  const int64_t M = a->M, C = a->C, H = a->H, L = a->L, inner = a->inner, dh = C / H;
+  PFPP_REQUIRE(M > 0 && C > 0 && H > 0 && C % H == 0 && inner > 0 && L > 0 && M == a->Fv * L && a->n_layers >= 0, "bad sizes");
+  const float eps = 1e-5f;
+  const int64_t ld_mod = 2 * C;
+  const int prec = a->single_pass ? PFPP_GEMM_F16 : PFPP_GEMM_F16X3;
+  for (int i = 0; i < a->n_layers; ++i) {
+    const pfpp_elayer_params& w = a->layers[i];
+    const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
+    const float* mod2 = a->mods + (int64_t)(2 * i + 1) * a->B * ld_mod;
+    TL_CALL(pfpp_layernorm_grouped_split(a->h, a->norm.hi, a->norm.lo, mod1, ld_mod, a->frag_b, L, M, C, eps, stream));
+    TL_CALL(gemm_ev(a->norm, w.qkv1, a->qkv, nullptr, M, 3 * C, C, C, 3 * C, nullptr, nullptr, PFPP_ACT_NONE, prec, a, stream));
+    TL_CALL(pfpp_attn_blockdiag_split(a->qkv, a->att.hi, a->att.lo, a->Fv, L, H, dh, a->att_scale, stream));
+    TL_CALL(gemm_ev(a->att, w.o1, a->h, nullptr, M, C, C, C, C, w.bo1, a->h, PFPP_ACT_NONE, prec, a, stream));
+    TL_CALL(pfpp_layernorm_grouped_split(a->h, a->norm.hi, a->norm.lo, mod2, ld_mod, a->frag_b, L, M, C, eps, stream));
+    TL_CALL(gemm_ev(a->norm, w.qkv2, a->qkv, nullptr, M, 3 * C, C, C, 3 * C, nullptr, nullptr, PFPP_ACT_NONE, prec, a, stream));
+    TL_CALL(pfpp_attn_dense_split(a->qkv, a->att.hi, a->att.lo, a->seq_off, a->seq_len, nullptr, 0, a->n_seq, a->max_len, H, dh, a->att_scale,
+                                  stream));
+    TL_CALL(gemm_ev(a->att, w.o2, a->h, nullptr, M, C, C, C, C, w.bo2, a->h, PFPP_ACT_NONE, prec, a, stream));
+    TL_CALL(pfpp_layernorm_split(a->h, a->norm.hi, a->norm.lo, nullptr, 0, w.g3, w.b3, M, C, 1, eps, stream));
+    TL_CALL(gemm_ev(a->norm, w.ff1, nullptr, &a->u, M, 2 * inner, C, C, inner, w.bff1, nullptr, PFPP_ACT_GEGLU, prec, a, stream));
+    TL_CALL(gemm_ev(a->u, w.ff2, a->h, nullptr, M, C, inner, inner, C, w.bff2, a->h, PFPP_ACT_NONE, prec, a, stream));
+  }
+  return PFPP_OK;
 }

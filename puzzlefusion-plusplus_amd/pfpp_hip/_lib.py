@@ -98,6 +98,31 @@ class GemmPlanesArgs(C.Structure):
 _pl = C.POINTER(PlanesC)
 
 
+class PwC(C.Structure):
+    """mirror of struct pfpp_pw (include/pfpp.h)"""
+
+    _fields_ = [("f32", _p), ("hi", _p), ("lo", _p), ("scale", _f32), ("ldw", _i64)]
+
+
+class ElayerParams(C.Structure):
+    """mirror of struct pfpp_elayer_params (include/pfpp.h)"""
+
+    _fields_ = ([(n, PwC) for n in ("qkv1", "o1", "qkv2", "o2", "ff1", "ff2")] + [(n, _p) for n in ("bo1", "bo2", "g3", "b3", "bff1", "bff2")])
+
+
+class TlayersEvalArgs(C.Structure):
+    """mirror of struct pfpp_tlayers_eval_args (include/pfpp.h)"""
+
+    _fields_ = [
+        ("n_layers", _i32), ("layers", C.POINTER(ElayerParams)),
+        ("M", _i64), ("C", _i64), ("H", _i64), ("L", _i64), ("inner", _i64), ("Fv", _i64), ("B", _i64),
+        ("h", _p), ("mods", _p), ("frag_b", _p), ("seq_off", _p), ("seq_len", _p),
+        ("n_seq", _i64), ("max_len", _i64), ("att_scale", _f32), ("single_pass", _i32),
+        ("norm", PlanesC), ("att", PlanesC), ("u", PlanesC), ("qkv", _p),
+        ("split_ws", _p), ("split_ws_bytes", _i64), ("split_cnt", _p), ("split_cnt_len", _i64),
+    ]
+
+
 class HeadParams(C.Structure):
     """mirror of struct pfpp_head_params (include/pfpp.h)"""
 
@@ -150,6 +175,7 @@ class TlayersArgs(C.Structure):
 
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
+    "pfpp_tlayers_eval": [C.POINTER(TlayersEvalArgs), _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "pfpp_heads_bwd": [_p, _p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
                        C.POINTER(HeadGrads), C.POINTER(HeadGrads), _f32, _p, _i64, _p],

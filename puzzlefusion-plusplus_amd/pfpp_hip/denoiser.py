@@ -73,6 +73,55 @@ def _fused_heads(pk, pooled, out, slot32=None) -> bool:
     return True
 
 
+def _eval_layers_c(pk, h, mods, lay, L: int, num_layers: int, num_heads: int, att_scale: float, inner: int) -> bool:
+    """the transformer blocks of the compact eval forward enqueued from C (pfpp_tlayers_eval, csrc/tlayer.hip): h is updated in place.
+    False when the mode is not the plane path's (exact fp32, fp32 hand-over, GEMM tracing, PFPP_EVAL_CSEQ=0): the caller then issues
+    the launches itself."""
+    import ctypes as C_
+    import os
+
+    from . import _lib
+    from ._lib import ElayerParams, PlanesC, PwC, TlayersEvalArgs
+
+    if not ops.split_mode() or ops.GEMM_TRACE is not None or os.environ.get("PFPP_EVAL_CSEQ", "1") != "1":
+        return False
+    st = pk.get("_cseq_eval")
+    if st is None:
+        layers = (ElayerParams * num_layers)()
+
+        def pw(w):
+            return PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1])
+
+        for i in range(num_layers):
+            for name, key in (("qkv1", f"{i}.self_attn.wqkv"), ("o1", f"{i}.self_attn.wo"), ("qkv2", f"{i}.global_attn.wqkv"),
+                              ("o2", f"{i}.global_attn.wo"), ("ff1", f"{i}.ff.w1"), ("ff2", f"{i}.ff.w2")):
+                setattr(layers[i], name, pw(pk[key]))
+            for name, key in (("bo1", f"{i}.self_attn.bo"), ("bo2", f"{i}.global_attn.bo"), ("g3", f"{i}.norm3.g"), ("b3", f"{i}.norm3.b"),
+                              ("bff1", f"{i}.ff.b1"), ("bff2", f"{i}.ff.b2")):
+                setattr(layers[i], name, pk[key].data_ptr())
+        args = TlayersEvalArgs()
+        args.n_layers, args.layers = num_layers, layers
+        st = pk["_cseq_eval"] = (args, layers)
+    args = st[0]
+    M, C = h.shape
+    dev = h.device
+    norm, att, u = ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, inner, dev)
+    qkv = torch.empty((M, 3 * C), dtype=torch.float32, device=dev)
+    ops._sync_attention_mode()
+    args.M, args.C, args.H, args.L, args.inner, args.Fv, args.B = M, C, num_heads, L, inner, lay.Fv, mods.shape[1]
+    args.h, args.mods = h.data_ptr(), mods.data_ptr()
+    args.frag_b, args.seq_off, args.seq_len = lay.frag_b.data_ptr(), lay.seq_off.data_ptr(), lay.seq_len.data_ptr()
+    args.n_seq, args.max_len, args.att_scale = lay.seq_off.numel(), lay.max_len, att_scale
+    args.single_pass = int(ops.SINGLE_PASS)
+    args.norm, args.att, args.u = (PlanesC(t.hi.data_ptr(), t.lo.data_ptr(), 1.0) for t in (norm, att, u))
+    args.qkv = qkv.data_ptr()
+    ws = ops._split_workspace(dev)
+    args.split_ws, args.split_ws_bytes = ws[0].data_ptr(), ws[0].numel() * 4
+    args.split_cnt, args.split_cnt_len = ws[1].data_ptr(), ws[1].numel()
+    _lib.check(_lib.load().pfpp_tlayers_eval(C_.byref(args), ops._stream()), "pfpp_tlayers_eval")
+    return True
+
+
 def dense_attention(qkv: torch.Tensor, B: int, T: int, H: int, dh: int, key_valid_u8: torch.Tensor,
                     scale: float, out: Optional[torch.Tensor] = None, seq=None) -> torch.Tensor:
     """softmax(Q K^T * scale + key mask) V per (sequence, head) from a packed [rows, 3*H*dh] projection —
@@ -214,21 +263,27 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     if Fv == 0:
         return out.view(B, P, 7)
     M = Fv * L
-    sf, pf = ops.token_features(latent.reshape(n_slots, L, -1)[slot].contiguous(), xyz.reshape(n_slots, L, 3)[slot].contiguous(),
-                                scale.reshape(n_slots)[slot].contiguous(), x.reshape(n_slots, 7)[slot].contiguous())
+    # the valid-fragment gather of the inputs happens inside the kernels (slot32): no gathered copies
+    f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+    sf, pf = ops.token_features(f32(latent).reshape(n_slots, L, -1), f32(xyz).reshape(n_slots, L, 3), f32(scale).reshape(n_slots),
+                                f32(x).reshape(n_slots, 7), slot=lay.slot32)
     shape_emb = ops.linear(sf, pk["shape.w"], pk["shape.b"])
     x_emb = ops.linear(pf, pk["param.w"], pk["param.b"])
-    ref_u8 = ref_part.reshape(n_slots)[slot].to(torch.uint8).contiguous()
-    h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p, L)
+    rp = ref_part.reshape(n_slots)
+    ref_u8 = rp.contiguous().view(torch.uint8) if rp.dtype == torch.bool else (rp if rp.dtype == torch.uint8 else (rp != 0).to(torch.uint8)).contiguous()
+    h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p, L, slot=lay.slot32)
     n_ada = 2 * num_layers
     mods = ada_mods(pk, timesteps, n_ada, C)
     att_scale = 1.0 / math.sqrt(dh)
     inner = pk["0.ff.w2"].K
-    if ops.split_mode():      # GEMM inputs produced by our own kernels travel as pre-split fp16 planes (see ops.split_mode)
+    in_c = _eval_layers_c(pk, h, mods, lay, L, num_layers, num_heads, att_scale, inner)
+    if in_c:
+        norm = att = u_buf = None
+    elif ops.split_mode():      # GEMM inputs produced by our own kernels travel as pre-split fp16 planes (see ops.split_mode)
         norm, att, u_buf = (ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, inner, dev))
     else:
         norm, att, u_buf = torch.empty_like(h), torch.empty_like(h), None
-    for i in range(num_layers):
+    for i in range(0 if in_c else num_layers):
         ops.layernorm_grouped(h, mods[2 * i], frag_b, L, out=norm)
         qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
         ops.attn_blockdiag(qkv, Fv, L, num_heads, dh, att_scale, out=att)

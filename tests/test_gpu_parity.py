@@ -1284,6 +1284,47 @@ def test_small_puzzle_forward_fused_heads_equal_layerwise(weights_sd, dev, parts
     assert (got_all - want_all).abs().max() <= 1e-5 * max(1.0, float(want_all.abs().max()))
 
 
+@pytest.mark.parametrize("parts", [(5,), (20, 3, 11), (2,) * 16])
+def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, monkeypatch):
+    """pfpp_tlayers_eval (csrc/tlayer.hip): the compact eval forward's six blocks enqueued from one C call are the same launches with
+    the same arguments as the Python sequence (PFPP_EVAL_CSEQ=0) — predicted noise bit-identical, for one puzzle in flight and for
+    ragged batches, in the parity arithmetic and in the single-pass fp16 mode"""
+    from pfpp_hip import config, ops
+    from puzzlefusion_plusplus.denoiser.model.modules.denoiser_transformer import DenoiserTransformer
+
+    m = DenoiserTransformer(config.denoiser_config())
+    m.load_state_dict(weights_sd("denoiser"), strict=True)
+    m = m.to(dev).eval()
+    m.compact_padded = True
+    B = len(parts)
+    gen = torch.Generator().manual_seed(sum(parts) + 31 * B)
+    valid = torch.zeros(B, 20)
+    for b, n in enumerate(parts):
+        valid[b, :n] = 1
+    x = torch.randn(B, 20, 7, generator=gen).to(dev)
+    latent = torch.randn(B, 20, 25, 64, generator=gen).to(dev) * valid[:, :, None, None].to(dev)
+    xyz = (torch.rand(B, 20, 25, 3, generator=gen) * 2 - 1).to(dev) * valid[:, :, None, None].to(dev)
+    scale = (torch.rand(B, 20, 1, generator=gen) + 0.5).to(dev)
+    ref = torch.zeros(B, 20, dtype=torch.bool)
+    ref[:, 0] = True
+    ts = torch.randint(0, 1000, (B,), generator=gen).to(dev)
+    valid_d, ref_d = valid.to(dev), ref.to(dev)
+    prev = ops.SINGLE_PASS
+    try:
+        for sp in (False, True):
+            ops.SINGLE_PASS = sp
+            outs = []
+            for flag in ("0", "1"):
+                monkeypatch.setenv("PFPP_EVAL_CSEQ", flag)
+                with torch.no_grad():
+                    outs.append(m(x, ts, latent, xyz, valid_d, scale, ref_d))
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0]).all() and float(outs[0][valid_d.bool()].abs().max()) > 1e-3
+            assert torch.equal(outs[0], outs[1]), sp
+    finally:
+        ops.SINGLE_PASS = prev
+
+
 def test_auto_aggl_batched_equals_single(weights_sd, dev):
     """throughput mode: several puzzles through the loop at once give each puzzle the result of its own test_step"""
     from pfpp_hip import config, synthetic
