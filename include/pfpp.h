@@ -862,8 +862,20 @@ typedef struct pfpp_tlayers_eval_args {
   int32_t single_pass;                             /* 1: PFPP_GEMM_F16 on the GEMMs (perf mode) */
   pfpp_planes norm, att, u; float* qkv;
   float* split_ws; int64_t split_ws_bytes; int32_t* split_cnt; int64_t split_cnt_len;
+  int64_t lnlin_max_rows;                          /* M <= this: LayerNorm + the following linear as one launch (pfpp_layernorm_linear_small) */
 } pfpp_tlayers_eval_args;
 int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
+/* LayerNorm fused into the linear layer that follows it, for small token counts (one puzzle in flight): y = LN(x) . W^T (+ bias), the
+ * normalised rows never reach HBM (MyAdaLayerNorm / nn.LayerNorm + to_q|k|v resp. the GEGLU projection, attention.py:21-25,77-90, eval
+ * mode).  mod [B, 2C] (scale | shift) with group_batch / group_rows as in pfpp_layernorm_grouped, or gamma / beta.  Plain form: out
+ * [M, ldc] fp32.  GEGLU form (u_planes set; w = packed 32 value | 32 gate rows, bias packed likewise): u = (v + b_v) * gelu(g + b_g)
+ * as planes [M, ldu], N = 2 * inner.  C = 512, N % 64 == 0.  LayerNorm arithmetic = pfpp_layernorm*; the contraction is summed in a
+ * different (fixed) order than pfpp_gemm's: equal to the two-launch path to fp32 rounding.  pfpp_tlayers_eval uses it for M <= 512
+ * (lnlin_max_rows; 0 = never).                                                                                                  */
+int pfpp_layernorm_linear_small(const float* x, const float* mod, int64_t ld_mod, const float* gamma, const float* beta,
+                                const int32_t* group_batch, int64_t group_rows, const pfpp_pw* w, const float* bias, float* out,
+                                int64_t ldc, const pfpp_planes* u_planes, int64_t ldu, int64_t M, int64_t N, int64_t C, float eps,
+                                pfpp_stream_t stream);
 
 /* ---- a15: the two output heads as one launch each way -------------------------------------------------------
  * DenoiserTransformer._out (denoiser_transformer.py:138-147) after the mean over the L latent points: pooled [R, C] ->

@@ -120,6 +120,7 @@ class TlayersEvalArgs(C.Structure):
         ("n_seq", _i64), ("max_len", _i64), ("att_scale", _f32), ("single_pass", _i32),
         ("norm", PlanesC), ("att", PlanesC), ("u", PlanesC), ("qkv", _p),
         ("split_ws", _p), ("split_ws_bytes", _i64), ("split_cnt", _p), ("split_cnt_len", _i64),
+        ("lnlin_max_rows", _i64),
     ]
 
 
@@ -176,6 +177,7 @@ class TlayersArgs(C.Structure):
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
     "pfpp_tlayers_eval": [C.POINTER(TlayersEvalArgs), _p],
+    "pfpp_layernorm_linear_small": [_p, _p, _i64, _p, _p, _p, _i64, C.POINTER(PwC), _p, _p, _i64, _pl, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "pfpp_heads_bwd": [_p, _p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
                        C.POINTER(HeadGrads), C.POINTER(HeadGrads), _f32, _p, _i64, _p],

@@ -31,6 +31,7 @@ SOURCES = {
     "sa_train.hip": ["-munsafe-fp-atomics"],
     "tlayer.hip": [],
     "heads.hip": ["-munsafe-fp-atomics"],
+    "lnlin_small.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],

@@ -842,6 +842,36 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
     return out
 
 
+def layernorm_linear_small(x: torch.Tensor, w, *, mod: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
+                           group_rows: int = 1, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                           bias: Optional[torch.Tensor] = None, geglu: bool = False, eps: float = 1e-5):
+    """LayerNorm(x) . w^T (+ bias) in one launch for few rows (pfpp_layernorm_linear_small): w = packing.PW [N, 512].
+    geglu: w / bias are the packed GEGLU pair -> SplitAct planes of u [M, N / 2]; else fp32 [M, N]"""
+    from ._lib import PlanesC, PwC
+
+    _chk(x, torch.float32, "x")
+    M, Cc = x.shape
+    N = w.N
+    pw = PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1])
+    for t_, nm in ((mod, "mod"), (gamma, "gamma"), (beta, "beta"), (bias, "bias")):
+        if t_ is not None:
+            _chk(t_, torch.float32, nm)
+    if group_batch is not None:
+        _chk(group_batch, torch.int32, "group_batch")
+    if geglu:
+        out = SplitAct.empty(M, N // 2, x.device)
+        up = PlanesC(out.hi.data_ptr(), out.lo.data_ptr(), 1.0)
+        check(_lib.load().pfpp_layernorm_linear_small(_ptr(x), _ptr(mod), 0 if mod is None else mod.stride(0), _ptr(gamma), _ptr(beta),
+                                                      _ptr(group_batch), group_rows, C.byref(pw), _ptr(bias), None, 0, C.byref(up), N // 2,
+                                                      M, N, Cc, eps, _stream()), "pfpp_layernorm_linear_small")
+        return out
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib.load().pfpp_layernorm_linear_small(_ptr(x), _ptr(mod), 0 if mod is None else mod.stride(0), _ptr(gamma), _ptr(beta),
+                                                  _ptr(group_batch), group_rows, C.byref(pw), _ptr(bias), _ptr(out), N, None, 0, M, N, Cc,
+                                                  eps, _stream()), "pfpp_layernorm_linear_small")
+    return out
+
+
 def attn_blockdiag(qkv: torch.Tensor, n_frag: int, L: int, H: int, dh: int, scale: float, out=None):
     _chk(qkv, torch.float32, "qkv")
     _sync_attention_mode()

@@ -1284,6 +1284,52 @@ def test_small_puzzle_forward_fused_heads_equal_layerwise(weights_sd, dev, parts
     assert (got_all - want_all).abs().max() <= 1e-5 * max(1.0, float(want_all.abs().max()))
 
 
+@pytest.mark.parametrize("M", [25, 125, 500, 333])
+def test_layernorm_linear_small_vs_float64(dev, M):
+    """csrc/lnlin_small.hip: LayerNorm (AdaLN with a per-fragment batch map, and affine) fused into the following linear for few rows —
+    the plain form against float64, and the GEGLU form (packed value | gate weights) against LayerNorm + the packed GEGLU GEMM it replaces"""
+    import math
+
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW, pack_geglu
+
+    g = torch.Generator().manual_seed(M)
+    C, L, B = 512, 25, 4
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3)
+    mod = torch.randn(B, 2 * C, generator=g) * 0.3
+    frag_b = torch.randint(0, B, ((M + L - 1) // L,), generator=g).to(torch.int32)
+    W = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    xd, modd, fbd = x.to(dev), mod.to(dev), frag_b.to(dev)
+    pw = PW(W.to(dev).contiguous())
+    got = ops.layernorm_linear_small(xd, pw, mod=modd, group_batch=fbd, group_rows=L)
+    b_of = frag_b.long()[torch.arange(M) // L]
+    xn = torch.nn.functional.layer_norm(x.double(), (C,)) * (1 + mod.double()[b_of, :C]) + mod.double()[b_of, C:]
+    We = ((pw.hi.double() + pw.lo.double()) / pw.scale).cpu()[:, :C]
+    want = xn @ We.t()
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 3e-6
+    # the two-launch path it replaces: same LayerNorm bits, another summation order
+    n = ops.SplitAct.empty(M, C, dev)
+    ops.layernorm_grouped(xd, modd, fbd, L, out=n)
+    two = ops.linear(n, pw)
+    assert float((got - two).abs().max() / two.abs().max()) < 2e-6
+    # GEGLU form
+    inner = 2048
+    W1 = torch.randn(2 * inner, C, generator=g) / math.sqrt(C)
+    b1 = torch.randn(2 * inner, generator=g) * 0.1
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1
+    w1p, b1p = pack_geglu(W1.to(dev), b1.to(dev))
+    pw1 = PW(w1p)
+    u = ops.layernorm_linear_small(xd, pw1, gamma=gamma.to(dev), beta=beta.to(dev), bias=b1p, geglu=True)
+    ops.layernorm(xd, gamma=gamma.to(dev), beta=beta.to(dev), out=n)
+    u2 = ops.SplitAct.empty(M, inner, dev)
+    ops.linear(n, pw1, b1p, act="geglu", out=u2)
+    assert u.hi.shape == (M, inner)
+    assert float((u.float() - u2.float()).abs().max() / u2.float().abs().max()) < 2e-6
+    z = torch.nn.functional.layer_norm(x.double(), (C,), gamma.double(), beta.double()) @ W1.double().t() + b1.double()
+    want_u = z[:, :inner] * torch.nn.functional.gelu(z[:, inner:])
+    assert float((u.float().double().cpu() - want_u).abs().max() / want_u.abs().max()) < 2e-5          # (weights rounded to 22 bits)
+
+
 @pytest.mark.parametrize("parts", [(5,), (20, 3, 11), (2,) * 16])
 def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, monkeypatch):
     """pfpp_tlayers_eval (csrc/tlayer.hip): the compact eval forward's six blocks enqueued from one C call are the same launches with
@@ -1314,13 +1360,21 @@ def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, 
         for sp in (False, True):
             ops.SINGLE_PASS = sp
             outs = []
+            monkeypatch.setenv("PFPP_EVAL_LNLIN_ROWS", "0")          # same launches as the Python sequence
             for flag in ("0", "1"):
                 monkeypatch.setenv("PFPP_EVAL_CSEQ", flag)
                 with torch.no_grad():
                     outs.append(m(x, ts, latent, xyz, valid_d, scale, ref_d))
+            # default: for <= 512 tokens the LayerNorms ride in the GEMMs that consume them (csrc/lnlin_small.hip): same LayerNorm
+            # bits, another summation order in the contraction -> equal to fp32 rounding, and deterministic
+            monkeypatch.setenv("PFPP_EVAL_LNLIN_ROWS", "512")
+            with torch.no_grad():
+                fused = [m(x, ts, latent, xyz, valid_d, scale, ref_d) for _ in range(2)]
             torch.cuda.synchronize()
             assert torch.isfinite(outs[0]).all() and float(outs[0][valid_d.bool()].abs().max()) > 1e-3
             assert torch.equal(outs[0], outs[1]), sp
+            assert torch.equal(fused[0], fused[1])
+            assert (fused[0] - outs[0]).abs().max() <= 1e-5 * max(1.0, float(outs[0].abs().max()))
     finally:
         ops.SINGLE_PASS = prev
 
