@@ -68,10 +68,14 @@ __device__ __forceinline__ void contract_rowmajor(const _Float16* sh, const _Flo
   const int NG = K / 64;                   // groups of 4 steps; a group = 8 half8 along a row
   half8 fh[2][4][NT], fl[2][4][NT];
   auto fetch = [&](int g, int slot) {
+    // one (tile, plane) after the other, its four pieces of a line back to back (alternating planes thrashed the L1)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { fh[slot][u][j] = bh[j][8 * g + u]; fl[slot][u][j] = bl[j][8 * g + u]; }
+      for (int u = 0; u < 4; ++u) fh[slot][u][j] = bh[j][8 * g + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fl[slot][u][j] = bl[j][8 * g + u];
+    }
   };
   fetch(0, 0);
   for (int g = 0; g < NG; g += 2) {

@@ -49,85 +49,84 @@ __global__ __launch_bounds__(64 * LNW) void lnlin_small_kernel(LnLinP p) {
   extern __shared__ __align__(16) char ll_smem[];
   _Float16* sh = reinterpret_cast<_Float16*>(ll_smem);
   _Float16* sl = sh + 32 * LKP;
-  float* part = reinterpret_cast<float*>(sl + 32 * LKP);       // [LNW][32][64] partial sums
+  _Float16* patches = sl + 32 * LKP;                            // LNW x [2 planes][32][128] halfs = 16 KB per wave
+  float* part = reinterpret_cast<float*>(patches);              // [LNW][32][64] partial sums (after the contraction: the patches are dead)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int r0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
 
-  // ---- weight fragments of this wave's contraction slice [128 wave, 128 wave + 128): two groups of 64, both column tiles
+  // ---- weights of this wave's contraction slice [128 wave, 128 wave + 128) for both column tiles.  Fetched COALESCED — one instruction
+  // = 4 weight rows x 256 contiguous bytes — into registers before the LayerNorm (their latency hides behind it), then passed through a
+  // wave-private LDS patch ([plane][32 rows][128 halfs], 16-byte chunks XOR-swizzled by the row) from which the MFMA operand fragments
+  // (lane = weight row, 8 contraction-consecutive halfs) are read.  Loading the fragments straight from global memory (every lane its own
+  // row: 32 lines per instruction, 16 bytes of each) ran at ~9 GB/s per workgroup: each 16-byte piece pulled its whole line from the L2.
   const int k0 = 128 * wave;
-  const half8 *bh[2], *bl[2];
+  const int srow = lane >> 4, schunk = lane & 15;          // staging: lane -> row 4 i + srow of the tile, chunk schunk (16 bytes)
+  half8 st[2][2][8];                                       // [tile][plane][instruction]
+  auto fetch_tile = [&](int j) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    bh[j] = reinterpret_cast<const half8*>(p.wh + (size_t)(n0 + 32 * j + l31) * p.ldw + k0 + 32 * lhi);
-    bl[j] = reinterpret_cast<const half8*>(p.wl + (size_t)(n0 + 32 * j + l31) * p.ldw + k0 + 32 * lhi);
-  }
-  half8 fh[2][4][2], fl[2][4][2];
-  auto fetch = [&](int g, int slot) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { fh[slot][u][j] = bh[j][8 * g + u]; fl[slot][u][j] = bl[j][8 * g + u]; }
+    for (int i = 0; i < 8; ++i) {
+      const size_t off = (size_t)(n0 + 32 * j + 4 * i + srow) * p.ldw + k0 + 8 * schunk;
+      st[j][0][i] = *reinterpret_cast<const half8*>(p.wh + off);
+      st[j][1][i] = *reinterpret_cast<const half8*>(p.wl + off);
+    }
   };
-  fetch(0, 0);
-  fetch(1, 1);
-  __builtin_amdgcn_sched_barrier(0);                   // both groups are requested before the LayerNorm starts
+  fetch_tile(0);
+  fetch_tile(1);
+  __builtin_amdgcn_sched_barrier(0);                   // all of it is requested before the LayerNorm starts
 
-  // ---- LayerNorm of rows r0 .. r0 + 31: wave w takes rows 8 w .. 8 w + 7, one row at a time across the wave (layernorm_kernel<2>)
+  // ---- LayerNorm of rows r0 .. r0 + 31: wave w takes rows 8 w .. 8 w + 7, one row at a time across the wave (layernorm_kernel<2>'s
+  // arithmetic).  All eight rows and their modulation rows are requested first: issued row by row, every row paid a memory round trip
+  // of its own (8 x ~1.5 us — the fused launch was then no faster than the two it replaces)
+  float4 v[8][2], m_a[8][2], m_b[8][2];
+#pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
-    const int lrow = 8 * wave + rr;
-    const int64_t row = r0 + lrow;
-    float4 v[2];
-    half4 hi[2], lo[2];
-    if (row < p.M) {
-      const float4* xr = reinterpret_cast<const float4*>(p.x + row * LC);
-      v[0] = xr[lane]; v[1] = xr[lane + 64];
-      const float* pa = p.gamma;
-      const float* pb = p.beta;
-      if (p.mod) {
-        const int64_t b = p.group_batch ? (int64_t)p.group_batch[row / p.group_rows] : 0;
-        pa = p.mod + b * p.ld_mod;
-        pb = pa + LC;
-      }
-      float4 m_a[2], m_b[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        m_a[k] = reinterpret_cast<const float4*>(pa)[lane + 64 * k];
-        m_b[k] = reinterpret_cast<const float4*>(pb)[lane + 64 * k];
-      }
-      float s = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-      const float mean = wave_sum(s) / (float)LC;
-      float q = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
-        q += (a * a + b * b) + (c * c + d * d);
-      }
-      const float var = wave_sum(q) / (float)LC;
-      const float rstd = 1.0f / sqrtf(var + p.eps);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float4 o;
-        o.x = (v[k].x - mean) * rstd; o.y = (v[k].y - mean) * rstd; o.z = (v[k].z - mean) * rstd; o.w = (v[k].w - mean) * rstd;
-        if (p.mod) {
-          o.x = o.x * (1.0f + m_a[k].x) + m_b[k].x; o.y = o.y * (1.0f + m_a[k].y) + m_b[k].y;
-          o.z = o.z * (1.0f + m_a[k].z) + m_b[k].z; o.w = o.w * (1.0f + m_a[k].w) + m_b[k].w;
-        } else {
-          o.x = o.x * m_a[k].x + m_b[k].x; o.y = o.y * m_a[k].y + m_b[k].y;
-          o.z = o.z * m_a[k].z + m_b[k].z; o.w = o.w * m_a[k].w + m_b[k].w;
-        }
-        PFPP_SPLIT_TO(o.x, hi[k][0], lo[k][0]); PFPP_SPLIT_TO(o.y, hi[k][1], lo[k][1]);
-        PFPP_SPLIT_TO(o.z, hi[k][2], lo[k][2]); PFPP_SPLIT_TO(o.w, hi[k][3], lo[k][3]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[k][e] = (_Float16)0.0f; lo[k][e] = (_Float16)0.0f; }
+    const int64_t row = min((int64_t)(r0 + 8 * wave + rr), (int64_t)p.M - 1);
+    const float4* xr = reinterpret_cast<const float4*>(p.x + row * LC);
+    v[rr][0] = xr[lane]; v[rr][1] = xr[lane + 64];
+    const float* pa = p.gamma;
+    const float* pb = p.beta;
+    if (p.mod) {
+      const int64_t b = (int64_t)p.group_batch[row / p.group_rows];
+      pa = p.mod + b * p.ld_mod;
+      pb = pa + LC;
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
+      m_a[rr][k] = reinterpret_cast<const float4*>(pa)[lane + 64 * k];
+      m_b[rr][k] = reinterpret_cast<const float4*>(pb)[lane + 64 * k];
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int lrow = 8 * wave + rr;
+    half4 hi[2], lo[2];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) s += (v[rr][k].x + v[rr][k].y) + (v[rr][k].z + v[rr][k].w);
+    const float mean = wave_sum(s) / (float)LC;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float a = v[rr][k].x - mean, b = v[rr][k].y - mean, c = v[rr][k].z - mean, d = v[rr][k].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = wave_sum(q) / (float)LC;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const bool live = r0 + lrow < p.M;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float4 o;
+      o.x = (v[rr][k].x - mean) * rstd; o.y = (v[rr][k].y - mean) * rstd; o.z = (v[rr][k].z - mean) * rstd; o.w = (v[rr][k].w - mean) * rstd;
+      if (p.mod) {
+        o.x = o.x * (1.0f + m_a[rr][k].x) + m_b[rr][k].x; o.y = o.y * (1.0f + m_a[rr][k].y) + m_b[rr][k].y;
+        o.z = o.z * (1.0f + m_a[rr][k].z) + m_b[rr][k].z; o.w = o.w * (1.0f + m_a[rr][k].w) + m_b[rr][k].w;
+      } else {
+        o.x = o.x * m_a[rr][k].x + m_b[rr][k].x; o.y = o.y * m_a[rr][k].y + m_b[rr][k].y;
+        o.z = o.z * m_a[rr][k].z + m_b[rr][k].z; o.w = o.w * m_a[rr][k].w + m_b[rr][k].w;
+      }
+      if (!live) o = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end: zero operand rows (their outputs are not stored)
+      PFPP_SPLIT_TO(o.x, hi[k][0], lo[k][0]); PFPP_SPLIT_TO(o.y, hi[k][1], lo[k][1]);
+      PFPP_SPLIT_TO(o.z, hi[k][2], lo[k][2]); PFPP_SPLIT_TO(o.w, hi[k][3], lo[k][3]);
       *reinterpret_cast<half4*>(sh + lrow * LKP + 4 * (lane + 64 * k)) = hi[k];
       *reinterpret_cast<half4*>(sl + lrow * LKP + 4 * (lane + 64 * k)) = lo[k];
     }
@@ -140,20 +139,31 @@ __global__ __launch_bounds__(64 * LNW) void lnlin_small_kernel(LnLinP p) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
-  const half8* ah = reinterpret_cast<const half8*>(sh + l31 * LKP + k0 + 32 * lhi);
-  const half8* al = reinterpret_cast<const half8*>(sl + l31 * LKP + k0 + 32 * lhi);
+  const half8* ah = reinterpret_cast<const half8*>(sh + l31 * LKP + k0 + 8 * lhi);
+  const half8* al = reinterpret_cast<const half8*>(sl + l31 * LKP + k0 + 8 * lhi);
+  half8* patch = reinterpret_cast<half8*>(patches + wave * (2 * 32 * 128));
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int j = 0; j < 2; ++j) {
+    // tile j: registers -> patch (chunk c of row r at position c ^ (r & 15)), then 8 steps of 16
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const half8 a_h = ah[8 * g + u], a_l = al[8 * g + u];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, fh[g][u][j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fl[g][u][j], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, fh[g][u][j], acc[j], 0, 0, 0);
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int r = 4 * i + srow;
+      patch[r * 16 + (schunk ^ (r & 15))] = st[j][0][i];
+      patch[512 + r * 16 + (schunk ^ (r & 15))] = st[j][1][i];
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int q = (2 * s8 + lhi) ^ (l31 & 15);
+      const half8 b_h = patch[l31 * 16 + q], b_l = patch[512 + l31 * 16 + q];
+      const half8 a_h = ah[2 * s8], a_l = al[2 * s8];
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, b_h, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_l, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, b_h, acc[j], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();                                     // every wave is done with its patch: the partial sums take their place
   // ---- partial sums -> LDS [wave][row][col], added in wave order
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -235,7 +245,7 @@ extern "C" int pfpp_layernorm_linear_small(const float* x, const float* mod, int
   p.bias = bias; p.out = out; p.ldc = ldc;
   p.uh = u_planes ? (_Float16*)u_planes->hi : nullptr; p.ul = u_planes ? (_Float16*)u_planes->lo : nullptr; p.ldu = ldu;
   p.M = (int)M; p.N = (int)N; p.eps = eps;
-  const size_t smem = (size_t)2 * 32 * LKP * sizeof(_Float16) + (size_t)LNW * 32 * 64 * sizeof(float);
+  const size_t smem = (size_t)2 * 32 * LKP * sizeof(_Float16) + (size_t)LNW * 2 * 32 * 128 * sizeof(_Float16);     // >= the partial sums
   const dim3 grid((unsigned)((M + 31) / 32), (unsigned)(N / 64));
   hipStream_t st = pfpp::as_stream(stream);
   static bool attr_set = false;
