@@ -260,12 +260,16 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   // Q fragments of this lane's query: dims 16c + 8*lhi .. +7
   const int q_row = q_base + wave * 32 + l31;
   const float* qp = base + (int64_t)min(q_row, T - 1) * ld + lhi * 8;
+  // the softmax runs in the log2 domain: q is pre-multiplied by scale * log2(e), so a probability is ONE v_exp_f32 of (score - max)
+  // — the per-score multiply by the scale and the one inside expf() are gone (the walk over the key tiles is VALU-bound for
+  // dim_head 32: ~180 vector instructions against 4 matrix instructions per tile)
+  const float qs = scale * 1.44269504088896340736f;
   ad_half8 qh[DH / 16], ql[DH / 16];
 #pragma unroll
   for (int c = 0; c < DH / 16; ++c) {
     const float4 a = *reinterpret_cast<const float4*>(qp + c * 16);
     const float4 bq = *reinterpret_cast<const float4*>(qp + c * 16 + 4);
-    const float x[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+    const float x[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, bq.x * qs, bq.y * qs, bq.z * qs, bq.w * qs};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       _Float16 hh, ll;
@@ -357,31 +361,39 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], s, 0, 0, 0);
     }
 
-    // ---- online softmax over this lane's query column ----
+    // ---- online softmax over this lane's query column (log2 domain) ----
     float mx = -__builtin_huge_valf();
+    if (kmask == 0xffffffffu) {                       // every key of the tile counts (all but the last tile of an unmasked sequence)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      const float v = (kmask >> key) & 1u ? s[e] * scale : -__builtin_huge_valf();
-      s[e] = v;
-      mx = fmaxf(mx, v);
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const float v = (kmask >> key) & 1u ? s[e] : -__builtin_huge_valf();
+        s[e] = v;
+        mx = fmaxf(mx, v);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pe = __expf(s[e] - m_new);
+      const float pe = __builtin_amdgcn_exp2f(s[e] - m_new);
       s[e] = pe;
       psum += pe;
     }
-    l_run = l_run * alpha + psum;
+    if (__ballot(m_new != m_run)) {                   // the running maximum moved for some query of the wave: rescale what was summed so far
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+    }
+    l_run += psum;
     m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
 
     // ---- O^T += V^T . P^T ----
     ad_half8 ph[2], pl[2];
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   // ---- normalise and store: lane holds O[query = l31][d = dt*32 + 8g + 4*lhi + (0..3)] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-  if (lse && q_row < T && lhi == 0) lse[(row0 + q_row) * H + h] = m_run + logf(l_tot);
+  if (lse && q_row < T && lhi == 0) lse[(row0 + q_row) * H + h] = m_run * 0.69314718055994530942f + logf(l_tot);     // back to natural log
   if (q_row < T) {
     const int64_t off = (row0 + q_row) * (int64_t)C + h * DH + lhi * 4;
 #pragma unroll
