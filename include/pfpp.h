@@ -43,6 +43,9 @@ typedef void* pfpp_stream_t;
 /* ---- library ------------------------------------------------------------ */
 int pfpp_version(void);                 /* ABI version, currently 1          */
 const char* pfpp_last_error(void);
+/* sizeof(struct pfpp_<name>) as this library was compiled ("gemm_planes_args", "tlayers_args", ...), -1 for an unknown name: a binding
+ * that mirrors the structs (pfpp_hip/_lib.py) checks its own layout against it when it loads, so a stale mirror fails loudly    */
+int64_t pfpp_abi_sizeof(const char* name);
 /* number of compute units of the current device (for grid sizing in hosts) */
 int pfpp_device_cu_count(void);
 /* process-wide arithmetic of the attention FORWARD kernels (pfpp_attn_dense*, pfpp_attn_blockdiag*; diffusers Attention,
@@ -260,6 +263,17 @@ int pfpp_attn_blockdiag_bwd_p(const float* qkv, const float* dout, float* dqkv, 
  * (dense per-chunk slabs + a reduction launch, deterministic) and through fp32 atomics otherwise (accumulate only).
  * splits = 0 / variant = 0: chosen by the library.  Results of the non-accumulating form are bit-identical to
  * pfpp_gemm(PFPP_GEMM_F16X3) on the same planes.                                                               */
+/* a K split's second pass, handed back instead of launched (pfpp_gemm_planes_args.defer): the slabs of `splits` chunks wait in ws
+ * (and the partial column sums in csum_ws); pfpp_slab_reduce_group adds up to PFPP_SLAB_GROUP_MAX of them in ONE launch — the six weight
+ * gradients of a transformer block leave one reduction behind instead of six.  splits == 0: the GEMM wrote C itself, nothing to do. */
+#define PFPP_SLAB_GROUP_MAX 8
+typedef struct pfpp_slab_job {
+  const float* ws; float* C; const float* csum_ws; float* csum;
+  int32_t M, N; int64_t ldc; int32_t splits, accumulate;
+} pfpp_slab_job;
+/* C (+)= sum over the chunks, chunk order (bit-identical to the reduction pfpp_gemm_planes launches itself); jobs with splits == 0 skipped */
+int pfpp_slab_reduce_group(const pfpp_slab_job* jobs, int32_t n_jobs, pfpp_stream_t stream);
+
 typedef struct pfpp_gemm_planes_args {
   const void* a_hi; const void* a_lo;   /* fp16 planes of A */
   const void* w_hi; const void* w_lo;   /* fp16 planes of W */
@@ -279,6 +293,8 @@ typedef struct pfpp_gemm_planes_args {
   float* colsum; float colsum_alpha;    /* dW form only (both operands k-major): colsum[m] += colsum_alpha * sum_k A[k][m], i.e. the bias
                                            gradient sum over rows of dY (nn.Linear backward) computed from the fragments the GEMM reads
                                            anyway; with a workspace K split it needs room for splits * M more floats             */
+  pfpp_slab_job* defer;                 /* NULL, or (no bias / residual / activation): a workspace K split leaves its reduction in *defer for
+                                           pfpp_slab_reduce_group; ws must stay untouched until that runs                        */
 } pfpp_gemm_planes_args;
 
 int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);

@@ -22,6 +22,7 @@
 // and VALU work into the gaps between matrix instructions; rows outside M/N are clamped (their
 // results are discarded) instead of predicated.  LDS rows are padded (36 floats / 40 halfs) so
 // that the 16-byte fragment reads are bank-conflict free.  Tile ids are remapped XCD-aware.
+#include <string.h>
 #include <stdlib.h>
 
 #include "gemm_common.h"
@@ -900,6 +901,7 @@ extern "C" int pfpp_gemm(const pfpp_gemm_args* a, pfpp_stream_t stream) {
   if (a->M == 0) return PFPP_OK;
 
   GemmP p;
+  memset(&p, 0, sizeof(p));          // (fields only the plane entry point sets — csum, defer — must read as absent here)
   p.A = a->A; p.W = a->W; p.C = a->C; p.Whi = a->w_hi; p.Wlo = a->w_lo;
   p.Ahi = a->a_hi; p.Alo = a->a_lo; p.Chi = a->c_hi; p.Clo = a->c_lo;
   p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.residual = a->residual;

@@ -38,6 +38,7 @@ struct GemmP {
   int x1;     // gemm_pl.hip: single-pass fp16 (hi planes only) — PFPP_GEMM_F16
   float* csum; float* csum_ws; float csum_alpha;   // gemm_pl.hip (k-major A): csum[m] += csum_alpha * sum_k A[k][m] — the bias gradient riding in dW = dY^T . X
   int accum;  // gemm_pl.hip: C += alpha * acc with fp32 atomics (set by the launcher for split-K / gradient accumulation)
+  pfpp_slab_job* defer;   // host side only (gemm_pl.hip launch_pl): hand the slab reduction back instead of launching it
   int dbg;    // gemm_pl.hip ablation switches (PFPP_GEMM_DBG; developer runs only): 1 no epilogue, 2 no DMA after the prologue, 4 no barrier / DMA wait
 };
 

@@ -752,6 +752,38 @@ __global__ __launch_bounds__(256) void pl_reduce_kernel(const float* ws, float* 
   *dstp = s;
 }
 
+// the same sums for up to PFPP_SLAB_GROUP_MAX deferred K splits in one launch (accumulate / store only: no bias, activation, residual)
+struct SlabGroupP {
+  pfpp_slab_job job[PFPP_SLAB_GROUP_MAX];
+  unsigned first_block[PFPP_SLAB_GROUP_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void pl_reduce_group_kernel(const SlabGroupP g) {
+  int j = 0;
+  while (j + 1 < g.n && blockIdx.x >= g.first_block[j + 1]) ++j;
+  const pfpp_slab_job& q = g.job[j];
+  const int64_t i = (int64_t)(blockIdx.x - g.first_block[j]) * blockDim.x + threadIdx.x;
+  const int M = q.M, N = q.N, n4 = N >> 2, splits = q.splits;
+  if (q.csum_ws && i < M) {
+    float s = q.csum_ws[i];
+    for (int k = 1; k < splits; ++k) s += q.csum_ws[(size_t)k * M + i];
+    q.csum[i] += s;
+  }
+  if (i >= (int64_t)M * n4) return;
+  const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) * 4;
+  const size_t slab = (size_t)M * N;
+  const float* src = q.ws + (size_t)row * N + col;
+  float4 s = *reinterpret_cast<const float4*>(src);
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(src + k * slab);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* dstp = reinterpret_cast<float4*>(q.C + (int64_t)row * q.ldc + col);
+  if (q.accumulate) { const float4 c = *dstp; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+  *dstp = s;
+}
+
 template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
   pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1, CS>(p);
@@ -800,7 +832,14 @@ int launch_pl(const GemmP& p0, int batch, hipStream_t st, int group_m, int split
   snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s, %s, %s>%s", MT, NT, WM, WN, NS, AK ? "true" : "false",
            WK ? "true" : "false", DBG, AF ? "true" : "false", X1 ? "true" : "false", CS ? "true" : "false", slabs ? "+pl_reduce_kernel" : "");
   hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::SMEM + (AF ? 2048 : 0), st, p);
-  if (slabs) {
+  if (p.defer) {
+    pfpp_slab_job& q = *p.defer;
+    q = pfpp_slab_job{};
+    if (slabs) {
+      q.ws = p.split_ws; q.C = p.C; q.csum_ws = p.csum_ws; q.csum = p.csum;
+      q.M = p.M; q.N = p.N; q.ldc = p.ldc; q.splits = p.split_k; q.accumulate = p.accum;
+    }
+  } else if (slabs) {
     const int64_t n4 = (int64_t)p.M * (p.N >> 2);
     hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.split_ws, p.C, p.bias, p.residual, p.M,
                        p.N, p.ldc, p.ldr, p.split_k, p.accum, p.act, p.csum_ws, p.csum);
@@ -980,6 +1019,27 @@ using namespace pfpp_gemm_detail;
 
 extern "C" const char* pfpp_last_gemm_kernel(void) { return pl::last_kernel; }
 
+extern "C" int pfpp_slab_reduce_group(const pfpp_slab_job* jobs, int32_t n_jobs, pfpp_stream_t stream) {
+  PFPP_REQUIRE(jobs && n_jobs >= 0 && n_jobs <= PFPP_SLAB_GROUP_MAX, "0..PFPP_SLAB_GROUP_MAX jobs");
+  pl::SlabGroupP g;
+  memset(&g, 0, sizeof(g));
+  unsigned blocks = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const pfpp_slab_job& q = jobs[j];
+    if (q.splits == 0) continue;
+    PFPP_REQUIRE(q.ws && q.C && q.M > 0 && q.N > 0 && q.N % 4 == 0 && q.ldc % 4 == 0 && q.splits >= 2 && (!q.csum_ws || q.csum) &&
+                 pfpp::aligned16(q.ws) && pfpp::aligned16(q.C), "slab job");
+    g.job[g.n] = q;
+    g.first_block[g.n] = blocks;
+    blocks += (unsigned)(((int64_t)q.M * (q.N >> 2) + 255) / 256);
+    ++g.n;
+  }
+  g.first_block[g.n] = blocks;
+  if (g.n == 0) return PFPP_OK;
+  hipLaunchKernelGGL(pl::pl_reduce_group_kernel, dim3(blocks), dim3(256), 0, pfpp::as_stream(stream), g);
+  return pfpp::check_launch("pfpp_slab_reduce_group");
+}
+
 extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a && a->a_hi && a->a_lo && a->w_hi && a->w_lo && a->C, "null pointer");
   PFPP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sizes must be positive");
@@ -1007,6 +1067,8 @@ extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t st
   pl::p_ws_bytes = p.ws_bytes;
   PFPP_SUPPORTED(!a->colsum || (a->a_kmajor && a->w_kmajor && !a->single_pass), "colsum rides with the k-major pair (dW = dY^T . X) only");
   p.csum = a->colsum; p.csum_alpha = a->colsum_alpha;
+  PFPP_SUPPORTED(!a->defer || (!a->bias && !a->residual && a->act == PFPP_ACT_NONE && a->ws), "defer: plain (accumulating) outputs with a workspace only");
+  p.defer = a->defer;
   hipStream_t st = pfpp::as_stream(stream);
   int variant = a->variant, splits = a->splits;
   const int nk = p.K / 32;

@@ -116,9 +116,10 @@ FwdLayout fwd_layout(int64_t M, int64_t C, int64_t H, int64_t inner) {
 
 int gemm_pl(const pfpp_planes& A, const pfpp_planes& W, float* Cout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
             bool a_km, bool w_km, const float* bias, const float* residual, bool accumulate, float* colsum, float* ws, int64_t ws_bytes,
-            int single_pass, pfpp_stream_t st, int splits = 0) {
+            int single_pass, pfpp_stream_t st, int splits = 0, pfpp_slab_job* defer = nullptr) {
   pfpp_gemm_planes_args a = {};
   a.splits = splits;
+  a.defer = defer;
   a.a_hi = A.hi; a.a_lo = A.lo; a.w_hi = W.hi; a.w_lo = W.lo;
   a.C = Cout; a.bias = bias; a.residual = residual;
   a.M = M; a.N = N; a.K = K;
@@ -230,6 +231,19 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   PFPP_REQUIRE(a->bwd_bytes >= o, "bwd_bytes smaller than pfpp_tlayers_bwd_bytes()");
 
   int cur_layer = 0;
+  // PFPP_TRAIN_GROUP_REDUCE=1: the K splits of a block's six weight-gradient GEMMs keep their slabs in their own stretches of the side
+  // workspace and are reduced by ONE launch behind the block's last weight gradient (42 -> 12 reduction launches per iteration).
+  // Measured (profiles/r04o_ab_group_reduce.txt): 0.04-0.1 ms per iteration SLOWER — 92 MB of slabs per block are re-read after the
+  // other five GEMMs have pushed them out of L2 instead of right behind their GEMM — so every GEMM reduces at once by default.
+  static const bool group_reduce = getenv("PFPP_TRAIN_GROUP_REDUCE") && atoi(getenv("PFPP_TRAIN_GROUP_REDUCE")) == 1;
+  pfpp_slab_job jobs[PFPP_SLAB_GROUP_MAX];
+  int n_jobs = 0;
+  int64_t ws_used = 0;
+  auto flush_jobs = [&]() -> int {
+    const int n = n_jobs;
+    n_jobs = 0; ws_used = 0;
+    return n ? pfpp_slab_reduce_group(jobs, n, side_t) : PFPP_OK;
+  };
   // planes of scale G in slot k, safe to write on the main stream
   auto fresh = [&](int k, int64_t elems, pfpp_planes* out) -> int {
     if (side) TL_CALL(slot_acquire(g_slots[k], slot_buf[k], main_s));
@@ -242,7 +256,15 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     static const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;      // lab: 0 = the library's choice
     static const int lab_skip = getenv("PFPP_LAB_SKIP_DW_LAYERS") ? atoi(getenv("PFPP_LAB_SKIP_DW_LAYERS")) : 0;   // lab (timing only, WRONG gradients): no dW for the last k layers
     if (lab_skip > 0 && cur_layer >= a->n_layers - lab_skip) return PFPP_OK;
-    TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t, dw_splits));
+    if (group_reduce) {
+      if (n_jobs == PFPP_SLAB_GROUP_MAX) TL_CALL(flush_jobs());
+      pfpp_slab_job& q = jobs[n_jobs];
+      TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side + ws_used / 4,
+                      a->ws_bytes - ws_used, 0, side_t, dw_splits, &q));
+      if (q.splits) { ws_used += up((int64_t)q.splits * q.M * (q.N + 1) * 4); ++n_jobs; }
+    } else {
+      TL_CALL(gemm_pl(dyp, xp, gw, n_out, n_in, M, n_out, n_in, n_in, true, true, nullptr, nullptr, true, gb, ws_side, a->ws_bytes, 0, side_t, dw_splits));
+    }
     if (side && k >= 0) TL_CALL(slot_read_on(g_slots[k], side_s));
     return PFPP_OK;
   };
@@ -319,6 +341,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
       if (a->dtok != a->dh && hipMemcpyAsync(a->dtok, a->dh, (size_t)M * C * 4, hipMemcpyDeviceToDevice, main_s) != hipSuccess)
         return pfpp::check_launch(__func__);
     }
+    TL_CALL(flush_jobs());
     if (a->adamw && side) {
       // optimizer in the backward: the layer's slice of the flat buffer is final once its weight gradients (side stream) and its
       // LayerNorm gradients (main stream, all queued by now) have run

@@ -81,6 +81,12 @@ class SampleLevel(C.Structure):
     _fields_ = [("S", _i64), ("nsample", _i64), ("r2", _f32), ("fps_idx", _p), ("new_xyz", _p), ("ball_idx", _p)]
 
 
+class SlabJob(C.Structure):
+    """pfpp_slab_job"""
+    _fields_ = [("ws", _p), ("C", _p), ("csum_ws", _p), ("csum", _p), ("M", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int64),
+                ("splits", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class GemmPlanesArgs(C.Structure):
     """mirror of struct pfpp_gemm_planes_args (include/pfpp.h)"""
 
@@ -92,6 +98,7 @@ class GemmPlanesArgs(C.Structure):
         ("alpha", _f32), ("single_pass", _i32),
         ("ws", _p), ("ws_bytes", _i64),
         ("colsum", _p), ("colsum_alpha", _f32),
+        ("defer", _p),
     ]
 
 
@@ -259,6 +266,7 @@ SIGNATURES = {
     "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
+    "pfpp_slab_reduce_group": [C.POINTER(SlabJob), C.c_int32, _p],
     "pfpp_split_planes": [_p, _i64, _pl, _p],
     "pfpp_colsum_planes": [_p, _p, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_geglu_p": [_p, _p, _i64, _i64, _f32, _u64, _u32, _pl, _p],
@@ -273,6 +281,7 @@ SIGNATURES = {
 PLAIN = {
     "pfpp_version": ([], C.c_int),
     "pfpp_last_error": ([], C.c_char_p),
+    "pfpp_abi_sizeof": ([C.c_char_p], C.c_int64),
     "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_get_attention_mode": ([], C.c_int),
@@ -281,6 +290,14 @@ PLAIN = {
     "pfpp_tlayers_bwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
     "pfpp_fragment_prepare_workspace": ([_i64, _i64], C.c_int64),
+}
+
+# struct name in include/pfpp.h (without the pfpp_ prefix) -> its mirror here; load() compares the sizes
+STRUCT_MIRRORS = {
+    "sample_level": SampleLevel, "gemm_args": GemmArgs, "planes": PlanesC, "slab_job": SlabJob, "gemm_planes_args": GemmPlanesArgs,
+    "sa_train_args": SaTrainArgs, "gemm_grad_args": GemmGradArgs, "tlayer_params": TlayerParams, "tlayer_grads": TlayerGrads,
+    "tlayer_adamw": TlayerAdamw, "tlayers_args": TlayersArgs, "pw": PwC, "elayer_params": ElayerParams,
+    "tlayers_eval_args": TlayersEvalArgs, "head_params": HeadParams, "head_grads": HeadGrads,
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}
@@ -328,6 +345,11 @@ def load() -> C.CDLL:
         fn.restype = restype
     if lib.pfpp_version() != 1:
         raise PfppError(f"libpfpp_hip.so ABI version {lib.pfpp_version()} != 1")
+    for cname, mirror in STRUCT_MIRRORS.items():
+        want = lib.pfpp_abi_sizeof(cname.encode())
+        if want != C.sizeof(mirror):
+            raise PfppError(f"struct pfpp_{cname}: the library has {want} bytes, the ctypes mirror {mirror.__name__} {C.sizeof(mirror)} — "
+                            "rebuild libpfpp_hip.so (python __graft_entry__.py) or update pfpp_hip/_lib.py")
     _lib = lib
     return lib
 

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT, GemmPlanesArgs, PlanesC, check
+from ._lib import ACT, GemmPlanesArgs, PlanesC, SlabJob, check
 from .ops import _chk, _ptr, _stream, raw_stream_id
 
 _f32 = torch.float32
@@ -98,7 +98,8 @@ def workspace_for(device, stream_handle: int) -> torch.Tensor:
 def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_kmajor: bool = False, w_kmajor: bool = False,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: str = "none",
          accumulate: bool = False, splits: int = 0, variant: int = 0, alpha: Optional[float] = None, use_ws: bool = True,
-         single_pass: bool = False, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+         single_pass: bool = False, colsum: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+         defer: Optional["SlabJob"] = None) -> torch.Tensor:
     """pfpp_gemm_planes: out [M, N] = act(alpha * A.W + bias) + residual, or += with accumulate.
        forward  : A [M, K],              W [N, K]
        dX       : A = dY [M, K],         W [K, N] (w_kmajor)
@@ -126,9 +127,13 @@ def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_k
         if colsum.numel() != M or not colsum.is_contiguous():
             raise ValueError("colsum: contiguous fp32 [M] expected")
         a.colsum, a.colsum_alpha = colsum.data_ptr(), 1.0 / A.scale
-    if use_ws:
+    if ws is not None:         # the caller's own stretch of workspace (deferred reductions keep theirs until slab_reduce_group)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    elif use_ws:
         ws = _workspace(out.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if defer is not None:
+        a.defer = C.addressof(defer)
     from . import ops
 
     if ops.GEMM_TRACE is not None:        # bench.py: HIP events around the launch on its stream, attributed to the kernel name
@@ -141,3 +146,9 @@ def gemm(A: Planes, W: Planes, out: torch.Tensor, *, M: int, N: int, K: int, a_k
         return out
     check(_lib.load().pfpp_gemm_planes(C.byref(a), _stream()), "pfpp_gemm_planes")
     return out
+
+
+def slab_reduce_group(jobs) -> None:
+    """pfpp_slab_reduce_group: the K-split reductions gemm(..., defer=job) handed back, all in one launch"""
+    arr = (SlabJob * len(jobs))(*jobs)
+    check(_lib.load().pfpp_slab_reduce_group(arr, len(jobs), _stream()), "pfpp_slab_reduce_group")

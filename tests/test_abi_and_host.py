@@ -52,6 +52,23 @@ def test_gemm_args_struct_matches_header():
     assert header_struct_fields("pfpp_gemm_grad_args") == [f[0] for f in GemmGradArgs._fields_]
 
 
+def test_every_ctypes_mirror_has_the_size_the_library_was_compiled_with(hip_lib):
+    """a struct that grew in include/pfpp.h without its mirror in pfpp_hip/_lib.py would make the library read past the caller's
+    memory; load() refuses such a pair — here every struct the header defines must be in that check, with equal sizes"""
+    import ctypes as C
+
+    from pfpp_hip import _lib
+
+    text = (ROOT / "include" / "pfpp.h").read_text()
+    declared = set(re.findall(r"^}\s*pfpp_(\w+);", text, flags=re.M))
+    declared |= set(re.findall(r"^typedef struct pfpp_\w+ \{[^}]*\} pfpp_(\w+);", text, flags=re.M))
+    lib = _lib.load()
+    assert declared == set(_lib.STRUCT_MIRRORS), declared ^ set(_lib.STRUCT_MIRRORS)
+    for name, mirror in _lib.STRUCT_MIRRORS.items():
+        assert lib.pfpp_abi_sizeof(name.encode()) == C.sizeof(mirror), name
+    assert lib.pfpp_abi_sizeof(b"no_such_struct") == -1
+
+
 def test_wrappers_reject_cpu_tensors(hip_lib):
     from pfpp_hip import ops
 

@@ -72,6 +72,45 @@ def test_plane_gemm_layouts_and_fused_bias_gradient(dev, rows, n_out, n_in, spli
     assert torch.equal(dW_b, dW) and torch.equal(db_b, db)
 
 
+def test_deferred_k_split_reductions_in_one_launch_equal_the_immediate_ones(dev):
+    """the six weight gradients of a transformer block (dW += dY^T . X, db += colsum dY) with their K-split reductions handed back
+    (pfpp_gemm_planes_args.defer) and run by ONE pfpp_slab_reduce_group launch == each GEMM reducing at once, bit for bit; an
+    unsplit GEMM leaves an empty job"""
+    from pfpp_hip import planes as P
+
+    g = torch.Generator().manual_seed(11)
+    rows, G = 3850, 4096.0
+    shapes = [(512, 2048, True), (4096, 512, True), (512, 512, True), (1536, 512, False), (512, 512, True), (1536, 512, False)]
+    ws = torch.empty(64 * 1024 * 1024, device=dev)
+    jobs, used, outs, refs = [], 0, [], []
+    for n_out, n_in, has_bias in shapes:
+        x = P.split(torch.randn(rows, n_in, generator=g).to(dev))
+        dy = P.split((torch.randn(rows, n_out, generator=g) * 1e-4).to(dev), G)
+        dW0, db0 = torch.randn(n_out, n_in, generator=g).to(dev) * 1e-3, torch.randn(n_out, generator=g).to(dev) * 1e-3
+        dW_r, db_r = dW0.clone(), db0.clone()
+        P.gemm(dy, x, dW_r, M=n_out, N=n_in, K=rows, a_kmajor=True, w_kmajor=True, accumulate=True, colsum=db_r if has_bias else None)
+        dW, db = dW0.clone(), db0.clone()
+        job = P.SlabJob()
+        P.gemm(dy, x, dW, M=n_out, N=n_in, K=rows, a_kmajor=True, w_kmajor=True, accumulate=True, colsum=db if has_bias else None,
+               ws=ws[used // 4:], defer=job)
+        assert job.splits >= 2 and job.M == n_out and job.N == n_in
+        assert torch.equal(dW, dW0)                    # nothing has been added yet
+        used += (job.splits * job.M * (job.N + 1) * 4 + 255) // 256 * 256
+        jobs.append(job); outs.append((dW, db)); refs.append((dW_r, db_r))
+    P.slab_reduce_group(jobs)
+    for (dW, db), (dW_r, db_r) in zip(outs, refs):
+        assert torch.equal(dW, dW_r) and torch.equal(db, db_r)
+    # an unsplit launch writes C itself and leaves nothing behind
+    x, dy = P.split(torch.randn(64, 512, generator=g).to(dev)), P.split(torch.randn(64, 512, generator=g).to(dev))
+    dW = torch.zeros(512, 512, device=dev)
+    job = P.SlabJob()
+    P.gemm(dy, x, dW, M=512, N=512, K=64, a_kmajor=True, w_kmajor=True, accumulate=True, splits=1, ws=ws, defer=job)
+    assert job.splits == 0 and float(dW.abs().max()) > 0
+    P.slab_reduce_group([job])                          # a no-op
+    with pytest.raises(P._lib.PfppError, match="defer"):
+        P.gemm(dy, x, dW, M=512, N=512, K=64, a_kmajor=True, w_kmajor=True, bias=torch.zeros(512, device=dev), ws=ws, defer=job)
+
+
 @pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (16000, 1536, 512), (1234 * 4, 512, 2048), (640, 512, 148), (32, 1024, 512)])
 def test_grad_weight_gemm(dev, M, N, K):
     """dW [N,K] = dY[M,N]^T . X[M,K]  (both operands k-major, split-K atomics)"""
