@@ -861,7 +861,10 @@ int pfpp_tlayers_bwd(const pfpp_tlayers_args* args, int32_t layer_lo, int32_t la
  * GEGLU pair interleaved 32 value / 32 gate rows, gate applied in the epilogue), pfpp_attn_blockdiag_split and pfpp_attn_dense_split,
  * enqueued from one call.  norm / att [M, C] and u [M, inner] are scratch planes, qkv [M, 3C] scratch fp32 (caller-owned);
  * split_ws / split_cnt: the split-K workspace of pfpp_gemm (see pfpp_gemm_args).                                              */
-typedef struct pfpp_pw { const float* f32; const void* hi; const void* lo; float scale; int64_t ldw; } pfpp_pw;
+/* fhi / flo (optional, NULL = absent): the same planes FRAGMENT-BLOCKED for the few-token kernels (pfpp_layernorm_linear_small): block
+ * (row tile r = n / 32, k-step s = k / 16) is 1 KB = 64 x 8 halfs, entry 32 (k % 16 / 8) + n % 32 holds W[n][16 s + 8 (k % 16 / 8) .. + 8) — the
+ * B operand of one v_mfma_f32_32x32x16_f16 as the 64 lanes hold it; blocks ordered [r][s].  N % 32 == 0, K % 16 == 0, no row padding. */
+typedef struct pfpp_pw { const float* f32; const void* hi; const void* lo; float scale; int64_t ldw; const void* fhi; const void* flo; } pfpp_pw;
 typedef struct pfpp_elayer_params {
   pfpp_pw qkv1, o1, qkv2, o2, ff1, ff2;            /* [3C,C], [C,C], [3C,C], [C,C], [2 inner (interleaved), C], [C, inner] */
   const float *bo1, *bo2, *g3, *b3, *bff1, *bff2;
@@ -888,6 +891,13 @@ int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
  * as planes [M, ldu], N = 2 * inner.  C = 512, N % 64 == 0.  LayerNorm arithmetic = pfpp_layernorm*; the contraction is summed in a
  * different (fixed) order than pfpp_gemm's: equal to the two-launch path to fp32 rounding.  pfpp_tlayers_eval uses it for M <= 512
  * (lnlin_max_rows; 0 = never).                                                                                                  */
+/* Plane GEMM for few rows: out [M, ldc] = A . W^T / (A.scale * w.scale) + bias + residual, A = planes [M, lda] of a [M, K] operand, w
+ * with its fragment-blocked planes (fhi / flo).  The out-projections of both attentions and the second feed-forward linear with their
+ * residual adds (attention.py:77-90), eval mode; out may be the residual (in place).  K % 512 == 0, N % 32 == 0.  Same products as
+ * pfpp_gemm's split-f16 path, one k-ordered chain per output (equal to it to fp32 rounding); pfpp_tlayers_eval uses it for
+ * M <= lnlin_max_rows.                                                                                                              */
+int pfpp_gemm_small(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr, float* out,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream);
 int pfpp_layernorm_linear_small(const float* x, const float* mod, int64_t ld_mod, const float* gamma, const float* beta,
                                 const int32_t* group_batch, int64_t group_rows, const pfpp_pw* w, const float* bias, float* out,
                                 int64_t ldc, const pfpp_planes* u_planes, int64_t ldu, int64_t M, int64_t N, int64_t C, float eps,

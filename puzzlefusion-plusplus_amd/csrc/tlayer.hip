@@ -395,6 +395,7 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
   const int prec = a->single_pass ? PFPP_GEMM_F16 : PFPP_GEMM_F16X3;
   // few tokens (one puzzle in flight): the LayerNorm rides in the GEMM that consumes it (csrc/lnlin_small.hip) — 18 launches less per step
   const bool fuse_ln = !a->single_pass && C == 512 && M <= a->lnlin_max_rows && (2 * inner) % 64 == 0;
+  const bool small = fuse_ln && a->layers[0].o1.fhi != nullptr;      // few tokens: the three residual GEMMs through pfpp_gemm_small as well
   for (int i = 0; i < a->n_layers; ++i) {
     const pfpp_elayer_params& w = a->layers[i];
     const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
@@ -407,7 +408,8 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
       TL_CALL(gemm_ev(a->norm, w.qkv1, a->qkv, nullptr, M, 3 * C, C, C, 3 * C, nullptr, nullptr, PFPP_ACT_NONE, prec, a, stream));
     }
     TL_CALL(pfpp_attn_blockdiag_split(a->qkv, a->att.hi, a->att.lo, a->Fv, L, H, dh, a->att_scale, stream));
-    TL_CALL(gemm_ev(a->att, w.o1, a->h, nullptr, M, C, C, C, C, w.bo1, a->h, PFPP_ACT_NONE, prec, a, stream));
+    if (small) TL_CALL(pfpp_gemm_small(&a->att, C, &w.o1, w.bo1, a->h, C, a->h, C, M, C, C, stream));
+    else TL_CALL(gemm_ev(a->att, w.o1, a->h, nullptr, M, C, C, C, C, w.bo1, a->h, PFPP_ACT_NONE, prec, a, stream));
     if (fuse_ln) {
       TL_CALL(pfpp_layernorm_linear_small(a->h, mod2, ld_mod, nullptr, nullptr, a->frag_b, L, &w.qkv2, nullptr, a->qkv, 3 * C, nullptr, 0, M,
                                           3 * C, C, eps, stream));
@@ -417,7 +419,8 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
     }
     TL_CALL(pfpp_attn_dense_split(a->qkv, a->att.hi, a->att.lo, a->seq_off, a->seq_len, nullptr, 0, a->n_seq, a->max_len, H, dh, a->att_scale,
                                   stream));
-    TL_CALL(gemm_ev(a->att, w.o2, a->h, nullptr, M, C, C, C, C, w.bo2, a->h, PFPP_ACT_NONE, prec, a, stream));
+    if (small) TL_CALL(pfpp_gemm_small(&a->att, C, &w.o2, w.bo2, a->h, C, a->h, C, M, C, C, stream));
+    else TL_CALL(gemm_ev(a->att, w.o2, a->h, nullptr, M, C, C, C, C, w.bo2, a->h, PFPP_ACT_NONE, prec, a, stream));
     if (fuse_ln) {
       TL_CALL(pfpp_layernorm_linear_small(a->h, nullptr, 0, w.g3, w.b3, nullptr, 1, &w.ff1, w.bff1, nullptr, 0, &a->u, inner, M, 2 * inner, C,
                                           eps, stream));
@@ -425,7 +428,8 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
       TL_CALL(pfpp_layernorm_split(a->h, a->norm.hi, a->norm.lo, nullptr, 0, w.g3, w.b3, M, C, 1, eps, stream));
       TL_CALL(gemm_ev(a->norm, w.ff1, nullptr, &a->u, M, 2 * inner, C, C, inner, w.bff1, nullptr, PFPP_ACT_GEGLU, prec, a, stream));
     }
-    TL_CALL(gemm_ev(a->u, w.ff2, a->h, nullptr, M, C, inner, inner, C, w.bff2, a->h, PFPP_ACT_NONE, prec, a, stream));
+    if (small && inner % 512 == 0) TL_CALL(pfpp_gemm_small(&a->u, inner, &w.ff2, w.bff2, a->h, C, a->h, C, M, C, inner, stream));
+    else TL_CALL(gemm_ev(a->u, w.ff2, a->h, nullptr, M, C, inner, inner, C, w.bff2, a->h, PFPP_ACT_NONE, prec, a, stream));
   }
   return PFPP_OK;
 }

@@ -32,6 +32,7 @@ SOURCES = {
     "tlayer.hip": [],
     "heads.hip": ["-munsafe-fp-atomics"],
     "lnlin_small.hip": [],
+    "gemm_small.hip": [],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
     "attention_bwd.hip": [],

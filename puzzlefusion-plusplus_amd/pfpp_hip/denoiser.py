@@ -90,7 +90,8 @@ def _eval_layers_c(pk, h, mods, lay, L: int, num_layers: int, num_heads: int, at
         layers = (ElayerParams * num_layers)()
 
         def pw(w):
-            return PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1])
+            fh, fl = w.frag()          # (kept alive by the PW in pk)
+            return PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
 
         for i in range(num_layers):
             for name, key in (("qkv1", f"{i}.self_attn.wqkv"), ("o1", f"{i}.self_attn.wo"), ("qkv2", f"{i}.global_attn.wqkv"),

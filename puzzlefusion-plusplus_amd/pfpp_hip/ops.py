@@ -842,6 +842,29 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
     return out
 
 
+def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a . w^T (+ bias) (+ residual) for few rows (pfpp_gemm_small): a = SplitAct planes [M, K], w = packing.PW [N, K] (its
+    fragment-blocked planes are built on first use); out may be the residual tensor"""
+    from ._lib import PlanesC, PwC
+
+    M, K = a.hi.shape
+    if K != w.K:
+        raise ValueError(f"gemm_small: A has K = {K}, the weight {w.K}")
+    fh, fl = w.frag()
+    pw = PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
+    for t_, nm in ((bias, "bias"), (residual, "residual"), (out, "out")):
+        if t_ is not None:
+            _chk(t_, torch.float32, nm)
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float32, device=a.hi.device)
+    ap = PlanesC(a.hi.data_ptr(), a.lo.data_ptr(), 1.0)
+    check(_lib.load().pfpp_gemm_small(C.byref(ap), a.hi.stride(0), C.byref(pw), _ptr(bias), _ptr(residual),
+                                      0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, w.N, K, _stream()),
+          "pfpp_gemm_small")
+    return out
+
+
 def layernorm_linear_small(x: torch.Tensor, w, *, mod: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
                            group_rows: int = 1, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
                            bias: Optional[torch.Tensor] = None, geglu: bool = False, eps: float = 1e-5):
@@ -852,7 +875,8 @@ def layernorm_linear_small(x: torch.Tensor, w, *, mod: Optional[torch.Tensor] = 
     _chk(x, torch.float32, "x")
     M, Cc = x.shape
     N = w.N
-    pw = PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1])
+    fh, fl = w.frag()
+    pw = PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
     for t_, nm in ((mod, "mod"), (gamma, "gamma"), (beta, "beta"), (bias, "bias")):
         if t_ is not None:
             _chk(t_, torch.float32, nm)

@@ -60,7 +60,7 @@ class PW:
     pre-split fp16 planes [N, K8] of `scale` * w for the split-f16 path (`scale`: a per-tensor power of two chosen at pack time,
     packing.plane_scale; 1.0 with prescale=False); `K` is the true reduction length"""
 
-    __slots__ = ("f32", "hi", "lo", "N", "K", "scale")
+    __slots__ = ("f32", "hi", "lo", "N", "K", "scale", "_frag")
 
     def __init__(self, w: torch.Tensor, K: int = None, prescale: bool = True):
         w2 = w.reshape(-1, w.shape[-1])
@@ -70,6 +70,18 @@ class PW:
         wk = w[..., : self.K] if self.K != w.shape[-1] else w
         self.scale = plane_scale(wk) if prescale else 1.0
         self.hi, self.lo = split_f16(wk * self.scale if self.scale != 1.0 else wk)
+        self._frag = None
+
+    def frag(self):
+        """(fhi, flo): the planes fragment-blocked (include/pfpp.h pfpp_pw.fhi / flo) for the few-token kernels, built on first use:
+        block (row tile n // 32, k-step k // 16) = the 64 lanes' B operands of one 32x32x16 MFMA, 1 KB contiguous"""
+        if self._frag is None:
+            if self.hi.dim() != 2 or self.N % 32 or self.K % 16 or self.hi.shape[-1] != self.K:
+                raise ValueError(f"PW.frag: [N % 32 == 0, K % 16 == 0] weights only, got N {self.N} K {self.K}")
+            def blocked(pl):
+                return pl.view(self.N // 32, 32, self.K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+            self._frag = (blocked(self.hi), blocked(self.lo))
+        return self._frag
 
     @property
     def device(self):

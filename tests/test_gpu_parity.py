@@ -1330,6 +1330,47 @@ def test_layernorm_linear_small_vs_float64(dev, M):
     assert float((u.float().double().cpu() - want_u).abs().max() / want_u.abs().max()) < 2e-5          # (weights rounded to 22 bits)
 
 
+@pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512)])
+def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
+    """csrc/gemm_small.hip (out-projections / second feed-forward linear of a few-token step): A planes . fragment-blocked weight planes
+    + bias + residual, in place — against float64 of the values the planes stand for, against the tiled plane GEMM it replaces
+    (same products, another association), and deterministic"""
+    import math
+
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a32 = torch.randn(M, K, generator=g).to(dev)
+    from pfpp_hip import planes as P
+    pl = P.split(a32)
+    a = ops.SplitAct(pl.hi, pl.lo)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev) * 0.1
+    res = torch.randn(M, N, generator=g).to(dev)
+    pw = PW(W.contiguous())
+    fh, fl = pw.frag()
+    assert fh.shape == (N // 32, K // 16, 2, 32, 8)
+    # block (row tile, k-step), entry (half, row): W[32 r + row][16 s + 8 half .. + 8)
+    assert torch.equal(fh[N // 32 - 1, 3, 1, 5], pw.hi[N - 32 + 5, 16 * 3 + 8: 16 * 3 + 16])
+    out = res.clone()
+    ops.gemm_small(a, pw, bias=bias, residual=out, out=out)              # in place over the residual
+    av = (a.hi.double() + a.lo.double()).cpu()
+    wv = ((pw.hi.double() + pw.lo.double()) / pw.scale).cpu()[:, :K]
+    want = av @ wv.t() + bias.double().cpu() + res.double().cpu()
+    assert float((out.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6
+    tiled = res.clone()
+    ops.gemm(a, pw, M=M, N=N, K=K, lda=K, out=tiled, ldc=N, bias=bias, residual=tiled, ldr=N)
+    assert float((out - tiled).abs().max() / tiled.abs().max()) < 2e-6
+    again = res.clone()
+    ops.gemm_small(a, pw, bias=bias, residual=again, out=again)
+    assert torch.equal(again, out)
+    plain = ops.gemm_small(a, pw)                                        # no bias, no residual, fresh output
+    assert float((plain.double().cpu() - av @ wv.t()).abs().max() / want.abs().max()) < 2e-6
+    with pytest.raises(Exception, match="512"):
+        ops.gemm_small(ops.SplitAct.empty(M, 256, dev), PW(W[:, :256].contiguous()))
+
+
 @pytest.mark.parametrize("parts", [(5,), (20, 3, 11), (2,) * 16])
 def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, monkeypatch):
     """pfpp_tlayers_eval (csrc/tlayer.hip): the compact eval forward's six blocks enqueued from one C call are the same launches with
