@@ -112,6 +112,31 @@ def test_packing_geglu_and_sa_first():
     assert torch.allclose(got, bn(conv(x)), atol=1e-5)
 
 
+def test_fragment_blocked_weight_planes_hold_the_mfma_operand_of_every_lane():
+    """packing.PW.frag() (include/pfpp.h pfpp_pw.fhi / flo, read by csrc/lnlin_small.hip and csrc/gemm_small.hip): block (row tile r,
+    k-step s) is the B operand of one v_mfma_f32_32x32x16_f16 as its 64 lanes hold it — lane 32 h + n has W[32 r + n][16 s + 8 h .. + 8) —
+    blocks ordered [r][s], 1 KB each, nothing added or dropped; weights whose shape does not tile are refused"""
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(96, 64, generator=g)
+    pw = PW(w)
+    fh, fl = pw.frag()
+    assert fh.is_contiguous() and fh.shape == (3, 4, 2, 32, 8) and fh.dtype == torch.float16 and fl.shape == fh.shape
+    flat_h, flat_l = fh.reshape(-1, 64, 8), fl.reshape(-1, 64, 8)          # [block][lane][8 halfs]
+    for r, s_, lane in ((0, 0, 0), (2, 3, 63), (1, 2, 37), (0, 1, 32)):
+        n, h = lane % 32, lane // 32
+        blk = r * 4 + s_
+        assert torch.equal(flat_h[blk, lane], pw.hi[32 * r + n, 16 * s_ + 8 * h: 16 * s_ + 8 * h + 8])
+        assert torch.equal(flat_l[blk, lane], pw.lo[32 * r + n, 16 * s_ + 8 * h: 16 * s_ + 8 * h + 8])
+    assert torch.equal(fh.permute(0, 3, 1, 2, 4).reshape(96, 64), pw.hi)       # a permutation of the plane
+    assert pw.frag()[0] is fh                                                  # built once
+    with pytest.raises(ValueError):
+        PW(torch.randn(40, 64, generator=g)).frag()
+    with pytest.raises(ValueError):
+        PW(torch.randn(32, 147, generator=g)).frag()
+
+
 def test_plane_scale_and_prescaled_weight_planes():
     """packing.plane_scale: a power of two that lifts max |w| into [2^12, 2^13); PW planes then stand for scale * w to 22 bits whatever
     the tensor's magnitude, and nothing reaches the fp16 overflow"""
