@@ -916,6 +916,8 @@ int pfpp_layernorm_linear_small(const float* x, const float* mod, int64_t ld_mod
 typedef struct pfpp_head_params {
   pfpp_planes w0, w2;                         /* [C, C], [C/2, C] */
   const float *w4, *b0, *b2, *b4;             /* [3 | 4, C/2], [C], [C/2], [3 | 4] */
+  pfpp_planes f0, f2;                         /* optional (hi == NULL: absent): w0 / w2 fragment-blocked as pfpp_pw.fhi / flo — static (eval)
+                                                 weights; pfpp_heads_fwd then loads the MFMA operands with fully coalesced instructions */
 } pfpp_head_params;
 typedef struct pfpp_head_grads { float *w4, *b4, *b2, *b0; } pfpp_head_grads;
 int pfpp_heads_fwd(const float* pooled, const pfpp_head_params* trans, const pfpp_head_params* rot, int64_t R, int64_t C,

@@ -32,6 +32,7 @@ __device__ __forceinline__ float silu_grad(float v) {
 
 struct HeadW {
   const _Float16 *w0h, *w0l, *w2h, *w2l;   // planes of scale * W0 [HC, HC], scale * W2 [HC2, HC] (row-major [out, in])
+  const half8 *f0h, *f0l, *f2h, *f2l;      // the same planes fragment-blocked (pfpp_pw.fhi / flo layout) or null: static weights
   const float *w4, *b0, *b2, *b4;          // W4 [n_out, HC2] fp32, biases
   float inv_s0, inv_s2;                    // 1 / plane scale
   int n_out, c0;                           // 3 | 4 output columns starting at column c0 of the 7-wide prediction
@@ -101,6 +102,52 @@ __device__ __forceinline__ void contract_rowmajor(const _Float16* sh, const _Flo
   }
 }
 
+// The same contraction with the weights read from their fragment-blocked planes (eval: static weights, packing.PW.frag()): block (row
+// tile, k-step) = the 64 lanes' B operands of one MFMA, 1 KB contiguous — one fully coalesced load per operand, where the row-major
+// form above pulls 32 lines per instruction through the L1 (measured on 8-20 pooled rows: 56 us for the launch, two workgroups
+// streaming 1.5 MB each).  tile0 = first 32-row tile of the weight; groups of four steps, one group in flight.
+template <int NT>
+__device__ __forceinline__ void contract_frag(const _Float16* sh, const _Float16* sl, const half8* __restrict__ fh, const half8* __restrict__ fl,
+                                              int K, int tile0, f32x16 (&acc)[NT]) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const half8* ah = reinterpret_cast<const half8*>(sh + l31 * KP + 8 * lhi);
+  const half8* al = reinterpret_cast<const half8*>(sl + l31 * KP + 8 * lhi);
+  const int S = K / 16, NG = K / 64;
+  half8 bh[2][4][NT], bl[2][4][NT];
+  auto fetch = [&](int g, int slot) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t blk = (size_t)(tile0 + j) * S + 4 * g + u;
+        bh[slot][u][j] = fh[blk * 64 + lane];
+        bl[slot][u][j] = fl[blk * 64 + lane];
+      }
+  };
+  fetch(0, 0);
+  for (int g = 0; g < NG; g += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int gg = g + half;
+      if (gg < NG) {
+        fetch(gg + 1 < NG ? gg + 1 : NG - 1, half ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const half8 a_h = ah[2 * (4 * gg + u)], a_l = al[2 * (4 * gg + u)];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, bh[half][u][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, bl[half][u][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, bh[half][u][j], acc[j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void zero(f32x16& a) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) a[e] = 0.0f;
@@ -128,7 +175,8 @@ __global__ __launch_bounds__(64 * NW) void heads_fwd_kernel(HeadsFwdP p) {
   {
     f32x16 acc[2];
     zero(acc[0]); zero(acc[1]);
-    contract_rowmajor<2>(sh, sl, w.w0h, w.w0l, HC, HC, 64 * wave, acc);
+    if (w.f0h) contract_frag<2>(sh, sl, w.f0h, w.f0l, HC, 2 * wave, acc);
+    else contract_rowmajor<2>(sh, sl, w.w0h, w.w0l, HC, HC, 64 * wave, acc);
     __syncthreads();                                   // every wave has read the input planes
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -155,7 +203,8 @@ __global__ __launch_bounds__(64 * NW) void heads_fwd_kernel(HeadsFwdP p) {
   {
     f32x16 acc[1];
     zero(acc[0]);
-    contract_rowmajor<1>(sh, sl, w.w2h, w.w2l, HC, HC, 32 * wave, acc);
+    if (w.f2h) contract_frag<1>(sh, sl, w.f2h, w.f2l, HC, wave, acc);
+    else contract_rowmajor<1>(sh, sl, w.w2h, w.w2l, HC, HC, 32 * wave, acc);
     __syncthreads();
     float* sv = reinterpret_cast<float*>(hd_smem);     // v1 [32][HC2 + 1] fp32 for the last layer
     const int col = 32 * wave + l31;
@@ -404,6 +453,9 @@ bool fill_head(HeadW& w, const pfpp_head_params& h, int n_out, int c0) {
   if (!(h.w0.hi && h.w0.lo && h.w2.hi && h.w2.lo && h.w4 && h.b0 && h.b2 && h.b4)) return false;
   w.w0h = (const _Float16*)h.w0.hi; w.w0l = (const _Float16*)h.w0.lo;
   w.w2h = (const _Float16*)h.w2.hi; w.w2l = (const _Float16*)h.w2.lo;
+  const bool frag = h.f0.hi && h.f0.lo && h.f2.hi && h.f2.lo;
+  w.f0h = frag ? (const half8*)h.f0.hi : nullptr; w.f0l = frag ? (const half8*)h.f0.lo : nullptr;
+  w.f2h = frag ? (const half8*)h.f2.hi : nullptr; w.f2l = frag ? (const half8*)h.f2.lo : nullptr;
   w.w4 = h.w4; w.b0 = h.b0; w.b2 = h.b2; w.b4 = h.b4;
   w.inv_s0 = 1.0f / h.w0.scale; w.inv_s2 = 1.0f / h.w2.scale;
   w.n_out = n_out; w.c0 = c0;

@@ -134,7 +134,7 @@ class TlayersEvalArgs(C.Structure):
 class HeadParams(C.Structure):
     """mirror of struct pfpp_head_params (include/pfpp.h)"""
 
-    _fields_ = [("w0", PlanesC), ("w2", PlanesC), ("w4", _p), ("b0", _p), ("b2", _p), ("b4", _p)]
+    _fields_ = [("w0", PlanesC), ("w2", PlanesC), ("w4", _p), ("b0", _p), ("b2", _p), ("b4", _p), ("f0", PlanesC), ("f2", PlanesC)]
 
 
 class HeadGrads(C.Structure):

@@ -68,7 +68,7 @@ def _fused_heads(pk, pooled, out, slot32=None) -> bool:
     hp = pk.get("_heads")
     if hp is None:
         hp = pk["_heads"] = tuple(T.head_params(pk[f"{n}.0.w"], pk[f"{n}.2.w"], pk[f"{n}.4.w"].f32, pk[f"{n}.0.b"], pk[f"{n}.2.b"],
-                                                pk[f"{n}.4.b"]) for n in ("mlp_out_trans", "mlp_out_rot"))
+                                                pk[f"{n}.4.b"], static=True) for n in ("mlp_out_trans", "mlp_out_rot"))
     T.heads_fwd(pooled, hp[0], hp[1], out, slot=slot32)
     return True
 

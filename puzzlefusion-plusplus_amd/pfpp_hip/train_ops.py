@@ -598,14 +598,19 @@ def attn_blockdiag_bwd_planes(qkv, dout, n_frag: int, L: int, H: int, dh: int, s
 # ------------------------------------------------------------------------------------------------------------------
 # the two output heads as one launch each way (csrc/heads.hip; denoiser_transformer.py:138-147)
 # ------------------------------------------------------------------------------------------------------------------
-def head_params(w0, w2, w4: torch.Tensor, b0: torch.Tensor, b2: torch.Tensor, b4: torch.Tensor):
-    """pfpp_head_params of one head: w0 / w2 = packing.PW (planes of scale * W), the last layer and the biases in fp32"""
+def head_params(w0, w2, w4: torch.Tensor, b0: torch.Tensor, b2: torch.Tensor, b4: torch.Tensor, static: bool = False):
+    """pfpp_head_params of one head: w0 / w2 = packing.PW (planes of scale * W), the last layer and the biases in fp32.
+    static (eval: the weights do not change under the struct): also their fragment-blocked planes (PW.frag)"""
     from ._lib import HeadParams, PlanesC
 
     for t_, nm in ((w4, "w4"), (b0, "b0"), (b2, "b2"), (b4, "b4")):
         _chk(t_, _f32, nm)
+    f0 = f2 = PlanesC(None, None, 0.0)
+    if static:
+        (h0, l0), (h2, l2) = w0.frag(), w2.frag()
+        f0, f2 = PlanesC(h0.data_ptr(), l0.data_ptr(), w0.scale), PlanesC(h2.data_ptr(), l2.data_ptr(), w2.scale)
     return HeadParams(PlanesC(w0.hi.data_ptr(), w0.lo.data_ptr(), w0.scale), PlanesC(w2.hi.data_ptr(), w2.lo.data_ptr(), w2.scale),
-                      w4.data_ptr(), b0.data_ptr(), b2.data_ptr(), b4.data_ptr())
+                      w4.data_ptr(), b0.data_ptr(), b2.data_ptr(), b4.data_ptr(), f0, f2)
 
 
 def heads_fwd(pooled: torch.Tensor, trans, rot, out: torch.Tensor, slot: Optional[torch.Tensor] = None, save: bool = False):

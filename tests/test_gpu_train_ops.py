@@ -690,6 +690,14 @@ def test_fused_output_heads_forward_and_backward_vs_float64(dev, R):
     for k in range(4):
         for hd in range(2):
             assert rel_err(saved[k][hd], inter[hd][k].detach()) < 2e-6, (k, hd)
+    # eval form: weights static -> read from their fragment-blocked planes (same products, another order of the k-steps)
+    st_structs = [T.head_params(pw0, pw2, *dev_t[2:], static=True) for (_, pw0, pw2, dev_t) in structs]
+    out_s = torch.zeros(R + 7, 7, device=dev)
+    T.heads_fwd(pooled.to(dev), st_structs[0], st_structs[1], out_s, slot=perm.to(dev))
+    assert rel_err(out_s.cpu()[perm.long()], want.detach()) < 2e-6 and float(out_s.cpu()[untouched].abs().max()) == 0.0
+    out_s2 = torch.zeros(R + 7, 7, device=dev)
+    T.heads_fwd(pooled.to(dev), st_structs[0], st_structs[1], out_s2, slot=perm.to(dev))
+    assert torch.equal(out_s2, out_s)
     dout = torch.randn(R, 7, generator=g) * 1e-3
     want.backward(dout.double())
     da0, da1, dx = T.heads_bwd(dout.to(dev), structs[0][0], structs[1][0], saved, gstructs[0], gstructs[1], G, L)
