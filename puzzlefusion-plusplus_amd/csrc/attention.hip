@@ -440,6 +440,236 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// SHORT sequences, few of them (one puzzle in flight: 100-500 tokens, one sequence): the kernel above gives a head ONE workgroup
+// per 128 queries whose four waves walk the key tiles together, a barrier per tile — 8-16 workgroups on the chip and 4-16
+// dependent tile steps (12-19 us per launch, six launches per DDPM step).  Here a workgroup owns 32 queries and its four waves
+// split the KEYS: wave w takes key tiles w, w + 4, ... with a private LDS slot (it loads, converts and reads back its own tile:
+// no workgroup barrier in the walk), then the four partial (max, sum, O) are merged in wave order through LDS — the
+// online-softmax merge, deterministic.  4x the workgroups, a quarter of the dependent steps.  Same products as the kernel
+// above, another association of the sums: equal to it to fp32 rounding.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dense_short_kernel(
+    const float* __restrict__ qkv, float* __restrict__ out, _Float16* __restrict__ out_hi,
+    _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
+    const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
+    int H, float scale) {
+  constexpr int KT = 32, NDT = DH / 32;
+  constexpr int LDKH = DH + 8, LDVH = KT + 8;
+  constexpr int F4 = KT * DH / 4 / 64;               // float4 pieces of a K (or V) tile per lane
+  constexpr int SLOT = 2 * KT * LDKH + 2 * DH * LDVH;        // halfs per wave slot: Kh | Kl | Vh | Vl
+  constexpr int OP = DH + 4;                         // floats per query row of the merge buffer
+  extern __shared__ __align__(16) char as_smem[];
+  _Float16* slots = reinterpret_cast<_Float16*>(as_smem);
+  float* ob = reinterpret_cast<float*>(as_smem + (size_t)4 * SLOT * sizeof(_Float16));     // [4 waves][32 queries][OP]
+  float* ms = ob + 4 * 32 * OP;                      // [4][32] running maxima, [4][32] sums
+  float* ls = ms + 4 * 32;
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = seq_len[b];
+  const int q_base = blockIdx.x * 32;
+  if (q_base >= T) return;
+  const int64_t row0 = seq_off[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int C = H * DH;
+  const int64_t ld = 3ll * C;
+  const float* base = qkv + row0 * ld + h * DH;
+  const uint8_t* kv = key_valid ? key_valid + (int64_t)b * kv_stride : nullptr;
+  _Float16* Kh = slots + wave * SLOT;
+  _Float16* Kl = Kh + KT * LDKH;
+  _Float16* Vh = Kl + KT * LDKH;
+  _Float16* Vl = Vh + DH * LDVH;
+
+  const int q_row = q_base + l31;                    // every wave holds the same 32 queries
+  const float* qp = base + (int64_t)min(q_row, T - 1) * ld + lhi * 8;
+  const float qs = scale * 1.44269504088896340736f;  // log2 domain, as above
+  ad_half8 qh[DH / 16], ql[DH / 16];
+#pragma unroll
+  for (int c = 0; c < DH / 16; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(qp + c * 16);
+    const float4 bq = *reinterpret_cast<const float4*>(qp + c * 16 + 4);
+    const float x[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, bq.x * qs, bq.y * qs, bq.z * qs, bq.w * qs};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 hh, ll;
+      ad_split(x[e], hh, ll);
+      qh[c][e] = hh; ql[c][e] = ll;
+    }
+  }
+  f32x16 o_acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  float4 rk[F4], rv[F4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = lane + 64 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float* src = base + (int64_t)min(k0 + r, T - 1) * ld + C + c4 * 4;
+      rk[it] = *reinterpret_cast<const float4*>(src);
+      rv[it] = *reinterpret_cast<const float4*>(src + C);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = lane + 64 * it;
+      const int r = idx / (DH / 4), c4 = idx % (DH / 4);
+      const float kx[4] = {rk[it].x, rk[it].y, rk[it].z, rk[it].w};
+      const float vx[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+      ad_half4 kh4, kl4, vh4, vl4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 hh, ll;
+        ad_split(kx[j], hh, ll);
+        kh4[j] = hh; kl4[j] = ll;
+        ad_split(vx[j], hh, ll);
+        vh4[j] = hh; vl4[j] = ll;
+      }
+      *reinterpret_cast<ad_half4*>(&Kh[r * LDKH + c4 * 4]) = kh4;
+      *reinterpret_cast<ad_half4*>(&Kl[r * LDKH + c4 * 4]) = kl4;
+      // V transposed ([dim][key]) exactly as in attn_dense_f16_kernel: rows r and r + 1 are DH / 4 lanes apart
+      union { ad_half4 h; int2 i; } uh, ul;
+      uh.h = vh4; ul.h = vl4;
+      const bool odd = r & 1;
+      const int keep_h = odd ? uh.i.y : uh.i.x, send_h = odd ? uh.i.x : uh.i.y;
+      const int keep_l = odd ? ul.i.y : ul.i.x, send_l = odd ? ul.i.x : ul.i.y;
+      const int got_h = __shfl_xor(send_h, DH / 4), got_l = __shfl_xor(send_l, DH / 4);
+      const int a_h = odd ? got_h : keep_h, b_h = odd ? keep_h : got_h;
+      const int a_l = odd ? got_l : keep_l, b_l = odd ? keep_l : got_l;
+      const int d0 = c4 * 4 + (odd ? 2 : 0), r0 = r & ~1;
+      *reinterpret_cast<int*>(&Vh[ad_toff(d0, r0)]) = (a_h & 0xffff) | (b_h << 16);
+      *reinterpret_cast<int*>(&Vh[ad_toff(d0 + 1, r0)]) = ((unsigned)a_h >> 16) | (b_h & 0xffff0000);
+      *reinterpret_cast<int*>(&Vl[ad_toff(d0, r0)]) = (a_l & 0xffff) | (b_l << 16);
+      *reinterpret_cast<int*>(&Vl[ad_toff(d0 + 1, r0)]) = ((unsigned)a_l >> 16) | (b_l & 0xffff0000);
+    }
+  };
+
+  const int nt = (T + KT - 1) / KT;
+  if (wave < nt) load_tile(wave * KT);
+  for (int t = wave; t < nt; t += 4) {
+    const int k0 = t * KT;
+    store_tile();
+    __builtin_amdgcn_wave_barrier();
+    load_tile(min(k0 + 4 * KT, (nt - 1) * KT));      // unconditional: the next tile of this wave (or a harmless re-read)
+
+    const int kidx = k0 + l31;
+    const bool kval = kidx < T && (!kv || kv[kidx] != 0);
+    const unsigned kmask = (unsigned)(__ballot(kval) & 0xffffffffull);
+    f32x16 sc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DH / 16; ++c) {
+      const ad_half8 kh = *reinterpret_cast<const ad_half8*>(&Kh[l31 * LDKH + c * 16 + lhi * 8]);
+      const ad_half8 kl = *reinterpret_cast<const ad_half8*>(&Kl[l31 * LDKH + c * 16 + lhi * 8]);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], sc, 0, 0, 0);
+    }
+    float mx = -__builtin_huge_valf();
+    if (kmask == 0xffffffffu) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const float v = (kmask >> key) & 1u ? sc[e] : -__builtin_huge_valf();
+        sc[e] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    float psum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(sc[e] - m_new);
+      sc[e] = pe;
+      psum += pe;
+    }
+    if (__ballot(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+    }
+    l_run += psum;
+    m_run = m_new;
+    ad_half8 ph[2], pl[2];
+    score_to_fragments(sc, lhi, ph, pl);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const ad_half8 vh = *reinterpret_cast<const ad_half8*>(&Vh[ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
+        const ad_half8 vl = *reinterpret_cast<const ad_half8*>(&Vl[ad_toff(dt * 32 + l31, g * 16 + lhi * 8)]);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[g], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[g], o_acc[dt], 0, 0, 0);
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[g], o_acc[dt], 0, 0, 0);
+      }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- merge the four waves' partial softmaxes (wave order): lane holds O[query = l31][d = dt*32 + 8g + 4*lhi + (0..3)]
+  const float l_w = l_run + __shfl_xor(l_run, 32);
+  if (lhi == 0) { ms[wave * 32 + l31] = m_run; ls[wave * 32 + l31] = l_w; }
+  __syncthreads();
+  {
+    const float m0 = ms[l31], m1 = ms[32 + l31], m2 = ms[64 + l31], m3 = ms[96 + l31];
+    const float m_all = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float f = __builtin_amdgcn_exp2f(m_run - m_all);        // 0 for a wave that saw no key (m_run = -1e30)
+    float* orow = ob + (wave * 32 + l31) * OP;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(orow + dt * 32 + 8 * g + 4 * lhi) =
+            make_float4(o_acc[dt][4 * g + 0] * f, o_acc[dt][4 * g + 1] * f, o_acc[dt][4 * g + 2] * f, o_acc[dt][4 * g + 3] * f);
+  }
+  __syncthreads();
+  // thread -> query tid / 8, dims (DH / 8) * (tid % 8) .. + DH / 8
+  constexpr int DPT = DH / 8;
+  const int q = tid >> 3, d0 = (tid & 7) * DPT;
+  if (q_base + q < T) {
+    float mw[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = ms[w * 32 + q]; lw[w] = ls[w * 32 + q]; }
+    const float m_all = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+    float l_tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) l_tot += lw[w] * __builtin_amdgcn_exp2f(mw[w] - m_all);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    const int64_t off = (row0 + q_base + q) * (int64_t)C + h * DH + d0;
+#pragma unroll
+    for (int j = 0; j < DPT; j += 4) {
+      float4 v = *reinterpret_cast<const float4*>(ob + q * OP + d0 + j);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 t4 = *reinterpret_cast<const float4*>(ob + (w * 32 + q) * OP + d0 + j);
+        v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+      }
+      v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+      if (out_hi) {
+        ad_half4 hi, lo;
+        PFPP_SPLIT_TO(v.x, hi[0], lo[0]); PFPP_SPLIT_TO(v.y, hi[1], lo[1]); PFPP_SPLIT_TO(v.z, hi[2], lo[2]); PFPP_SPLIT_TO(v.w, hi[3], lo[3]);
+        *reinterpret_cast<ad_half4*>(out_hi + off + j) = hi;
+        *reinterpret_cast<ad_half4*>(out_lo + off + j) = lo;
+      }
+      if (out) *reinterpret_cast<float4*>(out + off + j) = v;
+    }
+  }
+}
+
 }  // namespace
 
 static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Float16* out_lo, const int32_t* seq_off,
@@ -509,6 +739,22 @@ static int attn_dense_impl(const float* qkv, float* out, _Float16* out_hi, _Floa
     else
       hipLaunchKernelGGL((attn_dense_f16_kernel<32, true>), grid, dim3(256), 0, st, qkv, out, out_hi, out_lo, seq_off, seq_len,
                          key_valid, kv_stride, (int)H, scale, lse);
+    return pfpp::check_launch("pfpp_attn_dense");
+  }
+  // few short sequences (one puzzle in flight): keys split over the waves of 32-query workgroups (attn_dense_short_kernel)
+  const char* short_env = getenv("PFPP_ATTN_SHORT_MAX");          // (read per call: the tests compare both kernels in one process)
+  const int short_max = short_env ? atoi(short_env) : 512;
+  if (dh == 64 && f16x3 && !lse && max_len <= short_max && (int64_t)grid.x * H * n_seq <= 64) {
+    constexpr size_t smem = (size_t)4 * (2 * 32 * (64 + 8) + 2 * 64 * (32 + 8)) * sizeof(_Float16) + (size_t)(4 * 32 * (64 + 4) + 8 * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)attn_dense_short_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return pfpp::check_launch("pfpp_attn_dense");
+      attr_set = true;
+    }
+    const dim3 g32((unsigned)((max_len + 31) / 32), (unsigned)H, (unsigned)n_seq);
+    hipLaunchKernelGGL(attn_dense_short_kernel<64>, g32, dim3(256), smem, st, qkv, out, out_hi, out_lo, seq_off, seq_len, key_valid, kv_stride,
+                       (int)H, scale);
     return pfpp::check_launch("pfpp_attn_dense");
   }
   if (dh == 64 && f16x3)

@@ -335,6 +335,51 @@ def test_attn_dense_fused_vs_float64_and_unfused(dev, B, T, H, dh):
             assert (out3[o:o + L].cpu().double() - r).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("lens,masked", [((25,), False), ((100,), False), ((250,), True), ((500,), False), ((333, 75), True), ((1,), False)])
+def test_attn_dense_short_sequences_keys_split_over_the_waves(dev, lens, masked, monkeypatch):
+    """csrc/attention.hip attn_dense_short_kernel (one puzzle in flight: a few sequences of <= 512 tokens; 32-query workgroups whose
+    four waves split the key tiles and merge their partial softmaxes in wave order) against float64, against the tile-walking kernel it
+    replaces there (PFPP_ATTN_SHORT_MAX=0) and twice (deterministic); fp32 output and plane output"""
+    from pfpp_hip import ops
+
+    H, dh = 8, 64
+    C = H * dh
+    g = torch.Generator().manual_seed(sum(lens) + len(lens))
+    rows = sum(lens)
+    qkv = torch.randn(rows, 3 * C, generator=g)
+    offs = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=torch.int32)
+    ln = torch.tensor(lens, dtype=torch.int32)
+    max_len = max(lens)
+    valid = None
+    if masked:
+        valid = torch.rand(len(lens), max_len, generator=g) < 0.6
+        valid[0, :40] = False
+        valid[:, 0 if max_len < 41 else 40] = True
+        for i, L in enumerate(lens):
+            valid[i, L - 1] = True
+    kv = None if valid is None else valid.to(torch.uint8).to(dev)
+    scale = 1.0 / dh ** 0.5
+    qd = qkv.to(dev)
+    monkeypatch.setenv("PFPP_ATTN_SHORT_MAX", "512")
+    out = ops.attn_dense(qd, offs.to(dev), ln.to(dev), max_len, H, dh, scale, kv)
+    out_b = ops.attn_dense(qd, offs.to(dev), ln.to(dev), max_len, H, dh, scale, kv)
+    pl = ops.SplitAct.empty(rows, C, dev)
+    ops.attn_dense(qd, offs.to(dev), ln.to(dev), max_len, H, dh, scale, kv, out=pl)
+    monkeypatch.setenv("PFPP_ATTN_SHORT_MAX", "0")
+    walk = ops.attn_dense(qd, offs.to(dev), ln.to(dev), max_len, H, dh, scale, kv)
+    assert torch.equal(out, out_b)
+    assert (out - walk).abs().max() < 2e-6 * max(1.0, float(walk.abs().max()))
+    assert (pl.float() - out).abs().max() < 1e-6 * max(1.0, float(out.abs().max()))
+    for i, L in enumerate(lens):
+        o = int(offs[i])
+        q, k, v = (t[o:o + L].view(L, H, dh).transpose(0, 1).double() for t in qkv.chunk(3, dim=-1))
+        sc = q @ k.transpose(-1, -2) * scale
+        if valid is not None:
+            sc = sc.masked_fill(~valid[i, :L][None, None, :], float("-inf"))
+        r = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(L, C)
+        assert (out[o:o + L].cpu().double() - r).abs().max() < 2e-5
+
+
 # ----------------------------------------------------------------------------- transformer / scheduler / verifier
 def test_denoiser_vs_golden(golden, weights_sd, dev):
     from pfpp_hip import denoiser as D

@@ -15,7 +15,7 @@ c = sqlite3.connect(db)
 cur = c.execute("select * from kernels limit 1")
 cols = [d[0] for d in cur.description]
 print(cols)
-q = "select name, grid_x, grid_y, count(*), avg(end - start) / 1000.0 from kernels where name like '%gemm_pl_kernel<1, 1, 2, 1%' or name like '%lnlin%' or name like '%gemm_small%' or name like '%attn_dense_f16%' group by name, grid_x, grid_y order by name, grid_x"
+q = "select name, grid_x, grid_y, count(*), avg(end - start) / 1000.0 from kernels where name like '%gemm_pl_kernel<1, 1, 2, 1%' or name like '%lnlin%' or name like '%gemm_small%' or name like '%attn_dense%' group by name, grid_x, grid_y order by name, grid_x"
 try:
     for r in c.execute(q): print(r[0][:60], r[1:])
 except Exception as e:
