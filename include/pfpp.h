@@ -889,8 +889,8 @@ int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
  * mode).  mod [B, 2C] (scale | shift) with group_batch / group_rows as in pfpp_layernorm_grouped, or gamma / beta.  Plain form: out
  * [M, ldc] fp32.  GEGLU form (u_planes set; w = packed 32 value | 32 gate rows, bias packed likewise): u = (v + b_v) * gelu(g + b_g)
  * as planes [M, ldu], N = 2 * inner.  C = 512, N % 64 == 0.  LayerNorm arithmetic = pfpp_layernorm*; the contraction is summed in a
- * different (fixed) order than pfpp_gemm's: equal to the two-launch path to fp32 rounding.  pfpp_tlayers_eval uses it for M <= 512
- * (lnlin_max_rows; 0 = never).                                                                                                  */
+ * different (fixed) order than pfpp_gemm's: equal to the two-launch path to fp32 rounding.  pfpp_tlayers_eval uses it for M <= lnlin_max_rows
+ * (pfpp_hip passes 2048: up to there the few-token kernels beat the tiled GEMMs in the auto_aggl loop; 0 = never).                                                                                                  */
 /* Plane GEMM for few rows: out [M, ldc] = A . W^T / (A.scale * w.scale) + bias + residual, A = planes [M, lda] of a [M, K] operand, w
  * with its fragment-blocked planes (fhi / flo).  The out-projections of both attentions and the second feed-forward linear with their
  * residual adds (attention.py:77-90), eval mode; out may be the residual (in place).  K % 512 == 0, N % 32 == 0.  Same products as

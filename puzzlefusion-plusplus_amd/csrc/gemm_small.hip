@@ -1,4 +1,4 @@
-// Plane GEMM for FEW rows (one puzzle in flight: 25-500 tokens): out = A . W^T / scale + bias + residual.
+// Plane GEMM for FEW rows (one to a few puzzles in flight: 25-2,000 tokens): out = A . W^T / scale + bias + residual.
 //
 // Reference: the out-projections of the two attentions and the second feed-forward linear of EncoderLayer.forward
 // (denoiser/model/modules/attention.py:77-90: attn.to_out[0], ff.net[2], each followed by the residual add), eval mode, as sequenced

@@ -1,10 +1,11 @@
-// LayerNorm (AdaLN or affine) fused into the linear layer that follows it, for SMALL token counts (one puzzle in flight: 25-500 tokens).
+// LayerNorm (AdaLN or affine) fused into the linear layer that follows it, for SMALL token counts (one to a few puzzles in flight:
+// 25-2,000 tokens; pfpp_hip hands over to the tiled GEMMs above 2,048, measured in the auto_aggl loop with 2-32 puzzles in flight).
 //
 // Reference: MyAdaLayerNorm / nn.LayerNorm followed by to_q|to_k|to_v resp. the GEGLU projection in EncoderLayer.forward
 // (denoiser/model/modules/attention.py:21-25, 77-90), eval mode, as issued by pfpp_hip.denoiser.denoiser_forward_compact.
 //
 // Why: with one puzzle in flight the DDPM step is ~100 dependent launches of 5-17 us; 18 of them are LayerNorms of 5 us + a launch gap
-// each, every one followed by a GEMM whose A operand they produce.  For <= 512 tokens the normalised rows need not exist in HBM at all
+// each, every one followed by a GEMM whose A operand they produce.  For few tokens the normalised rows need not exist in HBM at all
 // (no backward, nothing else reads them): a workgroup normalises its 32 rows itself, keeps them in LDS as split-f16 planes and contracts
 // them with its share of the weight columns.
 //

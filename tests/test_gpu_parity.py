@@ -1329,7 +1329,7 @@ def test_small_puzzle_forward_fused_heads_equal_layerwise(weights_sd, dev, parts
     assert (got_all - want_all).abs().max() <= 1e-5 * max(1.0, float(want_all.abs().max()))
 
 
-@pytest.mark.parametrize("M", [25, 125, 500, 333])
+@pytest.mark.parametrize("M", [25, 125, 500, 333, 1500])
 def test_layernorm_linear_small_vs_float64(dev, M):
     """csrc/lnlin_small.hip: LayerNorm (AdaLN with a per-fragment batch map, and affine) fused into the following linear for few rows —
     the plain form against float64, and the GEGLU form (packed value | gate weights) against LayerNorm + the packed GEGLU GEMM it replaces"""
@@ -1375,7 +1375,7 @@ def test_layernorm_linear_small_vs_float64(dev, M):
     assert float((u.float().double().cpu() - want_u).abs().max() / want_u.abs().max()) < 2e-5          # (weights rounded to 22 bits)
 
 
-@pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512)])
+@pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512), (2000, 512, 2048)])
 def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
     """csrc/gemm_small.hip (out-projections / second feed-forward linear of a few-token step): A planes . fragment-blocked weight planes
     + bias + residual, in place — against float64 of the values the planes stand for, against the tiled plane GEMM it replaces
@@ -1453,7 +1453,7 @@ def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, 
                     outs.append(m(x, ts, latent, xyz, valid_d, scale, ref_d))
             # default: for <= 512 tokens the LayerNorms ride in the GEMMs that consume them (csrc/lnlin_small.hip): same LayerNorm
             # bits, another summation order in the contraction -> equal to fp32 rounding, and deterministic
-            monkeypatch.setenv("PFPP_EVAL_LNLIN_ROWS", "512")
+            monkeypatch.setenv("PFPP_EVAL_LNLIN_ROWS", "2048")
             with torch.no_grad():
                 fused = [m(x, ts, latent, xyz, valid_d, scale, ref_d) for _ in range(2)]
             torch.cuda.synchronize()
