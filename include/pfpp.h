@@ -891,6 +891,15 @@ int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
  * as planes [M, ldu], N = 2 * inner.  C = 512, N % 64 == 0.  LayerNorm arithmetic = pfpp_layernorm*; the contraction is summed in a
  * different (fixed) order than pfpp_gemm's: equal to the two-launch path to fp32 rounding.  pfpp_tlayers_eval uses it for M <= lnlin_max_rows
  * (pfpp_hip passes 2048: up to there the few-token kernels beat the tiled GEMMs in the auto_aggl loop; 0 = never).                                                                                                  */
+/* Token embedding for few tokens, one launch (denoiser_transformer.py:117-135, 150-156, 173-185; EmbedderNerf, utils/model_utils.py:68-69):
+ * tok[(f, l), :] = shape_embedding([latent | PE(xyz) | PE(scale)]) + param_fc(PE(x_f)) + ref_part_emb[ref_f] + pe[frag_pos_f] for the n listed
+ * fragments (slot: listed fragment -> slot of latent / xyz / scale / x / ref_part, or NULL).  w_cat = the CONCATENATED weight
+ * [W_shape (148 columns) | W_param (147) | 0 ... ] [C, 320] with its fragment-blocked planes, bias = shape bias + param bias.  Replaces
+ * pfpp_token_features + two pfpp_gemm + pfpp_token_combine for small n L (pfpp_hip: <= 2,048 tokens); equal to them to fp32 rounding
+ * (both linear layers share one accumulation).  L >= 11, C % 32 == 0.                                                                */
+int pfpp_embed_tokens_small(const float* latent, const float* xyz, const float* scale, const float* x, const int32_t* slot,
+                            const pfpp_pw* w_cat, const float* bias, const float* ref_emb, const uint8_t* ref_part, const float* pe,
+                            const int32_t* frag_pos, float* tok, int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
 /* Plane GEMM for few rows: out [M, ldc] = A . W^T / (A.scale * w.scale) + bias + residual, A = planes [M, lda] of a [M, K] operand, w
  * with its fragment-blocked planes (fhi / flo).  The out-projections of both attentions and the second feed-forward linear with their
  * residual adds (attention.py:77-90), eval mode; out may be the residual (in place).  K % 512 == 0, N % 32 == 0.  Same products as

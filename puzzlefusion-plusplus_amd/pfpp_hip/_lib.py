@@ -184,6 +184,7 @@ class TlayersArgs(C.Structure):
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
     "pfpp_tlayers_eval": [C.POINTER(TlayersEvalArgs), _p],
+    "pfpp_embed_tokens_small": [_p, _p, _p, _p, _p, C.POINTER(PwC), _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_gemm_small": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_layernorm_linear_small": [_p, _p, _i64, _p, _p, _p, _i64, C.POINTER(PwC), _p, _p, _i64, _pl, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],

@@ -10,6 +10,7 @@ down-projection (+bias, +residual).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -26,6 +27,14 @@ def pack_denoiser(sd: Dict[str, torch.Tensor], num_layers: int) -> Dict[str, tor
     pk["param.w"] = PW(sd["param_fc.weight"])
     pk["param.b"] = sd["param_fc.bias"].contiguous()
     pk["ref_emb"] = sd["ref_part_emb.weight"].contiguous()
+    # both embedding layers as ONE weight for the few-token kernel (csrc/embed_small.hip): [W_shape (148) | W_param (147) | 0] [C, 320]
+    ws, wp = sd["shape_embedding.weight"], sd["param_fc.weight"]
+    if ws.shape[1] == 148 and wp.shape[1] == 147:
+        wc = ws.new_zeros((ws.shape[0], 320))
+        wc[:, :148] = ws
+        wc[:, 148:295] = wp
+        pk["embed.w"] = PW(wc)
+        pk["embed.b"] = (sd["shape_embedding.bias"] + sd["param_fc.bias"]).contiguous()
     pk["pe"] = sd["pos_encoding.pe"][0].contiguous()
     tabs, lw, lb = [], [], []
     for i in range(num_layers):
@@ -267,13 +276,21 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
     M = Fv * L
     # the valid-fragment gather of the inputs happens inside the kernels (slot32): no gathered copies
     f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
-    sf, pf = ops.token_features(f32(latent).reshape(n_slots, L, -1), f32(xyz).reshape(n_slots, L, 3), f32(scale).reshape(n_slots),
-                                f32(x).reshape(n_slots, 7), slot=lay.slot32)
-    shape_emb = ops.linear(sf, pk["shape.w"], pk["shape.b"])
-    x_emb = ops.linear(pf, pk["param.w"], pk["param.b"])
     rp = ref_part.reshape(n_slots)
     ref_u8 = rp.contiguous().view(torch.uint8) if rp.dtype == torch.bool else (rp if rp.dtype == torch.uint8 else (rp != 0).to(torch.uint8)).contiguous()
-    h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p, L, slot=lay.slot32)
+    few = int(os.environ.get("PFPP_EVAL_LNLIN_ROWS", "2048"))
+    if (M <= few and "embed.w" in pk and ops.split_mode() and not ops.SINGLE_PASS and ops.GEMM_TRACE is None and L >= 11 and latent.shape[-1] == 64
+            and os.environ.get("PFPP_EMBED_FUSED", "1") == "1"):
+        # few tokens: features, both embedding layers and the combine in one launch (csrc/embed_small.hip)
+        h = ops.embed_tokens_small(f32(latent).reshape(n_slots, L, -1), f32(xyz).reshape(n_slots, L, 3), f32(scale).reshape(n_slots),
+                                   f32(x).reshape(n_slots, 7), lay.slot32, pk["embed.w"], pk["embed.b"], pk["ref_emb"], ref_u8, pk["pe"],
+                                   frag_p, Fv, L)
+    else:
+        sf, pf = ops.token_features(f32(latent).reshape(n_slots, L, -1), f32(xyz).reshape(n_slots, L, 3), f32(scale).reshape(n_slots),
+                                    f32(x).reshape(n_slots, 7), slot=lay.slot32)
+        shape_emb = ops.linear(sf, pk["shape.w"], pk["shape.b"])
+        x_emb = ops.linear(pf, pk["param.w"], pk["param.b"])
+        h = ops.token_combine_list(shape_emb, x_emb, pk["ref_emb"], ref_u8, pk["pe"], frag_p, L, slot=lay.slot32)
     n_ada = 2 * num_layers
     mods = ada_mods(pk, timesteps, n_ada, C)
     att_scale = 1.0 / math.sqrt(dh)

@@ -842,6 +842,28 @@ def layernorm(x: torch.Tensor, *, mod: Optional[torch.Tensor] = None, gamma: Opt
     return out
 
 
+def embed_tokens_small(latent: torch.Tensor, xyz: torch.Tensor, scale: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor], w_cat,
+                       bias: torch.Tensor, ref_emb: torch.Tensor, ref_u8: torch.Tensor, pe: torch.Tensor, frag_pos: torch.Tensor, n: int,
+                       L: int) -> torch.Tensor:
+    """the Denoiser's token embedding in one launch for few tokens (pfpp_embed_tokens_small): -> tok [n * L, C].
+    w_cat = packing.PW of [W_shape | W_param | 0] [C, 320], bias = shape bias + param bias (denoiser.pack_denoiser builds both)"""
+    from ._lib import PwC
+
+    for t_, nm in ((latent, "latent"), (xyz, "xyz"), (scale, "scale"), (x, "x"), (bias, "bias"), (ref_emb, "ref_emb"), (pe, "pe")):
+        _chk(t_, torch.float32, nm)
+    _chk(ref_u8, torch.uint8, "ref_part"); _chk(frag_pos, torch.int32, "frag_pos")
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+    Cc = bias.numel()
+    fh, fl = w_cat.frag()
+    pw = PwC(w_cat.f32.data_ptr(), w_cat.hi.data_ptr(), w_cat.lo.data_ptr(), w_cat.scale, w_cat.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
+    tok = torch.empty((n * L, Cc), dtype=torch.float32, device=latent.device)
+    check(_lib.load().pfpp_embed_tokens_small(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(slot), C.byref(pw), _ptr(bias), _ptr(ref_emb),
+                                              _ptr(ref_u8), _ptr(pe), _ptr(frag_pos), _ptr(tok), n, L, Cc, _stream()),
+          "pfpp_embed_tokens_small")
+    return tok
+
+
 def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """a . w^T (+ bias) (+ residual) for few rows (pfpp_gemm_small): a = SplitAct planes [M, K], w = packing.PW [N, K] (its

@@ -1375,6 +1375,44 @@ def test_layernorm_linear_small_vs_float64(dev, M):
     assert float((u.float().double().cpu() - want_u).abs().max() / want_u.abs().max()) < 2e-5          # (weights rounded to 22 bits)
 
 
+@pytest.mark.parametrize("parts", [(1,), (7,), (20,), (3, 9, 2)])
+def test_token_embedding_in_one_launch_equals_the_four_launch_path(weights_sd, dev, parts):
+    """csrc/embed_small.hip: features + shape_embedding + param_fc + ref / positional terms of the compacted fragment list in one launch
+    (both linear layers as one concatenated, fragment-blocked weight) against pfpp_token_features -> two GEMMs -> pfpp_token_combine on the
+    same inputs, to fp32 rounding; deterministic; and against float64 of the reference formula (denoiser_transformer.py:117-135,150-156,183-185)"""
+    import math
+
+    from pfpp_hip import denoiser as D, ops
+
+    pk = D.pack_denoiser(dsd(weights_sd("denoiser"), dev), 6)
+    B, P, L = len(parts), 20, 25
+    g = torch.Generator().manual_seed(sum(parts))
+    valid = torch.zeros(B, P)
+    for b, n in enumerate(parts):
+        valid[b, torch.randperm(P, generator=g)[:n]] = 1
+    latent = torch.randn(B * P, L, 64, generator=g).to(dev)
+    xyz = (torch.rand(B * P, L, 3, generator=g) * 2 - 1).to(dev)
+    scale = (torch.rand(B * P, generator=g) + 0.5).to(dev)
+    x = torch.randn(B * P, 7, generator=g).to(dev)
+    ref_u8 = (torch.rand(B * P, generator=g) < 0.3).to(torch.uint8).to(dev)
+    lay = D.CompactLayout(valid.to(dev), L)
+    Fv = lay.Fv
+    got = ops.embed_tokens_small(latent, xyz, scale, x, lay.slot32, pk["embed.w"], pk["embed.b"], pk["ref_emb"], ref_u8, pk["pe"], lay.frag_p, Fv, L)
+    again = ops.embed_tokens_small(latent, xyz, scale, x, lay.slot32, pk["embed.w"], pk["embed.b"], pk["ref_emb"], ref_u8, pk["pe"], lay.frag_p, Fv, L)
+    sf, pf = ops.token_features(latent, xyz, scale, x, slot=lay.slot32)
+    want = ops.token_combine_list(ops.linear(sf, pk["shape.w"], pk["shape.b"]), ops.linear(pf, pk["param.w"], pk["param.b"]), pk["ref_emb"],
+                                  ref_u8, pk["pe"], lay.frag_p, L, slot=lay.slot32)
+    assert got.shape == (Fv * L, 512) and torch.equal(got, again)
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    # float64 of the formula on the features the kernels agree on (sf / pf are the fp32 feature rows)
+    sd = weights_sd("denoiser")
+    Ws, bs, Wp, bp = (sd[k].double() for k in ("shape_embedding.weight", "shape_embedding.bias", "param_fc.weight", "param_fc.bias"))
+    slot = lay.slot.cpu()
+    ref64 = (sf.cpu().double()[:, :148] @ Ws.t() + bs).view(Fv, L, 512) + (pf.cpu().double()[:, :147] @ Wp.t() + bp)[:, None, :]
+    ref64 = ref64 + sd["ref_part_emb.weight"].double()[ref_u8.cpu().long()[slot]][:, None, :] + sd["pos_encoding.pe"][0].double()[lay.frag_p.cpu().long()][:, None, :]
+    assert float((got.cpu().double().view(Fv, L, 512) - ref64).abs().max()) < 2e-5 * max(1.0, float(ref64.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512), (2000, 512, 2048)])
 def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
     """csrc/gemm_small.hip (out-projections / second feed-forward linear of a few-token step): A planes . fragment-blocked weight planes
