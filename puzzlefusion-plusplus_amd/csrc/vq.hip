@@ -12,8 +12,10 @@
 namespace {
 
 constexpr int VQ_DIM = 16;
-constexpr int VQ_SPLIT = 4;      // lanes per sub-vector
 
+// VQ_SPLIT = lanes per sub-vector (4, 16 or 64: the host takes more lanes when there are few sub-vectors — one puzzle in flight has 800,
+// with four lanes each that was 13 workgroups scanning 256 codes per lane: 38 us)
+template <int VQ_SPLIT>
 __global__ __launch_bounds__(256) void vq_encode_kernel(
     const float* __restrict__ z_e, const float* __restrict__ codebook,
     const int32_t* __restrict__ slot, float* __restrict__ z_q, int32_t* __restrict__ codes,
@@ -126,13 +128,22 @@ extern "C" int pfpp_vq_encode(const float* z_e, const float* codebook, const int
   const size_t smem = (size_t)n_codes * (VQ_DIM + 1) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_encode_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (VQ_DIM + 1) * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_encode_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (VQ_DIM + 1) * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_encode_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (VQ_DIM + 1) * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vq_encode_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * (VQ_DIM + 1) * 4);
     attr_set = true;
   }
-  hipLaunchKernelGGL(vq_encode_kernel, dim3((unsigned)((total * VQ_SPLIT + 255) / 256)), dim3(256), smem,
-                     pfpp::as_stream(stream), z_e, codebook, slot, z_q, codes, total,
-                     (int)rows_per_frag, (int)n_codes);
+  hipStream_t st = pfpp::as_stream(stream);
+  // lanes per sub-vector: enough of them that the launch fills the chip (the argmin is the first minimum for every choice)
+  if (total <= 2048)
+    hipLaunchKernelGGL(vq_encode_kernel<64>, dim3((unsigned)((total * 64 + 255) / 256)), dim3(256), smem, st, z_e, codebook, slot, z_q, codes, total,
+                       (int)rows_per_frag, (int)n_codes);
+  else if (total <= 8192)
+    hipLaunchKernelGGL(vq_encode_kernel<16>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), smem, st, z_e, codebook, slot, z_q, codes, total,
+                       (int)rows_per_frag, (int)n_codes);
+  else
+    hipLaunchKernelGGL(vq_encode_kernel<4>, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), smem, st, z_e, codebook, slot, z_q, codes, total,
+                       (int)rows_per_frag, (int)n_codes);
   return pfpp::check_launch(__func__);
 }
 

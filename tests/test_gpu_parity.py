@@ -139,6 +139,26 @@ def test_vq_bit_exact_golden(golden, weights_sd, dev):
     assert torch.equal(zq2[slot.long()], zq) and zq2[[1, 4, 5, 6, 8, 10]].abs().max() == 0
 
 
+@pytest.mark.parametrize("F", [1, 8, 40, 120])
+def test_vq_codes_do_not_depend_on_the_lanes_per_sub_vector(weights_sd, dev, F):
+    """pfpp_vq_encode picks 64 / 16 / 4 lanes per sub-vector by the number of sub-vectors (F x 100: 100, 800 | 4,000 | 12,000): every choice
+    returns torch.argmin's first minimum of the same k-ordered distances — the codes of a fragment are the same whichever launch it is part of,
+    duplicated codebook rows (exact ties) included"""
+    from pfpp_hip import ops
+
+    g = torch.Generator().manual_seed(F)
+    cb = weights_sd("vqvae")["vector_quantization.embedding.weight"].clone()
+    cb[700] = cb[13]                                    # an exact tie between two codes: the lower index wins
+    cb = cb.to(dev)
+    z = torch.randn(120, 25, 64, generator=g) * cb.abs().max().cpu()
+    z[0, 0, :16] = cb[13].cpu()                          # a sub-vector sitting exactly on the duplicated code
+    zd = z.to(dev)
+    full_q, full_codes = ops.vq_encode(zd, cb, torch.arange(120, dtype=torch.int32, device=dev), 120, return_codes=True)   # 4 lanes
+    q, codes = ops.vq_encode(zd[:F].contiguous(), cb, torch.arange(F, dtype=torch.int32, device=dev), F, return_codes=True)
+    assert torch.equal(codes.reshape(-1), full_codes.reshape(-1)[: F * 100]) and torch.equal(q, full_q[:F])
+    assert int(codes.reshape(-1)[0]) == 13
+
+
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,act,pool,bn", [
     (1000, 192, 132, "relu", 0, True), (4096, 128, 64, "relu", 64, True), (2048, 64, 4, "relu", 32, True),
