@@ -882,6 +882,7 @@ typedef struct pfpp_tlayers_eval_args {
   pfpp_planes norm, att, u; float* qkv;
   float* split_ws; int64_t split_ws_bytes; int32_t* split_cnt; int64_t split_cnt_len;
   int64_t lnlin_max_rows;                          /* M <= this: LayerNorm + the following linear as one launch (pfpp_layernorm_linear_small) */
+  int32_t wd_gemm;                                 /* 1: above lnlin_max_rows the qkv / out / second feed-forward linears through pfpp_gemm_wd */
 } pfpp_tlayers_eval_args;
 int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* args, pfpp_stream_t stream);
 /* LayerNorm fused into the linear layer that follows it, for small token counts (one puzzle in flight): y = LN(x) . W^T (+ bias), the
@@ -907,6 +908,14 @@ int pfpp_embed_tokens_small(const float* latent, const float* xyz, const float* 
  * M <= lnlin_max_rows.                                                                                                              */
 int pfpp_gemm_small(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr, float* out,
                     int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream);
+/* The same operation above the few-token range, weights never staged through LDS (csrc/gemm_wd.hip): out [M, ldc] = (A . W^T) / (A.scale *
+ * w.scale) + bias + residual with A = row-major planes [M, lda] and w's fragment-blocked planes read straight into the matrix operands
+ * (attn.to_q|k|v / attn.to_out[0] / ff.net[2] of attention.py:77-90, eval mode: static weights).  N % 128 == 0, K % 32 == 0, 16-byte
+ * aligned rows; out may be the residual.  Bit-identical to pfpp_gemm's split-f16 plane path on the same operands (same products, same
+ * order, same epilogue); pfpp_tlayers_eval uses it for M > lnlin_max_rows when args.wd_gemm is set.                                      */
+int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr, float* out,
+                 int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream);
+int pfpp_gemm_wd_supported(int64_t M, int64_t N, int64_t K);
 int pfpp_layernorm_linear_small(const float* x, const float* mod, int64_t ld_mod, const float* gamma, const float* beta,
                                 const int32_t* group_batch, int64_t group_rows, const pfpp_pw* w, const float* bias, float* out,
                                 int64_t ldc, const pfpp_planes* u_planes, int64_t ldu, int64_t M, int64_t N, int64_t C, float eps,

@@ -1,0 +1,295 @@
+// Plane GEMM whose WEIGHT operand never touches LDS: out = (A . W^T) / scale + bias + residual.
+//
+// Reference: the linear layers of EncoderLayer.forward (denoiser/model/modules/attention.py:77-90: attn.to_q|k|v, attn.to_out[0],
+// ff.net[2], the latter two followed by the residual add), eval mode, as sequenced by pfpp_tlayers_eval above the few-token range.
+//
+// Why a kernel of its own.  The tiled plane GEMM (gemm_pl.hip) stages BOTH operands through its LDS-DMA ring: a 128 x 64 tile moves
+// 72 KB through LDS per 32-deep K-tile for 384 cycles of matrix work per SIMD — the loop is LDS-bound, and the ring (24 KB per stage)
+// cannot be deep.  Eval weights are static, so their FRAGMENT-BLOCKED planes exist (include/pfpp.h pfpp_pw.fhi / flo: one 1 KB block =
+// the 64 lanes' B operands of one v_mfma_f32_32x32x16_f16).  Here
+//   * a workgroup = 4 waves = (32 MT) rows x (128 NT) columns; wave w owns NT 32-column units and ALL rows of the tile: its weight
+//     fragments come straight from global memory into registers (one fully coalesced 1 KB load each, D K-tiles deep, no LDS pass, no
+//     sharing between the waves of a workgroup), the activation tile (row-major hi / lo planes, as every producer writes them) goes
+//     through a D-stage LDS-DMA ring shared by the four waves — 8 KB per stage at MT = 2;
+//   * per K-tile at MT = 2, NT = 1: 40 KB through LDS (72), 24 KB through the texture path, the same 48 matrix instructions;
+//   * one barrier per K-tile: it publishes the DMA pieces of tile kt and frees the stage tile kt + D - 1 lands in;
+//   * epilogue through a wave-private LDS patch (ds_write_b32 in accumulator order, ds_read_b128 along the rows): 16-byte stores.
+// Measured stand-alone (tools/lab/gemm_wdirect_probe.hip, 3850 rows): 512 x 512 10.1 us, 512 x 2048 29.6 us, 1536 x 512 27.1 us against
+// 19.2 / 48.0 / 33.0 us of the tiled kernel inside the step.
+// Arithmetic: the three split-f16 products of a 16-deep step in the order lo.hi, hi.lo, hi.hi, k ascending, one accumulator chain per
+// output, epilogue (acc * alpha + bias) + residual — gemm_pl_kernel's, bit for bit (tested).
+#include <type_traits>
+#include <utility>
+
+#include "pfpp_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+struct WdP {
+  const _Float16 *ah, *al; int64_t lda;      // planes of a_scale * A [M, K]
+  const half8 *fh, *fl;                      // fragment-blocked planes of w_scale * W [N, K]
+  float alpha;                               // 1 / (a_scale * w_scale)
+  const float* bias;                         // [N] or null
+  const float* res; int64_t ldr;             // [M, ldr] or null (may alias out)
+  float* out; int64_t ldc;
+  int M, N, K;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ half8 lds_rd(uint32_t addr) {
+  half8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ half8 gld(const half8* p) {
+  half8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <int MT, int NT, int D>
+struct WdCfg {
+  static constexpr int BM = 32 * MT, BN = 128 * NT;
+  static constexpr int PLANE = BM * 64, STAGE = 2 * PLANE;     // bytes: BM rows of 32 halfs, two planes
+  static constexpr int PATCH = 4096;                           // per wave: 32 rows x 32 floats
+  static constexpr size_t SMEM = (size_t)D * STAGE + 4 * PATCH;
+};
+
+template <int MT, int NT, int D>
+__global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
+  using C = WdCfg<MT, NT, D>;
+  constexpr int BM = C::BM, PLANE = C::PLANE, STAGE = C::STAGE;
+  constexpr int NPW = MT;                                      // 1 KB DMA pieces (16 rows of one plane) per wave and stage
+  constexpr int P = NPW + 4 * NT;                              // vector-memory operations a wave issues per K-tile
+  extern __shared__ __align__(1024) char wd_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int KB = p.K / 16, nk = p.K / 32;
+  const int tiles_n = p.N / C::BN;
+  // 1-D grid; the hardware deals workgroup ids to the 8 XCDs round-robin: remapped so that an XCD owns consecutive tiles (row-major:
+  // the column tiles of a row panel share one L2; the weights are read by every row panel anyway)
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q_ = nwg >> 3, r_ = nwg & 7;
+  const int tile = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + local;
+  const int bx = tile / tiles_n, by = tile - bx * tiles_n;
+  const int m0 = bx * BM;
+  const int nb0 = (by * 4 + wave) * NT;                        // this wave's first 32-column unit
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)wd_smem;
+
+  // ---- activation tile: piece q = wave + 4 j = 16 rows of one plane; lane i -> row i >> 2, physical chunk i & 3 holding the row's
+  //      logical 16-byte chunk (i & 3) ^ ((row >> 2) & 3)  (gemm_pl.hip's swizzle: conflict-free ds_read_b128); rows past M repeat row M - 1
+  const char* src[NPW];
+  uint32_t dst[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int q = wave + 4 * j;
+    const int pl = q / (2 * MT), row = (q % (2 * MT)) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int64_t grow = m0 + row < p.M ? m0 + row : p.M - 1;
+    src[j] = reinterpret_cast<const char*>((pl ? p.al : p.ah) + grow * p.lda + chunk * 8);
+    dst[j] = lds0 + q * 1024;
+  }
+  auto dma = [&](int kt, int stage) {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (size_t)kt * 64), (lds_void*)(uintptr_t)(dst[j] + stage * STAGE), 16, 0, 0);
+  };
+  // ---- weight fragments of K-tile kt: units nb0 .. nb0 + NT - 1, 16-deep steps 2 kt and 2 kt + 1, both planes
+  const half8* wbh[NT];
+  const half8* wbl[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    wbh[j] = p.fh + (size_t)(nb0 + j) * KB * 64 + lane;
+    wbl[j] = p.fl + (size_t)(nb0 + j) * KB * 64 + lane;
+  }
+  half8 wh[D][NT][2], wl[D][NT][2];
+  auto wload = [&](int kt, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const half8* ph = wbh[j] + (size_t)kt * 128;
+      const half8* pl = wbl[j] + (size_t)kt * 128;
+      wh[slot][j][0] = gld<0>(ph);
+      wh[slot][j][1] = gld<1024>(ph);
+      wl[slot][j][0] = gld<0>(pl);
+      wl[slot][j][1] = gld<1024>(pl);
+    }
+  };
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.0f;
+
+  const int sw = (l31 >> 2) & 3;
+  uint32_t a_ad[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) a_ad[s] = lds0 + l31 * 64 + (((2 * s + lhi) ^ sw) << 4);
+
+  auto rd_frags = [&](half8 (&fh)[MT], half8 (&fl)[MT], int stage, auto s_c) {
+    const uint32_t ad = a_ad[decltype(s_c)::value] + stage * STAGE;
+    static_for<MT>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      fh[t] = lds_rd<2048 * t>(ad);
+      fl[t] = lds_rd<PLANE + 2048 * t>(ad);
+    });
+  };
+  auto wait_frags = [&](half8 (&fh)[MT], half8 (&fl)[MT], auto left_c) {     // left = LDS reads issued behind these that may stay in flight
+    constexpr int LEFT = decltype(left_c)::value;
+    static_assert(MT == 2 || MT == 4, "row tiles per workgroup");
+    if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fl[0]), "+v"(fl[1]) : "n"(LEFT));
+    else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fh[3]), "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "n"(LEFT));
+  };
+  auto name_w = [&](auto slot_c) {      // the vmcnt wait in front orders the uses of this slot's registers: name them behind it
+    constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      half8 &r0 = wh[slot][j][0], &r1 = wh[slot][j][1], &r2 = wl[slot][j][0], &r3 = wl[slot][j][1];
+      asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    }
+  };
+  // term-major like gemm_pl_kernel: lo.hi of every tile, then hi.lo, then hi.hi (per accumulator: the same products in the same order)
+  auto mma = [&](const half8 (&fh)[MT], const half8 (&fl)[MT], auto slot_c, auto s_c) {
+    constexpr int slot = decltype(slot_c)::value, s = decltype(s_c)::value;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], wh[slot][j][s], acc[t][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], wl[slot][j][s], acc[t][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], wh[slot][j][s], acc[t][j], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // K-tile kt (stage = slot = U = kt % D): wait for its own loads (the D - 2 tiles behind it stay in flight), barrier (every wave's DMA
+  // pieces of tile kt have landed AND every wave is through tile kt - 1, whose stage / slot the next request overwrites), request tile
+  // kt + D - 1, multiply.
+  half8 f0h[MT], f0l[MT], f1h[MT], f1l[MT];
+  auto ktile = [&](int kt, auto u_c) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr int UN = (U + D - 1) % D;
+    const int behind = min(D - 2, nk - 1 - kt);
+    if (behind >= D - 2) wait_vmcnt<(D - 2) * P>();
+    else if (D >= 4 && behind == D - 3) wait_vmcnt<(D >= 4 ? D - 3 : 0) * P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    name_w(u_c);
+    if (kt + D - 1 < nk) {
+      dma(kt + D - 1, UN);
+      wload(kt + D - 1, std::integral_constant<int, UN>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    rd_frags(f0h, f0l, U, I0{});
+    rd_frags(f1h, f1l, U, I1{});
+    wait_frags(f0h, f0l, std::integral_constant<int, 2 * MT>{});
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0h, f0l, u_c, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_frags(f1h, f1l, I0{});
+    mma(f1h, f1l, u_c, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<D - 1>([&](auto u_c) {      // prologue: tiles 0 .. D - 2 requested
+    constexpr int U = decltype(u_c)::value;
+    if (U < nk) { dma(U, U); wload(U, u_c); }
+  });
+  int kt = 0;
+  for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile(kt + decltype(u_c)::value, u_c); });
+  static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile(kt + decltype(u_c)::value, u_c); });
+
+  // ---- epilogue: (acc * alpha + bias) + residual, every tile through the wave's private 4 KB patch (behind the ring: no barrier needed)
+  const uint32_t patch = lds0 + D * STAGE + wave * C::PATCH;
+  const float alpha = p.alpha;
+  const int rcol = (lane & 7) * 4, rrow = lane >> 3;           // read side: lane -> 4 floats at column 4 (lane % 8) of rows lane / 8 + 8 k
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col_w = (nb0 + j) * 32;
+    const float sh = p.bias ? p.bias[col_w + l31] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[t][j][e] * alpha;
+        const float w = v + sh;
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(patch + r * 128 + l31 * 4), "v"(w) : "memory");
+      }
+      f32x4 vv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(vv[k]) : "v"(patch + (rrow + 8 * k) * 128 + rcol * 4) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = m0 + t * 32 + rrow + 8 * k;
+        if (row < p.M) {
+          float4 v = make_float4(vv[k][0], vv[k][1], vv[k][2], vv[k][3]);
+          if (p.res) {
+            const float4 q = *reinterpret_cast<const float4*>(p.res + (int64_t)row * p.ldr + col_w + rcol);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+          }
+          *reinterpret_cast<float4*>(p.out + (int64_t)row * p.ldc + col_w + rcol) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int D>
+int launch_wd(const WdP& p, hipStream_t st) {
+  using C = WdCfg<MT, NT, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_wd_kernel<MT, NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM) != hipSuccess)
+      return pfpp::check_launch("pfpp_gemm_wd");
+    attr_set = true;
+  }
+  const unsigned tiles = (unsigned)(((p.M + C::BM - 1) / C::BM) * (p.N / C::BN));
+  hipLaunchKernelGGL((gemm_wd_kernel<MT, NT, D>), dim3(tiles), dim3(256), C::SMEM, st, p);
+  return pfpp::check_launch("pfpp_gemm_wd");
+}
+
+}  // namespace
+
+extern "C" int pfpp_gemm_wd_supported(int64_t M, int64_t N, int64_t K) { return M >= 1 && M <= 0x7fffffff && N >= 128 && N % 128 == 0 && K >= 32 && K % 32 == 0; }
+
+extern "C" int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
+                            float* out, int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream) {
+  PFPP_REQUIRE(A && A->hi && A->lo && w && out, "null pointer");
+  PFPP_REQUIRE(w->fhi && w->flo && pfpp::aligned16(w->fhi) && pfpp::aligned16(w->flo), "the weight's fragment-blocked planes (pfpp_pw.fhi / flo) are required");
+  PFPP_SUPPORTED(pfpp_gemm_wd_supported(M, N, K), "N % 128 != 0 or K % 32 != 0");
+  PFPP_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0 && (!residual || (ldr >= N && ldr % 4 == 0)), "sizes / leading dimensions");
+  PFPP_REQUIRE(pfpp::aligned16(A->hi) && pfpp::aligned16(A->lo) && pfpp::aligned16(out) && pfpp::aligned16(residual) && (!bias || pfpp::aligned16(bias)),
+               "16-byte aligned operands");
+  WdP p;
+  p.ah = (const _Float16*)A->hi; p.al = (const _Float16*)A->lo; p.lda = lda;
+  p.fh = (const half8*)w->fhi; p.fl = (const half8*)w->flo;
+  p.alpha = 1.0f / (A->scale * w->scale);
+  p.bias = bias; p.res = residual; p.ldr = ldr; p.out = out; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  hipStream_t st = pfpp::as_stream(stream);
+  // tile choice (measured, tools/lab/gemm_wdirect_probe.hip): the 128 x 256 tile once it fills the chip, the 64 x 128 tile below that
+  const int64_t big_tiles = ((M + 127) / 128) * (N / 256);
+  if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4>(p, st);
+  return launch_wd<2, 1, 3>(p, st);
+}

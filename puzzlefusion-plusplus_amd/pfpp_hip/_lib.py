@@ -127,7 +127,7 @@ class TlayersEvalArgs(C.Structure):
         ("n_seq", _i64), ("max_len", _i64), ("att_scale", _f32), ("single_pass", _i32),
         ("norm", PlanesC), ("att", PlanesC), ("u", PlanesC), ("qkv", _p),
         ("split_ws", _p), ("split_ws_bytes", _i64), ("split_cnt", _p), ("split_cnt_len", _i64),
-        ("lnlin_max_rows", _i64),
+        ("lnlin_max_rows", _i64), ("wd_gemm", _i32),
     ]
 
 
@@ -186,6 +186,8 @@ SIGNATURES = {
     "pfpp_tlayers_eval": [C.POINTER(TlayersEvalArgs), _p],
     "pfpp_embed_tokens_small": [_p, _p, _p, _p, _p, C.POINTER(PwC), _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_gemm_small": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_gemm_wd": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_gemm_wd_supported": [_i64, _i64, _i64],
     "pfpp_layernorm_linear_small": [_p, _p, _i64, _p, _p, _p, _i64, C.POINTER(PwC), _p, _p, _i64, _pl, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "pfpp_heads_bwd": [_p, _p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,

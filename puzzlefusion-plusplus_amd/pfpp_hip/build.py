@@ -33,6 +33,7 @@ SOURCES = {
     "heads.hip": ["-munsafe-fp-atomics"],
     "lnlin_small.hip": [],
     "gemm_small.hip": [],
+    "gemm_wd.hip": [],
     "embed_small.hip": ["-ffp-contract=off"],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],

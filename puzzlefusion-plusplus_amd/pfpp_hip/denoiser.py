@@ -129,6 +129,7 @@ def _eval_layers_c(pk, h, mods, lay, L: int, num_layers: int, num_heads: int, at
     args.split_ws, args.split_ws_bytes = ws[0].data_ptr(), ws[0].numel() * 4
     args.split_cnt, args.split_cnt_len = ws[1].data_ptr(), ws[1].numel()
     args.lnlin_max_rows = int(os.environ.get("PFPP_EVAL_LNLIN_ROWS", "2048"))     # <= this many tokens: the few-token kernels (LayerNorm inside the next GEMM, pfpp_gemm_small)
+    args.wd_gemm = int(os.environ.get("PFPP_EVAL_WD", "1") == "1")               # above that: weights straight into the matrix operands (pfpp_gemm_wd)
     _lib.check(_lib.load().pfpp_tlayers_eval(C_.byref(args), ops._stream()), "pfpp_tlayers_eval")
     return True
 

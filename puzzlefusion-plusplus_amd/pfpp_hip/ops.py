@@ -887,6 +887,30 @@ def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[
     return out
 
 
+def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a . w^T (+ bias) (+ residual) with the weight's fragment-blocked planes read straight into the matrix operands (pfpp_gemm_wd,
+    csrc/gemm_wd.hip): a = SplitAct planes [M, K], w = packing.PW [N, K]; N % 128 == 0, K % 32 == 0; out may be the residual tensor.
+    Bit-identical to the tiled plane GEMM (ops.linear on the same planes)."""
+    from ._lib import PlanesC, PwC
+
+    M, K = a.hi.shape
+    if K != w.K:
+        raise ValueError(f"gemm_wd: A has K = {K}, the weight {w.K}")
+    fh, fl = w.frag()
+    pw = PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
+    for t_, nm in ((bias, "bias"), (residual, "residual"), (out, "out")):
+        if t_ is not None:
+            _chk(t_, torch.float32, nm)
+    if out is None:
+        out = torch.empty((M, w.N), dtype=torch.float32, device=a.hi.device)
+    ap = PlanesC(a.hi.data_ptr(), a.lo.data_ptr(), 1.0)
+    check(_lib.load().pfpp_gemm_wd(C.byref(ap), a.hi.stride(0), C.byref(pw), _ptr(bias), _ptr(residual),
+                                   0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, w.N, K, _stream()),
+          "pfpp_gemm_wd")
+    return out
+
+
 def layernorm_linear_small(x: torch.Tensor, w, *, mod: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
                            group_rows: int = 1, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
                            bias: Optional[torch.Tensor] = None, geglu: bool = False, eps: float = 1e-5):

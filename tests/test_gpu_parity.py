@@ -1474,6 +1474,44 @@ def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
         ops.gemm_small(ops.SplitAct.empty(M, 256, dev), PW(W[:, :256].contiguous()))
 
 
+@pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (3850, 1536, 512), (3850, 512, 2048), (16000, 512, 512), (100, 128, 32), (1, 256, 64),
+                                   (2047, 1536, 1024), (16001, 1536, 512)])
+def test_gemm_wd_bit_identical_to_the_tiled_gemm(dev, M, N, K):
+    """csrc/gemm_wd.hip (qkv / out-projection / second feed-forward linear of the eval step above the few-token range): row-major A
+    planes through a deep LDS-DMA ring, the weight's fragment-blocked planes straight into the matrix operands — the same products in
+    the same order with the same epilogue as the tiled plane GEMM: bit-identical, in place over the residual, both tile shapes
+    (64 x 128 and, once it fills the chip, 128 x 256), ragged last row tile; and against float64 of the values the planes stand for"""
+    import math
+
+    from pfpp_hip import ops
+    from pfpp_hip import planes as P
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a32 = torch.randn(M, K, generator=g).to(dev)
+    pl = P.split(a32)
+    a = ops.SplitAct(pl.hi, pl.lo)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev) * 0.1
+    res = torch.randn(M, N, generator=g).to(dev)
+    pw = PW(W.contiguous())
+    out = res.clone()
+    ops.gemm_wd(a, pw, bias=bias, residual=out, out=out)                 # in place over the residual
+    tiled = res.clone()
+    ops.gemm(a, pw, M=M, N=N, K=K, lda=K, out=tiled, ldc=N, bias=bias, residual=tiled, ldr=N)
+    assert torch.equal(out, tiled)
+    plain = ops.gemm_wd(a, pw)                                           # no bias, no residual, fresh output
+    tiled_plain = torch.empty_like(plain)
+    ops.gemm(a, pw, M=M, N=N, K=K, lda=K, out=tiled_plain, ldc=N)
+    assert torch.equal(plain, tiled_plain)
+    av = (a.hi.double() + a.lo.double()).cpu()
+    wv = ((pw.hi.double() + pw.lo.double()) / pw.scale).cpu()[:, :K]
+    want = av @ wv.t() + bias.double().cpu() + res.double().cpu()
+    assert float((out.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6
+    with pytest.raises(Exception, match="128"):
+        ops.gemm_wd(a, PW(W[:96].contiguous()))
+
+
 @pytest.mark.parametrize("parts", [(5,), (20, 3, 11), (2,) * 16])
 def test_eval_blocks_sequenced_from_c_are_bit_identical(weights_sd, dev, parts, monkeypatch):
     """pfpp_tlayers_eval (csrc/tlayer.hip): the compact eval forward's six blocks enqueued from one C call are the same launches with
