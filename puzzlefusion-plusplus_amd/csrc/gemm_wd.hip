@@ -255,6 +255,60 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
   }
 }
 
+// ---- fragment-blocking of row-major planes (training: the weights change every step, their blocked copies are made where they are read)
+struct RbJob { const _Float16 *hi, *lo; _Float16 *fhi, *flo; int N, K; int64_t ldw; int transposed; int first_wg; };
+struct RbP { RbJob job[PFPP_REBLOCK_MAX]; int n; };
+
+// plain: piece ((nb * KB + kb) * 64 + lane) of the blocked plane = W[32 nb + lane % 32][16 kb + 8 (lane / 32) .. + 8); one thread per piece
+// transposed (the blocked planes of W^T [K, N], the operand of dX = dY . W): a workgroup stages 64 rows x 64 columns of both planes in
+//   LDS and writes the 2 x 4 blocks they make: piece lane of block (kb32, s) = W[16 s + 8 (lane / 32) + 0..7][32 kb32 + lane % 32]
+__global__ __launch_bounds__(256) void reblock_kernel(const RbP p) {
+  __shared__ __align__(16) _Float16 tile[2][64][72];
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < PFPP_REBLOCK_MAX; ++k)
+    if (k < p.n && (int)blockIdx.x >= p.job[k].first_wg) j = k;
+  const RbJob& q = p.job[j];
+  const int wg = blockIdx.x - q.first_wg, tid = threadIdx.x;
+  if (!q.transposed) {
+    const int KB = q.K / 16;
+    const int64_t piece = (int64_t)wg * 256 + tid;
+    if (piece >= (int64_t)(q.N / 32) * KB * 64) return;
+    const int lane = (int)(piece & 63), l31 = lane & 31, lhi = lane >> 5;
+    const int64_t blk = piece >> 6;
+    const int nb = (int)(blk / KB), kb = (int)(blk - (int64_t)nb * KB);
+    const int64_t src = (int64_t)(32 * nb + l31) * q.ldw + 16 * kb + 8 * lhi;
+    reinterpret_cast<half8*>(q.fhi)[piece] = *reinterpret_cast<const half8*>(q.hi + src);
+    reinterpret_cast<half8*>(q.flo)[piece] = *reinterpret_cast<const half8*>(q.lo + src);
+    return;
+  }
+  const int tiles_k = q.K / 64;
+  const int tn = wg / tiles_k, tk = wg - tn * tiles_k;      // rows 64 tn .. (contraction of W^T), columns 64 tk ..
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 3) + 32 * i, chunk = tid & 7;
+    const int64_t src = (int64_t)(64 * tn + row) * q.ldw + 64 * tk + 8 * chunk;
+    *reinterpret_cast<half8*>(&tile[0][row][8 * chunk]) = *reinterpret_cast<const half8*>(q.hi + src);
+    *reinterpret_cast<half8*>(&tile[1][row][8 * chunk]) = *reinterpret_cast<const half8*>(q.lo + src);
+  }
+  __syncthreads();
+  const int NB16 = q.N / 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pid = tid + 256 * i;
+    const int kbl = pid >> 8, s = (pid >> 6) & 3, lane = pid & 63, l31 = lane & 31, lhi = lane >> 5;
+    half8 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      vh[e] = tile[0][16 * s + 8 * lhi + e][32 * kbl + l31];
+      vl[e] = tile[1][16 * s + 8 * lhi + e][32 * kbl + l31];
+    }
+    const int64_t piece = ((int64_t)(2 * tk + kbl) * NB16 + (4 * tn + s)) * 64 + lane;
+    reinterpret_cast<half8*>(q.fhi)[piece] = vh;
+    reinterpret_cast<half8*>(q.flo)[piece] = vl;
+  }
+}
+
 template <int MT, int NT, int D>
 int launch_wd(const WdP& p, hipStream_t st) {
   using C = WdCfg<MT, NT, D>;
@@ -292,4 +346,26 @@ extern "C" int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w,
   const int64_t big_tiles = ((M + 127) / 128) * (N / 256);
   if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4>(p, st);
   return launch_wd<2, 1, 3>(p, st);
+}
+
+extern "C" int pfpp_reblock_planes(const pfpp_reblock_job* jobs, int32_t n, pfpp_stream_t stream) {
+  PFPP_REQUIRE(jobs && n >= 1 && n <= PFPP_REBLOCK_MAX, "1 .. PFPP_REBLOCK_MAX jobs");
+  RbP p;
+  p.n = n;
+  int64_t wgs = 0;
+  for (int i = 0; i < n; ++i) {
+    const pfpp_reblock_job& q = jobs[i];
+    PFPP_REQUIRE(q.w.hi && q.w.lo && q.fhi && q.flo, "null pointer");
+    PFPP_REQUIRE(q.N >= 32 && q.K >= 16 && q.N <= 0x7fffffff && q.K <= 0x7fffffff && q.ldw >= q.K && q.ldw % 8 == 0, "sizes");
+    PFPP_SUPPORTED(q.transposed ? (q.N % 64 == 0 && q.K % 64 == 0) : (q.N % 32 == 0 && q.K % 16 == 0), "N / K not a multiple of the block");
+    PFPP_REQUIRE(pfpp::aligned16(q.w.hi) && pfpp::aligned16(q.w.lo) && pfpp::aligned16(q.fhi) && pfpp::aligned16(q.flo), "16-byte aligned planes");
+    RbJob& r = p.job[i];
+    r.hi = (const _Float16*)q.w.hi; r.lo = (const _Float16*)q.w.lo; r.fhi = (_Float16*)q.fhi; r.flo = (_Float16*)q.flo;
+    r.N = (int)q.N; r.K = (int)q.K; r.ldw = q.ldw; r.transposed = q.transposed; r.first_wg = (int)wgs;
+    wgs += q.transposed ? (q.N / 64) * (q.K / 64) : ((q.N / 32) * (q.K / 16) * 64 + 255) / 256;
+  }
+  PFPP_REQUIRE(wgs <= 0x7fffffff, "too many workgroups");
+  for (int i = n; i < PFPP_REBLOCK_MAX; ++i) p.job[i] = p.job[0];
+  hipLaunchKernelGGL(reblock_kernel, dim3((unsigned)wgs), dim3(256), 0, pfpp::as_stream(stream), p);
+  return pfpp::check_launch(__func__);
 }

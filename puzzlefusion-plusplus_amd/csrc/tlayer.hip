@@ -134,7 +134,36 @@ int gemm_pl(const pfpp_planes& A, const pfpp_planes& W, float* Cout, int64_t M, 
   return pfpp_gemm_planes(&a, st);
 }
 
+// ---- weights straight into the matrix operands (csrc/gemm_wd.hip): the fragment-blocked copies of the layer's qkv1 / o1 / qkv2 / o2 / ff2
+// planes (transposed: of their transposes, the operands of the input gradients) are made in frag_ws right before they are read, on the
+// stream that reads them — a copy can never be stale, whoever updated the weights
+struct LayerFrag { pfpp_pw qkv1, o1, qkv2, o2, ff2; };
+int64_t frag_halfs(int64_t C, int64_t inner) { return 2 * 3 * C * C + 2 * C * C + C * inner; }      // per plane
+bool wd_shapes_ok(int64_t M, int64_t C, int64_t inner) {
+  return C % 128 == 0 && inner % 128 == 0 && pfpp_gemm_wd_supported(M, C, C) && pfpp_gemm_wd_supported(M, 3 * C, C) &&
+         pfpp_gemm_wd_supported(M, C, inner) && pfpp_gemm_wd_supported(M, C, 3 * C) && pfpp_gemm_wd_supported(M, inner, C);
+}
+int reblock_layer(const pfpp_tlayers_args* a, const pfpp_tlayer_params& w, bool transposed, LayerFrag* out, pfpp_stream_t st) {
+  const int64_t C = a->C, inner = a->inner;
+  _Float16* hi = static_cast<_Float16*>(a->frag_ws);
+  _Float16* lo = hi + frag_halfs(C, inner);
+  const pfpp_planes* src[5] = {&w.qkv1, &w.o1, &w.qkv2, &w.o2, &w.ff2};
+  const int64_t N[5] = {3 * C, C, 3 * C, C, C}, K[5] = {C, C, C, C, inner};
+  pfpp_pw* dst[5] = {&out->qkv1, &out->o1, &out->qkv2, &out->o2, &out->ff2};
+  pfpp_reblock_job jobs[5];
+  int64_t off = 0;
+  for (int i = 0; i < 5; ++i) {
+    jobs[i].w = *src[i]; jobs[i].N = N[i]; jobs[i].K = K[i]; jobs[i].ldw = K[i];
+    jobs[i].fhi = hi + off; jobs[i].flo = lo + off; jobs[i].transposed = transposed ? 1 : 0;
+    *dst[i] = pfpp_pw{nullptr, src[i]->hi, src[i]->lo, src[i]->scale, K[i], hi + off, lo + off};
+    off += N[i] * K[i];
+  }
+  return pfpp_reblock_planes(jobs, 5, st);
+}
+
 }  // namespace
+
+extern "C" int64_t pfpp_tlayers_frag_bytes(int64_t C, int64_t inner) { return 2 * frag_halfs(C, inner) * 2; }
 
 extern "C" int64_t pfpp_tlayers_fwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner) { return fwd_layout(M, C, H, inner).total; }
 
@@ -149,8 +178,18 @@ extern "C" int pfpp_tlayers_fwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   PFPP_REQUIRE(a->fwd_layer_bytes >= lo.total, "fwd_layer_bytes smaller than pfpp_tlayers_fwd_bytes()");
   const float eps = 1e-5f;
   const int64_t ld_mod = 2 * C;
+  const bool wd = a->frag_ws != nullptr && wd_shapes_ok(M, C, inner);
+  if (wd) PFPP_REQUIRE(a->frag_ws_bytes >= pfpp_tlayers_frag_bytes(C, inner), "frag_ws_bytes smaller than pfpp_tlayers_frag_bytes()");
+  // a linear of the block: out = A . W^T + bias (+ residual) — weights straight into the matrix operands, or the tiled kernel (bit-identical)
+  LayerFrag fr;
+  auto lin = [&](const pfpp_planes& A, const pfpp_planes& W, const pfpp_pw& F, float* out, int64_t N, int64_t K, const float* bias,
+                 const float* residual) -> int {
+    if (wd) { const pfpp_planes Ac = A; return pfpp_gemm_wd(&Ac, K, &F, bias, residual, N, out, N, M, N, K, stream); }
+    return gemm_pl(A, W, out, M, N, K, K, K, N, false, false, bias, residual, false, nullptr, a->ws_main, a->ws_bytes, 0, stream);
+  };
   for (int i = layer_lo; i < layer_hi; ++i) {
     const pfpp_tlayer_params& w = a->layers[i];
+    if (wd) TL_CALL(reblock_layer(a, w, false, &fr, stream));
     char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
     // the residual stream entering the layer: the tokens for layer 0, the previous layer's output otherwise
     float* h = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
@@ -167,31 +206,31 @@ extern "C" int pfpp_tlayers_fwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
                                        &n1, stream));
     else
       TL_CALL(pfpp_layernorm_grouped_split(h, n1.hi, n1.lo, mod1, ld_mod, a->frag_b, L, M, C, eps, stream));
-    TL_CALL(gemm_pl(n1, w.qkv1, qkv1, M, 3 * C, C, C, C, 3 * C, false, false, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(lin(n1, w.qkv1, fr.qkv1, qkv1, 3 * C, C, nullptr, nullptr));
     TL_CALL(pfpp_attn_blockdiag_split(qkv1, att1.hi, att1.lo, a->Fv, L, H, dh, a->att_scale, stream));
     if (a->p_lay > 0.0f) {
-      TL_CALL(gemm_pl(att1, w.o1, y1, M, C, C, C, C, C, false, false, w.bo1, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(lin(att1, w.o1, fr.o1, y1, C, C, w.bo1, nullptr));
       TL_CALL(pfpp_dropout_layernorm_p(y1, h, y1, nullptr, mod2, ld_mod, nullptr, nullptr, a->frag_b, L, 1, M, C, eps, a->p_lay, a->seed,
                                        (uint32_t)(1 + 3 * i), &n2, stream));
     } else {
-      TL_CALL(gemm_pl(att1, w.o1, y1, M, C, C, C, C, C, false, false, w.bo1, h, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(lin(att1, w.o1, fr.o1, y1, C, C, w.bo1, h));
       TL_CALL(pfpp_layernorm_grouped_split(y1, n2.hi, n2.lo, mod2, ld_mod, a->frag_b, L, M, C, eps, stream));
     }
     // ---- global attention (attention.py:82-85)
-    TL_CALL(gemm_pl(n2, w.qkv2, qkv2, M, 3 * C, C, C, C, 3 * C, false, false, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(lin(n2, w.qkv2, fr.qkv2, qkv2, 3 * C, C, nullptr, nullptr));
     TL_CALL(pfpp_attn_dense_train_p(qkv2, att2, lse, a->seq_off, a->seq_len, nullptr, 0, a->n_seq, a->max_len, H, dh, a->att_scale, &att2p, stream));
     if (a->p_lay > 0.0f) {
-      TL_CALL(gemm_pl(att2p, w.o2, y2, M, C, C, C, C, C, false, false, w.bo2, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(lin(att2p, w.o2, fr.o2, y2, C, C, w.bo2, nullptr));
       TL_CALL(pfpp_dropout_layernorm_p(y2, y1, y2, nullptr, nullptr, 0, w.g3, w.b3, nullptr, 1, 1, M, C, eps, a->p_lay, a->seed,
                                        (uint32_t)(2 + 3 * i), &n3, stream));
     } else {
-      TL_CALL(gemm_pl(att2p, w.o2, y2, M, C, C, C, C, C, false, false, w.bo2, y1, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+      TL_CALL(lin(att2p, w.o2, fr.o2, y2, C, C, w.bo2, y1));
       TL_CALL(pfpp_layernorm_split(y2, n3.hi, n3.lo, nullptr, 0, w.g3, w.b3, M, C, 1, eps, stream));
     }
     // ---- GEGLU feed-forward (attention.py:87-90)
     TL_CALL(gemm_pl(n3, w.ff1, z, M, 2 * inner, C, C, C, 2 * inner, false, false, w.bff1, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
     TL_CALL(pfpp_geglu_p(z, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &u, stream));
-    TL_CALL(gemm_pl(u, w.ff2, hout, M, C, inner, inner, inner, C, false, false, w.bff2, y2, false, nullptr, a->ws_main, a->ws_bytes, 0, stream));
+    TL_CALL(lin(u, w.ff2, fr.ff2, hout, C, inner, w.bff2, y2));
   }
   return PFPP_OK;
 }
@@ -268,7 +307,11 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     if (side && k >= 0) TL_CALL(slot_read_on(g_slots[k], side_s));
     return PFPP_OK;
   };
-  auto dx = [&](const pfpp_planes& dyp, const pfpp_planes& W, float* out, int64_t n_in, int64_t n_out) -> int {
+  const bool wd = a->frag_ws != nullptr && wd_shapes_ok(M, C, inner);
+  if (wd) PFPP_REQUIRE(a->frag_ws_bytes >= pfpp_tlayers_frag_bytes(C, inner), "frag_ws_bytes smaller than pfpp_tlayers_frag_bytes()");
+  LayerFrag fr;                         // blocked planes of the TRANSPOSED weights of the current layer
+  auto dx = [&](const pfpp_planes& dyp, const pfpp_planes& W, float* out, int64_t n_in, int64_t n_out, const pfpp_pw* Ft = nullptr) -> int {
+    if (wd && Ft) return pfpp_gemm_wd(&dyp, n_out, Ft, nullptr, nullptr, 0, out, n_in, M, n_in, n_out, stream);
     return gemm_pl(dyp, W, out, M, n_in, n_out, n_out, n_in, n_in, false, true, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream);
   };
 
@@ -280,6 +323,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     cur_layer = i;
     const pfpp_tlayer_params& w = a->layers[i];
     const pfpp_tlayer_grads& g = a->grads[i];
+    if (wd) TL_CALL(reblock_layer(a, w, true, &fr, stream));
     char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
     const float* h0 = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
     const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
@@ -298,7 +342,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     const int drop = a->p_lay > 0.0f ? 1 : 0;
     // ---- feed-forward (attention.py:87-90)
     TL_CALL(dw(dhp, dhp_slot, u, C, inner, g.ff2_w, g.ff2_b));
-    TL_CALL(dx(dhp, w.ff2, du, inner, C));
+    TL_CALL(dx(dhp, w.ff2, du, inner, C, &fr.ff2));
     pfpp_planes dzp, dyp, dqkvp;
     TL_CALL(fresh(SLOT_DZ0 + par, M * 2 * inner, &dzp));
     TL_CALL(pfpp_geglu_bwd_p(z, du, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &dzp, stream));
@@ -309,22 +353,22 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
                                  (uint32_t)(2 + 3 * i), drop, &dyp, nullptr, stream));
     // ---- global attention (attention.py:82-85)
     TL_CALL(dw(dyp, SLOT_DY0 + 2 * par, att2p, C, C, g.o2_w, g.o2_b));
-    TL_CALL(dx(dyp, w.o2, datt, C, C));
+    TL_CALL(dx(dyp, w.o2, datt, C, C, &fr.o2));
     TL_CALL(fresh(SLOT_QA0 + par, M * 3 * C, &dqkvp));
     TL_CALL(pfpp_attn_dense_bwd_p(qkv2, att2, datt, lse, reinterpret_cast<float*>(dvec_b), nullptr, a->seq_off, a->seq_len, nullptr, 0, a->n_seq,
                                   a->max_len, H, dh, a->att_scale, &dqkvp, stream));
     TL_CALL(dw(dqkvp, SLOT_QA0 + par, n2, 3 * C, C, g.qkv2_w, nullptr));
-    TL_CALL(dx(dqkvp, w.qkv2, dn, C, 3 * C));
+    TL_CALL(dx(dqkvp, w.qkv2, dn, C, 3 * C, &fr.qkv2));
     TL_CALL(fresh(SLOT_DY0 + 2 * par + 1, M * C, &dyp));
     TL_CALL(pfpp_layernorm_bwd_p(h1, dn, mod2, ld_mod, nullptr, a->frag_b, L, 1, a->dh, dmod2, dmod2 + C, ld_mod, M, C, eps, nullptr, a->p_lay,
                                  a->seed, (uint32_t)(1 + 3 * i), drop, &dyp, nullptr, stream));
     // ---- self attention (attention.py:77-80)
     TL_CALL(dw(dyp, SLOT_DY0 + 2 * par + 1, att1, C, C, g.o1_w, g.o1_b));
-    TL_CALL(dx(dyp, w.o1, datt, C, C));
+    TL_CALL(dx(dyp, w.o1, datt, C, C, &fr.o1));
     TL_CALL(fresh(SLOT_QB0 + par, M * 3 * C, &dqkvp));
     TL_CALL(pfpp_attn_blockdiag_bwd_p(qkv1, datt, nullptr, a->Fv, L, H, dh, a->att_scale, &dqkvp, stream));
     TL_CALL(dw(dqkvp, SLOT_QB0 + par, n1, 3 * C, C, g.qkv1_w, nullptr));
-    TL_CALL(dx(dqkvp, w.qkv1, dn, C, 3 * C));
+    TL_CALL(dx(dqkvp, w.qkv1, dn, C, 3 * C, &fr.qkv1));
     if (i > 0) {
       // the updated running gradient is the dY of layer i - 1's second feed-forward linear
       pfpp_planes nxt;

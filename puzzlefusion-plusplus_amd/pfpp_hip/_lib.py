@@ -179,7 +179,15 @@ class TlayersArgs(C.Structure):
         ("dh", _p), ("dhp", PlanesC), ("dhp_out", C.POINTER(PlanesC)), ("dmods", _p), ("dtok", _p),
         ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("bc1", _f32), ("bc2", _f32),
         ("opt_g_scale", _f32), ("opt_zero_grad", _i32), ("overflow", _p),
+        ("frag_ws", _p), ("frag_ws_bytes", _i64),
     ]
+
+
+class ReblockJob(C.Structure):
+    """mirror of struct pfpp_reblock_job (include/pfpp.h)"""
+
+    _fields_ = [("w", PlanesC), ("N", _i64), ("K", _i64), ("ldw", _i64), ("fhi", _p), ("flo", _p), ("transposed", _i32)]
+
 
 # name -> argtypes (all return int); must list every symbol include/pfpp.h declares
 SIGNATURES = {
@@ -188,6 +196,7 @@ SIGNATURES = {
     "pfpp_gemm_small": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_gemm_wd": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_gemm_wd_supported": [_i64, _i64, _i64],
+    "pfpp_reblock_planes": [C.POINTER(ReblockJob), _i32, _p],
     "pfpp_layernorm_linear_small": [_p, _p, _i64, _p, _p, _p, _i64, C.POINTER(PwC), _p, _p, _i64, _pl, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "pfpp_heads_bwd": [_p, _p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _p,
@@ -290,6 +299,7 @@ PLAIN = {
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_get_attention_mode": ([], C.c_int),
     "pfpp_tlayers_fwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
+    "pfpp_tlayers_frag_bytes": ([_i64, _i64], C.c_int64),
     "pfpp_tlayers_fwd_hout_offset": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_tlayers_bwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_bn_stats_workspace": ([_i64, _i64], C.c_int64),
@@ -301,7 +311,7 @@ STRUCT_MIRRORS = {
     "sample_level": SampleLevel, "gemm_args": GemmArgs, "planes": PlanesC, "slab_job": SlabJob, "gemm_planes_args": GemmPlanesArgs,
     "sa_train_args": SaTrainArgs, "gemm_grad_args": GemmGradArgs, "tlayer_params": TlayerParams, "tlayer_grads": TlayerGrads,
     "tlayer_adamw": TlayerAdamw, "tlayers_args": TlayersArgs, "pw": PwC, "elayer_params": ElayerParams,
-    "tlayers_eval_args": TlayersEvalArgs, "head_params": HeadParams, "head_grads": HeadGrads,
+    "tlayers_eval_args": TlayersEvalArgs, "head_params": HeadParams, "head_grads": HeadGrads, "reblock_job": ReblockJob,
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}

@@ -33,6 +33,10 @@ SA_TRAIN_UTAB = _os.environ.get("PFPP_SA_TRAIN_UTAB", "1") == "1"
 SA_EVAL_UTAB = int(_os.environ.get("PFPP_SA_EVAL_UTAB", "2"))
 SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 in train mode as rows launches (sa_wide_train_kernel)
 
+# eval-mode level 3 on the rows kernels of the train-mode chain (0 = elementwise pass + two tiled plane GEMMs: the cross-check), from
+# this many grouped rows up (a handful of fragments stays on the tiled path: a persistent rows workgroup loads a 140 KB weight slice first)
+SA_EVAL_ROWS = _os.environ.get("PFPP_SA_EVAL_ROWS", "1") == "1"
+SA_EVAL_ROWS_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS_MIN", str(32 * 25 * 64)))
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
@@ -182,6 +186,37 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
     return h
 
 
+def _sa_wide_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
+    """eval-mode wide level (sa3: 256 + 3 -> 256 -> 256 -> 512, 64 neighbours) on the ROWS kernels of the train-mode chain
+    (csrc/sa_train.hip sa_wide_train_kernel<256, 2, UG> / <256, 3>: a workgroup keeps a 128-column slice of the layer's weight planes in
+    LDS for its lifetime, a wave streams 32 rows at a time) instead of an elementwise pass + two tiled plane GEMMs with their
+    [rows, 256] planes in between: 430 instead of 766 us at 154 fragments.  Same entry point as training (pfpp_sa_train_stage) with the
+    FOLDED BatchNorm scale / shift as the layers' affines and zero conv biases (the folded shift carries them, pn2_utils.py:210-216 in
+    .eval()): layer 1 per point (U[point] - W_xyz . centroid), layer 2 from gathered table rows -> raw y_2, layer 3 -> per-neighbourhood
+    max / min of y_3, and max_p relu(s y_p + t) = relu(s (s >= 0 ? max y : min y) + t) exactly (monotone).  The statistics the train
+    kernels also accumulate go to a scratch buffer nobody reads."""
+    from . import train_ops as T
+
+    xyz, new_xyz, feats, ball = grp
+    dev = xyz.device
+    F, S = ball.shape[:2]
+    rows = F * S * nsample
+    ws = [pk[f"{name}.w{i}"] for i in range(3)]
+    aff = [(pk[f"{name}.s{i}"], pk[f"{name}.t{i}"]) for i in range(3)]
+    sc = pk.get(f"{name}._rows_eval")
+    if sc is None:
+        sc = pk[f"{name}._rows_eval"] = ([torch.zeros(w.N, dtype=torch.float32, device=dev) for w in ws],
+                                         [T.bn_stats_buffer(w.N, dev) for w in ws])
+    zb, st = sc
+    u = ops.sa_first_table(xyz, feats, ws[0], None)
+    y2 = torch.empty((rows, ws[1].N), dtype=torch.float32, device=dev)
+    ops.sa_train_stage(2, xyz, new_xyz, feats, ball, ws, zb, aff[:1], st[1], y_out=y2, u_in=u)
+    mx = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
+    mn = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
+    ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_in=y2, out_max=mx, out_min=mn)
+    return T.bn_minmax_apply(mx, mn, aff[2][0], aff[2][1])
+
+
 def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz: torch.Tensor,
                     feats: Optional[torch.Tensor], capture: Optional[dict] = None, sampled=None):
     """xyz [F,N,3], feats [F,N,D] or None -> new_xyz [F,S,3], new_feats [F,S,C3].  sampled = (fps_idx, new_xyz, ball_idx) when the
@@ -232,6 +267,10 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             capture[f"{name}.new_xyz"] = new_xyz
             capture[f"{name}.new_points"] = new_feats
         return new_xyz, new_feats
+    elif (SA_EVAL_ROWS and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
+          and feats.shape[2] == 256 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (256, 256, 512)
+          and F * npoint * nsample >= SA_EVAL_ROWS_MIN):
+        h = _sa_wide_eval(pk, name, grp, nsample)
     else:
         rows = F * npoint * nsample
         sp = ops.split_mode() and ops.GEMM_MODE == "f16x3"      # activations between the layers as split-f16 planes

@@ -911,6 +911,19 @@ def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[tor
     return out
 
 
+def reblock_planes(hi: torch.Tensor, lo: torch.Tensor, transposed: bool = False):
+    """fragment-blocked copies (pfpp_pw.fhi / flo layout) of row-major planes [N, K] — of the matrix itself, or (transposed) of its
+    transpose [K, N] (pfpp_reblock_planes; what pfpp_tlayers_fwd / _bwd do for a training layer's weights) -> (fhi, flo) flat fp16"""
+    from ._lib import PlanesC, ReblockJob
+
+    _chk(hi, torch.float16, "hi"); _chk(lo, torch.float16, "lo")
+    N, K = hi.shape
+    fhi, flo = torch.empty(N * K, dtype=torch.float16, device=hi.device), torch.empty(N * K, dtype=torch.float16, device=hi.device)
+    job = ReblockJob(PlanesC(hi.data_ptr(), lo.data_ptr(), 1.0), N, K, hi.stride(0), fhi.data_ptr(), flo.data_ptr(), int(transposed))
+    check(_lib.load().pfpp_reblock_planes(C.byref(job), 1, _stream()), "pfpp_reblock_planes")
+    return fhi, flo
+
+
 def layernorm_linear_small(x: torch.Tensor, w, *, mod: Optional[torch.Tensor] = None, group_batch: Optional[torch.Tensor] = None,
                            group_rows: int = 1, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
                            bias: Optional[torch.Tensor] = None, geglu: bool = False, eps: float = 1e-5):

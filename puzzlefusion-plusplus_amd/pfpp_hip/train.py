@@ -579,6 +579,13 @@ class DenoiserTrainEngine:
         args.layers, args.grads = layers, grads
         C = w["shape.b"].numel()
         args.C, args.H, args.inner = C, self.num_heads, w["0.ff1.w"].f32.shape[0] // 2
+        if os.environ.get("PFPP_TRAIN_WD", "1") == "1":
+            # scratch for the fragment-blocked copies of a layer's weights: qkv / out / second feed-forward linears and their input
+            # gradients with the weights read straight into the matrix operands (csrc/gemm_wd.hip; 0 = the tiled kernel, the cross-check)
+            from . import _lib
+            nbytes = int(_lib.load().pfpp_tlayers_frag_bytes(C, int(args.inner)))
+            self._frag_ws = torch.empty(nbytes, dtype=torch.uint8, device=w["shape.b"].device)
+            args.frag_ws, args.frag_ws_bytes = self._frag_ws.data_ptr(), nbytes
         self._cseq_static = (args, (layers, grads, adam))
         return self._cseq_static
 
