@@ -498,7 +498,7 @@ def roofline_from_trace(trace, steps: int, mode: str, serialised: bool = False):
     achieved = flops / (ms * 1e-3) / 1e12          # algorithmic 2*M*N*K of the launches / their duration
     flags = name.split("<")[1].split(">")[0].split(", ") if "gemm_pl_kernel<" in name else []
     single = len(flags) > 9 and flags[9] == "true"                     # template flag X1: single-pass fp16
-    split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name or "_train_kernel" in name) and not single
+    split = ("f16x3" in name or "gemm_grad" in name or "gemm_pl" in name or "gemm_wd" in name or "_train_kernel" in name) and not single
     # the split path spends 3 f16 matrix FLOPs per algorithmic FLOP: its ceiling for algorithmic
     # FLOPs is the f16 dense peak / 3
     peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)

@@ -303,21 +303,28 @@ def denoiser_forward_compact(pk, x, timesteps, latent, xyz, part_valids, scale, 
         norm, att, u_buf = (ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, C, dev), ops.SplitAct.empty(M, inner, dev))
     else:
         norm, att, u_buf = torch.empty_like(h), torch.empty_like(h), None
+    # bench.py's per-launch timing pass issues the blocks from Python: it then takes the weight-direct GEMMs pfpp_tlayers_eval takes, so
+    # that the roofline object describes the kernels of the timed region (untraced, this sequence stays the tiled cross-check)
+    wd = (not in_c and ops.GEMM_TRACE is not None and ops.split_mode() and not ops.SINGLE_PASS and os.environ.get("PFPP_EVAL_WD", "1") == "1"
+          and os.environ.get("PFPP_EVAL_CSEQ", "1") == "1" and M > int(os.environ.get("PFPP_EVAL_LNLIN_ROWS", "2048")) and C % 128 == 0)
+
+    def lin_res(a_, wkey, bkey, K_):
+        if wd:
+            return ops.gemm_wd(a_, pk[wkey], bias=pk[bkey], residual=h, out=h)
+        return ops.gemm(a_, pk[wkey], M=M, N=C, K=K_, lda=K_, out=h, ldc=C, bias=pk[bkey], residual=h, ldr=C)
+
     for i in range(0 if in_c else num_layers):
         ops.layernorm_grouped(h, mods[2 * i], frag_b, L, out=norm)
-        qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
+        qkv = ops.gemm_wd(norm, pk[f"{i}.self_attn.wqkv"]) if wd else ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
         ops.attn_blockdiag(qkv, Fv, L, num_heads, dh, att_scale, out=att)
-        ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
-                 bias=pk[f"{i}.self_attn.bo"], residual=h, ldr=C)
+        lin_res(att, f"{i}.self_attn.wo", f"{i}.self_attn.bo", C)
         ops.layernorm_grouped(h, mods[2 * i + 1], frag_b, L, out=norm)
-        qkv = ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
+        qkv = ops.gemm_wd(norm, pk[f"{i}.global_attn.wqkv"]) if wd else ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
         ops.attn_dense(qkv, seq_off, seq_len, max_len, num_heads, dh, att_scale, None, out=att)
-        ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
-                 bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
+        lin_res(att, f"{i}.global_attn.wo", f"{i}.global_attn.bo", C)
         ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
         u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu", out=u_buf)
-        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=inner, lda=inner, out=h, ldc=C,
-                 bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
+        lin_res(u, f"{i}.ff.w2", f"{i}.ff.b2", inner)
     pooled = ops.mean_pool(h, Fv, L)
     if _fused_heads(pk, pooled, out, lay.slot32):
         return out.view(B, P, 7)

@@ -152,3 +152,40 @@ def slab_reduce_group(jobs) -> None:
     """pfpp_slab_reduce_group: the K-split reductions gemm(..., defer=job) handed back, all in one launch"""
     arr = (SlabJob * len(jobs))(*jobs)
     check(_lib.load().pfpp_slab_reduce_group(arr, len(jobs), _stream()), "pfpp_slab_reduce_group")
+
+
+def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+    """the same linear as gemm(...) / gemm(..., w_kmajor=True) through the weight-direct kernel (csrc/gemm_wd.hip), the way
+    pfpp_tlayers_fwd / _bwd run it: W's planes are fragment-blocked first (pfpp_reblock_planes; transposed: W is [K, N] and its
+    transpose is blocked — the input-gradient form), then pfpp_gemm_wd.  Only the traced pass of bench.py issues it from Python (the
+    product path is the C sequencer): both launches are recorded in ops.GEMM_TRACE under their kernel names."""
+    from . import ops
+    from ._lib import PlanesC, PwC, ReblockJob
+
+    _chk(out, _f32, "out")
+    lib = _lib.load()
+    rows, cols = (K, N) if transposed else (N, K)               # W as stored
+    fhi = torch.empty(N * K, dtype=torch.float16, device=out.device)
+    flo = torch.empty(N * K, dtype=torch.float16, device=out.device)
+    job = ReblockJob(PlanesC(W.hi.data_ptr(), W.lo.data_ptr(), W.scale), rows, cols, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr(),
+                     int(transposed))
+    pw = PwC(None, W.hi.data_ptr(), W.lo.data_ptr(), W.scale, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr())
+    ap = PlanesC(A.hi.data_ptr(), A.lo.data_ptr(), A.scale)
+    trace = ops.GEMM_TRACE
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if trace is not None else None
+    if ev:
+        ev[0].record()
+    check(lib.pfpp_reblock_planes(C.byref(job), 1, _stream()), "pfpp_reblock_planes")
+    if ev:
+        ev[1].record(); ev[2].record()
+    check(lib.pfpp_gemm_wd(C.byref(ap), A.hi.shape[-1], C.byref(pw), None if bias is None else bias.data_ptr(),
+                           None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[-1],
+                           out.data_ptr(), out.shape[-1], M, N, K, _stream()), "pfpp_gemm_wd")
+    if ev:
+        ev[3].record()
+        big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 250
+        trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
+        trace.append((ev[2], ev[3], 2.0 * M * N * K, "gemm_wd_kernel<4, 2, 4>" if big else "gemm_wd_kernel<2, 1, 3>",
+                      (M, N, K, 1, "nn" if transposed else "nt", 0)))
+    return out

@@ -277,6 +277,13 @@ class TrainContext:
 _DIAG_HOST_DELAY_US = float(os.environ.get("PFPP_DIAG_HOST_DELAY_US", "0"))
 
 
+def _traced_wd() -> bool:
+    """bench.py's per-launch timing pass (ops.GEMM_TRACE) issues the blocks from Python; it then takes the weight-direct GEMMs the C
+    sequencer takes (PFPP_TRAIN_WD), so that the roofline object describes the kernels of the timed region — the untraced Python
+    sequence stays the tiled cross-check"""
+    return ops.GEMM_TRACE is not None and os.environ.get("PFPP_TRAIN_WD", "1") == "1" and not ops.SINGLE_PASS
+
+
 class DenoiserTrainEngine:
     """forward (train mode) / backward / optimizer step of a DenoiserTransformer on the HIP kernels"""
 
@@ -477,6 +484,8 @@ class DenoiserTrainEngine:
 
         def lin(a, key, N, K, bias=None, residual=None):
             out = torch.empty((M, N), dtype=torch.float32, device=dev)
+            if _traced_wd() and not key.endswith("ff1.w") and N % 128 == 0 and K % 64 == 0:
+                return P.gemm_wd(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual)
             return P.gemm(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual)
 
         def ln_planes(x, i_mod=None, gamma=None, beta=None):
@@ -989,6 +998,8 @@ class DenoiserTrainEngine:
 
         def dx(dyp, key, n_in):
             out = torch.empty((M, n_in), dtype=torch.float32, device=dev)
+            if _traced_wd() and not key.endswith("ff1.w") and n_in % 128 == 0 and dyp.shape[1] % 64 == 0:
+                return P.gemm_wd(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], transposed=True)
             return P.gemm(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], w_kmajor=True)
 
         drop_lay = fuse and p_lay > 0.0
