@@ -371,21 +371,29 @@ def denoiser_forward(pk, x, timesteps, latent, xyz, part_valids, scale, ref_part
                         ops.SplitAct.empty(M, inner, h.device))
     else:
         norm, att, u = torch.empty_like(h), torch.empty_like(h), None
+    # lab switch (PFPP_EVAL_WD_FULL=1): qkv / out-projection / second feed-forward linear through csrc/gemm_wd.hip (bit-identical).  With
+    # all 640 slots evaluated (16,000 tokens) the 256 x 128 tiled kernel has enough tiles per CU that its LDS traffic is not the bound:
+    # 6.756 vs 6.751 ms per sampler step (profiles/r04zw_ab_wd_full.txt) — off by default
+    wd = (split and not ops.SINGLE_PASS and capture is None and C % 128 == 0 and inner % 64 == 0
+          and os.environ.get("PFPP_EVAL_WD_FULL", "0") == "1")
+
+    def lin_res(a_, wkey, bkey, K_):
+        if wd:
+            return ops.gemm_wd(a_, pk[wkey], bias=pk[bkey], residual=h, out=h)
+        return ops.gemm(a_, pk[wkey], M=M, N=C, K=K_, lda=K_, out=h, ldc=C, bias=pk[bkey], residual=h, ldr=C)
+
     for i in range(num_layers):
         ops.layernorm(h, mod=mods[2 * i], rows_per_batch=T, out=norm)
-        qkv = ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
+        qkv = ops.gemm_wd(norm, pk[f"{i}.self_attn.wqkv"]) if wd else ops.linear(norm, pk[f"{i}.self_attn.wqkv"])
         ops.attn_blockdiag(qkv, n, L, num_heads, dh, att_scale, out=att)
-        ops.gemm(att, pk[f"{i}.self_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
-                 bias=pk[f"{i}.self_attn.bo"], residual=h, ldr=C)
+        lin_res(att, f"{i}.self_attn.wo", f"{i}.self_attn.bo", C)
         ops.layernorm(h, mod=mods[2 * i + 1], rows_per_batch=T, out=norm)
-        qkv = ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
+        qkv = ops.gemm_wd(norm, pk[f"{i}.global_attn.wqkv"]) if wd else ops.linear(norm, pk[f"{i}.global_attn.wqkv"])
         dense_attention(qkv, B, T, num_heads, dh, key_valid, att_scale, out=att)
-        ops.gemm(att, pk[f"{i}.global_attn.wo"], M=M, N=C, K=C, lda=C, out=h, ldc=C,
-                 bias=pk[f"{i}.global_attn.bo"], residual=h, ldr=C)
+        lin_res(att, f"{i}.global_attn.wo", f"{i}.global_attn.bo", C)
         ops.layernorm(h, gamma=pk[f"{i}.norm3.g"], beta=pk[f"{i}.norm3.b"], out=norm)
         u = ops.linear(norm, pk[f"{i}.ff.w1"], pk[f"{i}.ff.b1"], act="geglu", out=u)
-        ops.gemm(u, pk[f"{i}.ff.w2"], M=M, N=C, K=inner, lda=inner, out=h, ldc=C,
-                 bias=pk[f"{i}.ff.b2"], residual=h, ldr=C)
+        lin_res(u, f"{i}.ff.w2", f"{i}.ff.b2", inner)
         if capture is not None:
             capture[f"layer{i}"] = h.clone()
     pooled = ops.mean_pool(h, n, L)
