@@ -36,7 +36,10 @@ SA_TRAIN_WIDE = _os.environ.get("PFPP_SA_TRAIN_WIDE", "1") == "1"     # level 3 
 # eval-mode level 3 on the rows kernels of the train-mode chain (0 = elementwise pass + two tiled plane GEMMs: the cross-check), from
 # this many grouped rows up (a handful of fragments stays on the tiled path: a persistent rows workgroup loads a 140 KB weight slice first)
 SA_EVAL_ROWS = _os.environ.get("PFPP_SA_EVAL_ROWS", "1") == "1"
-SA_EVAL_ROWS_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS_MIN", str(32 * 25 * 64)))
+SA_EVAL_ROWS_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS_MIN", "0"))
+# the same for level 2 (128 + 3 -> 128 -> 128 -> 256: stage 2 writes the raw second-layer rows, stage 3 keeps the third layer's weights in LDS)
+SA_EVAL_ROWS2 = _os.environ.get("PFPP_SA_EVAL_ROWS2", "1") == "1"
+SA_EVAL_ROWS2_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS2_MIN", "200000"))      # one puzzle in flight (65 K rows): neutral, stays tiled
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
@@ -213,7 +216,10 @@ def _sa_wide_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
     ops.sa_train_stage(2, xyz, new_xyz, feats, ball, ws, zb, aff[:1], st[1], y_out=y2, u_in=u)
     mx = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
     mn = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
-    ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_in=y2, out_max=mx, out_min=mn)
+    if feats.shape[2] == 256:      # level 3: one rows launch per layer, the previous layer's raw rows come in as y_in
+        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_in=y2, out_max=mx, out_min=mn)
+    else:                          # level 2: stage 3 reads the raw rows stage 2 wrote, its 256 x 128 weight planes resident in LDS
+        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_out=y2, out_max=mx, out_min=mn)
     return T.bn_minmax_apply(mx, mn, aff[2][0], aff[2][1])
 
 
@@ -247,6 +253,14 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             capture[f"{name}.new_xyz"] = new_xyz
             capture[f"{name}.new_points"] = new_feats
         return new_xyz, new_feats
+    elif (SA_EVAL_ROWS and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
+          and feats.shape[2] == 256 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (256, 256, 512)
+          and F * npoint * nsample >= SA_EVAL_ROWS_MIN):
+        h = _sa_wide_eval(pk, name, grp, nsample)
+    elif (SA_EVAL_ROWS2 and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
+          and feats.shape[2] == 128 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (128, 128, 256)
+          and F * npoint * nsample >= SA_EVAL_ROWS2_MIN):
+        h = _sa_wide_eval(pk, name, grp, nsample)
     elif (SA_FUSED and fused and feats is not None and nsample == 64 and feats.shape[2] == 128
           and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N) == (128, 128)):
         # level 2: grouping + layers 1 and 2 in one kernel, layer 3 (+ max over nsample) as a GEMM
@@ -267,10 +281,6 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
             capture[f"{name}.new_xyz"] = new_xyz
             capture[f"{name}.new_points"] = new_feats
         return new_xyz, new_feats
-    elif (SA_EVAL_ROWS and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
-          and feats.shape[2] == 256 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (256, 256, 512)
-          and F * npoint * nsample >= SA_EVAL_ROWS_MIN):
-        h = _sa_wide_eval(pk, name, grp, nsample)
     else:
         rows = F * npoint * nsample
         sp = ops.split_mode() and ops.GEMM_MODE == "f16x3"      # activations between the layers as split-f16 planes

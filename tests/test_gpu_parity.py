@@ -1769,8 +1769,8 @@ def test_sa_table_planes_equals_grouped_first_layer(dev, F, N, S, D):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("F,N,S", [(3, 128, 25), (40, 128, 25)])
-def test_sa_wide_eval_rows_equals_the_tiled_level(dev, F, N, S, monkeypatch):
+@pytest.mark.parametrize("F,N,S,D", [(3, 128, 25, 256), (40, 128, 25, 256), (3, 256, 128, 128), (12, 256, 128, 128)])
+def test_sa_wide_eval_rows_equals_the_tiled_level(dev, F, N, S, D, monkeypatch):
     """eval-mode level 3 (256 + 3 -> 256 -> 256 -> 512, 64 neighbours, folded BatchNorm, max over the neighbourhood) on the rows kernels
     of the train-mode chain (encoder._sa_wide_eval: pfpp_sa_train_stage with the folded scale / shift as affines, max / min trick) against
     the elementwise pass + two tiled plane GEMMs it replaces and a float64 restatement of pn2_utils.py:203-216 in .eval(); negative
@@ -1779,41 +1779,45 @@ def test_sa_wide_eval_rows_equals_the_tiled_level(dev, F, N, S, monkeypatch):
     from pfpp_hip.packing import PW, pack_sa_first
 
     g = torch.Generator().manual_seed(F * 17 + S)
-    ns, D = 64, 256
+    ns = 64
+    lvl, radius = ("sa3", 0.8) if D == 256 else ("sa2", 0.4)
     xyz = torch.rand(F, N, 3, generator=g)
     feats = torch.randn(F, N, D, generator=g)
     new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
     idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32)
-    widths = (256, 256, 512)
-    w_ref = [torch.randn(256, D + 3, generator=g) * 0.06, torch.randn(256, 256, generator=g) * 0.06, torch.randn(512, 256, generator=g) * 0.06]
+    widths = (D, D, 2 * D)
+    w_ref = [torch.randn(D, D + 3, generator=g) * 0.06, torch.randn(D, D, generator=g) * 0.06, torch.randn(2 * D, D, generator=g) * 0.06]
     sc = [torch.rand(c, generator=g) + 0.5 for c in widths]
     sc[2][::3] *= -1.0                                         # some output channels with a negative folded scale
     sh = [torch.randn(c, generator=g) * 0.3 for c in widths]
     d = lambda t: t.to(dev)
     pk = {}
     for i in range(3):
-        pk[f"sa3.w{i}"] = PW(d(pack_sa_first(w_ref[0], D) if i == 0 else w_ref[i]).contiguous(), prescale=False)
-        pk[f"sa3.s{i}"], pk[f"sa3.t{i}"] = d(sc[i]), d(sh[i])
+        pk[f"{lvl}.w{i}"] = PW(d(pack_sa_first(w_ref[0], D) if i == 0 else w_ref[i]).contiguous(), prescale=False)
+        pk[f"{lvl}.s{i}"], pk[f"{lvl}.t{i}"] = d(sc[i]), d(sh[i])
     outs = []
     for rows_path in (False, True):
         monkeypatch.setattr(encoder, "SA_EVAL_ROWS", rows_path)
+        monkeypatch.setattr(encoder, "SA_EVAL_ROWS2", rows_path)
+        monkeypatch.setattr(encoder, "SA_EVAL_ROWS2_MIN", 0)
         monkeypatch.setattr(encoder, "SA_EVAL_ROWS_MIN", 0)
-        _, h = encoder.set_abstraction(pk, "sa3", S, 0.8, ns, d(xyz), d(feats), sampled=(None, d(new_xyz), d(idx)))
+        _, h = encoder.set_abstraction(pk, lvl, S, radius, ns, d(xyz), d(feats), sampled=(None, d(new_xyz), d(idx)))
         outs.append(h.clone())
     tiled, rows = outs
-    assert "sa3._rows_eval" in pk and rows.shape == tiled.shape == (F, S, 512)
+    assert f"{lvl}._rows_eval" in pk and rows.shape == tiled.shape == (F, S, 2 * D)
     ii = idx.long()
     gx = torch.gather(xyz.double().unsqueeze(1).expand(F, S, N, 3), 2, ii.unsqueeze(-1).expand(F, S, ns, 3)) - new_xyz.double().unsqueeze(2)
     gf = torch.gather(feats.double().unsqueeze(1).expand(F, S, N, D), 2, ii.unsqueeze(-1).expand(F, S, ns, D))
     y = torch.cat([gx, gf], -1).reshape(-1, D + 3)
     for i in range(3):
         y = torch.relu(y @ w_ref[i].double().t() * sc[i].double() + sh[i].double())
-    y = y.view(F, S, ns, 512).max(2).values
+    y = y.view(F, S, ns, 2 * D).max(2).values
     tol = 2e-5 * y.abs().max().item()
     assert (rows.double().cpu() - y).abs().max().item() < tol
     assert (rows - tiled).abs().max().item() < tol
     monkeypatch.setattr(encoder, "SA_EVAL_ROWS", True)
-    _, again = encoder.set_abstraction(pk, "sa3", S, 0.8, ns, d(xyz), d(feats), sampled=(None, d(new_xyz), d(idx)))
+    monkeypatch.setattr(encoder, "SA_EVAL_ROWS2", True)
+    _, again = encoder.set_abstraction(pk, lvl, S, radius, ns, d(xyz), d(feats), sampled=(None, d(new_xyz), d(idx)))
     assert torch.equal(again, rows)
 
 
