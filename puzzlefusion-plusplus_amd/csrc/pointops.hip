@@ -122,6 +122,89 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 
 // ---------------------------------------------------------------------------
+// One step of the farthest-point chain, shared by fps_kernel and the fused sampling kernel.  The step is a dependent chain (centroid
+// -> distances -> argmax -> next centroid), 255 of them for level 1: what counts is its LATENCY.
+//   * distances two points at a time (v_pk_add_f32 / v_pk_mul_f32: the same correctly rounded sub, mul, add per element, in the
+//     reference's order ((dx^2 + dy^2) + dz^2); -ffp-contract=off keeps them apart);
+//   * the lane's best is a max tree over its running minima (v_max3_f32), the index is NOT carried through the loop: after the wave
+//     maximum, the lowest lane holding it is found by ballot (blocked ownership: lowest lane = lowest index block) and the first of its
+//     points equal to the maximum by PPT compares — torch.argmax's first-maximum rule, as before;
+//   * waves exchange (maximum, index) as ONE 8-byte LDS write each and two 16-byte broadcast reads, behind a raw `s_waitcnt lgkmcnt(0);
+//     s_barrier`: __syncthreads() also drains vmcnt, i.e. waited every step for the global stores of the previous selection.
+// Measured (one puzzle in flight, rocprofv3): 1,000 -> 256 points 107.9 -> 94.0 us, 256 -> 128 33.2 -> 28.5 us.  Tried on top and
+// dropped (slower: 123 / 35 us): the winner's coordinates carried through v_readlane and a 16-byte exchange slot instead of the LDS
+// fetch by index, single-instruction v_max_f32_dpp steps and v_min / v_max without the IEEE-mode canonicalisation via inline asm —
+// the select chains and the opaque asm (an s_nop after every statement) cost more than the broadcast LDS reads they replace.
+// ---------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int PPT>
+struct FpsLane {
+  static constexpr int NP = (PPT + 1) / 2;
+  f2v x[NP], y[NP], z[NP], d[NP];      // this lane's points [t * PPT, (t + 1) * PPT) and their running minimum distances (pads: -1)
+
+  __device__ __forceinline__ void load(const float* xs, const float* ys, const float* zs, int stride, int t, int N) {
+#pragma unroll
+    for (int k = 0; k < 2 * NP; ++k) {
+      const int i = t * PPT + k;
+      const bool ok = k < PPT && i < N;
+      x[k >> 1][k & 1] = ok ? xs[(size_t)stride * i] : 0.0f;
+      y[k >> 1][k & 1] = ok ? ys[(size_t)stride * i] : 0.0f;
+      z[k >> 1][k & 1] = ok ? zs[(size_t)stride * i] : 0.0f;
+      d[k >> 1][k & 1] = ok ? __builtin_huge_valf() : -1.0f;   // pads can never win
+    }
+  }
+  // running minima against the new centroid -> this lane's maximum
+  __device__ __forceinline__ float update(float cx, float cy, float cz) {
+    const f2v c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const f2v dx = x[q] - c_x, dy = y[q] - c_y, dz = z[q] - c_z;
+      const f2v dd = (dx * dx + dy * dy) + dz * dz;
+      d[q][0] = fminf(d[q][0], dd[0]);
+      d[q][1] = fminf(d[q][1], dd[1]);
+    }
+    float b = d[0][0];
+#pragma unroll
+    for (int k = 1; k < 2 * NP; ++k) b = fmaxf(b, d[k >> 1][k & 1]);
+    return b;
+  }
+  // first of this lane's points whose running minimum equals v (meaningful in the lane that holds the wave maximum)
+  __device__ __forceinline__ int first_equal(float v) const {
+    int kk = PPT - 1;
+#pragma unroll
+    for (int k = PPT - 2; k >= 0; --k) kk = (d[k >> 1][k & 1] == v) ? k : kk;
+    return kk;
+  }
+};
+
+// LDS words of the exchange slots of G waves: [2][G] (maximum, index) pairs, 16-byte aligned
+#define PFPP_FPS_SLOT_WORDS(G) (4 * (G) + 4)
+
+// argmax over the G waves' lanes -> selected index (every thread of the G waves calls it; one raw barrier when G > 1)
+template <int G, int PPT>
+__device__ __forceinline__ int fps_argmax(const FpsLane<PPT>& pts, float lane_best, int t, int s, float* slot) {
+  const int lane = t & 63, wave = t >> 6;
+  const float wmax = wave_max_f32(lane_best);
+  const unsigned long long m = __ballot(lane_best == wmax);
+  const int widx = __builtin_amdgcn_readlane(t * PPT + pts.first_equal(wmax), __builtin_ctzll(m));
+  if (G == 1) return widx;
+  int2* cur = reinterpret_cast<int2*>(slot) + (s & 1) * G;
+  if (lane == 0) cur[wave] = make_int2(__float_as_int(wmax), widx);
+  lds_barrier();
+  float bm = __int_as_float(cur[0].x);
+  int bidx = cur[0].y;
+#pragma unroll
+  for (int w = 1; w < G; ++w) {
+    const int2 c = cur[w];
+    const float d2 = __int_as_float(c.x);
+    if (d2 > bm) { bm = d2; bidx = c.y; }
+  }
+  return bidx;
+}
+
+// ---------------------------------------------------------------------------
 // a2: farthest point sampling.  One workgroup per fragment; the fragment's
 // points live in registers (PPT per thread, blocked ownership: thread t owns
 // indices [t*PPT, (t+1)*PPT) so "lowest lane with the maximum" == "lowest
@@ -140,27 +223,15 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
   constexpr int NT = NWAVES * 64;
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
   const float* src = xyz + (size_t)f * N * 3;
   const float* s_pts = LDSPTS ? fps_smem : src;             // [3*N] (+pad)
-  float* s_slot_d = fps_smem + (LDSPTS ? ((3 * N + 3) & ~3) : 0);          // [2][NWAVES]
-  int* s_slot_i = reinterpret_cast<int*>(s_slot_d + 2 * NWAVES);  // [2][NWAVES]
+  float* s_slot = fps_smem + (LDSPTS ? ((3 * N + 3) & ~3) : 0);          // exchange slots of the waves (PFPP_FPS_SLOT_WORDS)
   if (LDSPTS) {
     for (int i = tid; i < 3 * N; i += NT) fps_smem[i] = src[i];
     __syncthreads();
   }
-
-  float px[PPT], py[PPT], pz[PPT], dist[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const int i = tid * PPT + k;
-    const bool ok = i < N;
-    px[k] = ok ? s_pts[3 * i + 0] : 0.0f;
-    py[k] = ok ? s_pts[3 * i + 1] : 0.0f;
-    pz[k] = ok ? s_pts[3 * i + 2] : 0.0f;
-    dist[k] = ok ? __builtin_huge_valf() : -1.0f;   // pads can never win
-  }
+  FpsLane<PPT> pts;
+  pts.load(s_pts, s_pts + 1, s_pts + 2, 3, tid, N);
   int sel = start ? min(max(start[f], 0), N - 1) : 0;
   float cx = s_pts[3 * sel + 0], cy = s_pts[3 * sel + 1], cz = s_pts[3 * sel + 2];
   int32_t* o_idx = idx_out + (size_t)f * S;
@@ -174,41 +245,8 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
       o_xyz[3 * s + 2] = cz;
     }
     if (++s >= S) break;
-    float best = -2.0f;
-    int bi = 0;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const float dx = __fsub_rn(px[k], cx);
-      const float dy = __fsub_rn(py[k], cy);
-      const float dz = __fsub_rn(pz[k], cz);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      const float nd = fminf(dist[k], d);
-      dist[k] = nd;
-      if (nd > best) { best = nd; bi = tid * PPT + k; }
-    }
-    const float wmax = wave_max_f32(best);
-    const unsigned long long m = __ballot(best == wmax);
-    const int src_lane = __builtin_ctzll(m);
-    const int widx = __builtin_amdgcn_readlane(bi, src_lane);
-    if (NWAVES > 1) {
-      const int par = (s & 1) * NWAVES;
-      if (lane == 0) {
-        s_slot_d[par + wave] = wmax;
-        s_slot_i[par + wave] = widx;
-      }
-      __syncthreads();
-      float bm = s_slot_d[par];
-      int bidx = s_slot_i[par];
-#pragma unroll
-      for (int w = 1; w < NWAVES; ++w) {
-        const float d2 = s_slot_d[par + w];
-        const int i2 = s_slot_i[par + w];
-        if (d2 > bm) { bm = d2; bidx = i2; }
-      }
-      sel = bidx;
-    } else {
-      sel = widx;
-    }
+    const float best = pts.update(cx, cy, cz);
+    sel = fps_argmax<NWAVES, PPT>(pts, best, tid, s, s_slot);
     cx = s_pts[3 * sel + 0];
     cy = s_pts[3 * sel + 1];
     cz = s_pts[3 * sel + 2];
@@ -303,18 +341,9 @@ struct SampleP {
 // G > 1: every thread of the workgroup must call it (one __syncthreads per selected point).
 template <int G, int PPT>
 __device__ __forceinline__ void fps_chain(const float* xs, const float* ys, const float* zs, int N, int S, int t, int32_t* o_idx,
-                                          float* o_xyz, float* nx, float* ny, float* nz, float* npp, float* slot_d, int* slot_i) {
-  const int lane = t & 63, wave = t >> 6;
-  float px[PPT], py[PPT], pz[PPT], dist[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const int i = t * PPT + k;
-    const bool ok = i < N;
-    px[k] = ok ? xs[i] : 0.0f;
-    py[k] = ok ? ys[i] : 0.0f;
-    pz[k] = ok ? zs[i] : 0.0f;
-    dist[k] = ok ? __builtin_huge_valf() : -1.0f;
-  }
+                                          float* o_xyz, float* nx, float* ny, float* nz, float* npp, float* slot) {
+  FpsLane<PPT> pts;
+  pts.load(xs, ys, zs, 1, t, N);
   int sel = 0;
   float cx = xs[0], cy = ys[0], cz = zs[0];
   for (int s = 0;;) {
@@ -325,37 +354,8 @@ __device__ __forceinline__ void fps_chain(const float* xs, const float* ys, cons
       npp[s] = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
     }
     if (++s >= S) break;
-    float best = -2.0f;
-    int bi = 0;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const float dx = __fsub_rn(px[k], cx);
-      const float dy = __fsub_rn(py[k], cy);
-      const float dz = __fsub_rn(pz[k], cz);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      const float nd = fminf(dist[k], d);
-      dist[k] = nd;
-      if (nd > best) { best = nd; bi = t * PPT + k; }
-    }
-    const float wmax = wave_max_f32(best);
-    const unsigned long long m = __ballot(best == wmax);
-    const int widx = __builtin_amdgcn_readlane(bi, __builtin_ctzll(m));
-    if (G > 1) {
-      const int par = (s & 1) * G;
-      if (lane == 0) { slot_d[par + wave] = wmax; slot_i[par + wave] = widx; }
-      __syncthreads();
-      float bm = slot_d[par];
-      int bidx = slot_i[par];
-#pragma unroll
-      for (int w = 1; w < G; ++w) {
-        const float d2 = slot_d[par + w];
-        const int i2 = slot_i[par + w];
-        if (d2 > bm) { bm = d2; bidx = i2; }
-      }
-      sel = bidx;
-    } else {
-      sel = widx;
-    }
+    const float best = pts.update(cx, cy, cz);
+    sel = fps_argmax<G, PPT>(pts, best, t, s, slot);
     cx = xs[sel]; cy = ys[sel]; cz = zs[sel];
   }
 }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) void sample_levels_kernel(const Samp
   float* c1x = pp + N;          float* c1y = c1x + S1; float* c1z = c1y + S1; float* c1p = c1z + S1;
   float* c2x = c1p + S1;        float* c2y = c2x + S2; float* c2z = c2y + S2; float* c2p = c2z + S2;
   float* c3x = c2p + S2;        float* c3y = c3x + S3; float* c3z = c3y + S3; float* c3p = c3z + S3;
-  float* slot_d = c3p + S3;     int* slot_i = reinterpret_cast<int*>(slot_d + 8);
+  float* slot = sl_smem + (((c3p + S3) - sl_smem + 3) & ~3);      // exchange slots of the four FPS waves (PFPP_FPS_SLOT_WORDS(4)), 16-byte aligned
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* src = p.xyz + (size_t)f * N * 3;
   for (int i = tid; i < N; i += SL_WAVES * 64) {
@@ -410,18 +410,18 @@ __global__ __launch_bounds__(SL_WAVES * 64) void sample_levels_kernel(const Samp
   // phase A: level-1 FPS on waves 0-3; the others only keep the barrier count (one per selected point)
   if (wave < 4) {
     fps_chain<4, PPT>(xs, ys, zs, N, S1, tid, p.lv[0].fps_idx ? p.lv[0].fps_idx + (size_t)f * S1 : nullptr,
-                      p.lv[0].new_xyz + (size_t)f * S1 * 3, c1x, c1y, c1z, c1p, slot_d, slot_i);
+                      p.lv[0].new_xyz + (size_t)f * S1 * 3, c1x, c1y, c1z, c1p, slot);
   } else {
-    for (int s = 1; s < S1; ++s) __syncthreads();
+    for (int s = 1; s < S1; ++s) lds_barrier();
   }
   __syncthreads();
   // phase B: wave 0 -> FPS of levels 2 and 3; waves 1-3 -> ball queries of level 1
   if (wave == 0) {
     fps_chain<1, 4>(c1x, c1y, c1z, S1, S2, lane, p.lv[1].fps_idx ? p.lv[1].fps_idx + (size_t)f * S2 : nullptr,
-                    p.lv[1].new_xyz + (size_t)f * S2 * 3, c2x, c2y, c2z, c2p, nullptr, nullptr);
+                    p.lv[1].new_xyz + (size_t)f * S2 * 3, c2x, c2y, c2z, c2p, nullptr);
     __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): lane 0's LDS writes of c2 before the wave reads them back
     fps_chain<1, 2>(c2x, c2y, c2z, S2, S3, lane, p.lv[2].fps_idx ? p.lv[2].fps_idx + (size_t)f * S3 : nullptr,
-                    p.lv[2].new_xyz + (size_t)f * S3 * 3, c3x, c3y, c3z, c3p, nullptr, nullptr);
+                    p.lv[2].new_xyz + (size_t)f * S3 * 3, c3x, c3y, c3z, c3p, nullptr);
   } else {
     int32_t* out = p.lv[0].ball + (size_t)f * S1 * p.lv[0].ns;
     for (int c = wave - 1; c < S1; c += SL_WAVES - 1)
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64) void pose_compose_kernel(
 template <int NWAVES, int PPT, bool LDSPTS = true>
 int launch_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int N, int S,
                hipStream_t st, const int32_t* start = nullptr) {
-  const size_t smem = (size_t)((LDSPTS ? ((3 * N + 3) & ~3) : 0) + 4 * NWAVES) * sizeof(float);
+  const size_t smem = (size_t)((LDSPTS ? ((3 * N + 3) & ~3) : 0) + PFPP_FPS_SLOT_WORDS(NWAVES)) * sizeof(float);
   hipLaunchKernelGGL((fps_kernel<NWAVES, PPT, LDSPTS>), dim3((unsigned)F), dim3(NWAVES * 64), smem, st,
                      xyz, idx, new_xyz, N, S, start);
   return pfpp::check_launch("pfpp_fps");
@@ -664,7 +664,7 @@ extern "C" int pfpp_sample_levels(const float* xyz, int64_t F, int64_t N, const 
   }
   PFPP_SUPPORTED(N <= 2048 && levels[0].S <= 256 && levels[1].S <= 128, "fused sampling: N <= 2048, S1 <= 256, S2 <= 128 (levels 2 and 3 run on one wave)");
   if (F == 0) return PFPP_OK;
-  const size_t smem = ((size_t)4 * (N + levels[0].S + levels[1].S + levels[2].S) + 16) * sizeof(float);
+  const size_t smem = ((size_t)4 * (N + levels[0].S + levels[1].S + levels[2].S) + 4 + PFPP_FPS_SLOT_WORDS(4)) * sizeof(float);
   hipStream_t st = pfpp::as_stream(stream);
   const dim3 grid((unsigned)F), block(SL_WAVES * 64);
   if (N <= 512) hipLaunchKernelGGL(sample_levels_kernel<2>, grid, block, smem, st, p);
