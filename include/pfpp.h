@@ -920,6 +920,10 @@ int pfpp_gemm_small(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const f
 int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr, float* out,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream);
 int pfpp_gemm_wd_supported(int64_t M, int64_t N, int64_t K);
+/* the same in the single-pass fp16 mode (hi planes only, one matrix instruction per product: PFPP_GEMM_F16 of pfpp_gemm — BASELINE configs[4]'s
+ * "fp16 MFMA" perf mode, never a parity mode); bit-identical to pfpp_gemm's single-pass plane path */
+int pfpp_gemm_wd_f16(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr, float* out,
+                     int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream);
 /* Fragment-blocked copies of row-major weight planes w [N, ldw] (N x K used), one launch for up to PFPP_REBLOCK_MAX weights: fhi / flo
  * receive the layout of pfpp_pw.fhi / flo of W (transposed == 0: N % 32 == 0, K % 16 == 0) or of W^T [K, N] (transposed == 1: the operand
  * of dX = dY . W for pfpp_gemm_wd; N % 64 == 0, K % 64 == 0).  Training weights change every step: pfpp_tlayers_fwd / _bwd make the

@@ -60,20 +60,22 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, bool X1 = false>
 struct WdCfg {
+  static constexpr int NPL = X1 ? 1 : 2;                       // planes per operand: the single-pass fp16 mode reads the hi planes only
   static constexpr int BM = 32 * MT, BN = 128 * NT;
-  static constexpr int PLANE = BM * 64, STAGE = 2 * PLANE;     // bytes: BM rows of 32 halfs, two planes
+  static constexpr int PLANE = BM * 64, STAGE = NPL * PLANE;   // bytes: BM rows of 32 halfs per plane
   static constexpr int PATCH = 4096;                           // per wave: 32 rows x 32 floats
   static constexpr size_t SMEM = (size_t)D * STAGE + 4 * PATCH;
 };
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, bool X1>
 __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
-  using C = WdCfg<MT, NT, D>;
-  constexpr int BM = C::BM, PLANE = C::PLANE, STAGE = C::STAGE;
-  constexpr int NPW = MT;                                      // 1 KB DMA pieces (16 rows of one plane) per wave and stage
-  constexpr int P = NPW + 4 * NT;                              // vector-memory operations a wave issues per K-tile
+  using C = WdCfg<MT, NT, D, X1>;
+  constexpr int BM = C::BM, PLANE = C::PLANE, STAGE = C::STAGE, NPL = C::NPL;
+  constexpr int NPW = NPL * MT / 2;                            // 1 KB DMA pieces (16 rows of one plane) per wave and stage
+  constexpr int P = NPW + 2 * NPL * NT;                        // vector-memory operations a wave issues per K-tile
+  static_assert(NPW >= 1, "at least one DMA piece per wave");
   extern __shared__ __align__(1024) char wd_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
   uint32_t dst[NPW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
-    const int q = wave + 4 * j;
+    const int q = wave + 4 * j;                                // (single-pass: pieces 0 .. 2 MT - 1, the hi plane only)
     const int pl = q / (2 * MT), row = (q % (2 * MT)) * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
     const int64_t grow = m0 + row < p.M ? m0 + row : p.M - 1;
@@ -124,8 +126,10 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
       const half8* pl = wbl[j] + (size_t)kt * 128;
       wh[slot][j][0] = gld<0>(ph);
       wh[slot][j][1] = gld<1024>(ph);
-      wl[slot][j][0] = gld<0>(pl);
-      wl[slot][j][1] = gld<1024>(pl);
+      if constexpr (!X1) {
+        wl[slot][j][0] = gld<0>(pl);
+        wl[slot][j][1] = gld<1024>(pl);
+      }
     }
   };
   f32x16 acc[MT][NT];
@@ -146,13 +150,15 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
     static_for<MT>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
       fh[t] = lds_rd<2048 * t>(ad);
-      fl[t] = lds_rd<PLANE + 2048 * t>(ad);
+      if constexpr (!X1) fl[t] = lds_rd<PLANE + 2048 * t>(ad);
     });
   };
   auto wait_frags = [&](half8 (&fh)[MT], half8 (&fl)[MT], auto left_c) {     // left = LDS reads issued behind these that may stay in flight
     constexpr int LEFT = decltype(left_c)::value;
     static_assert(MT == 2 || MT == 4, "row tiles per workgroup");
-    if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fl[0]), "+v"(fl[1]) : "n"(LEFT));
+    if constexpr (X1 && MT == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh[0]), "+v"(fh[1]) : "n"(LEFT));
+    else if constexpr (X1) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fh[3]) : "n"(LEFT));
+    else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fl[0]), "+v"(fl[1]) : "n"(LEFT));
     else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fh[3]), "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "n"(LEFT));
   };
   auto name_w = [&](auto slot_c) {      // the vmcnt wait in front orders the uses of this slot's registers: name them behind it
@@ -160,20 +166,23 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       half8 &r0 = wh[slot][j][0], &r1 = wh[slot][j][1], &r2 = wl[slot][j][0], &r3 = wl[slot][j][1];
-      asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+      if constexpr (X1) asm volatile("" : "+v"(r0), "+v"(r1));
+      else asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     }
   };
   // term-major like gemm_pl_kernel: lo.hi of every tile, then hi.lo, then hi.hi (per accumulator: the same products in the same order)
   auto mma = [&](const half8 (&fh)[MT], const half8 (&fl)[MT], auto slot_c, auto s_c) {
     constexpr int slot = decltype(slot_c)::value, s = decltype(s_c)::value;
+    if constexpr (!X1) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+      for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], wh[slot][j][s], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], wh[slot][j][s], acc[t][j], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+      for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], wl[slot][j][s], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], wl[slot][j][s], acc[t][j], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
     __builtin_amdgcn_sched_barrier(0);
     rd_frags(f0h, f0l, U, I0{});
     rd_frags(f1h, f1l, U, I1{});
-    wait_frags(f0h, f0l, std::integral_constant<int, 2 * MT>{});
+    wait_frags(f0h, f0l, std::integral_constant<int, NPL * MT>{});
     __builtin_amdgcn_sched_barrier(0);
     mma(f0h, f0l, u_c, I0{});
     __builtin_amdgcn_sched_barrier(0);
@@ -309,17 +318,17 @@ __global__ __launch_bounds__(256) void reblock_kernel(const RbP p) {
   }
 }
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, bool X1 = false>
 int launch_wd(const WdP& p, hipStream_t st) {
-  using C = WdCfg<MT, NT, D>;
+  using C = WdCfg<MT, NT, D, X1>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_wd_kernel<MT, NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_wd_kernel<MT, NT, D, X1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM) != hipSuccess)
       return pfpp::check_launch("pfpp_gemm_wd");
     attr_set = true;
   }
   const unsigned tiles = (unsigned)(((p.M + C::BM - 1) / C::BM) * (p.N / C::BN));
-  hipLaunchKernelGGL((gemm_wd_kernel<MT, NT, D>), dim3(tiles), dim3(256), C::SMEM, st, p);
+  hipLaunchKernelGGL((gemm_wd_kernel<MT, NT, D, X1>), dim3(tiles), dim3(256), C::SMEM, st, p);
   return pfpp::check_launch("pfpp_gemm_wd");
 }
 
@@ -327,8 +336,8 @@ int launch_wd(const WdP& p, hipStream_t st) {
 
 extern "C" int pfpp_gemm_wd_supported(int64_t M, int64_t N, int64_t K) { return M >= 1 && M <= 0x7fffffff && N >= 128 && N % 128 == 0 && K >= 32 && K % 32 == 0; }
 
-extern "C" int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
-                            float* out, int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream) {
+static int gemm_wd_impl(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
+                        float* out, int64_t ldc, int64_t M, int64_t N, int64_t K, bool single_pass, pfpp_stream_t stream) {
   PFPP_REQUIRE(A && A->hi && A->lo && w && out, "null pointer");
   PFPP_REQUIRE(w->fhi && w->flo && pfpp::aligned16(w->fhi) && pfpp::aligned16(w->flo), "the weight's fragment-blocked planes (pfpp_pw.fhi / flo) are required");
   PFPP_SUPPORTED(pfpp_gemm_wd_supported(M, N, K), "N % 128 != 0 or K % 32 != 0");
@@ -344,8 +353,22 @@ extern "C" int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w,
   hipStream_t st = pfpp::as_stream(stream);
   // tile choice (measured, tools/lab/gemm_wdirect_probe.hip): the 128 x 256 tile once it fills the chip, the 64 x 128 tile below that
   const int64_t big_tiles = ((M + 127) / 128) * (N / 256);
+  if (single_pass) {     // hi . hi only (PFPP_GEMM_F16: configs[4]'s perf mode, never for parity)
+    if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4, true>(p, st);
+    return launch_wd<2, 1, 3, true>(p, st);
+  }
   if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4>(p, st);
   return launch_wd<2, 1, 3>(p, st);
+}
+
+extern "C" int pfpp_gemm_wd(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
+                            float* out, int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream) {
+  return gemm_wd_impl(A, lda, w, bias, residual, ldr, out, ldc, M, N, K, false, stream);
+}
+
+extern "C" int pfpp_gemm_wd_f16(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
+                                float* out, int64_t ldc, int64_t M, int64_t N, int64_t K, pfpp_stream_t stream) {
+  return gemm_wd_impl(A, lda, w, bias, residual, ldr, out, ldc, M, N, K, true, stream);
 }
 
 extern "C" int pfpp_reblock_planes(const pfpp_reblock_job* jobs, int32_t n, pfpp_stream_t stream) {

@@ -442,8 +442,9 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
   const bool small = fuse_ln && a->layers[0].o1.fhi != nullptr;      // few tokens: the three residual GEMMs through pfpp_gemm_small as well
   // above the few-token range: the qkv / out / second feed-forward linears with the weights read straight into the matrix operands
   // (csrc/gemm_wd.hip; bit-identical to the tiled kernel)
-  const bool wd = !fuse_ln && !a->single_pass && a->wd_gemm && a->layers[0].o1.fhi != nullptr && pfpp_gemm_wd_supported(M, C, C) &&
+  const bool wd = !fuse_ln && a->wd_gemm && a->layers[0].o1.fhi != nullptr && pfpp_gemm_wd_supported(M, C, C) &&
                   pfpp_gemm_wd_supported(M, 3 * C, C) && pfpp_gemm_wd_supported(M, C, inner);
+  const auto gemm_wd = a->single_pass ? pfpp_gemm_wd_f16 : pfpp_gemm_wd;
   for (int i = 0; i < a->n_layers; ++i) {
     const pfpp_elayer_params& w = a->layers[i];
     const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;
@@ -453,25 +454,25 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
                                           3 * C, C, eps, stream));
     } else {
       TL_CALL(pfpp_layernorm_grouped_split(a->h, a->norm.hi, a->norm.lo, mod1, ld_mod, a->frag_b, L, M, C, eps, stream));
-      if (wd) TL_CALL(pfpp_gemm_wd(&a->norm, C, &w.qkv1, nullptr, nullptr, 0, a->qkv, 3 * C, M, 3 * C, C, stream));
+      if (wd) TL_CALL(gemm_wd(&a->norm, C, &w.qkv1, nullptr, nullptr, 0, a->qkv, 3 * C, M, 3 * C, C, stream));
       else TL_CALL(gemm_ev(a->norm, w.qkv1, a->qkv, nullptr, M, 3 * C, C, C, 3 * C, nullptr, nullptr, PFPP_ACT_NONE, prec, a, stream));
     }
     TL_CALL(pfpp_attn_blockdiag_split(a->qkv, a->att.hi, a->att.lo, a->Fv, L, H, dh, a->att_scale, stream));
     if (small) TL_CALL(pfpp_gemm_small(&a->att, C, &w.o1, w.bo1, a->h, C, a->h, C, M, C, C, stream));
-    else if (wd) TL_CALL(pfpp_gemm_wd(&a->att, C, &w.o1, w.bo1, a->h, C, a->h, C, M, C, C, stream));
+    else if (wd) TL_CALL(gemm_wd(&a->att, C, &w.o1, w.bo1, a->h, C, a->h, C, M, C, C, stream));
     else TL_CALL(gemm_ev(a->att, w.o1, a->h, nullptr, M, C, C, C, C, w.bo1, a->h, PFPP_ACT_NONE, prec, a, stream));
     if (fuse_ln) {
       TL_CALL(pfpp_layernorm_linear_small(a->h, mod2, ld_mod, nullptr, nullptr, a->frag_b, L, &w.qkv2, nullptr, a->qkv, 3 * C, nullptr, 0, M,
                                           3 * C, C, eps, stream));
     } else {
       TL_CALL(pfpp_layernorm_grouped_split(a->h, a->norm.hi, a->norm.lo, mod2, ld_mod, a->frag_b, L, M, C, eps, stream));
-      if (wd) TL_CALL(pfpp_gemm_wd(&a->norm, C, &w.qkv2, nullptr, nullptr, 0, a->qkv, 3 * C, M, 3 * C, C, stream));
+      if (wd) TL_CALL(gemm_wd(&a->norm, C, &w.qkv2, nullptr, nullptr, 0, a->qkv, 3 * C, M, 3 * C, C, stream));
       else TL_CALL(gemm_ev(a->norm, w.qkv2, a->qkv, nullptr, M, 3 * C, C, C, 3 * C, nullptr, nullptr, PFPP_ACT_NONE, prec, a, stream));
     }
     TL_CALL(pfpp_attn_dense_split(a->qkv, a->att.hi, a->att.lo, a->seq_off, a->seq_len, nullptr, 0, a->n_seq, a->max_len, H, dh, a->att_scale,
                                   stream));
     if (small) TL_CALL(pfpp_gemm_small(&a->att, C, &w.o2, w.bo2, a->h, C, a->h, C, M, C, C, stream));
-    else if (wd) TL_CALL(pfpp_gemm_wd(&a->att, C, &w.o2, w.bo2, a->h, C, a->h, C, M, C, C, stream));
+    else if (wd) TL_CALL(gemm_wd(&a->att, C, &w.o2, w.bo2, a->h, C, a->h, C, M, C, C, stream));
     else TL_CALL(gemm_ev(a->att, w.o2, a->h, nullptr, M, C, C, C, C, w.bo2, a->h, PFPP_ACT_NONE, prec, a, stream));
     if (fuse_ln) {
       TL_CALL(pfpp_layernorm_linear_small(a->h, nullptr, 0, w.g3, w.b3, nullptr, 1, &w.ff1, w.bff1, nullptr, 0, &a->u, inner, M, 2 * inner, C,
@@ -481,7 +482,7 @@ extern "C" int pfpp_tlayers_eval(const pfpp_tlayers_eval_args* a, pfpp_stream_t 
       TL_CALL(gemm_ev(a->norm, w.ff1, nullptr, &a->u, M, 2 * inner, C, C, inner, w.bff1, nullptr, PFPP_ACT_GEGLU, prec, a, stream));
     }
     if (small && inner % 512 == 0) TL_CALL(pfpp_gemm_small(&a->u, inner, &w.ff2, w.bff2, a->h, C, a->h, C, M, C, inner, stream));
-    else if (wd) TL_CALL(pfpp_gemm_wd(&a->u, inner, &w.ff2, w.bff2, a->h, C, a->h, C, M, C, inner, stream));
+    else if (wd) TL_CALL(gemm_wd(&a->u, inner, &w.ff2, w.bff2, a->h, C, a->h, C, M, C, inner, stream));
     else TL_CALL(gemm_ev(a->u, w.ff2, a->h, nullptr, M, C, inner, inner, C, w.bff2, a->h, PFPP_ACT_NONE, prec, a, stream));
   }
   return PFPP_OK;

@@ -196,6 +196,7 @@ SIGNATURES = {
     "pfpp_gemm_small": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_gemm_wd": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_gemm_wd_supported": [_i64, _i64, _i64],
+    "pfpp_gemm_wd_f16": [_pl, _i64, C.POINTER(PwC), _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_reblock_planes": [C.POINTER(ReblockJob), _i32, _p],
     "pfpp_layernorm_linear_small": [_p, _p, _i64, _p, _p, _p, _i64, C.POINTER(PwC), _p, _p, _i64, _pl, _i64, _i64, _i64, _i64, _f32, _p],
     "pfpp_heads_fwd": [_p, C.POINTER(HeadParams), C.POINTER(HeadParams), _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],

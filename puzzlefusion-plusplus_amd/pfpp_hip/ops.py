@@ -888,7 +888,7 @@ def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[
 
 
 def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, single_pass: bool = False) -> torch.Tensor:
     """a . w^T (+ bias) (+ residual) with the weight's fragment-blocked planes read straight into the matrix operands (pfpp_gemm_wd,
     csrc/gemm_wd.hip): a = SplitAct planes [M, K], w = packing.PW [N, K]; N % 128 == 0, K % 32 == 0; out may be the residual tensor.
     Bit-identical to the tiled plane GEMM (ops.linear on the same planes)."""
@@ -909,9 +909,9 @@ def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[tor
     if GEMM_TRACE is not None:            # bench.py: HIP events around the launch, attributed to the instantiation the library picks
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(_lib.load().pfpp_gemm_wd(C.byref(ap), a.hi.stride(0), C.byref(pw), _ptr(bias), _ptr(residual),
-                                   0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, w.N, K, _stream()),
-          "pfpp_gemm_wd")
+    fn = _lib.load().pfpp_gemm_wd_f16 if single_pass else _lib.load().pfpp_gemm_wd      # single_pass: hi planes only (perf mode)
+    check(fn(C.byref(ap), a.hi.stride(0), C.byref(pw), _ptr(bias), _ptr(residual),
+             0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, w.N, K, _stream()), "pfpp_gemm_wd")
     if ev is not None:
         ev[1].record()
         big = w.N % 256 == 0 and ((M + 127) // 128) * (w.N // 256) >= 250

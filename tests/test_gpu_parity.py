@@ -1510,6 +1510,18 @@ def test_gemm_wd_bit_identical_to_the_tiled_gemm(dev, M, N, K):
     assert float((out.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6
     with pytest.raises(Exception, match="128"):
         ops.gemm_wd(a, PW(W[:96].contiguous()))
+    # the single-pass fp16 form (hi planes only: configs[4]'s perf mode) against the tiled kernel in the same mode
+    prev = ops.SINGLE_PASS
+    try:
+        ops.SINGLE_PASS = True
+        sp_t = res.clone()
+        ops.gemm(a, pw, M=M, N=N, K=K, lda=K, out=sp_t, ldc=N, bias=bias, residual=sp_t, ldr=N)
+    finally:
+        ops.SINGLE_PASS = prev
+    sp = res.clone()
+    ops.gemm_wd(a, pw, bias=bias, residual=sp, out=sp, single_pass=True)
+    assert torch.equal(sp, sp_t)
+    assert float((sp.double().cpu() - want).abs().max() / want.abs().max()) < 3e-3
 
 
 @pytest.mark.parametrize("N,K", [(1536, 512), (512, 512), (512, 2048), (64, 64)])
