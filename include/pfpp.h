@@ -847,8 +847,10 @@ typedef struct pfpp_tlayers_args {
   float* dmods;                                 /* [2 n_layers, B, 2C] AdaLN row gradients (accumulated) */
   float* dtok;                                  /* [M, C] gradient w.r.t. the tokens (needed when the range reaches layer 0) */
   float lr, beta1, beta2, eps, weight_decay, bc1, bc2, opt_g_scale; int32_t opt_zero_grad; int32_t* overflow;   /* with adamw */
-  /* optional (NULL: the tiled kernel everywhere): scratch of pfpp_tlayers_frag_bytes() for the fragment-blocked copies of a layer's
-   * weights — the qkv / out / second feed-forward linears of the forward and their input gradients then run through pfpp_gemm_wd */
+  /* optional (NULL: the tiled kernel everywhere): scratch of at least pfpp_tlayers_frag_bytes() for the fragment-blocked copies of a
+   * layer's weights — the qkv / out / second feed-forward linears of the forward and their input gradients then run through
+   * pfpp_gemm_wd.  With room for every layer of the call's range (n x pfpp_tlayers_frag_bytes()) the range's weights are blocked by ONE
+   * launch at the top of the call instead of one per layer (a launch on the dependency chain costs its gap as well as its time) */
   void* frag_ws; int64_t frag_ws_bytes;
 } pfpp_tlayers_args;
 int64_t pfpp_tlayers_frag_bytes(int64_t C, int64_t inner);
@@ -928,7 +930,7 @@ int pfpp_gemm_wd_f16(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const 
  * receive the layout of pfpp_pw.fhi / flo of W (transposed == 0: N % 32 == 0, K % 16 == 0) or of W^T [K, N] (transposed == 1: the operand
  * of dX = dY . W for pfpp_gemm_wd; N % 64 == 0, K % 64 == 0).  Training weights change every step: pfpp_tlayers_fwd / _bwd make the
  * copies of a layer where they read them (args.frag_ws), so that a copy can never be stale.                                         */
-#define PFPP_REBLOCK_MAX 8
+#define PFPP_REBLOCK_MAX 32
 typedef struct pfpp_reblock_job { pfpp_planes w; int64_t N, K, ldw; void *fhi, *flo; int32_t transposed; } pfpp_reblock_job;
 int pfpp_reblock_planes(const pfpp_reblock_job* jobs, int32_t n, pfpp_stream_t stream);
 int pfpp_layernorm_linear_small(const float* x, const float* mod, int64_t ld_mod, const float* gamma, const float* beta,

@@ -143,14 +143,14 @@ bool wd_shapes_ok(int64_t M, int64_t C, int64_t inner) {
   return C % 128 == 0 && inner % 128 == 0 && pfpp_gemm_wd_supported(M, C, C) && pfpp_gemm_wd_supported(M, 3 * C, C) &&
          pfpp_gemm_wd_supported(M, C, inner) && pfpp_gemm_wd_supported(M, C, 3 * C) && pfpp_gemm_wd_supported(M, inner, C);
 }
-int reblock_layer(const pfpp_tlayers_args* a, const pfpp_tlayer_params& w, bool transposed, LayerFrag* out, pfpp_stream_t st) {
+// jobs of one layer's five weights into the scratch slice `slice` (0 = the only one); returns the number of jobs appended
+int layer_jobs(const pfpp_tlayers_args* a, const pfpp_tlayer_params& w, bool transposed, int slice, LayerFrag* out, pfpp_reblock_job* jobs) {
   const int64_t C = a->C, inner = a->inner;
-  _Float16* hi = static_cast<_Float16*>(a->frag_ws);
+  _Float16* hi = static_cast<_Float16*>(a->frag_ws) + (int64_t)slice * 2 * frag_halfs(C, inner);
   _Float16* lo = hi + frag_halfs(C, inner);
   const pfpp_planes* src[5] = {&w.qkv1, &w.o1, &w.qkv2, &w.o2, &w.ff2};
   const int64_t N[5] = {3 * C, C, 3 * C, C, C}, K[5] = {C, C, C, C, inner};
   pfpp_pw* dst[5] = {&out->qkv1, &out->o1, &out->qkv2, &out->o2, &out->ff2};
-  pfpp_reblock_job jobs[5];
   int64_t off = 0;
   for (int i = 0; i < 5; ++i) {
     jobs[i].w = *src[i]; jobs[i].N = N[i]; jobs[i].K = K[i]; jobs[i].ldw = K[i];
@@ -158,7 +158,23 @@ int reblock_layer(const pfpp_tlayers_args* a, const pfpp_tlayer_params& w, bool 
     *dst[i] = pfpp_pw{nullptr, src[i]->hi, src[i]->lo, src[i]->scale, K[i], hi + off, lo + off};
     off += N[i] * K[i];
   }
+  return 5;
+}
+int reblock_layer(const pfpp_tlayers_args* a, const pfpp_tlayer_params& w, bool transposed, LayerFrag* out, pfpp_stream_t st) {
+  pfpp_reblock_job jobs[5];
+  layer_jobs(a, w, transposed, 0, out, jobs);
   return pfpp_reblock_planes(jobs, 5, st);
+}
+// all layers of [lo, hi) in one launch (needs (hi - lo) scratch slices and 5 (hi - lo) <= PFPP_REBLOCK_MAX jobs); fr[i - lo] = layer i's views
+constexpr int MAX_BATCHED_LAYERS = PFPP_REBLOCK_MAX / 5;
+bool can_batch(const pfpp_tlayers_args* a, int lo, int hi) {
+  return hi - lo > 1 && hi - lo <= MAX_BATCHED_LAYERS && a->frag_ws_bytes >= (int64_t)(hi - lo) * 2 * frag_halfs(a->C, a->inner) * 2;
+}
+int reblock_range(const pfpp_tlayers_args* a, int lo, int hi, bool transposed, LayerFrag* fr, pfpp_stream_t st) {
+  pfpp_reblock_job jobs[PFPP_REBLOCK_MAX];
+  int n = 0;
+  for (int i = lo; i < hi; ++i) n += layer_jobs(a, a->layers[i], transposed, i - lo, &fr[i - lo], jobs + n);
+  return pfpp_reblock_planes(jobs, n, st);
 }
 
 }  // namespace
@@ -181,7 +197,9 @@ extern "C" int pfpp_tlayers_fwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   const bool wd = a->frag_ws != nullptr && wd_shapes_ok(M, C, inner);
   if (wd) PFPP_REQUIRE(a->frag_ws_bytes >= pfpp_tlayers_frag_bytes(C, inner), "frag_ws_bytes smaller than pfpp_tlayers_frag_bytes()");
   // a linear of the block: out = A . W^T + bias (+ residual) — weights straight into the matrix operands, or the tiled kernel (bit-identical)
-  LayerFrag fr;
+  LayerFrag frs[MAX_BATCHED_LAYERS], fr;
+  const bool batched = wd && can_batch(a, layer_lo, layer_hi);
+  if (batched) TL_CALL(reblock_range(a, layer_lo, layer_hi, false, frs, stream));
   auto lin = [&](const pfpp_planes& A, const pfpp_planes& W, const pfpp_pw& F, float* out, int64_t N, int64_t K, const float* bias,
                  const float* residual) -> int {
     if (wd) { const pfpp_planes Ac = A; return pfpp_gemm_wd(&Ac, K, &F, bias, residual, N, out, N, M, N, K, stream); }
@@ -189,7 +207,8 @@ extern "C" int pfpp_tlayers_fwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   };
   for (int i = layer_lo; i < layer_hi; ++i) {
     const pfpp_tlayer_params& w = a->layers[i];
-    if (wd) TL_CALL(reblock_layer(a, w, false, &fr, stream));
+    if (batched) fr = frs[i - layer_lo];
+    else if (wd) TL_CALL(reblock_layer(a, w, false, &fr, stream));
     char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
     // the residual stream entering the layer: the tokens for layer 0, the previous layer's output otherwise
     float* h = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
@@ -309,7 +328,8 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   };
   const bool wd = a->frag_ws != nullptr && wd_shapes_ok(M, C, inner);
   if (wd) PFPP_REQUIRE(a->frag_ws_bytes >= pfpp_tlayers_frag_bytes(C, inner), "frag_ws_bytes smaller than pfpp_tlayers_frag_bytes()");
-  LayerFrag fr;                         // blocked planes of the TRANSPOSED weights of the current layer
+  LayerFrag frs[MAX_BATCHED_LAYERS], fr;      // blocked planes of the TRANSPOSED weights (fr: of the current layer)
+  const bool batched = wd && can_batch(a, layer_lo, layer_hi);
   auto dx = [&](const pfpp_planes& dyp, const pfpp_planes& W, float* out, int64_t n_in, int64_t n_out, const pfpp_pw* Ft = nullptr) -> int {
     if (wd && Ft) return pfpp_gemm_wd(&dyp, n_out, Ft, nullptr, nullptr, 0, out, n_in, M, n_in, n_out, stream);
     return gemm_pl(dyp, W, out, M, n_in, n_out, n_out, n_in, n_in, false, true, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream);
@@ -319,11 +339,13 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   int dhp_slot = -1;                    // the caller's buffer on entry (kept alive by the caller), one of ours afterwards
   for (int k = SLOT_DH0; k <= SLOT_DH1; ++k)
     if (a->dhp.hi == slot_buf[k]) dhp_slot = k;      // a continued range: the previous call's dhp_out
+  if (batched) TL_CALL(reblock_range(a, layer_lo, layer_hi, true, frs, stream));      // (before any AdamW of this call: dX needs the forward's weights)
   for (int i = layer_hi - 1; i >= layer_lo; --i) {
     cur_layer = i;
     const pfpp_tlayer_params& w = a->layers[i];
     const pfpp_tlayer_grads& g = a->grads[i];
-    if (wd) TL_CALL(reblock_layer(a, w, true, &fr, stream));
+    if (batched) fr = frs[i - layer_lo];
+    else if (wd) TL_CALL(reblock_layer(a, w, true, &fr, stream));
     char* base = static_cast<char*>(a->fwd_arena) + (int64_t)i * a->fwd_layer_bytes;
     const float* h0 = i == 0 ? a->h_in : f32_at(static_cast<char*>(a->fwd_arena) + (int64_t)(i - 1) * a->fwd_layer_bytes, lo.hout);
     const float* mod1 = a->mods + (int64_t)(2 * i) * a->B * ld_mod;

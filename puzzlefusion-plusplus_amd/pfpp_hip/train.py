@@ -592,7 +592,7 @@ class DenoiserTrainEngine:
             # scratch for the fragment-blocked copies of a layer's weights: qkv / out / second feed-forward linears and their input
             # gradients with the weights read straight into the matrix operands (csrc/gemm_wd.hip; 0 = the tiled kernel, the cross-check)
             from . import _lib
-            nbytes = int(_lib.load().pfpp_tlayers_frag_bytes(C, int(args.inner)))
+            nbytes = int(_lib.load().pfpp_tlayers_frag_bytes(C, int(args.inner))) * n      # room for every layer: one blocking launch per call
             self._frag_ws = torch.empty(nbytes, dtype=torch.uint8, device=w["shape.b"].device)
             args.frag_ws, args.frag_ws_bytes = self._frag_ws.data_ptr(), nbytes
         self._cseq_static = (args, (layers, grads, adam))
