@@ -850,7 +850,7 @@ typedef struct pfpp_tlayers_args {
   /* optional (NULL: the tiled kernel everywhere): scratch of at least pfpp_tlayers_frag_bytes() for the fragment-blocked copies of a
    * layer's weights — the qkv / out / second feed-forward linears of the forward and their input gradients then run through
    * pfpp_gemm_wd.  With room for every layer of the call's range (n x pfpp_tlayers_frag_bytes()) the range's weights are blocked by ONE
-   * launch at the top of the call instead of one per layer (a launch on the dependency chain costs its gap as well as its time) */
+   * launch at the top of the call instead of one per layer */
   void* frag_ws; int64_t frag_ws_bytes;
 } pfpp_tlayers_args;
 int64_t pfpp_tlayers_frag_bytes(int64_t C, int64_t inner);
