@@ -189,8 +189,8 @@ def _sa_mlp_train(pk, name: str, A: Optional[torch.Tensor], nsample: int, grp=No
     return h
 
 
-def _sa_wide_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
-    """eval-mode wide level (sa3: 256 + 3 -> 256 -> 256 -> 512, 64 neighbours) on the ROWS kernels of the train-mode chain
+def _sa_rows_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
+    """eval-mode level with input features (sa3: 256 + 3 -> 256 -> 256 -> 512; sa2: 128 + 3 -> 128 -> 128 -> 256; 64 neighbours) on the ROWS kernels of the train-mode chain
     (csrc/sa_train.hip sa_wide_train_kernel<256, 2, UG> / <256, 3>: a workgroup keeps a 128-column slice of the layer's weight planes in
     LDS for its lifetime, a wave streams 32 rows at a time) instead of an elementwise pass + two tiled plane GEMMs with their
     [rows, 256] planes in between: 430 instead of 766 us at 154 fragments.  Same entry point as training (pfpp_sa_train_stage) with the
@@ -256,11 +256,11 @@ def set_abstraction(pk, name: str, npoint: int, radius: float, nsample: int, xyz
     elif (SA_EVAL_ROWS and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
           and feats.shape[2] == 256 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (256, 256, 512)
           and F * npoint * nsample >= SA_EVAL_ROWS_MIN):
-        h = _sa_wide_eval(pk, name, grp, nsample)
+        h = _sa_rows_eval(pk, name, grp, nsample)
     elif (SA_EVAL_ROWS2 and fused and ops.split_mode() and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS and feats is not None and nsample == 64
           and feats.shape[2] == 128 and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N, pk[f"{name}.w2"].N) == (128, 128, 256)
           and F * npoint * nsample >= SA_EVAL_ROWS2_MIN):
-        h = _sa_wide_eval(pk, name, grp, nsample)
+        h = _sa_rows_eval(pk, name, grp, nsample)
     elif (SA_FUSED and fused and feats is not None and nsample == 64 and feats.shape[2] == 128
           and (pk[f"{name}.w0"].N, pk[f"{name}.w1"].N) == (128, 128)):
         # level 2: grouping + layers 1 and 2 in one kernel, layer 3 (+ max over nsample) as a GEMM

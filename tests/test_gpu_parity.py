@@ -1782,9 +1782,9 @@ def test_sa_table_planes_equals_grouped_first_layer(dev, F, N, S, D):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("F,N,S,D", [(3, 128, 25, 256), (40, 128, 25, 256), (3, 256, 128, 128), (12, 256, 128, 128)])
-def test_sa_wide_eval_rows_equals_the_tiled_level(dev, F, N, S, D, monkeypatch):
+def test_sa_rows_eval_rows_equals_the_tiled_level(dev, F, N, S, D, monkeypatch):
     """eval-mode level 3 (256 + 3 -> 256 -> 256 -> 512, 64 neighbours, folded BatchNorm, max over the neighbourhood) on the rows kernels
-    of the train-mode chain (encoder._sa_wide_eval: pfpp_sa_train_stage with the folded scale / shift as affines, max / min trick) against
+    of the train-mode chain (encoder._sa_rows_eval: pfpp_sa_train_stage with the folded scale / shift as affines, max / min trick) against
     the elementwise pass + two tiled plane GEMMs it replaces and a float64 restatement of pn2_utils.py:203-216 in .eval(); negative
     scales included (the max / min selection)"""
     from pfpp_hip import encoder, ops
