@@ -354,10 +354,10 @@ static int gemm_wd_impl(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, con
   // tile choice (measured, tools/lab/gemm_wdirect_probe.hip): the 128 x 256 tile once it fills the chip, the 64 x 128 tile below that
   const int64_t big_tiles = ((M + 127) / 128) * (N / 256);
   if (single_pass) {     // hi . hi only (PFPP_GEMM_F16: configs[4]'s perf mode, never for parity)
-    if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4, true>(p, st);
+    if (N % 256 == 0 && big_tiles >= 240) return launch_wd<4, 2, 4, true>(p, st);
     return launch_wd<2, 1, 3, true>(p, st);
   }
-  if (N % 256 == 0 && big_tiles >= 250) return launch_wd<4, 2, 4>(p, st);
+  if (N % 256 == 0 && big_tiles >= 240) return launch_wd<4, 2, 4>(p, st);
   return launch_wd<2, 1, 3>(p, st);
 }
 

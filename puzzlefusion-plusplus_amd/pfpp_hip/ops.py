@@ -914,7 +914,7 @@ def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[tor
              0 if residual is None else residual.stride(0), _ptr(out), out.stride(0), M, w.N, K, _stream()), "pfpp_gemm_wd")
     if ev is not None:
         ev[1].record()
-        big = w.N % 256 == 0 and ((M + 127) // 128) * (w.N // 256) >= 250
+        big = w.N % 256 == 0 and ((M + 127) // 128) * (w.N // 256) >= 240
         GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * w.N * K, "gemm_wd_kernel<4, 2, 4>" if big else "gemm_wd_kernel<2, 1, 3>",
                            (M, w.N, K, 1, "none", 0)))
     return out

@@ -184,7 +184,7 @@ def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: i
                            out.data_ptr(), out.shape[-1], M, N, K, _stream()), "pfpp_gemm_wd")
     if ev:
         ev[3].record()
-        big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 250
+        big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 240
         trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
         trace.append((ev[2], ev[3], 2.0 * M * N * K, "gemm_wd_kernel<4, 2, 4>" if big else "gemm_wd_kernel<2, 1, 3>",
                       (M, N, K, 1, "nn" if transposed else "nt", 0)))
