@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
     constexpr int LEFT = decltype(left_c)::value;
     if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fh[0]), "+v"(fl[0]) : "n"(LEFT));
     else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fl[0]), "+v"(fl[1]) : "n"(LEFT));
+    else if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]) : "n"(LEFT));
     else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fh[0]), "+v"(fh[1]), "+v"(fh[2]), "+v"(fh[3]), "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "n"(LEFT));
   };
   auto name_w = [&](auto slot_c) {      // the preceding vmcnt wait orders the uses of this slot's registers
