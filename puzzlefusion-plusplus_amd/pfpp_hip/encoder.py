@@ -41,6 +41,7 @@ SA_EVAL_ROWS_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS_MIN", "0"))
 SA_EVAL_ROWS2 = _os.environ.get("PFPP_SA_EVAL_ROWS2", "1") == "1"
 SA_EVAL_ROWS2_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS2_MIN", "200000"))      # one puzzle in flight (65 K rows): neutral, stays tiled
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
+SAMPLE_FUSED_MIN = int(_os.environ.get("PFPP_SAMPLE_FUSED_MIN", "32"))    # ... from this many fragments up
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
@@ -314,7 +315,7 @@ def pn2_encode(pk, pts: torch.Tensor, num_point: int = 25, capture: Optional[dic
     lv = tuple((npoint or num_point, radius, nsample) for _, npoint, radius, nsample in SA_LEVELS)
     # (a handful of fragments — one puzzle in flight — is latency-bound either way; there the per-level kernels' wider ball-query grids
     # win: 171 vs 189 us at F = 8)
-    sampled = (ops.sample_levels(pts, lv) if (SAMPLE_FUSED and pts.shape[0] >= 32 and ops.sample_levels_supported(pts.shape[1], lv))
+    sampled = (ops.sample_levels(pts, lv) if (SAMPLE_FUSED and pts.shape[0] >= SAMPLE_FUSED_MIN and ops.sample_levels_supported(pts.shape[1], lv))
                else (None,) * 3)
     for (name, npoint, radius, nsample), smp in zip(SA_LEVELS, sampled):
         xyz, feats = set_abstraction(pk, name, npoint or num_point, radius, nsample, xyz, feats, capture, sampled=smp)
