@@ -55,21 +55,26 @@ def pmc_traffic(kernel: str, mode: str = "train"):
     KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section).  -> (bytes or None, description)"""
     import csv
     import glob
+    import re
 
     prof = os.path.join(ROOT, "profiles")
     for fetch in sorted(glob.glob(os.path.join(prof, f"*_bench_{mode}_pmc_FETCH_SIZE.csv")), reverse=True):
         write = fetch.replace("FETCH_SIZE", "WRITE_SIZE")
         if not os.path.exists(write):
             continue
-        vals = {}
+        vals, matched = {}, None
         for path, key in ((fetch, "fetch"), (write, "write")):
             with open(path, newline="") as fh:
                 for row in csv.DictReader(fh):
-                    if kernel in row["kernel"]:
+                    # the traced kernel's name is the row's name up to its argument list (the full template instantiation: a shorter
+                    # label must not pick up a sibling instantiation, and a stale one must not fall through to an older file silently)
+                    m = re.search(r"(\w+(?:<[^()]*>)?)\(", row["kernel"])        # name<template arguments> in front of the argument list
+                    if m and m.group(1) == kernel:
                         vals[key] = float(row["mean_value_per_dispatch"])
+                        matched = m.group(1)
         if len(vals) == 2:
             return (int((2.0 * vals["fetch"] + vals["write"]) * 1024),
-                    f"{os.path.basename(fetch)} (x2, gfx950) + {os.path.basename(write)}, mean per dispatch")
+                    f"{os.path.basename(fetch)} (x2, gfx950) + {os.path.basename(write)}, mean per dispatch of {matched}")
     return None, None
 
 
@@ -832,7 +837,13 @@ def main():
                                  "note": "padded fragment slots dropped in the transformer; identical predictions for valid fragments"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_protocol("train" if train else "sample")
+        if train:
+            # the line's own workload (training iterations) on the CPU port, and next to it BASELINE.md section 3's protocol as written
+            # (the 20-step eval sampler on configs[0]) — the figure the plan names; both bounded, both on this host in this run
+            cpu = cpu_protocol("train", budget_s=28.0)
+            cpu["sampler_protocol"] = cpu_protocol("sample", budget_s=18.0)
+        else:
+            cpu = cpu_protocol("sample")
 
     if rank == 0:
         line = {

@@ -298,6 +298,24 @@ typedef struct pfpp_gemm_planes_args {
 } pfpp_gemm_planes_args;
 
 int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);
+
+/* ---- the weight gradients of one transformer block in ONE launch ------------------------------------------------
+ * dW_j += dY_j^T . X_j and db_j += colsum(dY_j) for up to PFPP_DW_GROUP_MAX Linear layers whose backward shares the contraction (the
+ * K token rows of the step): autograd of to_q/k/v, to_out.0, ff.net.0.proj, ff.net.2 of one EncoderLayer
+ * (denoiser/model/modules/attention.py:46-72, 77-90) in Denoiser.training_step (denoiser.py:128-145).  dy [K, M = out] and x [K, N = in]
+ * are k-major fp16 planes read in place (leading dimensions M and N; scales folded out: gw += dY^T.X / (dy.scale * x.scale),
+ * gb += colsum(dY) / dy.scale; gb may be NULL).  Every output tile runs the whole contraction in one accumulator chain (no K split,
+ * no workspace, no reduction launch; deterministic); the problems' tiles are dealt to the XCDs as one concatenated list.
+ * variant: 0 = the library's choice; 3 = 128 x 128 tiles, 6 / 7 = 128 x 64 (three / two stages), 2 = 256 x 128 (lab).             */
+#define PFPP_DW_GROUP_MAX 8
+typedef struct pfpp_dw_job {
+  pfpp_planes dy;      /* [K, M] */
+  pfpp_planes x;       /* [K, N] */
+  float* gw;           /* [M, N] fp32, accumulated in place */
+  float* gb;           /* [M] fp32 or NULL */
+  int64_t M, N;
+} pfpp_dw_job;
+int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64_t K, int32_t variant, pfpp_stream_t stream);
 /* name of the kernel instantiation the calling thread's last pfpp_gemm / pfpp_gemm_planes call launched through the plane
  * path ("" when that call took another kernel): lets a profiler-side tool attribute event timings to kernel names */
 const char* pfpp_last_gemm_kernel(void);

@@ -238,8 +238,10 @@ __device__ __forceinline__ void epilogue_wide(const GemmP& p, f32x16 (&acc)[MT][
 }
 
 // One workgroup = one output tile.  NS-stage DMA ring; see the header for the schedule.
-template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false>
-__device__ __forceinline__ void pl_body(const GemmP& p) {
+// EXT: the (tile, K chunk) of this workgroup comes from the caller (ext_tile of the problem's row-major tile list, whole contraction)
+// instead of blockIdx — the grouped weight-gradient launch, where a workgroup first finds its problem in a table.
+template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false, bool EXT = false>
+__device__ __forceinline__ void pl_body(const GemmP& p, int ext_tile = 0) {
   static_assert(!(AF && AK), "an fp32 A operand is row-major");
   static_assert(!CS || (AK && !X1), "column sums ride with a k-major split A operand (dW = dY^T . X)");
   static_assert(!(AF && X1), "the single-pass mode takes pre-split operands");
@@ -260,9 +262,9 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   // 1-D grid of (K chunk, tile) pairs, chunk-major after the XCD remap: an XCD walks one K range over many tiles
-  const int wg = remap_tile(blockIdx.x, gridDim.x);
+  const int wg = EXT ? ext_tile : remap_tile(blockIdx.x, gridDim.x);
   const int n_tiles = p.tiles_m * p.tiles_n;
-  const int split = wg / n_tiles;
+  const int split = EXT ? 0 : wg / n_tiles;
   const int tile = wg - split * n_tiles;
   int tm, tn;
   tile_coords(p, tile, tm, tn);
@@ -271,7 +273,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   const int nk_base = nk_all / p.split_k, nk_rem = nk_all - nk_base * p.split_k;
   const int kt0 = split * nk_base + min(split, nk_rem);      // first K-tile of this workgroup
   const int nk = nk_base + (split < nk_rem ? 1 : 0);
-  const int z = blockIdx.z;
+  const int z = EXT ? 0 : blockIdx.z;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
   const int64_t a_offz = z0 * p.sA0 + z1 * p.sA1;
   const int64_t w_offz = z0 * p.sW0 + z1 * p.sW1;
@@ -352,10 +354,13 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   // CS: the workgroups of tile column 0 also sum their A operand over the contraction (sum_k dY[k][m] = the bias gradient):
   // v_dot2c_f32_f16 with ones on the fragments the MFMAs consume anyway, issued in the shadow of the first MFMAs of a half-step
-  const bool do_cs = CS && tn == 0 && wn == 0;
+  const bool do_cs = CS && tn == 0 && wn == 0 && (!EXT || p.csum != nullptr);
   float bsum[CS ? MT : 1];
 #pragma unroll
   for (int i = 0; i < (CS ? MT : 1); ++i) bsum[i] = 0.0f;
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  const _Float16 cs_w = do_cs ? (_Float16)1.0f : (_Float16)0.0f;
+  const half2v cs_one = {cs_w, cs_w};
 
   // ---- fragment addressing -----------------------------------------------------------------------------------------------
   // row-major: lane (l31, lhi) reads row l31 of a 32-row tile, logical chunk 2*s + lhi; one address per 16-deep step s
@@ -543,17 +548,15 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       mma1(a, b, mh_c, m_c);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CS && m < 2 * HS) {
-        if (do_cs) {
-          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-          constexpr int ii = m >> 1;
-          const half8 v = (m & 1) ? a.l[ii] : a.h[ii];
-          const half2v one = {(_Float16)1.0f, (_Float16)1.0f};
-          float& s_ = bsum[HS * decltype(mh_c)::value + ii];
-          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), one, s_, false);
-          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 2, 3), one, s_, false);
-          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 4, 5), one, s_, false);
-          s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), one, s_, false);
-        }
+        // branch-free (cs_one is 0 in the workgroups that do not own the sums): no control flow between the fragment reads in flight
+        // and their wait — see the note on wait placement below
+        constexpr int ii = m >> 1;
+        const half8 v = (m & 1) ? a.l[ii] : a.h[ii];
+        float& s_ = bsum[HS * decltype(mh_c)::value + ii];
+        s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 0, 1), cs_one, s_, false);
+        s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 2, 3), cs_one, s_, false);
+        s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 4, 5), cs_one, s_, false);
+        s_ = __builtin_amdgcn_fdot2(__builtin_shufflevector(v, v, 6, 7), cs_one, s_, false);
       }
       constexpr int f0 = m * NF / NMMA, f1 = (m + 1) * NF / NMMA;
       static_for<f1 - f0>([&](auto k_c) { fill(std::integral_constant<int, f0 + decltype(k_c)::value>{}); });
@@ -582,6 +585,18 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
   __builtin_amdgcn_s_barrier();
   static_for<RA>([&](auto q_c) { rd_a(fa[0], 0, I0{}, I0{}, q_c); });
   static_for<RB>([&](auto q_c) { rd_b(fb[0], 0, I0{}, q_c); });
+  // WAIT PLACEMENT (round 5; the cause of round 4's "two-rank" discrepancy).  The fragment reads are inline asm, so the
+  // compiler's own s_waitcnt insertion does not know that their destination registers are in flight until our wait statement, which
+  // re-defines them ("+v").  Inside straight-line code the read and its wait share the registers; but a value that is live ACROSS A
+  // CONTROL-FLOW EDGE (prologue -> loop, the loop's back edge, loop -> last tile) may be moved by a compiler-inserted copy on that
+  // edge — in the column-sum (CS) instantiations hipcc placed eight v_mov_b64 of freshly read fragments ~200 instructions after their
+  // ds_read_b64_tr_b16 and BEFORE the wait.  With the LDS pipeline to itself the data had long arrived; with another process's
+  // LDS-bound waves on the same CU the copy read the registers' old contents: one 32 x 32 accumulator tile of a weight gradient off
+  // by one 16-deep step's contribution, once in ~50 backward passes.  Therefore: every fragment read is waited for in the region
+  // that issued it — here, and at the END of tile_body for the next tile's first fragments (dynamically the same place as a wait at
+  // the top of the next tile: nothing but the loop branch lies between) — so only waited-for values ever cross an edge.
+  // tests/test_abi_and_host.py scans the built library's disassembly for accesses to registers with an LDS read in flight.
+  wait_ab(fa[0], fb[0]);
 
   // One K-tile.  On entry the fragments of half-step 0 (fa[0], fb[0]) are in flight.  LAST: no tile follows.
   // DMA of tile kt + NS - 1 (second half of its pieces) rides in the first half-step, tile kt + NS (first half) in the last one,
@@ -611,7 +626,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
     };
     if constexpr (NH == 2) {
       // h0 = (s0, first row tiles)   h1 = (s0, last row tiles)   h2 = (s1, first)   h3 = (s1, last)
-      wait_ab(fa[0], fb[0]);
+      // (fa[0], fb[0] were waited for by whoever issued them: the prologue or the previous tile)
       half_step(fa[0], fb[0], I0{}, std::integral_constant<int, G0 + NP2>{}, [&](auto m_c) {
         constexpr int m = decltype(m_c)::value;
         if constexpr (m < RA) rd_a(fa[1], cur, I0{}, I1{}, m_c);
@@ -635,7 +650,6 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       half_step(fa[1], fb[1], I1{}, std::integral_constant<int, G0 + NP1>{}, fill_next);
     } else {
       // h0 = s0, h1 = s1 (all row tiles of the wave)
-      wait_ab(fa[0], fb[0]);
       half_step(fa[0], fb[0], I0{}, std::integral_constant<int, G0 + NP2>{}, [&](auto m_c) {
         constexpr int m = decltype(m_c)::value;
         if constexpr (m < RA) rd_a(fa[1], cur, I1{}, I0{}, m_c);
@@ -647,6 +661,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p) {
       kt_aff = kt + 1;
       half_step(fa[1], fb[1], I0{}, std::integral_constant<int, G0 + NP1>{}, fill_next);
     }
+    if constexpr (!LAST) wait_ab(fa[0], fb[0]);      // the next tile's first fragments: waited for before the loop edge (see above)
   };
 
   uint32_t cur = 0, prv = (NS - 1) * STAGE;
@@ -787,6 +802,71 @@ __global__ __launch_bounds__(256) void pl_reduce_group_kernel(const SlabGroupP g
 template <int MT, int NT, int WM, int WN, int NS, bool AK, bool WK, int DBG, bool AF = false, bool X1 = false, bool CS = false>
 __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl_kernel(const GemmP p) {
   pl_body<MT, NT, WM, WN, NS, AK, WK, DBG, AF, X1, CS>(p);
+}
+
+// ---- grouped weight gradients: up to PFPP_DW_GROUP_MAX problems dW_j += dY_j^T . X_j (+ db_j += colsum dY_j) over the SAME contraction
+// (the token rows of one transformer block's backward) in ONE launch.  The problems' tiles form one concatenated list (row-major
+// within a problem: the tiles of a row panel share their dY columns) and XCD x owns a contiguous 1/8 of it (remap_tile), so an XCD
+// mostly works on one problem, walks the whole contraction in lock-step over all of its resident tiles and fetches each operand
+// column it needs once.  Every tile runs the full contraction in one accumulator chain: no K split, no slabs, no reduction launch;
+// the accumulation into the gradient buffer is the in-place residual of the 16-byte-store epilogue (one writer per element).
+struct DwJobP {
+  const void* ahi; const void* alo; const void* whi; const void* wlo;
+  float* C; float* csum;
+  int M, N, tiles_n, first_tile;
+  float alpha, csum_alpha;
+};
+struct DwGroupP {
+  DwJobP job[PFPP_DW_GROUP_MAX];
+  int n, K, k_valid;
+};
+
+template <int MT, int NT, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_pl_dwgroup_kernel(const DwGroupP g) {
+  const int t = remap_tile(blockIdx.x, gridDim.x);
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < PFPP_DW_GROUP_MAX; ++k)
+    if (k < g.n && t >= g.job[k].first_tile) j = k;
+  const DwJobP& q = g.job[j];
+  GemmP p;
+  p.A = nullptr; p.W = nullptr; p.C = q.C;
+  p.Whi = q.whi; p.Wlo = q.wlo; p.Ahi = q.ahi; p.Alo = q.alo;
+  p.Chi = nullptr; p.Clo = nullptr;
+  p.bias = nullptr; p.scale = nullptr; p.shift = nullptr; p.residual = q.C;       // C += alpha * acc, in place
+  p.M = q.M; p.N = q.N; p.K = g.K;
+  p.lda = q.M; p.ldw = q.N; p.ldc = q.N; p.ldr = q.N;
+  p.act = PFPP_ACT_NONE; p.pool = 0; p.zdiv = 1;
+  p.sA0 = p.sA1 = p.sW0 = p.sW1 = p.sC0 = p.sC1 = p.sV0 = p.sV1 = 0;
+  p.alpha = q.alpha;
+  p.tiles_n = q.tiles_n; p.tiles_m = 0; p.group_m = 0;
+  p.a_mul = nullptr; p.a_add = nullptr; p.stats = nullptr; p.stats_copies = 1; p.Cmin = nullptr;
+  p.split_ws = nullptr; p.split_cnt = nullptr; p.split_k = 1; p.k_chunk = 0;
+  p.g_idx = nullptr; p.g_xyz = nullptr; p.g_ctr = nullptr; p.g_N = p.g_S = p.g_ns = 0;
+  p.ws_bytes = 0; p.k_valid = g.k_valid; p.x1 = 0;
+  p.csum = q.csum; p.csum_ws = nullptr; p.csum_alpha = q.csum_alpha;
+  p.accum = 0; p.defer = nullptr; p.dbg = 0;
+  pl_body<MT, NT, WM, WN, NS, true, true, 0, false, false, true, true>(p, t - q.first_tile);
+}
+
+template <int MT, int NT, int WM, int WN, int NS>
+int launch_dwgroup(DwGroupP& g, const pfpp_dw_job* jobs, hipStream_t st) {
+  using C = Cfg<MT, NT, WM, WN, NS, false>;
+  static bool attr_set = false;
+  auto kern = gemm_pl_dwgroup_kernel<MT, NT, WM, WN, NS>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  int tiles = 0;
+  for (int j = 0; j < g.n; ++j) {
+    g.job[j].tiles_n = (int)((jobs[j].N + C::BN - 1) / C::BN);
+    g.job[j].first_tile = tiles;
+    tiles += (int)((jobs[j].M + C::BM - 1) / C::BM) * g.job[j].tiles_n;
+  }
+  snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_dwgroup_kernel<%d, %d, %d, %d, %d>", MT, NT, WM, WN, NS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NTHR), C::SMEM, st, g);
+  return pfpp::check_launch("pfpp_gemm_dw_group");
 }
 
 template <int MT, int NT, int WM, int WN, int NS, bool AK = false, bool WK = false, int DBG = 0, bool AF = false, bool X1 = false, bool CS = false>
@@ -1038,6 +1118,39 @@ extern "C" int pfpp_slab_reduce_group(const pfpp_slab_job* jobs, int32_t n_jobs,
   if (g.n == 0) return PFPP_OK;
   hipLaunchKernelGGL(pl::pl_reduce_group_kernel, dim3(blocks), dim3(256), 0, pfpp::as_stream(stream), g);
   return pfpp::check_launch("pfpp_slab_reduce_group");
+}
+
+extern "C" int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64_t K, int32_t variant, pfpp_stream_t stream) {
+  PFPP_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= PFPP_DW_GROUP_MAX, "1 .. PFPP_DW_GROUP_MAX jobs");
+  PFPP_REQUIRE(K > 0 && K < (1ll << 31), "contraction length");
+  pl::DwGroupP g;
+  memset(&g, 0, sizeof(g));
+  g.n = n_jobs;
+  g.K = (int)((K + 31) / 32 * 32);
+  g.k_valid = (int)K;
+  for (int j = 0; j < n_jobs; ++j) {
+    const pfpp_dw_job& q = jobs[j];
+    PFPP_REQUIRE(q.dy.hi && q.dy.lo && q.x.hi && q.x.lo && q.gw, "null pointer");
+    PFPP_REQUIRE(q.M >= 8 && q.N >= 8 && q.M % 8 == 0 && q.N % 8 == 0 && q.M < (1ll << 31) && q.N < (1ll << 31), "M, N: multiples of 8");
+    PFPP_REQUIRE(pfpp::aligned16(q.dy.hi) && pfpp::aligned16(q.dy.lo) && pfpp::aligned16(q.x.hi) && pfpp::aligned16(q.x.lo) &&
+                 pfpp::aligned16(q.gw), "16-byte aligned operands");
+    PFPP_REQUIRE(q.dy.scale > 0.0f && q.x.scale > 0.0f, "plane scales");
+    pl::DwJobP& r = g.job[j];
+    r.ahi = q.dy.hi; r.alo = q.dy.lo; r.whi = q.x.hi; r.wlo = q.x.lo;
+    r.C = q.gw; r.csum = q.gb;
+    r.M = (int)q.M; r.N = (int)q.N;
+    r.alpha = 1.0f / (q.dy.scale * q.x.scale);
+    r.csum_alpha = 1.0f / q.dy.scale;
+  }
+  hipStream_t st = pfpp::as_stream(stream);
+  static const int env_v = getenv("PFPP_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_DW_GROUP_VARIANT")) : 0;
+  const int v = variant ? variant : (env_v ? env_v : 3);
+  switch (v) {
+    case 6: return pl::launch_dwgroup<2, 1, 2, 2, 3>(g, jobs, st);       // 128 x 64, three stages (72 KB: two workgroups per CU)
+    case 7: return pl::launch_dwgroup<2, 1, 2, 2, 2>(g, jobs, st);       // 128 x 64, two stages (48 KB: three per CU)
+    case 2: return pl::launch_dwgroup<2, 2, 4, 2, 3>(g, jobs, st);       // 256 x 128, 8 waves
+    default: return pl::launch_dwgroup<2, 2, 2, 2, 2>(g, jobs, st);      // 128 x 128, two stages (64 KB: two per CU)
+  }
 }
 
 extern "C" int pfpp_gemm_planes(const pfpp_gemm_planes_args* a, pfpp_stream_t stream) {

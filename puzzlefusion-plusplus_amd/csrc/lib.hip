@@ -49,7 +49,7 @@ extern "C" int64_t pfpp_abi_sizeof(const char* name) {
 #define PFPP_SZ(n) if (!strcmp(name, #n)) return (int64_t)sizeof(pfpp_##n);
   PFPP_SZ(sample_level) PFPP_SZ(gemm_args) PFPP_SZ(planes) PFPP_SZ(slab_job) PFPP_SZ(gemm_planes_args) PFPP_SZ(sa_train_args)
   PFPP_SZ(gemm_grad_args) PFPP_SZ(tlayer_params) PFPP_SZ(tlayer_grads) PFPP_SZ(tlayer_adamw) PFPP_SZ(tlayers_args) PFPP_SZ(pw)
-  PFPP_SZ(elayer_params) PFPP_SZ(tlayers_eval_args) PFPP_SZ(head_params) PFPP_SZ(head_grads) PFPP_SZ(reblock_job)
+  PFPP_SZ(elayer_params) PFPP_SZ(tlayers_eval_args) PFPP_SZ(head_params) PFPP_SZ(head_grads) PFPP_SZ(reblock_job) PFPP_SZ(dw_job)
 #undef PFPP_SZ
   return -1;
 }

@@ -183,6 +183,12 @@ class TlayersArgs(C.Structure):
     ]
 
 
+class DwJob(C.Structure):
+    """mirror of struct pfpp_dw_job (include/pfpp.h)"""
+
+    _fields_ = [("dy", PlanesC), ("x", PlanesC), ("gw", _p), ("gb", _p), ("M", _i64), ("N", _i64)]
+
+
 class ReblockJob(C.Structure):
     """mirror of struct pfpp_reblock_job (include/pfpp.h)"""
 
@@ -281,6 +287,7 @@ SIGNATURES = {
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
     "pfpp_slab_reduce_group": [C.POINTER(SlabJob), C.c_int32, _p],
+    "pfpp_gemm_dw_group": [C.POINTER(DwJob), _i32, _i64, _i32, _p],
     "pfpp_split_planes": [_p, _i64, _pl, _p],
     "pfpp_colsum_planes": [_p, _p, _p, _i64, _i64, _i64, _f32, _p],
     "pfpp_geglu_p": [_p, _p, _i64, _i64, _f32, _u64, _u32, _pl, _p],
@@ -312,7 +319,7 @@ STRUCT_MIRRORS = {
     "sample_level": SampleLevel, "gemm_args": GemmArgs, "planes": PlanesC, "slab_job": SlabJob, "gemm_planes_args": GemmPlanesArgs,
     "sa_train_args": SaTrainArgs, "gemm_grad_args": GemmGradArgs, "tlayer_params": TlayerParams, "tlayer_grads": TlayerGrads,
     "tlayer_adamw": TlayerAdamw, "tlayers_args": TlayersArgs, "pw": PwC, "elayer_params": ElayerParams,
-    "tlayers_eval_args": TlayersEvalArgs, "head_params": HeadParams, "head_grads": HeadGrads, "reblock_job": ReblockJob,
+    "tlayers_eval_args": TlayersEvalArgs, "head_params": HeadParams, "head_grads": HeadGrads, "reblock_job": ReblockJob, "dw_job": DwJob,
 }
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "geglu": 4}

@@ -95,6 +95,8 @@ def _eval_layers_c(pk, h, mods, lay, L: int, num_layers: int, num_heads: int, at
     if not ops.split_mode() or ops.GEMM_TRACE is not None or os.environ.get("PFPP_EVAL_CSEQ", "1") != "1":
         return False
     st = pk.get("_cseq_eval")
+    if st is False:
+        return False
     if st is None:
         layers = (ElayerParams * num_layers)()
 
@@ -102,10 +104,15 @@ def _eval_layers_c(pk, h, mods, lay, L: int, num_layers: int, num_heads: int, at
             fh, fl = w.frag()          # (kept alive by the PW in pk)
             return PwC(w.f32.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), w.scale, w.hi.shape[-1], fh.data_ptr(), fl.data_ptr())
 
+        try:
+            for i in range(num_layers):
+                for name, key in (("qkv1", f"{i}.self_attn.wqkv"), ("o1", f"{i}.self_attn.wo"), ("qkv2", f"{i}.global_attn.wqkv"),
+                                  ("o2", f"{i}.global_attn.wo"), ("ff1", f"{i}.ff.w1"), ("ff2", f"{i}.ff.w2")):
+                    setattr(layers[i], name, pw(pk[key]))
+        except ValueError:                 # a width the fragment-blocked layout does not cover (N % 32, K % 16): the Python sequence of
+            pk["_cseq_eval"] = False       # tiled launches serves any shape
+            return False
         for i in range(num_layers):
-            for name, key in (("qkv1", f"{i}.self_attn.wqkv"), ("o1", f"{i}.self_attn.wo"), ("qkv2", f"{i}.global_attn.wqkv"),
-                              ("o2", f"{i}.global_attn.wo"), ("ff1", f"{i}.ff.w1"), ("ff2", f"{i}.ff.w2")):
-                setattr(layers[i], name, pw(pk[key]))
             for name, key in (("bo1", f"{i}.self_attn.bo"), ("bo2", f"{i}.global_attn.bo"), ("g3", f"{i}.norm3.g"), ("b3", f"{i}.norm3.b"),
                               ("bff1", f"{i}.ff.b1"), ("bff2", f"{i}.ff.b2")):
                 setattr(layers[i], name, pk[key].data_ptr())

@@ -163,6 +163,7 @@ class Trainer:
         are given.  Otherwise this process becomes rank 0 and re-executes its command line for ranks 1..N-1 (Lightning's subprocess
         launcher does the same for strategy=ddp)."""
         world = self.devices
+        self._launcher = False
         if "LOCAL_RANK" in os.environ:
             self.local_rank = int(os.environ["LOCAL_RANK"])
             self.global_rank = int(os.environ.get("RANK", self.local_rank))
@@ -170,8 +171,12 @@ class Trainer:
             if self.world_size != world and world > 1:
                 raise RuntimeError(f"Trainer(devices={world}) under a launcher with WORLD_SIZE={self.world_size}")
         elif world > 1:
+            # this process is the launcher: remembered on the object (and the rank variables taken out of its environment again
+            # after fit — a second fit() in this process must not mistake itself for a launched rank)
+            self._launcher = True
+            self._env_before = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_RANK", "RANK")}
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ["MASTER_PORT"] = str(_free_port())
             os.environ.update(WORLD_SIZE=str(world), LOCAL_RANK="0", RANK="0")
             self.world_size = world
             main = sys.modules.get("__main__")
@@ -181,6 +186,8 @@ class Trainer:
                 env = dict(os.environ, LOCAL_RANK=str(r), RANK=str(r))
                 self._children.append(subprocess.Popen(cmd, env=env))
         if self.world_size > 1:
+            import datetime
+
             import torch.distributed as dist
 
             backend = os.environ.get("PFPP_DDP_BACKEND", "nccl")
@@ -190,7 +197,51 @@ class Trainer:
             torch.cuda.set_device(self.local_rank % max(1, n_dev))
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group(backend, rank=self.global_rank, world_size=self.world_size)
+                if self._children:
+                    # a child that died before the rendezvous would leave rank 0 waiting for the full timeout: look at them first
+                    import time
+
+                    time.sleep(0.2)
+                    self._check_children()
+                dist.init_process_group(backend, rank=self.global_rank, world_size=self.world_size,
+                                        timeout=datetime.timedelta(seconds=int(os.environ.get("PFPP_DDP_TIMEOUT_S", "1800"))))
+
+    def _check_children(self) -> None:
+        """a worker rank that has exited while rank 0 still trains means every collective from here on would hang: stop now"""
+        for p in self._children:
+            rc = p.poll()
+            if rc is not None and rc != 0:
+                raise RuntimeError(f"Trainer: worker rank (pid {p.pid}) exited with code {rc} while rank 0 was still running")
+
+    def _abort(self) -> None:
+        """failure path of fit(): no barrier (the other ranks may sit in a collective this rank will never enter) — the children are
+        terminated and reaped, the process group is dropped without a handshake"""
+        for p in self._children:
+            if p.poll() is None:
+                p.terminate()
+        for p in self._children:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        self._children = []
+        try:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:             # noqa: BLE001 — already failing; the original exception is the one to report
+            pass
+
+    def _restore_env(self) -> None:
+        if getattr(self, "_launcher", False):
+            for k, v in self._env_before.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            self._launcher = False
 
     def _join(self) -> None:
         rc = 0
@@ -220,17 +271,46 @@ class Trainer:
 
     # -- fit ----------------------------------------------------------------------------------------------
     def fit(self, model, train_dataloaders, val_dataloaders=None, ckpt_path: Optional[str] = None) -> None:
-        self._launch()
-        try:
-            self._fit(model, train_dataloaders, val_dataloaders, ckpt_path)
-        finally:
-            if self.world_size > 1:
-                import torch.distributed as dist
+        if self.callbacks or self.logger is not None:
+            import warnings
 
-                if dist.is_initialized():
-                    dist.barrier()
-                    dist.destroy_process_group()
+            warnings.warn("pfpp_hip.launch.Trainer: callbacks / logger objects are accepted and IGNORED (no ModelCheckpoint(monitor=...) "
+                          "top-k files, no LearningRateMonitor, no wandb): only last.ckpt is written, per epoch, by rank 0")
+        try:
+            self._launch()
+            self._fit(model, train_dataloaders, val_dataloaders, ckpt_path)
+        except BaseException:
+            self._abort()
+            self._restore_env()
+            raise
+        # success path only: every rank got here, so the barrier cannot hang
+        if self.world_size > 1:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+        try:
             self._join()
+        finally:
+            self._restore_env()
+
+    def _sync_replicas(self, engine) -> None:
+        """what Lightning's DDP does at start-up (broadcast of rank 0's module state): parameters, both Adam moments and the step count
+        from rank 0, then the fp16 planes re-split — replicas are equal by construction, not by every rank having seeded and loaded
+        identically (the per-element AdamW guard relies on bit-identical replicas)"""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+
+        f = engine.flat
+        for t in (f.params, f.exp_avg, f.exp_avg_sq):
+            dist.broadcast(t, src=0)
+        step = torch.tensor([engine.step_count], dtype=torch.int64, device=f.params.device)
+        dist.broadcast(step, src=0)
+        engine.step_count = int(step.item())
+        f.refresh_planes()
+        f.after_optimizer_step()
 
     def _fit(self, model, train_loader, val_loader, ckpt_path) -> None:
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -253,6 +333,7 @@ class Trainer:
             if sched is not None and ck.get("lr_schedulers"):
                 sched.load_state_dict(ck["lr_schedulers"][0])
             start_epoch, self.global_step = int(ck.get("epoch", -1)) + 1, int(ck.get("global_step", 0))
+        self._sync_replicas(engine)
         train_loader, sampler = self._shard(train_loader, True)
         if val_loader is not None:
             val_loader, _ = self._shard(val_loader, False)
@@ -278,6 +359,8 @@ class Trainer:
                     opt.step()
                     opt.zero_grad()
                     self.global_step += 1
+                    if self._children and self.global_step % 16 == 0:
+                        self._check_children()
                     if 0 < self.max_steps <= self.global_step:
                         break
             if sched is not None:

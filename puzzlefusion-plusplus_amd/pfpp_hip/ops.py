@@ -887,6 +887,12 @@ def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[
     return out
 
 
+def wd_kernel_name(big: bool, single_pass: bool = False) -> str:
+    """the instantiation pfpp_gemm_wd / pfpp_gemm_wd_f16 launch (csrc/gemm_wd.hip gemm_wd_impl: tile by shape, X1 = single pass), spelled
+    as rocprofv3 prints it — bench.py looks the counter traffic of the dominant kernel up under this name"""
+    return "gemm_wd_kernel<%s, %s>" % ("4, 2, 4" if big else "2, 1, 3", "true" if single_pass else "false")
+
+
 def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, single_pass: bool = False) -> torch.Tensor:
     """a . w^T (+ bias) (+ residual) with the weight's fragment-blocked planes read straight into the matrix operands (pfpp_gemm_wd,
@@ -915,8 +921,7 @@ def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[tor
     if ev is not None:
         ev[1].record()
         big = w.N % 256 == 0 and ((M + 127) // 128) * (w.N // 256) >= 240
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * w.N * K, "gemm_wd_kernel<4, 2, 4>" if big else "gemm_wd_kernel<2, 1, 3>",
-                           (M, w.N, K, 1, "none", 0)))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * w.N * K, wd_kernel_name(big, single_pass), (M, w.N, K, 1, "none", 0)))
     return out
 
 

@@ -186,6 +186,25 @@ def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: i
         ev[3].record()
         big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 240
         trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
-        trace.append((ev[2], ev[3], 2.0 * M * N * K, "gemm_wd_kernel<4, 2, 4>" if big else "gemm_wd_kernel<2, 1, 3>",
-                      (M, N, K, 1, "nn" if transposed else "nt", 0)))
+        trace.append((ev[2], ev[3], 2.0 * M * N * K, ops.wd_kernel_name(big), (M, N, K, 1, "nn" if transposed else "nt", 0)))
     return out
+
+
+def dw_group(problems, K: int, variant: int = 0) -> None:
+    """pfpp_gemm_dw_group: for every (dY planes [K, M], X planes [K, N], gw [M, N], gb [M] or None) of `problems` (at most 8):
+    gw += dY^T . X / (dY.scale * X.scale), gb += colsum(dY) / dY.scale — the weight gradients of one transformer block in ONE launch,
+    each output tile over the whole contraction in one accumulator chain (no K split, no workspace)."""
+    from ._lib import DwJob, PlanesC
+
+    n = len(problems)
+    jobs = (DwJob * n)()
+    for j, (dy, x, gw, gb) in enumerate(problems):
+        _chk(gw, _f32, "gw")
+        if gb is not None:
+            _chk(gb, _f32, "gb")
+        M, N = gw.shape
+        if dy.hi.shape[-1] != M or x.hi.shape[-1] != N or dy.hi.shape[0] < K or x.hi.shape[0] < K:
+            raise ValueError("dw_group: plane shapes do not match the gradient's")
+        jobs[j] = DwJob(PlanesC(dy.hi.data_ptr(), dy.lo.data_ptr(), dy.scale), PlanesC(x.hi.data_ptr(), x.lo.data_ptr(), x.scale),
+                        gw.data_ptr(), None if gb is None else gb.data_ptr(), M, N)
+    check(_lib.load().pfpp_gemm_dw_group(jobs, n, K, variant, _stream()), "pfpp_gemm_dw_group")

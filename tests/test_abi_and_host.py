@@ -404,3 +404,49 @@ def test_library_has_no_fused_mixed_precision_conversions(hip_lib, tmp_path):
             n_cvt += "v_cvt_f16_f32" in line or "v_cvt_pk_f16_f32" in line
         assert proc.wait() == 0
     assert n_inst > 1000 and n_cvt > 1000          # it really was the kernels' code that was read
+
+
+def test_library_never_touches_a_register_with_an_lds_read_in_flight(hip_lib, tmp_path):
+    """The cause of round 4's 'two-rank' gradient discrepancy.  The plane GEMM issues its fragment
+    reads from inline asm (ds_read_b128 / ds_read_b64_tr_b16) and waits for them with an asm statement that names the destination
+    registers; the compiler's own s_waitcnt insertion does not know those registers are in flight.  In the column-sum instantiations of
+    the weight-gradient GEMM hipcc placed eight `v_mov_b64` copies of freshly read fragments on a control-flow edge BEFORE our wait —
+    harmless while the LDS pipeline answers within ~200 instructions, wrong (one 32 x 32 tile of dW off by one 16-deep step) when
+    another process's LDS-bound waves share the CU.  csrc/gemm_pl.hip now waits for every fragment read inside the region that issued
+    it; this test disassembles the built library and runs tools/diag/lds_hazard_scan.py (lgkmcnt model over each kernel's control-flow
+    graph) over every kernel: no instruction may read or write a VGPR that an outstanding LDS read targets."""
+    import shutil
+    import subprocess
+    import sys
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools" / "diag"))
+    import lds_hazard_scan as scanner
+
+    # the scanner itself: a copy of a pending register is found, the same copy behind the wait is not
+    head = "0000000000001000 <k>:\n"
+    bad = head + ("\tds_read_b64_tr_b16 v[10:11], v2                 // 000000001000: D9C60000\n"
+                  "\tv_mov_b64_e32 v[4:5], v[10:11]                 // 000000001008: 7E087110\n"
+                  "\ts_waitcnt lgkmcnt(0)                           // 00000000100C: BF8CC07F\n"
+                  "\ts_endpgm                                       // 000000001010: BF810000\n")
+    good = head + ("\tds_read_b64_tr_b16 v[10:11], v2                 // 000000001000: D9C60000\n"
+                   "\ts_waitcnt lgkmcnt(0)                           // 000000001008: BF8CC07F\n"
+                   "\tv_mov_b64_e32 v[4:5], v[10:11]                 // 00000000100C: 7E087110\n"
+                   "\ts_endpgm                                       // 000000001010: BF810000\n")
+    assert len(scanner.scan(bad.splitlines(True))) == 1 and not scanner.scan(good.splitlines(True))
+
+    lib = tmp_path / "libpfpp_hip.so"
+    shutil.copy(hip_lib, lib)
+    subprocess.run([str(objdump), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = sorted(tmp_path.glob("libpfpp_hip.so.*gfx950*"))
+    assert objs, "no gfx950 code object found in libpfpp_hip.so"
+    n_kernels = n_reads = 0
+    for o in objs:
+        text = subprocess.run([str(objdump), "-d", "--mcpu=gfx950", str(o)], check=True, capture_output=True, text=True).stdout
+        n_kernels += text.count(">:\n")
+        n_reads += text.count("ds_read_b64_tr_b16")
+        rep = scanner.scan(text.splitlines(True))
+        assert not rep, {scanner.demangle(k)[:120]: [(h[1][:60], h[2][1][:60]) for h in v[:3]] for k, v in rep.items()}
+    assert n_kernels > 100 and n_reads > 500          # it really was the kernels' code that was scanned

@@ -434,6 +434,40 @@ def test_denoiser_compact_mode_equals_full_on_valid_fragments(golden, weights_sd
     assert comp.cpu()[~valid].abs().max() == 0
 
 
+def test_denoiser_eval_at_the_benchmarked_size_vs_oracle(weights_sd, dev):
+    """the eval-mode step at the size bench.py times — 32 puzzles x 20 slots, the valid-fragment counts of
+    the bench's puzzles (154 fragments = 3,850 tokens compact, 16,000 tokens with every slot evaluated) — against the CPU oracle's
+    DenoiserTransformer.forward (oracle.denoiser_forward).  At this size the C sequencer takes the weight-direct GEMMs
+    (M > lnlin_max_rows) and the full-slot step the tiled plane GEMMs: neither path had met the oracle above 1,000 tokens before.
+    Bar: 1e-4 on predicted noise (north_star)."""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import denoiser as D
+    from pfpp_hip import synthetic
+
+    B, P, L = 32, 20, 25
+    batch = synthetic.make_batch(0, B, num_points=32)          # the bench's puzzle ids: same valid-fragment counts (points unused here)
+    valid, ref, scale = batch["part_valids"], batch["ref_part"], batch["part_scale"]
+    assert int(valid.sum()) * L > 2048                         # above the few-token kernels' range: weight-direct / tiled GEMMs
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, P, 7, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    latent = torch.randn(B, P, L, 64, generator=g) * 0.5
+    xyz = torch.rand(B, P, L, 3, generator=g) - 0.5
+    latent[~valid.bool()] = 0                                  # the encoder leaves padded slots at zero (denoiser.py:70-77)
+    xyz[~valid.bool()] = 0
+    sd = weights_sd("denoiser")
+    want = O.denoiser_forward(sd, x, t, latent, xyz, valid, scale, ref.bool())
+    pk = D.pack_denoiser(dsd(sd, dev), 6)
+    args = [v.to(dev) for v in (x, t, latent, xyz, valid, scale, ref)]
+    full = D.denoiser_forward(pk, *args, num_layers=6, num_heads=8).cpu()
+    comp = D.denoiser_forward_compact(pk, *args, num_layers=6, num_heads=8).cpu()
+    m = valid.bool()
+    assert (full - want)[m].abs().max() < TOL, float((full - want)[m].abs().max())
+    assert (comp - want)[m].abs().max() < TOL, float((comp - want)[m].abs().max())
+    assert (full - want).abs().max() < 5 * TOL                 # padded slots: no information, still the reference's arithmetic
+    assert comp[~m].abs().max() == 0
+
+
 def test_scheduler_vs_golden(golden, dev):
     from pfpp_hip.scheduler import PiecewiseScheduler
 
