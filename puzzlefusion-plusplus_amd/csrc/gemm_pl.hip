@@ -1144,7 +1144,11 @@ extern "C" int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64
   }
   hipStream_t st = pfpp::as_stream(stream);
   static const int env_v = getenv("PFPP_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_DW_GROUP_VARIANT")) : 0;
-  const int v = variant ? variant : (env_v ? env_v : 3);
+  // default: the 256 x 128 tile (8 waves, one workgroup per CU).  Measured on a block's six problems at 3,850 tokens
+  // (profiles/r05a_lab_dw_group_bench.txt): 166 us against 195-213 us for the 128 x 64 / 128 x 128 tiles (and 256 us for six separate
+  // launches + their slab reductions) although its 160 tiles leave 96 CUs without one; in the overlapped training iteration 6.06 ms
+  // against 6.28 (small tiles) and 6.23 (separate launches) — profiles/r05a_ab_dwgroup.txt
+  const int v = variant ? variant : (env_v ? env_v : 2);
   switch (v) {
     case 6: return pl::launch_dwgroup<2, 1, 2, 2, 3>(g, jobs, st);       // 128 x 64, three stages (72 KB: two workgroups per CU)
     case 7: return pl::launch_dwgroup<2, 1, 2, 2, 2>(g, jobs, st);       // 128 x 64, two stages (48 KB: three per CU)

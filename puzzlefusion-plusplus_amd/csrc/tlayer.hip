@@ -308,8 +308,33 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     *out = planes_at(slot_buf[k], 0, elems, G);
     return PFPP_OK;
   };
+  // PFPP_TRAIN_DW_GROUP (default 1, round 5): a block's six weight gradients as ONE launch (pfpp_gemm_dw_group, csrc/gemm_pl.hip: every
+  // output tile over the whole contraction, no K split, no slabs, no reduction launches) behind the block's last gradient kernel,
+  // 2: two launches (feed-forward pair behind the GEGLU backward, the four attention linears at the block's end); 0 = one
+  // pfpp_gemm_planes launch (+ slab reduction) per weight as through round 4 (the cross-check of the tests)
+  const int dw_group = getenv("PFPP_TRAIN_DW_GROUP") ? atoi(getenv("PFPP_TRAIN_DW_GROUP")) : 1;          // (read per call: the tests switch it)
+  const int dw_group_variant = getenv("PFPP_TRAIN_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_TRAIN_DW_GROUP_VARIANT")) : 0;
+  pfpp_dw_job dw_jobs[PFPP_DW_GROUP_MAX];
+  int dw_slots[PFPP_DW_GROUP_MAX];
+  int n_dw = 0;
+  auto flush_dw = [&]() -> int {
+    if (n_dw == 0) return PFPP_OK;
+    if (side) TL_CALL(order_after(side_s, main_s));
+    TL_CALL(pfpp_gemm_dw_group(dw_jobs, n_dw, M, dw_group_variant, side_t));
+    for (int q = 0; q < n_dw; ++q)
+      if (side && dw_slots[q] >= 0) TL_CALL(slot_read_on(g_slots[dw_slots[q]], side_s));
+    n_dw = 0;
+    return PFPP_OK;
+  };
   // dW += dY^T . X, db += colsum(dY): both operands read in place as k-major planes, on the side stream; `k` = the slot dY lives in
   auto dw = [&](const pfpp_planes& dyp, int k, const pfpp_planes& xp, int64_t n_out, int64_t n_in, float* gw, float* gb) -> int {
+    if (dw_group && n_out % 8 == 0 && n_in % 8 == 0) {
+      if (n_dw == PFPP_DW_GROUP_MAX) TL_CALL(flush_dw());
+      pfpp_dw_job& q = dw_jobs[n_dw];
+      q.dy = dyp; q.x = xp; q.gw = gw; q.gb = gb; q.M = n_out; q.N = n_in;
+      dw_slots[n_dw++] = k;
+      return PFPP_OK;
+    }
     if (side) TL_CALL(order_after(side_s, main_s));
     static const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;      // lab: 0 = the library's choice
     static const int lab_skip = getenv("PFPP_LAB_SKIP_DW_LAYERS") ? atoi(getenv("PFPP_LAB_SKIP_DW_LAYERS")) : 0;   // lab (timing only, WRONG gradients): no dW for the last k layers
@@ -369,6 +394,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     TL_CALL(fresh(SLOT_DZ0 + par, M * 2 * inner, &dzp));
     TL_CALL(pfpp_geglu_bwd_p(z, du, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &dzp, stream));
     TL_CALL(dw(dzp, SLOT_DZ0 + par, n3, 2 * inner, C, g.ff1_w, g.ff1_b));
+    if (dw_group == 2) TL_CALL(flush_dw());
     TL_CALL(dx(dzp, w.ff1, dn, C, 2 * inner));
     TL_CALL(fresh(SLOT_DY0 + 2 * par, M * C, &dyp));
     TL_CALL(pfpp_layernorm_bwd_p(h2, dn, nullptr, 0, w.g3, nullptr, 32, 1, a->dh, g.g3, g.b3, 0, M, C, eps, nullptr, a->p_lay, a->seed,
@@ -407,6 +433,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
       if (a->dtok != a->dh && hipMemcpyAsync(a->dtok, a->dh, (size_t)M * C * 4, hipMemcpyDeviceToDevice, main_s) != hipSuccess)
         return pfpp::check_launch(__func__);
     }
+    TL_CALL(flush_dw());
     TL_CALL(flush_jobs());
     if (a->adamw && side) {
       // optimizer in the backward: the layer's slice of the flat buffer is final once its weight gradients (side stream) and its

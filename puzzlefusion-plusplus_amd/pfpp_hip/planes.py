@@ -207,4 +207,15 @@ def dw_group(problems, K: int, variant: int = 0) -> None:
             raise ValueError("dw_group: plane shapes do not match the gradient's")
         jobs[j] = DwJob(PlanesC(dy.hi.data_ptr(), dy.lo.data_ptr(), dy.scale), PlanesC(x.hi.data_ptr(), x.lo.data_ptr(), x.scale),
                         gw.data_ptr(), None if gb is None else gb.data_ptr(), M, N)
+    from . import ops
+
+    if ops.GEMM_TRACE is not None:        # bench.py: HIP events around the launch, attributed to the instantiation the library picked
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().pfpp_gemm_dw_group(jobs, n, K, variant, _stream()), "pfpp_gemm_dw_group")
+        e1.record()
+        flops = sum(2.0 * K * gw.shape[0] * gw.shape[1] for _, _, gw, _ in problems)
+        ops.GEMM_TRACE.append((e0, e1, flops, _lib.load().pfpp_last_gemm_kernel().decode(),
+                               (sum(gw.shape[0] * gw.shape[1] for _, _, gw, _ in problems), n, K, 1, "tn-group", 0)))
+        return
     check(_lib.load().pfpp_gemm_dw_group(jobs, n, K, variant, _stream()), "pfpp_gemm_dw_group")

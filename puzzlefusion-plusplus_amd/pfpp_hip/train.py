@@ -346,6 +346,7 @@ class DenoiserTrainEngine:
         self._heads_static = None
         self._cseq_static = None
         self._arena_pool: Dict[tuple, list] = {}
+        self._dw_pending = None                       # traced Python backward: the block's weight gradients collected for one grouped launch
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
         self._early: List[Tuple[int, int]] = []       # [a, b) ranges of the flat buffer the armed backward has already updated
@@ -942,6 +943,12 @@ class DenoiserTrainEngine:
         """dW += dY^T . X (both operands read in place as k-major planes), db += colsum(dY) — on the side stream"""
         from . import planes as P
 
+        if self._dw_pending is not None:       # bench.py's traced pass: the block's weight gradients go out as ONE launch, like the C sequencer's
+            self._dw_pending.append((dyp, xp, gw, gb if (gb is not None and gb.is_contiguous()) else None))
+            if gb is not None and not gb.is_contiguous():
+                P.colsum(dyp, gb)
+            return
+
         def issue():
             fused = gb is not None and self._fuse_colsum and gb.is_contiguous()      # the bias gradient rides in the dW kernel
             P.gemm(dyp, xp, gw, M=gw.shape[0], N=gw.shape[1], K=dyp.shape[0], a_kmajor=True, w_kmajor=True, accumulate=True,
@@ -956,6 +963,21 @@ class DenoiserTrainEngine:
         self._run_on(st, issue)
         dyp.record_stream(st)
         xp.record_stream(st)
+
+    def _dw_flush(self, K: int) -> None:
+        """the collected weight gradients of a block as one pfpp_gemm_dw_group launch (side stream when there is one)"""
+        from . import planes as P
+
+        jobs, self._dw_pending = self._dw_pending, []
+        if not jobs:
+            return
+        if self._side is None:
+            P.dw_group(jobs, K)
+            return
+        self._run_on(self._side, lambda: P.dw_group(jobs, K))
+        for dyp, xp, _, _ in jobs:
+            dyp.record_stream(self._side)
+            xp.record_stream(self._side)
 
     def _run_on(self, st, fn) -> None:
         """fn() only launches pfpp kernels into existing buffers: send them to stream `st`, ordered after everything queued on the
@@ -1005,6 +1027,9 @@ class DenoiserTrainEngine:
         drop_lay = fuse and p_lay > 0.0
         dhp = P.split(dh_, G)                         # d/dh of the last block's output: dY of its second feed-forward linear
         dtok = None
+        # the traced pass of bench.py takes the launches the C sequencer takes: weight-direct GEMMs (dx above) and the grouped
+        # weight-gradient launch; untraced, this sequence stays the per-weight cross-check
+        self._dw_pending = [] if (ops.GEMM_TRACE is not None and os.environ.get("PFPP_TRAIN_DW_GROUP", "1") != "0") else None
         for i in reversed(range(self.num_layers)):
             lay = s["layers"][i]
             inner = lay["u"].shape[1]
@@ -1045,7 +1070,10 @@ class DenoiserTrainEngine:
             else:
                 dtok = T.layernorm_bwd(lay["h0"], dn, dh_, mod=s["mods"][0], group_batch=frag_b, group_rows=L, dmult=dmods[0],
                                        dadd=dmods[0][:, C:], ld_d=2 * C, drop=(p_tok, seed, 0) if fuse and p_tok > 0.0 else None)
+            if self._dw_pending is not None:
+                self._dw_flush(M)
             self._layer_done(i)
+        self._dw_pending = None
         return dtok
 
     def _linear_bwd(self, dy, x, wpw, gw, gb, guard: bool = False) -> None:

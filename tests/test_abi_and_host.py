@@ -442,11 +442,16 @@ def test_library_never_touches_a_register_with_an_lds_read_in_flight(hip_lib, tm
     subprocess.run([str(objdump), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
     objs = sorted(tmp_path.glob("libpfpp_hip.so.*gfx950*"))
     assert objs, "no gfx950 code object found in libpfpp_hip.so"
-    n_kernels = n_reads = 0
+    n_kernels = n_reads = n_wd = 0
     for o in objs:
         text = subprocess.run([str(objdump), "-d", "--mcpu=gfx950", str(o)], check=True, capture_output=True, text=True).stdout
         n_kernels += text.count(">:\n")
         n_reads += text.count("ds_read_b64_tr_b16")
         rep = scanner.scan(text.splitlines(True))
         assert not rep, {scanner.demangle(k)[:120]: [(h[1][:60], h[2][1][:60]) for h in v[:3]] for k, v in rep.items()}
-    assert n_kernels > 100 and n_reads > 500          # it really was the kernels' code that was scanned
+        # the same hazard class on the vector-memory side: the weight-direct GEMM (the only kernel that loads VGPRs from inline asm)
+        # must never have one of its asm-loaded registers copied
+        for k, moves in scanner.moves_of_loaded_registers(text.splitlines(True), "gemm_wd_kernel").items():
+            n_wd += 1
+            assert not moves, (scanner.demangle(k)[:100], moves[:4])
+    assert n_kernels > 100 and n_reads > 500 and n_wd >= 4          # it really was the kernels' code that was scanned

@@ -1227,7 +1227,10 @@ def test_blocks_sequenced_from_c_equal_the_python_sequence(golden, weights_sd, d
     # (weights blocked per layer where they are read).  One k-ordered chain per output there; at this test's few tokens the tiled kernel
     # splits K over workgroups, so the two agree to fp32 rounding — bit-identity at the sizes where the tiled kernel does not split is
     # test_gemm_wd_bit_identical_to_the_tiled_gemm's.  wd = "0": the same launches as the Python sequence, bit-identical.
+    # the block's weight gradients: wd = "0" keeps one pfpp_gemm_planes launch per weight (what the Python sequence issues), wd = "1"
+    # takes the default — ONE pfpp_gemm_dw_group launch per block, each output tile over the whole contraction (round 5)
     monkeypatch.setenv("PFPP_TRAIN_WD", wd)
+    monkeypatch.setenv("PFPP_TRAIN_DW_GROUP", "0" if wd == "0" else "1")
     inp, noise, _ = golden_inputs(golden, dev)
     hp = dict(lr=1e-3, weight_decay=1e-2)
     out = []

@@ -16,6 +16,7 @@ import sys
 
 reg_re = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 lg_re = re.compile(r"lgkmcnt\((\d+)\)")
+vm_re = re.compile(r"vmcnt\((\d+)\)")
 ins_re = re.compile(r"^\s+(\S+)(?:\s+(.*?))?\s*//\s*([0-9A-Fa-f]+):")
 
 
@@ -47,8 +48,11 @@ def _merge(a, b):
     return tuple(out), changed or len(a) != len(b)
 
 
-def analyse_function(ins):
-    """ins: list of (addr, op, args, line_no, text) -> list of (line_no, text, (pending line, pending text))"""
+def analyse_function(ins, vm=False):
+    """ins: list of (addr, op, args, line_no, text) -> list of (line_no, text, (pending line, pending text)).
+    vm: also model vmcnt (vector-memory loads into VGPRs).  Off by default: the analysis is path-insensitive, and the compiler lowers
+    `if (c) s_waitcnt vmcnt(a) else s_waitcnt vmcnt(b)` to two correlated branches whose infeasible combination (neither wait) shows up
+    as false positives in the software-pipelined loops of gemm_wd.hip; moves_of_loaded_registers() covers that file instead."""
     index = {a: i for i, (a, *_rest) in enumerate(ins)}
     n = len(ins)
     succ = [[] for _ in range(n)]
@@ -72,19 +76,24 @@ def analyse_function(ins):
             continue
         if nxt is not None:
             succ[i].append(nxt)
+    # state = (lgkm queue, vm queue): LDS / scalar-memory operations counted by lgkmcnt, vector-memory operations counted by vmcnt
+    # (gfx9: loads and stores share the counter and retire in issue order — the compiler's own model)
     state_in = [None] * n
-    state_in[0] = ()
+    state_in[0] = ((), ())
     work = [0]
     hazards = {}
     steps = 0
-    while work and steps < 40 * n + 1000:
+    while work and steps < 60 * n + 1000:
         steps += 1
         i = work.pop()
-        q = list(state_in[i])
+        q, v = list(state_in[i][0]), list(state_in[i][1])
         addr, op, args, ln, text = ins[i]
 
         def pending(used):
             for dst, l0, t0 in q:
+                if dst & used:
+                    return l0, t0
+            for dst, l0, t0 in v:
                 if dst & used:
                     return l0, t0
             return None
@@ -94,48 +103,98 @@ def analyse_function(ins):
             if m:
                 k = int(m.group(1))
                 q = q[len(q) - k:] if k > 0 else []
-            elif "cnt" not in args:
-                q = []
+            m = vm_re.search(args)
+            if m:
+                k = int(m.group(1))
+                v = v[len(v) - k:] if k > 0 else []
+            if "cnt" not in args:
+                q, v = [], []
         else:
             is_lds = op.startswith("ds_")
             is_smem = op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_memtime") or op.startswith("s_memrealtime")
+            is_vmem = vm and op.startswith(("global_", "buffer_", "flat_", "scratch_", "tbuffer_", "image_"))
             if is_lds or is_smem:
                 toks = args.split(",")
                 reads = is_lds and (op.startswith("ds_read") or op.startswith("ds_load") or "permute" in op or op.startswith("ds_swizzle") or "rtn" in op)
                 dst = regs(toks[0]) if reads else set()
                 used = regs(",".join(toks[1:] if reads else toks))
-                hit = pending(used | dst)
+                hit = pending(used)              # (a re-load into a register whose earlier load is pending is safe: same counter, in-order return)
                 if hit:
                     hazards[ln] = (ln, text, hit)
                 q.append((frozenset(dst), ln, text))
                 if len(q) > 64:
                     q = q[-64:]
-            elif q:
+            elif is_vmem:
+                toks = args.split(",")
+                to_lds = "_lds_" in op or " lds" in args
+                loads = ("load" in op and not to_lds) or ("atomic" in op and ("sc0" in args or "glc" in args))
+                dst = regs(toks[0]) if loads else set()
+                used = regs(",".join(toks[1:] if loads else toks))
+                hit = pending(used)
+                if hit:
+                    hazards[ln] = (ln, text, hit)
+                v.append((frozenset(dst), ln, text))
+                if len(v) > 64:
+                    v = v[-64:]
+            elif q or v:
                 used = regs(args)
                 hit = pending(used) if used else None
                 if hit:
                     hazards[ln] = (ln, text, hit)
-        out = tuple(q)
+        out = (tuple(q), tuple(v))
         for j in succ[i]:
             if state_in[j] is None:
                 state_in[j] = out
                 work.append(j)
             else:
-                merged, changed = _merge(state_in[j], out)
-                if changed:
-                    state_in[j] = merged
+                mq, cq = _merge(state_in[j][0], out[0])
+                mv, cv = _merge(state_in[j][1], out[1])
+                if cq or cv:
+                    state_in[j] = (mq, mv)
                     work.append(j)
     return [hazards[k] for k in sorted(hazards)]
 
 
-def scan(lines):
+def moves_of_loaded_registers(lines, name_filter):
+    """for the functions whose (mangled) name contains name_filter: register-to-register moves (v_mov*, v_accvgpr_*) whose source is,
+    anywhere in the function, the destination of a global_load into VGPRs.  The weight-direct GEMM issues those loads from inline asm
+    and keeps D K-tiles of them in flight across its loop's back edge; its counted vmcnt waits are only valid while the compiler never
+    copies such a register (a copy would read it before our wait).  -> {name: [text, ...]}"""
+    out = {}
+    name, ins = None, []
+
+    def flush():
+        if name is None or name_filter not in name:
+            return
+        loaded = set()
+        for op, args in ins:
+            if op.startswith("global_load_dword") and "lds" not in op:
+                loaded |= regs(args.split(",")[0])
+        bad = [f"{op} {args}" for op, args in ins
+               if op.startswith(("v_mov_b", "v_accvgpr_write", "v_accvgpr_mov", "v_pk_mov")) and regs(",".join(args.split(",")[1:])) & loaded]
+        out[name] = bad
+
+    for line in lines:
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            flush()
+            name, ins = m.group(1), []
+            continue
+        m = ins_re.match(line)
+        if name is not None and m:
+            ins.append((m.group(1), m.group(2) or ""))
+    flush()
+    return out
+
+
+def scan(lines, vm=False):
     """-> {mangled function name: [(line no, text, (pending since line, text)), ...]} for functions with at least one hazard"""
     report = {}
     name, ins = None, []
 
     def flush():
         if name is not None and ins:
-            hz = analyse_function(ins)
+            hz = analyse_function(ins, vm)
             if hz:
                 report[name] = hz
 
