@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void attn_dense_f16_kernel(
     _Float16* __restrict__ out_lo, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, const uint8_t* __restrict__ key_valid, int64_t kv_stride,
     int H, float scale, float* __restrict__ lse) {
+  pfpp_chain_prio();
   constexpr int KT = 32, NDT = DH / 32;      // NDT: 32-wide tiles of the head dimension
   constexpr int LDKH = DH + 8;          // halfs per K row  (16-byte fragment reads conflict-free)
   constexpr int LDVH = KT + 8;          // halfs per V^T row

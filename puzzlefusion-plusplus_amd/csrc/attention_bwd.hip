@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ dvec, float* __restrict__ dqkv,
     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
+  pfpp_chain_prio();
   __shared__ __align__(16) char smem[AB_DQ_SMEM];
   ab_dq_f16_body(smem, blockIdx.x, qkv, out, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
 }
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ dvec, float* __restrict__ dqkv, const int32_t* __restrict__ seq_off,
     const int32_t* __restrict__ seq_len, int H, float scale, pfpp_planes_out po) {
+  pfpp_chain_prio();
   __shared__ __align__(16) char smem[AB_DKV_SMEM];
   ab_dkv_f16_body(smem, blockIdx.x, qkv, dout, lse, dvec, dqkv, seq_off, seq_len, H, scale, po);
 }
@@ -1057,6 +1059,7 @@ __device__ __forceinline__ f32x16 bdf_mma3(const ab_half8 ah, const ab_half8 al,
 __global__ __launch_bounds__(64) void attn_blockdiag_bwd_f16_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                     float* __restrict__ dqkv, int64_t n_pairs, int L, int H,
                                                                     float scale, pfpp_planes_out po) {
+  pfpp_chain_prio();
   __shared__ __align__(16) _Float16 planes[3][2][BD_L * BDF_LD];      // q, k, dO x (hi, lo), row-major [token][dim]
   const int lane = threadIdx.x;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -1185,6 +1188,7 @@ constexpr float BDF_PS = 2048.0f;
 __global__ __launch_bounds__(64) void attn_blockdiag_f16_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                 _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
                                                                 int64_t n_pairs, int L, int H, float scale) {
+  pfpp_chain_prio();
   __shared__ __align__(16) _Float16 planes[2][BD_L * BDF_LD];       // v (hi, lo), row-major [token][dim]
   const int lane = threadIdx.x;
   const int l31 = lane & 31, lhi = lane >> 5;

@@ -254,6 +254,7 @@ __device__ __forceinline__ void pl_body(const GemmP& p, int ext_tile = 0) {
   constexpr int RA = (AK ? 2 : 1) * NPL * HS, RB = (WK ? 2 : 1) * NPL * NT;   // fragment reads of a half-step's A tiles / a step's W tiles
   constexpr int CPR_A = BM / 8, CPR_W = BN / 8;                  // 16-byte chunks per contraction row of a k-major tile
   extern __shared__ __align__(1024) char pl_smem[];
+  if constexpr (!AF && !(AK && WK)) pfpp_chain_prio();      // forward / input-gradient forms: the step's dependency chain
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

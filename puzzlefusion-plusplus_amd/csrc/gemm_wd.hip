@@ -71,6 +71,7 @@ struct WdCfg {
 
 template <int MT, int NT, int D, bool X1>
 __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
+  pfpp_chain_prio();
   using C = WdCfg<MT, NT, D, X1>;
   constexpr int BM = C::BM, PLANE = C::PLANE, STAGE = C::STAGE, NPL = C::NPL;
   constexpr int NPW = NPL * MT / 2;                            // 1 KB DMA pieces (16 rows of one plane) per wave and stage

@@ -105,3 +105,18 @@ inline uint32_t pfpp_drop_thresh(float p) {
       return PFPP_EUNSUPPORTED;                                   \
     }                                                             \
   } while (0)
+
+// Wave priority of the kernels on the training step's dependency chain (round 5; -DPFPP_CHAIN_PRIO=n at build time, 0 = off):
+// s_setprio only arbitrates instruction issue between the waves resident on one SIMD, so chain kernels that share CUs with the next
+// iteration's encoder (CU-masked stream) or the weight-gradient stream issue first and the co-runners fill their stalls.  The
+// iteration is the chain (4.93 ms alone) stretched by the encoder running under it (5.98 ms; the weight gradients are fully hidden:
+// profiles/r05c_ab_masks_and_lab_skips.txt); priority 3 takes 1.3 % off (6.18 -> 6.10 ms alternating on one box,
+// profiles/r05d_ab_chain_prio.txt).  Results are unchanged bit for bit (scheduling only).
+#ifndef PFPP_CHAIN_PRIO
+#define PFPP_CHAIN_PRIO 3
+#endif
+#ifdef __HIPCC__
+__device__ __forceinline__ void pfpp_chain_prio() {
+  if constexpr (PFPP_CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PFPP_CHAIN_PRIO);
+}
+#endif

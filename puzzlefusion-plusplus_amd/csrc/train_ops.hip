@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 __global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ z, float* __restrict__ u, int64_t rows,
                                                     int inner, uint32_t thresh, float inv_keep, uint64_t seed,
                                                     uint32_t site, pfpp_planes_out po) {
+  pfpp_chain_prio();
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // index into u [rows, inner]
   if (i4 >= rows * inner) return;
   const int64_t r = i4 / inner;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ dz, int64_t rows, int inner,
                                                         uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site,
                                                         pfpp_planes_out po) {
+  pfpp_chain_prio();
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= rows * inner) return;
   const int64_t r = i4 / inner;
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     float* __restrict__ dx, float* __restrict__ dmult, float* __restrict__ dadd, int64_t ld_d, int64_t rows,
     float eps, float* __restrict__ drop_out, uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site,
     int do_drop, pfpp_planes_out po_ret, pfpp_planes_out po_dx) {
+  pfpp_chain_prio();
   // po_ret: planes of the value the backward chain continues with (the dropped-out gradient when do_drop, else the updated
   // dx); po_dx: planes of the updated dx.  drop_out may be null when only the planes of the dropped-out gradient are wanted.
   constexpr int C = 256 * VPL;
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(256) void dropout_layernorm_kernel(
     const float* __restrict__ mod, int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta,
     int64_t rows, int rows_per_batch, float eps, const int32_t* __restrict__ group_batch, int group_rows,
     uint32_t thresh, float inv_keep, uint64_t seed, uint32_t site, pfpp_planes_out po) {
+  pfpp_chain_prio();
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ mod,
     int64_t ld_mod, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
     int rows_per_batch, float eps, const int32_t* __restrict__ group_batch = nullptr, int group_rows = 1) {
+  pfpp_chain_prio();
   constexpr int C = 256 * VPL;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -49,7 +49,9 @@ SOURCES = {
 # instructions unavailable every fp32 -> fp16 conversion is a plain v_cvt of the rounded fp32 value, so a split can only ever
 # see one hi.  tests/test_abi_and_host.py disassembles the library and checks that none is left.
 NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX]
+# PFPP_CHAIN_PRIO=n (lab, build time): s_setprio n in the kernels of the training step's dependency chain (csrc/pfpp_common.h)
+CHAIN_PRIO = [f"-DPFPP_CHAIN_PRIO={int(os.environ['PFPP_CHAIN_PRIO'])}"] if os.environ.get("PFPP_CHAIN_PRIO") else []
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX, *CHAIN_PRIO]
 
 
 def _hipcc() -> str:

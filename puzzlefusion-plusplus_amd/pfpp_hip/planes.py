@@ -154,8 +154,36 @@ def slab_reduce_group(jobs) -> None:
     check(_lib.load().pfpp_slab_reduce_group(arr, len(jobs), _stream()), "pfpp_slab_reduce_group")
 
 
+def reblock_many(items):
+    """ONE pfpp_reblock_planes launch for up to PFPP_REBLOCK_MAX weights: items = [(W planes as stored [rows, cols], transposed)] ->
+    [(fhi, flo)] — what pfpp_tlayers_fwd / _bwd do at the top of a six-layer call (the traced pass of bench.py issues the same two
+    launches per iteration as the timed region)"""
+    from . import ops
+    from ._lib import PlanesC, ReblockJob
+
+    n = len(items)
+    jobs = (ReblockJob * n)()
+    outs = []
+    for j, (W, transposed) in enumerate(items):
+        rows, cols = W.hi.shape
+        fhi = torch.empty(rows * cols, dtype=torch.float16, device=W.hi.device)
+        flo = torch.empty(rows * cols, dtype=torch.float16, device=W.hi.device)
+        jobs[j] = ReblockJob(PlanesC(W.hi.data_ptr(), W.lo.data_ptr(), W.scale), rows, cols, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr(),
+                             int(transposed))
+        outs.append((fhi, flo))
+    trace = ops.GEMM_TRACE
+    if trace is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.load().pfpp_reblock_planes(jobs, n, _stream()), "pfpp_reblock_planes")
+    if trace is not None:
+        e1.record()
+        trace.append((e0, e1, 0.0, "reblock_kernel", (n, 0, 0, 1, "reblock_many", 0)))
+    return outs
+
+
 def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
-            residual: Optional[torch.Tensor] = None, transposed: bool = False) -> torch.Tensor:
+            residual: Optional[torch.Tensor] = None, transposed: bool = False, frag=None) -> torch.Tensor:
     """the same linear as gemm(...) / gemm(..., w_kmajor=True) through the weight-direct kernel (csrc/gemm_wd.hip), the way
     pfpp_tlayers_fwd / _bwd run it: W's planes are fragment-blocked first (pfpp_reblock_planes; transposed: W is [K, N] and its
     transpose is blocked — the input-gradient form), then pfpp_gemm_wd.  Only the traced pass of bench.py issues it from Python (the
@@ -166,17 +194,21 @@ def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: i
     _chk(out, _f32, "out")
     lib = _lib.load()
     rows, cols = (K, N) if transposed else (N, K)               # W as stored
-    fhi = torch.empty(N * K, dtype=torch.float16, device=out.device)
-    flo = torch.empty(N * K, dtype=torch.float16, device=out.device)
-    job = ReblockJob(PlanesC(W.hi.data_ptr(), W.lo.data_ptr(), W.scale), rows, cols, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr(),
-                     int(transposed))
+    if frag is not None:                                        # blocked beforehand (reblock_many)
+        fhi, flo = frag
+    else:
+        fhi = torch.empty(N * K, dtype=torch.float16, device=out.device)
+        flo = torch.empty(N * K, dtype=torch.float16, device=out.device)
+        job = ReblockJob(PlanesC(W.hi.data_ptr(), W.lo.data_ptr(), W.scale), rows, cols, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr(),
+                         int(transposed))
     pw = PwC(None, W.hi.data_ptr(), W.lo.data_ptr(), W.scale, W.hi.shape[-1], fhi.data_ptr(), flo.data_ptr())
     ap = PlanesC(A.hi.data_ptr(), A.lo.data_ptr(), A.scale)
     trace = ops.GEMM_TRACE
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if trace is not None else None
     if ev:
         ev[0].record()
-    check(lib.pfpp_reblock_planes(C.byref(job), 1, _stream()), "pfpp_reblock_planes")
+    if frag is None:
+        check(lib.pfpp_reblock_planes(C.byref(job), 1, _stream()), "pfpp_reblock_planes")
     if ev:
         ev[1].record(); ev[2].record()
     check(lib.pfpp_gemm_wd(C.byref(ap), A.hi.shape[-1], C.byref(pw), None if bias is None else bias.data_ptr(),
@@ -185,7 +217,8 @@ def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: i
     if ev:
         ev[3].record()
         big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 240
-        trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
+        if frag is None:
+            trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
         trace.append((ev[2], ev[3], 2.0 * M * N * K, ops.wd_kernel_name(big), (M, N, K, 1, "nn" if transposed else "nt", 0)))
     return out
 

@@ -483,10 +483,13 @@ class DenoiserTrainEngine:
             pw = w[key]
             return P.Planes(pw.hi, pw.lo, pw.scale)
 
+        # traced pass: every layer's five weights blocked by ONE launch up front, as pfpp_tlayers_fwd does for a six-layer call
+        frags = self._traced_frags(w, transposed=False) if _traced_wd() else {}
+
         def lin(a, key, N, K, bias=None, residual=None):
             out = torch.empty((M, N), dtype=torch.float32, device=dev)
             if _traced_wd() and not key.endswith("ff1.w") and N % 128 == 0 and K % 64 == 0:
-                return P.gemm_wd(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual)
+                return P.gemm_wd(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual, frag=frags.get(key))
             return P.gemm(a, wp(key), out, M=M, N=N, K=K, bias=bias, residual=residual)
 
         def ln_planes(x, i_mod=None, gamma=None, beta=None):
@@ -540,6 +543,18 @@ class DenoiserTrainEngine:
         return h
 
     # ------------------------------------------------------------------------------------------ blocks sequenced from C
+    def _traced_frags(self, w, transposed: bool):
+        """fragment-blocked planes of every layer's qkv / out / second feed-forward weights (of their transposes: the input-gradient
+        operands) from ONE reblock launch -> {weight key: (fhi, flo)}; only the weights whose widths the blocked layout covers"""
+        from . import planes as P
+
+        keys = [f"{i}.{k}" for i in range(self.num_layers) for k in ("self_attn.qkv.w", "self_attn.o.w", "global_attn.qkv.w", "global_attn.o.w", "ff2.w")]
+        ok = [k for k in keys if w[k].hi.shape[0] % 64 == 0 and w[k].hi.shape[1] % 64 == 0]
+        if not ok or len(ok) > 32:
+            return {}
+        out = P.reblock_many([(P.Planes(w[k].hi, w[k].lo, w[k].scale), transposed) for k in ok])
+        return dict(zip(ok, out))
+
     def _take_arena(self, kind: str, nbytes: int, dev) -> torch.Tensor:
         """a persistent byte arena of the C-sequenced path.  Reuse needs no event: an arena goes back to the pool at the end of the
         backward that read it — after the main stream was made to wait for the weight-gradient stream (_all_done) — and its next user
@@ -1018,10 +1033,12 @@ class DenoiserTrainEngine:
             pw = w[key]
             return P.Planes(pw.hi, pw.lo, pw.scale)
 
+        frags = self._traced_frags(w, transposed=True) if _traced_wd() else {}
+
         def dx(dyp, key, n_in):
             out = torch.empty((M, n_in), dtype=torch.float32, device=dev)
             if _traced_wd() and not key.endswith("ff1.w") and n_in % 128 == 0 and dyp.shape[1] % 64 == 0:
-                return P.gemm_wd(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], transposed=True)
+                return P.gemm_wd(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], transposed=True, frag=frags.get(key))
             return P.gemm(dyp, wp(key), out, M=M, N=n_in, K=dyp.shape[1], w_kmajor=True)
 
         drop_lay = fuse and p_lay > 0.0
