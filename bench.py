@@ -205,10 +205,15 @@ class TrainWorkload:
     def _step(self):
         m, d = self.model, self.data
         sch = m.noise_scheduler
+        between = None
         if self.pipeline is not None:
             # the frozen encoder of the NEXT iteration's (noise, t) draw runs on its own stream under this iteration's
             # transformer work; every iteration still does one full encoder pass + one full transformer step
-            f = self.pipeline.next(d, self.gt, self.ref, self._draw)
+            if os.environ.get("PFPP_BENCH_ENC_AFTER_FWD", "0") == "1":       # lab: the next encoder under the BACKWARD instead of the forward
+                f = self.pipeline.take(d, self.gt, self.ref, self._draw)
+                between = lambda: self.pipeline.issue_next(d, self.gt, self.ref, self._draw)
+            else:
+                f = self.pipeline.next(d, self.gt, self.ref, self._draw)
             noisy, t, latent, xyz, noise = f["noisy"], f["t"], f["latent"], f["xyz"], f["noise"]
         else:
             noise, t = self._draw()
@@ -220,7 +225,7 @@ class TrainWorkload:
         if self._opt_in_bwd:
             self.engine.arm_optimizer(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6, zero_grad=True)
         self.last_loss = self.engine.loss_and_grads(noisy, t, latent, xyz, d["part_valids"], d["part_scale"], self.ref, noise,
-                                                    seed=1000 + self.i, train=True)
+                                                    seed=1000 + self.i, train=True, between=between)
         self.engine.optimizer_step(lr=2e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,
                                    zero_grad=True)      # optimizer.step() + optimizer.zero_grad() in one pass over the buffers
         self.i += 1

@@ -790,6 +790,15 @@ int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi, void* lo, 
 int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
                        float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);
+/* the same update restricted by ROWS of a stack of embedding tables [n_tables, rows_per_table, C] (the 12 AdaLN timestep tables,
+ * MyAdaLayerNorm.emb = nn.Embedding(num_embeds_ada_norm, dim), attention.py:18-25): a step touches only the rows of the batch's
+ * timesteps t [n_t] (int64, device), every other row has an exactly zero gradient and its update (moment decay, weight decay, the
+ * step of the decayed first moment) depends on nothing of this step's backward.  mode 0: every row EXCEPT t[.] — issued at the
+ * start of the backward, off the iteration's exposed tail; mode 1: only the rows t[.] (each once, whatever the duplicates in t) —
+ * after their gradients are final.  Both together = one pfpp_adamw_guarded over the stack, element for element.          */
+int pfpp_adamw_rows(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n_tables, int64_t rows_per_table, int64_t C,
+                    const int64_t* t, int64_t n_t, int mode, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float bc1, float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);
 
 /* ---- train-mode BatchNorm of the (frozen, but .train()) encoder (utils/pn2_utils.py:211-214) -------------
  * The reference freezes the encoder's parameters only (train_denoiser.py:33-35); under Lightning's
@@ -870,6 +879,17 @@ typedef struct pfpp_tlayers_args {
    * pfpp_gemm_wd.  With room for every layer of the call's range (n x pfpp_tlayers_frag_bytes()) the range's weights are blocked by ONE
    * launch at the top of the call instead of one per layer */
   void* frag_ws; int64_t frag_ws_bytes;
+  /* optional (ada_se == NULL: the caller does this after the call), backward, side != NULL: the two AdaLN linears of every block
+   * (MyAdaLayerNorm.linear, attention.py:21-25: mods_j = silu(table_j[t]) . W_j^T + b_j, j = 2 i, 2 i + 1) take their gradients as soon
+   * as block i's backward is through — gb_j += colsum(dmods_j), gw_j += dmods_j^T . se_j, and the gradient w.r.t. the embedded timestep
+   * dse_j = dmods_j . W_j — on the side stream, followed (with adamw) by the AdamW update of W_j / b_j (ada_adamw_w / _b [n_layers]:
+   * the block's slices [2 i, 2 i + 2) of the stacked parameters): none of it is left for the exposed tail of the iteration */
+  const float* ada_se;                          /* [2 n_layers, B, C] silu(table[t]) rows of the forward */
+  float* ada_dse;                               /* [2 n_layers, B, C] out */
+  const float* ada_w;                           /* [2 n_layers, 2C, C] fp32 weights (read before their update) */
+  float* ada_gw; float* ada_gb;                 /* [2 n_layers, 2C, C], [2 n_layers, 2C] gradients, accumulated */
+  const pfpp_tlayer_adamw* ada_adamw_w;         /* [n_layers] or NULL */
+  const pfpp_tlayer_adamw* ada_adamw_b;         /* [n_layers] or NULL */
 } pfpp_tlayers_args;
 int64_t pfpp_tlayers_frag_bytes(int64_t C, int64_t inner);
 int64_t pfpp_tlayers_fwd_bytes(int64_t M, int64_t C, int64_t H, int64_t inner);

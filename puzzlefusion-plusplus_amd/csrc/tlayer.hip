@@ -310,7 +310,8 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   };
   // PFPP_TRAIN_DW_GROUP (default 1, round 5): a block's six weight gradients as ONE launch (pfpp_gemm_dw_group, csrc/gemm_pl.hip: every
   // output tile over the whole contraction, no K split, no slabs, no reduction launches) behind the block's last gradient kernel,
-  // 2: two launches (feed-forward pair behind the GEGLU backward, the four attention linears at the block's end); 0 = one
+  // 2: two launches (feed-forward pair behind the GEGLU backward, the four attention linears at the block's end), 3: two launches for
+  // layer 0 only (the last block of the backward: what is left on the side stream when the chain ends is the iteration's tail); 0 = one
   // pfpp_gemm_planes launch (+ slab reduction) per weight as through round 4 (the cross-check of the tests)
   const int dw_group = getenv("PFPP_TRAIN_DW_GROUP") ? atoi(getenv("PFPP_TRAIN_DW_GROUP")) : 1;          // (read per call: the tests switch it)
   const int dw_group_variant = getenv("PFPP_TRAIN_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_TRAIN_DW_GROUP_VARIANT")) : 0;
@@ -394,7 +395,7 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     TL_CALL(fresh(SLOT_DZ0 + par, M * 2 * inner, &dzp));
     TL_CALL(pfpp_geglu_bwd_p(z, du, nullptr, M, inner, a->p_lay, a->seed, (uint32_t)(3 + 3 * i), &dzp, stream));
     TL_CALL(dw(dzp, SLOT_DZ0 + par, n3, 2 * inner, C, g.ff1_w, g.ff1_b));
-    if (dw_group == 2) TL_CALL(flush_dw());
+    if (dw_group == 2 || (dw_group == 3 && i == 0)) TL_CALL(flush_dw());      // 3: only the LAST block to run (layer 0) goes out in two launches
     TL_CALL(dx(dzp, w.ff1, dn, C, 2 * inner));
     TL_CALL(fresh(SLOT_DY0 + 2 * par, M * C, &dyp));
     TL_CALL(pfpp_layernorm_bwd_p(h2, dn, nullptr, 0, w.g3, nullptr, 32, 1, a->dh, g.g3, g.b3, 0, M, C, eps, nullptr, a->p_lay, a->seed,
@@ -435,13 +436,41 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     }
     TL_CALL(flush_dw());
     TL_CALL(flush_jobs());
+    if ((a->adamw || a->ada_se) && side) TL_CALL(order_after(side_s, main_s));      // the layer's main-stream kernels are all queued by now
     if (a->adamw && side) {
       // optimizer in the backward: the layer's slice of the flat buffer is final once its weight gradients (side stream) and its
       // LayerNorm gradients (main stream, all queued by now) have run
       const pfpp_tlayer_adamw& ad = a->adamw[i];
-      TL_CALL(order_after(side_s, main_s));
       TL_CALL(pfpp_adamw_guarded(ad.p, ad.g, ad.m, ad.v, ad.hi, ad.lo, ad.n, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->bc1, a->bc2,
                                  a->opt_g_scale, a->opt_zero_grad, a->overflow, side_t));
+    }
+    if (a->ada_se && side) {
+      // the block's two AdaLN linears (attention.py:21-25): dmods rows 2 i, 2 i + 1 are final (both LayerNorm backward launches of
+      // the block have been queued) — bias / weight gradients, the gradient w.r.t. the embedded timestep, then (armed) their AdamW;
+      // same launches with the same arguments as pfpp_hip.train's tail issued them for all blocks at once
+      const int64_t B = a->B, j = 2 * i;
+      const float* dm = a->dmods + j * B * ld_mod;
+      TL_CALL(pfpp_colsum(dm, a->ada_gb + j * ld_mod, B, ld_mod, ld_mod, 2, B * ld_mod, ld_mod, 1, side_t));
+      pfpp_gemm_grad_args q = {};
+      q.A = dm; q.W = a->ada_se + j * B * C; q.C = a->ada_gw + j * ld_mod * C;
+      q.M = ld_mod; q.N = C; q.K = B; q.lda = ld_mod; q.ldw = C; q.ldc = C;
+      q.a_kmajor = 1; q.w_kmajor = 1; q.accumulate = 1; q.split_k = 0; q.batch = 2;
+      q.sA = B * ld_mod; q.sW = B * C; q.sC = ld_mod * C;
+      q.a_scale = G; q.w_scale = 1.0f; q.alpha = 1.0f;
+      TL_CALL(pfpp_gemm_grad(&q, side_t));
+      pfpp_gemm_grad_args d = {};
+      d.A = dm; d.W = a->ada_w + j * ld_mod * C; d.C = a->ada_dse + j * B * C;
+      d.M = B; d.N = C; d.K = ld_mod; d.lda = ld_mod; d.ldw = C; d.ldc = C;
+      d.a_kmajor = 0; d.w_kmajor = 1; d.accumulate = 0; d.split_k = 0; d.batch = 2;
+      d.sA = B * ld_mod; d.sW = ld_mod * C; d.sC = B * C;
+      d.a_scale = G; d.w_scale = 1.0f; d.alpha = 1.0f;
+      TL_CALL(pfpp_gemm_grad(&d, side_t));
+      if (a->adamw && a->ada_adamw_w && a->ada_adamw_b) {
+        const pfpp_tlayer_adamw* ads[2] = {&a->ada_adamw_w[i], &a->ada_adamw_b[i]};
+        for (const pfpp_tlayer_adamw* ad : ads)
+          TL_CALL(pfpp_adamw_guarded(ad->p, ad->g, ad->m, ad->v, ad->hi, ad->lo, ad->n, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay,
+                                     a->bc1, a->bc2, a->opt_g_scale, a->opt_zero_grad, a->overflow, side_t));
+      }
     }
   }
   if (a->dhp_out) *a->dhp_out = dhp;

@@ -602,6 +602,64 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
+// AdamW over a stack of embedding tables restricted by rows (see pfpp_adamw_rows): MODE 0 = one thread per element of the stack, rows
+// listed in t skipped (a 3,072-bit row mask built in LDS per workgroup); MODE 1 = one thread per element of the listed rows, a row
+// listed twice is taken by its first occurrence only.  Same arithmetic per element as adamw_kernel<true>.
+template <int MODE, bool GUARD>
+__global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                         int64_t n_tables, int rows_per_table, int C, const int64_t* __restrict__ t,
+                                                         int n_t, float decay, float w1, float beta2, float w2, float eps,
+                                                         float step_size, float inv_sqrt_bc2, float g_scale, int zero_g,
+                                                         int* __restrict__ overflow) {
+  int64_t i;
+  if (MODE == 0) {
+    __shared__ unsigned mask[128];              // rows_per_table <= 4096
+    for (int k = threadIdx.x; k < 128; k += 256) mask[k] = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_t; k += 256) {
+      const int64_t r = t[k];
+      if (r >= 0 && r < rows_per_table) atomicOr(&mask[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_tables * rows_per_table * (int64_t)C) return;
+    const int r = (int)((i / C) % rows_per_table);
+    if ((mask[r >> 5] >> (r & 31)) & 1u) return;
+  } else {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (table, listed entry, column)
+    if (e >= n_tables * n_t * (int64_t)C) return;
+    const int c = (int)(e % C);
+    const int k = (int)((e / C) % n_t);
+    const int64_t tab = e / ((int64_t)C * n_t);
+    const int64_t r = t[k];
+    if (r < 0 || r >= rows_per_table) return;
+    for (int k2 = 0; k2 < k; ++k2)
+      if (t[k2] == r) return;                   // a duplicate: its first occurrence does the row
+    i = (tab * rows_per_table + r) * C + c;
+  }
+  float gr = g[i] * g_scale;
+  if (zero_g) g[i] = 0.0f;
+  if (GUARD) {
+    if (!(fabsf(gr) <= 3.0e38f)) {              // inf or NaN: the element is left untouched (adamw_kernel<true>'s rule)
+      atomicOr(overflow, 1);
+      atomicAdd(overflow + 1, 1);
+      return;
+    }
+  }
+  float pp = p[i] * decay;
+  float mm = m[i];
+  mm = mm + w1 * (gr - mm);
+  const float vv = v[i] * beta2 + w2 * (gr * gr);
+  const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+  pp = pp - step_size * (mm / denom);
+  p[i] = pp; m[i] = mm; v[i] = vv;
+  if (hi) {
+    const pfpp_hl s = pfpp_split(pp);
+    hi[i] = s.hi; lo[i] = s.lo;
+  }
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -909,6 +967,30 @@ extern "C" int pfpp_adamw_zero(float* p, float* g, float* m, float* v, void* hi,
                                float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
                                float g_scale, int zero_grad, pfpp_stream_t stream) {
   return pfpp_adamw_guarded(p, g, m, v, hi, lo, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, zero_grad, nullptr, stream);
+}
+
+extern "C" int pfpp_adamw_rows(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n_tables, int64_t rows_per_table,
+                               int64_t C, const int64_t* t, int64_t n_t, int mode, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float bc1, float bc2, float g_scale, int zero_grad, int32_t* overflow,
+                               pfpp_stream_t stream) {
+  PFPP_REQUIRE(p && g && m && v && t, "null pointer");
+  PFPP_REQUIRE(!hi == !lo, "hi and lo go together");
+  PFPP_REQUIRE(bc1 > 0.0f && bc2 > 0.0f, "bias corrections must be positive");
+  PFPP_REQUIRE(n_tables >= 1 && rows_per_table >= 1 && rows_per_table <= 4096 && C >= 1 && C < (1 << 30) && n_t >= 0 && n_t <= 4096, "sizes");
+  PFPP_REQUIRE(mode == 0 || mode == 1, "mode: 0 = all rows but the listed ones, 1 = the listed rows");
+  hipStream_t st = pfpp::as_stream(stream);
+  const int64_t n = mode == 0 ? n_tables * rows_per_table * C : n_tables * n_t * C;
+  if (n == 0) return PFPP_OK;
+  const dim3 grid(blocks_for(n, 256));
+  const float decay = 1.0f - lr * weight_decay, w1 = 1.0f - beta1, w2 = 1.0f - beta2, step = lr / bc1, isb = 1.0f / sqrtf(bc2);
+#define PFPP_ROWS_LAUNCH(MODE, GUARD)                                                                                             \
+  hipLaunchKernelGGL((adamw_rows_kernel<MODE, GUARD>), grid, dim3(256), 0, st, p, g, m, v, (_Float16*)hi, (_Float16*)lo, n_tables,  \
+                     (int)rows_per_table, (int)C, t, (int)n_t, decay, w1, beta2, w2, eps, step, isb, g_scale, zero_grad ? 1 : 0,   \
+                     (int*)overflow)
+  if (mode == 0) { if (overflow) PFPP_ROWS_LAUNCH(0, true); else PFPP_ROWS_LAUNCH(0, false); }
+  else { if (overflow) PFPP_ROWS_LAUNCH(1, true); else PFPP_ROWS_LAUNCH(1, false); }
+#undef PFPP_ROWS_LAUNCH
+  return pfpp::check_launch(__func__);
 }
 
 extern "C" int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n, float lr,

@@ -180,6 +180,8 @@ class TlayersArgs(C.Structure):
         ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32), ("bc1", _f32), ("bc2", _f32),
         ("opt_g_scale", _f32), ("opt_zero_grad", _i32), ("overflow", _p),
         ("frag_ws", _p), ("frag_ws_bytes", _i64),
+        ("ada_se", _p), ("ada_dse", _p), ("ada_w", _p), ("ada_gw", _p), ("ada_gb", _p),
+        ("ada_adamw_w", C.POINTER(TlayerAdamw)), ("ada_adamw_b", C.POINTER(TlayerAdamw)),
     ]
 
 
@@ -284,6 +286,7 @@ SIGNATURES = {
     "pfpp_adamw_zero": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p],
     "pfpp_sa_train_stage": [C.POINTER(SaTrainArgs), _p],
     "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
+    "pfpp_adamw_rows": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, C.c_int, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels
     "pfpp_gemm_planes": [C.POINTER(GemmPlanesArgs), _p],
     "pfpp_slab_reduce_group": [C.POINTER(SlabJob), C.c_int32, _p],

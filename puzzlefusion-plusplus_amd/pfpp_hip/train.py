@@ -346,6 +346,9 @@ class DenoiserTrainEngine:
         self._heads_static = None
         self._cseq_static = None
         self._arena_pool: Dict[tuple, list] = {}
+        self._tables_rows = None                      # armed single-rank step: (timesteps, table shape, end of the table range) — rows updated early
+        self._ada_ranges = []
+        self._ada_static = (None, None)
         self._dw_pending = None                       # traced Python backward: the block's weight gradients collected for one grouped launch
         self._armed = None                            # arm_optimizer(): hyper-parameters of an optimizer-in-backward step
         self._armed_zero = False
@@ -599,6 +602,21 @@ class DenoiserTrainEngine:
             a, b = f.layer_ranges[i]
             adam[i] = TlayerAdamw(f.params[a:b].data_ptr(), f.grads[a:b].data_ptr(), f.exp_avg[a:b].data_ptr(), f.exp_avg_sq[a:b].data_ptr(),
                                   f.hi[a:b].data_ptr(), f.lo[a:b].data_ptr(), b - a)
+        # the blocks' AdaLN linears (stacked [2 n, 2C, C] / [2 n, 2C]): block i's slices [2 i, 2 i + 2) for the per-block gradients /
+        # AdamW the C sequencer queues on the side stream (single rank)
+        ada_w_ad, ada_b_ad = (TlayerAdamw * n)(), (TlayerAdamw * n)()
+        t0 = "transformer_layers.0"
+        aw, ab = f.offset[f"{t0}.norm1.linear.weight"], f.offset[f"{t0}.norm1.linear.bias"]
+        Cw = w["shape.b"].numel()
+        for i in range(n):
+            x0, x1 = aw + 2 * i * 2 * Cw * Cw, aw + (2 * i + 2) * 2 * Cw * Cw
+            y0, y1 = ab + 2 * i * 2 * Cw, ab + (2 * i + 2) * 2 * Cw
+            ada_w_ad[i] = TlayerAdamw(f.params[x0:x1].data_ptr(), f.grads[x0:x1].data_ptr(), f.exp_avg[x0:x1].data_ptr(),
+                                      f.exp_avg_sq[x0:x1].data_ptr(), f.hi[x0:x1].data_ptr(), f.lo[x0:x1].data_ptr(), x1 - x0)
+            ada_b_ad[i] = TlayerAdamw(f.params[y0:y1].data_ptr(), f.grads[y0:y1].data_ptr(), f.exp_avg[y0:y1].data_ptr(),
+                                      f.exp_avg_sq[y0:y1].data_ptr(), f.hi[y0:y1].data_ptr(), f.lo[y0:y1].data_ptr(), y1 - y0)
+        self._ada_ranges = [(aw, aw + 2 * n * 2 * Cw * Cw), (ab, ab + 2 * n * 2 * Cw)]
+        self._ada_static = (ada_w_ad, ada_b_ad)
         args = TlayersArgs()
         args.n_layers = n
         args.layers, args.grads = layers, grads
@@ -684,6 +702,41 @@ class DenoiserTrainEngine:
         args.dhp_out = C_.pointer(nxt)
         reducing = self._exchange.reducing()
         in_c = self._armed is not None and self._side is not None and not self._exchange.active()
+        # lab (PFPP_TRAIN_ADA_IN_C=1, single rank): the blocks' AdaLN-linear gradients (and, armed, their AdamW) per block on the side
+        # stream instead of in the iteration's tail.  Measured SLOWER (6.10 -> 6.27 ms, profiles/r05f_ab_tail_ada_tables.txt): what ends the
+        # iteration is the side stream's work for layer 0 (its grouped weight gradients + AdamW, ~260 us behind the chain), which the
+        # tail's own launches used to cover — moving them onto that stream lengthens exactly the critical part.  Default off.
+        ada_c = (self._side is not None and not self._exchange.active() and os.environ.get("PFPP_TRAIN_ADA_IN_C", "0") == "1")
+        if ada_c:
+            se = s["se"]
+            dse = torch.empty_like(se)
+            opsd = self.flat.operands()
+            args.ada_se, args.ada_dse = se.data_ptr(), dse.data_ptr()
+            args.ada_w, args.ada_gw, args.ada_gb = opsd["w"]["ada.w"].f32.data_ptr(), g["ada.w"].data_ptr(), g["ada.b"].data_ptr()
+            args.ada_adamw_w, args.ada_adamw_b = (self._ada_static if in_c else (None, None))
+            for t_ in (se, dse, dmods):
+                t_.record_stream(self._side)
+            s["_ada_dse"] = dse
+        else:
+            args.ada_se = args.ada_dse = args.ada_w = args.ada_gw = args.ada_gb = None
+            args.ada_adamw_w = args.ada_adamw_b = None
+        if in_c and os.environ.get("PFPP_TRAIN_TABLES_EARLY", "0") == "1":
+            # lab (PFPP_TRAIN_TABLES_EARLY=1): the 12 timestep tables (a third of all parameters) — only the batch's rows get a gradient
+            # this step, so every other row's AdamW update needs nothing of this backward and can go out now, on the side stream
+            # (pfpp_adamw_rows; bit-identical to the one-pass update, tested).  Measured neutral (6.14 / 6.12 ms,
+            # profiles/r05g_ab_tail_tables_dwsplit.txt): the tail is bounded by the side stream's layer-0 work, not by this launch.
+            hp = self._armed
+            f = self.flat
+            n_tab = f.offset["transformer_layers.0.norm1.linear.weight"]
+            shp = opsd["w"]["ada.tables"].shape if ada_c else self.flat.operands()["w"]["ada.tables"].shape
+            t64 = s["t64"]
+            views = [f_[:n_tab].view(shp) for f_ in (f.params, f.grads, f.exp_avg, f.exp_avg_sq)]
+            self._run_on(self._side, lambda: T.adamw_rows(*views, t64, mode=0, lr=hp["lr"], beta1=hp["betas"][0], beta2=hp["betas"][1],
+                                                          eps=hp["eps"], weight_decay=hp["weight_decay"], step=self.step_count + 1,
+                                                          hi=f.hi[:n_tab], lo=f.lo[:n_tab], g_scale=1.0, zero_grad=self._armed_zero,
+                                                          overflow=self._overflow))
+            t64.record_stream(self._side)
+            self._tables_rows = (t64, shp, n_tab)
         if in_c:
             # optimizer in the backward (arm_optimizer), single rank: each layer's AdamW is queued on the side stream by the C sequencer
             hp = self._armed
@@ -700,6 +753,10 @@ class DenoiserTrainEngine:
             _lib.check(lib.pfpp_tlayers_bwd(C_.byref(args), 0, self.num_layers, C_.c_void_p(main_h), side_arg), "pfpp_tlayers_bwd")
             if in_c:
                 self._early.extend(self.flat.layer_ranges)
+                if ada_c:
+                    self._early.extend(self._ada_ranges)
+                if self._tables_rows is not None:
+                    self._early.append((0, self._tables_rows[2]))
         else:
             for i in reversed(range(self.num_layers)):
                 _lib.check(lib.pfpp_tlayers_bwd(C_.byref(args), i, i + 1, C_.c_void_p(main_h), side_arg), "pfpp_tlayers_bwd")
@@ -833,14 +890,19 @@ class DenoiserTrainEngine:
         # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
         n_ada = 2 * self.num_layers
         se = s["se"]
-        if self._ada_layerwise is None:
-            T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
-            T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
-                        accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+        dse = s.pop("_ada_dse", None)
+        if dse is not None:
+            # the C sequencer queued the AdaLN linears' gradients and d/d(embedded timestep) per block on the side stream
+            torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            if self._ada_layerwise is None:
+                T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)
+                T.gemm_grad(dmods, se, g["ada.w"], M=2 * C, N=C, K=B, lda=2 * C, ldw=C, ldc=C, a_kmajor=True, w_kmajor=True,
+                            accumulate=True, batch=n_ada, sA=B * 2 * C, sW=B * C, sC=2 * C * C, a_scale=G)
+            dse = torch.empty_like(se)
+            T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
+                        sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
         self._ada_layerwise = None
-        dse = torch.empty_like(se)
-        T.gemm_grad(dmods, w["ada.w"].f32, dse, M=B, N=C, K=2 * C, lda=2 * C, ldw=C, ldc=C, w_kmajor=True, batch=n_ada,
-                    sA=B * 2 * C, sW=2 * C * C, sC=B * C, a_scale=G)
         if self._sparse_tables and self._exchange.reducing() and not self._accumulated:
             dse_all, t_all = self._exchange.gather_rows(dse, s["t64"], dim=1)       # [n_ada, world*B, C], [world*B]
             T.silu_embed_bwd(w["ada.tables"], t_all, dse_all, g["ada.tables"])
@@ -1199,6 +1261,7 @@ class DenoiserTrainEngine:
         self._armed = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         self._armed_zero = bool(zero_grad)          # the per-layer updates also clear their gradients (optimizer_step(zero_grad=True))
         self._early = []
+        self._tables_rows = None
 
     def _adamw_range(self, a: int, b: int, *, step: int, g_scale: float, lr, betas, eps, weight_decay, zero_grad: bool = False) -> None:
         f = self.flat
@@ -1219,11 +1282,19 @@ class DenoiserTrainEngine:
         hp = dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=float(weight_decay))
         early, self._early = self._early, []
         armed, self._armed = self._armed, None
+        rows, self._tables_rows = self._tables_rows, None
         if early:
             if armed != hp:
                 raise RuntimeError("optimizer_step: hyper-parameters differ from the ones the backward was armed with")
             if zero_grad != self._armed_zero:
                 raise RuntimeError("optimizer_step: zero_grad differs from what the backward was armed with")
+            if rows is not None:
+                # the timestep tables: every row but the batch's was updated at the start of the backward; now the batch's rows
+                t64, shp, n_tab = rows
+                T.adamw_rows(*(f_[:n_tab].view(shp) for f_ in (f.params, f.grads, f.exp_avg, f.exp_avg_sq)), t64, mode=1, lr=hp["lr"],
+                             beta1=hp["betas"][0], beta2=hp["betas"][1], eps=hp["eps"], weight_decay=hp["weight_decay"],
+                             step=self.step_count, hi=f.hi[:n_tab], lo=f.lo[:n_tab], g_scale=g_scale, zero_grad=zero_grad,
+                             overflow=self._overflow)
             pos, total = 0, f.params.numel()
             for a, b in sorted(early) + [(total, total)]:
                 if a > pos:
@@ -1283,9 +1354,12 @@ class DenoiserTrainEngine:
 
     # ------------------------------------------------------------------------------------------ whole step
     def loss_and_grads(self, x, timesteps, latent, xyz, part_valids, scale, ref_part, noise, *, seed: int = 0,
-                       train: bool = True) -> torch.Tensor:
-        """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1]"""
+                       train: bool = True, between=None) -> torch.Tensor:
+        """forward + Denoiser._loss (denoiser.py:118-126) + backward; returns the loss [1].  between(): called once the forward is
+        enqueued, before the backward (a scheduling hook: e.g. issue the next batch's encoder there)"""
         pred, ctx = self.forward(x, timesteps, latent, xyz, part_valids, scale, ref_part, seed=seed, train=train)
+        if between is not None:
+            between()
         n = pred.shape[0] * pred.shape[1]
         # the selection (valid & ~reference) is evaluated inside the loss kernel, which also leaves max |dpred| for the gradient scale
         amax = torch.empty(1, dtype=torch.float32, device=pred.device) if self._dyn_gscale else None
@@ -1381,6 +1455,21 @@ class FeaturePipeline:
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return dict(noisy=noisy, latent=latent, xyz=xyz, noise=noise, t=t, event=ev)
+
+    def take(self, data, gt, ref, draw):
+        """-> features of the batch issued last (issued now when there is none); the caller issues the following one itself
+        (issue_next) — at a point of its choice inside the iteration"""
+        if self.pending is None:
+            self.pending = self._issue(data, gt, ref, *draw())
+        cur, self.pending = self.pending, None
+        main = torch.cuda.current_stream()
+        main.wait_event(cur["event"])
+        for k in ("noisy", "latent", "xyz"):
+            cur[k].record_stream(main)
+        return cur
+
+    def issue_next(self, data, gt, ref, draw) -> None:
+        self.pending = self._issue(data, gt, ref, *draw())
 
     def next(self, data, gt, ref, draw):
         """-> features of the batch issued on the previous call (or now, the first time), and issues the following one.

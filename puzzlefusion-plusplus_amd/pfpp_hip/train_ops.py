@@ -408,6 +408,23 @@ def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *,
                                          weight_decay, bc1, bc2, g_scale, int(zero_grad), _ptr(overflow), _stream()), "pfpp_adamw_guarded")
 
 
+def adamw_rows(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, t: torch.Tensor, *, mode: int, lr: float, beta1: float,
+               beta2: float, eps: float, weight_decay: float, step: int, hi: Optional[torch.Tensor] = None,
+               lo: Optional[torch.Tensor] = None, g_scale: float = 1.0, zero_grad: bool = False,
+               overflow: Optional[torch.Tensor] = None) -> None:
+    """adamw() over a stack of embedding tables p [n_tables, rows, C] restricted by rows (pfpp_adamw_rows): mode 0 = every row but
+    the ones listed in t (int64 [n]), mode 1 = only the listed rows (each once); the two together are one adamw() over the stack"""
+    for t_, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t_, _f32, nm)
+    _chk(t, torch.int64, "t")
+    n_tab, rows, Cc = p.shape
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.load().pfpp_adamw_rows(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), n_tab, rows, Cc, _ptr(t), t.numel(), mode,
+                                      lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, int(zero_grad), _ptr(overflow), _stream()),
+          "pfpp_adamw_rows")
+
+
 def bn_stats(x: torch.Tensor, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
              momentum: float = 0.1) -> Tuple[torch.Tensor, torch.Tensor]:
     """per-column batch mean / biased variance of x [rows, C]; updates the running statistics in place like

@@ -145,7 +145,7 @@ def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev, armed):
             eng.arm_optimizer(lr=lr)
         eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
         if armed:
-            assert sorted(eng._early) == sorted(eng.flat.layer_ranges)       # every layer's slice went early
+            assert set(eng.flat.layer_ranges) <= set(eng._early)             # every layer's slice went early (+ the timestep tables' untouched rows)
         eng.optimizer_step(lr=lr)
         assert eng._armed is None and eng._early == []
     named = dict(eng.module.named_parameters())

@@ -479,6 +479,43 @@ def test_adamw_matches_torch(dev):
     assert (hi.float() + lo.float() - p).abs().max() < 1e-7
 
 
+def test_adamw_by_rows_equals_one_pass_over_the_tables(dev):
+    """round 5: the AdaLN timestep tables (MyAdaLayerNorm.emb, attention.py:18-25; a third of all parameters) get gradients in the
+    batch's rows only, so the armed single-rank step updates every OTHER row at the start of the backward (pfpp_adamw_rows mode 0, off
+    the iteration's exposed tail) and the batch's rows at the end (mode 1, each once whatever the duplicates among the timesteps).  The
+    two passes together are bit-identical to one guarded AdamW over the stack — parameters, both moments, planes, cleared gradients —
+    including a non-finite gradient in a listed row (skipped and flagged)."""
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(5)
+    n_tab, rows, C = 12, 3072, 64
+    t = torch.tensor([7, 3071, 0, 7, 1500, 3, 1500, 2999], dtype=torch.int64)          # duplicates on purpose
+    p0 = torch.randn(n_tab, rows, C, generator=g) * 0.05
+    m0, v0 = torch.randn(n_tab, rows, C, generator=g) * 1e-3, torch.rand(n_tab, rows, C, generator=g) * 1e-6
+    grad = torch.zeros(n_tab, rows, C)
+    grad[:, t.unique()] = torch.randn(n_tab, t.unique().numel(), C, generator=g) * 1e-3
+    grad[3, 1500, 5] = float("inf")
+    hp = dict(lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=1e-6, step=3)
+    out = []
+    for by_rows in (False, True):
+        p, m, v, gr = (x.clone().to(dev) for x in (p0, m0, v0, grad))
+        hi = torch.zeros(p.shape, dtype=torch.float16, device=dev)
+        lo = torch.zeros(p.shape, dtype=torch.float16, device=dev)
+        ovf = torch.zeros(2, dtype=torch.int32, device=dev)
+        if by_rows:
+            T.adamw_rows(p, gr, m, v, t.to(dev), mode=0, hi=hi, lo=lo, zero_grad=True, overflow=ovf, **hp)
+            T.adamw_rows(p, gr, m, v, t.to(dev), mode=1, hi=hi, lo=lo, zero_grad=True, overflow=ovf, **hp)
+        else:
+            T.adamw(p.view(-1), gr.view(-1), m.view(-1), v.view(-1), hi=hi.view(-1), lo=lo.view(-1), zero_grad=True, overflow=ovf, **hp)
+        torch.cuda.synchronize()
+        out.append((p.cpu(), m.cpu(), v.cpu(), hi.cpu(), lo.cpu(), gr.cpu(), ovf.cpu()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert out[1][6].tolist() == [1, 1] and float(out[1][5].abs().max()) == 0.0
+    assert torch.equal(out[1][0][3, 1500, 5], p0[3, 1500, 5])                        # the overflowed element was left alone
+    assert not torch.equal(out[1][0][0, 10], p0[0, 10])                              # an unlisted row did move (decay, first-moment step)
+
+
 # ----------------------------------------------------------------------------- train-mode BatchNorm
 @pytest.mark.parametrize("rows,C,pool", [(154 * 256 * 32 // 16, 64, 0), (8192 * 3 + 64, 128, 64), (1600 * 4, 512, 64)])
 def test_bn_stats_and_apply(dev, rows, C, pool):
