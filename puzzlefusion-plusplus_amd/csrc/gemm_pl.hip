@@ -811,15 +811,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MT * NT >= 16 ? 1 : 2)) void gemm_pl
 // mostly works on one problem, walks the whole contraction in lock-step over all of its resident tiles and fetches each operand
 // column it needs once.  Every tile runs the full contraction in one accumulator chain: no K split, no slabs, no reduction launch;
 // the accumulation into the gradient buffer is the in-place residual of the 16-byte-store epilogue (one writer per element).
-struct DwJobP {
-  const void* ahi; const void* alo; const void* whi; const void* wlo;
-  float* C; float* csum;
-  int M, N, tiles_n, first_tile;
-  float alpha, csum_alpha;
-};
+// The argument carries one complete GemmP per problem (416 bytes each, 3.4 KB of kernel arguments): the workgroup indexes the table in
+// the kernarg segment.  (A GemmP assembled in the kernel lived in scratch — 416 bytes per thread, 34 MB of private-segment writes per
+// launch: counter WRITE_SIZE 52.8 MB for a 21 MB output in profiles/r05b_*.)
 struct DwGroupP {
-  DwJobP job[PFPP_DW_GROUP_MAX];
-  int n, K, k_valid;
+  GemmP p[PFPP_DW_GROUP_MAX];
+  int first_tile[PFPP_DW_GROUP_MAX];
+  int n;
 };
 
 template <int MT, int NT, int WM, int WN, int NS>
@@ -828,26 +826,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_pl_dwgroup_kernel(const 
   int j = 0;
 #pragma unroll
   for (int k = 1; k < PFPP_DW_GROUP_MAX; ++k)
-    if (k < g.n && t >= g.job[k].first_tile) j = k;
-  const DwJobP& q = g.job[j];
-  GemmP p;
-  p.A = nullptr; p.W = nullptr; p.C = q.C;
-  p.Whi = q.whi; p.Wlo = q.wlo; p.Ahi = q.ahi; p.Alo = q.alo;
-  p.Chi = nullptr; p.Clo = nullptr;
-  p.bias = nullptr; p.scale = nullptr; p.shift = nullptr; p.residual = q.C;       // C += alpha * acc, in place
-  p.M = q.M; p.N = q.N; p.K = g.K;
-  p.lda = q.M; p.ldw = q.N; p.ldc = q.N; p.ldr = q.N;
-  p.act = PFPP_ACT_NONE; p.pool = 0; p.zdiv = 1;
-  p.sA0 = p.sA1 = p.sW0 = p.sW1 = p.sC0 = p.sC1 = p.sV0 = p.sV1 = 0;
-  p.alpha = q.alpha;
-  p.tiles_n = q.tiles_n; p.tiles_m = 0; p.group_m = 0;
-  p.a_mul = nullptr; p.a_add = nullptr; p.stats = nullptr; p.stats_copies = 1; p.Cmin = nullptr;
-  p.split_ws = nullptr; p.split_cnt = nullptr; p.split_k = 1; p.k_chunk = 0;
-  p.g_idx = nullptr; p.g_xyz = nullptr; p.g_ctr = nullptr; p.g_N = p.g_S = p.g_ns = 0;
-  p.ws_bytes = 0; p.k_valid = g.k_valid; p.x1 = 0;
-  p.csum = q.csum; p.csum_ws = nullptr; p.csum_alpha = q.csum_alpha;
-  p.accum = 0; p.defer = nullptr; p.dbg = 0;
-  pl_body<MT, NT, WM, WN, NS, true, true, 0, false, false, true, true>(p, t - q.first_tile);
+    if (k < g.n && t >= g.first_tile[k]) j = k;
+  pl_body<MT, NT, WM, WN, NS, true, true, 0, false, false, true, true>(g.p[j], t - g.first_tile[j]);
 }
 
 template <int MT, int NT, int WM, int WN, int NS>
@@ -861,9 +841,9 @@ int launch_dwgroup(DwGroupP& g, const pfpp_dw_job* jobs, hipStream_t st) {
   }
   int tiles = 0;
   for (int j = 0; j < g.n; ++j) {
-    g.job[j].tiles_n = (int)((jobs[j].N + C::BN - 1) / C::BN);
-    g.job[j].first_tile = tiles;
-    tiles += (int)((jobs[j].M + C::BM - 1) / C::BM) * g.job[j].tiles_n;
+    g.p[j].tiles_n = (int)((jobs[j].N + C::BN - 1) / C::BN);
+    g.first_tile[j] = tiles;
+    tiles += (int)((jobs[j].M + C::BM - 1) / C::BM) * g.p[j].tiles_n;
   }
   snprintf(last_kernel, sizeof(last_kernel), "gemm_pl_dwgroup_kernel<%d, %d, %d, %d, %d>", MT, NT, WM, WN, NS);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NTHR), C::SMEM, st, g);
@@ -1127,8 +1107,6 @@ extern "C" int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64
   pl::DwGroupP g;
   memset(&g, 0, sizeof(g));
   g.n = n_jobs;
-  g.K = (int)((K + 31) / 32 * 32);
-  g.k_valid = (int)K;
   for (int j = 0; j < n_jobs; ++j) {
     const pfpp_dw_job& q = jobs[j];
     PFPP_REQUIRE(q.dy.hi && q.dy.lo && q.x.hi && q.x.lo && q.gw, "null pointer");
@@ -1136,12 +1114,14 @@ extern "C" int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64
     PFPP_REQUIRE(pfpp::aligned16(q.dy.hi) && pfpp::aligned16(q.dy.lo) && pfpp::aligned16(q.x.hi) && pfpp::aligned16(q.x.lo) &&
                  pfpp::aligned16(q.gw), "16-byte aligned operands");
     PFPP_REQUIRE(q.dy.scale > 0.0f && q.x.scale > 0.0f, "plane scales");
-    pl::DwJobP& r = g.job[j];
-    r.ahi = q.dy.hi; r.alo = q.dy.lo; r.whi = q.x.hi; r.wlo = q.x.lo;
-    r.C = q.gw; r.csum = q.gb;
-    r.M = (int)q.M; r.N = (int)q.N;
-    r.alpha = 1.0f / (q.dy.scale * q.x.scale);
-    r.csum_alpha = 1.0f / q.dy.scale;
+    GemmP& p = g.p[j];                       // (zeroed above: every optional pointer null, pool / act / stats off)
+    p.Ahi = q.dy.hi; p.Alo = q.dy.lo; p.Whi = q.x.hi; p.Wlo = q.x.lo;
+    p.C = q.gw; p.residual = q.gw;           // C += alpha * acc: the in-place residual of the wide epilogue
+    p.M = (int)q.M; p.N = (int)q.N; p.K = (int)((K + 31) / 32 * 32); p.k_valid = (int)K;
+    p.lda = q.M; p.ldw = q.N; p.ldc = q.N; p.ldr = q.N;
+    p.act = PFPP_ACT_NONE; p.zdiv = 1; p.split_k = 1; p.stats_copies = 1;
+    p.alpha = 1.0f / (q.dy.scale * q.x.scale);
+    p.csum = q.gb; p.csum_alpha = 1.0f / q.dy.scale;
   }
   hipStream_t st = pfpp::as_stream(stream);
   static const int env_v = getenv("PFPP_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_DW_GROUP_VARIANT")) : 0;

@@ -116,9 +116,10 @@ FwdLayout fwd_layout(int64_t M, int64_t C, int64_t H, int64_t inner) {
 
 int gemm_pl(const pfpp_planes& A, const pfpp_planes& W, float* Cout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc,
             bool a_km, bool w_km, const float* bias, const float* residual, bool accumulate, float* colsum, float* ws, int64_t ws_bytes,
-            int single_pass, pfpp_stream_t st, int splits = 0, pfpp_slab_job* defer = nullptr) {
+            int single_pass, pfpp_stream_t st, int splits = 0, pfpp_slab_job* defer = nullptr, int variant = 0) {
   pfpp_gemm_planes_args a = {};
   a.splits = splits;
+  a.variant = variant;
   a.defer = defer;
   a.a_hi = A.hi; a.a_lo = A.lo; a.w_hi = W.hi; a.w_lo = W.lo;
   a.C = Cout; a.bias = bias; a.residual = residual;
@@ -358,7 +359,11 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
   const bool batched = wd && can_batch(a, layer_lo, layer_hi);
   auto dx = [&](const pfpp_planes& dyp, const pfpp_planes& W, float* out, int64_t n_in, int64_t n_out, const pfpp_pw* Ft = nullptr) -> int {
     if (wd && Ft) return pfpp_gemm_wd(&dyp, n_out, Ft, nullptr, nullptr, 0, out, n_in, M, n_in, n_out, stream);
-    return gemm_pl(dyp, W, out, M, n_in, n_out, n_out, n_in, n_in, false, true, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream);
+    // lab: tile variant / K split of the one input gradient that stays on the tiled kernel (the GEGLU projection's, K = 2 inner)
+    static const int dxv = getenv("PFPP_TRAIN_DXFF1_VARIANT") ? atoi(getenv("PFPP_TRAIN_DXFF1_VARIANT")) : 0;
+    static const int dxs = getenv("PFPP_TRAIN_DXFF1_SPLITS") ? atoi(getenv("PFPP_TRAIN_DXFF1_SPLITS")) : 0;
+    return gemm_pl(dyp, W, out, M, n_in, n_out, n_out, n_in, n_in, false, true, nullptr, nullptr, false, nullptr, a->ws_main, a->ws_bytes, 0, stream,
+                   dxs, nullptr, dxv);
   };
 
   pfpp_planes dhp = a->dhp;

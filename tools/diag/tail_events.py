@@ -17,7 +17,7 @@ orig_fwd = eng.forward
 
 
 def all_done():
-    eng._flush_dw()
+
     em, es = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     em.record(torch.cuda.current_stream())
     if eng._side is not None:
