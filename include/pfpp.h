@@ -759,6 +759,33 @@ int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part, float* dx
 int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const float* dse, float* dtables,
                         int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, pfpp_stream_t stream);
 
+/* ---- backward of the AdaLN modulation linears (MyAdaLayerNorm.forward, attention.py:21-25: mods_j = Linear_j(silu(emb_j(t))), one per
+ * norm, 2 * num_layers of them) in two launches per 32 puzzles, plain fp32, fixed summation order (csrc/ada_bwd.hip):
+ *   g_w[j][n, k] += sum_b dmods[j][b, n] se[j][b, k]     g_b[j][n] += sum_b dmods[j][b, n]     dse[j][b, k] = sum_n dmods[j][b, n] w[j][n, k]
+ * dmods [n_ada, B, N2], se / dse [n_ada, B, C], w / g_w [n_ada, N2, C], g_b [n_ada, N2]; scratch: pfpp_ada_linear_bwd_scratch_floats()
+ * floats (16-byte aligned).  Replaces a column sum and two tiled gradient GEMMs (the contraction of the weight gradient is only B deep). */
+/* ---- backward of the token embedding in one launch (DenoiserTransformer._gen_cond / _add_ref_part_emb / forward,
+ * denoiser_transformer.py:117-135, 150-156, 173-185; csrc/embed_train.hip).  The forward leaves the EXTENDED feature rows
+ *   F[m] = [shape features (148) | pose features of the token's fragment (147) | [ref_part = 0] | [ref_part = 1] | 1 | 0 ...]  (320 columns)
+ * transposed as split-f16 planes ft_hi / ft_lo [320, Mp] (Mp = pfpp_token_features_t_cols(n, L): n L rounded up to 16, zero padded;
+ * arguments as pfpp_token_features_slots plus ref_part [slots]); pfpp_token_embed_bwd contracts dtok [n L, C] with them over the tokens:
+ *   g_shape_w [C, 148] += dtok^T sf   g_param_w [C, 147] += (sum_l dtok)^T pf   g_shape_b, g_param_b [C] += sum_m dtok[m]
+ *   g_ref_emb [2, C]: row r += the sum of dtok over the tokens of fragments with ref_part = r
+ * split-f16 products of (g_scale * dtok) (g_scale a power of two, divided out), fixed summation order, no atomics. */
+/* training forward: the operand of pfpp_embed_tokens_small built from the fp32 parameters of the step — [W_shape (148) | W_param (147) | 0]
+ * [C, 320] as fragment-blocked split-f16 planes fhi / flo (C * 320 halfs each, scale 1) and bias [C] = b_shape + b_param */
+int pfpp_embed_pack_weights(const float* w_shape, const float* w_param, const float* b_shape, const float* b_param, void* fhi, void* flo,
+                            float* bias, int64_t C, pfpp_stream_t stream);
+int64_t pfpp_token_features_t_cols(int64_t n, int64_t L);
+int pfpp_token_features_t(const float* latent, const float* xyz, const float* scale, const float* x, const int32_t* slot,
+                          const uint8_t* ref_part, void* ft_hi, void* ft_lo, int64_t n, int64_t L, pfpp_stream_t stream);
+int pfpp_token_embed_bwd(const float* dtok, const void* ft_hi, const void* ft_lo, float* g_shape_w, float* g_shape_b, float* g_param_w,
+                         float* g_param_b, float* g_ref_emb, int64_t n, int64_t L, int64_t C, float g_scale, pfpp_stream_t stream);
+
+int64_t pfpp_ada_linear_bwd_scratch_floats(int64_t n_ada, int64_t N2);
+int pfpp_ada_linear_bwd(const float* dmods, const float* se, const float* w, float* g_w, float* g_b, float* dse, float* scratch,
+                        int64_t n_ada, int64_t B, int64_t C, int64_t N2, pfpp_stream_t stream);
+
 /* ---- loss (Denoiser._loss, denoiser.py:118-126) ---------------------------------------------------------
  * loss = mean over the selected rows (valid, non-reference fragments) x 7 of (pred - target)^2;
  * dpred = grad_out * 2 (pred - target) / (7 * n_sel) on selected rows, 0 elsewhere.  loss [1].       */

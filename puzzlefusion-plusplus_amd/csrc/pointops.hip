@@ -138,7 +138,11 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // ---------------------------------------------------------------------------
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+#ifdef PFPP_FPS_FULL_BARRIER      // lab: the compiler's full barrier (waits for vmcnt as well) instead of the raw one
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 template <int PPT>
 struct FpsLane {
   static constexpr int NP = (PPT + 1) / 2;
@@ -149,22 +153,40 @@ struct FpsLane {
     for (int k = 0; k < 2 * NP; ++k) {
       const int i = t * PPT + k;
       const bool ok = k < PPT && i < N;
+#ifdef PFPP_FPS_VOLATILE_LOAD   // lab: dword reads of the points only (no ds_read_b96 / b64 merges)
+      x[k >> 1][k & 1] = ok ? *(const volatile float*)&xs[(size_t)stride * i] : 0.0f;
+      y[k >> 1][k & 1] = ok ? *(const volatile float*)&ys[(size_t)stride * i] : 0.0f;
+      z[k >> 1][k & 1] = ok ? *(const volatile float*)&zs[(size_t)stride * i] : 0.0f;
+#else
       x[k >> 1][k & 1] = ok ? xs[(size_t)stride * i] : 0.0f;
       y[k >> 1][k & 1] = ok ? ys[(size_t)stride * i] : 0.0f;
       z[k >> 1][k & 1] = ok ? zs[(size_t)stride * i] : 0.0f;
+#endif
       d[k >> 1][k & 1] = ok ? __builtin_huge_valf() : -1.0f;   // pads can never win
     }
   }
   // running minima against the new centroid -> this lane's maximum
   __device__ __forceinline__ float update(float cx, float cy, float cz) {
+#ifdef PFPP_FPS_NOPK      // lab: one point at a time (no packed fp32 instructions)
+#pragma unroll
+    for (int k = 0; k < 2 * NP; ++k) {
+      const float dx = __fsub_rn(x[k >> 1][k & 1], cx), dy = __fsub_rn(y[k >> 1][k & 1], cy), dz = __fsub_rn(z[k >> 1][k & 1], cz);
+      const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      d[k >> 1][k & 1] = fminf(d[k >> 1][k & 1], dd);
+    }
+#else
     const f2v c_x = {cx, cx}, c_y = {cy, cy}, c_z = {cz, cz};
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const f2v dx = x[q] - c_x, dy = y[q] - c_y, dz = z[q] - c_z;
-      const f2v dd = (dx * dx + dy * dy) + dz * dz;
+      f2v dd = (dx * dx + dy * dy) + dz * dz;
+#ifdef PFPP_FPS_PKNOP      // lab: an explicit wait state between the packed add and its first consumer
+      asm volatile("s_nop 1" : "+v"(dd));
+#endif
       d[q][0] = fminf(d[q][0], dd[0]);
       d[q][1] = fminf(d[q][1], dd[1]);
     }
+#endif
     float b = d[0][0];
 #pragma unroll
     for (int k = 1; k < 2 * NP; ++k) b = fmaxf(b, d[k >> 1][k & 1]);
@@ -180,9 +202,16 @@ struct FpsLane {
 };
 
 // LDS words of the exchange slots of G waves: [2][G] (maximum, index) pairs, 16-byte aligned
+#ifdef PFPP_FPS_CHECK
+#define PFPP_FPS_SLOT_WORDS(G) (8 * (G) + 4)
+#else
 #define PFPP_FPS_SLOT_WORDS(G) (4 * (G) + 4)
+#endif
 
 // argmax over the G waves' lanes -> selected index (every thread of the G waves calls it; one raw barrier when G > 1)
+#ifdef PFPP_FPS_CHECK      // lab (tools/diag/fps_race.py): every exchange entry carries (step, wave); readers count entries of another step / wave
+__device__ unsigned long long pfpp_fps_violations[4];      // [0] entries of an OLDER step, [1] of a NEWER step, [2] wrong wave tag, [3] reads checked
+#endif
 template <int G, int PPT>
 __device__ __forceinline__ int fps_argmax(const FpsLane<PPT>& pts, float lane_best, int t, int s, float* slot) {
   const int lane = t & 63, wave = t >> 6;
@@ -190,6 +219,27 @@ __device__ __forceinline__ int fps_argmax(const FpsLane<PPT>& pts, float lane_be
   const unsigned long long m = __ballot(lane_best == wmax);
   const int widx = __builtin_amdgcn_readlane(t * PPT + pts.first_equal(wmax), __builtin_ctzll(m));
   if (G == 1) return widx;
+#ifdef PFPP_FPS_CHECK
+  {
+    int4* cur4 = reinterpret_cast<int4*>(slot) + (s & 1) * G;
+    if (lane == 0) cur4[wave] = make_int4(__float_as_int(wmax), widx, s, wave);
+    lds_barrier();
+    float bm4 = -1.0f; int bidx4 = 0;
+#pragma unroll
+    for (int w = 0; w < G; ++w) {
+      const int4 c = cur4[w];
+      if (lane == 0) {
+        if (c.z < s) atomicAdd(&pfpp_fps_violations[0], 1ull);
+        if (c.z > s) atomicAdd(&pfpp_fps_violations[1], 1ull);
+        if (c.w != w) atomicAdd(&pfpp_fps_violations[2], 1ull);
+        if (wave == 0 && w == 0) atomicAdd(&pfpp_fps_violations[3], 1ull);
+      }
+      const float d2 = __int_as_float(c.x);
+      if (w == 0 || d2 > bm4) { bm4 = d2; bidx4 = c.y; }
+    }
+    return bidx4;
+  }
+#endif
   int2* cur = reinterpret_cast<int2*>(slot) + (s & 1) * G;
   if (lane == 0) cur[wave] = make_int2(__float_as_int(wmax), widx);
   lds_barrier();
@@ -236,13 +286,25 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
   float cx = s_pts[3 * sel + 0], cy = s_pts[3 * sel + 1], cz = s_pts[3 * sel + 2];
   int32_t* o_idx = idx_out + (size_t)f * S;
   float* o_xyz = new_xyz + (size_t)f * S * 3;
+#ifdef PFPP_FPS_LDS_OUT
+  // lab: the selections collect in LDS ([S] indices, [3 S] coordinates behind the exchange slots) and leave in one coalesced pass
+  int32_t* st_idx = reinterpret_cast<int32_t*>(s_slot + PFPP_FPS_SLOT_WORDS(NWAVES));
+  float* st_xyz = reinterpret_cast<float*>(st_idx + S);
+#endif
 
   for (int s = 0;;) {
     if (tid == 0) {
+#ifdef PFPP_FPS_LDS_OUT
+      st_idx[s] = sel;
+      st_xyz[3 * s + 0] = cx;
+      st_xyz[3 * s + 1] = cy;
+      st_xyz[3 * s + 2] = cz;
+#else
       o_idx[s] = sel;
       o_xyz[3 * s + 0] = cx;
       o_xyz[3 * s + 1] = cy;
       o_xyz[3 * s + 2] = cz;
+#endif
     }
     if (++s >= S) break;
     const float best = pts.update(cx, cy, cz);
@@ -251,6 +313,11 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(
     cy = s_pts[3 * sel + 1];
     cz = s_pts[3 * sel + 2];
   }
+#ifdef PFPP_FPS_LDS_OUT
+  __syncthreads();
+  for (int i = tid; i < S; i += NT) o_idx[i] = st_idx[i];
+  for (int i = tid; i < 3 * S; i += NT) o_xyz[i] = st_xyz[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -568,7 +635,10 @@ __global__ __launch_bounds__(64) void pose_compose_kernel(
 template <int NWAVES, int PPT, bool LDSPTS = true>
 int launch_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int N, int S,
                hipStream_t st, const int32_t* start = nullptr) {
-  const size_t smem = (size_t)((LDSPTS ? ((3 * N + 3) & ~3) : 0) + PFPP_FPS_SLOT_WORDS(NWAVES)) * sizeof(float);
+  size_t smem = (size_t)((LDSPTS ? ((3 * N + 3) & ~3) : 0) + PFPP_FPS_SLOT_WORDS(NWAVES)) * sizeof(float);
+#ifdef PFPP_FPS_LDS_OUT
+  smem += (size_t)4 * S * sizeof(float);
+#endif
   hipLaunchKernelGGL((fps_kernel<NWAVES, PPT, LDSPTS>), dim3((unsigned)F), dim3(NWAVES * 64), smem, st,
                      xyz, idx, new_xyz, N, S, start);
   return pfpp::check_launch("pfpp_fps");
@@ -619,6 +689,14 @@ static int fps_impl(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, i
   if (N <= 16384) return launch_fps<16, 16, false>(xyz, idx, new_xyz, F, n, s, st, start);
   return launch_fps<16, 32, false>(xyz, idx, new_xyz, F, n, s, st, start);
 }
+
+#ifdef PFPP_FPS_CHECK
+extern "C" int pfpp_lab_fps_violations(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(pfpp_fps_violations), 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pfpp_fps_violations), z, 32) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 extern "C" int pfpp_fps(const float* xyz, int32_t* idx, float* new_xyz, int64_t F, int64_t N,
                         int64_t S, pfpp_stream_t stream) {

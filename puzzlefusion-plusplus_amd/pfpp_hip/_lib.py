@@ -6,9 +6,11 @@ kernel wrapper raises, and every wrapper refuses non-CUDA tensors.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libpfpp_hip.so"
+# PFPP_LIB_PATH (lab): another build of the library (A/B of build flags on one box)
+LIB_PATH = Path(os.environ["PFPP_LIB_PATH"]).resolve() if os.environ.get("PFPP_LIB_PATH") else Path(__file__).resolve().parent / "libpfpp_hip.so"
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -277,6 +279,10 @@ SIGNATURES = {
     "pfpp_mean_pool_bwd": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_token_combine_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_embed_pack_weights": [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "pfpp_token_features_t": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "pfpp_token_embed_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_float, _p],
+    "pfpp_ada_linear_bwd": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
     "pfpp_mse_loss": [_p, _p, _p, _p, _p, _i64, _i64, _f32, _p],
     "pfpp_bn_stats": [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _p],
     "pfpp_bn_finalize": [_p, _i64, _i64, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p],
@@ -309,6 +315,8 @@ PLAIN = {
     "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
     "pfpp_get_attention_mode": ([], C.c_int),
+    "pfpp_ada_linear_bwd_scratch_floats": ([_i64, _i64], C.c_int64),
+    "pfpp_token_features_t_cols": ([_i64, _i64], C.c_int64),
     "pfpp_tlayers_fwd_bytes": ([_i64, _i64, _i64, _i64], C.c_int64),
     "pfpp_tlayers_frag_bytes": ([_i64, _i64], C.c_int64),
     "pfpp_tlayers_fwd_hout_offset": ([_i64, _i64, _i64, _i64], C.c_int64),

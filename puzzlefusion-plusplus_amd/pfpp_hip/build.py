@@ -37,6 +37,8 @@ SOURCES = {
     "embed_small.hip": ["-ffp-contract=off"],
     "gemm_grad.hip": ["-munsafe-fp-atomics"],
     "train_ops.hip": ["-munsafe-fp-atomics"],
+    "ada_bwd.hip": [],
+    "embed_train.hip": ["-ffp-contract=off"],
     "attention_bwd.hip": [],
     "bn_train.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
@@ -49,9 +51,16 @@ SOURCES = {
 # instructions unavailable every fp32 -> fp16 conversion is a plain v_cvt of the rounded fp32 value, so a split can only ever
 # see one hi.  tests/test_abi_and_host.py disassembles the library and checks that none is left.
 NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+# -packed-fp32-ops (target feature off): no v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 anywhere in the library.  Round 5: with them, fps_kernel
+# picked a wrong farthest point once in 10^2 .. 10^4 launches whenever a GEMM of another stream shared its CUs — the running minimum of a
+# lane's first point kept a stale value in lanes 52-61 of a wave (tools/diag/fps_race.py: 490 wrong chains in 48,000 launches
+# with the packed instructions in five different builds of the kernel, 0 in 48,000 + 8,000 in the two builds without them; exchange slots,
+# barrier flavour, LDS contents and point loads all ruled out).  The same instructions sat in the hi / lo splits of the GEMM operand
+# staging (x - hi feeding v_cvt_pk_f16_f32).  tests/test_abi_and_host.py checks the disassembly; PFPP_PACKED_FP32=1 (lab) leaves them on.
+NO_PK = [] if os.environ.get("PFPP_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # PFPP_CHAIN_PRIO=n (lab, build time): s_setprio n in the kernels of the training step's dependency chain (csrc/pfpp_common.h)
 CHAIN_PRIO = [f"-DPFPP_CHAIN_PRIO={int(os.environ['PFPP_CHAIN_PRIO'])}"] if os.environ.get("PFPP_CHAIN_PRIO") else []
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX, *CHAIN_PRIO]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX, *NO_PK, *CHAIN_PRIO]
 
 
 def _hipcc() -> str:
@@ -87,7 +96,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         # the x86 half of the compilation does not know the AMDGPU feature name NO_MIX switches off: its notice is noise
-        err = "\n".join(ln for ln in r.stderr.splitlines() if "'-fma-mix-insts' is not a recognized feature" not in ln and ln.strip())
+        err = "\n".join(ln for ln in r.stderr.splitlines() if ln.strip() and "'-fma-mix-insts' is not a recognized feature" not in ln
+                        and "'-packed-fp32-ops' is not a recognized feature" not in ln)
         if err:
             print(err, file=os.sys.stderr, flush=True)
         if r.returncode != 0:

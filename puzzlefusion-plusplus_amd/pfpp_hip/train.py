@@ -106,6 +106,8 @@ class FlatParams:
         self.lo = torch.zeros(total, dtype=torch.float16, device=dev)
         self.named = named
         self._odd_buf = None
+        self._embed_buf = None
+        self.embed_fused = False           # set by the engine: the forward takes the one-launch token embedding
         self._clean = False
         with torch.no_grad():
             for n in self.order:
@@ -230,6 +232,22 @@ class FlatParams:
             from . import planes as P_
 
             with torch.no_grad():
+                if self.embed_fused:
+                    # the one-launch token embedding takes [W_shape | W_param | 0] fragment-blocked, packed from the fp32 parameters in one
+                    # launch per optimizer step (csrc/embed_train.hip) instead of the two K-padded copies + splits
+                    if self._embed_buf is None:
+                        Cw = self.view(self.params, "shape_embedding.bias").numel()
+                        dev_ = self.params.device
+                        self._embed_buf = (torch.empty(Cw * 320, dtype=torch.float16, device=dev_), torch.empty(Cw * 320, dtype=torch.float16, device=dev_),
+                                           torch.empty(Cw, dtype=torch.float32, device=dev_))
+                    from . import train_ops as T_
+
+                    T_.embed_pack_weights(self.view(self.params, "shape_embedding.weight"), self.view(self.params, "param_fc.weight"),
+                                          self.view(self.params, "shape_embedding.bias"), self.view(self.params, "param_fc.bias"), *self._embed_buf)
+                    self._odd = {"embed.w": self._embed_buf[:2], "embed.b": self._embed_buf[2]}
+                    w = dict(self._views["w"])
+                    w.update(self._odd)
+                    return {"w": w, "g": self._views["g"]}
                 if self._odd_buf is None:
                     self._odd_buf = {}
                     for key, name in (("shape.w", "shape_embedding.weight"), ("param.w", "param_fc.weight")):
@@ -290,6 +308,13 @@ class DenoiserTrainEngine:
     def __init__(self, module: torch.nn.Module, *, dropout: Optional[float] = None, token_dropout: float = TOKEN_DROPOUT,
                  grad_scale: float = 4096.0):
         self.flat = FlatParams(module)
+        # token embedding: forward in one launch on the packed [W_shape | W_param] planes, backward in one launch on the transposed feature
+        # planes (csrc/embed_train.hip); 0 = features + two skinny GEMMs + combine / two weight-gradient GEMMs + sums (cross-checks)
+        shp = getattr(module, "shape_embedding", None), getattr(module, "param_fc", None)
+        odd_ok = all(m_ is not None for m_ in shp) and shp[0].weight.shape[1] == 148 and shp[1].weight.shape[1] == 147 and shp[0].weight.shape[0] % 32 == 0
+        self._embed_bwd_fused = odd_ok and os.environ.get("PFPP_TRAIN_EMBED_BWD_FUSED", "1") != "0"
+        self._embed_fwd_fused = odd_ok and os.environ.get("PFPP_TRAIN_EMBED_FWD_FUSED", "1") != "0"
+        self.flat.embed_fused = self._embed_fwd_fused
         self.module = module
         self.num_layers = module.num_layers
         self.num_heads = module.num_heads
@@ -304,6 +329,7 @@ class DenoiserTrainEngine:
         # observed two backward passes ago (read from pinned memory: no stall, no device read in the step, deterministic).
         self._dyn_gscale = os.environ.get("PFPP_TRAIN_DYN_GSCALE", "1") != "0"
         self._ada_per_layer = os.environ.get("PFPP_TRAIN_ADA_PER_LAYER", "1") != "0"
+        self._ada_bwd_fused = os.environ.get("PFPP_TRAIN_ADA_BWD_FUSED", "1") != "0"    # 0 = column sum + two tiled gradient GEMMs (cross-check)
         self._ada_layerwise = None
         self._amax_ring = None
         self._n_backward = 0
@@ -388,12 +414,20 @@ class DenoiserTrainEngine:
         M = Fv * L
         # the valid-fragment gather of the inputs happens inside the kernels (slot32): no gathered copies of latent / xyz / scale / x / ref
         slot32 = lay.slot32
-        sf, pf = ops.token_features(_f32c(latent).reshape(n_slots, L, -1), _f32c(xyz).reshape(n_slots, L, 3), _f32c(scale).reshape(n_slots),
-                                    _f32c(x).reshape(n_slots, 7), slot=slot32)
-        shape_emb = ops.linear(sf, w["shape.w"], w["shape.b"])
-        x_emb = ops.linear(pf, w["param.w"], w["param.b"])
+        raw = (_f32c(latent).reshape(n_slots, L, -1), _f32c(xyz).reshape(n_slots, L, 3), _f32c(scale).reshape(n_slots), _f32c(x).reshape(n_slots, 7))
         ref_u8 = _u8(ref_part).reshape(n_slots)           # padded flags; the kernels read ref_u8[slot[f]]
-        h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L, slot=slot32)
+        sf = pf = ft = None
+        if self._embed_bwd_fused:
+            # the backward's operand: the extended feature rows transposed as split-f16 planes (csrc/embed_train.hip)
+            ft = T.token_features_t(*raw, slot32, ref_u8, Fv, L)
+        if "embed.w" in w:
+            h = T.embed_tokens_packed(*raw, slot32, *w["embed.w"], w["embed.b"], w["ref_emb"], ref_u8, w["pe"], frag_p, Fv, L)
+        if "embed.w" not in w or ft is None:
+            sf, pf = ops.token_features(*raw, slot=slot32)
+        if "embed.w" not in w:
+            shape_emb = ops.linear(sf, w["shape.w"], w["shape.b"])
+            x_emb = ops.linear(pf, w["param.w"], w["param.b"])
+            h = ops.token_combine_list(shape_emb, x_emb, w["ref_emb"], ref_u8, w["pe"], frag_p, L, slot=slot32)
         fuse = self._fuse_drop                        # dropout sites ride in the LayerNorm kernels that follow them
         if p_tok > 0.0 and not fuse:
             T.dropout(h, p_tok, seed, 0, out=h)
@@ -406,7 +440,7 @@ class DenoiserTrainEngine:
         att_scale = 1.0 / math.sqrt(dh)
         s.update(dict(B=B, P=P, L=L, C=C, Fv=Fv, M=M, slot=slot, frag_b=frag_b, seq_len=seq_len, seq_off=seq_off,
                       max_len=max_len, sf=sf, pf=pf, ref_u8=ref_u8, slot32=slot32, t64=t64, se=se, mods=mods, seed=seed, p_tok=p_tok,
-                      p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse))
+                      p_lay=p_lay, att_scale=att_scale, n_slots=n_slots, fuse=fuse, ft=ft))
         layers = []
         if self._planes and self._use_cseq(fuse):
             h = self._forward_layers_c(h, w, s, mods, p_tok, p_lay, seed, Fv, L, H, att_scale)
@@ -847,7 +881,7 @@ class DenoiserTrainEngine:
         dout_c = None if fused_heads else dpred[s["slot"]].contiguous()         # [Fv, 7] (the fused heads kernel gathers by slot itself)
 
         # every small zero-initialised buffer of the backward out of ONE zeroed arena (one fill launch instead of eight)
-        ld_sf, ld_pf = s["sf"].shape[1], s["pf"].shape[1]
+        ld_sf, ld_pf = (s["sf"].shape[1], s["pf"].shape[1]) if s["sf"] is not None else (0, 0)
         h1 = C // 2                                     # hidden width of the heads' second linear
         sizes = [Fv * C, Fv * 4, Fv * 4, 4 * h1, 4 * h1, s["mods"].numel(), C * ld_sf, C * ld_pf]
         offs = [0]
@@ -877,15 +911,19 @@ class DenoiserTrainEngine:
         # ---- tokens (denoiser_transformer.py:117-135,150-156,173-185)
         if p_tok > 0.0 and not fuse:
             dtok = T.dropout(dh_, p_tok, seed, 0)
-        dws = carve(6, C, ld_sf)
-        T.grad_weight(dtok, s["sf"], dws, g_scale=G)
-        g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
-        T.colsum(dtok, g["shape.b"])
-        dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L, slot=s["slot32"])
-        dwp = carve(7, C, ld_pf)
-        T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
-        g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
-        T.colsum(dx_emb, g["param.b"])
+        if s.get("ft") is not None:
+            # all five gradients of the embedding from one contraction over the tokens (csrc/embed_train.hip)
+            T.token_embed_bwd(dtok, *s["ft"], g["shape.w"], g["shape.b"], g["param.w"], g["param.b"], g["ref_emb"], Fv, L, g_scale=G)
+        else:
+            dws = carve(6, C, ld_sf)
+            T.grad_weight(dtok, s["sf"], dws, g_scale=G)
+            g["shape.w"].add_(dws[:, : g["shape.w"].shape[1]])
+            T.colsum(dtok, g["shape.b"])
+            dx_emb = T.token_combine_bwd(dtok, s["ref_u8"], g["ref_emb"], L, slot=s["slot32"])
+            dwp = carve(7, C, ld_pf)
+            T.grad_weight(dx_emb, s["pf"], dwp, g_scale=G)
+            g["param.w"].add_(dwp[:, : g["param.w"].shape[1]])
+            T.colsum(dx_emb, g["param.b"])
 
         # ---- AdaLN modulation (attention.py:21-25): mods[j] = silu(table_j[t]) . W_j^T + b_j
         n_ada = 2 * self.num_layers
@@ -894,6 +932,9 @@ class DenoiserTrainEngine:
         if dse is not None:
             # the C sequencer queued the AdaLN linears' gradients and d/d(embedded timestep) per block on the side stream
             torch.cuda.current_stream().wait_stream(self._side)
+        elif self._ada_layerwise is None and self._ada_bwd_fused and C % 32 == 0:
+            # both gradients and d/d(embedded timestep) of the twelve linears in two fp32 launches (csrc/ada_bwd.hip)
+            dse = T.ada_linear_bwd(dmods, se, w["ada.w"].f32.view(n_ada, 2 * C, C), g["ada.w"].view(n_ada, 2 * C, C), g["ada.b"])
         else:
             if self._ada_layerwise is None:
                 T.colsum(dmods, g["ada.b"], rows=B, cols=2 * C, ld=2 * C, batch=n_ada, sx=B * 2 * C, so=2 * C)

@@ -362,6 +362,94 @@ def silu_embed_bwd(tables: torch.Tensor, t: torch.Tensor, dse: torch.Tensor, dta
     return dtables
 
 
+def embed_pack_weights(w_shape: torch.Tensor, w_param: torch.Tensor, b_shape: torch.Tensor, b_param: torch.Tensor, fhi: torch.Tensor,
+                       flo: torch.Tensor, bias: torch.Tensor) -> None:
+    """[W_shape | W_param | 0] [C, 320] -> fragment-blocked split-f16 planes fhi / flo (C * 320 halfs each), bias = b_shape + b_param:
+    the weight operand of the one-launch token embedding, from the step's fp32 parameters (csrc/embed_train.hip)"""
+    for t_, nm in ((w_shape, "w_shape"), (w_param, "w_param"), (b_shape, "b_shape"), (b_param, "b_param"), (bias, "bias")):
+        _chk(t_, _f32, nm)
+    _chk(fhi, torch.float16, "fhi"); _chk(flo, torch.float16, "flo")
+    Cc = b_shape.numel()
+    if tuple(w_shape.shape) != (Cc, 148) or tuple(w_param.shape) != (Cc, 147) or fhi.numel() != Cc * 320 or flo.numel() != Cc * 320 or bias.numel() != Cc:
+        raise ValueError("embed_pack_weights: shapes")
+    check(_lib.load().pfpp_embed_pack_weights(_ptr(w_shape), _ptr(w_param), _ptr(b_shape), _ptr(b_param), _ptr(fhi), _ptr(flo), _ptr(bias), Cc,
+                                              _stream()), "pfpp_embed_pack_weights")
+
+
+def embed_tokens_packed(latent: torch.Tensor, xyz: torch.Tensor, scale: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor],
+                        fhi: torch.Tensor, flo: torch.Tensor, bias: torch.Tensor, ref_emb: torch.Tensor, ref_u8: torch.Tensor, pe: torch.Tensor,
+                        frag_pos: torch.Tensor, n: int, L: int) -> torch.Tensor:
+    """the token embedding in one launch (pfpp_embed_tokens_small) on the planes of embed_pack_weights -> tok [n L, C]"""
+    from ._lib import PwC
+
+    for t_, nm in ((latent, "latent"), (xyz, "xyz"), (scale, "scale"), (x, "x"), (bias, "bias"), (ref_emb, "ref_emb"), (pe, "pe")):
+        _chk(t_, _f32, nm)
+    _chk(ref_u8, torch.uint8, "ref_part"); _chk(frag_pos, torch.int32, "frag_pos")
+    _chk(fhi, torch.float16, "fhi"); _chk(flo, torch.float16, "flo")
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+    Cc = bias.numel()
+    if fhi.numel() != Cc * 320 or flo.numel() != Cc * 320:
+        raise ValueError("embed_tokens_packed: the planes do not belong to a [C, 320] weight")
+    pw = PwC(0, 0, 0, 1.0, 320, fhi.data_ptr(), flo.data_ptr())
+    tok = torch.empty((n * L, Cc), dtype=torch.float32, device=latent.device)
+    check(_lib.load().pfpp_embed_tokens_small(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(slot), C.byref(pw), _ptr(bias), _ptr(ref_emb),
+                                              _ptr(ref_u8), _ptr(pe), _ptr(frag_pos), _ptr(tok), n, L, Cc, _stream()),
+          "pfpp_embed_tokens_small")
+    return tok
+
+
+def token_features_t(latent: torch.Tensor, xyz: torch.Tensor, scale: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor],
+                     ref_u8: torch.Tensor, n: int, L: int):
+    """-> (ft_hi, ft_lo) [320, Mp] fp16: the extended token features of the n listed fragments, transposed (csrc/embed_train.hip);
+    latent [slots, L, 64], xyz [slots, L, 3], scale [slots], x [slots, 7], ref_u8 [slots], slot [n] int32 or None"""
+    for t_, nm in ((latent, "latent"), (xyz, "xyz"), (scale, "scale"), (x, "x")):
+        _chk(t_, _f32, nm)
+    _chk(ref_u8, torch.uint8, "ref_part")
+    if slot is not None:
+        _chk(slot, torch.int32, "slot")
+    Mp = _lib.load().pfpp_token_features_t_cols(n, L)
+    ft = torch.empty((2, 320, Mp), dtype=torch.float16, device=latent.device)
+    check(_lib.load().pfpp_token_features_t(_ptr(latent), _ptr(xyz), _ptr(scale), _ptr(x), _ptr(slot),
+                                            _ptr(ref_u8), _ptr(ft[0]), _ptr(ft[1]), n, L, _stream()), "pfpp_token_features_t")
+    return ft[0], ft[1]
+
+
+def token_embed_bwd(dtok: torch.Tensor, ft_hi: torch.Tensor, ft_lo: torch.Tensor, g_shape_w: torch.Tensor, g_shape_b: torch.Tensor,
+                    g_param_w: torch.Tensor, g_param_b: torch.Tensor, g_ref_emb: torch.Tensor, n: int, L: int, *, g_scale: float = 1.0) -> None:
+    """gradients of shape_embedding / param_fc / ref_part_emb accumulated from dtok [n L, C] in one launch (csrc/embed_train.hip)"""
+    _chk(dtok, _f32, "dtok"); _chk(ft_hi, torch.float16, "ft_hi"); _chk(ft_lo, torch.float16, "ft_lo")
+    Cc = dtok.shape[1]
+    for t_, nm, shape in ((g_shape_w, "g_shape_w", (Cc, 148)), (g_shape_b, "g_shape_b", (Cc,)), (g_param_w, "g_param_w", (Cc, 147)),
+                          (g_param_b, "g_param_b", (Cc,)), (g_ref_emb, "g_ref_emb", (2, Cc))):
+        _chk(t_, _f32, nm)
+        if tuple(t_.shape) != shape:
+            raise ValueError(f"token_embed_bwd: {nm} has shape {tuple(t_.shape)}, expected {shape}")
+    if dtok.shape[0] != n * L or ft_hi.shape != ft_lo.shape or ft_hi.shape[0] != 320 or ft_hi.shape[1] != _lib.load().pfpp_token_features_t_cols(n, L):
+        raise ValueError("token_embed_bwd: dtok / feature planes do not belong to n fragments of L tokens")
+    check(_lib.load().pfpp_token_embed_bwd(_ptr(dtok), _ptr(ft_hi), _ptr(ft_lo), _ptr(g_shape_w), _ptr(g_shape_b), _ptr(g_param_w),
+                                           _ptr(g_param_b), _ptr(g_ref_emb), n, L, Cc, g_scale, _stream()), "pfpp_token_embed_bwd")
+
+
+def ada_linear_bwd(dmods: torch.Tensor, se: torch.Tensor, w: torch.Tensor, g_w: torch.Tensor, g_b: torch.Tensor,
+                   dse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """backward of the AdaLN modulation linears (csrc/ada_bwd.hip): g_w[j] += dmods[j]^T se[j], g_b[j] += column sums of dmods[j],
+    -> dse[j] = dmods[j] w[j];  dmods [n, B, N2], se [n, B, C], w / g_w [n, N2, C], g_b [n, N2]"""
+    for t_, nm in ((dmods, "dmods"), (se, "se"), (w, "w"), (g_w, "g_w"), (g_b, "g_b")):
+        _chk(t_, _f32, nm)
+    n, B, N2 = dmods.shape
+    Cc = se.shape[2]
+    if se.shape != (n, B, Cc) or w.shape != (n, N2, Cc) or g_w.shape != (n, N2, Cc) or g_b.numel() != n * N2:
+        raise ValueError("ada_linear_bwd: shapes")
+    if dse is None:
+        dse = torch.empty_like(se)
+    _chk(dse, _f32, "dse")
+    scratch = torch.empty(_lib.load().pfpp_ada_linear_bwd_scratch_floats(n, N2), dtype=torch.float32, device=dmods.device)
+    check(_lib.load().pfpp_ada_linear_bwd(_ptr(dmods), _ptr(se), _ptr(w), _ptr(g_w), _ptr(g_b), _ptr(dse), _ptr(scratch), n, B, Cc, N2,
+                                          _stream()), "pfpp_ada_linear_bwd")
+    return dse
+
+
 def mse_loss_masked(pred: torch.Tensor, target: torch.Tensor, valid: torch.Tensor, ref_u8: torch.Tensor, grad_out: float = 1.0,
                     amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """mse_loss over the rows with valid != 0 and ref == 0, the selection never materialised (pfpp_mse_loss_masked); amax [1]

@@ -400,6 +400,13 @@ def test_library_has_no_fused_mixed_precision_conversions(hip_lib, tmp_path):
             if "v_fma_mix" in line or "v_mad_mix" in line:
                 proc.kill()
                 raise AssertionError(f"mixed-precision fused conversion in the library: {line.strip()}")
+            if "v_pk_add_f32" in line or "v_pk_mul_f32" in line or "v_pk_fma_f32" in line:
+                # round 5: with the packed fp32 instructions fps_kernel selected a wrong farthest point once in
+                # 10^2 .. 10^4 launches next to a GEMM of another stream (stale running minimum in the upper lanes of a wave);
+                # pfpp_hip.build switches the target feature off for the whole library (tools/diag/fps_race.py; GPU side:
+                # test_sampling_chain_is_exact_next_to_a_gemm_on_another_stream)
+                proc.kill()
+                raise AssertionError(f"packed fp32 instruction in the library: {line.strip()}")
             n_inst += "v_mfma_" in line
             n_cvt += "v_cvt_f16_f32" in line or "v_cvt_pk_f16_f32" in line
         assert proc.wait() == 0

@@ -90,6 +90,41 @@ def test_ball_query_bit_exact_vs_oracle(dev, oracle_lib, N, S, r, ns):
     assert torch.equal(got.cpu().long(), want)
 
 
+@pytest.mark.parametrize("N,S,F", [(1024, 256, 16), (512, 256, 8)])
+def test_sampling_chain_is_exact_next_to_a_gemm_on_another_stream(dev, oracle_lib, N, S, F):
+    """Round 5: pfpp_fps + pfpp_ball_query of one input, launch after launch, while a second stream of the process runs a
+    GEMM on the same CUs — the situation of the training schedule (the next batch's encoder under the transformer).  With packed fp32
+    instructions in fps_kernel a wave's upper lanes occasionally kept a stale running minimum and the chain took a wrong point (1 launch
+    in 10^2 .. 10^4, tools/diag/fps_race.py); the library is built without them.  Every launch must reproduce the oracle's indices."""
+    from oracle import pfpp_oracle as O
+    from pfpp_hip import ops
+    from pfpp_hip.packing import PW
+
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(F, N, 3, generator=g) * 2 - 1
+    want = np.empty((F, S), np.int32)
+    O.clib().oracle_fps(O._np32(pts).ctypes.data, F, N, S, want.ctypes.data)
+    x0 = pts.to(dev)
+    big = torch.randn(4096, 512, generator=g).to(dev)
+    wbig = PW(torch.randn(512, 512, generator=g).to(dev))
+    side = torch.cuda.Stream(device=dev)
+    idx0, nx0 = ops.fps(x0, S)
+    ball0 = ops.ball_query(x0, nx0, 0.2, 32)
+    assert np.array_equal(idx0.cpu().numpy(), want)
+    bad = 0
+    for it in range(3000):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            o = ops.linear(big, wbig)
+        idx, nx = ops.fps(x0, S)
+        ball = ops.ball_query(x0, nx, 0.2, 32)
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+        bad += int(not (torch.equal(idx, idx0) and torch.equal(nx, nx0) and torch.equal(ball, ball0)))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
 def test_ball_query_empty_and_padding(dev):
     from pfpp_hip import ops
 

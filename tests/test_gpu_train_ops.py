@@ -187,6 +187,34 @@ def test_gemm_grad_batched_and_bad_args(dev):
                     accumulate=True)
 
 
+@pytest.mark.parametrize("n,B,C", [(12, 32, 512), (4, 7, 512), (2, 45, 128), (3, 1, 64)])
+def test_ada_linear_backward_vs_float64(dev, n, B, C):
+    """pfpp_ada_linear_bwd (csrc/ada_bwd.hip): weight / bias gradients (accumulated into what is there) and d(embedded timestep) of the
+    AdaLN modulation linears (attention.py:21-25) against float64; B below, at and above the 32 puzzles of one pass; twice = bit-identical"""
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(n * 1000 + B)
+    N2 = 2 * C
+    dmods = torch.randn(n, B, N2, generator=g) * 1e-3
+    se = torch.randn(n, B, C, generator=g)
+    w = torch.randn(n, N2, C, generator=g) / math.sqrt(C)
+    gw0 = torch.randn(n, N2, C, generator=g) * 1e-3
+    gb0 = torch.randn(n, N2, generator=g) * 1e-3
+    want_gw = gw0.double() + torch.einsum("jbn,jbk->jnk", dmods.double(), se.double())
+    want_gb = gb0.double() + dmods.double().sum(1)
+    want_dse = torch.einsum("jbn,jnk->jbk", dmods.double(), w.double())
+    outs = []
+    for _ in range(2):
+        gw, gb = gw0.to(dev), gb0.to(dev)
+        dse = T.ada_linear_bwd(dmods.to(dev), se.to(dev), w.to(dev), gw, gb)
+        outs.append((gw.clone(), gb.clone(), dse.clone()))
+    gw, gb, dse = outs[0]
+    assert rel_err(gw, want_gw) < 1e-6 and rel_err(gb, want_gb) < 1e-6 and rel_err(dse, want_dse) < 2e-6
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    with pytest.raises(Exception):
+        T.ada_linear_bwd(dmods.to(dev), se.to(dev), w.to(dev)[:, :, : C - 1].contiguous(), gw, gb)
+
+
 def test_colsum(dev):
     from pfpp_hip import train_ops as T
 
@@ -440,6 +468,53 @@ def test_pool_token_embed_backward(dev):
     dt = torch.zeros(n_tab, n_emb, C, device=dev)
     T.silu_embed_bwd(tables.detach().float().to(dev), t.to(dev), dse.float().to(dev), dt)
     assert rel_err(dt, tables.grad) < 1e-6
+
+
+@pytest.mark.parametrize("n,L,slots", [(154, 25, 640), (3, 25, 3), (37, 11, 60)])
+def test_token_embedding_backward_in_one_launch_vs_float64(dev, n, L, slots):
+    """pfpp_token_features_t + pfpp_token_embed_bwd (csrc/embed_train.hip): the transposed feature planes hold exactly the split of
+    pfpp_token_features' values (+ the ref_part indicators and the ones column); the five gradients of shape_embedding / param_fc /
+    ref_part_emb (denoiser_transformer.py:117-135, 150-156, 173-185) accumulate into what is there and equal float64 of
+    dtok^T . features; run twice = bit-identical (no atomics)"""
+    from pfpp_hip import ops, train_ops as T
+
+    g = torch.Generator().manual_seed(n * 7 + L)
+    C = 512
+    latent = torch.randn(slots, L, 64, generator=g)
+    xyz = torch.rand(slots, L, 3, generator=g) * 2 - 1
+    scale = torch.rand(slots, generator=g) + 0.5
+    x = torch.randn(slots, 7, generator=g)
+    ref = (torch.rand(slots, generator=g) < 0.3).to(torch.uint8)
+    slot = torch.randperm(slots, generator=g)[:n].sort().values.to(torch.int32)
+    dtok = torch.randn(n * L, C, generator=g) * 1e-4
+    d = lambda t_: t_.to(dev)
+    sf, pf = ops.token_features(d(latent), d(xyz), d(scale), d(x), slot=d(slot))
+    fh, fl = T.token_features_t(d(latent), d(xyz), d(scale), d(x), d(slot), d(ref), n, L)
+    M = n * L
+    assert fh.shape[1] % 16 == 0 and fh.shape[1] >= M
+    feat = (fh.float() + fl.float()).cpu()                                   # [320, Mp]
+    sfc, pfc = sf.cpu(), pf.cpu()
+    assert (feat[:148, :M].t() - sfc[:, :148]).abs().max() <= 2.0 ** -22 * sfc.abs().max() + 3e-8
+    assert (feat[148:295, :M].t() - pfc[:, :147].repeat_interleave(L, 0)).abs().max() <= 2.0 ** -22 * pfc.abs().max() + 3e-8
+    rl = ref[slot.long()].repeat_interleave(L)
+    assert torch.equal(feat[295, :M], (rl == 0).float()) and torch.equal(feat[296, :M], (rl == 1).float())
+    assert torch.equal(feat[297, :M], torch.ones(M)) and float(feat[298:].abs().max()) == 0.0 and float(feat[:, M:].abs().sum()) == 0.0
+    g0 = [torch.randn(*shape, generator=g) * 1e-3 for shape in ((C, 148), (C,), (C, 147), (C,), (2, C))]
+    D = dtok.double()
+    dx = D.view(n, L, C).sum(1)
+    rs = ref[slot.long()].bool()
+    want = [g0[0].double() + D.t() @ sfc[:, :148].double(), g0[1].double() + D.sum(0), g0[2].double() + dx.t() @ pfc[:, :147].double(),
+            g0[3].double() + D.sum(0), g0[4].double() + torch.stack([dx[~rs].sum(0), dx[rs].sum(0)])]
+    runs = []
+    for _ in range(2):
+        gs = [d(t_.clone()) for t_ in g0]
+        T.token_embed_bwd(d(dtok), fh, fl, *gs, n, L, g_scale=4096.0)
+        runs.append(gs)
+    for got, w_, base in zip(runs[0], want, g0):
+        assert float((got.double().cpu() - w_).abs().max() / ((w_ - base.double()).abs().max() + 1e-30)) < 2e-6
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    with pytest.raises(Exception):
+        T.token_embed_bwd(d(dtok), fh, fl, *runs[0], n + 1, L)
 
 
 def test_mse_loss(dev):

@@ -35,6 +35,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef ABL
 #define ABL 0      // ablations: 1 no MFMA, 2 no weight loads after the prologue, 4 no DMA after the prologue, 8 no barrier, 32 no epilogue stores
 #endif
+#ifndef KT_
+#define KT_ 1      // K-tile depth in units of 32: 2 = 64-deep stages (one barrier per 24 matrix instructions at MT 2, whole 128-byte lines of A per row)
+#endif
+#ifndef IL
+#define IL 0       // PF form: 1 = the next tile's LDS reads and the new tile's loads are spread between the matrix instructions
+#endif
+#ifndef PF
+#define PF 0       // 1 = the activation fragments of tile kt + 1 are read from LDS while tile kt is multiplied (register double buffer; DEPTH even)
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int N>
@@ -57,17 +66,20 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-template <int MT, int NT, int D>
+template <int MT, int NT, int D, int KT>
 __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict__ a_hi, const _Float16* __restrict__ a_lo,
                                                       const half8* __restrict__ w_fh, const half8* __restrict__ w_fl,
                                                       float* __restrict__ C, int M, int N, int K) {
-  constexpr int BM = 32 * MT, PLANE = BM * 64, STAGE = 2 * PLANE;      // bytes: BM rows of 32 halfs, two planes
-  constexpr int NPW = MT;                                              // 1 KB DMA pieces (16 rows of one plane) per wave and stage
-  constexpr int P = NPW + 4 * NT;                                      // vector-memory operations a wave issues per K-tile
+  constexpr int ROWB = 64 * KT;                                        // bytes of a row of one plane in a stage
+  constexpr int BM = 32 * MT, PLANE = BM * ROWB, STAGE = 2 * PLANE;    // bytes: BM rows of 32 KT halfs, two planes
+  constexpr int NPW = MT * KT;                                         // 1 KB DMA pieces (16 / KT rows of one plane) per wave and stage
+  constexpr int P = NPW + 4 * NT * KT;                                 // vector-memory operations a wave issues per K-tile
+  constexpr int CH = 4 * KT, RPP = 64 / CH;                            // 16-byte chunks per row, rows per piece
+  constexpr int NS = 2 * KT;                                           // 16-deep steps per K-tile
   extern __shared__ __align__(1024) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int KB = K / 16, nk = K / 32;
+  const int KB = K / 16, nk = K / (32 * KT);
   const int tiles_n = N / (128 * NT);
 #if XCD
   const int nwg = gridDim.x;
@@ -87,9 +99,10 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
   uint32_t dst[NPW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
-    const int q = wave + 4 * j;
-    const int pl = q / (2 * MT), row = (q % (2 * MT)) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int q = wave + 4 * j;                                        // piece: plane q / (PLANE / 1024), rows RPP (q % ..) ..
+    const int pl = q / (PLANE / 1024), row = (q % (PLANE / 1024)) * RPP + lane / CH;
+    const int sw_ = KT == 1 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+    const int chunk = (lane % CH) ^ sw_;
     const int grow = m0 + row < M ? m0 + row : M - 1;
     src[j] = reinterpret_cast<const char*>((pl ? a_lo : a_hi) + (size_t)grow * K + chunk * 8);
     dst[j] = lds0 + q * 1024;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
   auto dma = [&](int kt, int stage) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (size_t)kt * 64), (lds_void*)(uintptr_t)(dst[j] + stage * STAGE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (size_t)kt * ROWB), (lds_void*)(uintptr_t)(dst[j] + stage * STAGE), 16, 0, 0);
   };
   // ---- weight fragments of K-tile kt: units nb0 .. nb0 + NT - 1, steps 2 kt and 2 kt + 1, both planes
   const half8* wbh[NT];
@@ -107,17 +120,18 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
     wbh[j] = w_fh + (size_t)(nb0 + j) * KB * 64 + lane;
     wbl[j] = w_fl + (size_t)(nb0 + j) * KB * 64 + lane;
   }
-  half8 wh[D][NT][2], wl[D][NT][2];
+  half8 wh[D][NT][NS], wl[D][NT][NS];
   auto wload = [&](int kt, auto slot_c) {
     constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const half8* ph = wbh[j] + (size_t)kt * 128;
-      const half8* pl = wbl[j] + (size_t)kt * 128;
-      wh[slot][j][0] = gld<0>(ph);
-      wh[slot][j][1] = gld<1024>(ph);
-      wl[slot][j][0] = gld<0>(pl);
-      wl[slot][j][1] = gld<1024>(pl);
+      const half8* ph = wbh[j] + (size_t)kt * 64 * NS;
+      const half8* pl = wbl[j] + (size_t)kt * 64 * NS;
+      static_for<NS>([&](auto s_c) {
+        constexpr int s_ = decltype(s_c)::value;
+        wh[slot][j][s_] = gld<1024 * s_>(ph);
+        wl[slot][j][s_] = gld<1024 * s_>(pl);
+      });
     }
   };
   f32x16 acc[MT][NT];
@@ -128,18 +142,18 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.0f;
 
-  const int sw = (l31 >> 2) & 3;
-  uint32_t a_ad[2];
+  const int sw = KT == 1 ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+  uint32_t a_ad[NS];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) a_ad[s] = lds0 + l31 * 64 + (((2 * s + lhi) ^ sw) << 4);
+  for (int s = 0; s < NS; ++s) a_ad[s] = lds0 + l31 * ROWB + (((2 * s + lhi) ^ sw) << 4);
 
   auto rd_frags = [&](half8 (&fh)[MT], half8 (&fl)[MT], int stage, auto s_c) {
     constexpr int s = decltype(s_c)::value;
     const uint32_t ad = a_ad[s] + stage * STAGE;
     static_for<MT>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
-      fh[t] = lds_rd<2048 * t>(ad);
-      fl[t] = lds_rd<PLANE + 2048 * t>(ad);
+      fh[t] = lds_rd<32 * ROWB * t>(ad);
+      fl[t] = lds_rd<PLANE + 32 * ROWB * t>(ad);
     });
   };
   auto wait_frags = [&](half8 (&fh)[MT], half8 (&fl)[MT], auto left_c) {     // left = LDS reads issued behind these that may stay in flight
@@ -152,10 +166,11 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
   auto name_w = [&](auto slot_c) {      // the preceding vmcnt wait orders the uses of this slot's registers
     constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      half8 &r0 = wh[slot][j][0], &r1 = wh[slot][j][1], &r2 = wl[slot][j][0], &r3 = wl[slot][j][1];
-      asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-    }
+    for (int j = 0; j < NT; ++j)
+      static_for<NS>([&](auto s_c) {
+        half8 &r0 = wh[slot][j][decltype(s_c)::value], &r2 = wl[slot][j][decltype(s_c)::value];
+        asm volatile("" : "+v"(r0), "+v"(r2));
+      });
   };
   auto mma = [&](const half8 (&fh)[MT], const half8 (&fl)[MT], auto slot_c, auto s_c) {
     constexpr int slot = decltype(slot_c)::value, s = decltype(s_c)::value;
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
   // K-tile kt (stage = slot = U = kt % D): wait for its own loads (the tile after it may be in flight behind them), barrier (every
   // wave's DMA pieces of tile kt have landed AND every wave is through tile kt - 1, whose stage the next DMA overwrites), request
   // tile kt + D - 1, multiply.
-  half8 f0h[MT], f0l[MT], f1h[MT], f1l[MT];
+  half8 ffh[NS][MT], ffl[NS][MT];
   auto ktile = [&](int kt, auto u_c) {
     constexpr int U = decltype(u_c)::value;
     constexpr int UN = (U + D - 1) % D;
@@ -205,16 +220,16 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
       if (!(ABL & 2)) wload(kt + D - 1, std::integral_constant<int, UN>{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    rd_frags(f0h, f0l, U, I0{});
-    rd_frags(f1h, f1l, U, I1{});
-    wait_frags(f0h, f0l, std::integral_constant<int, 2 * MT>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f0h, f0l, u_c, I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    wait_frags(f1h, f1l, I0{});
-    mma(f1h, f1l, u_c, I1{});
-    __builtin_amdgcn_sched_barrier(0);
+    static_for<NS>([&](auto s_c) { rd_frags(ffh[decltype(s_c)::value], ffl[decltype(s_c)::value], U, s_c); });
+    static_for<NS>([&](auto s_c) {
+      constexpr int s_ = decltype(s_c)::value;
+      wait_frags(ffh[s_], ffl[s_], std::integral_constant<int, 2 * MT * (NS - 1 - s_)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ffh[s_], ffl[s_], u_c, s_c);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
+  if constexpr (PF == 0) {
   // prologue: tiles 0 .. D - 2 requested
   static_for<D - 1>([&](auto u_c) {
     constexpr int U = decltype(u_c)::value;
@@ -223,6 +238,67 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
   int kt = 0;
   for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile(kt + decltype(u_c)::value, u_c); });
   static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile(kt + decltype(u_c)::value, u_c); });
+  } else {
+  // ---- software-pipelined form: the fragments of tile kt + 1 are requested from LDS in front of tile kt's matrix instructions
+  static_assert(PF == 0 || (D % 2 == 0 && KT == 1), "register double buffer: even depth, 32-deep tiles");
+  half8 gh[2][2][MT], gl[2][2][MT];                 // [parity of the tile][16-deep step][row block]
+  auto wait_all = [&](auto par_c) {
+    constexpr int par = decltype(par_c)::value;
+    static_for<2>([&](auto s_c) { wait_frags(gh[par][decltype(s_c)::value], gl[par][decltype(s_c)::value], I0{}); });
+  };
+  auto ktile_pf = [&](int kt, auto u_c) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr int UN = (U + D - 1) % D, U1 = (U + 1) % D;
+    constexpr int par = U & 1, npar = par ^ 1;
+    // tile kt + 1 has to have landed: the loads of tiles kt + 2 .. kt + D - 2 (those that exist) may stay in flight
+    const int behind = max(0, min(D - 3, nk - 2 - kt));
+    if (!(ABL & 8)) {
+      if (D >= 4 && behind >= D - 3) wait_vmcnt<(D >= 4 ? D - 3 : 0) * P>();
+      else if (D >= 6 && behind == D - 4) wait_vmcnt<(D >= 6 ? D - 4 : 0) * P>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    name_w(u_c);
+    if (IL) {
+      // 6 matrix instructions (s = 0) right behind the barrier, the memory instructions in their shadow, then the other 6
+      __builtin_amdgcn_sched_barrier(0);
+      mma(gh[par][0], gl[par][0], u_c, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + D - 1 < nk) {
+      if (!(ABL & 4)) dma(kt + D - 1, UN);
+      if (!(ABL & 2)) wload(kt + D - 1, std::integral_constant<int, UN>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 64) && kt + 1 < nk) {
+      rd_frags(gh[npar][0], gl[npar][0], U1, I0{});
+      rd_frags(gh[npar][1], gl[npar][1], U1, I1{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!IL) mma(gh[par][0], gl[par][0], u_c, I0{});
+    mma(gh[par][1], gl[par][1], u_c, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_all(std::integral_constant<int, npar>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_for<D - 1>([&](auto u_c) {
+    constexpr int U = decltype(u_c)::value;
+    if (U < nk) { dma(U, U); wload(U, u_c); }
+  });
+  {
+    const int behind = min(D - 2, nk - 1);
+    if (behind >= D - 2) wait_vmcnt<(D - 2) * P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    rd_frags(gh[0][0], gl[0][0], 0, I0{});
+    rd_frags(gh[0][1], gl[0][1], 0, I1{});
+    if (ABL & 64) { rd_frags(gh[1][0], gl[1][0], 0, I0{}); rd_frags(gh[1][1], gl[1][1], 0, I1{}); wait_all(I1{}); }
+    wait_all(I0{});
+  }
+  int kt = 0;
+  for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile_pf(kt + decltype(u_c)::value, u_c); });
+  static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile_pf(kt + decltype(u_c)::value, u_c); });
+  }
 
   // plain epilogue (probe): lane = column, register e = row (e & 3) + 8 (e >> 2) + 4 lhi
 #pragma unroll
@@ -240,8 +316,8 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 3850, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 512;
-  constexpr int MT = MT_, NT = NT_, D = DEPTH;
-  if (N % (128 * NT) || K % 32) { printf("N %% %d or K %% 32\n", 128 * NT); return 1; }
+  constexpr int MT = MT_, NT = NT_, D = DEPTH, KT = KT_;
+  if (N % (128 * NT) || K % (32 * KT)) { printf("N %% %d or K %% 32\n", 128 * NT); return 1; }
   const int NB = N / 32, KB = K / 16;
   std::vector<float> A((size_t)M * K), W((size_t)N * K);
   unsigned s = 777;
@@ -262,8 +338,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d_ah, ahi.data(), ahi.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d_al, alo.data(), alo.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_wh, whi.data(), whi.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d_wl, wlo.data(), wlo.size() * 2, hipMemcpyHostToDevice));
   const int tiles = ((M + 32 * MT - 1) / (32 * MT)) * (N / (128 * NT));
-  const size_t smem = (size_t)D * 2 * 32 * MT * 64;
-  auto kern = wdirect_kernel<MT, NT, D>;
+  const size_t smem = (size_t)D * 2 * 32 * MT * 64 * KT;
+  auto kern = wdirect_kernel<MT, NT, D, KT>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, 0, d_ah, d_al, (const half8*)d_wh, (const half8*)d_wl, d_c, M, N, K); };
@@ -283,7 +359,7 @@ int main(int argc, char** argv) {
     worst = fmax(worst, fabs(ref - Cc[(size_t)m * N + n])); scale = fmax(scale, fabs(ref));
   }
   const double us = ms / it * 1e3;
-  printf("MT %d NT %d D %d XCD %d ABL %d | M %d N %d K %d: %.1f us per launch, %.1f TFLOP/s (fp32-grade), %d workgroups, LDS %zu B, max |err| %.2e of %.2e\n",
-         MT, NT, D, XCD, ABL, M, N, K, us, 2.0 * M * N * K / us * 1e-6, tiles, smem, worst, scale);
+  printf("MT %d NT %d D %d KT %d XCD %d ABL %d PF %d IL %d | M %d N %d K %d: %.1f us per launch, %.1f TFLOP/s (fp32-grade), %d workgroups, LDS %zu B, max |err| %.2e of %.2e\n",
+         MT, NT, D, KT, XCD, ABL, PF, IL, M, N, K, us, 2.0 * M * N * K / us * 1e-6, tiles, smem, worst, scale);
   return 0;
 }
