@@ -10,9 +10,9 @@
 //   ada_dw_kernel   workgroup = (norm j, 32 rows n of W_j): the 32 x 32 block of dmods_j transposed into LDS ([n][b], also written out
 //                   as dmT for the second kernel); a thread keeps se_j[0..31][4 columns] in registers and walks 16 rows: one 16-byte
 //                   load / store of g_W per 128 FMAs, the dmods values as LDS broadcasts.  Column sums (g_b) from the same block.
-//   ada_dse_kernel  workgroup = (norm j, 32 columns k): wave w walks a quarter of the rows n, 8 rows per step (lane = row x 16-byte
+//   ada_dse_kernel  workgroup = (norm j, 32 columns k): wave w of eight walks an eighth of the rows n, 8 rows per step (lane = row x 16-byte
 //                   column piece); every lane accumulates its row's contribution to all 32 x 4 outputs, then a reduce-scatter over the
-//                   8 rows of a step (3 exchange rounds, each halving what a lane holds), then the four waves through LDS.  Fixed
+//                   8 rows of a step (3 exchange rounds, each halving what a lane holds), then the eight waves through LDS.  Fixed
 //                   summation tree: deterministic, so data-parallel replicas stay bit-equal.
 // Arithmetic is plain fp32 (b ascending for g_W / g_b); the tiled kernels' split-f16 products differ from it below 1e-6 relative.
 #include "pfpp_common.h"
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ada_dw_kernel(const AdaP p) {
       if (b < nb) s4[b] = *reinterpret_cast<const f32x4*>(p.se + ((int64_t)j * p.B + p.b0 + b) * p.C + kq * 4);
     }
     float* g = p.gw + ((int64_t)j * p.N2 + n0 + half * (RB / 2)) * p.C + kq * 4;
-#pragma unroll 4
+#pragma unroll 8
     for (int r = 0; r < RB / 2; ++r) {
       const float* d = dm + (half * (RB / 2) + r) * DLD;
       f32x4 acc = *reinterpret_cast<const f32x4*>(g + (int64_t)r * p.C);
@@ -90,17 +90,18 @@ __device__ __forceinline__ f32x4 xchg(const f32x4 v, const int mask) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void ada_dse_kernel(const AdaP p) {
-  __shared__ __align__(16) float red[4][BC][32];
+constexpr int DW = 8;             // waves of ada_dse_kernel (each an eighth of the rows n: 16 steps of 8 rows, enough of them per SIMD to hide the loads)
+__global__ __launch_bounds__(64 * DW) void ada_dse_kernel(const AdaP p) {
+  __shared__ __align__(16) float red[DW][BC][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = blockIdx.y, k0 = blockIdx.x * 32;
   const int kq = lane & 7, rs = lane >> 3;
-  const int rows_w = p.N2 / 4;
+  const int rows_w = p.N2 / DW;
   const float* wrow = p.w + ((int64_t)j * p.N2 + wave * rows_w + rs) * p.C + k0 + kq * 4;
   const float* drow = p.dmt + ((int64_t)j * p.N2 + wave * rows_w + rs) * BC;
   f32x4 acc[BC];
 #pragma unroll
   for (int b = 0; b < BC; ++b) acc[b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
+#pragma unroll 4
   for (int it = 0; it < rows_w / 8; ++it) {
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (int64_t)it * 8 * p.C);
 #pragma unroll
@@ -141,10 +142,10 @@ __global__ __launch_bounds__(256) void ada_dse_kernel(const AdaP p) {
   for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&red[wave][bb + i][kq * 4]) = a4[i];
   __syncthreads();
   const int b = tid >> 3, c4 = (tid & 7) * 4;
-  if (p.b0 + b < p.B) {
+  if (tid < 256 && p.b0 + b < p.B) {
     f32x4 s = *reinterpret_cast<const f32x4*>(&red[0][b][c4]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) s += *reinterpret_cast<const f32x4*>(&red[w][b][c4]);
+    for (int w = 1; w < DW; ++w) s += *reinterpret_cast<const f32x4*>(&red[w][b][c4]);
     *reinterpret_cast<f32x4*>(p.dse + ((int64_t)j * p.B + p.b0 + b) * p.C + k0 + c4) = s;
   }
 }
@@ -157,7 +158,7 @@ extern "C" int pfpp_ada_linear_bwd(const float* dmods, const float* se, const fl
                                    int64_t n_ada, int64_t B, int64_t C, int64_t N2, pfpp_stream_t stream) {
   PFPP_REQUIRE(dmods && se && w && g_w && g_b && dse && scratch, "null pointer");
   PFPP_REQUIRE(n_ada >= 1 && n_ada <= 65535 && B >= 1 && B <= 0x7fffffff, "sizes");
-  PFPP_SUPPORTED(C >= 32 && C % 32 == 0 && N2 >= 32 && N2 % 32 == 0 && C <= 0x7fffffff && N2 <= 0x7fffffff, "C % 32 != 0 or N2 % 32 != 0");
+  PFPP_SUPPORTED(C >= 32 && C % 32 == 0 && N2 >= 64 && N2 % 64 == 0 && C <= 0x7fffffff && N2 <= 0x7fffffff, "C % 32 != 0 or N2 % 64 != 0");
   PFPP_REQUIRE(pfpp::aligned16(dmods) && pfpp::aligned16(se) && pfpp::aligned16(w) && pfpp::aligned16(g_w) && pfpp::aligned16(dse) &&
                pfpp::aligned16(scratch), "16-byte aligned operands");
   AdaP p;
@@ -167,7 +168,7 @@ extern "C" int pfpp_ada_linear_bwd(const float* dmods, const float* se, const fl
   for (int64_t b0 = 0; b0 < B; b0 += BC) {      // more than 32 puzzles per step: one pass per 32 (the scratch block is reused in stream order)
     p.b0 = (int)b0;
     hipLaunchKernelGGL(ada_dw_kernel, dim3((unsigned)(N2 / RB), (unsigned)n_ada), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(ada_dse_kernel, dim3((unsigned)(C / 32), (unsigned)n_ada), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(ada_dse_kernel, dim3((unsigned)(C / 32), (unsigned)n_ada), dim3(64 * DW), 0, st, p);
   }
   return pfpp::check_launch(__func__);
 }

@@ -10,7 +10,7 @@
 // (the pose features repeat over a fragment's tokens, which turns the sum over l into part of the contraction).  The forward leaves F
 // TRANSPOSED as split-f16 planes FT[k][m] (embed_feat_t_kernel; m padded to a multiple of 16 with zeros), so a feature fragment of
 // v_mfma_f32_32x32x16_f16 is one 16-byte load; the dtok fragment is 8 dword loads of 128-byte row pieces, split in registers after the
-// power-of-two gradient scale.  A workgroup owns a 32 (features) x 32 (channels) tile of G^T over ALL tokens: its four waves take the
+// power-of-two gradient scale.  A workgroup owns a 32 (features) x 32 (channels) tile of G^T over ALL tokens: its eight waves take the
 // 16-token steps round-robin (8 steps of loads in flight each), meet in LDS, and add into the gradient buffers — no atomics, no partial
 // slabs, a fixed summation tree.  160 workgroups (320 / 32 x C / 32).
 // Replaces: two tiled weight-gradient GEMMs (K = 3,850 / 154) + two adds of their padded results + two column sums + the per-fragment
@@ -102,11 +102,12 @@ struct EbP {
 };
 
 constexpr int PD = 8;                        // 16-token steps a wave keeps in flight
+constexpr int EW = 8;                        // waves per workgroup of embed_bwd_kernel (the token steps round-robin over them)
 
 struct Step { half8 ah, al; float b[8]; };
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const EbP p) {
-  __shared__ __align__(16) float red[4][32][33];
+__global__ __launch_bounds__(64 * EW) void embed_bwd_kernel(const EbP p) {
+  __shared__ __align__(16) float red[EW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int nsteps = p.Mp / 16;
@@ -140,28 +141,33 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EbP p) {
   };
   Step ring[PD];
 #pragma unroll
-  for (int i = 0; i < PD; ++i) load(wave + 4 * i, ring[i]);
-  for (int base = 0; wave + 4 * base < nsteps; base += PD) {
+  for (int i = 0; i < PD; ++i) load(wave + EW * i, ring[i]);
+  for (int base = 0; wave + EW * base < nsteps; base += PD) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
       compute(ring[i]);
-      load(wave + 4 * (base + PD + i), ring[i]);
+      load(wave + EW * (base + PD + i), ring[i]);
     }
   }
   // acc[e]: feature row (e & 3) + 8 (e >> 2) + 4 lhi of the tile, channel l31
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * lhi][l31] = acc[e];
   __syncthreads();
-  const int n = n0 + (tid >> 3);
+  if (tid < 256) {
+    const int n = n0 + (tid >> 3);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kk = (tid & 7) * 4 + i, k = k0 + kk;
-    const float v = (((red[0][kk][tid >> 3] + red[1][kk][tid >> 3]) + red[2][kk][tid >> 3]) + red[3][kk][tid >> 3]) * p.inv_scale;
-    if (k < FS) p.g_ws[(int64_t)n * FS + k] += v;
-    else if (k < K_REF0) p.g_wp[(int64_t)n * FP + (k - FS)] += v;
-    else if (k == K_REF0) p.g_ref[n] += v;
-    else if (k == K_REF1) p.g_ref[p.C + n] += v;
-    else if (k == K_ONE) { p.g_bs[n] += v; p.g_bp[n] += v; }
+    for (int i = 0; i < 4; ++i) {
+      const int kk = (tid & 7) * 4 + i, k = k0 + kk;
+      float v = red[0][kk][tid >> 3];
+#pragma unroll
+      for (int w = 1; w < EW; ++w) v += red[w][kk][tid >> 3];
+      v *= p.inv_scale;
+      if (k < FS) p.g_ws[(int64_t)n * FS + k] += v;
+      else if (k < K_REF0) p.g_wp[(int64_t)n * FP + (k - FS)] += v;
+      else if (k == K_REF0) p.g_ref[n] += v;
+      else if (k == K_REF1) p.g_ref[p.C + n] += v;
+      else if (k == K_ONE) { p.g_bs[n] += v; p.g_bp[n] += v; }
+    }
   }
 }
 
@@ -204,6 +210,6 @@ extern "C" int pfpp_token_embed_bwd(const float* dtok, const void* ft_hi, const 
   p.g_ws = g_shape_w; p.g_wp = g_param_w; p.g_bs = g_shape_b; p.g_bp = g_param_b; p.g_ref = g_ref_emb;
   p.g_scale = g_scale; p.inv_scale = 1.0f / g_scale;
   p.M = (int)(n * L); p.Mp = (int)pfpp_token_features_t_cols(n, L); p.C = (int)C;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(C / 32), KE / 32), dim3(256), 0, pfpp::as_stream(stream), p);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(C / 32), KE / 32), dim3(64 * EW), 0, pfpp::as_stream(stream), p);
   return pfpp::check_launch(__func__);
 }

@@ -246,6 +246,49 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
     constexpr int par = decltype(par_c)::value;
     static_for<2>([&](auto s_c) { wait_frags(gh[par][decltype(s_c)::value], gl[par][decltype(s_c)::value], I0{}); });
   };
+  // IL == 2 (MT 2, NT 1): one memory instruction in the shadow of every matrix instruction — a wave stalled in the issue of a vector-memory
+  // instruction (texture queue full) issues no matrix instruction either; used for the tiles that still request a tile and read a next one
+  auto ktile_il2 = [&](int kt, auto u_c) {
+    constexpr int U = decltype(u_c)::value;
+    constexpr int UN = (U + D - 1) % D, U1 = (U + 1) % D;
+    constexpr int par = U & 1, npar = par ^ 1;
+    wait_vmcnt<(D >= 4 ? D - 3 : 0) * P>();
+    __builtin_amdgcn_s_barrier();
+    name_w(u_c);
+    const uint32_t ad0 = a_ad[0] + U1 * STAGE, ad1 = a_ad[1] + U1 * STAGE;
+    const half8* ph = wbh[0] + (size_t)(kt + D - 1) * 64 * NS;
+    const half8* pl = wbl[0] + (size_t)(kt + D - 1) * 64 * NS;
+    auto mem = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      if constexpr (i == 0) gh[npar][0][0] = lds_rd<0>(ad0);
+      else if constexpr (i == 1) gl[npar][0][0] = lds_rd<PLANE>(ad0);
+      else if constexpr (i == 2) gh[npar][0][1] = lds_rd<32 * ROWB>(ad0);
+      else if constexpr (i == 3) gl[npar][0][1] = lds_rd<PLANE + 32 * ROWB>(ad0);
+      else if constexpr (i == 4) gh[npar][1][0] = lds_rd<0>(ad1);
+      else if constexpr (i == 5) gl[npar][1][0] = lds_rd<PLANE>(ad1);
+      else if constexpr (i == 6) gh[npar][1][1] = lds_rd<32 * ROWB>(ad1);
+      else if constexpr (i == 7) gl[npar][1][1] = lds_rd<PLANE + 32 * ROWB>(ad1);
+      else if constexpr (i == 8) __builtin_amdgcn_global_load_lds((gbl_void*)(src[0] + (size_t)(kt + D - 1) * ROWB), (lds_void*)(uintptr_t)(dst[0] + UN * STAGE), 16, 0, 0);
+      else if constexpr (i == 9) __builtin_amdgcn_global_load_lds((gbl_void*)(src[1] + (size_t)(kt + D - 1) * ROWB), (lds_void*)(uintptr_t)(dst[1] + UN * STAGE), 16, 0, 0);
+      else if constexpr (i == 10) wh[UN][0][0] = gld<0>(ph);
+      else if constexpr (i == 11) wh[UN][0][1] = gld<1024>(ph);
+      else if constexpr (i == 12) wl[UN][0][0] = gld<0>(pl);
+      else if constexpr (i == 13) wl[UN][0][1] = gld<1024>(pl);
+    };
+    static_for<12>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value, s_ = i / 6, r = i % 6, term = r / 2, t = r % 2;
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? gl[par][s_][t] : gh[par][s_][t], term == 1 ? wl[U][0][s_] : wh[U][0][s_], acc[t][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mem(i_c);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    mem(std::integral_constant<int, 12>{});
+    mem(std::integral_constant<int, 13>{});
+    __builtin_amdgcn_sched_barrier(0);
+    wait_all(std::integral_constant<int, npar>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto ktile_pf = [&](int kt, auto u_c) {
     constexpr int U = decltype(u_c)::value;
     constexpr int UN = (U + D - 1) % D, U1 = (U + 1) % D;
@@ -259,7 +302,7 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
       __builtin_amdgcn_s_barrier();
     }
     name_w(u_c);
-    if (IL) {
+    if (IL == 1) {
       // 6 matrix instructions (s = 0) right behind the barrier, the memory instructions in their shadow, then the other 6
       __builtin_amdgcn_sched_barrier(0);
       mma(gh[par][0], gl[par][0], u_c, I0{});
@@ -275,7 +318,7 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
       rd_frags(gh[npar][1], gl[npar][1], U1, I1{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!IL) mma(gh[par][0], gl[par][0], u_c, I0{});
+    if (IL != 1) mma(gh[par][0], gl[par][0], u_c, I0{});
     mma(gh[par][1], gl[par][1], u_c, I1{});
     __builtin_amdgcn_sched_barrier(0);
     wait_all(std::integral_constant<int, npar>{});
@@ -296,8 +339,13 @@ __global__ __launch_bounds__(256) void wdirect_kernel(const _Float16* __restrict
     wait_all(I0{});
   }
   int kt = 0;
+  if constexpr (IL == 2 && MT == 2 && NT == 1 && KT == 1 && ABL == 0) {
+    for (; kt + 2 * D - 1 <= nk; kt += D) static_for<D>([&](auto u_c) { ktile_il2(kt + decltype(u_c)::value, u_c); });
+    for (; kt < nk; ++kt) static_for<D>([&](auto u_c) { if (kt % D == decltype(u_c)::value) ktile_pf(kt, u_c); });
+  } else {
   for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile_pf(kt + decltype(u_c)::value, u_c); });
   static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile_pf(kt + decltype(u_c)::value, u_c); });
+  }
   }
 
   // plain epilogue (probe): lane = column, register e = row (e & 3) + 8 (e >> 2) + 4 lhi
