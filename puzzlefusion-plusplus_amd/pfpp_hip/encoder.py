@@ -346,8 +346,12 @@ def extract_features(pk, part_pcs: torch.Tensor, pose: torch.Tensor, slot: torch
     B, P, N, _ = part_pcs.shape
     n_slots = B * P
     dev = part_pcs.device
-    latent = torch.zeros((n_slots, num_point, pk["conv6.w"].N), dtype=torch.float32, device=dev)
-    xyz_out = torch.zeros((n_slots, num_point, 3), dtype=torch.float32, device=dev)
+    # both padded outputs out of ONE zero fill (one launch instead of two on the one-puzzle-in-flight chain)
+    Cz = pk["conv6.w"].N
+    n_lat = n_slots * num_point * Cz
+    both = torch.zeros(n_lat + n_slots * num_point * 3, dtype=torch.float32, device=dev)
+    latent = both[:n_lat].view(n_slots, num_point, Cz)
+    xyz_out = both[n_lat:].view(n_slots, num_point, 3)
     pcs_flat = part_pcs.view(n_slots, N, 3)
     pose_flat = pose.reshape(n_slots, 7).contiguous()
     F = slot.numel()
