@@ -513,6 +513,20 @@ def roofline_from_trace(trace, steps: int, mode: str, serialised: bool = False):
     # FLOPs is the f16 dense peak / 3
     peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)
     traffic, traffic_src = pmc_traffic(name.split("+")[0].split("(")[0], mode)
+    # what a HIP-event pair reads around a launch that does (almost) nothing: the start marker's completion -> dispatch -> a one-element
+    # kernel -> end marker.  Box dependent (0.3 .. 2.5 us seen); rocprofv3's kernel durations do not contain it, the averages below do
+    floor_us = None
+    try:
+        one = torch.zeros(1, device="cuda")
+        pairs = []
+        for _ in range(80):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(); one.fill_(1.0); b_.record()
+            pairs.append((a_, b_))
+        torch.cuda.synchronize()
+        floor_us = round(sorted(a_.elapsed_time(b_) for a_, b_ in pairs[16:])[len(pairs[16:]) // 2] * 1e3, 2)
+    except Exception:      # noqa: BLE001 (a diagnostic field only)
+        pass
     roofline = {
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -521,6 +535,7 @@ def roofline_from_trace(trace, steps: int, mode: str, serialised: bool = False):
         "mfma_tflops_executed": round(achieved * (3 if split else 1), 1),
         "launches_per_step": cnt / steps, "avg_launch_ms": round(ms / cnt, 4),
         "measured": "HIP events around every launch in a second pass over the same steps" + (", streams serialised (python bench.py --serial reproduces it under rocprofv3)" if serialised else ""),
+        "event_pair_floor_us": floor_us,
         "variants": {k: {"launches_per_step": round(v[2] / steps, 1), "avg_launch_ms": round(v[1] / v[2], 4),
                          "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)}
                      for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])},
