@@ -979,7 +979,7 @@ def test_module_surface_runs_the_benchmarked_schedule(dev):
     """the schedule bench.py times (loop body on a high-priority stream, next batch's frozen encoder one iteration
     ahead on the CU-masked stream, AdamW per layer under the backward with the gradient clear) is what a plain loop over the
     MODULE surface gets — `for batch in model.training_schedule(loader): training_step / backward / optimizer.step / zero_grad`,
-    called from the default stream — within 12 % of the engine-level iteration of bench.TrainWorkload at BASELINE configs[1]'s size
+    called from the default stream — within 8 % of the engine-level iteration of bench.TrainWorkload at BASELINE configs[1]'s size
     (best of three windows each).  The module loop issues the same kernels for the same kernel time (profiles/r03o_*); what separates
     the two is host time: the engine loop enqueues an iteration in 6.3 ms against 6.7 ms of GPU time, the module loop (autograd hop,
     optimizer wrapper, logging) in 6.4-7.3 ms depending on how the host schedules its two threads — 2 to 10 % in practice.
@@ -1015,26 +1015,29 @@ def test_module_surface_runs_the_benchmarked_schedule(dev):
     data = {k: v.to(dev) for k, v in synthetic.make_batch(0, 32, num_points=1024).items()}
     losses = []
 
-    def loop(n):
+    def loop(n, skip=0):
+        """-> seconds per iteration of iterations skip .. n - 1 (the first `skip` fill the encoder pipeline of this pass over the loader)"""
+        t0 = time.perf_counter()
         for i, batch in enumerate(model.training_schedule([data] * n)):
+            if i == skip:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
             loss = model.training_step(batch, i)
             loss.backward()
             opt.step()
             opt.zero_grad()
             losses.append(loss.detach())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (n - skip)
 
     loop(6)
-    torch.cuda.synchronize()
-    t_module = float("inf")
-    for _ in range(3):
-        t0 = time.perf_counter()
-        loop(20)
-        torch.cuda.synchronize()
-        t_module = min(t_module, (time.perf_counter() - t0) / 20)
+    # steady state of ONE pass over a loader, like the engine-level windows above (a fresh pass starts with an in-line encoder: that
+    # start-up is the loader's, not the iteration's)
+    t_module = min(loop(26, skip=6) for _ in range(3))
     print(f"engine-level iteration {t_engine * 1e3:.3f} ms, module-surface iteration {t_module * 1e3:.3f} ms")
     ls = torch.stack(losses).cpu()
     assert torch.isfinite(ls).all() and float(ls[-5:].mean()) < float(ls[:5].mean())          # it trains
-    assert t_module <= 1.12 * t_engine, (t_module, t_engine)
+    assert t_module <= 1.08 * t_engine, (t_module, t_engine)          # measured 4.8 - 5.5 % (round 5, three runs on one box)
     # same draw -> the prefetched features equal the in-line ones: forward with injected (noise, t) == forward through the schedule
     from pfpp_hip.train import FeaturePipeline
 
