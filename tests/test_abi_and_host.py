@@ -375,6 +375,32 @@ def test_dataset_dropins_equal_the_reference_loaders(golden, tmp_path):
     assert checked >= 60
 
 
+def test_packed_fp32_forwarding_scanner_finds_the_pattern():
+    """tools/diag/pk_hazard_scan.py (the survey behind build.py's NO_PK: 108 packed fp32 results in 39 kernels were consumed by the next
+    vector instruction with only scalar fillers in between): a consumer behind an s_addc is reported, the same behind an s_nop or further
+    down the stream is not"""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools" / "diag"))
+    import pk_hazard_scan as scanner
+
+    head = "0000000000001000 <k>:\n"
+    bad = head + ("\tv_pk_add_f32 v[24:25], v[26:27], v[24:25]          // 000000001000: D3B24018\n"
+                  "\ts_addc_u32 s13, s13, 0                             // 000000001008: 820D800D\n"
+                  "\tv_min_f32_e32 v17, v2, v24                         // 00000000100C: 14223102\n"
+                  "\ts_endpgm                                           // 000000001010: BF810000\n")
+    good = head + ("\tv_pk_add_f32 v[24:25], v[26:27], v[24:25]          // 000000001000: D3B24018\n"
+                   "\ts_nop 0                                            // 000000001008: BF800000\n"
+                   "\tv_min_f32_e32 v17, v2, v24                         // 00000000100C: 14223102\n"
+                   "\ts_endpgm                                           // 000000001010: BF810000\n")
+    other = head + ("\tv_pk_add_f32 v[24:25], v[26:27], v[24:25]          // 000000001000: D3B24018\n"
+                    "\ts_addc_u32 s13, s13, 0                             // 000000001008: 820D800D\n"
+                    "\tv_min_f32_e32 v17, v2, v30                         // 00000000100C: 14223D02\n"
+                    "\ts_endpgm                                           // 000000001010: BF810000\n")
+    assert sum(len(v) for v in scanner.scan(bad.splitlines(True)).values()) == 1
+    assert not scanner.scan(good.splitlines(True)) and not scanner.scan(other.splitlines(True))
+
+
 def test_library_has_no_fused_mixed_precision_conversions(hip_lib, tmp_path):
     """The hi / lo split (csrc/pfpp_common.h) needs ONE fp16 rounding of its argument: `hi = f16(x)`, `lo = f16(x - hi)`.  With the
     gfx950 mix instructions available the compiler may take the stored hi from `v_fma_mixlo_f16` (the exact a * b + c rounded once)
