@@ -18,6 +18,7 @@
 // 19.2 / 48.0 / 33.0 us of the tiled kernel inside the step.
 // Arithmetic: the three split-f16 products of a 16-deep step in the order lo.hi, hi.lo, hi.hi, k ascending, one accumulator chain per
 // output, epilogue (acc * alpha + bias) + residual — gemm_pl_kernel's, bit for bit (tested).
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -69,8 +70,8 @@ struct WdCfg {
   static constexpr size_t SMEM = (size_t)D * STAGE + 4 * PATCH;
 };
 
-template <int MT, int NT, int D, bool X1>
-__global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
+template <int MT, int NT, int D, bool X1, bool PF>
+__device__ __forceinline__ void gemm_wd_body(const WdP& p) {
   pfpp_chain_prio();
   using C = WdCfg<MT, NT, D, X1>;
   constexpr int BM = C::BM, PLANE = C::PLANE, STAGE = C::STAGE, NPL = C::NPL;
@@ -224,9 +225,99 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
     constexpr int U = decltype(u_c)::value;
     if (U < nk) { dma(U, U); wload(U, u_c); }
   });
-  int kt = 0;
-  for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile(kt + decltype(u_c)::value, u_c); });
-  static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile(kt + decltype(u_c)::value, u_c); });
+  if constexpr (!PF) {
+    int kt = 0;
+    for (; kt + D <= nk; kt += D) static_for<D>([&](auto u_c) { ktile(kt + decltype(u_c)::value, u_c); });
+    static_for<D - 1>([&](auto u_c) { if (kt + decltype(u_c)::value < nk) ktile(kt + decltype(u_c)::value, u_c); });
+  } else {
+    // ---- software-pipelined form (round 5; 64 x 128 tile, three workgroups' worth of tiles per CU: the 1536- / 2048-wide outputs).
+    // A wave that stalls in the issue of a vector-memory instruction (texture queue full) issues no matrix instruction either, and the
+    // loop above issues its six loads and eight LDS reads in one block in front of the twelve matrix instructions.  Here the fragments of
+    // tile kt + 1 are read from LDS while tile kt is multiplied (register double buffer), and every memory instruction sits in the shadow
+    // of one matrix instruction: 26.4 -> 23.5 us at 3850 x 1536 x 512, 34.4 -> 30.2 at 16000 x 512 x 512; no gain where one workgroup has
+    // a CU to itself (512-wide outputs at 3,850 rows: those keep the loop above).  Same products in the same order per accumulator.
+    static_assert(!PF || (MT == 2 && NT == 1 && !X1 && D == 4), "pipelined form: 64 x 128 tile, split-f16, four stages");
+    half8 gh[2][2][MT], gl[2][2][MT];                 // [parity of the tile][16-deep step][row block]
+    auto wait_all = [&](auto par_c) {
+      constexpr int par = decltype(par_c)::value;
+      wait_frags(gh[par][0], gl[par][0], I0{});
+      wait_frags(gh[par][1], gl[par][1], I0{});
+    };
+    auto ktile_il = [&](int kt, auto u_c) {           // tiles that still request tile kt + D - 1 and read tile kt + 1
+      constexpr int U = decltype(u_c)::value;
+      constexpr int UN = (U + D - 1) % D, U1 = (U + 1) % D;
+      constexpr int par = U & 1, npar = par ^ 1;
+      wait_vmcnt<(D - 3) * P>();                      // tile kt + 1 has landed (tile kt + 2 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      name_w(u_c);
+      const uint32_t ad0 = a_ad[0] + U1 * STAGE, ad1 = a_ad[1] + U1 * STAGE;
+      const half8* ph = wbh[0] + (size_t)(kt + D - 1) * 128;
+      const half8* pl = wbl[0] + (size_t)(kt + D - 1) * 128;
+      auto mem = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i == 0) gh[npar][0][0] = lds_rd<0>(ad0);
+        else if constexpr (i == 1) gl[npar][0][0] = lds_rd<PLANE>(ad0);
+        else if constexpr (i == 2) gh[npar][0][1] = lds_rd<2048>(ad0);
+        else if constexpr (i == 3) gl[npar][0][1] = lds_rd<PLANE + 2048>(ad0);
+        else if constexpr (i == 4) gh[npar][1][0] = lds_rd<0>(ad1);
+        else if constexpr (i == 5) gl[npar][1][0] = lds_rd<PLANE>(ad1);
+        else if constexpr (i == 6) gh[npar][1][1] = lds_rd<2048>(ad1);
+        else if constexpr (i == 7) gl[npar][1][1] = lds_rd<PLANE + 2048>(ad1);
+        else if constexpr (i == 8) __builtin_amdgcn_global_load_lds((gbl_void*)(src[0] + (size_t)(kt + D - 1) * 64), (lds_void*)(uintptr_t)(dst[0] + UN * STAGE), 16, 0, 0);
+        else if constexpr (i == 9) __builtin_amdgcn_global_load_lds((gbl_void*)(src[1] + (size_t)(kt + D - 1) * 64), (lds_void*)(uintptr_t)(dst[1] + UN * STAGE), 16, 0, 0);
+        else if constexpr (i == 10) wh[UN][0][0] = gld<0>(ph);
+        else if constexpr (i == 11) wh[UN][0][1] = gld<1024>(ph);
+        else if constexpr (i == 12) wl[UN][0][0] = gld<0>(pl);
+        else if constexpr (i == 13) wl[UN][0][1] = gld<1024>(pl);
+      };
+      static_for<12>([&](auto i_c) {                  // term-major per 16-deep step, as mma(): lo.hi, hi.lo, hi.hi of both row blocks
+        constexpr int i = decltype(i_c)::value, s_ = i / 6, r = i % 6, term = r / 2, t = r % 2;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? gl[par][s_][t] : gh[par][s_][t], term == 1 ? wl[U][0][s_] : wh[U][0][s_], acc[t][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mem(i_c);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      mem(std::integral_constant<int, 12>{});
+      mem(std::integral_constant<int, 13>{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_all(std::integral_constant<int, npar>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto ktile_tail = [&](int kt, auto u_c) {         // the last tiles: requests and reads only where a tile is left
+      constexpr int U = decltype(u_c)::value;
+      constexpr int UN = (U + D - 1) % D, U1 = (U + 1) % D;
+      constexpr int par = U & 1, npar = par ^ 1;
+      if (nk - 2 - kt >= D - 3) wait_vmcnt<(D - 3) * P>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      name_w(u_c);
+      if (kt + D - 1 < nk) {
+        dma(kt + D - 1, UN);
+        wload(kt + D - 1, std::integral_constant<int, UN>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        rd_frags(gh[npar][0], gl[npar][0], U1, I0{});
+        rd_frags(gh[npar][1], gl[npar][1], U1, I1{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(gh[par][0], gl[par][0], u_c, I0{});
+      mma(gh[par][1], gl[par][1], u_c, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      wait_all(std::integral_constant<int, npar>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nk - 1 >= D - 2) wait_vmcnt<(D - 2) * P>();   // tile 0 has landed
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    rd_frags(gh[0][0], gl[0][0], 0, I0{});
+    rd_frags(gh[0][1], gl[0][1], 0, I1{});
+    wait_all(I0{});
+    int kt = 0;
+    for (; kt + 2 * D - 1 <= nk; kt += D) static_for<D>([&](auto u_c) { ktile_il(kt + decltype(u_c)::value, u_c); });
+    for (; kt < nk; ++kt) static_for<D>([&](auto u_c) { if (kt % D == decltype(u_c)::value) ktile_tail(kt, u_c); });
+  }
 
   // ---- epilogue: (acc * alpha + bias) + residual, every tile through the wave's private 4 KB patch (behind the ring: no barrier needed)
   const uint32_t patch = lds0 + D * STAGE + wave * C::PATCH;
@@ -264,6 +355,12 @@ __global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) {
     }
   }
 }
+
+template <int MT, int NT, int D, bool X1>
+__global__ __launch_bounds__(256) void gemm_wd_kernel(const WdP p) { gemm_wd_body<MT, NT, D, X1, false>(p); }
+// the software-pipelined loop (a kernel name of its own: the profiles' instantiation names of the plain loop stay what they were)
+template <int MT, int NT, int D>
+__global__ __launch_bounds__(256) void gemm_wd_pf_kernel(const WdP p) { gemm_wd_body<MT, NT, D, false, true>(p); }
 
 // ---- fragment-blocking of row-major planes (training: the weights change every step, their blocked copies are made where they are read)
 struct RbJob { const _Float16 *hi, *lo; _Float16 *fhi, *flo; int N, K; int64_t ldw; int transposed; int first_wg; };
@@ -319,17 +416,21 @@ __global__ __launch_bounds__(256) void reblock_kernel(const RbP p) {
   }
 }
 
-template <int MT, int NT, int D, bool X1 = false>
+template <int MT, int NT, int D, bool X1 = false, bool PF = false>
 int launch_wd(const WdP& p, hipStream_t st) {
   using C = WdCfg<MT, NT, D, X1>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_wd_kernel<MT, NT, D, X1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM) != hipSuccess)
+    const void* fn;
+    if constexpr (PF) fn = (const void*)gemm_wd_pf_kernel<MT, NT, D>;
+    else fn = (const void*)gemm_wd_kernel<MT, NT, D, X1>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::SMEM) != hipSuccess)
       return pfpp::check_launch("pfpp_gemm_wd");
     attr_set = true;
   }
   const unsigned tiles = (unsigned)(((p.M + C::BM - 1) / C::BM) * (p.N / C::BN));
-  hipLaunchKernelGGL((gemm_wd_kernel<MT, NT, D, X1>), dim3(tiles), dim3(256), C::SMEM, st, p);
+  if constexpr (PF) hipLaunchKernelGGL((gemm_wd_pf_kernel<MT, NT, D>), dim3(tiles), dim3(256), C::SMEM, st, p);
+  else hipLaunchKernelGGL((gemm_wd_kernel<MT, NT, D, X1>), dim3(tiles), dim3(256), C::SMEM, st, p);
   return pfpp::check_launch("pfpp_gemm_wd");
 }
 
@@ -359,6 +460,10 @@ static int gemm_wd_impl(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, con
     return launch_wd<2, 1, 3, true>(p, st);
   }
   if (N % 256 == 0 && big_tiles >= 240) return launch_wd<4, 2, 4>(p, st);
+  // 64 x 128 tiles: the software-pipelined loop where more than two workgroups' worth of tiles meet on a CU (PFPP_WD_PF=0: the plain loop)
+  static const bool pf_on = !(getenv("PFPP_WD_PF") && atoi(getenv("PFPP_WD_PF")) == 0);
+  const int64_t small_tiles = ((M + 63) / 64) * (N / 128);
+  if (pf_on && small_tiles >= 512 && K >= 7 * 32) return launch_wd<2, 1, 4, false, true>(p, st);
   return launch_wd<2, 1, 3>(p, st);
 }
 

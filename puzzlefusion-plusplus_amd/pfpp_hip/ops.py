@@ -887,9 +887,17 @@ def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[
     return out
 
 
-def wd_kernel_name(big: bool, single_pass: bool = False) -> str:
-    """the instantiation pfpp_gemm_wd / pfpp_gemm_wd_f16 launch (csrc/gemm_wd.hip gemm_wd_impl: tile by shape, X1 = single pass), spelled
-    as rocprofv3 prints it — bench.py looks the counter traffic of the dominant kernel up under this name"""
+WD_PF = _os.environ.get("PFPP_WD_PF", "1") != "0"
+
+
+def wd_kernel_name(big: bool, single_pass: bool = False, shape=None) -> str:
+    """the instantiation pfpp_gemm_wd / pfpp_gemm_wd_f16 launch (csrc/gemm_wd.hip gemm_wd_impl: tile by shape, X1 = single pass; the
+    software-pipelined loop from 512 small tiles up — shape = (M, N, K)), spelled as rocprofv3 prints it — bench.py looks the counter
+    traffic of the dominant kernel up under this name"""
+    if not big and not single_pass and shape is not None and WD_PF:
+        M, N, K = shape
+        if ((M + 63) // 64) * (N // 128) >= 512 and K >= 224:
+            return "gemm_wd_pf_kernel<2, 1, 4>"
     return "gemm_wd_kernel<%s, %s>" % ("4, 2, 4" if big else "2, 1, 3", "true" if single_pass else "false")
 
 
@@ -921,7 +929,7 @@ def gemm_wd(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[tor
     if ev is not None:
         ev[1].record()
         big = w.N % 256 == 0 and ((M + 127) // 128) * (w.N // 256) >= 240
-        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * w.N * K, wd_kernel_name(big, single_pass), (M, w.N, K, 1, "none", 0)))
+        GEMM_TRACE.append((ev[0], ev[1], 2.0 * M * w.N * K, wd_kernel_name(big, single_pass, (M, w.N, K)), (M, w.N, K, 1, "none", 0)))
     return out
 
 

@@ -219,7 +219,7 @@ def gemm_wd(A: "Planes", W: "Planes", out: torch.Tensor, *, M: int, N: int, K: i
         big = N % 256 == 0 and ((M + 127) // 128) * (N // 256) >= 240
         if frag is None:
             trace.append((ev[0], ev[1], 0.0, "reblock_kernel", (rows, cols, 0, 1, "reblock_t" if transposed else "reblock", 0)))
-        trace.append((ev[2], ev[3], 2.0 * M * N * K, ops.wd_kernel_name(big), (M, N, K, 1, "nn" if transposed else "nt", 0)))
+        trace.append((ev[2], ev[3], 2.0 * M * N * K, ops.wd_kernel_name(big, False, (M, N, K)), (M, N, K, 1, "nn" if transposed else "nt", 0)))
     return out
 
 

@@ -484,7 +484,7 @@ def test_library_never_touches_a_register_with_an_lds_read_in_flight(hip_lib, tm
         assert not rep, {scanner.demangle(k)[:120]: [(h[1][:60], h[2][1][:60]) for h in v[:3]] for k, v in rep.items()}
         # the same hazard class on the vector-memory side: the weight-direct GEMM (the only kernel that loads VGPRs from inline asm)
         # must never have one of its asm-loaded registers copied
-        for k, moves in scanner.moves_of_loaded_registers(text.splitlines(True), "gemm_wd_kernel").items():
+        for k, moves in scanner.moves_of_loaded_registers(text.splitlines(True), "gemm_wd_").items():
             n_wd += 1
             assert not moves, (scanner.demangle(k)[:100], moves[:4])
-    assert n_kernels > 100 and n_reads > 500 and n_wd >= 4          # it really was the kernels' code that was scanned
+    assert n_kernels > 100 and n_reads > 500 and n_wd >= 5          # it really was the kernels' code that was scanned

@@ -1544,7 +1544,9 @@ def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(3850, 512, 512), (3850, 1536, 512), (3850, 512, 2048), (16000, 512, 512), (100, 128, 32), (1, 256, 64),
-                                   (2047, 1536, 1024), (16001, 1536, 512)])
+                                   (2047, 1536, 1024), (16001, 1536, 512),
+                                   # the software-pipelined loop (from 512 small tiles up, K >= 224): 7, 8, 11 and 17 K-tiles, a ragged last row tile
+                                   (3850, 1536, 224), (3850, 1536, 256), (3850, 1536, 352), (4100, 1024, 544)])
 def test_gemm_wd_bit_identical_to_the_tiled_gemm(dev, M, N, K):
     """csrc/gemm_wd.hip (qkv / out-projection / second feed-forward linear of the eval step above the few-token range): row-major A
     planes through a deep LDS-DMA ring, the weight's fragment-blocked planes straight into the matrix operands — the same products in
