@@ -1332,16 +1332,21 @@ def test_blocks_sequenced_from_c_equal_the_python_sequence(golden, weights_sd, d
             dpred = ((pred - noise).reshape(n, 7).float() * (2.0 / n)).contiguous()
             eng.backward(ctx, dpred)
             torch.cuda.synchronize()
+            if step == 0:
+                grads0 = eng.flat.grads.clone()          # same weights on both sides: only the gradient atomics' order differs
             grads = eng.flat.grads.clone()
             eng.optimizer_step(**hp)
         torch.cuda.synchronize()
-        out.append((first, pred.clone(), grads, eng.flat.params.clone(), eng.flat.exp_avg.clone()))
+        out.append((first, pred.clone(), grads, eng.flat.params.clone(), eng.flat.exp_avg.clone(), grads0))
         del eng
-    (f0, p0, g0, w0, m0), (f1, p1, g1, w1, m1) = out
+    (f0, p0, g0, w0, m0, s0), (f1, p1, g1, w1, m1, s1) = out
     assert torch.equal(f0, f1) if wd == "0" else rel(f1, f0.cpu()) < 2e-6
     assert rel(p1, p0.cpu()) < 1e-4
     tol = 2e-6 if wd == "0" else 2e-5          # wd: one chain per output against the tiled kernel's K-split partial sums at these few tokens
-    assert rel(g1, g0.cpu()) < tol and rel(m1, m0.cpu()) < tol
+    assert rel(s1, s0.cpu()) < tol
+    # the second step runs on weights that already differ where Adam's sign-like first update met a noise-level gradient element: its
+    # gradients agree to a few 1e-6 (2.0 - 2.5e-6 seen on one box in 4 of 22 whole-suite runs, profiles/r05x_suite_loop_after_fix_2.txt)
+    assert rel(g1, g0.cpu()) < 5 * tol and rel(m1, m0.cpu()) < 5 * tol
     assert float((w1 - w0).abs().max()) <= 2e-3 * 1.0001 * 2        # Adam moves an element by at most ~lr per step; sign flips only at noise-level gradients
     moved = float(((w1 - w0).abs() > 1e-6).float().mean())
     print(f"parameters that differ by more than 1e-6 after two steps: {moved:.3e}")
