@@ -460,8 +460,11 @@ static int gemm_wd_impl(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, con
     return launch_wd<2, 1, 3, true>(p, st);
   }
   if (N % 256 == 0 && big_tiles >= 240) return launch_wd<4, 2, 4>(p, st);
-  // 64 x 128 tiles: the software-pipelined loop where more than two workgroups' worth of tiles meet on a CU (PFPP_WD_PF=0: the plain loop)
-  static const bool pf_on = !(getenv("PFPP_WD_PF") && atoi(getenv("PFPP_WD_PF")) == 0);
+  // 64 x 128 tiles: the software-pipelined loop where more than two workgroups' worth of tiles meet on a CU.  Lab switch PFPP_WD_PF=1, OFF by
+  // default: stand-alone it takes 11 % off the 1536-wide GEMM, inside the overlapped training iteration it costs 0.6 % (6.186 / 6.139 / 6.109
+  // against 6.129 / 6.072 / 6.091 ms alternating on one box: two waves per SIMD and 48 KB of LDS leave the co-running streams less room) and the
+  // compact sampler step does not move (2.92 against 2.93 ms) — profiles/r05zz_ab_wd_pf.txt
+  static const bool pf_on = getenv("PFPP_WD_PF") && atoi(getenv("PFPP_WD_PF")) == 1;
   const int64_t small_tiles = ((M + 63) / 64) * (N / 128);
   if (pf_on && small_tiles >= 512 && K >= 7 * 32) return launch_wd<2, 1, 4, false, true>(p, st);
   return launch_wd<2, 1, 3>(p, st);

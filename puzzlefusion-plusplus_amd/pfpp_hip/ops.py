@@ -887,7 +887,7 @@ def gemm_small(a, w, *, bias: Optional[torch.Tensor] = None, residual: Optional[
     return out
 
 
-WD_PF = _os.environ.get("PFPP_WD_PF", "1") != "0"
+WD_PF = _os.environ.get("PFPP_WD_PF", "0") == "1"          # lab: the software-pipelined loop of csrc/gemm_wd.hip (off by default)
 
 
 def wd_kernel_name(big: bool, single_pass: bool = False, shape=None) -> str:
