@@ -514,7 +514,7 @@ def roofline_from_trace(trace, steps: int, mode: str, serialised: bool = False):
     peak = PEAK_F16_MFMA_TFLOPS if single else (PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS)
     traffic, traffic_src = pmc_traffic(name.split("+")[0].split("(")[0], mode)
     # what a HIP-event pair reads around a launch that does (almost) nothing: the start marker's completion -> dispatch -> a one-element
-    # kernel -> end marker.  Box dependent (0.3 .. 2.5 us seen); rocprofv3's kernel durations do not contain it, the averages below do
+    # kernel -> end marker (10 us seen; a 20 us kernel hides all but ~2 us of it).  rocprofv3's kernel durations do not contain it, the averages below do
     floor_us = None
     try:
         one = torch.zeros(1, device="cuda")
