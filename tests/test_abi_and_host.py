@@ -78,6 +78,31 @@ def test_wrappers_reject_cpu_tensors(hip_lib):
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
 
 
+def test_round5_entry_points_refuse_bad_arguments_before_any_launch(hip_lib):
+    """argument checks of the round-5 entry points (no GPU needed: they return before a launch): null pointers, widths the kernels do not
+    cover, a non-positive gradient scale — error code and message through pfpp_last_error; the wrappers refuse CPU tensors"""
+    import ctypes as C
+
+    from pfpp_hip import _lib, train_ops as T
+
+    lib = _lib.load()
+    one = C.c_void_p(4096)                        # any non-null, 16-byte aligned address: never dereferenced on these paths
+    assert lib.pfpp_ada_linear_bwd(None, one, one, one, one, one, one, 12, 32, 512, 1024, None) != 0 and b"null" in lib.pfpp_last_error()
+    assert lib.pfpp_ada_linear_bwd(one, one, one, one, one, one, one, 12, 32, 500, 1024, None) != 0 and b"unsupported" in lib.pfpp_last_error()
+    assert lib.pfpp_ada_linear_bwd(one, one, one, one, one, one, one, 12, 0, 512, 1024, None) != 0
+    assert lib.pfpp_token_embed_bwd(one, one, one, one, one, one, one, one, 154, 25, 500, C.c_float(1.0), None) != 0
+    assert lib.pfpp_token_embed_bwd(one, one, one, one, one, one, one, one, 154, 25, 512, C.c_float(0.0), None) != 0 and b"scale" in lib.pfpp_last_error()
+    assert lib.pfpp_token_embed_bwd(one, None, one, one, one, one, one, one, 154, 25, 512, C.c_float(1.0), None) != 0
+    assert lib.pfpp_token_features_t(one, one, one, one, None, None, one, one, 154, 25, None) != 0
+    assert lib.pfpp_embed_pack_weights(one, one, one, one, one, one, one, 500, None) != 0
+    assert lib.pfpp_token_features_t_cols(154, 25) == 3856 and lib.pfpp_ada_linear_bwd_scratch_floats(12, 1024) == 12 * 1024 * 32
+    with pytest.raises(ValueError, match="GPU"):
+        T.ada_linear_bwd(torch.zeros(2, 4, 64), torch.zeros(2, 4, 32), torch.zeros(2, 64, 32), torch.zeros(2, 64, 32), torch.zeros(2, 64))
+    with pytest.raises(ValueError, match="GPU"):
+        T.token_embed_bwd(torch.zeros(50, 32), torch.zeros(320, 64, dtype=torch.float16), torch.zeros(320, 64, dtype=torch.float16),
+                          torch.zeros(32, 148), torch.zeros(32), torch.zeros(32, 147), torch.zeros(32), torch.zeros(2, 32), 2, 25)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from pfpp_hip import _lib
 
