@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <utility>
 #include <type_traits>
@@ -406,8 +407,10 @@ int main(int argc, char** argv) {
     for (int k = 0; k < K; ++k) ref += (double)A[(size_t)m * K + k] * (double)W[(size_t)n * K + k];
     worst = fmax(worst, fabs(ref - Cc[(size_t)m * N + n])); scale = fmax(scale, fabs(ref));
   }
+  unsigned long long hsh = 1469598103934665603ull;
+  for (size_t i = 0; i < Cc.size(); ++i) { unsigned u; memcpy(&u, &Cc[i], 4); hsh = (hsh ^ u) * 1099511628211ull; }
   const double us = ms / it * 1e3;
-  printf("MT %d NT %d D %d KT %d XCD %d ABL %d PF %d IL %d | M %d N %d K %d: %.1f us per launch, %.1f TFLOP/s (fp32-grade), %d workgroups, LDS %zu B, max |err| %.2e of %.2e\n",
-         MT, NT, D, KT, XCD, ABL, PF, IL, M, N, K, us, 2.0 * M * N * K / us * 1e-6, tiles, smem, worst, scale);
+  printf("MT %d NT %d D %d KT %d XCD %d ABL %d PF %d IL %d | M %d N %d K %d: %.1f us per launch, %.1f TFLOP/s (fp32-grade), %d workgroups, LDS %zu B, max |err| %.2e of %.2e, hash %016llx\n",
+         MT, NT, D, KT, XCD, ABL, PF, IL, M, N, K, us, 2.0 * M * N * K / us * 1e-6, tiles, smem, worst, scale, hsh);
   return 0;
 }
