@@ -306,7 +306,8 @@ int pfpp_gemm_planes(const pfpp_gemm_planes_args* args, pfpp_stream_t stream);
  * are k-major fp16 planes read in place (leading dimensions M and N; scales folded out: gw += dY^T.X / (dy.scale * x.scale),
  * gb += colsum(dY) / dy.scale; gb may be NULL).  Every output tile runs the whole contraction in one accumulator chain (no K split,
  * no workspace, no reduction launch; deterministic); the problems' tiles are dealt to the XCDs as one concatenated list.
- * variant: 0 = the library's choice; 3 = 128 x 128 tiles, 6 / 7 = 128 x 64 (three / two stages), 2 = 256 x 128 (lab).             */
+ * variant: 0 = the library's choice (= 2: 256 x 128 tiles, 160 workgroups for a block's six problems, unless the environment
+ * names another one in PFPP_DW_GROUP_VARIANT); alternatives: 3 = 128 x 128 tiles, 6 / 7 = 128 x 64 (three / two stages).       */
 #define PFPP_DW_GROUP_MAX 8
 typedef struct pfpp_dw_job {
   pfpp_planes dy;      /* [K, M] */

@@ -857,6 +857,99 @@ def test_full_size_training_iteration_properties(weights_sd, dev):
     assert (outs[1] - outs[3]).abs().max() <= 1e-5 * outs[1].abs().max()
 
 
+def test_training_step_at_the_benchmarked_size_vs_oracle_autograd(weights_sd, dev):
+    """VERDICT r5 item 2a.  The training step at the size bench.py times (BASELINE configs[1]: 32 puzzles x 20 slots, 154 valid
+    fragments = 3,850 tokens, dropouts ON) against torch autograd through the CPU oracle on the same inputs: the oracle applies the
+    very keep masks the kernels generate (counter-based generator read back per site), so the two computations differ by rounding
+    only.  At this size the weight gradients are the six-problem grouped launch over 160 workgroups, the forward / input-gradient
+    GEMMs run their 3,850-row tiles (the 700-token goldens take other tiles): loss 2e-5, prediction 1e-4 on the selected
+    fragments, every parameter's gradient within 2e-4 of its max."""
+    from pfpp_hip import config, synthetic
+    from pfpp_hip import train_ops as TO
+    from pfpp_hip.train import DenoiserTrainEngine
+    from puzzlefusion_plusplus.denoiser.model.denoiser import Denoiser
+
+    torch.manual_seed(0)
+    model = Denoiser(config.denoiser_config())
+    model.encoder.load_state_dict(weights_sd("vqvae")); model.denoiser.load_state_dict(weights_sd("denoiser"))
+    model = model.to(dev)
+    model.encoder.eval()
+    B, P, L = 32, 20, 25
+    data = {k: v.to(dev) for k, v in synthetic.make_batch(0, B, num_points=1024).items()}      # puzzles 0 .. 31: bench.py's batch on rank 0
+    gt = torch.cat([data["part_trans"], data["part_rots"]], -1).float().contiguous()
+    ref = data["ref_part"]
+    gen = torch.Generator(device=dev).manual_seed(11)
+    noise = torch.randn(gt.shape, device=dev, generator=gen)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=gen)
+    noisy = model.noise_scheduler.add_noise(gt, noise, t)
+    noisy = torch.where(ref.bool().unsqueeze(-1), gt, noisy)
+    with torch.no_grad():
+        latent, xyz = model._extract_features(data["part_pcs"], data["part_valids"], noisy)
+    inp = [noisy, t, latent, xyz, data["part_valids"], data["part_scale"], ref]
+    inp_c = [v.cpu() for v in inp]
+    eng = DenoiserTrainEngine(model.denoiser)
+    seed = 20260930
+    valid = inp_c[4].reshape(-1).bool()
+    slot = torch.nonzero(valid).flatten()
+    Fv = slot.numel()
+    assert Fv * L == 3850, Fv
+
+    def drop(site, tensor):
+        width = tensor.shape[-1]
+        p = eng.p_token if site == 0 else eng.p_layer
+        keep_c = TO.dropout_mask(Fv * L * width, p, seed, site, dev).view(Fv, L, width).cpu().to(tensor.dtype)
+        keep = torch.ones(B * P, L, width, dtype=tensor.dtype)
+        keep[slot] = keep_c                                   # compact row order = ascending valid slots
+        return tensor * keep.view(B, P * L, width) / (1 - p)
+
+    sd, pred_o, loss_o = _oracle_grads(weights_sd, inp_c, noise.cpu(), drop)
+    pred, ctx = eng.forward(*inp, seed=seed, train=True)
+    sel = valid.view(B, P)
+    assert (pred.cpu() - pred_o)[sel].abs().max() < 1e-4
+    eng.flat.zero_grad()
+    loss = eng.loss_and_grads(*inp, noise, seed=seed, train=True)
+    assert abs(float(loss) - float(loss_o)) < 2e-5 * float(loss_o)
+    named = dict(eng.module.named_parameters())
+    errs = {n: rel(named[n].grad, sd[n].grad) for n in named}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 2e-4, (worst, errs[worst])
+
+
+@pytest.mark.parametrize("variant", [0, 3])      # 0 = the library's 256 x 128 tile, 3 = 128 x 128
+def test_grouped_weight_gradient_launch_at_3850_rows_vs_float64(dev, variant):
+    """VERDICT r5 item 2b.  pfpp_gemm_dw_group with a transformer block's six REAL problems over the benchmarked 3,850 token rows
+    (qkv x 2: 1536 x 512, out-projection x 2: 512 x 512, ff1: 4096 x 512, ff2: 512 x 2048; 160 output tiles of 256 x 128 dealt to the
+    XCDs as one concatenated list - where an indexing slip between problems would hide) against float64 (2e-6 of each gradient's
+    max, bias sums too), accumulating onto a non-zero gradient, and against the six single launches (association of the partial
+    sums only: 2e-6)."""
+    from pfpp_hip import planes as P
+
+    torch.manual_seed(17)
+    K = 3850
+    shapes = [(1536, 512, True), (512, 512, True), (1536, 512, True), (512, 512, True), (4096, 512, True), (512, 2048, True)]
+    jobs, singles, wants = [], [], []
+    for M, N, bias in shapes:
+        dy = torch.randn(K, M, device=dev) * 1e-3
+        x = torch.randn(K, N, device=dev)
+        g0 = torch.randn(M, N, device=dev) * 1e-2            # the gradient buffer already holds something (accumulation)
+        b0 = torch.randn(M, device=dev) * 1e-2
+        dyp, xp = P.split(dy, 4096.0), P.split(x, 1.0)
+        gw, gb = g0.clone(), b0.clone()
+        jobs.append((dyp, xp, gw, gb if bias else None))
+        singles.append((dyp, xp, g0.clone(), b0.clone(), M, N))
+        wants.append((g0.double() + dy.double().t() @ x.double(), b0.double() + dy.double().sum(0)))
+    P.dw_group(jobs, K, variant)
+    for dyp, xp, gw1, gb1, M, N in singles:
+        P.gemm(dyp, xp, gw1, M=M, N=N, K=K, a_kmajor=True, w_kmajor=True, accumulate=True, colsum=gb1)
+    torch.cuda.synchronize()
+    for i, ((_, _, gw, gb), (_, _, gw1, gb1, _, _), (ww, wb)) in enumerate(zip(jobs, singles, wants)):
+        sw, sb = float(ww.abs().max()), float(wb.abs().max())
+        assert float((gw.double() - ww).abs().max()) < 2e-6 * sw, (i, "dW vs float64")
+        assert float((gb.double() - wb).abs().max()) < 2e-6 * sb, (i, "db vs float64")
+        assert float((gw - gw1).abs().max()) < 2e-6 * sw, (i, "grouped vs single launch")
+        assert float((gb - gb1).abs().max()) < 2e-6 * sb, (i, "grouped vs single launch (bias)")
+
+
 def test_feature_pipeline_equals_inline_encoder(weights_sd, dev):
     """the encoder of iteration i+1 issued on its own stream during iteration i yields the same features, losses and
     encoder buffers as running it in line (same (noise, t) draws)"""
