@@ -41,14 +41,20 @@ extern "C" {
 typedef void* pfpp_stream_t;
 
 /* ---- library ------------------------------------------------------------ */
-int pfpp_version(void);                 /* ABI version, currently 1          */
+#define PFPP_ABI_VERSION 2
+int pfpp_version(void);                 /* ABI version = PFPP_ABI_VERSION (2: pfpp_build_info, per-thread attention mode) */
+/* "abi=2;arch=gfx950;fma_mix_insts=off;packed_fp32_ops=off;chain_prio=3": the code-generation switches this binary was compiled
+ * with.  Two of them are CORRECTNESS switches: a binding must refuse a library that does not say "off" for both
+ * (pfpp_hip/_lib.py does; PFPP_PACKED_FP32=1 is the lab override for the second) */
+const char* pfpp_build_info(void);
 const char* pfpp_last_error(void);
 /* sizeof(struct pfpp_<name>) as this library was compiled ("gemm_planes_args", "tlayers_args", ...), -1 for an unknown name: a binding
  * that mirrors the structs (pfpp_hip/_lib.py) checks its own layout against it when it loads, so a stale mirror fails loudly    */
 int64_t pfpp_abi_sizeof(const char* name);
 /* number of compute units of the current device (for grid sizing in hosts) */
 int pfpp_device_cu_count(void);
-/* process-wide arithmetic of the attention FORWARD kernels (pfpp_attn_dense*, pfpp_attn_blockdiag*; diffusers Attention,
+/* arithmetic of the attention FORWARD kernels for launches issued by the CALLING THREAD (thread-local like pfpp_last_error: the
+ * library keeps no process-global mutable state) (pfpp_attn_dense*, pfpp_attn_blockdiag*; diffusers Attention,
  * attention.py:46-72 via denoiser_transformer.py:46-72): -1 = each kernel's default (split-f16 unless its PFPP_ATTN_* environment
  * switch says otherwise), 0 = exact fp32 matrix instructions (the range fallback of the sampler loops, pfpp_hip.ops.exact_fp32),
  * 1 = split-f16, 2 = single-pass fp16 (perf mode of BASELINE configs[4]; never a parity mode). */

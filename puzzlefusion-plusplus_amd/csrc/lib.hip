@@ -24,7 +24,9 @@ int check_launch(const char* what) {
   return PFPP_OK;
 }
 
-static int g_attn_mode = -1;
+// arithmetic mode of the attention kernels for launches issued by THIS thread (pfpp_set_attention_mode): like the error text, state
+// of the calling thread, not of the process - two host threads driving two streams never see each other's setting
+static thread_local int g_attn_mode = -1;
 int attn_mode() { return g_attn_mode; }
 
 }  // namespace pfpp
@@ -40,7 +42,27 @@ extern "C" int pfpp_set_attention_mode(int mode) {
 
 extern "C" int pfpp_get_attention_mode(void) { return pfpp::g_attn_mode; }
 
-extern "C" int pfpp_version(void) { return 1; }
+extern "C" int pfpp_version(void) { return PFPP_ABI_VERSION; }
+
+// What this binary was compiled with (pfpp_hip/build.py passes the switch AND its attestation macro together in the flags every
+// translation unit gets; a build that bypasses it reports "unattested" and pfpp_hip._lib.load() refuses the library):
+//   fma_mix_insts=off    no v_fma_mix* : every fp32 -> fp16 conversion of a hi / lo split is one v_cvt of the rounded value
+//   packed_fp32_ops=off  no v_pk_{add,mul,fma}_f32 : round 5's wrong farthest point next to a co-running GEMM
+#ifdef PFPP_ATTEST_NO_MIX
+#define PFPP_BI_MIX "off"
+#else
+#define PFPP_BI_MIX "unattested"
+#endif
+#ifdef PFPP_ATTEST_NO_PK
+#define PFPP_BI_PK "off"
+#else
+#define PFPP_BI_PK "unattested"
+#endif
+#define PFPP_STR2(x) #x
+#define PFPP_STR(x) PFPP_STR2(x)
+extern "C" const char* pfpp_build_info(void) {
+  return "abi=" PFPP_STR(PFPP_ABI_VERSION) ";arch=gfx950;fma_mix_insts=" PFPP_BI_MIX ";packed_fp32_ops=" PFPP_BI_PK ";chain_prio=" PFPP_STR(PFPP_CHAIN_PRIO);
+}
 
 extern "C" const char* pfpp_last_error(void) { return pfpp::g_err; }
 

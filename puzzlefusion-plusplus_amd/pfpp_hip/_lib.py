@@ -311,6 +311,7 @@ SIGNATURES = {
 PLAIN = {
     "pfpp_version": ([], C.c_int),
     "pfpp_last_error": ([], C.c_char_p),
+    "pfpp_build_info": ([], C.c_char_p),
     "pfpp_abi_sizeof": ([C.c_char_p], C.c_int64),
     "pfpp_last_gemm_kernel": ([], C.c_char_p),
     "pfpp_device_cu_count": ([], C.c_int),
@@ -356,6 +357,34 @@ def _bind_torch_hip_runtime() -> None:
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+ABI_VERSION = 2
+
+
+def build_info(lib) -> dict:
+    """pfpp_build_info() as a dict ("abi", "arch", "fma_mix_insts", "packed_fp32_ops", "chain_prio")"""
+    fn = lib.pfpp_build_info
+    fn.argtypes, fn.restype = [], C.c_char_p
+    return dict(kv.split("=", 1) for kv in fn().decode().split(";") if "=" in kv)
+
+
+def _attest(lib) -> None:
+    """Refuse a libpfpp_hip.so of another ABI revision or one compiled without the two correctness switches of pfpp_hip/build.py:
+    `-fma-mix-insts` (one fp16 rounding per hi / lo split) and `-packed-fp32-ops` (round 5: with v_pk_*_f32 in the
+    library, fps_kernel picked a wrong farthest point next to a co-running GEMM once in 10^2 .. 10^4 launches, and 117 of 150 training
+    steps differed between two runs).  PFPP_PACKED_FP32=1 (the lab switch that BUILDS such a library) also lets it load."""
+    lib.pfpp_version.argtypes, lib.pfpp_version.restype = [], C.c_int
+    if not hasattr(lib, "pfpp_build_info") or lib.pfpp_version() != ABI_VERSION:
+        raise PfppError(f"{LIB_PATH}: ABI version {lib.pfpp_version()} != {ABI_VERSION} — rebuild it (python __graft_entry__.py)")
+    info = build_info(lib)
+    if info.get("fma_mix_insts") != "off":
+        raise PfppError(f"{LIB_PATH} was not built by pfpp_hip/build.py: fma_mix_insts={info.get('fma_mix_insts')} "
+                        "(the hi / lo splits need `-Xclang -target-feature -Xclang -fma-mix-insts`; DESIGN.md 6.1)")
+    if info.get("packed_fp32_ops") != "off" and os.environ.get("PFPP_PACKED_FP32") != "1":
+        raise PfppError(f"{LIB_PATH} was built with packed fp32 instructions (packed_fp32_ops={info.get('packed_fp32_ops')}): wrong "
+                        "farthest-point samples next to co-running kernels (DESIGN.md 6).  Rebuild with pfpp_hip/build.py, or set "
+                        "PFPP_PACKED_FP32=1 to load it anyway (lab)")
+
+
 def load() -> C.CDLL:
     """dlopen libpfpp_hip.so and attach prototypes; raises if it has not been built."""
     global _lib
@@ -368,6 +397,7 @@ def load() -> C.CDLL:
         )
     _bind_torch_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
+    _attest(lib)          # ABI revision and code-generation switches first: a foreign build must not get as far as a launch
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -376,8 +406,6 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.pfpp_version() != 1:
-        raise PfppError(f"libpfpp_hip.so ABI version {lib.pfpp_version()} != 1")
     for cname, mirror in STRUCT_MIRRORS.items():
         want = lib.pfpp_abi_sizeof(cname.encode())
         if want != C.sizeof(mirror):

@@ -50,14 +50,14 @@ SOURCES = {
 # double-rounding case the two hi's differ by an fp16 ulp and hi + lo is off by 5e-4 relative.  With the mix
 # instructions unavailable every fp32 -> fp16 conversion is a plain v_cvt of the rounded fp32 value, so a split can only ever
 # see one hi.  tests/test_abi_and_host.py disassembles the library and checks that none is left.
-NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts", "-DPFPP_ATTEST_NO_MIX=1"]     # the switch and its attestation travel together (pfpp_build_info)
 # -packed-fp32-ops (target feature off): no v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 anywhere in the library.  Round 5: with them, fps_kernel
 # picked a wrong farthest point once in 10^2 .. 10^4 launches whenever a GEMM of another stream shared its CUs — the running minimum of a
 # lane's first point kept a stale value in lanes 52-61 of a wave (tools/diag/fps_race.py: 490 wrong chains in 48,000 launches
 # with the packed instructions in five different builds of the kernel, 0 in 48,000 + 8,000 in the two builds without them; exchange slots,
 # barrier flavour, LDS contents and point loads all ruled out).  The same instructions sat in the hi / lo splits of the GEMM operand
 # staging (x - hi feeding v_cvt_pk_f16_f32).  tests/test_abi_and_host.py checks the disassembly; PFPP_PACKED_FP32=1 (lab) leaves them on.
-NO_PK = [] if os.environ.get("PFPP_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NO_PK = [] if os.environ.get("PFPP_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DPFPP_ATTEST_NO_PK=1"]
 # PFPP_CHAIN_PRIO=n (lab, build time): s_setprio n in the kernels of the training step's dependency chain (csrc/pfpp_common.h)
 CHAIN_PRIO = [f"-DPFPP_CHAIN_PRIO={int(os.environ['PFPP_CHAIN_PRIO'])}"] if os.environ.get("PFPP_CHAIN_PRIO") else []
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", *NO_MIX, *NO_PK, *CHAIN_PRIO]

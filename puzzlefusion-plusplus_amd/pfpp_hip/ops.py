@@ -208,20 +208,21 @@ SINGLE_PASS = _os.environ.get("PFPP_GEMM_SINGLE_PASS", "0") == "1"
 import contextlib as _ctx
 
 
+import threading as _threading
+
 _EXACT_DEPTH = 0
-_ATTN_MODE_SET = None
+_ATTN_MODE_SET = _threading.local()      # what THIS thread last told the library (its attention mode is per calling thread)
 
 
 def _sync_attention_mode() -> None:
-    """the library's process-wide attention arithmetic (pfpp_set_attention_mode) follows this module's state: exact fp32 inside
+    """the library's attention arithmetic for this thread's launches (pfpp_set_attention_mode) follows this module's state: exact fp32 inside
     exact_fp32(), single-pass fp16 while SINGLE_PASS is on (the perf mode of BASELINE configs[4]: plane GEMMs AND attention forward
     on one fp16 matrix instruction per product), the kernels' defaults otherwise.  Called by the attention wrappers; a foreign call
     only when the state changed."""
-    global _ATTN_MODE_SET
     want = 0 if _EXACT_DEPTH > 0 else (2 if (SINGLE_PASS and GEMM_MODE == "f16x3") else -1)
-    if want != _ATTN_MODE_SET:
+    if want != getattr(_ATTN_MODE_SET, "mode", None):
         check(_lib.load().pfpp_set_attention_mode(want), "pfpp_set_attention_mode")
-        _ATTN_MODE_SET = want
+        _ATTN_MODE_SET.mode = want
 
 
 @_ctx.contextmanager
