@@ -44,19 +44,20 @@ __global__ __launch_bounds__(256 * WPS) void chains(const half8* __restrict__ in
   if (s == 1234.5f) out[0] = s;
 }
 
+static int g_grid = 256;
 template <int NC, int FILL, int WPS, bool SMALL>
 void run(const half8* in, float* out) {
   const int iters = 2000;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((chains<NC, FILL, WPS, SMALL>), dim3(256), dim3(256 * WPS), 0, 0, in, out, iters);
+  hipLaunchKernelGGL((chains<NC, FILL, WPS, SMALL>), dim3(g_grid), dim3(256 * WPS), 0, 0, in, out, iters);
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((chains<NC, FILL, WPS, SMALL>), dim3(256), dim3(256 * WPS), 0, 0, in, out, iters);
+  hipLaunchKernelGGL((chains<NC, FILL, WPS, SMALL>), dim3(g_grid), dim3(256 * WPS), 0, 0, in, out, iters);
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double n = (double)iters * (24 / NC) * NC * WPS;     // matrix instructions per SIMD
   const double flops = SMALL ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2;
-  printf("%s chains %d fill %d waves/SIMD %d: %.1f ns per instruction per SIMD = %.1f cycles at 2.4 GHz; chip %.0f TFLOP/s\n", SMALL ? "16x16x32" : "32x32x16", NC, FILL, WPS,
-         ms * 1e6 / n, ms * 1e6 / n * 2.4, n * 1024 * flops / (ms * 1e-3) * 1e-12);
+  printf("grid %3d %s chains %d fill %d waves/SIMD %d: %.1f ns per instruction per SIMD = %.1f cycles at 2.4 GHz; chip %.0f TFLOP/s\n", g_grid, SMALL ? "16x16x32" : "32x32x16", NC, FILL, WPS,
+         ms * 1e6 / n, ms * 1e6 / n * 2.4, n * 4 * g_grid * flops / (ms * 1e-3) * 1e-12);
 }
 
 int main() {
@@ -66,6 +67,8 @@ int main() {
   unsigned s = 12345;
   for (int i = 0; i < 1024; ++i) { s = s * 1664525u + 1013904223u; h[i] = (_Float16)(((s >> 8) & 0xffff) / 32768.0f - 1.0f); }
   CK(hipMemcpy(in, h, 2048, hipMemcpyHostToDevice));
+  for (int g : {64, 128, 160, 192, 224, 256}) { g_grid = g; run<4, 0, 1, false>(in, out); run<4, 0, 2, false>(in, out); }
+  g_grid = 256;
   run<1, 0, 1, false>(in, out); run<2, 0, 1, false>(in, out); run<3, 0, 1, false>(in, out); run<4, 0, 1, false>(in, out); run<6, 0, 1, false>(in, out); run<8, 0, 1, false>(in, out);
   run<2, 1, 1, false>(in, out); run<2, 2, 1, false>(in, out); run<4, 2, 1, false>(in, out); run<6, 2, 1, false>(in, out);
   run<2, 0, 2, false>(in, out); run<2, 2, 2, false>(in, out); run<4, 0, 2, false>(in, out);
