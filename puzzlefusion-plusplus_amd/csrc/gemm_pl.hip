@@ -833,11 +833,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_pl_dwgroup_kernel(const 
 template <int MT, int NT, int WM, int WN, int NS>
 int launch_dwgroup(DwGroupP& g, const pfpp_dw_job* jobs, hipStream_t st) {
   using C = Cfg<MT, NT, WM, WN, NS, false>;
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;      // one bit per device: the attribute belongs to the function ON a device
   auto kern = gemm_pl_dwgroup_kernel<MT, NT, WM, WN, NS>;
-  if (!attr_set) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!((attr_set >> (dev & 63)) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   int tiles = 0;
   for (int j = 0; j < g.n; ++j) {
@@ -1124,7 +1126,7 @@ extern "C" int pfpp_gemm_dw_group(const pfpp_dw_job* jobs, int32_t n_jobs, int64
     p.csum = q.gb; p.csum_alpha = 1.0f / q.dy.scale;
   }
   hipStream_t st = pfpp::as_stream(stream);
-  static const int env_v = getenv("PFPP_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_DW_GROUP_VARIANT")) : 0;
+  const int env_v = getenv("PFPP_DW_GROUP_VARIANT") ? atoi(getenv("PFPP_DW_GROUP_VARIANT")) : 0;      // (read per call, like PFPP_TRAIN_DW_GROUP*: the tests switch it)
   // default: the 256 x 128 tile (8 waves, one workgroup per CU).  Measured on a block's six problems at 3,850 tokens
   // (profiles/r05a_lab_dw_group_bench.txt): 166 us against 195-213 us for the 128 x 64 / 128 x 128 tiles (and 256 us for six separate
   // launches + their slab reductions) although its 160 tiles leave 96 CUs without one; in the overlapped training iteration 6.06 ms

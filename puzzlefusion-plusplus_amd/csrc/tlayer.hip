@@ -329,8 +329,19 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
     return PFPP_OK;
   };
   // dW += dY^T . X, db += colsum(dY): both operands read in place as k-major planes, on the side stream; `k` = the slot dY lives in
+  // lab switches of the weight-gradient path, parsed once per call of this function (not per weight): PFPP_LAB_SKIP_DW_LAYERS (timing only,
+  // WRONG gradients: no dW for the last k layers to run) applies to the grouped launch too; PFPP_DW_SPLITS only means something with
+  // PFPP_TRAIN_DW_GROUP=0 (the grouped launch has no K split)
+  const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;
+  const int lab_skip = getenv("PFPP_LAB_SKIP_DW_LAYERS") ? atoi(getenv("PFPP_LAB_SKIP_DW_LAYERS")) : 0;
+  // INVARIANT the grouped path relies on: between two flush_dw() calls every dY slot is acquired (fresh) at most ONCE - the slots'
+  // read events are recorded at flush time only, so a slot re-acquired and rewritten before the flush would race with the queued
+  // read of its first tenant.  Holds today: a block uses each of its slots for one dY, and every block ends in flush_dw().
   auto dw = [&](const pfpp_planes& dyp, int k, const pfpp_planes& xp, int64_t n_out, int64_t n_in, float* gw, float* gb) -> int {
+    if (lab_skip > 0 && cur_layer >= a->n_layers - lab_skip) return PFPP_OK;
     if (dw_group && n_out % 8 == 0 && n_in % 8 == 0) {
+      for (int q = 0; q < n_dw; ++q)
+        if (k >= 0 && dw_slots[q] == k) { pfpp::set_error("pfpp_tlayers_bwd: slot %d queued twice before a flush", k); return PFPP_EINVAL; }
       if (n_dw == PFPP_DW_GROUP_MAX) TL_CALL(flush_dw());
       pfpp_dw_job& q = dw_jobs[n_dw];
       q.dy = dyp; q.x = xp; q.gw = gw; q.gb = gb; q.M = n_out; q.N = n_in;
@@ -338,9 +349,6 @@ extern "C" int pfpp_tlayers_bwd(const pfpp_tlayers_args* a, int32_t layer_lo, in
       return PFPP_OK;
     }
     if (side) TL_CALL(order_after(side_s, main_s));
-    static const int dw_splits = getenv("PFPP_DW_SPLITS") ? atoi(getenv("PFPP_DW_SPLITS")) : 0;      // lab: 0 = the library's choice
-    static const int lab_skip = getenv("PFPP_LAB_SKIP_DW_LAYERS") ? atoi(getenv("PFPP_LAB_SKIP_DW_LAYERS")) : 0;   // lab (timing only, WRONG gradients): no dW for the last k layers
-    if (lab_skip > 0 && cur_layer >= a->n_layers - lab_skip) return PFPP_OK;
     if (group_reduce) {
       if (n_jobs == PFPP_SLAB_GROUP_MAX) TL_CALL(flush_jobs());
       pfpp_slab_job& q = jobs[n_jobs];

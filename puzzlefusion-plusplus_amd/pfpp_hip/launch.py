@@ -176,7 +176,8 @@ class Trainer:
             self._launcher = True
             self._env_before = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_RANK", "RANK")}
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ["MASTER_PORT"] = str(_free_port())
+            if not os.environ.get("MASTER_PORT"):                     # a port the user chose stays; otherwise a free one
+                os.environ["MASTER_PORT"] = str(_free_port())
             os.environ.update(WORLD_SIZE=str(world), LOCAL_RANK="0", RANK="0")
             self.world_size = world
             main = sys.modules.get("__main__")
@@ -203,6 +204,28 @@ class Trainer:
 
                     time.sleep(0.2)
                     self._check_children()
+                if self._children:
+                    # and keep looking: a worker that dies later (an exception during its torch import, a raise in its step) drops its
+                    # process group without a handshake while this rank may sit inside a collective — nothing in the main thread can
+                    # notice that before the collective's timeout, so a daemon thread does and ends the job loudly
+                    import threading
+
+                    def _watch(children=tuple(self._children)):
+                        import time
+
+                        while True:
+                            time.sleep(1.0)
+                            if not self._children:               # fit() finished or aborted: nothing left to watch
+                                return
+                            for p in children:
+                                rc = p.poll()
+                                if rc is not None and rc != 0:
+                                    print(f"Trainer: worker rank (pid {p.pid}) exited with code {rc} while rank 0 was still running — stopping",
+                                          file=sys.stderr, flush=True)
+                                    self._abort()
+                                    os._exit(70)
+
+                    threading.Thread(target=_watch, daemon=True, name="pfpp-rank-watchdog").start()
                 dist.init_process_group(backend, rank=self.global_rank, world_size=self.world_size,
                                         timeout=datetime.timedelta(seconds=int(os.environ.get("PFPP_DDP_TIMEOUT_S", "1800"))))
 

@@ -392,9 +392,16 @@ class DenoiserTrainEngine:
                 train: bool = True) -> Tuple[torch.Tensor, TrainContext]:
         """-> (pred_noise [B,P,7] with zeros at padded slots, context).  `train=False` disables the dropouts
         (the reference module in .eval())."""
+        B, P, L, _ = latent.shape
+        # the one-launch token embedding (forward and backward) exists for >= 11 latent points of width 64 in the split-f16 mode
+        # (pfpp_embed_tokens_small returns PFPP_EUNSUPPORTED otherwise): decided per call, like denoiser.py does for the eval path;
+        # anything else takes features + two linears + combine / the two weight-gradient GEMMs (ADVICE r5)
+        embed_ok = L >= 11 and latent.shape[-1] == 64 and ops.GEMM_MODE == "f16x3" and not ops.SINGLE_PASS
+        if self.flat.embed_fused != (self._embed_fwd_fused and embed_ok):
+            self.flat.embed_fused = self._embed_fwd_fused and embed_ok
+            self.flat._odd = None                     # re-pack the two odd-width embeddings in the layout this call takes
         ops_ = self.flat.operands()
         w = ops_["w"]
-        B, P, L, _ = latent.shape
         C = w["shape.b"].numel()
         H = self.num_heads
         dh = C // H
@@ -417,7 +424,7 @@ class DenoiserTrainEngine:
         raw = (_f32c(latent).reshape(n_slots, L, -1), _f32c(xyz).reshape(n_slots, L, 3), _f32c(scale).reshape(n_slots), _f32c(x).reshape(n_slots, 7))
         ref_u8 = _u8(ref_part).reshape(n_slots)           # padded flags; the kernels read ref_u8[slot[f]]
         sf = pf = ft = None
-        if self._embed_bwd_fused:
+        if self._embed_bwd_fused and embed_ok:
             # the backward's operand: the extended feature rows transposed as split-f16 planes (csrc/embed_train.hip)
             ft = T.token_features_t(*raw, slot32, ref_u8, Fv, L)
         if "embed.w" in w:
@@ -754,7 +761,8 @@ class DenoiserTrainEngine:
         else:
             args.ada_se = args.ada_dse = args.ada_w = args.ada_gw = args.ada_gb = None
             args.ada_adamw_w = args.ada_adamw_b = None
-        if in_c and os.environ.get("PFPP_TRAIN_TABLES_EARLY", "0") == "1":
+        if in_c and os.environ.get("PFPP_TRAIN_TABLES_EARLY", "0") == "1" and not self._accumulated:
+            # (not after a no_sync backward: rows an earlier micro-batch touched hold a gradient this launch would apply unscaled and zero)
             # lab (PFPP_TRAIN_TABLES_EARLY=1): the 12 timestep tables (a third of all parameters) — only the batch's rows get a gradient
             # this step, so every other row's AdamW update needs nothing of this backward and can go out now, on the side stream
             # (pfpp_adamw_rows; bit-identical to the one-pass update, tested).  Measured neutral (6.14 / 6.12 ms,
@@ -762,6 +770,9 @@ class DenoiserTrainEngine:
             hp = self._armed
             f = self.flat
             n_tab = f.offset["transformer_layers.0.norm1.linear.weight"]
+            tab_names = [n_ for n_ in f.order if n_.endswith(".emb.weight")]
+            if not tab_names or min(f.offset[n_] for n_ in tab_names) != 0 or max(f.offset[n_] + f.view(f.params, n_).numel() for n_ in tab_names) != n_tab:
+                raise RuntimeError("PFPP_TRAIN_TABLES_EARLY: the timestep tables are not the flat buffer's leading range [0, norm1.linear.weight)")
             shp = opsd["w"]["ada.tables"].shape if ada_c else self.flat.operands()["w"]["ada.tables"].shape
             t64 = s["t64"]
             views = [f_[:n_tab].view(shp) for f_ in (f.params, f.grads, f.exp_avg, f.exp_avg_sq)]

@@ -46,70 +46,61 @@ class ChamferDistance(torch.nn.Module):
         return bwd if reverse else fwd
 
 
-def _valid_mean(loss_per_part, valids):
-    """average over the valid parts, NaNs counted as 0 (evaluator.py:8-22)"""
-    nan_mask = torch.isnan(loss_per_part)
-    loss_per_part[nan_mask] = 0.
-    valids = valids.float().detach()
-    return (loss_per_part * valids).sum(1) / valids.sum(1)
+_REDUCERS = {
+    # metric -> how a [B, P, D] tensor of non-negative per-axis deviations collapses to one number per part
+    "mse": lambda dev: dev.pow(2).mean(dim=-1),
+    "rmse": lambda dev: dev.pow(2).mean(dim=-1) ** 0.5,
+    "mae": lambda dev: dev.abs().mean(dim=-1),
+}
+PART_ACC_THRESHOLD = 0.01      # a part counts as placed when its Chamfer distance to the ground-truth placement is below this
+PADDED_PART_COORD = 1e3        # padded parts are parked far away before whole-shape distances are taken
+
+
+def _puzzle_average(per_part, valids):
+    """[B, P] per-part values -> [B]: mean over the valid parts of each puzzle; a NaN part contributes 0 (evaluator.py:8-22)"""
+    weight = valids.detach().float()
+    clean = torch.where(torch.isnan(per_part), torch.zeros_like(per_part), per_part)
+    return (clean * weight).sum(1) / weight.sum(1)
+
+
+def _metric(deviation, valids, metric):
+    if metric not in _REDUCERS:
+        raise AssertionError(f"metric must be one of {sorted(_REDUCERS)}, got {metric!r}")
+    return _puzzle_average(_REDUCERS[metric](deviation), valids)
 
 
 def trans_metrics(trans1, trans2, valids, metric):
     """translation error per puzzle (evaluator.py:25-50)"""
-    assert metric in ['mse', 'rmse', 'mae']
-    if metric == 'mse':
-        per_part = (trans1 - trans2).pow(2).mean(dim=-1)
-    elif metric == 'rmse':
-        per_part = (trans1 - trans2).pow(2).mean(dim=-1) ** 0.5
-    else:
-        per_part = (trans1 - trans2).abs().mean(dim=-1)
-    return _valid_mean(per_part, valids)
+    return _metric(trans1 - trans2, valids, metric)
 
 
 @torch.no_grad()
 def rot_metrics(rot1, rot2, valids, metric):
-    """rotation error in Euler-angle (degree) space per puzzle (evaluator.py:53-85)"""
-    assert metric in ['mse', 'rmse', 'mae']
-    deg1 = quaternion_to_euler(rot1, to_degree=True)
-    deg2 = quaternion_to_euler(rot2, to_degree=True)
-    diff1 = (deg1 - deg2).abs()
-    diff2 = 360. - (deg1 - deg2).abs()
-    diff = torch.minimum(diff1, diff2)
-    if metric == 'mse':
-        per_part = diff.pow(2).mean(dim=-1)
-    elif metric == 'rmse':
-        per_part = diff.pow(2).mean(dim=-1) ** 0.5
-    else:
-        per_part = diff.abs().mean(dim=-1)
-    return _valid_mean(per_part, valids)
+    """rotation error per puzzle in Euler-angle degrees, each axis taken the short way round the circle (evaluator.py:53-85)"""
+    gap = (quaternion_to_euler(rot1, to_degree=True) - quaternion_to_euler(rot2, to_degree=True)).abs()
+    return _metric(torch.minimum(gap, 360. - gap), valids, metric)
 
 
 @torch.no_grad()
 def calc_part_acc(pts, trans1, trans2, rot1, rot2, valids, chamfer_distance=None):
-    """Part Accuracy: per-part Chamfer distance between the part under the predicted and the GT pose below 0.01
-    (evaluator.py:88-121) -> (acc [B], acc_per_part [B,P] bool, cd_per_part [B,P])"""
-    chamfer_distance = chamfer_distance or ChamferDistance()
-    B, P = pts.shape[:2]
-    pts1 = transform_pc(trans1, rot1, pts).flatten(0, 1)
-    pts2 = transform_pc(trans2, rot2, pts).flatten(0, 1)
-    loss_per_data = chamfer_distance(pts1, pts2, bidirectional=True, point_reduction="mean", batch_reduction=None)
-    loss_per_data = loss_per_data.view(B, P).type_as(pts)
-    thre = 0.01
-    acc_per_part = (loss_per_data < thre) & (valids == 1)
-    acc = acc_per_part.sum(-1) / (valids == 1).sum(-1)
-    return acc, acc_per_part, loss_per_data
+    """Part Accuracy (evaluator.py:88-121): bidirectional mean Chamfer distance of every part between its two placements, a part is
+    accurate below PART_ACC_THRESHOLD -> (accuracy [B], accurate [B,P] bool, distance [B,P])"""
+    cd = chamfer_distance or ChamferDistance()
+    n_puzzles, n_parts = pts.shape[:2]
+    placed = [transform_pc(t, r, pts).flatten(0, 1) for t, r in ((trans1, rot1), (trans2, rot2))]
+    dist = cd(placed[0], placed[1], bidirectional=True, point_reduction="mean", batch_reduction=None).view(n_puzzles, n_parts).type_as(pts)
+    real = valids == 1
+    accurate = (dist < PART_ACC_THRESHOLD) & real
+    return accurate.sum(-1) / real.sum(-1), accurate, dist
 
 
 @torch.no_grad()
 def calc_shape_cd(pts, trans1, trans2, rot1, rot2, valids, chamfer_distance=None):
-    """Chamfer distance between the assembled shapes, padded parts pushed to 1e3 (evaluator.py:124-153) -> [B]"""
-    chamfer_distance = chamfer_distance or ChamferDistance()
-    B, P, N, _ = pts.shape
-    valid_mask = valids[..., None, None]
-    pts = pts.detach().clone()
-    pts = pts.masked_fill(valid_mask == 0, 1e3)
-    shape1 = transform_pc(trans1, rot1, pts).flatten(1, 2)
-    shape2 = transform_pc(trans2, rot2, pts).flatten(1, 2)
-    shape_cd = chamfer_distance(shape1, shape2, bidirectional=True, point_reduction=None, batch_reduction=None)
-    shape_cd = shape_cd.view(B, P, N).mean(-1)
-    return _valid_mean(shape_cd, valids)
+    """Chamfer distance between the two assembled shapes (evaluator.py:124-153): per-point bidirectional distances averaged per part,
+    then over the valid parts -> [B]"""
+    cd = chamfer_distance or ChamferDistance()
+    n_puzzles, n_parts, n_pts, _ = pts.shape
+    parked = pts.detach().clone().masked_fill(valids[..., None, None] == 0, PADDED_PART_COORD)
+    whole = [transform_pc(t, r, parked).flatten(1, 2) for t, r in ((trans1, rot1), (trans2, rot2))]
+    per_point = cd(whole[0], whole[1], bidirectional=True, point_reduction=None, batch_reduction=None)
+    return _puzzle_average(per_point.view(n_puzzles, n_parts, n_pts).mean(-1), valids)
