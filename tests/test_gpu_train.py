@@ -1446,6 +1446,61 @@ def test_blocks_sequenced_from_c_equal_the_python_sequence(golden, weights_sd, d
     assert moved < 1e-3
 
 
+def test_second_step_gradient_slack_is_adam_sign_flips_at_noise_level_gradients(golden, weights_sd, dev, monkeypatch):
+    """VERDICT r5 weak 2, the measurement behind the 5 x tolerance of the test above.  Python-sequenced and C-sequenced engines side by
+    side: after ONE optimizer step their parameters differ only where the first step's gradient element is noise (Adam's first update
+    is lr * sign(g): an element whose gradient is a rounding residue around zero can take opposite signs on the two sides) — measured
+    here as: every parameter that differs lies where |g| < 1e-4 of its tensor's largest gradient.  And when the second step starts
+    from IDENTICAL weights and moments (copied across), its gradients agree to the first step's tolerance again — so the slack of
+    the trajectory test is the weight difference, not the sequencer."""
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    monkeypatch.setenv("PFPP_TRAIN_WD", "0")
+    monkeypatch.setenv("PFPP_TRAIN_DW_GROUP", "0")
+    inp, noise, _ = golden_inputs(golden, dev)
+    hp = dict(lr=1e-3, weight_decay=1e-2)
+    engs = []
+    for cseq in (False, True):
+        e = DenoiserTrainEngine(make_module(weights_sd, dev))
+        e._cseq = cseq
+        engs.append(e)
+
+    def step(e, seed):
+        e.flat.zero_grad()
+        pred, ctx = e.forward(*inp, seed=seed, train=True)
+        n = pred.shape[0] * pred.shape[1]
+        e.backward(ctx, ((pred - noise).reshape(n, 7).float() * (2.0 / n)).contiguous())
+        torch.cuda.synchronize()
+        return e.flat.grads.clone()
+
+    g_py, g_c = step(engs[0], 11), step(engs[1], 11)
+    assert rel(g_c, g_py.cpu()) < 2e-6
+    for e in engs:
+        e.optimizer_step(**hp)
+    torch.cuda.synchronize()
+    w_py, w_c = engs[0].flat.params, engs[1].flat.params
+    differs = (w_py - w_c).abs() > 1e-6
+    n_diff = int(differs.sum())
+    worst = 0.0
+    f = engs[0].flat
+    for name in f.order:                                        # gradient of the differing elements relative to their tensor's largest
+        d = f.view(differs, name)
+        if bool(d.any()):
+            g = f.view(g_py, name)
+            worst = max(worst, float(g[d].abs().max() / g.abs().max()))
+    print(f"{n_diff} of {w_py.numel()} parameters differ after one step; largest |g| / max|g| among them: {worst:.2e}")
+    assert n_diff < 1e-3 * w_py.numel() and worst < 1e-4
+    # the second step from identical state: the C sequencer's gradients are back inside the first step's tolerance
+    with torch.no_grad():
+        for a, b in ((engs[1].flat.params, engs[0].flat.params), (engs[1].flat.exp_avg, engs[0].flat.exp_avg),
+                     (engs[1].flat.exp_avg_sq, engs[0].flat.exp_avg_sq)):
+            a.copy_(b)
+    engs[1].flat.refresh_planes()
+    engs[0].flat.refresh_planes()
+    g_py2, g_c2 = step(engs[0], 12), step(engs[1], 12)
+    assert rel(g_c2, g_py2.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_fused_embedding_and_adaln_ends_equal_the_layerwise_path(golden, weights_sd, dev, train, monkeypatch):
     """VERDICT r4 'do this' 5: the training step's skinny ends — token embedding forward in one launch on the packed [W_shape | W_param]
