@@ -83,6 +83,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
     headers = [INCLUDE / "pfpp.h", CSRC / "pfpp_common.h", CSRC / "gemm_common.h", CSRC / "sa_common.h"]
+    # the linked library newer than every source and header: nothing to do — also where the object files did not travel (the GPU box
+    # gets libpfpp_hip.so but not csrc/build/, .gpurunignore): without this a test fixture there would recompile all 25 units
+    if not force and not _stale(LIB_PATH, [CSRC / src for src in SOURCES] + headers):
+        return LIB_PATH
     objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = CSRC / src
