@@ -2,8 +2,8 @@
 # N consecutive runs of the whole -m gpu suite on one box (no retry wrapper, every run must be green)
 cd $GRAFT_REPO_ROOT
 N=${1:-25}; TAG=${2:-A}
-mkdir -p gpurun_out/r05x
-OUT=gpurun_out/r05x/suite_loop_$TAG.txt
+mkdir -p gpurun_out/suite
+OUT=gpurun_out/suite/suite_loop_$TAG.txt
 : > $OUT
 for i in $(seq 1 $N); do
   t0=$(date +%s)
