@@ -1,6 +1,7 @@
 """dense (global) attention of the benchmarked batch stand-alone: forward (with lse), backward (dq + dk/dv passes) timed with one event
-pair around N back-to-back calls, PFPP_ATTN_PF2 = 0 / 1 (the distance-2 row prefetch of round 6) in the same process; results compared
-bit for bit.     python tools/diag/attn_time.py [reps]"""
+pair around N back-to-back calls, with an environment switch at 0 / 1 in the same process (PFPP_ATTN_AB names it; round 6 used it for two
+experiments that are not in the library: a distance-2 row prefetch and 8-wave workgroups) and results compared bit for bit; then the time
+by sequence length.     PFPP_ATTN_AB=PFPP_SOME_SWITCH python tools/diag/attn_time.py [reps]"""
 import os
 import sys
 from pathlib import Path
@@ -39,15 +40,15 @@ def timed(fn):
 
 
 res = {}
-for pf in ("1",):
-    os.environ["PFPP_ATTN_PF2"] = pf
+for pf in ("0", "1", "0", "1"):
+    os.environ[os.environ.get("PFPP_ATTN_AB", "PFPP_ATTN_AB_UNUSED")] = pf
     out, outp, lse = T.attn_dense_train_planes(qkv, seq_off, seq_len, max_len, H, dh, scale)
     dq = T.attn_dense_bwd_planes(qkv, out, dout, lse, seq_off, seq_len, max_len, H, dh, scale, 4096.0)
     t_f = timed(lambda: T.attn_dense_train_planes(qkv, seq_off, seq_len, max_len, H, dh, scale))
     t_b = timed(lambda: T.attn_dense_bwd_planes(qkv, out, dout, lse, seq_off, seq_len, max_len, H, dh, scale, 4096.0))
-    print(f"PFPP_ATTN_PF2={pf}: forward {t_f:6.1f} us   backward (dq + dkv) {t_b:6.1f} us")
+    print(f"switch={pf}: forward {t_f:6.1f} us   backward (dq + dkv) {t_b:6.1f} us")
     res.setdefault(pf, (out.clone(), lse.clone(), dq.hi.clone(), dq.lo.clone()))
-same = True
+same = all(torch.equal(a, b) for a, b in zip(res["0"], res["1"]))
 print("results bit-identical between the two:", same)
 
 # per-tile cost of the walk: 32 sequences of one uniform length each (32 keys per tile)
