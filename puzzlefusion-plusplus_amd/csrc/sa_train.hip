@@ -36,6 +36,33 @@ struct SaTP {
   int N, S, G;
   const float* u; int D;       // first layer applied per point (pfpp_sa_train_args.u_in); feature count of the level
   _Float16* e_hi; _Float16* e_lo;      // eval form: output planes
+  const int32_t* sched;                // pfpp_sa_pad_schedule of idx (64-neighbour levels) or null
+};
+
+// Padding-aware walk over the neighbourhoods of a 64-neighbour level.  The ball query (utils/pn2_utils.py:103-123) lists the points in range
+// in ascending order and fills the rest of the nsample slots with the FIRST of them, so with at most 32 points in range rows 32..63 of the
+// neighbourhood are 32 copies of its row 0 (the schedule tests exactly that — slots 32..63 all equal to slot 0 — not the count): their pre-activations equal row 0's in every layer, they add 32 y_0 and 32 y_0^2 to the batch
+// sums and nothing to the max / min.  The rows kernels take such a neighbourhood as ONE half; its second half is neither computed nor
+// (stage 2) written nor (stage 3) read.  On the benchmarked batch that is 48 % of level 2's neighbourhoods and 12 % of level 3's.
+// sched [G + 1] (pfpp_sa_pad_schedule): the two-half neighbourhoods, then the one-half ones (ascending inside each class), and their
+// split point in sched[G].  Wave k of S takes positions k, k + S, ... of the first class and goes on round-robin through the second where
+// the first stopped, so every wave's work differs by at most one half from its neighbours' — a static, run-to-run identical partition.
+struct PadWalk {
+  const int32_t* order;
+  int G, n2, S, i, ib;
+  __device__ __forceinline__ PadWalk(const int32_t* sched, int G_, int k, int S_) : order(sched), G(G_), S(S_), i(k) {
+    n2 = sched ? sched[G_] : G_;
+    const int r = n2 % S_;
+    ib = n2 + (k >= r ? k - r : k - r + S_);
+    if (i >= n2) i = ib;
+  }
+  __device__ __forceinline__ bool two() const { return i < n2; }
+  // neighbourhood at the current position (G = past the end: the callers' loaders clamp it)
+  __device__ __forceinline__ int g() const { return i < G ? (order ? order[i] : i) : G; }
+  __device__ __forceinline__ void next() {
+    const int j = i + S;
+    i = (i < n2 && j >= n2) ? ib : j;
+  }
 };
 
 // train-mode BatchNorm + ReLU of a transposed tile (lane = sample): channel of register e is c0 + (e&3) + 8*(e>>2) + 4*lhi;
@@ -654,12 +681,18 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
     }
   };
   float4 raw[K / 16][2];
-  load_rows(g0, 0, raw);
+  // the walk runs two neighbourhoods ahead of the rows (the schedule entry of g2 is in flight while g is multiplied)
+  PadWalk wk(p.sched, p.G, g0, stride);
+  int g = wk.g(); bool two = wk.two(); wk.next();
+  int g1 = wk.g(); bool two1 = wk.two(); wk.next();
+  int g2 = wk.g(); bool two2 = wk.two();
+  load_rows(g, 0, raw);
   float mx[N / 32], mn[N / 32];
 
-  for (int g = g0; g < p.G; g += stride) {
+  for (; g < p.G; g = g1, two = two1, g1 = g2, two1 = two2, wk.next(), g2 = wk.g(), two2 = wk.two()) {
+    const int nh = two ? 2 : 1;
 #pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < nh; ++h) {
       asm volatile("" ::: "memory");
       half8 fh[K / 16], fl[K / 16];
 #pragma unroll
@@ -678,8 +711,8 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
         }
       }
       // the next half's rows are in flight during this one's contraction
-      if (h == 0) load_rows(g, 1, raw);
-      else load_rows(g + stride, 0, raw);
+      if (h + 1 < nh) load_rows(g, 1, raw);
+      else load_rows(g1, 0, raw);
 #pragma unroll 1
       for (int n = 0; n < N / 32; ++n) {
         f32x16 acc;
@@ -703,9 +736,14 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
         }
         ss[n] += (double)s;
         sq[n] += (double)q;
-        if (h == 0) { mx[n] = hi; mn[n] = lo; }
+        if (nh == 1) {      // rows 32..63 are copies of row 0 (register 0 of the lower lane half)
+          const double y0 = lhi == 0 ? (double)(acc[0] + bs[n]) : 0.0;
+          ss[n] += 32.0 * y0;
+          sq[n] += 32.0 * y0 * y0;
+        }
+        if (h + 1 < nh) { mx[n] = hi; mn[n] = lo; }
         else {
-          hi = fmaxf(hi, mx[n]); lo = fminf(lo, mn[n]);
+          if (h == 1) { hi = fmaxf(hi, mx[n]); lo = fminf(lo, mn[n]); }
           hi = fmaxf(hi, __shfl_xor(hi, 32));
           lo = fminf(lo, __shfl_xor(lo, 32));
           if (lhi == 0) {
@@ -839,9 +877,15 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   };
   float4 raw[K / 16][2];
   float qx[3] = {0.f, 0.f, 0.f}, cx[3] = {0.f, 0.f, 0.f};
-  load_half(g0, 0, raw, qx, cx);
+  // padding-aware walk (PadWalk), two neighbourhoods ahead of the rows; the eval form writes every row for the next layer's plane GEMM
+  PadWalk wk(EVAL ? nullptr : p.sched, p.G, g0, stride);
+  int g = wk.g(); bool two = wk.two(); wk.next();
+  int g1 = wk.g(); bool two1 = wk.two(); wk.next();
+  int g2 = wk.g(); bool two2 = wk.two();
+  load_half(g, 0, raw, qx, cx);
 
-  for (int g = g0; g < p.G; g += stride) {
+  for (; g < p.G; g = g1, two = two1, g1 = g2, two1 = two2, wk.next(), g2 = wk.g(), two2 = wk.two()) {
+    const int nh = two ? 2 : 1;
     float mx[4], mn[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { mx[n] = -__builtin_huge_valf(); mn[n] = __builtin_huge_valf(); }
@@ -855,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
       }
     }
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < nh; ++half) {
       asm volatile("" ::: "memory");
       half8 fh[KS], fl[KS];
 #pragma unroll
@@ -889,7 +933,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         }
       }
       // the rows of the next half (or of the next neighbourhood) travel during this half's contraction
-      if (half == 0) load_half(g, 1, raw, qx, cx); else load_half(g + stride, 0, raw, qx, cx);
+      if (half + 1 < nh) load_half(g, 1, raw, qx, cx); else load_half(g1, 0, raw, qx, cx);
       f32x16 acc[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n)
@@ -940,6 +984,11 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         }
         ss[n] += (double)s;
         sq[n] += (double)q;
+        if (nh == 1) {      // rows 32..63 are copies of row 0 (register 0 of the lower lane half): 32 y_0, 32 y_0^2
+          const double y0 = lhi == 0 ? (double)(acc[n][0] + bs[n]) : 0.0;
+          ss[n] += 32.0 * y0;
+          sq[n] += 32.0 * y0 * y0;
+        }
       }
     }
     if (LAYER == 3) {
@@ -993,19 +1042,33 @@ __global__ __launch_bounds__(256) void sa_first_stats_kernel(const SaTP p) {
       s[c] = 0.0f; q[c] = 0.0f;
     }
     const float* ub = p.u + (int64_t)f * p.N * K + lane * CPL;
-#pragma unroll 16
-    for (int j = 0; j < 64; ++j) {
-      const int idj = __shfl(id, j);
-      const vecf r = *reinterpret_cast<const vecf*>(ub + (int64_t)idj * K);
+    // the points in range come first, the rest of the 64 slots repeat slot 0 (see PadWalk): the rows are gathered in runs of 16 (all
+    // loads of a run in flight together) up to the last slot that differs from slot 0; the copies of row 0 beyond the last run enter
+    // the sums as n y_0 and n y_0^2
+    const int id0 = __shfl(id, 0);
+    const unsigned long long live = __ballot(id != id0);
+    const int runs = live ? (64 - __clzll(live) + 15) >> 4 : 1;
+    const vecf r0 = *reinterpret_cast<const vecf*>(ub + (int64_t)id0 * K);
+    float y0[CPL];
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const float y = r[c] - v[c];
-        s[c] += y;
-        q[c] = __builtin_fmaf(y, y, q[c]);
+    for (int c = 0; c < CPL; ++c) y0[c] = r0[c] - v[c];
+#pragma unroll 1
+    for (int j0 = 0; j0 < runs * 16; j0 += 16) {
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int idj = __shfl(id, j0 + jj);
+        const vecf r = *reinterpret_cast<const vecf*>(ub + (int64_t)idj * K);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const float y = r[c] - v[c];
+          s[c] += y;
+          q[c] = __builtin_fmaf(y, y, q[c]);
+        }
       }
     }
+    const double np = (double)(64 - runs * 16);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { ss[c] += (double)s[c]; sq[c] += (double)q[c]; }
+    for (int c = 0; c < CPL; ++c) { ss[c] += (double)s[c] + np * (double)y0[c]; sq[c] += (double)q[c] + np * (double)y0[c] * (double)y0[c]; }
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) { red[0][wave][lane * CPL + c] = ss[c]; red[1][wave][lane * CPL + c] = sq[c]; }
@@ -1071,7 +1134,62 @@ __global__ __launch_bounds__(256) void sa_table_apply_kernel(const SaTP p) {
   }
 }
 
+// pfpp_sa_pad_schedule, two launches.  (1) one thread per neighbourhood, all CUs: flag = some slot of 32..63 differs from slot 0 (for a
+// ball query's list <=> more than 32 points in range; checked slot by slot, so the skip is exact for ANY index list) — two cache
+// lines per neighbourhood; a single workgroup fetching all of them through one CU's L2 port took 75 us at 19,712 neighbourhoods.  (2) one workgroup over the flags:
+// thread t takes a contiguous run, an exclusive scan of the per-thread counts places the two-half neighbourhoods in ascending order at
+// the front and the one-half ones behind them.
+__global__ __launch_bounds__(256) void sa_pad_flags_kernel(const int32_t* __restrict__ idx, int G, int32_t* __restrict__ flags) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const int id0 = idx[(int64_t)g * 64];
+  const int4* h2 = reinterpret_cast<const int4*>(idx + (int64_t)g * 64 + 32);      // one 128-byte line
+  int live = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int4 v = h2[i];
+    live |= (v.x != id0) | (v.y != id0) | (v.z != id0) | (v.w != id0);
+  }
+  flags[g] = live;
+}
+
+__global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __restrict__ flags, int G, int32_t* __restrict__ sched) {
+  __shared__ int sc[1024];
+  const int t = threadIdx.x;
+  const int per = (G + 1023) / 1024;
+  const int b = t * per < G ? t * per : G, e = b + per < G ? b + per : G;
+  int n = 0;
+  for (int g = b; g < e; ++g) n += flags[g];
+  sc[t] = n;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? sc[t - d] : 0;
+    __syncthreads();
+    sc[t] += v;
+    __syncthreads();
+  }
+  const int total2 = sc[1023];
+  int a = sc[t] - n;                    // two-half neighbourhoods before this thread's run
+  int o = total2 + (b - a);             // one-half ones before it, behind all the two-half ones
+  for (int g = b; g < e; ++g) {
+    if (flags[g]) sched[a++] = g;
+    else sched[o++] = g;
+  }
+  if (t == 0) sched[G] = total2;
+}
+
 }  // namespace
+
+extern "C" int pfpp_sa_pad_schedule(const int32_t* idx, int64_t G, int64_t ns, int32_t* sched, pfpp_stream_t stream) {
+  PFPP_REQUIRE(idx && sched && G >= 0, "null pointer / negative size");
+  PFPP_SUPPORTED(ns == 64, "the padding schedule is for 64-neighbour levels (two halves of 32 rows)");
+  PFPP_REQUIRE(G < (1ll << 25), "too many neighbourhoods");
+  if (G == 0) return PFPP_OK;
+  int32_t* flags = sched + G + 1;      // scratch behind the schedule
+  hipLaunchKernelGGL(sa_pad_flags_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, pfpp::as_stream(stream), idx, (int)G, flags);
+  hipLaunchKernelGGL(sa_pad_schedule_kernel, dim3(1), dim3(1024), 0, pfpp::as_stream(stream), (const int32_t*)flags, (int)G, sched);
+  return pfpp::check_launch("pfpp_sa_pad_schedule");
+}
 
 extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t stream) {
   PFPP_REQUIRE(a, "null args");
@@ -1095,6 +1213,7 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
     p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
     p.u = a->u_in; p.D = (int)a->D;
+    p.e_hi = nullptr; p.e_lo = nullptr; p.sched = a->sched;
     hipStream_t st = pfpp::as_stream(stream);
     int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;
     if (a->stage == 1) {
@@ -1140,6 +1259,8 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
     p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
     p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
     p.u = nullptr; p.D = (int)a->D;
+    p.e_hi = nullptr; p.e_lo = nullptr; p.sched = a->sched;
+    PFPP_SUPPORTED(!(a->sched && L == 1), "the grouped first layer of the wide level takes no padding schedule (use the per-point table: u_in)");
     const int n_total = L == 3 ? 512 : 256;
     const int n_slices = n_total / 128;
     int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;
@@ -1169,6 +1290,7 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   for (int i = rows3 ? 1 : 0; i + 1 < a->stage; ++i)
     PFPP_REQUIRE(a->a_mul[i] && a->a_add[i], "finalised BatchNorm affine of an earlier layer is missing");
   if (lvl1) {
+    PFPP_SUPPORTED(!a->sched, "no padding schedule for the 32-neighbour level");
     PFPP_SUPPORTED(a->ns == 32 && a->C1 == 64 && a->C2 == 64 && a->C3 == 128, "train-mode chain without features: nsample 32, widths 64/64/128 only");
     PFPP_REQUIRE(a->stage < 3 || (a->out_max && a->out_min), "stage 3 writes the per-neighbourhood max and min");
     PFPP_REQUIRE(a->F * a->S < (1ll << 31), "too many neighbourhoods");
@@ -1191,6 +1313,7 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
   p.y_out = a->y_out; p.out_max = a->out_max; p.out_min = a->out_min;
   p.N = (int)a->N; p.S = (int)a->S; p.G = (int)(a->F * a->S);
   p.u = nullptr; p.D = (int)a->D;
+  p.e_hi = nullptr; p.e_lo = nullptr; p.sched = a->sched;
   const int64_t cap = a->max_workgroups > 0 ? a->max_workgroups : 256;       // persistent: one 4-wave workgroup per CU the stream may use
   const int64_t wgs_needed = (p.G + 3) / 4;
   const unsigned grid = (unsigned)(wgs_needed < cap ? wgs_needed : cap);
@@ -1213,11 +1336,13 @@ extern "C" int pfpp_sa_train_stage(const pfpp_sa_train_args* a, pfpp_stream_t st
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa2_train_kernel<d, c1, c2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
       attr_set = true;
     }
+    PFPP_SUPPORTED(!a->sched || a->stage == 3, "stages 1 and 2 take the padding schedule only in their table-fed form (u_in)");
     if (a->stage == 1) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 1>), dim3(grid), dim3(256), smem1, st, p);
     else if (a->stage == 2) hipLaunchKernelGGL((sa2_train_kernel<d, c1, c2, 2>), dim3(grid), dim3(256), smem2, st, p);
     else {
       // two waves per SIMD (8-wave workgroups, half a neighbourhood per wave step) unless PFPP_SA_ROWS8=0
       static const bool rows8 = !(getenv("PFPP_SA_ROWS8") && atoi(getenv("PFPP_SA_ROWS8")) == 0);
+      PFPP_SUPPORTED(!a->sched || rows8, "the padding schedule needs the 8-wave rows kernel (PFPP_SA_ROWS8=0 is set)");
       const int64_t need8 = (p.G + 7) / 8;
       if (rows8) hipLaunchKernelGGL((sa_rows8_train_kernel<c2, c3>), dim3((unsigned)(need8 < cap ? need8 : cap)), dim3(512), smem3, st, p);
       else hipLaunchKernelGGL((sa_rows_train_kernel<c2, c3>), dim3(grid), dim3(256), smem3, st, p);

@@ -67,7 +67,7 @@ class SaTrainArgs(C.Structure):
         ("stats", _p), ("stats_copies", _i64),
         ("y_out", _p), ("y_in", _p), ("u_in", _p), ("out_max", _p), ("out_min", _p),
         ("F", _i64), ("N", _i64), ("S", _i64), ("ns", _i64), ("D", _i64), ("C1", _i64), ("C2", _i64), ("C3", _i64),
-        ("stage", _i32), ("max_workgroups", _i64),
+        ("stage", _i32), ("max_workgroups", _i64), ("sched", _p),
     ]
 
 
@@ -291,6 +291,7 @@ SIGNATURES = {
     "pfpp_adamw": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _p],
     "pfpp_adamw_zero": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p],
     "pfpp_sa_train_stage": [C.POINTER(SaTrainArgs), _p],
+    "pfpp_sa_pad_schedule": [_p, _i64, _i64, _p, _p],
     "pfpp_adamw_guarded": [_p, _p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     "pfpp_adamw_rows": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, C.c_int, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     # ---- plane GEMM and plane-producing forms of the training kernels

@@ -43,6 +43,9 @@ SA_EVAL_ROWS2_MIN = int(_os.environ.get("PFPP_SA_EVAL_ROWS2_MIN", "200000"))    
 SAMPLE_FUSED = _os.environ.get("PFPP_SAMPLE_FUSED", "1") != "0"     # FPS + ball query of the three levels in one kernel
 SAMPLE_FUSED_MIN = int(_os.environ.get("PFPP_SAMPLE_FUSED_MIN", "32"))    # ... from this many fragments up
 
+# 64-neighbour levels: neighbourhoods the ball query padded beyond their first 32 slots are taken as one half (ops.sa_pad_schedule)
+SA_PAD_SKIP = _os.environ.get("PFPP_SA_PAD_SKIP", "1") != "0"
+
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
 
@@ -115,6 +118,8 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     wide = feats is not None and feats.shape[2] == 256       # level 3: one rows launch per layer (no two weight matrices fit in LDS)
     y_prev = None
     utab = ops.sa_first_table(xyz, feats, ws[0], bs[0]) if (SA_TRAIN_UTAB and feats is not None) else None
+    # the padding schedule goes to all stages of the level or to none: with the per-point table every stage takes it
+    sched = ops.sa_pad_schedule(ball) if (SA_PAD_SKIP and utab is not None and nsample == 64) else None
     for i in range(n_chain):
         Cout = ws[i].N
         st = pk.get(f"{name}.stats{i}")
@@ -126,19 +131,19 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
         if utab is not None and i < 2:
             # first layer by linearity: statistics of U[idx] - W_xyz . centroid (no matrix work), then the second layer from gathered rows
             y_cur = torch.empty((rows, Cout), dtype=torch.float32, device=dev) if i == 1 else None
-            ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, u_in=utab)
+            ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, u_in=utab, sched=sched)
             y_prev = y2 = y_cur
         elif wide:
             y_cur = torch.empty((rows, Cout), dtype=torch.float32, device=dev) if i < 2 else None
             ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y_cur, y_in=y_prev,
-                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
+                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None, sched=sched)
             y_prev = y_cur
         else:
             if feats is not None and i == 1:
                 y2 = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
             # level 2: stage 2 writes the raw second-layer rows, stage 3 (weights of the third convolution resident in LDS) reads them
             ops.sa_train_stage(i + 1, xyz, new_xyz, feats, ball, ws, bs, affs, st, y_out=y2 if i >= 1 else None,
-                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None)
+                               out_max=mx if i == 2 else None, out_min=mn if i == 2 else None, sched=sched if i == 2 else None)
         affs.append(T.bn_finalize(st, rows, pk[f"{name}.g{i}"], pk[f"{name}.be{i}"], pk[f"{name}.rm{i}"], pk[f"{name}.rv{i}"],
                                   momentum=0.1, eps=1e-5))
     torch._foreach_add_([pk[f"{name}.nbt{i}"] for i in range(3)], 1)
@@ -214,13 +219,14 @@ def _sa_rows_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
     zb, st = sc
     u = ops.sa_first_table(xyz, feats, ws[0], None)
     y2 = torch.empty((rows, ws[1].N), dtype=torch.float32, device=dev)
-    ops.sa_train_stage(2, xyz, new_xyz, feats, ball, ws, zb, aff[:1], st[1], y_out=y2, u_in=u)
+    sched = ops.sa_pad_schedule(ball) if SA_PAD_SKIP else None      # padded second halves add nothing to a max / min
+    ops.sa_train_stage(2, xyz, new_xyz, feats, ball, ws, zb, aff[:1], st[1], y_out=y2, u_in=u, sched=sched)
     mx = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
     mn = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
     if feats.shape[2] == 256:      # level 3: one rows launch per layer, the previous layer's raw rows come in as y_in
-        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_in=y2, out_max=mx, out_min=mn)
+        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_in=y2, out_max=mx, out_min=mn, sched=sched)
     else:                          # level 2: stage 3 reads the raw rows stage 2 wrote, its 256 x 128 weight planes resident in LDS
-        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_out=y2, out_max=mx, out_min=mn)
+        ops.sa_train_stage(3, xyz, new_xyz, feats, ball, ws, zb, aff[:2], st[2], y_out=y2, out_max=mx, out_min=mn, sched=sched)
     return T.bn_minmax_apply(mx, mn, aff[2][0], aff[2][1])
 
 

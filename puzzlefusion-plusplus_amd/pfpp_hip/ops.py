@@ -542,15 +542,27 @@ def sa_mlp3_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, idx: torch.Tensor, w
 PERSISTENT_WGS: Optional[int] = None
 
 
+def sa_pad_schedule(idx: torch.Tensor) -> torch.Tensor:
+    """pfpp_sa_pad_schedule: idx [F, S, 64] ball-query indices -> int32 [2 F*S + 1]: the neighbourhoods with more than 32 points in range,
+    then the others (each class ascending), the size of the first class at [F*S], scratch behind it"""
+    _chk(idx, torch.int32, "idx")
+    F, S, ns = idx.shape
+    sched = torch.empty((2 * F * S + 1,), dtype=torch.int32, device=idx.device)
+    check(_lib.load().pfpp_sa_pad_schedule(_ptr(idx), F * S, ns, _ptr(sched), _stream()), "pfpp_sa_pad_schedule")
+    return sched
+
+
 def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: Optional[torch.Tensor], idx: torch.Tensor, ws, biases,
                    affines, stats: torch.Tensor, y_out: Optional[torch.Tensor] = None, out_max: Optional[torch.Tensor] = None,
                    out_min: Optional[torch.Tensor] = None, y_in: Optional[torch.Tensor] = None,
-                   u_in: Optional[torch.Tensor] = None) -> None:
+                   u_in: Optional[torch.Tensor] = None, sched: Optional[torch.Tensor] = None) -> None:
     """one stage of the train-mode set-abstraction chain (pfpp_sa_train_stage): batch statistics of layer `stage` by recomputation
     of layers 1..stage-1 with their finalised BatchNorm affines; ws / biases = packing.PW / conv bias per layer (at least `stage` of
     them), affines = [(a_mul, a_add)] of the finalised layers (stage - 1 of them), stats = train_ops.bn_stats_buffer(C_stage).
     u_in (levels with features, stages 1 and 2): the first convolution applied per point (sa_first_table) — stage 1 then only takes
-    statistics, stage 2 gathers its rows from the table and writes y_out [F*S*ns, C2]"""
+    statistics, stage 2 gathers its rows from the table and writes y_out [F*S*ns, C2].
+    sched (64-neighbour levels): sa_pad_schedule(idx) — neighbourhoods with at most 32 points in range are taken as one half; every stage
+    of the level gets it or none does (the raw rows of a skipped half are neither written nor read)"""
     _chk(xyz, torch.float32, "xyz"); _chk(new_xyz, torch.float32, "new_xyz"); _chk(idx, torch.int32, "idx")
     F, N, _ = xyz.shape
     _, S, ns = idx.shape
@@ -618,6 +630,11 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     a.C1, a.C2, a.C3 = (widths[0] or full[0]), (widths[1] or full[1]), (widths[2] or full[2])
     a.stage = stage
     a.max_workgroups = int(PERSISTENT_WGS or 0)
+    if sched is not None:
+        _chk(sched, torch.int32, "sched")
+        if sched.shape != (2 * F * S + 1,):
+            raise ValueError("sa_train_stage: sched must be sa_pad_schedule(idx): int32 [2 F*S + 1]")
+        a.sched = sched.data_ptr()
     if GEMM_TRACE is not None:            # bench.py: HIP events around the launch; FLOPs = the layers this launch actually computes
         rows = F * S * ns
         kin = [D + 3 if feats is not None else 3, full[0], full[1]]
