@@ -24,6 +24,12 @@
 #include "pfpp_common.h"
 #include "sa_common.h"
 
+// lab only (tools/lab/sa_ablate.sh): what the rows kernels' time is made of.  1 = no matrix instructions, 2 = no normalise / split of the
+// operand rows, 4 = no statistics / stores, 8 = the row loads of the first half only
+#ifndef SA_ABL
+#define SA_ABL 0
+#endif
+
 namespace {
 
 struct SaTP {
@@ -704,6 +710,7 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
         const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+          if (SA_ABL & 2) { fh[ks][q] = (_Float16)x[q]; fl[ks][q] = (_Float16)mv[q]; continue; }
           const float v = fmaxf(__builtin_fmaf(x[q], mv[q], av[q]), 0.0f);     // relu(batch-norm(y_2)), as the GEMM's A loader
           _Float16 hh, ll;
           split1(v, hh, ll);
@@ -711,8 +718,10 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
         }
       }
       // the next half's rows are in flight during this one's contraction
-      if (h + 1 < nh) load_rows(g, 1, raw);
-      else load_rows(g1, 0, raw);
+      if (!(SA_ABL & 8)) {
+        if (h + 1 < nh) load_rows(g, 1, raw);
+        else load_rows(g1, 0, raw);
+      }
 #pragma unroll 1
       for (int n = 0; n < N / 32; ++n) {
         f32x16 acc;
@@ -722,10 +731,12 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
         for (int ks = 0; ks < K / 16; ++ks) {
           const half8 wh = *reinterpret_cast<const half8*>(Wh + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
           const half8 wl = *reinterpret_cast<const half8*>(Wl + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
+          if (SA_ABL & 1) { asm volatile("" :: "v"(fl[ks]), "v"(fh[ks]), "v"(wh), "v"(wl)); continue; }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], wh, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wl, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wh, acc, 0, 0, 0);
         }
+        if (SA_ABL & 4) { asm volatile("" :: "v"(acc)); continue; }
         float s = 0.0f, q = 0.0f, hi = -__builtin_huge_valf(), lo = __builtin_huge_valf();
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -920,6 +931,12 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
           fh[ks][q8] = h; fl[ks][q8] = l;
         }
       }
+      if (SA_ABL & 2) {
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) { fh[ks][q8] = (_Float16)reinterpret_cast<const float*>(&raw[ks][0])[q8]; fl[ks][q8] = fh[ks][q8]; }
+      }
       if (GATHER) {
 #pragma unroll
         for (int q8 = 0; q8 < 8; ++q8) { fh[KS - 1][q8] = (_Float16)0.0f; fl[KS - 1][q8] = (_Float16)0.0f; }
@@ -933,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         }
       }
       // the rows of the next half (or of the next neighbourhood) travel during this half's contraction
-      if (half + 1 < nh) load_half(g, 1, raw, qx, cx); else load_half(g1, 0, raw, qx, cx);
+      if (!(SA_ABL & 8)) { if (half + 1 < nh) load_half(g, 1, raw, qx, cx); else load_half(g1, 0, raw, qx, cx); }
       f32x16 acc[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n)
@@ -947,6 +964,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
           wh[n] = *reinterpret_cast<const half8*>(Wh + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
           wl[n] = *reinterpret_cast<const half8*>(Wl + (n * 32 + l31) * LD + ks * 16 + lhi * 8);
         }
+        if (SA_ABL & 1) { asm volatile("" :: "v"(fl[ks]), "v"(fh[ks]), "v"(wh[0]), "v"(wl[0]), "v"(wh[1]), "v"(wl[1]), "v"(wh[2]), "v"(wl[2]), "v"(wh[3]), "v"(wl[3])); continue; }
         // term-major: consecutive MFMAs on different accumulators (the three products of one accumulator keep their order)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], wh[n], acc[n], 0, 0, 0);
@@ -955,6 +973,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], wh[n], acc[n], 0, 0, 0);
       }
+      if (SA_ABL & 4) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); continue; }
       if (EVAL) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
