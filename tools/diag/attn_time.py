@@ -50,6 +50,9 @@ for pf in ("0", "1", "0", "1"):
     res.setdefault(pf, (out.clone(), lse.clone(), dq.hi.clone(), dq.lo.clone()))
 same = all(torch.equal(a, b) for a, b in zip(res["0"], res["1"]))
 print("results bit-identical between the two:", same)
+if not same:
+    for nm, a, b in zip(("out", "lse", "dq.hi", "dq.lo"), res["0"], res["1"]):
+        print(f"  {nm}: max |diff| {float((a.float() - b.float()).abs().max()):.3e} of {float(a.float().abs().max()):.3e}")
 
 # per-tile cost of the walk: 32 sequences of one uniform length each (32 keys per tile)
 print("uniform lengths (32 sequences): tokens per sequence -> forward us, backward us")
