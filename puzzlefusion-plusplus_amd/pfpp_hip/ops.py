@@ -642,7 +642,8 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
         flops = sum(2.0 * rows * kin[i] * full[i] for i in layers)
         name = ((f"sa_first_stats_kernel<{D}>" if stage == 1 else f"sa_wide_train_kernel<{D}, 2, true>") if utab else
                 f"sa1_train_kernel<64, 64, 128, {stage}>" if feats is None else f"sa_wide_train_kernel<256, {stage}>" if wide else
-                "sa_rows_train_kernel<128, 256>" if stage == 3 else f"sa2_train_kernel<128, 128, 128, {stage}>")
+                ("sa_rows_train_kernel<128, 256>" if _os.environ.get("PFPP_SA_ROWS8") == "0" else "sa_rows8_train_kernel<128, 256>") if stage == 3
+                else f"sa2_train_kernel<128, 128, 128, {stage}>")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().pfpp_sa_train_stage(C.byref(a), _stream()), "pfpp_sa_train_stage")

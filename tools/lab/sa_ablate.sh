@@ -1,6 +1,6 @@
 #!/bin/bash
 # builds libpfpp_hip variants whose sa_train.hip is compiled with -DSA_ABL=n (run here, before gpurun): bash tools/lab/sa_ablate.sh 1 2 4 8 ...
-# then on the GPU box: PFPP_LAB_LIB=tools/lab/_run/libpfpp_abl<n>.so python tools/lab/sa_ablate_time.py
+# then on the GPU box: PFPP_LIB_PATH=tools/lab/_run/libpfpp_abl<n>.so python tools/diag/enc_time.py
 R=$(cd $(dirname $0)/../.. && pwd)
 C=$R/puzzlefusion-plusplus_amd/csrc
 for n in "$@"; do
