@@ -1173,26 +1173,52 @@ __global__ __launch_bounds__(256) void sa_pad_flags_kernel(const int32_t* __rest
 }
 
 __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __restrict__ flags, int G, int32_t* __restrict__ sched) {
-  __shared__ int sc[1024];
-  const int t = threadIdx.x;
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (G + 1023) / 1024;
   const int b = t * per < G ? t * per : G, e = b + per < G ? b + per : G;
+  // up to 32 neighbourhoods per thread (G <= 32,768: every level of the path) stay in a register mask between the count and the scatter
+  constexpr int PER_REG = 32;
+  unsigned mask = 0;
   int n = 0;
-  for (int g = b; g < e; ++g) n += flags[g];
-  sc[t] = n;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = t >= d ? sc[t - d] : 0;
-    __syncthreads();
-    sc[t] += v;
-    __syncthreads();
+  if (per <= PER_REG) {
+#pragma unroll
+    for (int i = 0; i < PER_REG; ++i)
+      if (b + i < e) mask |= (flags[b + i] != 0 ? 1u : 0u) << i;
+    n = __popc(mask);
+  } else {
+    for (int g = b; g < e; ++g) n += flags[g] != 0;
   }
-  const int total2 = sc[1023];
-  int a = sc[t] - n;                    // two-half neighbourhoods before this thread's run
+  // exclusive scan of the per-thread counts: inside the wave by shuffles, across the 16 waves through 16 words of LDS
+  int inc = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int before = 0, total2 = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int v = wsum[w];
+    before += w < wave ? v : 0;
+    total2 += v;
+  }
+  int a = before + inc - n;             // two-half neighbourhoods before this thread's run
   int o = total2 + (b - a);             // one-half ones before it, behind all the two-half ones
-  for (int g = b; g < e; ++g) {
-    if (flags[g]) sched[a++] = g;
-    else sched[o++] = g;
+  if (per <= PER_REG) {
+#pragma unroll
+    for (int i = 0; i < PER_REG; ++i)
+      if (b + i < e) {
+        if ((mask >> i) & 1u) sched[a++] = b + i;
+        else sched[o++] = b + i;
+      }
+  } else {
+    for (int g = b; g < e; ++g) {
+      if (flags[g]) sched[a++] = g;
+      else sched[o++] = g;
+    }
   }
   if (t == 0) sched[G] = total2;
 }
