@@ -45,6 +45,7 @@ SAMPLE_FUSED_MIN = int(_os.environ.get("PFPP_SAMPLE_FUSED_MIN", "32"))    # ... 
 
 # 64-neighbour levels: neighbourhoods the ball query padded beyond their first 32 slots are taken as one half (ops.sa_pad_schedule)
 SA_PAD_SKIP = _os.environ.get("PFPP_SA_PAD_SKIP", "1") != "0"
+SA_PAD_SKIP_MIN = int(_os.environ.get("PFPP_SA_PAD_SKIP_MIN", "2048"))     # ... from this many neighbourhoods up (one puzzle in flight: the schedule's two launches cost more than they save)
 
 # (name, npoint, radius, nsample) — vqvae/model/modules/pn2.py:16-18
 SA_LEVELS = (("sa1", 256, 0.2, 32), ("sa2", 128, 0.4, 64), ("sa3", None, 0.8, 64))
@@ -119,7 +120,7 @@ def _sa_chain_train(pk, name: str, grp, nsample: int) -> torch.Tensor:
     y_prev = None
     utab = ops.sa_first_table(xyz, feats, ws[0], bs[0]) if (SA_TRAIN_UTAB and feats is not None) else None
     # the padding schedule goes to all stages of the level or to none: with the per-point table every stage takes it
-    sched = ops.sa_pad_schedule(ball) if (SA_PAD_SKIP and utab is not None and nsample == 64) else None
+    sched = ops.sa_pad_schedule(ball) if (SA_PAD_SKIP and utab is not None and nsample == 64 and F * S >= SA_PAD_SKIP_MIN) else None
     for i in range(n_chain):
         Cout = ws[i].N
         st = pk.get(f"{name}.stats{i}")
@@ -219,7 +220,7 @@ def _sa_rows_eval(pk, name: str, grp, nsample: int) -> torch.Tensor:
     zb, st = sc
     u = ops.sa_first_table(xyz, feats, ws[0], None)
     y2 = torch.empty((rows, ws[1].N), dtype=torch.float32, device=dev)
-    sched = ops.sa_pad_schedule(ball) if SA_PAD_SKIP else None      # padded second halves add nothing to a max / min
+    sched = ops.sa_pad_schedule(ball) if (SA_PAD_SKIP and F * S >= SA_PAD_SKIP_MIN) else None      # padded second halves add nothing to a max / min
     ops.sa_train_stage(2, xyz, new_xyz, feats, ball, ws, zb, aff[:1], st[1], y_out=y2, u_in=u, sched=sched)
     mx = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)
     mn = torch.empty((F * S, ws[2].N), dtype=torch.float32, device=dev)

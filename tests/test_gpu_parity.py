@@ -1899,6 +1899,12 @@ def test_sa_rows_eval_rows_equals_the_tiled_level(dev, F, N, S, D, monkeypatch):
     feats = torch.randn(F, N, D, generator=g)
     new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
     idx = torch.randint(0, N, (F, S, ns), generator=g, dtype=torch.int32)
+    # the ball query's padding (slots beyond the in-range count repeat slot 0): 40 % of the neighbourhoods with at most 32 live slots — taken
+    # as one half by the padding schedule (round 6) — and some padded inside their second half
+    live = torch.randint(1, 33, (F, S), generator=g)
+    live = torch.where(torch.rand(F, S, generator=g) < 0.4, live, torch.randint(33, 65, (F, S), generator=g))
+    idx = torch.where(torch.arange(ns).view(1, 1, ns) < live.unsqueeze(-1), idx, idx[:, :, :1])
+    monkeypatch.setattr(encoder, "SA_PAD_SKIP_MIN", 0)
     widths = (D, D, 2 * D)
     w_ref = [torch.randn(D, D + 3, generator=g) * 0.06, torch.randn(D, D, generator=g) * 0.06, torch.randn(2 * D, D, generator=g) * 0.06]
     sc = [torch.rand(c, generator=g) + 0.5 for c in widths]

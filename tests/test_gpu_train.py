@@ -506,6 +506,8 @@ def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev, flag):
     pts = (torch.rand(12, 1024, 3, generator=gen) * 2 - 1) * torch.rand(12, 1, 3, generator=gen)
     res = {}
     prev = getattr(encoder, flag)
+    prev_min = encoder.SA_PAD_SKIP_MIN
+    encoder.SA_PAD_SKIP_MIN = 0                   # 12 fragments are below the size from which the padding schedule is built by default
     try:
         for chain in (False, True):
             setattr(encoder, flag, chain)
@@ -525,6 +527,7 @@ def test_encoder_train_chain_equals_layerwise_batchnorm(weights_sd, dev, flag):
                               stats={k: v.detach().cpu().clone() for k, v in enc.state_dict().items() if "running" in k or "tracked" in k})
     finally:
         setattr(encoder, flag, prev)
+        encoder.SA_PAD_SKIP_MIN = prev_min
     a, b = res[True], res[False]
     assert torch.equal(a["xyz"], b["xyz"])
     for k in b["feats"]:
