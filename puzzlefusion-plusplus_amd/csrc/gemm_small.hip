@@ -15,6 +15,8 @@
 //   * bias and residual are fetched before the contraction starts and added from registers (out may alias the residual).
 // Arithmetic: the split-f16 products of pfpp_gemm (small terms first) in k order, one chain per output: equal to the tiled GEMM to fp32
 // rounding (another association of the same products), deterministic.
+#include <stdlib.h>
+
 #include "pfpp_common.h"
 
 namespace {
@@ -134,6 +136,76 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GsP p) {
   }
 }
 
+// The same GEMM with the CONTRACTION split over the waves of a workgroup (round 6).  At 100-500 rows the kernel above runs 4-16 row tiles
+// x N / 128 groups = 16-64 workgroups, and each of its waves walks the whole K in one accumulator chain: 96 (K = 512) to 384 (K = 2048)
+// dependent matrix instructions behind four to sixteen rounds of weight loads, on a tenth of the chip.  Here a workgroup owns ONE 32 x 32
+// output unit and NW waves (8 for K = 2048, the second feed-forward linear; 4 x 1 round would be K = 512): wave w takes k in [128 R w, 128 R (w + 1)) in R rounds of 128 (R = 1 / 2) —
+// the 16 A fragments of a round (rows of the planes, 16 bytes per lane) and its 16 weight fragments (fragment-blocked planes: one load =
+// the 64 lanes' operand) are requested in one go, 24 matrix instructions follow, the partial tile goes to LDS and the waves add the NW
+// partials in wave order (fixed order: deterministic), scale, add bias / residual and store.  R global round trips, one barrier;
+// N / 32 x M / 32 workgroups.  (16 waves of one round each for K = 2048 leave a wave 128 registers: 25 spilled.)
+// Arithmetic: the same split-f16 products, small terms first, summed in 128-deep partial chains: equal to the kernel above to fp32 rounding.
+template <int NW, int R>
+__global__ __launch_bounds__(64 * NW) void gemm_small_ks_kernel(GsP p) {
+  extern __shared__ __align__(16) char gs_smem[];
+  float* red = reinterpret_cast<float*>(gs_smem);                // [NW][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lhi = lane >> 5;
+  const int r0 = blockIdx.x * 32, u = blockIdx.y;
+  const int64_t arow = min(r0 + l31, p.M - 1);                   // rows past the end repeat the last one (their outputs are not stored)
+  const _Float16* ah = p.ah + arow * p.lda + 128 * R * wave + 8 * lhi;
+  const _Float16* al = p.al + arow * p.lda + 128 * R * wave + 8 * lhi;
+  const size_t blk0 = ((size_t)u * (p.K / 16) + 8 * R * wave) * 64 + lane;
+  half8 fa[2][8], fw[2][8];
+  auto fetch = [&](int r) {
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      fw[0][s8] = p.fh[blk0 + (size_t)(8 * r + s8) * 64];
+      fw[1][s8] = p.fl[blk0 + (size_t)(8 * r + s8) * 64];
+      fa[0][s8] = *reinterpret_cast<const half8*>(ah + 128 * r + 16 * s8);
+      fa[1][s8] = *reinterpret_cast<const half8*>(al + 128 * r + 16 * s8);
+    }
+  };
+  fetch(0);
+  // this thread's outputs after the reduction: registers e = wave, wave + NW, ... of the tile (row (e & 3) + 8 (e >> 2) + 4 lhi, column l31)
+  constexpr int EPW = 16 / NW;
+  const int col = 32 * u + l31;
+  float add[EPW];
+  {
+    const float bb = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < EPW; ++j) {
+      const int e = wave + NW * j;
+      const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      add[j] = bb + ((p.res && row < p.M) ? p.res[(int64_t)row * p.ldr + col] : 0.0f);
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r > 0) fetch(r);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][s8], fw[0][s8], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][s8], fw[1][s8], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][s8], fw[0][s8], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < EPW; ++j) {
+    const int e = wave + NW * j;
+    float v = red[e * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[(w * 16 + e) * 64 + lane];
+    const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+    if (row < p.M) p.out[(int64_t)row * p.ldc + col] = v * p.inv_scale + add[j];
+  }
+}
+
 }  // namespace
 
 extern "C" int pfpp_gemm_small(const pfpp_planes* A, int64_t lda, const pfpp_pw* w, const float* bias, const float* residual, int64_t ldr,
@@ -149,6 +221,17 @@ extern "C" int pfpp_gemm_small(const pfpp_planes* A, int64_t lda, const pfpp_pw*
   p.inv_scale = 1.0f / (A->scale * w->scale);
   p.bias = bias; p.res = residual; p.ldr = ldr; p.out = out; p.ldc = ldc;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  // contraction split over the waves (gemm_small_ks_kernel) for the depths of the path, while the row tiles leave most of the chip idle;
+  // PFPP_GEMM_SMALL_KS=0: the one-chain kernel everywhere (cross-check)
+  const char* ks_env = getenv("PFPP_GEMM_SMALL_KS");
+  // measured (tools/diag/small_time.py, dependent launches, N = 512): K = 2048 at 200 / 500 rows 20.7 -> 14.5 us, at 1,000 rows 21 -> 26
+  // (every unit's workgroup re-reads the row tile's A planes); K = 512 is at the launch floor either way (7.5 - 8.2 us) and keeps the chain
+  const bool ks = !(ks_env && atoi(ks_env) == 0) && K == 2048 && M <= 512;
+  if (ks) {
+    const dim3 gk((unsigned)((M + 31) / 32), (unsigned)(N / 32));
+    hipLaunchKernelGGL((gemm_small_ks_kernel<8, 2>), gk, dim3(512), (size_t)8 * 16 * 64 * sizeof(float), pfpp::as_stream(stream), p);
+    return pfpp::check_launch(__func__);
+  }
   const size_t smem = (size_t)2 * 2 * 32 * LKP * sizeof(_Float16);
   static bool attr_set = false;
   if (!attr_set) {

@@ -1535,8 +1535,8 @@ def test_token_embedding_in_one_launch_equals_the_four_launch_path(weights_sd, d
     assert float((got.cpu().double().view(Fv, L, 512) - ref64).abs().max()) < 2e-5 * max(1.0, float(ref64.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512), (2000, 512, 2048)])
-def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(25, 512, 512), (125, 512, 2048), (500, 512, 512), (333, 1536, 1024), (1, 128, 512), (2000, 512, 2048), (512, 512, 2048), (37, 1536, 2048)])
+def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K, monkeypatch):
     """csrc/gemm_small.hip (out-projections / second feed-forward linear of a few-token step): A planes . fragment-blocked weight planes
     + bias + residual, in place — against float64 of the values the planes stand for, against the tiled plane GEMM it replaces
     (same products, another association), and deterministic"""
@@ -1570,6 +1570,13 @@ def test_gemm_small_vs_float64_and_the_tiled_gemm(dev, M, N, K):
     again = res.clone()
     ops.gemm_small(a, pw, bias=bias, residual=again, out=again)
     assert torch.equal(again, out)
+    # round 6: K = 2048 at <= 512 rows runs with the contraction split over eight waves (gemm_small_ks_kernel); the one-chain kernel agrees
+    monkeypatch.setenv("PFPP_GEMM_SMALL_KS", "0")
+    chain = res.clone()
+    ops.gemm_small(a, pw, bias=bias, residual=chain, out=chain)
+    monkeypatch.delenv("PFPP_GEMM_SMALL_KS")
+    assert float((out - chain).abs().max() / chain.abs().max()) < 2e-6
+    assert (K == 2048 and M <= 512) or torch.equal(out, chain)
     plain = ops.gemm_small(a, pw)                                        # no bias, no residual, fresh output
     assert float((plain.double().cpu() - av @ wv.t()).abs().max() / want.abs().max()) < 2e-6
     with pytest.raises(Exception, match="512"):
