@@ -417,15 +417,17 @@ typedef struct pfpp_sa_train_args {
   int64_t max_workgroups;
   const int32_t* sched;        /* optional, ns == 64: pfpp_sa_pad_schedule(idx).  A neighbourhood with at most 32 points in range is taken as
                                   ONE half of 32 rows (its rows 32..63 are copies of row 0: 32 y_0 and 32 y_0^2 to the sums, nothing to max /
-                                  min); stage 2 does not write and stage 3 does not read the raw rows of such a second half, so the stages of
-                                  one level must all get the schedule or none.  Table-fed stages 1-2 (u_in), stage 3 of both levels */
+                                  min).  Of the raw second-layer rows stage 2 writes and stage 3 reads the LIVE ones only (slots below the
+                                  neighbourhood's count; a copy is read as row 0), so the stages of one level must all get the schedule or
+                                  none.  Table-fed stages 1-2 (u_in), stage 3 of both levels */
 } pfpp_sa_train_args;
 int pfpp_sa_train_stage(const pfpp_sa_train_args* args, pfpp_stream_t stream);
 
 /* Padding schedule of a 64-neighbour level for pfpp_sa_train_args.sched.  query_ball_point (utils/pn2_utils.py:103-123) sorts the in-range
- * point indices ascending and fills the remaining nsample slots with the first one, so with at most 32 points in range slots 32..63 all
- * repeat slot 0 — which is what is tested, slot by slot: the schedule is exact for any index list.  sched [2 G + 1] int32: [0, G) the neighbourhoods with two live halves (ascending), then those with one; [G] the
- * number of the former; the G entries behind it are scratch (the per-neighbourhood flags).  idx [G, 64].  Two small launches per level. */
+ * point indices ascending and fills the remaining nsample slots with the first one: slots cnt .. 63 repeat slot 0.  cnt = 1 + the highest
+ * slot that differs from slot 0 is found slot by slot, so the schedule is exact for any index list.
+ * sched [3 G + 1] int32: [0, G) the neighbourhoods with cnt > 32 (two live halves; ascending), then those with one; [G] the number of the
+ * former; [G + 1, 2 G + 1) cnt by neighbourhood; [2 G + 1, 3 G + 1) cnt in schedule order.  idx [G, 64].  Two small launches per level. */
 int pfpp_sa_pad_schedule(const int32_t* idx, int64_t G, int64_t ns, int32_t* sched, pfpp_stream_t stream);
 
 

@@ -63,6 +63,10 @@ struct PadWalk {
     if (i >= n2) i = ib;
   }
   __device__ __forceinline__ bool two() const { return i < n2; }
+  // live slots of the neighbourhood at the current position: slots cnt .. 63 repeat slot 0 (sched's third stretch, in schedule order so
+  // that the entry does not wait for g()); 64 without a schedule.  Stage 2 stores and stage 3 loads rows [0, cnt) only: the raw rows
+  // of the copies are never written and a reader takes row 0 in their place
+  __device__ __forceinline__ int cnt() const { return (order && i < G) ? order[2 * G + 1 + i] : 64; }
   // neighbourhood at the current position (G = past the end: the callers' loaders clamp it)
   __device__ __forceinline__ int g() const { return i < G ? (order ? order[i] : i) : G; }
   __device__ __forceinline__ void next() {
@@ -677,9 +681,10 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
   const int g0 = blockIdx.x * NWAVE + wave;
   const float* rows = p.y_out;
   // half-neighbourhood h (0, 1) of neighbourhood g: rows g * 64 + 32 h + l31
-  auto load_rows = [&](int g, int h, float4 (&raw)[K / 16][2]) {
+  auto load_rows = [&](int g, int h, int live, float4 (&raw)[K / 16][2]) {
     const int gc = g < p.G ? g : p.G - 1;
-    const float* row = rows + ((int64_t)gc * 64 + h * 32 + l31) * K + lhi * 8;
+    const int j = h * 32 + l31;
+    const float* row = rows + ((int64_t)gc * 64 + (j < live ? j : 0)) * K + lhi * 8;
 #pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) {
       raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
@@ -689,14 +694,14 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
   float4 raw[K / 16][2];
   // the walk runs two neighbourhoods ahead of the rows (the schedule entry of g2 is in flight while g is multiplied)
   PadWalk wk(p.sched, p.G, g0, stride);
-  int g = wk.g(); bool two = wk.two(); wk.next();
-  int g1 = wk.g(); bool two1 = wk.two(); wk.next();
-  int g2 = wk.g(); bool two2 = wk.two();
-  load_rows(g, 0, raw);
+  int g = wk.g(), c = wk.cnt(); wk.next();
+  int g1 = wk.g(), c1 = wk.cnt(); wk.next();
+  int g2 = wk.g(), c2 = wk.cnt();
+  load_rows(g, 0, c, raw);
   float mx[N / 32], mn[N / 32];
 
-  for (; g < p.G; g = g1, two = two1, g1 = g2, two1 = two2, wk.next(), g2 = wk.g(), two2 = wk.two()) {
-    const int nh = two ? 2 : 1;
+  for (; g < p.G; g = g1, c = c1, g1 = g2, c1 = c2, wk.next(), g2 = wk.g(), c2 = wk.cnt()) {
+    const int nh = c > 32 ? 2 : 1;
 #pragma unroll 1
     for (int h = 0; h < nh; ++h) {
       asm volatile("" ::: "memory");
@@ -719,8 +724,8 @@ __global__ __launch_bounds__(512, 1) void sa_rows8_train_kernel(const SaTP p) {
       }
       // the next half's rows are in flight during this one's contraction
       if (!(SA_ABL & 8)) {
-        if (h + 1 < nh) load_rows(g, 1, raw);
-        else load_rows(g1, 0, raw);
+        if (h + 1 < nh) load_rows(g, 1, c, raw);
+        else load_rows(g1, 0, c1, raw);
       }
 #pragma unroll 1
       for (int n = 0; n < N / 32; ++n) {
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   // a wave walks neighbourhoods (64 rows) in two halves of 32 rows
   const int stride = row_wgs * 4;
   const int g0 = wg_row * 4 + wave;
-  auto load_half = [&](int g, int half, float4 (&raw)[K / 16][2], float (&q)[3], float (&c)[3]) {
+  auto load_half = [&](int g, int half, int live, float4 (&raw)[K / 16][2], float (&q)[3], float (&c)[3]) {
     const int gc = g < p.G ? g : p.G - 1;
     if (GATHER) {
       const int f = gc / p.S;
@@ -878,7 +883,8 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         for (int d = 0; d < 3; ++d) c[d] = c3[d];
       }
     } else {
-      const float* row = y_in + ((int64_t)gc * 64 + half * 32 + l31) * K + lhi * 8;
+      const int j = half * 32 + l31;
+      const float* row = y_in + ((int64_t)gc * 64 + (j < live ? j : 0)) * K + lhi * 8;
 #pragma unroll
       for (int ks = 0; ks < K / 16; ++ks) {
         raw[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
@@ -890,13 +896,13 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
   float qx[3] = {0.f, 0.f, 0.f}, cx[3] = {0.f, 0.f, 0.f};
   // padding-aware walk (PadWalk), two neighbourhoods ahead of the rows; the eval form writes every row for the next layer's plane GEMM
   PadWalk wk(EVAL ? nullptr : p.sched, p.G, g0, stride);
-  int g = wk.g(); bool two = wk.two(); wk.next();
-  int g1 = wk.g(); bool two1 = wk.two(); wk.next();
-  int g2 = wk.g(); bool two2 = wk.two();
-  load_half(g, 0, raw, qx, cx);
+  int g = wk.g(), lv = wk.cnt(); wk.next();
+  int g1 = wk.g(), lv1 = wk.cnt(); wk.next();
+  int g2 = wk.g(), lv2 = wk.cnt();
+  load_half(g, 0, lv, raw, qx, cx);
 
-  for (; g < p.G; g = g1, two = two1, g1 = g2, two1 = two2, wk.next(), g2 = wk.g(), two2 = wk.two()) {
-    const int nh = two ? 2 : 1;
+  for (; g < p.G; g = g1, lv = lv1, g1 = g2, lv1 = lv2, wk.next(), g2 = wk.g(), lv2 = wk.cnt()) {
+    const int nh = lv > 32 ? 2 : 1;
     float mx[4], mn[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) { mx[n] = -__builtin_huge_valf(); mn[n] = __builtin_huge_valf(); }
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
         }
       }
       // the rows of the next half (or of the next neighbourhood) travel during this half's contraction
-      if (!(SA_ABL & 8)) { if (half + 1 < nh) load_half(g, 1, raw, qx, cx); else load_half(g1, 0, raw, qx, cx); }
+      if (!(SA_ABL & 8)) { if (half + 1 < nh) load_half(g, 1, lv, raw, qx, cx); else load_half(g1, 0, lv1, raw, qx, cx); }
       f32x16 acc[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n)
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(256, 1) void sa_wide_train_kernel(const SaTP p, con
           s += y;
           q = __builtin_fmaf(y, y, q);
           if (LAYER == 3) { mx[n] = fmaxf(mx[n], y); mn[n] = fminf(mn[n], y); }
-          else orow[(int64_t)((e & 3) + 8 * (e >> 2)) * n_total] = y;
+          else if (half * 32 + 4 * lhi + (e & 3) + 8 * (e >> 2) < lv) orow[(int64_t)((e & 3) + 8 * (e >> 2)) * n_total] = y;      // live rows only
         }
         ss[n] += (double)s;
         sq[n] += (double)q;
@@ -1153,26 +1159,30 @@ __global__ __launch_bounds__(256) void sa_table_apply_kernel(const SaTP p) {
   }
 }
 
-// pfpp_sa_pad_schedule, two launches.  (1) one thread per neighbourhood, all CUs: flag = some slot of 32..63 differs from slot 0 (for a
-// ball query's list <=> more than 32 points in range; checked slot by slot, so the skip is exact for ANY index list) — two cache
-// lines per neighbourhood; a single workgroup fetching all of them through one CU's L2 port took 75 us at 19,712 neighbourhoods.  (2) one workgroup over the flags:
+// pfpp_sa_pad_schedule, two launches.  (1) one thread per neighbourhood, all CUs: its live-slot count = 1 + the highest slot that differs
+// from slot 0 (for a ball query's list = the number of points in range; found slot by slot, so the skip is exact for ANY index list) —
+// two cache lines per neighbourhood; a single workgroup fetching all of them through one CU's L2 port took 75 us at 19,712 neighbourhoods.  (2) one workgroup over the flags:
 // thread t takes a contiguous run, an exclusive scan of the per-thread counts places the two-half neighbourhoods in ascending order at
 // the front and the one-half ones behind them.
 __global__ __launch_bounds__(256) void sa_pad_flags_kernel(const int32_t* __restrict__ idx, int G, int32_t* __restrict__ flags) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= G) return;
+  const int4* sl = reinterpret_cast<const int4*>(idx + (int64_t)g * 64);      // two 128-byte lines
   const int id0 = idx[(int64_t)g * 64];
-  const int4* h2 = reinterpret_cast<const int4*>(idx + (int64_t)g * 64 + 32);      // one 128-byte line
-  int live = 0;
+  int last = 0;                                // highest slot that differs from slot 0
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int4 v = h2[i];
-    live |= (v.x != id0) | (v.y != id0) | (v.z != id0) | (v.w != id0);
+  for (int i = 0; i < 16; ++i) {
+    const int4 v = sl[i];
+    last = v.x != id0 ? 4 * i : last;
+    last = v.y != id0 ? 4 * i + 1 : last;
+    last = v.z != id0 ? 4 * i + 2 : last;
+    last = v.w != id0 ? 4 * i + 3 : last;
   }
-  flags[g] = live;
+  flags[g] = last + 1;                         // live slots: cnt .. 63 repeat slot 0
 }
 
 __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __restrict__ flags, int G, int32_t* __restrict__ sched) {
+  int32_t* __restrict__ cnt_at = sched + 2 * G + 1;      // live-slot counts in schedule order
   __shared__ int wsum[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (G + 1023) / 1024;
@@ -1184,10 +1194,10 @@ __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __
   if (per <= PER_REG) {
 #pragma unroll
     for (int i = 0; i < PER_REG; ++i)
-      if (b + i < e) mask |= (flags[b + i] != 0 ? 1u : 0u) << i;
+      if (b + i < e) mask |= (flags[b + i] > 32 ? 1u : 0u) << i;
     n = __popc(mask);
   } else {
-    for (int g = b; g < e; ++g) n += flags[g] != 0;
+    for (int g = b; g < e; ++g) n += flags[g] > 32;
   }
   // exclusive scan of the per-thread counts: inside the wave by shuffles, across the 16 waves through 16 words of LDS
   int inc = n;
@@ -1211,13 +1221,15 @@ __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __
 #pragma unroll
     for (int i = 0; i < PER_REG; ++i)
       if (b + i < e) {
-        if ((mask >> i) & 1u) sched[a++] = b + i;
-        else sched[o++] = b + i;
+        const int pos = (mask >> i) & 1u ? a++ : o++;
+        sched[pos] = b + i;
+        cnt_at[pos] = flags[b + i];
       }
   } else {
     for (int g = b; g < e; ++g) {
-      if (flags[g]) sched[a++] = g;
-      else sched[o++] = g;
+      const int pos = flags[g] > 32 ? a++ : o++;
+      sched[pos] = g;
+      cnt_at[pos] = flags[g];
     }
   }
   if (t == 0) sched[G] = total2;

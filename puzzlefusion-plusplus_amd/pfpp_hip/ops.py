@@ -543,11 +543,12 @@ PERSISTENT_WGS: Optional[int] = None
 
 
 def sa_pad_schedule(idx: torch.Tensor) -> torch.Tensor:
-    """pfpp_sa_pad_schedule: idx [F, S, 64] ball-query indices -> int32 [2 F*S + 1]: the neighbourhoods with more than 32 points in range,
-    then the others (each class ascending), the size of the first class at [F*S], scratch behind it"""
+    """pfpp_sa_pad_schedule: idx [F, S, 64] ball-query indices -> int32 [3 F*S + 1]: the neighbourhoods with more than 32 live slots,
+    then the others (each class ascending), the size of the first class at [F*S], then the live-slot counts by neighbourhood and in
+    schedule order"""
     _chk(idx, torch.int32, "idx")
     F, S, ns = idx.shape
-    sched = torch.empty((2 * F * S + 1,), dtype=torch.int32, device=idx.device)
+    sched = torch.empty((3 * F * S + 1,), dtype=torch.int32, device=idx.device)
     check(_lib.load().pfpp_sa_pad_schedule(_ptr(idx), F * S, ns, _ptr(sched), _stream()), "pfpp_sa_pad_schedule")
     return sched
 
@@ -632,8 +633,8 @@ def sa_train_stage(stage: int, xyz: torch.Tensor, new_xyz: torch.Tensor, feats: 
     a.max_workgroups = int(PERSISTENT_WGS or 0)
     if sched is not None:
         _chk(sched, torch.int32, "sched")
-        if sched.shape != (2 * F * S + 1,):
-            raise ValueError("sa_train_stage: sched must be sa_pad_schedule(idx): int32 [2 F*S + 1]")
+        if sched.shape != (3 * F * S + 1,):
+            raise ValueError("sa_train_stage: sched must be sa_pad_schedule(idx): int32 [3 F*S + 1]")
         a.sched = sched.data_ptr()
     if GEMM_TRACE is not None:            # bench.py: HIP events around the launch; FLOPs = the layers this launch actually computes
         rows = F * S * ns

@@ -487,6 +487,8 @@ def test_padding_schedule_lists_the_two_half_neighbourhoods_first(dev):
     n2 = int(sched[G])
     assert n2 == int(two.sum())
     assert np.array_equal(sched[:n2], np.nonzero(two)[0]) and np.array_equal(sched[n2:G], np.nonzero(~two)[0])
+    # live-slot counts, by neighbourhood and in schedule order (stage 2 stores / stage 3 loads only those rows)
+    assert np.array_equal(sched[G + 1:2 * G + 1], cnt) and np.array_equal(sched[2 * G + 1:3 * G + 1], cnt[sched[:G]])
 
 
 @pytest.mark.parametrize("flag", ["SA_TRAIN_CHAIN", "SA_TRAIN_UTAB", "SA_TRAIN_WIDE", "SA_PAD_SKIP"])
