@@ -1191,10 +1191,13 @@ __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __
   constexpr int PER_REG = 32;
   unsigned mask = 0;
   int n = 0;
+  int live[PER_REG];
   if (per <= PER_REG) {
 #pragma unroll
-    for (int i = 0; i < PER_REG; ++i)
-      if (b + i < e) mask |= (flags[b + i] > 32 ? 1u : 0u) << i;
+    for (int i = 0; i < PER_REG; ++i) {
+      live[i] = b + i < e ? flags[b + i] : 0;
+      mask |= (live[i] > 32 ? 1u : 0u) << i;
+    }
     n = __popc(mask);
   } else {
     for (int g = b; g < e; ++g) n += flags[g] > 32;
@@ -1223,7 +1226,7 @@ __global__ __launch_bounds__(1024) void sa_pad_schedule_kernel(const int32_t* __
       if (b + i < e) {
         const int pos = (mask >> i) & 1u ? a++ : o++;
         sched[pos] = b + i;
-        cnt_at[pos] = flags[b + i];
+        cnt_at[pos] = live[i];
       }
   } else {
     for (int g = b; g < e; ++g) {
