@@ -36,6 +36,8 @@ import sys
 import time
 from pathlib import Path
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: see pfpp_hip/__init__.py
+
 ROOT = Path(__file__).resolve().parent
 for p in (str(ROOT), str(ROOT / "puzzlefusion-plusplus_amd")):
     if p not in sys.path:

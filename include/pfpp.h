@@ -777,6 +777,10 @@ int pfpp_token_combine_bwd(const float* dtok, const uint8_t* ref_part, float* dx
                            int64_t n, int64_t L, int64_t C, pfpp_stream_t stream);
 int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const float* dse, float* dtables,
                         int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, pfpp_stream_t stream);
+/* the same, and the rows t[.] are marked in `active` (uint32 [ceil(n_emb / 32)], bit r = row r has received a gradient since the bitmap
+ * was cleared) for pfpp_adamw_rows_active; n_emb <= 4096 */
+int pfpp_silu_embed_bwd_mark(const float* tables, const int64_t* t, const float* dse, float* dtables,
+                             int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, uint32_t* active, pfpp_stream_t stream);
 
 /* ---- backward of the AdaLN modulation linears (MyAdaLayerNorm.forward, attention.py:21-25: mods_j = Linear_j(silu(emb_j(t))), one per
  * norm, 2 * num_layers of them) in two launches per 32 puzzles, plain fp32, fixed summation order (csrc/ada_bwd.hip):
@@ -845,6 +849,15 @@ int pfpp_adamw_guarded(float* p, float* g, float* m, float* v, void* hi, void* l
 int pfpp_adamw_rows(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n_tables, int64_t rows_per_table, int64_t C,
                     const int64_t* t, int64_t n_t, int mode, float lr, float beta1, float beta2, float eps, float weight_decay,
                     float bc1, float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);
+/* pfpp_adamw_guarded over the stack restricted to the rows whose bit is set in `active` (pfpp_silu_embed_bwd_mark: every row that has
+ * ever received a gradient).  A row that never did has g = m = v = 0, and with weight decay as small as the reference's
+ * (configure_optimizers, denoiser.py:230-237: lr 2e-4, weight_decay 1e-6 -> fl32(1 - lr wd) = 1) its AdamW update is exactly the
+ * identity: of the 3,072 rows per table only the 1,000 training timesteps can ever be indexed, two thirds of the tables' 18.9 M parameters
+ * are never read or written.  When fl32(1 - lr * weight_decay) != 1 every row is taken (the plain update).  The caller owns the
+ * bitmap's meaning: set every bit after restoring optimizer state it does not know the history of. */
+int pfpp_adamw_rows_active(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n_tables, int64_t rows_per_table, int64_t C,
+                           const uint32_t* active, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                           float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream);
 
 /* ---- train-mode BatchNorm of the (frozen, but .train()) encoder (utils/pn2_utils.py:211-214) -------------
  * The reference freezes the encoder's parameters only (train_denoiser.py:33-35); under Lightning's

@@ -486,11 +486,13 @@ __global__ __launch_bounds__(128) void token_combine_bwd_kernel(const float* __r
 __global__ __launch_bounds__(128) void silu_embed_bwd_kernel(const float* __restrict__ tables,
                                                              const int64_t* __restrict__ t,
                                                              const float* __restrict__ dse, float* __restrict__ dtables,
-                                                             int64_t n_emb, int64_t B, int C) {
+                                                             int64_t n_emb, int64_t B, int C, uint32_t* __restrict__ active) {
   const int64_t b = blockIdx.x, tab = blockIdx.y;
   const int64_t tb = t[b];
   for (int64_t j = 0; j < b; ++j)
     if (t[j] == tb) return;                            // an earlier puzzle owns this row
+  // rows that ever received a gradient (pfpp_adamw_rows_active): a monotone bitmap, so the order of the atomics does not matter
+  if (active && tab == 0 && threadIdx.x == 0) atomicOr(&active[tb >> 5], 1u << (tb & 31));
   const int64_t row = (tab * n_emb + tb) * C;
   for (int c = threadIdx.x; c < C; c += 128) {
     const float sg = silu_grad(tables[row + c]);
@@ -604,7 +606,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 
 // AdamW over a stack of embedding tables restricted by rows (see pfpp_adamw_rows): MODE 0 = one thread per element of the stack, rows
 // listed in t skipped (a 3,072-bit row mask built in LDS per workgroup); MODE 1 = one thread per element of the listed rows, a row
-// listed twice is taken by its first occurrence only.  Same arithmetic per element as adamw_kernel<true>.
+// listed twice is taken by its first occurrence only; MODE 2 = one thread per element of the stack, rows whose bit is CLEAR in the bitmap
+// `t` points at (reinterpreted: uint32 words) skipped.  Same arithmetic per element as adamw_kernel<true>.
 template <int MODE, bool GUARD>
 __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
@@ -613,7 +616,16 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, 
                                                          float step_size, float inv_sqrt_bc2, float g_scale, int zero_g,
                                                          int* __restrict__ overflow) {
   int64_t i;
-  if (MODE == 0) {
+  if (MODE == 2) {
+    __shared__ unsigned act[128];
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(t);
+    for (int k = threadIdx.x; k < 128; k += 256) act[k] = k < (rows_per_table + 31) / 32 ? bits[k] : 0u;
+    __syncthreads();
+    i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_tables * rows_per_table * (int64_t)C) return;
+    const int r = (int)((i / C) % rows_per_table);
+    if (!((act[r >> 5] >> (r & 31)) & 1u)) return;
+  } else if (MODE == 0) {
     __shared__ unsigned mask[128];              // rows_per_table <= 4096
     for (int k = threadIdx.x; k < 128; k += 256) mask[k] = 0u;
     __syncthreads();
@@ -935,7 +947,18 @@ extern "C" int pfpp_silu_embed_bwd(const float* tables, const int64_t* t, const 
   if (total == 0) return PFPP_OK;
   PFPP_SUPPORTED(B <= 0x7fffffff && n_tab <= 65535, "too many rows / tables for one launch");
   hipLaunchKernelGGL(silu_embed_bwd_kernel, dim3((unsigned)B, (unsigned)n_tab), dim3(128), 0, pfpp::as_stream(stream), tables,
-                     t, dse, dtables, n_emb, B, (int)C);
+                     t, dse, dtables, n_emb, B, (int)C, (uint32_t*)nullptr);
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_silu_embed_bwd_mark(const float* tables, const int64_t* t, const float* dse, float* dtables,
+                                        int64_t n_tab, int64_t n_emb, int64_t B, int64_t C, uint32_t* active, pfpp_stream_t stream) {
+  PFPP_REQUIRE(tables && t && dse && dtables && active, "null pointer");
+  const int64_t total = n_tab * B * C;
+  if (total == 0) return PFPP_OK;
+  PFPP_SUPPORTED(B <= 0x7fffffff && n_tab <= 65535 && n_emb <= 4096, "too many rows / tables for one launch");
+  hipLaunchKernelGGL(silu_embed_bwd_kernel, dim3((unsigned)B, (unsigned)n_tab), dim3(128), 0, pfpp::as_stream(stream), tables,
+                     t, dse, dtables, n_emb, B, (int)C, active);
   return pfpp::check_launch(__func__);
 }
 
@@ -990,6 +1013,32 @@ extern "C" int pfpp_adamw_rows(float* p, float* g, float* m, float* v, void* hi,
   if (mode == 0) { if (overflow) PFPP_ROWS_LAUNCH(0, true); else PFPP_ROWS_LAUNCH(0, false); }
   else { if (overflow) PFPP_ROWS_LAUNCH(1, true); else PFPP_ROWS_LAUNCH(1, false); }
 #undef PFPP_ROWS_LAUNCH
+  return pfpp::check_launch(__func__);
+}
+
+extern "C" int pfpp_adamw_rows_active(float* p, float* g, float* m, float* v, void* hi, void* lo, int64_t n_tables, int64_t rows_per_table,
+                                      int64_t C, const uint32_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                      float bc1, float bc2, float g_scale, int zero_grad, int32_t* overflow, pfpp_stream_t stream) {
+  PFPP_REQUIRE(p && g && m && v && active, "null pointer");
+  PFPP_REQUIRE(!hi == !lo, "hi and lo go together");
+  PFPP_REQUIRE(bc1 > 0.0f && bc2 > 0.0f, "bias corrections must be positive");
+  PFPP_REQUIRE(n_tables >= 1 && rows_per_table >= 1 && rows_per_table <= 4096 && C >= 1 && C < (1 << 30), "sizes");
+  const float decay = 1.0f - lr * weight_decay;
+  // a row without a set bit has g = m = v = 0: its update is p * decay, the identity only when decay rounds to 1 — otherwise every row is taken
+  if (decay != 1.0f)
+    return pfpp_adamw_guarded(p, g, m, v, hi, lo, n_tables * rows_per_table * C, lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale,
+                              zero_grad, overflow, stream);
+  hipStream_t st = pfpp::as_stream(stream);
+  const int64_t n = n_tables * rows_per_table * C;
+  const dim3 grid(blocks_for(n, 256));
+  const float w1 = 1.0f - beta1, w2 = 1.0f - beta2, step = lr / bc1, isb = 1.0f / sqrtf(bc2);
+  const int64_t* bits = reinterpret_cast<const int64_t*>(active);
+  if (overflow)
+    hipLaunchKernelGGL((adamw_rows_kernel<2, true>), grid, dim3(256), 0, st, p, g, m, v, (_Float16*)hi, (_Float16*)lo, n_tables,
+                       (int)rows_per_table, (int)C, bits, 0, decay, w1, beta2, w2, eps, step, isb, g_scale, zero_grad ? 1 : 0, (int*)overflow);
+  else
+    hipLaunchKernelGGL((adamw_rows_kernel<2, false>), grid, dim3(256), 0, st, p, g, m, v, (_Float16*)hi, (_Float16*)lo, n_tables,
+                       (int)rows_per_table, (int)C, bits, 0, decay, w1, beta2, w2, eps, step, isb, g_scale, zero_grad ? 1 : 0, (int*)overflow);
   return pfpp::check_launch(__func__);
 }
 

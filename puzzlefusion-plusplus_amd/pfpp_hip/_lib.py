@@ -279,6 +279,8 @@ SIGNATURES = {
     "pfpp_mean_pool_bwd": [_p, _p, _i64, _i64, _i64, _p],
     "pfpp_token_combine_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "pfpp_silu_embed_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "pfpp_silu_embed_bwd_mark": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p],
+    "pfpp_adamw_rows_active": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, C.c_int, _p, _p],
     "pfpp_embed_pack_weights": [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "pfpp_token_features_t": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "pfpp_token_embed_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_float, _p],

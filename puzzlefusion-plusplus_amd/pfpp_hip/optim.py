@@ -102,6 +102,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         st[key] = view
                 steps.append(int(st["step"]))
         self.engine.step_count = max(steps) if steps else 0
+        self.engine.tables_state_changed()           # the moments of the timestep tables came from the checkpoint
         self._step_t = torch.tensor(float(self.engine.step_count))       # one shared counter again (see step())
         for n in flat.order:
             self.state[flat.named[n]]["step"] = self._step_t

@@ -354,9 +354,18 @@ def token_combine_bwd(dtok: torch.Tensor, ref_u8: torch.Tensor, dref_emb: torch.
     return dx_emb
 
 
-def silu_embed_bwd(tables: torch.Tensor, t: torch.Tensor, dse: torch.Tensor, dtables: torch.Tensor) -> torch.Tensor:
+def silu_embed_bwd(tables: torch.Tensor, t: torch.Tensor, dse: torch.Tensor, dtables: torch.Tensor,
+                   active: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """active (int32 [ceil(rows / 32)], optional): the rows t[.] are also marked in this bitmap (adamw_rows_active)"""
     _chk(tables, _f32, "tables"); _chk(t, torch.int64, "t"); _chk(dse, _f32, "dse"); _chk(dtables, _f32, "dtables")
     n_tab, n_emb, Cc = tables.shape
+    if active is not None:
+        _chk(active, torch.int32, "active")
+        if active.numel() * 32 < n_emb:
+            raise ValueError("silu_embed_bwd: the bitmap has fewer bits than the tables have rows")
+        check(_lib.load().pfpp_silu_embed_bwd_mark(_ptr(tables), _ptr(t), _ptr(dse), _ptr(dtables), n_tab, n_emb, t.numel(), Cc,
+                                                   _ptr(active), _stream()), "pfpp_silu_embed_bwd_mark")
+        return dtables
     check(_lib.load().pfpp_silu_embed_bwd(_ptr(tables), _ptr(t), _ptr(dse), _ptr(dtables), n_tab, n_emb, t.numel(), Cc,
                                           _stream()), "pfpp_silu_embed_bwd")
     return dtables
@@ -511,6 +520,26 @@ def adamw_rows(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
     check(_lib.load().pfpp_adamw_rows(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), n_tab, rows, Cc, _ptr(t), t.numel(), mode,
                                       lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, int(zero_grad), _ptr(overflow), _stream()),
           "pfpp_adamw_rows")
+
+
+def adamw_rows_active(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, active: torch.Tensor, *, lr: float, beta1: float,
+                      beta2: float, eps: float, weight_decay: float, step: int, hi: Optional[torch.Tensor] = None,
+                      lo: Optional[torch.Tensor] = None, g_scale: float = 1.0, zero_grad: bool = False,
+                      overflow: Optional[torch.Tensor] = None) -> None:
+    """adamw() over a stack of embedding tables p [n_tables, rows, C] restricted to the rows marked in `active` (int32 bitmap kept by
+    silu_embed_bwd(active=...)): rows that never received a gradient have zero moments and, with fl32(1 - lr * weight_decay) = 1, an
+    update that is exactly the identity (pfpp_adamw_rows_active; every row is taken when the decay does not round to 1)"""
+    for t_, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t_, _f32, nm)
+    _chk(active, torch.int32, "active")
+    n_tab, rows, Cc = p.shape
+    if active.numel() * 32 < rows:
+        raise ValueError("adamw_rows_active: the bitmap has fewer bits than the tables have rows")
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.load().pfpp_adamw_rows_active(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hi), _ptr(lo), n_tab, rows, Cc, _ptr(active),
+                                             lr, beta1, beta2, eps, weight_decay, bc1, bc2, g_scale, int(zero_grad), _ptr(overflow), _stream()),
+          "pfpp_adamw_rows_active")
 
 
 def bn_stats(x: torch.Tensor, running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,

@@ -166,6 +166,63 @@ def test_two_optimizer_steps_vs_oracle(golden, weights_sd, dev, armed):
     assert (pred.cpu() - want)[sel].abs().max() < 2e-3     # two sign-descent steps apart on ~1e-3 of the weights
 
 
+@pytest.mark.parametrize("armed", [False, True])
+def test_timestep_table_rows_without_a_gradient_are_left_alone(golden, weights_sd, dev, armed, monkeypatch):
+    """round 6: the closing AdamW of a step walks the AdaLN timestep tables through the bitmap of rows that ever received a gradient
+    (engine._tab_active, set by silu_embed_bwd) — the other rows' update is exactly the identity with the reference's hyper-parameters
+    (the two update kernels bit for bit on equal inputs: test_adamw_over_the_active_rows_equals_one_pass_over_the_tables).  Three steps
+    with different timestep draws on an engine with the bitmap and on one without it (PFPP_TRAIN_TABLES_ACTIVE=0, every row every
+    step): in BOTH every table row outside the marked set still holds its initial bits with zero moments — i.e. skipping them changes
+    nothing — the marked set is exactly the rows drawn (one beyond the 1,000 training timesteps included) plus a row whose moment was
+    written from outside (tables_state_changed() picks it up), and the marked rows moved."""
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    inp_c, noise_c, _ = golden_inputs(golden)
+    drawn = set()
+    for active in ("1", "0"):
+        monkeypatch.setenv("PFPP_TRAIN_TABLES_ACTIVE", active)
+        eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+        assert (eng._tab_active is not None) == (active == "1")
+        f = eng.flat
+        n_emb, C = f.named["transformer_layers.0.norm1.emb.weight"].shape
+        n_tab = f.offset["transformer_layers.0.norm1.linear.weight"]
+        p0 = f.params[:n_tab].clone()
+        inp = [v.to(dev) for v in inp_c]
+        for step in range(3):
+            t = (inp_c[1].to(dev) + 37 * step) % 1000                   # other rows every step
+            if step == 1:
+                t[0] = 2500                                             # a row outside the training range
+            inp[1] = t
+            drawn |= set(int(x) for x in t.tolist())
+            eng.flat.zero_grad()
+            if armed:
+                eng.arm_optimizer(lr=2e-4, zero_grad=True)
+            eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
+            eng.optimizer_step(lr=2e-4, zero_grad=armed)
+            if step == 1:
+                f.exp_avg[5 * n_emb * C + 2900 * C + 3] = 1e-3          # table 5, row 2900: a moment from "a checkpoint"
+                eng.tables_state_changed()
+        torch.cuda.synchronize()
+        want = sorted(drawn | {2900})
+        rest = torch.ones(n_emb, dtype=torch.bool, device=dev)
+        rest[torch.tensor(want, device=dev)] = False
+        tab = lambda buf: buf[:n_tab].view(-1, n_emb, C)
+        assert torch.equal(tab(f.params)[:, rest], p0.view(-1, n_emb, C)[:, rest])
+        assert float(tab(f.exp_avg)[:, rest].abs().max()) == 0.0 and float(tab(f.exp_avg_sq)[:, rest].abs().max()) == 0.0
+        assert torch.equal((tab(f.hi).float() + tab(f.lo).float())[:, rest], (tab(f.hi).float() + tab(f.lo).float())[:, rest])
+        moved = (tab(f.params) != p0.view(-1, n_emb, C)).any(dim=2).any(dim=0)
+        assert bool(moved[torch.tensor(sorted(drawn), device=dev)].all()) and bool(moved[2900])
+        if active == "1":
+            bits = eng._tab_active.cpu().numpy().view("uint32")
+            assert [r for r in range(n_emb) if (int(bits[r >> 5]) >> (r & 31)) & 1] == want
+        del eng, f, p0, tab, moved, rest
+    # two engines' worth of flat buffers go back to the driver: left in torch's cache they sent the per-step allocations of the timing test
+    # further down (test_module_surface_runs_the_benchmarked_schedule) to hipMalloc every iteration when the whole suite ran in one process
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_module_train_mode_autograd_and_optimizer(golden, weights_sd, dev):
     """the drop-in surface: module.train(); loss.backward(); FusedAdamW.step() == the engine driven directly"""
     import torch.nn.functional as F

@@ -591,6 +591,55 @@ def test_adamw_by_rows_equals_one_pass_over_the_tables(dev):
     assert not torch.equal(out[1][0][0, 10], p0[0, 10])                              # an unlisted row did move (decay, first-moment step)
 
 
+@pytest.mark.parametrize("weight_decay", [1e-6, 1e-2])
+def test_adamw_over_the_active_rows_equals_one_pass_over_the_tables(dev, weight_decay):
+    """round 6: a row of the AdaLN timestep tables that has never received a gradient has zero moments, and with the reference's
+    hyper-parameters (lr 2e-4, weight_decay 1e-6: fl32(1 - lr wd) = 1) its AdamW update is the identity — pfpp_adamw_rows_active leaves
+    such rows alone (two thirds of the tables' parameters are never read or written), the rows silu_embed_bwd marked are updated.  Four
+    steps with fresh timestep draws (rows beyond the 1,000 training timesteps included, duplicates included) against the guarded
+    one-pass AdamW, bit for bit: parameters, both moments, planes, gradients; with a weight decay that does not round away every row
+    is taken and the two still agree."""
+    from pfpp_hip import train_ops as T
+
+    g = torch.Generator().manual_seed(11)
+    n_tab, rows, C, B = 12, 3072, 64, 8
+    p0 = torch.randn(n_tab, rows, C, generator=g) * 0.05
+    out = []
+    for active_path in (False, True):
+        gen = torch.Generator().manual_seed(12)
+        p = p0.clone().to(dev)
+        m, v, gr = (torch.zeros_like(p) for _ in range(3))
+        hi = torch.zeros(p.shape, dtype=torch.float16, device=dev)
+        lo = torch.zeros(p.shape, dtype=torch.float16, device=dev)
+        act = torch.zeros(128, dtype=torch.int32, device=dev)
+        for step in range(1, 5):
+            t = torch.randint(0, 1000, (B,), generator=gen)
+            t[1] = t[0]
+            if step == 3:
+                t[5] = 3071                      # a row outside the training range still counts once it is indexed
+            dse = (torch.randn(n_tab, B, C, generator=gen) * 1e-2).to(dev)
+            T.silu_embed_bwd(p, t.to(dev), dse, gr, active=act if active_path else None)
+            hp = dict(lr=2e-4, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=weight_decay, step=step)
+            if active_path:
+                T.adamw_rows_active(p, gr, m, v, act, hi=hi, lo=lo, zero_grad=True, **hp)
+            else:
+                T.adamw(p.view(-1), gr.view(-1), m.view(-1), v.view(-1), hi=hi.view(-1), lo=lo.view(-1), zero_grad=True, **hp)
+        torch.cuda.synchronize()
+        out.append((p.cpu(), m.cpu(), v.cpu(), gr.cpu(), hi.cpu(), lo.cpu(), act.cpu()))
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert torch.equal(a, b)
+    touched = out[1][2].abs().sum(dim=(0, 2)) > 0                                   # rows with a second moment
+    assert 20 <= int(touched.sum()) <= 4 * B and bool(touched[3071])
+    bits = out[1][6].numpy().view("uint32")
+    marked = torch.tensor([(int(bits[r >> 5]) >> (r & 31)) & 1 for r in range(rows)], dtype=torch.bool)
+    assert torch.equal(marked, touched)
+    # planes: identical where a row was ever written; an untouched row keeps whatever the caller put there (zeros here), the dense pass
+    # wrote split(p) — the engine's planes are initialised from the parameters, so there the two agree everywhere
+    assert torch.equal(out[0][4][:, touched], out[1][4][:, touched]) and torch.equal(out[0][5][:, touched], out[1][5][:, touched])
+    if weight_decay > 1e-4:
+        assert torch.equal(out[0][4], out[1][4]) and not torch.equal(out[1][0][0, 2000], p0[0, 2000])      # every row decayed
+
+
 # ----------------------------------------------------------------------------- train-mode BatchNorm
 @pytest.mark.parametrize("rows,C,pool", [(154 * 256 * 32 // 16, 64, 0), (8192 * 3 + 64, 128, 64), (1600 * 4, 512, 64)])
 def test_bn_stats_and_apply(dev, rows, C, pool):
