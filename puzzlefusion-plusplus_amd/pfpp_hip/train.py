@@ -386,6 +386,10 @@ class DenoiserTrainEngine:
         # moments and — with fl32(1 - lr * weight_decay) = 1, the reference's hyper-parameters — an AdamW update that is exactly the
         # identity, so the iteration's closing update skips them (two thirds of the tables: 12.7 M of 57.6 M parameters).
         # PFPP_TRAIN_TABLES_ACTIVE=0: every row every step (cross-check).  None = not tracked (every row is taken)
+        self._join_pending = False                   # the last backward left the join with the weight-gradient stream to optimizer_step()
+        self._tail_overlap = os.environ.get("PFPP_TRAIN_TAIL_OVERLAP", "1") != "0"
+        self._heads_dw_ev: Optional[torch.cuda.Event] = None
+        self._heads_ev_fresh = False                 # ... recorded by the backward that is running
         self._tab_active: Optional[torch.Tensor] = None
         if os.environ.get("PFPP_TRAIN_TABLES_ACTIVE", "1") != "0":
             self._tab_active = torch.zeros(128, dtype=torch.int32, device=self.flat.params.device)
@@ -424,6 +428,7 @@ class DenoiserTrainEngine:
                 train: bool = True) -> Tuple[torch.Tensor, TrainContext]:
         """-> (pred_noise [B,P,7] with zeros at padded slots, context).  `train=False` disables the dropouts
         (the reference module in .eval())."""
+        self._join_side()                 # (a backward whose optimizer_step() was skipped)
         B, P, L, _ = latent.shape
         # the one-launch token embedding (forward and backward) exists for >= 11 latent points of width 64 in the split-f16 mode
         # (pfpp_embed_tokens_small returns PFPP_EUNSUPPORTED otherwise): decided per call, like denoiser.py does for the eval path;
@@ -902,6 +907,8 @@ class DenoiserTrainEngine:
             t_end = time.perf_counter() + _DIAG_HOST_DELAY_US * 1e-6
             while time.perf_counter() < t_end:
                 pass
+        self._join_side()
+        self._heads_ev_fresh = False
         self._exchange.enabled = self._sync
         self._exchanged = self._exchange.active() and self._sync
         if self._exchange.active() and not self._sync:
@@ -1028,6 +1035,10 @@ class DenoiserTrainEngine:
             self._run_on(self._side, lambda: T.grad_weight_group(problems, g_scale=G))
             for t_ in (da0, da1, v0, pooled):
                 t_.record_stream(self._side)
+            if self._heads_dw_ev is None:
+                self._heads_dw_ev = torch.cuda.Event()
+            self._heads_dw_ev.record(self._side)          # (the closing AdamW waits for this instead of for the whole stream: _all_done)
+            self._heads_ev_fresh = True
         return dh_
 
     def _heads_backward_layerwise(self, s, w, g, dout_c, G, Fv, L, C, carve, dpads, dw4s):
@@ -1324,7 +1335,23 @@ class DenoiserTrainEngine:
             st = self._comm = torch.cuda.Stream(device=self.flat.params.device)
         return st
 
+    def _join_side(self) -> None:
+        """the caller's stream waits for the weight-gradient stream if the last backward left that to the optimizer step"""
+        if self._join_pending:
+            self._join_pending = False
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _all_done(self) -> None:
+        # armed single-rank step through the C sequencer: what is still running on the weight-gradient stream when the chain ends is the
+        # first block's weight gradients and update (~0.1 ms), and nothing the closing AdamW of optimizer_step() touches — tables,
+        # AdaLN linears, embeddings, heads — comes from there (the heads' wide weight gradients were queued first on that stream:
+        # an event).  The join therefore moves behind those launches (optimizer_step), which then run under the stream's tail instead
+        # of behind it; forward() joins too, should a caller skip the step.  PFPP_TRAIN_TAIL_OVERLAP=0: join here, as before
+        if (self._side is not None and self._early and self._tail_overlap and self._heads_ev_fresh and getattr(self, "_comm", None) is None
+                and not self._exchange.active()):
+            self._join_pending = True
+            self._exchange.all_done(dense=self._accumulated)
+            return
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         if getattr(self, "_comm", None) is not None:
@@ -1399,6 +1426,8 @@ class DenoiserTrainEngine:
                              beta1=hp["betas"][0], beta2=hp["betas"][1], eps=hp["eps"], weight_decay=hp["weight_decay"],
                              step=self.step_count, hi=f.hi[:n_tab], lo=f.lo[:n_tab], g_scale=g_scale, zero_grad=zero_grad,
                              overflow=self._overflow)
+            if self._join_pending and self._heads_dw_ev is not None:
+                torch.cuda.current_stream().wait_event(self._heads_dw_ev)
             pos, total = 0, f.params.numel()
             for a, b in sorted(early) + [(total, total)]:
                 if a > pos:
@@ -1411,6 +1440,7 @@ class DenoiserTrainEngine:
             pos = self._adamw_tables_active(0, f.params.numel(), True, g_scale, zero_grad, hp)
             self._adamw_range(pos, f.params.numel(), step=self.step_count, g_scale=g_scale, zero_grad=zero_grad, **hp)
             f._clean = bool(zero_grad)
+        self._join_side()                 # (deferred by _all_done: the launches above ran under the weight-gradient stream's tail)
         self._after_step_overflow()
         f.after_optimizer_step()
         cache = getattr(self.module, "_cache", None)

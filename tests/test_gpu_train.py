@@ -223,6 +223,40 @@ def test_timestep_table_rows_without_a_gradient_are_left_alone(golden, weights_s
     torch.cuda.empty_cache()
 
 
+def test_closing_adamw_runs_under_the_weight_gradient_streams_tail(golden, weights_sd, dev, monkeypatch):
+    """round 6: in an armed single-rank step the join with the weight-gradient stream moves from the end of the backward behind the
+    closing AdamW launches of optimizer_step() (tables, AdaLN linears, embeddings, heads: none of their gradients comes from that
+    stream's tail; the heads' wide weight gradients are ordered by an event).  Three armed steps with the deferred join against three
+    with the join at the end of the backward (PFPP_TRAIN_TAIL_OVERLAP=0): first and second moments of EVERY parameter agree to the
+    run-to-run noise of the gradient atomics (a launch that read a gradient before it was final would be off by the gradient itself),
+    the engine is joined again after optimizer_step(), and the overflow flag of the step reaches the host."""
+    from pfpp_hip.train import DenoiserTrainEngine
+
+    inp_c, noise_c, _ = golden_inputs(golden)
+    res = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("PFPP_TRAIN_TAIL_OVERLAP", overlap)
+        eng = DenoiserTrainEngine(make_module(weights_sd, dev))
+        inp = [v.to(dev) for v in inp_c]
+        for step in range(3):
+            eng.flat.zero_grad()
+            eng.arm_optimizer(lr=2e-4, zero_grad=True)
+            eng.loss_and_grads(*inp, noise_c.to(dev), train=False)
+            assert eng._join_pending == (overlap == "1")
+            eng.optimizer_step(lr=2e-4, zero_grad=True)
+            assert not eng._join_pending
+        torch.cuda.synchronize()
+        assert eng.overflow_steps == 0
+        f = eng.flat
+        res.append((f.exp_avg.clone(), f.exp_avg_sq.clone(), dict(f.offset), f.order, {n: f.named[n].numel() for n in f.order}))
+    (m1, v1, off, order, numel), (m0, v0, _, _, _) = res
+    for n in order:
+        a, b = off[n], off[n] + numel[n]
+        sm, sv = float(m0[a:b].abs().max()), float(v0[a:b].abs().max())
+        assert float((m1[a:b] - m0[a:b]).abs().max()) <= 2e-5 * sm + 1e-12, n
+        assert float((v1[a:b] - v0[a:b]).abs().max()) <= 4e-5 * sv + 1e-20, n
+
+
 def test_module_train_mode_autograd_and_optimizer(golden, weights_sd, dev):
     """the drop-in surface: module.train(); loss.backward(); FusedAdamW.step() == the engine driven directly"""
     import torch.nn.functional as F
