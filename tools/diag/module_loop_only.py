@@ -23,3 +23,10 @@ def loop(n):
 loop(6); torch.cuda.synchronize()
 t0 = time.perf_counter(); loop(20); torch.cuda.synchronize()
 print(f"module loop {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/iteration")
+if len(sys.argv) > 1 and sys.argv[1] == "profile":       # host time of the loop's own thread (the encoder is issued from a second one)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    t0 = time.perf_counter(); loop(20); t1 = time.perf_counter()
+    pr.disable(); torch.cuda.synchronize()
+    print(f"enqueue {(t1 - t0) / 20 * 1e3:.3f} ms/iteration")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
